@@ -1,0 +1,488 @@
+"""torch-CPU fp32 restatement of the reference's detection hot path.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py): the checker for the HIP path, never the
+thing measured or shipped.  Every function cites the reference file:line it follows.
+It is functional (no nn.Module): the network is a list of plain layer records produced by
+``parse_cfg`` and a ``state_dict`` using the reference's key names
+(``model.{i}.conv.weight``, ``model.{i}.bn.*``, ``model.{i}[.{j}].cv1.conv.weight``,
+``model.{L}.m.{k}.weight|bias``, ``model.{L}.anchors``).
+
+Pinned against the unmodified reference by tests/golden/make_golden.py (run where
+/root/reference exists) -> tests/golden/*.pt, re-checked by tests/test_oracle_golden.py.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Any
+
+import torch
+import torch.nn.functional as F
+
+from . import upstream
+
+BN_EPS = 1e-3  # reference models/yolo.py:229 via upstream initialize_weights
+BN_MOMENTUM = 0.03
+
+
+# =========================================================================== topology
+@dataclass
+class Layer:
+    i: int
+    f: Any  # int or list[int], reference "from"
+    kind: str  # Conv | Bottleneck | SPP | Concat | Upsample | MaxPool | ZeroPad | Detect
+    n: int = 1  # repeats (Bottleneck xN is a Sequential in the reference)
+    c1: int = 0
+    c2: int = 0
+    args: list = field(default_factory=list)
+
+
+def parse_cfg(d: dict, ch: int = 3, nc: int | None = None, anchors=None):
+    """Topology from a model dict; follows reference models/yolo.py:298-380 (parse_model) for the
+    module kinds the yolov3*.yaml files use.  Returns (layers, save, anchors, nc)."""
+    d = dict(d)
+    if nc is not None:
+        d["nc"] = nc  # reference models/yolo.py:207-209
+    if anchors is not None:
+        d["anchors"] = anchors  # reference models/yolo.py:210-212
+    anchors_v, nc_v = d["anchors"], d["nc"]
+    gd, gw = d["depth_multiple"], d["width_multiple"]
+    na = len(anchors_v[0]) // 2 if isinstance(anchors_v, list) else anchors_v
+    no = na * (nc_v + 5)
+    layers, save, chans, c2 = [], [], [ch], ch
+    for i, (f, n, m, args) in enumerate(d["backbone"] + d["head"]):
+        args = [nc_v if a == "nc" else anchors_v if a == "anchors" else (None if a == "None" else a) for a in args]
+        n = max(round(n * gd), 1) if n > 1 else n  # reference models/yolo.py:325
+        m = m.replace("nn.", "")
+        if m in ("Conv", "Bottleneck", "SPP"):
+            c1, c2 = chans[f], args[0]
+            if c2 != no:
+                c2 = upstream.make_divisible(c2 * gw, 8)  # reference models/yolo.py:347-348
+            lay = Layer(i, f, m, n, c1, c2, list(args[1:]))
+        elif m == "Concat":
+            c2 = sum(chans[x] for x in f)
+            lay = Layer(i, f, "Concat", 1, 0, c2, list(args))
+        elif m == "Detect":
+            lay = Layer(i, f, "Detect", 1, 0, 0, [args[0], args[1], [chans[x] for x in f]])
+        elif m == "Upsample":
+            c2 = chans[f]
+            lay = Layer(i, f, "Upsample", 1, c2, c2, list(args))
+        elif m == "MaxPool2d":
+            c2 = chans[f]
+            lay = Layer(i, f, "MaxPool", 1, c2, c2, list(args))
+        elif m == "ZeroPad2d":
+            c2 = chans[f]
+            lay = Layer(i, f, "ZeroPad", 1, c2, c2, list(args))
+        else:
+            raise NotImplementedError(f"module {m} is not used by the yolov3 yamls")
+        save.extend(x % i for x in ([f] if isinstance(f, int) else f) if x != -1)  # reference models/yolo.py:375
+        layers.append(lay)
+        if i == 0:
+            chans = []
+        chans.append(c2)
+    return layers, sorted(save), anchors_v, nc_v
+
+
+def layer_hw(layers, h, w):
+    """Output (h, w) of every layer for an (h, w) input -- spatial bookkeeping only."""
+    sizes = []
+    cur = (h, w)
+    for lay in layers:
+        if lay.kind == "Detect":
+            sizes.append(None)
+            continue
+        if isinstance(lay.f, int):
+            src = cur if lay.f == -1 else sizes[lay.f]
+        else:
+            src = cur if lay.f[0] == -1 else sizes[lay.f[0]]
+        if lay.kind == "Conv":
+            k = lay.args[0] if lay.args else 1
+            st = lay.args[1] if len(lay.args) > 1 else 1
+            cur = tuple((v + 2 * (k // 2) - k) // st + 1 for v in src)
+        elif lay.kind == "Upsample":
+            cur = tuple(v * lay.args[1] for v in src)
+        elif lay.kind == "MaxPool":
+            k, st, p = (list(lay.args) + [None, 0])[:3]
+            st = k if st is None else st
+            cur = tuple((v + 2 * p - k) // st + 1 for v in src)
+        elif lay.kind == "ZeroPad":
+            l, r, t, b = lay.args[0]
+            cur = (src[0] + t + b, src[1] + l + r)
+        else:  # Bottleneck, SPP, Concat keep the spatial size
+            cur = src
+        sizes.append(cur)
+    return sizes
+
+
+def model_strides(layers, s=256):
+    """Strides of the Detect inputs.  reference models/yolo.py:219-222 dry-runs a 256x256 zero
+    image through the net; the same numbers fall out of the spatial bookkeeping."""
+    sizes = layer_hw(layers, s, s)
+    det = layers[-1]
+    return [s // sizes[x][0] for x in det.f]
+
+
+# =========================================================================== layers
+def _conv_block(sd, prefix, x, k, s, training, stats=None):
+    """Conv = act(bn(conv(x))): reference models/common.py:57-81.  Fused form (no ``bn`` keys,
+    conv has bias) follows forward_fuse :77-81.  pad = k//2 (autopad :48-54)."""
+    w = sd[prefix + ".conv.weight"]
+    b = sd.get(prefix + ".conv.bias")
+    y = F.conv2d(x, w, b, stride=s, padding=k // 2)
+    if prefix + ".bn.weight" in sd:
+        rm, rv = sd[prefix + ".bn.running_mean"], sd[prefix + ".bn.running_var"]
+        if training:
+            rm, rv = rm.clone(), rv.clone()
+            y = F.batch_norm(y, rm, rv, sd[prefix + ".bn.weight"], sd[prefix + ".bn.bias"], True, BN_MOMENTUM, BN_EPS)
+            if stats is not None:
+                stats[prefix + ".bn.running_mean"], stats[prefix + ".bn.running_var"] = rm, rv
+        else:
+            y = F.batch_norm(y, rm, rv, sd[prefix + ".bn.weight"], sd[prefix + ".bn.bias"], False, BN_MOMENTUM, BN_EPS)
+    return F.silu(y)
+
+
+def _bottleneck(sd, prefix, x, shortcut, c1, c2, training, stats):
+    """x + cv2(cv1(x)) when shortcut and c1==c2: reference models/common.py:150-165."""
+    y = _conv_block(sd, prefix + ".cv1", x, 1, 1, training, stats)
+    y = _conv_block(sd, prefix + ".cv2", y, 3, 1, training, stats)
+    return x + y if (shortcut and c1 == c2) else y
+
+
+def _spp(sd, prefix, x, ks, training, stats):
+    """cv2(cat([x, mp5, mp9, mp13])): reference models/common.py:267-290."""
+    x = _conv_block(sd, prefix + ".cv1", x, 1, 1, training, stats)
+    pools = [F.max_pool2d(x, k, 1, k // 2) for k in ks]
+    return _conv_block(sd, prefix + ".cv2", torch.cat([x] + pools, 1), 1, 1, training, stats)
+
+
+def detect_decode(raw, anchors_grid, strides):
+    """Eval branch of Detect.forward: reference models/yolo.py:100-110 with grids from :112-123.
+    ``raw``: list of (bs,na,ny,nx,no); ``anchors_grid``: (nl,na,2) in grid units; returns (bs,sum,no).
+    Arithmetic is done in raw's dtype exactly in the reference's op order."""
+    z = []
+    for i, x in enumerate(raw):
+        bs, na, ny, nx, no = x.shape
+        t = anchors_grid.dtype
+        yv, xv = torch.meshgrid(torch.arange(ny, dtype=t), torch.arange(nx, dtype=t), indexing="ij")
+        grid = torch.stack((xv, yv), 2).expand(1, na, ny, nx, 2) - 0.5
+        agrid = (anchors_grid[i] * strides[i]).view(1, na, 1, 1, 2).expand(1, na, ny, nx, 2)
+        s = x.sigmoid()
+        xy = (s[..., 0:2] * 2 + grid) * strides[i]
+        wh = (s[..., 2:4] * 2) ** 2 * agrid
+        z.append(torch.cat((xy, wh, s[..., 4:]), 4).view(bs, na * ny * nx, no))
+    return torch.cat(z, 1)
+
+
+def forward(layers, save, sd, x, strides=None, training=False, stats=None):
+    """Graph walk: reference models/yolo.py:135-147 (_forward_once).  Returns the Detect output:
+    training -> list of raw (bs,na,ny,nx,no); eval -> (pred(bs,N,no), raw list) (models/yolo.py:110)."""
+    ys = []
+    for lay in layers:
+        if lay.f != -1:
+            x = ys[lay.f] if isinstance(lay.f, int) else [x if j == -1 else ys[j] for j in lay.f]
+        p = f"model.{lay.i}"
+        if lay.kind == "Conv":
+            k = lay.args[0] if lay.args else 1
+            s = lay.args[1] if len(lay.args) > 1 else 1
+            x = _conv_block(sd, p, x, k, s, training, stats)
+        elif lay.kind == "Bottleneck":
+            shortcut = lay.args[0] if lay.args else True
+            c1 = lay.c1
+            for j in range(lay.n):
+                pj = f"{p}.{j}" if lay.n > 1 else p
+                x = _bottleneck(sd, pj, x, shortcut, c1, lay.c2, training, stats)
+                c1 = lay.c2
+        elif lay.kind == "SPP":
+            x = _spp(sd, p, x, lay.args[0] if lay.args else (5, 9, 13), training, stats)
+        elif lay.kind == "Concat":
+            x = torch.cat(x, 1)  # reference models/common.py:428
+        elif lay.kind == "Upsample":
+            x = F.interpolate(x, scale_factor=float(lay.args[1]), mode=lay.args[2])
+        elif lay.kind == "MaxPool":
+            k, s, pd = (list(lay.args) + [None, 0])[:3]
+            x = F.max_pool2d(x, k, k if s is None else s, pd)
+        elif lay.kind == "ZeroPad":
+            x = F.pad(x, lay.args[0])
+        elif lay.kind == "Detect":
+            nc, anchors, chs = lay.args
+            na = len(anchors[0]) // 2
+            no = nc + 5
+            raw = []
+            for k_, xi in enumerate(x):
+                yi = F.conv2d(xi, sd[f"{p}.m.{k_}.weight"], sd[f"{p}.m.{k_}.bias"])  # models/yolo.py:96
+                bs, _, ny, nx = yi.shape
+                raw.append(yi.view(bs, na, no, ny, nx).permute(0, 1, 3, 4, 2).contiguous())  # :98
+            if training:
+                return raw
+            return detect_decode(raw, sd[f"{p}.anchors"], strides), raw
+        ys.append(x if lay.i in save else None)
+    return x
+
+
+# =========================================================================== NMS
+def non_max_suppression(
+    prediction,
+    conf_thres=0.25,
+    iou_thres=0.45,
+    classes=None,
+    agnostic=False,
+    multi_label=False,
+    labels=(),
+    max_det=300,
+    nm=0,
+    stable_sort=True,
+):
+    """reference utils/general.py:630-750, per image:
+      :669 obj filter (strict >) -> :689-695 optional apriori label rows -> :702 cls*=obj (input dtype)
+      -> :705 xywh->xyxy (input dtype) -> :709-714 multi-label rows in nonzero order / best class
+      -> :717-718 class filter -> :728 descending score sort, cap 30000 -> :731-733 class-offset
+      boxes (fp32) into nms -> :734 max_det -> :743 gather.
+    The wall-clock guard (:675,746-748) is intentionally absent (SURVEY 8a' item 5).
+    ``stable_sort=True`` makes score ties deterministic (the reference argsort is unstable, so ties
+    are undefined there; see SURVEY 8a' item 3)."""
+    assert 0 <= conf_thres <= 1, f"Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0"
+    assert 0 <= iou_thres <= 1, f"Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0"
+    if isinstance(prediction, (list, tuple)):
+        prediction = prediction[0]
+    bs = prediction.shape[0]
+    nc = prediction.shape[2] - nm - 5
+    max_wh, max_nms = 7680, 30000
+    multi_label = multi_label and nc > 1
+    mi = 5 + nc
+    cand = prediction[..., 4] > conf_thres
+    out = [torch.zeros((0, 6 + nm))] * bs
+    for xi in range(bs):
+        x = prediction[xi][cand[xi]]
+        if labels and len(labels[xi]):
+            lb = labels[xi]
+            v = torch.zeros((len(lb), nc + nm + 5))
+            v[:, :4] = lb[:, 1:5]
+            v[:, 4] = 1.0
+            v[range(len(lb)), lb[:, 0].long() + 5] = 1.0
+            x = torch.cat((x, v), 0)
+        if not x.shape[0]:
+            continue
+        x = x.clone()
+        x[:, 5:] *= x[:, 4:5]
+        box = upstream.xywh2xyxy(x[:, :4])
+        mask = x[:, mi:]
+        if multi_label:
+            i, j = (x[:, 5:mi] > conf_thres).nonzero(as_tuple=False).T
+            x = torch.cat((box[i], x[i, 5 + j, None], j[:, None].float(), mask[i]), 1)
+        else:
+            conf, j = x[:, 5:mi].max(1, keepdim=True)
+            x = torch.cat((box, conf, j.float(), mask), 1)[conf.view(-1) > conf_thres]
+        if classes is not None:
+            x = x[(x[:, 5:6] == torch.tensor(classes)).any(1)]
+        if not x.shape[0]:
+            continue
+        x = x[x[:, 4].argsort(descending=True, stable=stable_sort)[:max_nms]]
+        c = x[:, 5:6] * (0 if agnostic else max_wh)
+        keep = upstream.nms(x[:, :4] + c, x[:, 4], iou_thres)[:max_det]
+        out[xi] = x[keep]
+    return out
+
+
+# =========================================================================== loss
+def build_targets(shapes, targets, anchors_grid, anchor_t=4.0):
+    """reference utils/loss.py:183-244.  ``shapes``: list of (bs,na,ny,nx,no) shapes;
+    ``targets``: (nt,6) [img, cls, x, y, w, h] normalised; ``anchors_grid``: (nl,na,2).
+    Returns per level (b, a, gj, gi, tbox(n,4), anch(n,2), tcls) with the reference's row order
+    (offset-major, then anchor-major, then target order; SURVEY 8a' item 12)."""
+    na, nt = anchors_grid.shape[1], targets.shape[0]
+    ai = torch.arange(na).float().view(na, 1).repeat(1, nt)
+    tt = torch.cat((targets.repeat(na, 1, 1), ai[..., None]), 2)  # (na,nt,7)
+    g = 0.5
+    off = torch.tensor([[0, 0], [1, 0], [0, 1], [-1, 0], [0, -1]]).float() * g
+    out = []
+    gain = torch.ones(7)
+    for i, shp in enumerate(shapes):
+        anchors = anchors_grid[i]
+        gain[2:6] = torch.tensor(shp)[[3, 2, 3, 2]].float()
+        t = tt * gain
+        if nt:
+            r = t[..., 4:6] / anchors[:, None]
+            j = torch.max(r, 1 / r).max(2)[0] < anchor_t
+            t = t[j]
+            gxy = t[:, 2:4]
+            gxi = gain[[2, 3]] - gxy
+            j, k = ((gxy % 1 < g) & (gxy > 1)).T
+            l, m = ((gxi % 1 < g) & (gxi > 1)).T
+            sel = torch.stack((torch.ones_like(j), j, k, l, m))
+            t = t.repeat((5, 1, 1))[sel]
+            offsets = (torch.zeros_like(gxy)[None] + off[:, None])[sel]
+        else:
+            t = tt[0]
+            offsets = 0
+        bc, gxy, gwh, a = t.chunk(4, 1)
+        a, (b, c) = a.long().view(-1), bc.long().T
+        gij = (gxy - offsets).long()
+        gi, gj = gij.T
+        gj = gj.clamp(0, shp[2] - 1)
+        gi = gi.clamp(0, shp[3] - 1)
+        out.append((b, a, gj, gi, torch.cat((gxy - gij, gwh), 1), anchors[a], c))
+    return out
+
+
+def compute_loss(p, targets, anchors_grid, hyp, nc):
+    """reference utils/loss.py:131-181 with criteria from :104-129 (BCEWithLogits with pos_weight,
+    label smoothing, balance [4,1,0.4] for 3 levels else first nl of [4,1,.25,.06,.02]; gr=1;
+    autobalance off).  FocalLoss (:31-63) applied when hyp['fl_gamma']>0.
+    Returns (loss(1,), items(3,), aux) where loss=(lbox+lobj+lcls)*bs (:181)."""
+    nl = len(p)
+    balance = {3: [4.0, 1.0, 0.4]}.get(nl, [4.0, 1.0, 0.25, 0.06, 0.02])
+    cp, cn = upstream.smooth_bce(eps=hyp.get("label_smoothing", 0.0))
+    cls_pw = torch.tensor([hyp["cls_pw"]])
+    obj_pw = torch.tensor([hyp["obj_pw"]])
+    gamma = hyp.get("fl_gamma", 0.0)
+
+    def bce(pred, true, pw):
+        if gamma > 0:  # FocalLoss around BCE(reduction='none'), alpha=0.25: utils/loss.py:31-63
+            loss = F.binary_cross_entropy_with_logits(pred, true, pos_weight=pw, reduction="none")
+            pp = torch.sigmoid(pred)
+            p_t = true * pp + (1 - true) * (1 - pp)
+            alpha_factor = true * 0.25 + (1 - true) * (1 - 0.25)
+            return (loss * alpha_factor * (1.0 - p_t) ** gamma).mean()
+        return F.binary_cross_entropy_with_logits(pred, true, pos_weight=pw)
+
+    lcls, lbox, lobj = torch.zeros(1), torch.zeros(1), torch.zeros(1)
+    tg = build_targets([pi.shape for pi in p], targets, anchors_grid, hyp["anchor_t"])
+    aux = []
+    for i, pi in enumerate(p):
+        b, a, gj, gi, tbox, anch, tcls = tg[i]
+        tobj = torch.zeros(pi.shape[:4], dtype=pi.dtype)
+        n = b.shape[0]
+        if n:
+            pxy, pwh, _, pcls = pi[b, a, gj, gi].split((2, 2, 1, nc), 1)
+            pxy = pxy.sigmoid() * 2 - 0.5
+            pwh = (pwh.sigmoid() * 2) ** 2 * anch
+            iou = upstream.bbox_iou(torch.cat((pxy, pwh), 1), tbox, CIoU=True).squeeze(-1)
+            lbox = lbox + (1.0 - iou).mean()
+            tobj[b, a, gj, gi] = iou.detach().clamp(0).type(tobj.dtype)
+            if nc > 1:
+                t = torch.full_like(pcls, cn)
+                t[range(n), tcls] = cp
+                lcls = lcls + bce(pcls, t, cls_pw)
+        lobj = lobj + bce(pi[..., 4], tobj, obj_pw) * balance[i]
+        aux.append(tobj)
+    lbox = lbox * hyp["box"]
+    lobj = lobj * hyp["obj"]
+    lcls = lcls * hyp["cls"]
+    bs = p[0].shape[0]
+    return (lbox + lobj + lcls) * bs, torch.cat((lbox, lobj, lcls)).detach(), aux
+
+
+# =========================================================================== synthetic inputs
+def seeded_state_dict(layers, nc, anchors, strides, seed=0, fused=False):
+    """Random-but-well-conditioned parameters with the reference's key names: conv Kaiming-uniform
+    (torch default), BN gamma~U(.5,1.5), beta~N(0,.1), running_mean~N(0,.1), running_var~U(.5,1.5);
+    Detect biases per reference models/yolo.py:282-292 (_initialize_biases)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def conv(prefix, c1, c2, k):
+        bound = 1.0 / math.sqrt(c1 * k * k)  # kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(fan_in), +)
+        sd[prefix + ".conv.weight"] = (torch.rand(c2, c1, k, k, generator=g) * 2 - 1) * bound
+        sd[prefix + ".bn.weight"] = torch.rand(c2, generator=g) + 0.5
+        sd[prefix + ".bn.bias"] = torch.randn(c2, generator=g) * 0.1
+        sd[prefix + ".bn.running_mean"] = torch.randn(c2, generator=g) * 0.1
+        sd[prefix + ".bn.running_var"] = torch.rand(c2, generator=g) + 0.5
+        sd[prefix + ".bn.num_batches_tracked"] = torch.tensor(0)
+
+    for lay in layers:
+        p = f"model.{lay.i}"
+        if lay.kind == "Conv":
+            conv(p, lay.c1, lay.c2, lay.args[0] if lay.args else 1)
+        elif lay.kind == "Bottleneck":
+            c1 = lay.c1
+            for j in range(lay.n):
+                pj = f"{p}.{j}" if lay.n > 1 else p
+                c_ = int(lay.c2 * 0.5)
+                conv(pj + ".cv1", c1, c_, 1)
+                conv(pj + ".cv2", c_, lay.c2, 3)
+                c1 = lay.c2
+        elif lay.kind == "SPP":
+            ks = lay.args[0] if lay.args else (5, 9, 13)
+            c_ = lay.c1 // 2
+            conv(p + ".cv1", lay.c1, c_, 1)
+            conv(p + ".cv2", c_ * (len(ks) + 1), lay.c2, 1)
+        elif lay.kind == "Detect":
+            ncls, anc, chs = lay.args
+            na = len(anc[0]) // 2
+            no = ncls + 5
+            a = torch.tensor(anc).float().view(len(anc), -1, 2)
+            sd[p + ".anchors"] = a / torch.tensor(strides).float().view(-1, 1, 1)  # models/yolo.py:224
+            for k_, c in enumerate(chs):
+                bound = 1.0 / math.sqrt(c)
+                sd[f"{p}.m.{k_}.weight"] = (torch.rand(na * no, c, 1, 1, generator=g) * 2 - 1) * bound
+                b = ((torch.rand(na * no, generator=g) * 2 - 1) * bound).view(na, -1)
+                b[:, 4] += math.log(8 / (640 / strides[k_]) ** 2)
+                b[:, 5 : 5 + ncls] += math.log(0.6 / (ncls - 0.99999))
+                sd[f"{p}.m.{k_}.bias"] = b.view(-1)
+    if fused:
+        sd = fuse_state_dict(sd)
+    return sd
+
+
+def fuse_state_dict(sd):
+    """Fold every BN into its conv (fp32), as reference models/yolo.py:163-172 + upstream
+    fuse_conv_and_bn do; keys become ``*.conv.weight`` / ``*.conv.bias``."""
+    out = {}
+    for k, v in sd.items():
+        if ".bn." in k:
+            continue
+        if k.endswith(".conv.weight") and k.replace(".conv.weight", ".bn.weight") in sd:
+            p = k[: -len(".conv.weight")]
+            scale = sd[p + ".bn.weight"] / torch.sqrt(BN_EPS + sd[p + ".bn.running_var"])
+            w = torch.mm(torch.diag(scale), v.view(v.shape[0], -1)).view(v.shape)
+            b = sd[p + ".bn.bias"] - sd[p + ".bn.weight"] * sd[p + ".bn.running_mean"] / torch.sqrt(
+                sd[p + ".bn.running_var"] + BN_EPS
+            )
+            out[p + ".conv.weight"], out[p + ".conv.bias"] = w, b
+        else:
+            out[k] = v
+    return out
+
+
+def synth_targets(bs, nc, seed=1):
+    """Targets (nt,6) [img, cls, x, y, w, h]: n_i~Poisson(7) clipped [0,30]; xy~U(.05,.95);
+    wh log-uniform(.02,.6)."""
+    g = torch.Generator().manual_seed(seed)
+    rows = []
+    for b in range(bs):
+        n = int(torch.poisson(torch.tensor(7.0), generator=g).clamp(0, 30))
+        if n == 0:
+            continue
+        cls = torch.randint(0, nc, (n, 1), generator=g).float()
+        xy = torch.rand(n, 2, generator=g) * 0.9 + 0.05
+        wh = torch.exp(torch.rand(n, 2, generator=g) * (math.log(0.6) - math.log(0.02)) + math.log(0.02))
+        rows.append(torch.cat((torch.full((n, 1), float(b)), cls, xy, wh), 1))
+    return torch.cat(rows, 0) if rows else torch.zeros(0, 6)
+
+
+def synth_predictions(bs, n_rows=25200, nc=80, img=640, seed=2, hits=0.03, n_gt=12, dtype=torch.float32):
+    """Decoded prediction tensor (bs, n_rows, 5+nc) for NMS tests/bench, decoupled from the
+    random-weight model: obj logit~N(-9,2.5) background, 3% 'hit' rows jittered
+    around n_gt ground-truth boxes with obj~N(1.5,1.5) and the GT class logit~N(2,1); other class
+    logits~N(-5,1.5).  Values are post-sigmoid, boxes in pixels (xywh)."""
+    g = torch.Generator().manual_seed(seed)
+    out = torch.empty(bs, n_rows, 5 + nc)
+    for b in range(bs):
+        gt_xy = torch.rand(n_gt, 2, generator=g) * (img * 0.8) + img * 0.1
+        gt_wh = torch.exp(torch.rand(n_gt, 2, generator=g) * (math.log(0.5) - math.log(0.04)) + math.log(0.04)) * img
+        gt_c = torch.randint(0, nc, (n_gt,), generator=g)
+        xy = torch.rand(n_rows, 2, generator=g) * img
+        wh = torch.exp(torch.rand(n_rows, 2, generator=g) * (math.log(0.6) - math.log(0.02)) + math.log(0.02)) * img
+        obj = torch.randn(n_rows, generator=g) * 2.5 - 9.0
+        cls = torch.randn(n_rows, nc, generator=g) * 1.5 - 5.0
+        is_hit = torch.rand(n_rows, generator=g) < hits
+        idx = is_hit.nonzero().view(-1)
+        k = torch.randint(0, n_gt, (idx.numel(),), generator=g)
+        xy[idx] = gt_xy[k] + torch.randn(idx.numel(), 2, generator=g) * 0.08 * gt_wh[k]
+        wh[idx] = gt_wh[k] * torch.exp(torch.randn(idx.numel(), 2, generator=g) * 0.15)
+        obj[idx] = torch.randn(idx.numel(), generator=g) * 1.5 + 1.5
+        cls[idx, gt_c[k]] = torch.randn(idx.numel(), generator=g) + 2.0
+        out[b, :, 0:2], out[b, :, 2:4] = xy, wh
+        out[b, :, 4] = obj.sigmoid()
+        out[b, :, 5:] = cls.sigmoid()
+    return out.to(dtype)
