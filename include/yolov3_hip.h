@@ -1,0 +1,126 @@
+/* yolov3_hip.h -- C ABI of libyolov3_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (ultralytics/yolov3) is 100 % Python and has no FFI of its own:
+ * every op on its detection hot path is an ATen call.  This header is the boundary a maintainer
+ * binds instead of those ATen calls; each entry point names the reference call site it replaces.
+ * The Python host side (yolov3_amd/) mirrors the reference's own signatures
+ * (DetectionModel/Detect.forward, non_max_suppression, ComputeLoss) on top of these symbols.
+ *
+ * Conventions
+ *  - plain pointers + sizes only; every pointer is DEVICE memory owned by the caller (the host side
+ *    allocates through torch's caching allocator so it is stream-ordered); no hidden hipMalloc,
+ *    no host synchronisation inside any call; `stream` is a hipStream_t passed as void*.
+ *  - activations are NHWC ("pixel-major"): element (n,h,w,c) at data[((n*H+h)*W+w)*pitch + c];
+ *    `pitch` >= c lets a tensor be a channel slice of a wider buffer (zero-copy Concat).
+ *  - return 0 on success, negative on error; y3_last_error() gives the thread-local message.
+ */
+#ifndef YOLOV3_HIP_H
+#define YOLOV3_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define Y3_ABI_VERSION 1
+
+typedef enum { Y3_F16 = 0, Y3_BF16 = 1, Y3_F32 = 2, Y3_U8 = 3 } y3_dtype;
+typedef enum { Y3_ACT_NONE = 0, Y3_ACT_SILU = 1 } y3_act;
+typedef enum { Y3_ALGO_AUTO = 0, Y3_ALGO_MFMA = 1, Y3_ALGO_DIRECT = 2 } y3_algo;
+
+/* NHWC view. `data` already points at channel 0 of the slice. */
+typedef struct {
+    void* data;
+    int32_t n, h, w, c;
+    int32_t pitch; /* elements between consecutive pixels (>= c) */
+} y3_tensor;
+
+/* Fused Conv2d(k in {1,3}, stride in {1,2}, pad=k/2, groups=1) + bias + activation (+ residual).
+ * Replaces reference models/common.py:75 / :81 (Conv.forward / forward_fuse: conv -> bn -> SiLU),
+ * the residual add of models/common.py:165 (Bottleneck.forward), the nn.Upsample(x2, nearest) of
+ * models/yolov3.yaml:43,51 (upsample2x != 0: every output pixel is written to its 2x2 block of the
+ * (2*Ho, 2*Wo) destination) and torch.cat of models/common.py:428 (write into a channel slice). */
+typedef struct {
+    int32_t dtype;      /* y3_dtype of x / w / residual / y (F16, BF16, F32) */
+    int32_t ksize;      /* 1 or 3 */
+    int32_t stride;     /* 1 or 2 */
+    int32_t act;        /* y3_act */
+    int32_t upsample2x; /* 0 / 1 */
+    int32_t algo;       /* y3_algo; AUTO = MFMA for F16/BF16, DIRECT for F32 */
+    int32_t cin;        /* logical input channels of the packed filter (x->c must equal it) */
+    int32_t cout;       /* output channels stored (multiple of 8; pad filters with zero rows) */
+} y3_conv_desc;
+
+int y3_abi_version(void);
+const char* y3_last_error(void);
+
+/* number of elements (of `dtype`) of a packed filter bank for (cout, cin, ksize) */
+size_t y3_packed_filter_elems(int32_t cout, int32_t cin, int32_t ksize);
+/* OIHW fp32 (cout_src x cin_src x k x k) -> packed [cout_pad][k*k*cin_pad (+K pad)] in `dtype`;
+ * `cout`/`cin` are the padded logical sizes used by y3_conv2d_fwd (>= the source sizes; pad = 0).
+ * Replaces the layout the reference gets from nn.Conv2d.weight (models/common.py:68). */
+int y3_pack_filter(const float* w_oihw, int32_t cout_src, int32_t cin_src, int32_t ksize, int32_t cout, int32_t cin,
+                   int32_t dtype, void* packed, void* stream);
+
+int y3_conv2d_fwd(const y3_conv_desc* desc, const y3_tensor* x, const void* packed_filter, const float* bias,
+                  const y3_tensor* residual /* may be NULL */, const y3_tensor* y, void* stream);
+
+/* NCHW (u8 / f16 / bf16 / f32) image batch -> NHWC `out_dtype`: cast, then true-divide by `divisor`
+ * (1.0 = none) in the output dtype, channels zero-padded to out->c.
+ * Replaces `im.half()/float(); im /= 255` of reference val.py:354-360 / train.py:380 when src is u8. */
+int y3_nchw_to_nhwc(const void* src, int32_t src_dtype, int32_t n, int32_t c, int32_t h, int32_t w, float divisor,
+                    int32_t out_dtype, const y3_tensor* out, void* stream);
+/* NHWC -> contiguous NCHW of the same dtype (debug / feature export). */
+int y3_nhwc_to_nchw(const y3_tensor* src, int32_t dtype, void* dst, void* stream);
+
+/* MaxPool2d(k, stride, pad) with -inf padding; optional zero padding on the right/bottom edge first
+ * (zpad_r, zpad_b) = nn.ZeroPad2d([0,zpad_r,0,zpad_b]).  Replaces reference models/yolov3-tiny.yaml:21-32
+ * (nn.MaxPool2d / nn.ZeroPad2d) and one branch of SPP (models/common.py:287-290). */
+int y3_maxpool2d(const y3_tensor* x, const y3_tensor* y, int32_t dtype, int32_t k, int32_t stride, int32_t pad,
+                 int32_t zpad_r, int32_t zpad_b, void* stream);
+/* SPP pyramid: y[..., c:2c]=mp5(x), [2c:3c]=mp9(x), [3c:4c]=mp13(x) in ONE pass; x may alias y[..., 0:c].
+ * Replaces reference models/common.py:287-290 (3x max_pool2d + cat). */
+int y3_spp_pyramid(const y3_tensor* x, const y3_tensor* y3c /* slice starting at channel c, 3c wide */, int32_t dtype,
+                   void* stream);
+/* nearest x2 upsample / channel-slice copy (fallbacks when not fused into a conv epilogue):
+ * reference models/yolov3.yaml:43 (nn.Upsample) and models/common.py:428 (torch.cat). */
+int y3_upsample2x(const y3_tensor* x, const y3_tensor* y, int32_t dtype, void* stream);
+int y3_copy_slice(const y3_tensor* x, const y3_tensor* y, int32_t dtype, void* stream);
+
+/* Detect head post-conv: reference models/yolo.py:98 (view/permute -> raw (bs,na,ny,nx,no)) and
+ * :104-108 (sigmoid, xy=(s*2+grid)*stride, wh=(s*2)^2*anchor_grid, cat, view) for ONE level.
+ * head: NHWC (bs,ny,nx, >= na*no) conv output; raw (may be NULL): contiguous (bs,na,ny,nx,no);
+ * z (may be NULL): rows [row_offset, row_offset+na*ny*nx) of a contiguous (bs,total_rows,no) tensor.
+ * anchors_px: na*2 floats on the HOST (anchor w,h in pixels = Detect.anchors[i]*stride[i]).
+ * Arithmetic rounds after every op in `dtype`, as torch does for half tensors. */
+int y3_detect_decode(const y3_tensor* head, int32_t dtype, int32_t na, int32_t no, const float* anchors_px,
+                     float stride, void* raw, void* z, int64_t row_offset, int64_t total_rows, void* stream);
+
+/* Batched non_max_suppression: reference utils/general.py:630-750 incl. torchvision.ops.nms (:733).
+ * pred: contiguous (bs, n_rows, 5+nc) of `dtype`.  Output: out_rows (bs, max_det, 6) fp32
+ * [x1,y1,x2,y2,conf,cls] in descending-score order (score ties keep the reference's nonzero order, i.e.
+ * torch.sort(stable=True)), out_counts (bs) int32.  classes: optional device int32 list.
+ * Work space from y3_nms_workspace_bytes().  No host sync: counts stay on device. */
+typedef struct {
+    double iou_thres;           /* compared in double, as torchvision's CPU kernel does */
+    float conf_thres;           /* rounded to `dtype` before the compares, as torch does for a python scalar */
+    int32_t multi_label, agnostic;
+    int32_t max_det, max_nms;   /* reference: 300 / 30000 */
+    float max_wh;               /* reference: 7680 */
+    int32_t n_classes_filter;   /* 0 = no class filter */
+} y3_nms_params;
+/* capacity = candidate slots for the whole batch; <= 0 picks the default (bs*16384, clamped to the
+ * worst case).  y3_nms uses the largest capacity that fits the workspace it is given. */
+size_t y3_nms_workspace_bytes(int32_t bs, int32_t n_rows, int32_t nc, const y3_nms_params* p, int64_t capacity);
+/* out_status (device, 2 x int32): [0] = 1 if the candidate capacity overflowed (results invalid: call
+ * again with a workspace sized for capacity >= out_status[1]); [1] = total candidates found. */
+int y3_nms(const void* pred, int32_t dtype, int32_t bs, int32_t n_rows, int32_t nc, const y3_nms_params* p,
+           const int32_t* classes, float* out_rows, int32_t* out_counts, int32_t* out_status, void* workspace,
+           size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLOV3_HIP_H */

@@ -1,0 +1,108 @@
+"""ctypes binding of libyolov3_hip.so (include/yolov3_hip.h).  There is NO fallback: if the library is
+missing or a symbol is absent this module raises -- the product path never routes around the HIP code."""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "lib" / "libyolov3_hip.so"
+
+Y3_F16, Y3_BF16, Y3_F32, Y3_U8 = 0, 1, 2, 3
+Y3_ACT_NONE, Y3_ACT_SILU = 0, 1
+Y3_ALGO_AUTO, Y3_ALGO_MFMA, Y3_ALGO_DIRECT = 0, 1, 2
+
+
+class Y3Tensor(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32), ("pitch", C.c_int32)]
+
+
+class Y3ConvDesc(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32),
+        ("ksize", C.c_int32),
+        ("stride", C.c_int32),
+        ("act", C.c_int32),
+        ("upsample2x", C.c_int32),
+        ("algo", C.c_int32),
+        ("cin", C.c_int32),
+        ("cout", C.c_int32),
+    ]
+
+
+class Y3NmsParams(C.Structure):
+    _fields_ = [
+        ("iou_thres", C.c_double),
+        ("conf_thres", C.c_float),
+        ("multi_label", C.c_int32),
+        ("agnostic", C.c_int32),
+        ("max_det", C.c_int32),
+        ("max_nms", C.c_int32),
+        ("max_wh", C.c_float),
+        ("n_classes_filter", C.c_int32),
+    ]
+
+
+_P = C.POINTER
+# symbol -> (restype, argtypes).  Every symbol include/yolov3_hip.h declares is listed here and is REQUIRED.
+_SIGNATURES = {
+    "y3_abi_version": (C.c_int, []),
+    "y3_last_error": (C.c_char_p, []),
+    "y3_packed_filter_elems": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "y3_pack_filter": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "y3_conv2d_fwd": (C.c_int, [_P(Y3ConvDesc), _P(Y3Tensor), C.c_void_p, C.c_void_p, _P(Y3Tensor), _P(Y3Tensor), C.c_void_p]),
+    "y3_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P(Y3Tensor), C.c_void_p]),
+    "y3_nhwc_to_nchw": (C.c_int, [_P(Y3Tensor), C.c_int32, C.c_void_p, C.c_void_p]),
+    "y3_maxpool2d": (C.c_int, [_P(Y3Tensor), _P(Y3Tensor), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "y3_spp_pyramid": (C.c_int, [_P(Y3Tensor), _P(Y3Tensor), C.c_int32, C.c_void_p]),
+    "y3_upsample2x": (C.c_int, [_P(Y3Tensor), _P(Y3Tensor), C.c_int32, C.c_void_p]),
+    "y3_copy_slice": (C.c_int, [_P(Y3Tensor), _P(Y3Tensor), C.c_int32, C.c_void_p]),
+    "y3_detect_decode": (C.c_int, [_P(Y3Tensor), C.c_int32, C.c_int32, C.c_int32, _P(C.c_float), C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "y3_nms_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, _P(Y3NmsParams), C.c_int64]),
+    "y3_nms": (
+        C.c_int,
+        [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P(Y3NmsParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p],
+    ),
+}
+
+_lib = None
+
+
+class Y3Error(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    return list(_SIGNATURES)
+
+
+def lib() -> C.CDLL:
+    """Load libyolov3_hip.so (once).  Import torch first so the HIP runtime torch ships is the one the library
+    binds to (same SONAME libamdhip64.so.7): streams and device pointers then belong to one runtime."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (must precede the dlopen, see docstring)
+
+    if not LIB_PATH.exists():
+        raise Y3Error(
+            f"{LIB_PATH} is missing: the MI355X HIP library has not been built. Run `python -m yolov3_amd.build` "
+            "(needs hipcc, gfx950). There is no CPU or PyTorch fallback for this path."
+        )
+    handle = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as e:
+            raise Y3Error(f"{LIB_PATH} does not export {name}; rebuild with `python -m yolov3_amd.build --force`") from e
+        fn.restype, fn.argtypes = res, args
+    if handle.y3_abi_version() != 1:
+        raise Y3Error(f"ABI version mismatch: library reports {handle.y3_abi_version()}, bindings expect 1")
+    _lib = handle
+    return handle
+
+
+def check(status: int, what: str = ""):
+    if status != 0:
+        msg = lib().y3_last_error().decode(errors="replace")
+        raise Y3Error(f"{what}: {msg}" if what else msg)

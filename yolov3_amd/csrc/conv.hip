@@ -1,0 +1,455 @@
+// Fused Conv2d + bias + SiLU (+ residual, + nearest-x2 scatter, + channel-slice write) for gfx950.
+//
+// Replaces reference models/common.py:75/:81 (Conv.forward / forward_fuse), :165 (Bottleneck add),
+// models/yolov3.yaml:43,51 (nn.Upsample) and models/common.py:428 (torch.cat) -- see include/yolov3_hip.h.
+//
+// Formulation: implicit GEMM, D[cout][pixel] = sum_k W[cout][k] * X[pixel][k], k = (kh, kw, cin).
+//   * activations NHWC, filters packed [cout][kh][kw][cin]: BOTH operands are K-contiguous, so a lane's
+//     16-byte load is exactly the 8-element k-group an MFMA fragment wants.
+//   * v_mfma_f32_32x32x16_{f16,bf16}: A operand = filters (rows = cout), B operand = pixels (cols),
+//     so each lane ends up holding 4 consecutive couts of ONE pixel per register quad -> NHWC friendly.
+//   * 256 threads = 4 waves; tile TC couts x TP pixels x BK; register-staged global->LDS with XOR-swizzled
+//     16-byte slots (conflict-free ds_read_b128 fragment reads), double-buffered LDS, one barrier / K-step.
+//   * epilogue: bias + SiLU in registers, fp32 tile through LDS, then fully coalesced 16-byte row stores
+//     with the residual added on the way out (single rounding).
+//   * grid: 1-D, XCD-aware (block b runs on XCD b%8): each XCD owns a contiguous range of pixel tiles and
+//     walks all cout tiles of a pixel tile back-to-back, so the X tile is L2-hot for its siblings.
+#include "y3_common.h"
+
+namespace {
+
+struct ConvArgs {
+    const void* x;
+    const void* w;
+    const float* bias;
+    const void* res;
+    void* y;
+    int N, H, W, Cin, xpitch;  // input
+    int Ho, Wo, Cout, ypitch;  // output (Ho, Wo are the conv output dims, before any upsample scatter)
+    int rpitch;
+    int ks, stride, pad;
+    int act, ups;
+    int M;          // N*Ho*Wo
+    int Kpad;       // packed filter row length (elements)
+    int nk;         // K iterations
+    int cin_blocks; // Cin / BK (uniform-tap path)
+    int n_pt, n_ct;
+};
+
+template <typename T> struct Mfma;
+template <> struct Mfma<f16_t> {
+    typedef f16x8 frag;
+    static Y3_DEV f32x16 run(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mfma<bf16_t> {
+    typedef bf16x8 frag;
+    static Y3_DEV f32x16 run(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+
+template <int BK> Y3_DEV int swz(int row) {
+    constexpr int S = BK / 8;   // 16-byte slots per row
+    constexpr int R = 16 / S;   // rows per 256-byte LDS line
+    return (row / R) % S;
+}
+
+// Bijective remap of the hardware block id so that consecutive logical tiles share an XCD.
+Y3_DEV int xcd_remap(int b, int nb) {
+    const int xcd = b & 7, i = b >> 3;
+    const int q = nb >> 3, r = nb & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + i;
+}
+
+template <typename T, int BK, int WAVES_C, int WAVES_P, int MC, int MP, bool SMALLC>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
+    constexpr int TC = WAVES_C * MC * 32;
+    constexpr int TP = WAVES_P * MP * 32;
+    constexpr int S = BK / 8;                 // 16-byte slots per tile row
+    constexpr int WJ = (TC * S + 255) / 256;  // filter chunks per thread per K-step
+    constexpr int XJ = (TP * S + 255) / 256;  // pixel chunks per thread per K-step
+    constexpr int STAGE_BYTES = (TC + TP) * BK * 2;
+    constexpr int EP = TC + 4;                // fp32 epilogue row pitch (floats)
+    constexpr int EPI_BYTES = TP * EP * 4;
+    constexpr int LDS_BYTES = 2 * STAGE_BYTES > EPI_BYTES ? 2 * STAGE_BYTES : EPI_BYTES;
+    static_assert(WAVES_C * WAVES_P == 4, "4 waves");
+    typedef typename Mfma<T>::frag frag;
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
+    const int wc = wv / WAVES_P, wp = wv % WAVES_P;
+
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int pt = L / p.n_ct, ct = L % p.n_ct;
+
+    const T* __restrict__ xg = (const T*)p.x;
+    const T* __restrict__ wg = (const T*)p.w;
+
+    // ---- per-thread gather bookkeeping (fixed 16-byte slot, XJ pixel rows / WJ filter rows) ----
+    const int slot = tid % S;
+    const int row0 = tid / S;                 // rows: row0 + j * (256 / S)
+    constexpr int ROWSTEP = 256 / S;
+
+    long long xbase[XJ];                      // element offset of (n, hi0, wi0, 0); may point outside -> guarded
+    int hi0[XJ], wi0[XJ];
+    bool mvalid[XJ];
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) {
+        const int row = row0 + j * ROWSTEP;
+        const int m = pt * TP + row;
+        const bool v = (row < TP) && (m < p.M);
+        const int mm = v ? m : 0;
+        const int n = mm / (p.Ho * p.Wo);
+        const int rem = mm - n * (p.Ho * p.Wo);
+        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        hi0[j] = ho * p.stride - p.pad;
+        wi0[j] = wo * p.stride - p.pad;
+        xbase[j] = ((long long)(n * p.H + hi0[j]) * p.W + wi0[j]) * p.xpitch;
+        mvalid[j] = v;
+    }
+    long long wbase[WJ];
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) {
+        const int row = row0 + j * ROWSTEP;
+        wbase[j] = (long long)(ct * TC + (row < TC ? row : 0)) * p.Kpad + slot * 8;
+    }
+
+    uint4 xr[XJ], wr[WJ];
+
+    auto load_tile = [&](int it) {
+        int kh, kw, c0;
+        bool tapok = true;
+        if (SMALLC) {
+            const int cg = p.Cin >> 3;                 // 8-channel groups per tap (1 or 2 or 3)
+            const int g = it * S + slot;
+            const int tap = g / cg;
+            c0 = (g - tap * cg) * 8;
+            kh = tap / p.ks;
+            kw = tap - kh * p.ks;
+            tapok = tap < p.ks * p.ks;
+        } else {
+            const int tap = it / p.cin_blocks;
+            const int cb = it - tap * p.cin_blocks;
+            kh = tap / p.ks;
+            kw = tap - kh * p.ks;
+            c0 = cb * BK + slot * 8;
+        }
+        const long long tapoff = (long long)(kh * p.W + kw) * p.xpitch + c0;
+#pragma unroll
+        for (int j = 0; j < XJ; ++j) {
+            const int hi = hi0[j] + kh, wi = wi0[j] + kw;
+            const bool ok = tapok && mvalid[j] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (ok) v = *(const uint4*)(xg + xbase[j] + tapoff);
+            xr[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+            const int row = row0 + j * ROWSTEP;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (row < TC) v = *(const uint4*)(wg + wbase[j] + (long long)it * BK);
+            wr[j] = v;
+        }
+    };
+    auto store_tile = [&](int stage) {
+        unsigned char* wl = smem + stage * STAGE_BYTES;
+        unsigned char* xl = wl + TC * BK * 2;
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+            const int row = row0 + j * ROWSTEP;
+            if (row < TC) *(uint4*)(wl + row * (BK * 2) + ((slot ^ swz<BK>(row)) << 4)) = wr[j];
+        }
+#pragma unroll
+        for (int j = 0; j < XJ; ++j) {
+            const int row = row0 + j * ROWSTEP;
+            if (row < TP) *(uint4*)(xl + row * (BK * 2) + ((slot ^ swz<BK>(row)) << 4)) = xr[j];
+        }
+    };
+
+    f32x16 acc[MC][MP];
+#pragma unroll
+    for (int a = 0; a < MC; ++a)
+#pragma unroll
+        for (int b = 0; b < MP; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    const int frow = lane & 31;       // fragment row within a 32-tile
+    const int fk = lane >> 5;         // which 8-wide k half of a 16-wide MFMA step
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int it = 0; it < p.nk; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < p.nk) load_tile(it + 1);
+
+        const unsigned char* wl = smem + cur * STAGE_BYTES;
+        const unsigned char* xl = wl + TC * BK * 2;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            frag af[MC], bf[MP];
+            const int ks = kk * 2 + fk;
+#pragma unroll
+            for (int a = 0; a < MC; ++a) {
+                const int row = (wc * MC + a) * 32 + frow;
+                af[a] = *(const frag*)(wl + row * (BK * 2) + ((ks ^ swz<BK>(row)) << 4));
+            }
+#pragma unroll
+            for (int b = 0; b < MP; ++b) {
+                const int row = (wp * MP + b) * 32 + frow;
+                bf[b] = *(const frag*)(xl + row * (BK * 2) + ((ks ^ swz<BK>(row)) << 4));
+            }
+#pragma unroll
+            for (int a = 0; a < MC; ++a)
+#pragma unroll
+                for (int b = 0; b < MP; ++b) acc[a][b] = Mfma<T>::run(af[a], bf[b], acc[a][b]);
+        }
+
+        if (it + 1 < p.nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias + activation in registers -> fp32 tile in LDS -> coalesced row stores ----
+    float* el = (float*)smem;
+#pragma unroll
+    for (int a = 0; a < MC; ++a) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int cl = (wc * MC + a) * 32 + 8 * g + 4 * fk;  // cout within tile (4 consecutive)
+            const int cgl = ct * TC + cl;
+            float b4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b4[q] = (cgl + q < p.Cout) ? p.bias[cgl + q] : 0.0f;
+#pragma unroll
+            for (int b = 0; b < MP; ++b) {
+                const int pl = (wp * MP + b) * 32 + frow;         // pixel within tile
+                f32x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float t = acc[a][b][4 * g + q] + b4[q];
+                    if (p.act == Y3_ACT_SILU) t = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));
+                    v[q] = t;
+                }
+                *(f32x4*)(el + pl * EP + cl) = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    constexpr int CR = TC / 8;              // 8-cout chunks per pixel row
+    constexpr int EJ = (TP * CR + 255) / 256;
+    T* __restrict__ yg = (T*)p.y;
+    const T* __restrict__ rg = (const T*)p.res;
+#pragma unroll
+    for (int j = 0; j < EJ; ++j) {
+        const int idx = tid + j * 256;
+        const int row = idx / CR, ch = idx - row * CR;
+        const int m = pt * TP + row;
+        const int c = ct * TC + ch * 8;
+        if (row < TP && m < p.M && c + 8 <= p.Cout) {
+            const f32x4 v0 = *(const f32x4*)(el + row * EP + ch * 8);
+            const f32x4 v1 = *(const f32x4*)(el + row * EP + ch * 8 + 4);
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            const int n = m / (p.Ho * p.Wo);
+            const int rem = m - n * (p.Ho * p.Wo);
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            if (rg) {
+                const uint4 rv = *(const uint4*)(rg + ((long long)(n * p.Ho + ho) * p.Wo + wo) * p.rpitch + c);
+                const T* rp = (const T*)&rv;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] += to_f32<T>(rp[q]);
+            }
+            uint4 ov;
+            T* op = (T*)&ov;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) op[q] = from_f32<T>(v[q]);
+            if (!p.ups) {
+                *(uint4*)(yg + ((long long)(n * p.Ho + ho) * p.Wo + wo) * p.ypitch + c) = ov;
+            } else {
+                const int H2 = p.Ho * 2, W2 = p.Wo * 2;
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx)
+                        *(uint4*)(yg + ((long long)(n * H2 + 2 * ho + dy) * W2 + 2 * wo + dx) * p.ypitch + c) = ov;
+            }
+        }
+    }
+}
+
+// ---- direct (one thread per output element) kernel: fp32 dtype path and debug cross-check -----------
+template <typename T>
+__global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs p) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)p.M * p.Cout;
+    if (idx >= total) return;
+    const int c = (int)(idx % p.Cout);
+    const int m = (int)(idx / p.Cout);
+    const int n = m / (p.Ho * p.Wo);
+    const int rem = m - n * (p.Ho * p.Wo);
+    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+    const T* xg = (const T*)p.x;
+    const T* wg = (const T*)p.w + (long long)c * p.Kpad;
+    float acc = 0.0f;
+    for (int kh = 0; kh < p.ks; ++kh) {
+        const int hi = ho * p.stride - p.pad + kh;
+        if ((unsigned)hi >= (unsigned)p.H) continue;
+        for (int kw = 0; kw < p.ks; ++kw) {
+            const int wi = wo * p.stride - p.pad + kw;
+            if ((unsigned)wi >= (unsigned)p.W) continue;
+            const T* xp = xg + ((long long)(n * p.H + hi) * p.W + wi) * p.xpitch;
+            const T* wp = wg + (kh * p.ks + kw) * p.Cin;
+            for (int ci = 0; ci < p.Cin; ++ci) acc = fmaf(to_f32<T>(xp[ci]), to_f32<T>(wp[ci]), acc);
+        }
+    }
+    float t = acc + p.bias[c];
+    if (p.act == Y3_ACT_SILU) t = t / (1.0f + expf(-t));
+    if (p.res) t += to_f32<T>(((const T*)p.res)[((long long)(n * p.Ho + ho) * p.Wo + wo) * p.rpitch + c]);
+    T* yg = (T*)p.y;
+    const T o = from_f32<T>(t);
+    if (!p.ups) {
+        yg[((long long)(n * p.Ho + ho) * p.Wo + wo) * p.ypitch + c] = o;
+    } else {
+        const int H2 = p.Ho * 2, W2 = p.Wo * 2;
+        for (int dy = 0; dy < 2; ++dy)
+            for (int dx = 0; dx < 2; ++dx) yg[((long long)(n * H2 + 2 * ho + dy) * W2 + 2 * wo + dx) * p.ypitch + c] = o;
+    }
+}
+
+// OIHW fp32 -> packed [rows][Kpad] T, K = (kh, kw, cin_pad)
+template <typename T>
+__global__ void pack_filter_kernel(const float* __restrict__ src, int cout_src, int cin_src, int ks, int cin, int rows,
+                                   int kpad, T* __restrict__ dst) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)rows * kpad;
+    if (idx >= total) return;
+    const int k = (int)(idx % kpad);
+    const int co = (int)(idx / kpad);
+    float v = 0.0f;
+    if (co < cout_src && k < ks * ks * cin) {
+        const int tap = k / cin, ci = k - tap * cin;
+        const int kh = tap / ks, kw = tap - kh * ks;
+        if (ci < cin_src) v = src[(((long long)co * cin_src + ci) * ks + kh) * ks + kw];
+    }
+    dst[idx] = from_f32<T>(v);
+}
+
+template <typename T, int BK, int WAVES_C, int WAVES_P, int MC, int MP, bool SMALLC>
+int launch_igemm(ConvArgs& a, hipStream_t st) {
+    constexpr int TC = WAVES_C * MC * 32, TP = WAVES_P * MP * 32;
+    a.n_ct = y3_ceil_div(a.Cout, TC);
+    a.n_pt = y3_ceil_div(a.M, TP);
+    if (SMALLC) {
+        a.nk = y3_ceil_div(a.ks * a.ks * a.Cin, BK);
+        a.cin_blocks = 1;
+    } else {
+        a.cin_blocks = a.Cin / BK;
+        a.nk = a.ks * a.ks * a.cin_blocks;
+    }
+    const long long nb = (long long)a.n_ct * a.n_pt;
+    if (nb > 0x7fffffffLL) Y3_FAIL("conv grid too large");
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BK, WAVES_C, WAVES_P, MC, MP, SMALLC>), dim3((unsigned)nb), dim3(256), 0, st, a);
+    Y3_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename T> int dispatch_igemm(ConvArgs& a, hipStream_t st) {
+    const bool c64 = (a.Cin % 64) == 0, c32 = (a.Cin % 32) == 0;
+    if (a.Cout > 64) {
+        if (c64) return launch_igemm<T, 64, 2, 2, 2, 2, false>(a, st);
+        if (c32) return launch_igemm<T, 32, 2, 2, 2, 2, false>(a, st);
+        return launch_igemm<T, 32, 2, 2, 2, 2, true>(a, st);
+    } else if (a.Cout > 32) {
+        if (c64) return launch_igemm<T, 64, 1, 4, 2, 2, false>(a, st);
+        if (c32) return launch_igemm<T, 32, 1, 4, 2, 2, false>(a, st);
+        return launch_igemm<T, 32, 1, 4, 2, 2, true>(a, st);
+    } else {
+        if (c64) return launch_igemm<T, 64, 1, 4, 1, 2, false>(a, st);
+        if (c32) return launch_igemm<T, 32, 1, 4, 1, 2, false>(a, st);
+        return launch_igemm<T, 32, 1, 4, 1, 2, true>(a, st);
+    }
+}
+
+template <typename T> int launch_direct(ConvArgs& a, hipStream_t st) {
+    const long long total = (long long)a.M * a.Cout;
+    hipLaunchKernelGGL((conv_direct_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+    Y3_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" size_t y3_packed_filter_elems(int32_t cout, int32_t cin, int32_t ksize) {
+    return (size_t)y3_filter_rows(cout) * (size_t)y3_filter_kpad(cin, ksize);
+}
+
+extern "C" int y3_pack_filter(const float* w, int32_t cout_src, int32_t cin_src, int32_t ks, int32_t cout, int32_t cin,
+                              int32_t dtype, void* packed, void* stream) {
+    if (!w || !packed) Y3_FAIL("y3_pack_filter: null pointer");
+    if (cout < cout_src || cin < cin_src || (cin % 8) != 0) Y3_FAIL("y3_pack_filter: bad padded sizes cout=%d cin=%d", cout, cin);
+    const int rows = y3_filter_rows(cout), kpad = y3_filter_kpad(cin, ks);
+    const long long total = (long long)rows * kpad;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case Y3_F16: hipLaunchKernelGGL((pack_filter_kernel<f16_t>), grid, dim3(256), 0, st, w, cout_src, cin_src, ks, cin, rows, kpad, (f16_t*)packed); break;
+        case Y3_BF16: hipLaunchKernelGGL((pack_filter_kernel<bf16_t>), grid, dim3(256), 0, st, w, cout_src, cin_src, ks, cin, rows, kpad, (bf16_t*)packed); break;
+        case Y3_F32: hipLaunchKernelGGL((pack_filter_kernel<float>), grid, dim3(256), 0, st, w, cout_src, cin_src, ks, cin, rows, kpad, (float*)packed); break;
+        default: Y3_FAIL("y3_pack_filter: bad dtype %d", dtype);
+    }
+    Y3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int y3_conv2d_fwd(const y3_conv_desc* d, const y3_tensor* x, const void* filt, const float* bias,
+                             const y3_tensor* res, const y3_tensor* y, void* stream) {
+    if (!d || !x || !filt || !bias || !y) Y3_FAIL("y3_conv2d_fwd: null argument");
+    if (d->ksize != 1 && d->ksize != 3) Y3_FAIL("y3_conv2d_fwd: ksize %d unsupported", d->ksize);
+    if (d->stride != 1 && d->stride != 2) Y3_FAIL("y3_conv2d_fwd: stride %d unsupported", d->stride);
+    if (x->c != d->cin) Y3_FAIL("y3_conv2d_fwd: x has %d channels, filter expects %d", x->c, d->cin);
+    if ((d->cin % 8) || (d->cout % 8)) Y3_FAIL("y3_conv2d_fwd: cin/cout must be multiples of 8 (%d/%d)", d->cin, d->cout);
+    const int pad = d->ksize / 2;
+    const int Ho = (x->h + 2 * pad - d->ksize) / d->stride + 1;
+    const int Wo = (x->w + 2 * pad - d->ksize) / d->stride + 1;
+    const int up = d->upsample2x ? 2 : 1;
+    if (y->n != x->n || y->h != Ho * up || y->w != Wo * up || y->c != d->cout)
+        Y3_FAIL("y3_conv2d_fwd: output is (%d,%d,%d,%d), expected (%d,%d,%d,%d)", y->n, y->h, y->w, y->c, x->n, Ho * up, Wo * up, d->cout);
+    if (res && (res->n != x->n || res->h != Ho || res->w != Wo || res->c != d->cout)) Y3_FAIL("y3_conv2d_fwd: residual shape mismatch");
+    if (res && d->upsample2x) Y3_FAIL("y3_conv2d_fwd: residual + upsample2x unsupported");
+    const int esz = d->dtype == Y3_F32 ? 4 : 2;
+    const int vec = 16 / esz;
+    if (d->dtype != Y3_F32) {
+        if ((x->pitch % vec) || (y->pitch % vec) || (res && (res->pitch % vec)) || ((uintptr_t)x->data & 15) || ((uintptr_t)y->data & 15) ||
+            (res && ((uintptr_t)res->data & 15)) || ((uintptr_t)filt & 15))
+            Y3_FAIL("y3_conv2d_fwd: tensors must be 16-byte aligned with pitch %% %d == 0", vec);
+    }
+    if ((long long)x->n * Ho * Wo > 0x7fffffffLL) Y3_FAIL("y3_conv2d_fwd: too many output pixels");
+
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x->data; a.w = filt; a.bias = bias; a.res = res ? res->data : nullptr; a.y = y->data;
+    a.N = x->n; a.H = x->h; a.W = x->w; a.Cin = d->cin; a.xpitch = x->pitch;
+    a.Ho = Ho; a.Wo = Wo; a.Cout = d->cout; a.ypitch = y->pitch; a.rpitch = res ? res->pitch : 0;
+    a.ks = d->ksize; a.stride = d->stride; a.pad = pad; a.act = d->act; a.ups = d->upsample2x ? 1 : 0;
+    a.M = x->n * Ho * Wo;
+    a.Kpad = y3_filter_kpad(d->cin, d->ksize);
+    hipStream_t st = (hipStream_t)stream;
+
+    int algo = d->algo;
+    if (algo == Y3_ALGO_AUTO) algo = (d->dtype == Y3_F32) ? Y3_ALGO_DIRECT : Y3_ALGO_MFMA;
+    if (algo == Y3_ALGO_MFMA) {
+        if (d->dtype == Y3_F16) return dispatch_igemm<f16_t>(a, st);
+        if (d->dtype == Y3_BF16) return dispatch_igemm<bf16_t>(a, st);
+        Y3_FAIL("y3_conv2d_fwd: MFMA path needs f16/bf16");
+    }
+    switch (d->dtype) {
+        case Y3_F16: return launch_direct<f16_t>(a, st);
+        case Y3_BF16: return launch_direct<bf16_t>(a, st);
+        case Y3_F32: return launch_direct<float>(a, st);
+    }
+    Y3_FAIL("y3_conv2d_fwd: bad dtype %d", d->dtype);
+}

@@ -1,0 +1,489 @@
+// Detect decode + batched non_max_suppression for gfx950.  Built with -ffp-contract=off: every float op here
+// must round exactly like the reference's CPU path (no fused multiply-adds).
+//
+// Decode   : reference models/yolo.py:98-110.  HBM-bound streaming kernel.
+// NMS      : reference utils/general.py:630-750 + torchvision.ops.nms.  Pipeline (no host sync anywhere):
+//   1 count    wave per 64 anchor rows: obj filter by ballot, per-row label count (multi-label / best class)
+//   2 scan     rocprim exclusive scan of the per-row counts -> ordered (nonzero-order) emission slots
+//   3 emit     candidates: xyxy box (input-dtype rounding), fp32 score, class; key1 = [img | ~score | ordinal]
+//   4 sort     rocprim radix sort by key1 -> per-image descending-score order (ties keep nonzero order)
+//   5 rank     cut at max_nms per image, class-offset boxes (+cls*max_wh, fp32), key2 = [img | class | rank]
+//   6 sort     by key2 -> per (image, class) segments in score order.  Boxes of different classes cannot overlap
+//              after the class offset when every |coord| < max_wh/2, so greedy NMS factorises per class; an
+//              image that violates the bound (or agnostic mode) falls back to ONE segment for the image.
+//   7 greedy   block per (image, class): visit in order; a kept box suppresses later ones with
+//              inter/(a_i+a_j-inter) > thr (strict, compared in double like torchvision's CPU kernel);
+//              IoU rows are evaluated lazily for kept boxes only; stop after max_det kept per segment.
+//   8 gather   block per image: kept flags back in score order, first max_det rows -> (bs, max_det, 6) fp32.
+#include "y3_common.h"
+
+#include <rocprim/rocprim.hpp>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ decode
+template <typename T>
+__global__ __launch_bounds__(256) void decode_kernel(const T* __restrict__ head, int bs, int ny, int nx, int pitch, int na, int no, float aw0, float ah0,
+                                                       float aw1, float ah1, float aw2, float ah2, float aw3, float ah3, float aw4, float ah4, float stride,
+                                                       T* __restrict__ raw, T* __restrict__ z, long long row_offset, long long total_rows) {
+    const int nch = na * no;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)bs * ny * nx * nch;
+    if (idx >= total) return;
+    const int ch = (int)(idx % nch);
+    long long t = idx / nch;
+    const int x = (int)(t % nx);
+    t /= nx;
+    const int y = (int)(t % ny);
+    const int b = (int)(t / ny);
+    const int a = ch / no, o = ch - a * no;
+    const T hv = head[((long long)(b * ny + y) * nx + x) * pitch + ch];
+    const long long cell = ((long long)(b * na + a) * ny + y) * nx + x;  // (bs,na,ny,nx) index
+    if (raw) raw[cell * no + o] = hv;
+    if (z) {
+        const float v = to_f32<T>(hv);
+        const float s = rt<T>(1.0f / (1.0f + expf(-v)));
+        float r;
+        if (o < 2) {
+            const float g = rt<T>((o == 0 ? (float)x : (float)y) - 0.5f);
+            r = rt<T>(rt<T>(rt<T>(s * 2.0f) + g) * rt<T>(stride));
+        } else if (o < 4) {
+            const float aw = a == 0 ? aw0 : a == 1 ? aw1 : a == 2 ? aw2 : a == 3 ? aw3 : aw4;
+            const float ah = a == 0 ? ah0 : a == 1 ? ah1 : a == 2 ? ah2 : a == 3 ? ah3 : ah4;
+            const float d = rt<T>(s * 2.0f);
+            r = rt<T>(rt<T>(d * d) * (o == 2 ? aw : ah));
+        } else {
+            r = s;
+        }
+        const long long row = row_offset + ((long long)a * ny + y) * nx + x;
+        z[((long long)b * total_rows + row) * no + o] = from_f32<T>(r);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ NMS
+constexpr int IMG_BITS = 11, ORD_BITS = 21, CLS_BITS = 12, RANK_BITS = 15;
+constexpr unsigned long long KEY_UNUSED = ~0ull;
+
+struct NmsWs {  // device pointers carved from the caller's workspace
+    int* row_count;                // bs*n_rows (+1)
+    int* row_off;                  // bs*n_rows + 1 (exclusive scan, last = total)
+    unsigned* img_maxabs;          // bs  (float bits of max |coord| among the image's candidates)
+    unsigned long long* key_a;     // cap
+    unsigned long long* key_b;     // cap
+    unsigned* val_a;               // cap
+    unsigned* val_b;               // cap
+    unsigned long long* key_c;     // cap  (sorted key2)
+    unsigned* val_c;               // cap  (sorted-1 positions in segment order)
+    float4* cbox;                  // cap  emitted xyxy (no class offset)
+    float* cscore;                 // cap
+    int* ccls;                     // cap
+    float4* sbox;                  // cap  class-offset boxes in sorted-1 order
+    unsigned char* keep;           // cap  indexed by sorted-1 position
+    void* tmp;                     // rocprim temp storage
+    size_t tmp_bytes;
+    long long cap;
+};
+
+template <typename T> Y3_DEV bool gt_thr(float v, float thr_T) { return v > thr_T; }
+
+Y3_DEV bool class_allowed(int c, const int* __restrict__ classes, int ncf) {
+    if (ncf == 0) return true;
+    bool ok = false;
+    for (int i = 0; i < ncf; ++i) ok |= (classes[i] == c);
+    return ok;
+}
+
+// One wave per 64 consecutive anchor rows of one image.  MODE 0 = count, MODE 1 = emit.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void nms_candidates_kernel(const T* __restrict__ pred, int bs, int n_rows, int nc, float thr, int multi_label,
+                                                               const int* __restrict__ classes, int ncf, NmsWs ws, int* __restrict__ status) {
+    const int lane = threadIdx.x & 63;
+    const int chunks_per_img = (n_rows + 63) / 64;
+    const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wave_id >= (long long)bs * chunks_per_img) return;
+    const int img = (int)(wave_id / chunks_per_img);
+    const int r0 = (int)(wave_id % chunks_per_img) * 64;
+    const int no = nc + 5;
+    const T* __restrict__ base = pred + (long long)img * n_rows * no;
+
+    const int myrow = r0 + lane;
+    float obj_l = 0.0f;
+    if (myrow < n_rows) obj_l = to_f32<T>(base[(long long)myrow * no + 4]);
+    const bool pass_l = (myrow < n_rows) && (obj_l > thr);
+    unsigned long long mask = __ballot(pass_l);
+    int mycount = 0;
+    int myoff = 0;
+    if (MODE == 1 && myrow < n_rows) myoff = ws.row_off[(long long)img * n_rows + myrow];
+    const long long img_off0 = MODE == 1 ? (long long)ws.row_off[(long long)img * n_rows] : 0;
+    float maxabs = 0.0f;
+
+    while (mask) {
+        const int r = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const int row = r0 + r;
+        const T* __restrict__ rp = base + (long long)row * no;
+        const float obj = __shfl(obj_l, r);
+        int cnt = 0;
+        float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
+        int off = 0;
+        if (MODE == 1) {
+            off = __shfl(myoff, r);
+            // xywh2xyxy in the input dtype: half = wh/2 (rounded), xy -/+ half (rounded)   utils/general.py:705
+            const float cx = to_f32<T>(rp[0]), cy = to_f32<T>(rp[1]);
+            const float hw = rt<T>(to_f32<T>(rp[2]) / 2.0f), hh = rt<T>(to_f32<T>(rp[3]) / 2.0f);
+            box = make_float4(rt<T>(cx - hw), rt<T>(cy - hh), rt<T>(cx + hw), rt<T>(cy + hh));
+        }
+        if (multi_label) {
+            for (int c0 = 0; c0 < nc; c0 += 64) {
+                const int c = c0 + lane;
+                float conf = 0.0f;
+                bool ok = false;
+                if (c < nc) {
+                    conf = rt<T>(to_f32<T>(rp[5 + c]) * obj);  // x[:, 5:] *= x[:, 4:5] in the input dtype  (:702)
+                    ok = (conf > thr) && class_allowed(c, classes, ncf);
+                }
+                const unsigned long long m = __ballot(ok);
+                if (MODE == 1 && ok) {
+                    const int k = cnt + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                    const long long g = (long long)off + k;
+                    if (g < ws.cap) {
+                        const unsigned ord = (unsigned)(g - img_off0);
+                        ws.cbox[g] = box;
+                        ws.cscore[g] = conf;
+                        ws.ccls[g] = c;
+                        ws.key_a[g] = ((unsigned long long)img << (32 + ORD_BITS)) | ((unsigned long long)(~__float_as_uint(conf)) << ORD_BITS) |
+                                      (unsigned long long)(ord & ((1u << ORD_BITS) - 1u));
+                        ws.val_a[g] = (unsigned)g;
+                    } else {
+                        status[0] = 1;
+                    }
+                }
+                cnt += __builtin_popcountll(m);
+            }
+        } else {
+            // best class: max over classes, first index on ties (:713), then conf > thr (:714)
+            float best = -INFINITY;
+            int bi = 0x7fffffff;
+            for (int c = lane; c < nc; c += 64) {
+                const float conf = rt<T>(to_f32<T>(rp[5 + c]) * obj);
+                if (conf > best) { best = conf; bi = c; }
+            }
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) {
+                const float ob = __shfl_xor(best, s);
+                const int oi = __shfl_xor(bi, s);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            const bool ok = (best > thr) && class_allowed(bi, classes, ncf);
+            cnt = ok ? 1 : 0;
+            if (MODE == 1 && ok && lane == 0) {
+                const long long g = off;
+                if (g < ws.cap) {
+                    const unsigned ord = (unsigned)(g - img_off0);
+                    ws.cbox[g] = box;
+                    ws.cscore[g] = best;
+                    ws.ccls[g] = bi;
+                    ws.key_a[g] = ((unsigned long long)img << (32 + ORD_BITS)) | ((unsigned long long)(~__float_as_uint(best)) << ORD_BITS) |
+                                  (unsigned long long)(ord & ((1u << ORD_BITS) - 1u));
+                    ws.val_a[g] = (unsigned)g;
+                } else {
+                    status[0] = 1;
+                }
+            }
+        }
+        if (MODE == 1 && cnt > 0) {
+            const float m4 = fmaxf(fmaxf(fabsf(box.x), fabsf(box.y)), fmaxf(fabsf(box.z), fabsf(box.w)));
+            maxabs = (m4 == m4) ? fmaxf(maxabs, m4) : INFINITY;  // NaN -> forbid class partitioning
+        }
+        if (lane == r) mycount = cnt;
+    }
+    if (MODE == 0) {
+        if (myrow < n_rows) ws.row_count[(long long)img * n_rows + myrow] = mycount;
+    } else {
+        if (lane == 0 && maxabs > 0.0f) atomicMax(&ws.img_maxabs[img], __float_as_uint(maxabs));
+    }
+}
+
+// sorted-1 order -> per-image rank, max_nms cut, class-offset boxes, key2
+__global__ __launch_bounds__(256) void nms_rank_kernel(NmsWs ws, int bs, int n_rows, int max_nms, float max_wh, int agnostic, const unsigned long long* __restrict__ key1,
+                                                        const unsigned* __restrict__ idx1, unsigned long long* __restrict__ key2, unsigned* __restrict__ val2,
+                                                        int* __restrict__ status) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= ws.cap) return;
+    const long long total = ws.row_off[(long long)bs * n_rows];
+    if (i == 0) status[1] = (int)(total > 0x7fffffffLL ? 0x7fffffff : total);
+    unsigned long long k2 = KEY_UNUSED;
+    ws.keep[i] = 0;
+    if (i < total && key1[i] != KEY_UNUSED) {
+        const int img = (int)(key1[i] >> (32 + ORD_BITS));
+        const long long start = ws.row_off[(long long)img * n_rows];
+        const long long rank = i - start;
+        if (rank < max_nms) {
+            const unsigned g = idx1[i];
+            const int cls = ws.ccls[g];
+            const float4 b = ws.cbox[g];
+            const bool part = !agnostic && (__uint_as_float(ws.img_maxabs[img]) < max_wh * 0.5f);
+            const float c = (float)cls * (agnostic ? 0.0f : max_wh);  // x[:, 5:6] * (0 if agnostic else max_wh)  (:731)
+            ws.sbox[i] = make_float4(b.x + c, b.y + c, b.z + c, b.w + c);
+            const unsigned seg = part ? (unsigned)cls : 0u;
+            k2 = ((unsigned long long)img << (CLS_BITS + RANK_BITS)) | ((unsigned long long)seg << RANK_BITS) | (unsigned long long)rank;
+        }
+    }
+    key2[i] = k2;
+    val2[i] = (unsigned)i;
+}
+
+Y3_DEV long long lower_bound_u64(const unsigned long long* __restrict__ a, long long n, unsigned long long v) {
+    long long lo = 0, hi = n;
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// greedy NMS of one (image, segment); positions refer to sorted-1 order (ws.sbox / ws.keep)
+__global__ __launch_bounds__(256) void nms_greedy_kernel(NmsWs ws, int nseg, double iou_thr, int max_det, int max_nms, const unsigned long long* __restrict__ key2,
+                                                          const unsigned* __restrict__ pos2) {
+    __shared__ unsigned removed[(1 << RANK_BITS) / 32];  // 32768 bits = 4 KiB
+    __shared__ int s_next;
+    const int img = blockIdx.x / nseg, seg = blockIdx.x % nseg;
+    const unsigned long long kbase = ((unsigned long long)img << (CLS_BITS + RANK_BITS)) | ((unsigned long long)seg << RANK_BITS);
+    const long long lo = lower_bound_u64(key2, ws.cap, kbase);
+    const long long hi = lower_bound_u64(key2, ws.cap, kbase + (1ull << RANK_BITS));
+    const int n = (int)(hi - lo);
+    if (n <= 0) return;
+    const int tid = threadIdx.x;
+    for (int w = tid; w < (n + 31) / 32; w += 256) removed[w] = 0u;
+    __syncthreads();
+    const unsigned* __restrict__ pos = pos2 + lo;
+    int cur = 0, kept = 0;
+    while (cur < n && kept < max_det) {
+        const unsigned pi = pos[cur];
+        if (tid == 0) ws.keep[pi] = 1;
+        ++kept;
+        const float4 bi = ws.sbox[pi];
+        const float iarea = (bi.z - bi.x) * (bi.w - bi.y);
+        for (int j = cur + 1 + tid; j < n; j += 256) {
+            if (removed[j >> 5] & (1u << (j & 31))) continue;
+            const float4 bj = ws.sbox[pos[j]];
+            const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
+            const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
+            float w = xx2 - xx1, h = yy2 - yy1;
+            w = w > 0.0f ? w : 0.0f;
+            h = h > 0.0f ? h : 0.0f;
+            const float inter = w * h;
+            const float jarea = (bj.z - bj.x) * (bj.w - bj.y);
+            const float ovr = inter / (iarea + jarea - inter);
+            if ((double)ovr > iou_thr) atomicOr(&removed[j >> 5], 1u << (j & 31));
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int nx = cur + 1;
+            while (nx < n) {
+                const unsigned wbits = ~removed[nx >> 5] & (0xffffffffu << (nx & 31));
+                if (wbits) { nx = (nx & ~31) + __builtin_ctz(wbits); break; }
+                nx = (nx & ~31) + 32;
+            }
+            s_next = nx < n ? nx : n;
+        }
+        __syncthreads();
+        cur = s_next;
+        __syncthreads();
+    }
+}
+
+// per image: kept candidates in descending-score order, first max_det -> out rows
+__global__ __launch_bounds__(256) void nms_gather_kernel(NmsWs ws, int n_rows, int max_det, int max_nms, const unsigned* __restrict__ idx1,
+                                                          float* __restrict__ out_rows, int* __restrict__ out_counts) {
+    __shared__ int wave_cnt[4];
+    __shared__ int s_base;
+    const int img = blockIdx.x;
+    const long long start = ws.row_off[(long long)img * n_rows];
+    long long cnt = (long long)ws.row_off[(long long)(img + 1) * n_rows] - start;
+    if (start + cnt > ws.cap) cnt = ws.cap - start > 0 ? ws.cap - start : 0;
+    if (cnt > max_nms) cnt = max_nms;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (long long c0 = 0; c0 < cnt; c0 += 256) {
+        const long long i = c0 + tid;
+        const bool k = (i < cnt) && ws.keep[start + i];
+        const unsigned long long m = __ballot(k);
+        if (lane == 0) wave_cnt[wv] = __builtin_popcountll(m);
+        __syncthreads();
+        int before = s_base;
+        for (int w = 0; w < wv; ++w) before += wave_cnt[w];
+        const int slot = before + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+        if (k && slot < max_det) {
+            const unsigned g = idx1[start + i];
+            const float4 b = ws.cbox[g];
+            float* o = out_rows + ((long long)img * max_det + slot) * 6;
+            o[0] = b.x; o[1] = b.y; o[2] = b.z; o[3] = b.w;
+            o[4] = ws.cscore[g];
+            o[5] = (float)ws.ccls[g];
+        }
+        __syncthreads();
+        if (tid == 0) s_base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+        if (s_base >= max_det) break;
+    }
+    if (tid == 0) out_counts[img] = s_base < max_det ? s_base : max_det;
+}
+
+size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+long long worst_capacity(int bs, int n_rows, int nc, const y3_nms_params* p) {
+    return (long long)bs * n_rows * ((p->multi_label && nc > 1) ? nc : 1);
+}
+long long default_capacity(int bs, int n_rows, int nc, const y3_nms_params* p) {
+    const long long worst = worst_capacity(bs, n_rows, nc, p);
+    long long cap = (long long)bs * 16384;
+    if (cap > worst) cap = worst;
+    if (cap < 1024) cap = 1024;
+    return cap;
+}
+
+size_t temp_bytes(long long cap, size_t scan_n) {
+    size_t a = 0, b = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, a, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr, (size_t)cap, 0u,
+                                    64u, (hipStream_t)0);
+    (void)rocprim::exclusive_scan(nullptr, b, (int*)nullptr, (int*)nullptr, 0, scan_n + 1, rocprim::plus<int>(), (hipStream_t)0);
+    return align_up(a > b ? a : b);
+}
+
+size_t carve(NmsWs& ws, unsigned char* base, int bs, long long cap, size_t scan_n) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        unsigned char* p = base ? base + off : nullptr;
+        off += align_up(bytes);
+        return p;
+    };
+    ws.cap = cap;
+    ws.row_count = (int*)take((scan_n + 1) * sizeof(int));
+    ws.row_off = (int*)take((scan_n + 1) * sizeof(int));
+    ws.img_maxabs = (unsigned*)take((size_t)bs * sizeof(unsigned));
+    ws.key_a = (unsigned long long*)take((size_t)cap * 8);
+    ws.key_b = (unsigned long long*)take((size_t)cap * 8);
+    ws.key_c = (unsigned long long*)take((size_t)cap * 8);
+    ws.val_a = (unsigned*)take((size_t)cap * 4);
+    ws.val_b = (unsigned*)take((size_t)cap * 4);
+    ws.val_c = (unsigned*)take((size_t)cap * 4);
+    ws.cbox = (float4*)take((size_t)cap * 16);
+    ws.cscore = (float*)take((size_t)cap * 4);
+    ws.ccls = (int*)take((size_t)cap * 4);
+    ws.sbox = (float4*)take((size_t)cap * 16);
+    ws.keep = (unsigned char*)take((size_t)cap);
+    ws.tmp_bytes = temp_bytes(cap, scan_n);
+    ws.tmp = take(ws.tmp_bytes);
+    return off;
+}
+
+template <typename T>
+int run_nms(const void* pred, int bs, int n_rows, int nc, const y3_nms_params* p, const int* classes, float* out_rows, int* out_counts, int* out_status,
+            void* workspace, size_t workspace_bytes, hipStream_t st) {
+    const size_t scan_n = (size_t)bs * n_rows;
+    // capacity: the default one, or as large as the given workspace allows (the host grows it after an overflow)
+    long long cap = default_capacity(bs, n_rows, nc, p);
+    NmsWs ws;
+    if (carve(ws, nullptr, bs, cap, scan_n) > workspace_bytes) Y3_FAIL("y3_nms: workspace too small (%zu bytes given)", workspace_bytes);
+    const long long worst = worst_capacity(bs, n_rows, nc, p);
+    while (cap < worst) {
+        const long long c2 = cap * 2 > worst ? worst : cap * 2;
+        if (carve(ws, nullptr, bs, c2, scan_n) > workspace_bytes) break;
+        cap = c2;
+    }
+    if (cap > 0x7ffffff0LL) Y3_FAIL("y3_nms: capacity too large");
+    carve(ws, (unsigned char*)workspace, bs, cap, scan_n);
+
+    const float thr = (float)(T)(p->conf_thres);              // python scalar -> tensor dtype before the compare
+    const int multi = (p->multi_label && nc > 1) ? 1 : 0;       // multi_label &= nc > 1   (utils/general.py:677)
+    const int ncf = classes ? p->n_classes_filter : 0;
+    const bool one_seg = p->agnostic != 0;
+    const int nseg = one_seg ? 1 : nc;
+
+    Y3_HIP(hipMemsetAsync(out_status, 0, 2 * sizeof(int), st));
+    Y3_HIP(hipMemsetAsync(ws.img_maxabs, 0, (size_t)bs * sizeof(unsigned), st));
+    Y3_HIP(hipMemsetAsync(ws.key_a, 0xff, (size_t)cap * 8, st));
+    Y3_HIP(hipMemsetAsync(ws.row_count + scan_n, 0, sizeof(int), st));
+
+    const long long waves = (long long)bs * ((n_rows + 63) / 64);
+    const unsigned cblocks = (unsigned)((waves + 3) / 4);
+    hipLaunchKernelGGL((nms_candidates_kernel<T, 0>), dim3(cblocks), dim3(256), 0, st, (const T*)pred, bs, n_rows, nc, thr, multi, classes, ncf, ws, out_status);
+    Y3_CHECK_LAUNCH();
+    size_t tb = ws.tmp_bytes;
+    if (rocprim::exclusive_scan(ws.tmp, tb, ws.row_count, ws.row_off, 0, scan_n + 1, rocprim::plus<int>(), st) != hipSuccess) Y3_FAIL("y3_nms: scan failed");
+    hipLaunchKernelGGL((nms_candidates_kernel<T, 1>), dim3(cblocks), dim3(256), 0, st, (const T*)pred, bs, n_rows, nc, thr, multi, classes, ncf, ws, out_status);
+    Y3_CHECK_LAUNCH();
+    tb = ws.tmp_bytes;
+    if (rocprim::radix_sort_pairs(ws.tmp, tb, ws.key_a, ws.key_b, ws.val_a, ws.val_b, (size_t)cap, 0u, 64u, st) != hipSuccess) Y3_FAIL("y3_nms: sort-1 failed");
+    // (key_b, val_b) = per-image descending-score order.  key_a / val_a are free again: reuse for key2 / positions.
+    const unsigned rblocks = (unsigned)((cap + 255) / 256);
+    hipLaunchKernelGGL(nms_rank_kernel, dim3(rblocks), dim3(256), 0, st, ws, bs, n_rows, p->max_nms, p->max_wh, p->agnostic, ws.key_b, ws.val_b, ws.key_a, ws.val_a,
+                       out_status);
+    Y3_CHECK_LAUNCH();
+    tb = ws.tmp_bytes;
+    if (rocprim::radix_sort_pairs(ws.tmp, tb, ws.key_a, ws.key_c, ws.val_a, ws.val_c, (size_t)cap, 0u, (unsigned)(IMG_BITS + CLS_BITS + RANK_BITS), st) != hipSuccess)
+        Y3_FAIL("y3_nms: sort-2 failed");
+    hipLaunchKernelGGL(nms_greedy_kernel, dim3((unsigned)(bs * nseg)), dim3(256), 0, st, ws, nseg, p->iou_thres, p->max_det, p->max_nms, ws.key_c, ws.val_c);
+    Y3_CHECK_LAUNCH();
+    hipLaunchKernelGGL(nms_gather_kernel, dim3((unsigned)bs), dim3(256), 0, st, ws, n_rows, p->max_det, p->max_nms, ws.val_b, out_rows, out_counts);
+    Y3_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" size_t y3_nms_workspace_bytes(int32_t bs, int32_t n_rows, int32_t nc, const y3_nms_params* p, int64_t capacity) {
+    if (!p || bs <= 0 || n_rows <= 0 || nc <= 0) return 0;
+    long long cap = capacity > 0 ? capacity : default_capacity(bs, n_rows, nc, p);
+    const long long worst = worst_capacity(bs, n_rows, nc, p);
+    if (cap > worst) cap = worst;
+    if (cap < 1024) cap = 1024;
+    NmsWs ws;
+    return carve(ws, nullptr, bs, cap, (size_t)bs * n_rows);
+}
+
+extern "C" int y3_nms(const void* pred, int32_t dtype, int32_t bs, int32_t n_rows, int32_t nc, const y3_nms_params* p, const int32_t* classes, float* out_rows,
+                      int32_t* out_counts, int32_t* out_status, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!pred || !p || !out_rows || !out_counts || !out_status || !workspace) Y3_FAIL("y3_nms: null argument");
+    if (!(p->conf_thres >= 0.0f && p->conf_thres <= 1.0f)) Y3_FAIL("Invalid Confidence threshold %g, valid values are between 0.0 and 1.0", (double)p->conf_thres);
+    if (!(p->iou_thres >= 0.0 && p->iou_thres <= 1.0)) Y3_FAIL("Invalid IoU %g, valid values are between 0.0 and 1.0", p->iou_thres);
+    if (bs <= 0 || bs >= (1 << IMG_BITS) - 1) Y3_FAIL("y3_nms: batch size %d unsupported (max %d)", bs, (1 << IMG_BITS) - 2);
+    if (nc <= 0 || nc >= (1 << CLS_BITS)) Y3_FAIL("y3_nms: class count %d unsupported", nc);
+    if (p->max_nms <= 0 || p->max_nms > (1 << RANK_BITS) - 1) Y3_FAIL("y3_nms: max_nms %d unsupported (max %d)", p->max_nms, (1 << RANK_BITS) - 1);
+    if ((long long)n_rows * (p->multi_label ? nc : 1) >= (1ll << ORD_BITS)) Y3_FAIL("y3_nms: too many candidate slots per image");
+    if ((long long)bs * n_rows >= 0x7fffffffLL) Y3_FAIL("y3_nms: too many rows");
+    if (p->max_det <= 0) Y3_FAIL("y3_nms: max_det must be positive");
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case Y3_F16: return run_nms<f16_t>(pred, bs, n_rows, nc, p, classes, out_rows, out_counts, out_status, workspace, workspace_bytes, st);
+        case Y3_BF16: return run_nms<bf16_t>(pred, bs, n_rows, nc, p, classes, out_rows, out_counts, out_status, workspace, workspace_bytes, st);
+        case Y3_F32: return run_nms<float>(pred, bs, n_rows, nc, p, classes, out_rows, out_counts, out_status, workspace, workspace_bytes, st);
+    }
+    Y3_FAIL("y3_nms: bad dtype %d", dtype);
+}
+
+extern "C" int y3_detect_decode(const y3_tensor* head, int32_t dtype, int32_t na, int32_t no, const float* anchors_px, float stride, void* raw, void* z,
+                                int64_t row_offset, int64_t total_rows, void* stream) {
+    if (!head || !anchors_px) Y3_FAIL("y3_detect_decode: null argument");
+    if (na < 1 || na > 5) Y3_FAIL("y3_detect_decode: na=%d unsupported (1..5)", na);
+    if (head->c < na * no) Y3_FAIL("y3_detect_decode: head has %d channels, needs %d", head->c, na * no);
+    float a[10] = {0};
+    for (int i = 0; i < na * 2; ++i) a[i] = anchors_px[i];
+    const long long total = (long long)head->n * head->h * head->w * na * no;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    hipStream_t st = (hipStream_t)stream;
+#define Y3_DECODE(T)                                                                                                                                        \
+    hipLaunchKernelGGL((decode_kernel<T>), grid, dim3(256), 0, st, (const T*)head->data, head->n, head->h, head->w, head->pitch, na, no, a[0], a[1], a[2], a[3], \
+                       a[4], a[5], a[6], a[7], a[8], a[9], stride, (T*)raw, (T*)z, (long long)row_offset, (long long)total_rows)
+    switch (dtype) {
+        case Y3_F16: Y3_DECODE(f16_t); break;
+        case Y3_BF16: Y3_DECODE(bf16_t); break;
+        case Y3_F32: Y3_DECODE(float); break;
+        default: Y3_FAIL("y3_detect_decode: bad dtype %d", dtype);
+    }
+#undef Y3_DECODE
+    Y3_CHECK_LAUNCH();
+    return 0;
+}

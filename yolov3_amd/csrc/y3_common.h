@@ -1,0 +1,58 @@
+// Shared device/host helpers for libyolov3_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/yolov3_hip.h"
+
+#define Y3_DEV __device__ __forceinline__
+
+typedef _Float16 f16_t;
+typedef __bf16 bf16_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// ---- error plumbing -------------------------------------------------------------------------
+void y3_set_error(const char* fmt, ...);
+#define Y3_FAIL(...)               \
+    do {                           \
+        y3_set_error(__VA_ARGS__); \
+        return -1;                 \
+    } while (0)
+#define Y3_CHECK_LAUNCH()                                                     \
+    do {                                                                      \
+        hipError_t e_ = hipGetLastError();                                    \
+        if (e_ != hipSuccess) Y3_FAIL("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+    } while (0)
+
+#define Y3_HIP(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) Y3_FAIL("%s:%d %s failed: %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+    } while (0)
+
+// ---- scalar conversions ----------------------------------------------------------------------
+template <typename T> Y3_DEV float to_f32(T v);
+template <> Y3_DEV float to_f32<f16_t>(f16_t v) { return (float)v; }
+template <> Y3_DEV float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+template <> Y3_DEV float to_f32<float>(float v) { return v; }
+template <typename T> Y3_DEV T from_f32(float v);
+template <> Y3_DEV f16_t from_f32<f16_t>(float v) { return (f16_t)v; }   // round-to-nearest-even
+template <> Y3_DEV bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; } // round-to-nearest-even
+template <> Y3_DEV float from_f32<float>(float v) { return v; }
+
+// round a float through T (what torch does after every elementwise op on a half tensor)
+template <typename T> Y3_DEV float rt(float v) { return to_f32<T>(from_f32<T>(v)); }
+
+Y3_DEV float silu_f32(float v) { return v / (1.0f + __expf(-v)); }
+
+static inline int y3_ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline size_t y3_round_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+// packed filter geometry (see conv.hip): rows padded to 128 filters, K padded to 64
+static inline int y3_filter_rows(int cout) { return (int)y3_round_up((size_t)cout, 128); }
+static inline int y3_filter_kpad(int cin, int ksize) { return (int)y3_round_up((size_t)ksize * ksize * cin, 64); }
