@@ -1,0 +1,236 @@
+"""bench.py -- images/sec of the YOLOv3 inference hot path (forward + Detect decode + batched NMS) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload = BASELINE.json configs[1]: yolov3, 640x640, batch 32 per GPU, fp16, + NMS with val.py's settings
+(conf 0.001, iou 0.6, multi_label, max_det 300 -- reference val.py:374-376).  One "step" = one pass of the hot
+path over one batch resident in HBM: DetectionModel.forward (75 fused conv launches + decode) on synthetic
+images, then non_max_suppression on a synthetic (32, 25200, 85) fp16 prediction tensor from the seeded
+generator of SURVEY.md 8(d) (a random-weight model's own objectness is ~0.003 everywhere, which would make the NMS
+leg degenerate; the generator gives ~5k candidate rows per image like a trained model at conf 0.001).  Both
+legs run in full every step.
+
+Multi-GPU: inference does not exchange data -> N independent replicas, one process per GPU,
+"weak" scaling; the only collective is the timing barrier / max-reduce.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` and `cpu_baseline`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+MFMA_PEAK_TFLOPS = 2500.0  # dense fp16/bf16, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def igemm_variant(cin, cout):
+    """Mirror of dispatch_igemm() in csrc/conv.hip: which template instance a conv launch lands on."""
+    bk = 64 if cin % 64 == 0 else 32
+    small = "" if cin % 32 == 0 else "_smallc"
+    tile = "tc128xtp128" if cout > 64 else "tc64xtp256" if cout > 32 else "tc32xtp256"
+    return f"conv_igemm<f16,bk{bk},{tile}{small}>"
+
+
+def per_kernel_times(plan, reps=5):
+    """HIP-event timing of every launch of the compiled plan on the stream the kernels run on (torch's current
+    stream).  Returns {variant: [flops, bytes, seconds, launches]} averaged over `reps` passes."""
+    from yolov3_amd import ops
+
+    stream = ops.stream_ptr()
+    acc = {}
+    for _ in range(reps):
+        evs = []
+        for ln in plan.launches:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ln.fn(*ln.args, stream)
+            e1.record()
+            evs.append((ln, e0, e1))
+        torch.cuda.synchronize()
+        for ln, e0, e1 in evs:
+            if ln.flops:
+                w = ln.keep[4]
+                key = igemm_variant(w.cin, w.cout)
+            else:
+                key = ln.label.split(".")[-1]
+            a = acc.setdefault(key, [0.0, 0.0, 0.0, 0])
+            a[0] += ln.flops
+            a[1] += ln.bytes
+            a[2] += e0.elapsed_time(e1) * 1e-3
+            a[3] += 1
+    return acc
+
+
+def cpu_baseline(bs_sample=4):
+    """The oracle (torch-CPU fp32 restatement of the reference, fused eval forward + NMS) on the host cores, on a
+    bounded sample of the same workload.  kind="port": the reference itself needs /root/reference + stubs and
+    cannot travel to the GPU box."""
+    import yaml
+
+    from oracle import yolo_oracle as yo
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    d = yaml.safe_load(open(ROOT / "yolov3_amd" / "cfg" / "yolov3.yaml"))
+    layers, save, anchors, nc = yo.parse_cfg(d)
+    strides = yo.model_strides(layers)
+    sd = yo.fuse_state_dict(yo.seeded_state_dict(layers, nc, anchors, strides, seed=0))
+    x = torch.rand(bs_sample, 3, 640, 640, generator=torch.Generator().manual_seed(0))
+    pred_s = yo.synth_predictions(bs=bs_sample, n_rows=25200, nc=80, seed=2)
+    with torch.inference_mode():
+        yo.forward(layers, save, sd, x[:1], strides)  # warm-up
+        best_f, best_n = 1e9, 1e9
+        for _ in range(2):
+            t0 = time.perf_counter()
+            yo.forward(layers, save, sd, x, strides)
+            best_f = min(best_f, time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            yo.non_max_suppression(pred_s, 0.001, 0.6, multi_label=True, max_det=300)
+            best_n = min(best_n, time.perf_counter() - t0)
+    return {
+        "value": round(bs_sample / (best_f + best_n), 3),
+        "unit": "images/sec",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"{bs_sample} images 640x640 fp32 fused-eval forward ({best_f:.2f}s) + NMS val settings ({best_n:.2f}s), best of 2, oracle/yolo_oracle.py",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--imgsz", type=int, default=640)
+    ap.add_argument("--model", default="yolov3")
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-layers", action="store_true", help="print the per-launch table (rank 0)")
+    args = ap.parse_args()
+
+    from yolov3_amd import parallel
+
+    rank, local_rank, world = parallel.init()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from oracle import yolo_oracle as yo  # only for the seeded synthetic inputs + cpu_baseline leg
+    from yolov3_amd import DetectionModel, non_max_suppression
+
+    dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+    bs, hw = args.batch, args.imgsz
+    torch.manual_seed(0)
+    model = DetectionModel(f"{args.model}.yaml")
+    for m in model.modules():  # well-conditioned BN statistics so activations stay O(1) through 75 layers
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.1)
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    model = model.to(dev).to(dtype).eval()
+    x = torch.rand(bs, 3, hw, hw, generator=torch.Generator().manual_seed(rank)).to(dev).to(dtype)
+    n_rows = sum(3 * (hw // s) ** 2 for s in (8, 16, 32)) if args.model != "yolov3-tiny" else sum(3 * (hw // s) ** 2 for s in (16, 32))
+    pred_synth = yo.synth_predictions(bs=bs, n_rows=n_rows, nc=80, seed=2 + rank, img=hw).to(dev).to(dtype)
+    nms_kw = dict(conf_thres=0.001, iou_thres=0.6, multi_label=True, max_det=300)
+
+    def step():
+        pred, _ = model(x)
+        return pred, non_max_suppression(pred_synth, **nms_kw)
+
+    barrier = parallel.barrier
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pred, dets = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    dt = parallel.max_over_ranks(dt, dev)
+
+    if rank == 0:
+        # ---- leg split + per-kernel roofline (outside the timed region) ----
+        def timed(fn, n=5):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / n
+
+        t_fwd = timed(lambda: model(x))
+        t_nms = timed(lambda: non_max_suppression(pred_synth, **nms_kw))
+        t_nms_own = timed(lambda: non_max_suppression(pred, **nms_kw))
+        plan = next(iter(model._plans.values()))
+        groups = per_kernel_times(plan)
+        if args.profile_layers:
+            model(x, profile=True)
+        dom = max((k for k in groups if groups[k][0] > 0), key=lambda k: groups[k][2])
+        fl, by, sec, nl = groups[dom]
+        total_conv_flops = sum(g[0] for g in groups.values()) / 5
+        total_kernel_s = sum(g[2] for g in groups.values()) / 5
+        roofline = {
+            "kernel": dom,
+            "bound": "mfma",
+            "achieved": round(fl / sec / 1e12, 2),
+            "peak": MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": round(fl / sec / 1e12 / MFMA_PEAK_TFLOPS, 4),
+            "traffic": None,
+            "launches_per_forward": nl // 5,
+            "avg_launch_us": round(sec / nl * 1e6, 2),
+            "algorithmic_gflop_per_launch": round(fl / nl / 1e9, 3),
+            "hbm_frac_of_same_kernel": round(by / sec / 1e9 / HBM_PEAK_GBS, 4),
+            "whole_forward": {
+                "conv_tflops": round(total_conv_flops / total_kernel_s / 1e12, 2),
+                "gflop_per_image": round(total_conv_flops / bs / 1e9, 2),
+                "kernel_ms": round(total_kernel_s * 1e3, 3),
+                "by_kernel_ms": {k: round(g[2] / 5 * 1e3, 3) for k, g in sorted(groups.items(), key=lambda kv: -kv[1][2])},
+            },
+        }
+        cpu = None if args.no_cpu_baseline else cpu_baseline()
+        value = world * bs * args.steps / dt
+        out = {
+            "metric": "images/sec (640x640) inference+NMS",
+            "value": round(value, 2),
+            "unit": "images/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16" if dtype == torch.float16 else "bf16",
+            "data": "synthetic (seeded uniform images; random-init weights with conditioned BN stats; NMS leg on the seeded synthetic prediction tensor of SURVEY 8d)",
+            "config": {
+                "workload": f"{args.model} inference {hw}x{hw} batch={bs}/GPU {args.dtype} + NMS(conf 0.001, iou 0.6, multi_label, max_det 300) [BASELINE configs[1]]",
+                "global_batch": world * bs,
+                "parallelism": f"replicas x{world} (no data-path collective)",
+            },
+            "legs_ms": {"forward+decode": round(t_fwd * 1e3, 3), "nms_synthetic_pred": round(t_nms * 1e3, 3), "nms_on_model_output": round(t_nms_own * 1e3, 3)},
+            "nms_candidates_per_image": None,
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    parallel.finalize()
+
+
+if __name__ == "__main__":
+    main()

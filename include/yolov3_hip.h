@@ -112,13 +112,13 @@ typedef struct {
     int32_t n_classes_filter;   /* 0 = no class filter */
 } y3_nms_params;
 /* capacity = candidate slots for the whole batch; <= 0 picks the default (bs*16384, clamped to the
- * worst case).  y3_nms uses the largest capacity that fits the workspace it is given. */
+ * worst case bs*n_rows*nc).  Pass the same capacity to both calls. */
 size_t y3_nms_workspace_bytes(int32_t bs, int32_t n_rows, int32_t nc, const y3_nms_params* p, int64_t capacity);
 /* out_status (device, 2 x int32): [0] = 1 if the candidate capacity overflowed (results invalid: call
  * again with a workspace sized for capacity >= out_status[1]); [1] = total candidates found. */
 int y3_nms(const void* pred, int32_t dtype, int32_t bs, int32_t n_rows, int32_t nc, const y3_nms_params* p,
-           const int32_t* classes, float* out_rows, int32_t* out_counts, int32_t* out_status, void* workspace,
-           size_t workspace_bytes, void* stream);
+           const int32_t* classes, float* out_rows, int32_t* out_counts, int32_t* out_status, int64_t capacity,
+           void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -6,7 +6,7 @@
  *   - areas = (x2-x1)*(y2-y1) in float32
  *   - visit boxes by STABLE descending score order
  *   - a visited, un-suppressed box i is kept; every later j with
- *       inter / (area_i + area_j - inter) > thr      (strict, float32)
+ *       inter / (area_i + area_j - inter) > thr      (strict; float32 ratio compared with the DOUBLE threshold)
  *     is suppressed, where inter = max(0, min(x2)-max(x1)) * max(0, min(y2)-max(y1))
  *   - returns kept indices in visiting order.
  * Build with -ffp-contract=off so no product is fused into the adds.
@@ -33,7 +33,7 @@ static void merge_sort_desc(const float* key, long* idx, long* tmp, long n) {
     }
 }
 
-long y3o_nms(const float* boxes, const float* scores, long n, float thr, long* keep_out) {
+long y3o_nms(const float* boxes, const float* scores, long n, double thr, long* keep_out) {
     if (n <= 0) return 0;
     long* order = (long*)malloc((size_t)n * sizeof(long));
     long* tmp = (long*)malloc((size_t)n * sizeof(long));
@@ -64,7 +64,7 @@ long y3o_nms(const float* boxes, const float* scores, long n, float thr, long* k
             float h = yy2 - yy1; if (!(h > 0.0f)) h = 0.0f;
             float inter = w * h;
             float ovr = inter / (iarea + area[j] - inter);
-            if (ovr > thr) dead[j] = 1;
+            if ((double)ovr > thr) dead[j] = 1; /* float ovr vs double threshold, as torchvision's nms_kernel_impl */
         }
     }
     free(order); free(tmp); free(area); free(dead);

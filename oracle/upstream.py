@@ -185,7 +185,7 @@ def nms_py(boxes: np.ndarray, scores: np.ndarray, thr: float) -> np.ndarray:
     areas = (x2 - x1) * (y2 - y1)
     dead = np.zeros(n, dtype=bool)
     keep = []
-    thr = np.float32(thr)
+    thr = float(thr)  # torchvision compares the float32 ratio with the double threshold
     zero = np.float32(0)
     for a in range(n):
         i = order[a]
@@ -198,7 +198,7 @@ def nms_py(boxes: np.ndarray, scores: np.ndarray, thr: float) -> np.ndarray:
         inter = w * h
         with np.errstate(divide="ignore", invalid="ignore"):
             ovr = inter / (areas[i] + areas[rest] - inter)
-        dead[rest[ovr > thr]] = True
+        dead[rest[ovr.astype(np.float64) > thr]] = True
     return np.asarray(keep, dtype=np.int64)
 
 
@@ -219,7 +219,7 @@ def _load_nms_c():
         )
     lib = ctypes.CDLL(str(so))
     lib.y3o_nms.restype = ctypes.c_long
-    lib.y3o_nms.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_float, ctypes.c_void_p]
+    lib.y3o_nms.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_double, ctypes.c_void_p]
     _NMS_LIB = lib
     return lib
 

@@ -1,0 +1,103 @@
+"""Host-logic test (CPU, no GPU): compile the static plan for each model and INTERPRET its symbolic steps with
+torch CPU ops over the planned NHWC buffers (recycled storage, channel slices, fused upsample / zero-pad).
+The result must match the oracle's graph walk, which proves the planner's aliasing, lifetimes and
+concat offsets.  The HIP kernels themselves are covered by the -m gpu tests."""
+import pytest
+import torch
+import torch.nn.functional as F
+import yaml
+
+from oracle import yolo_oracle as yo
+from yolov3_amd import DetectionModel, engine, ops
+from pathlib import Path
+
+CFG = Path(__file__).resolve().parents[1] / "yolov3_amd" / "cfg"
+
+
+def interpret(plan, x_nchw):
+    xin = plan.input_view.real().as_nhwc()
+    xin.zero_()
+    xin[..., : x_nchw.shape[1]] = x_nchw.permute(0, 2, 3, 1)
+    for kind, kw in plan.trace:
+        if kind == "conv":
+            w = kw["w"]
+            wf, bf = w.folded
+            x = kw["x"].real().as_nhwc()[..., : wf.shape[1]].permute(0, 3, 1, 2)
+            y = F.conv2d(x, wf, bf, stride=w.s, padding=w.k // 2)
+            if w.act:
+                y = F.silu(y)
+            if kw["res"] is not None:
+                y = y + kw["res"].real().as_nhwc().permute(0, 3, 1, 2)
+            if kw["ups"]:
+                y = F.interpolate(y, scale_factor=2.0, mode="nearest")
+            dst = kw["y"].real().as_nhwc()
+            dst.zero_()
+            dst[..., : y.shape[1]] = y.permute(0, 2, 3, 1)
+        elif kind == "maxpool":
+            x = kw["x"].real().as_nhwc().permute(0, 3, 1, 2)
+            if kw["zr"] or kw["zb"]:
+                x = F.pad(x, [0, kw["zr"], 0, kw["zb"]])
+            kw["y"].real().as_nhwc().copy_(F.max_pool2d(x, kw["k"], kw["s"], kw["p"]).permute(0, 2, 3, 1))
+        elif kind == "spp":
+            x = kw["x"].real().as_nhwc().permute(0, 3, 1, 2)
+            y = torch.cat([F.max_pool2d(x, k, 1, k // 2) for k in (5, 9, 13)], 1)
+            kw["y"].real().as_nhwc().copy_(y.permute(0, 2, 3, 1))
+        elif kind == "upsample":
+            x = kw["x"].real().as_nhwc().permute(0, 3, 1, 2)
+            kw["y"].real().as_nhwc().copy_(F.interpolate(x, scale_factor=2.0, mode="nearest").permute(0, 2, 3, 1))
+        elif kind == "copy":
+            kw["y"].real().as_nhwc().copy_(kw["x"].real().as_nhwc())
+        else:
+            raise AssertionError(kind)
+    det, heads = plan.detect
+    raws = []
+    for hv in heads:
+        t = hv.real().as_nhwc()[..., : det.na * det.no]
+        raws.append(t.reshape(t.shape[0], t.shape[1], t.shape[2], det.na, det.no).permute(0, 3, 1, 2, 4).contiguous())
+    return raws
+
+
+@pytest.mark.parametrize("name,hw,nc", [("yolov3-tiny", 96, 80), ("yolov3", 64, 80), ("yolov3-spp", 64, 5)])
+def test_plan_interpreted_on_cpu_matches_oracle(monkeypatch, name, hw, nc):
+    monkeypatch.setattr(ops, "pack_filter", lambda w, cout, cin, dtype: torch.zeros(1))
+    monkeypatch.setattr(engine, "KEEP_FOLDED", True)
+    d = yaml.safe_load(open(CFG / f"{name}.yaml"))
+    layers, save, anchors, nc_v = yo.parse_cfg(d, 3, nc)
+    strides = yo.model_strides(layers)
+    sd = yo.seeded_state_dict(layers, nc_v, anchors, strides, seed=4)
+    m = DetectionModel(f"{name}.yaml", nc=nc).eval()
+    m.load_state_dict(sd)
+    x = torch.rand(2, 3, hw, hw + 32, generator=torch.Generator().manual_seed(9))
+    with torch.no_grad():
+        plan = engine.compile_model(m, 2, hw, hw + 32, torch.float32, torch.device("cpu"))
+        raws = interpret(plan, x)
+        _, ref = yo.forward(layers, save, sd, x, strides, training=False)
+    assert len(raws) == len(ref)
+    for a, b in zip(raws, ref):
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-4)
+    # buffers really are recycled (fewer allocations than symbolic buffers)
+    storages = {b.tensor.data_ptr() for b in plan.bufs if b.tensor is not None}
+    assert len(storages) < sum(b.tensor is not None for b in plan.bufs)
+    n_conv = sum(k == "conv" for k, _ in plan.trace)
+    assert n_conv == {"yolov3-tiny": 13, "yolov3": 75, "yolov3-spp": 76}[name]
+    assert not any(k in ("upsample", "copy") for k, _ in plan.trace)  # both fused away
+
+
+def test_fuse_matches_unfused_plan_weights(monkeypatch):
+    monkeypatch.setattr(ops, "pack_filter", lambda w, cout, cin, dtype: torch.zeros(1))
+    monkeypatch.setattr(engine, "KEEP_FOLDED", True)
+    m = DetectionModel("yolov3-tiny.yaml").eval()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.normal_(0, 0.1)
+            mod.running_var.uniform_(0.5, 1.5)
+    with torch.no_grad():
+        p1 = engine.compile_model(m, 1, 64, 64, torch.float32, torch.device("cpu"))
+        keys_before = set(m.state_dict())
+        m.fuse()
+        p2 = engine.compile_model(m, 1, 64, 64, torch.float32, torch.device("cpu"))
+    assert any(".bn." in k for k in keys_before) and not any(".bn." in k for k in m.state_dict())
+    for (k1, a), (k2, b) in zip(p1.trace, p2.trace):
+        if k1 == "conv":
+            torch.testing.assert_close(a["w"].folded[0], b["w"].folded[0], rtol=1e-6, atol=1e-7)
+            torch.testing.assert_close(a["w"].folded[1], b["w"].folded[1], rtol=1e-6, atol=1e-6)

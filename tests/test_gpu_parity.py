@@ -1,0 +1,392 @@
+"""-m gpu parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden vectors.
+
+Tolerances (stated per test):
+  * integer / index work (NMS keep sets, candidate order): bit-exact;
+  * fp32 engine (direct kernels): 1e-4 absolute on logits/boxes (BASELINE.json north_star);
+  * fp16 / bf16 MFMA engine vs the fp32 oracle fed the SAME rounded inputs/weights: per-layer error is one
+    output rounding (2^-11 / 2^-8 relative) plus fp32 accumulation-order noise.
+"""
+import math
+from pathlib import Path
+
+import pytest
+import torch
+import torch.nn.functional as F
+import yaml
+
+from oracle import yolo_oracle as yo
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parents[1]
+CFG = ROOT / "yolov3_amd" / "cfg"
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch.device("cuda:0")
+
+
+def _ops():
+    from yolov3_amd import _lib, ops
+
+    return _lib, ops
+
+
+def checksum(t):
+    return float(t.double().abs().sum())
+
+
+# ------------------------------------------------------------------------------------------------ conv
+def run_conv(dev, dtype, n, h, w, cin, cout, k, s, act=True, residual=False, ups=False, sliced=False, algo=0, seed=0, cin_real=None, cout_real=None):
+    """Returns (hip output NCHW fp32 cpu, reference NCHW fp32 cpu computed from the SAME rounded operands)."""
+    _lib, ops = _ops()
+    g = torch.Generator().manual_seed(seed)
+    cin_real = cin_real or cin
+    cout_real = cout_real or cout
+    x = torch.randn(n, cin_real, h, w, generator=g)
+    wt = torch.randn(cout_real, cin_real, k, k, generator=g) / math.sqrt(cin_real * k * k)
+    b = torch.randn(cout_real, generator=g) * 0.5
+    xq, wq = x.to(dtype).float(), wt.to(dtype).float()
+    ho, wo = (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
+    res = torch.randn(n, cout_real, ho, wo, generator=g).to(dtype).float() if residual else None
+    ref = F.conv2d(xq, wq, b, stride=s, padding=k // 2)
+    if act:
+        ref = F.silu(ref)
+    if residual:
+        ref = ref + res
+    if ups:
+        ref = F.interpolate(ref, scale_factor=2.0, mode="nearest")
+
+    xv = ops.View.alloc(n, h, w, cin, dtype, dev)
+    ops.nchw_to_nhwc(x.to(dev), xv)
+    filt = ops.pack_filter(wt.to(dev), cout, cin, dtype)
+    bias = torch.zeros(cout, device=dev)
+    bias[:cout_real] = b.to(dev)
+    up = 2 if ups else 1
+    if sliced:  # write into the middle of a wider buffer (zero-copy concat)
+        big = ops.View.alloc(n, ho * up, wo * up, cout + 24, dtype, dev)
+        big.buf.fill_(7.0)
+        yv = big.slice(16, cout)
+    else:
+        yv = ops.View.alloc(n, ho * up, wo * up, cout, dtype, dev)
+    rv = None
+    if residual:
+        rv = ops.View.alloc(n, ho, wo, cout, dtype, dev)
+        rv.buf.zero_()
+        ops.nchw_to_nhwc(res.to(dev), rv)
+    ops.conv2d(xv, filt, bias, yv, k, s, act, rv, ups, algo)
+    torch.cuda.synchronize()
+    out = yv.as_nhwc().float().cpu().permute(0, 3, 1, 2)[:, :cout_real]
+    if sliced:
+        full = big.as_nhwc().float().cpu()
+        assert torch.all(full[..., :16] == 7.0) and torch.all(full[..., 16 + cout :] == 7.0), "conv wrote outside its channel slice"
+    return out, ref
+
+
+CONV_CASES = [
+    # name, (n,h,w,cin,cout,k,s), kwargs
+    ("3x3s1_bk64_tc128", (2, 20, 20, 64, 128, 3, 1), {}),
+    ("3x3s2_bk64_tc128", (2, 23, 19, 128, 256, 3, 2), {}),
+    ("3x3s1_bk32_tc64", (1, 17, 33, 32, 64, 3, 1), {}),
+    ("3x3s2_bk32_tc64", (2, 32, 32, 32, 64, 3, 2), {}),
+    ("first_layer_cin3", (2, 40, 36, 8, 32, 3, 1), {"cin_real": 3}),
+    ("tiny_cin16", (2, 26, 26, 16, 32, 3, 1), {}),
+    ("tiny_first_cout16", (1, 32, 32, 8, 16, 3, 1), {"cin_real": 3}),
+    ("1x1_cout32", (2, 40, 40, 64, 32, 1, 1), {}),
+    ("1x1_cout64", (2, 20, 20, 128, 64, 1, 1), {}),
+    ("1x1_k1024", (2, 10, 10, 1024, 512, 1, 1), {}),
+    ("1x1_k768_concat_in", (1, 20, 20, 768, 256, 1, 1), {}),
+    ("head_255", (2, 20, 20, 256, 256, 1, 1), {"cout_real": 255, "act": False}),
+    ("residual", (2, 20, 20, 64, 128, 3, 1), {"residual": True}),
+    ("upsample_scatter", (2, 10, 10, 512, 256, 1, 1), {"ups": True}),
+    ("sliced_output", (2, 20, 20, 64, 128, 3, 1), {"sliced": True}),
+    ("big_k_3x3_512", (1, 20, 20, 512, 1024, 3, 1), {}),
+    ("partial_tiles", (1, 7, 5, 64, 136, 3, 1), {}),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name,shape,kw", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_mfma_vs_fp32_reference(dev, dtype, name, shape, kw):
+    out, ref = run_conv(dev, dtype, *shape, algo=1, **kw)
+    eps = 2.0**-10 if dtype == torch.float16 else 2.0**-7
+    err = (out - ref).abs()
+    tol = eps * ref.abs() + 2e-3 if dtype == torch.float16 else eps * ref.abs() + 1.5e-2
+    bad = (err > tol).sum().item()
+    assert bad == 0, f"{name} {dtype}: {bad}/{err.numel()} outside tolerance, max abs err {err.max():.4g}, ref max {ref.abs().max():.3g}"
+
+
+@pytest.mark.parametrize("name,shape,kw", CONV_CASES[:8], ids=[c[0] for c in CONV_CASES[:8]])
+def test_conv_direct_fp32_vs_reference(dev, name, shape, kw):
+    out, ref = run_conv(dev, torch.float32, *shape, algo=2, **kw)
+    err = (out - ref).abs().max().item()
+    assert err < 1e-4, f"{name}: max abs err {err:.3g}"  # fp32 path: north-star tolerance
+
+
+def test_conv_mfma_matches_direct_kernel(dev):
+    """same operands through both HIP kernels: identical up to fp32 summation order"""
+    a, _ = run_conv(dev, torch.float16, 2, 20, 20, 128, 256, 3, 1, algo=1)
+    b, _ = run_conv(dev, torch.float16, 2, 20, 20, 128, 256, 3, 1, algo=2)
+    assert (a - b).abs().max().item() <= 2.0**-9 * max(1.0, b.abs().max().item())
+
+
+# ------------------------------------------------------------------------------------------------ pooling / layout
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_layout_and_pool_kernels(dev, dtype):
+    _lib, ops = _ops()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 16, 13, 14, generator=g).to(dtype)
+    xv = ops.View.alloc(2, 13, 14, 16, dtype, dev)
+    ops.nchw_to_nhwc(x.to(dev), xv)
+    assert torch.equal(ops.nhwc_to_nchw(xv).cpu(), x)
+    # MaxPool2d(2,2,0)
+    yv = ops.View.alloc(2, 6, 7, 16, dtype, dev)
+    ops.maxpool2d(xv, yv, 2, 2, 0)
+    assert torch.equal(ops.nhwc_to_nchw(yv).cpu(), F.max_pool2d(x.float(), 2, 2, 0).to(dtype))
+    # ZeroPad2d([0,1,0,1]) + MaxPool2d(2,1,0)  (yolov3-tiny layers 11-12)
+    yv = ops.View.alloc(2, 13, 14, 16, dtype, dev)
+    ops.maxpool2d(xv, yv, 2, 1, 0, 1, 1)
+    assert torch.equal(ops.nhwc_to_nchw(yv).cpu(), F.max_pool2d(F.pad(x.float(), [0, 1, 0, 1]), 2, 1, 0).to(dtype))
+    # SPP pyramid into channel slices of a 4C buffer
+    cat = ops.View.alloc(2, 13, 14, 64, dtype, dev)
+    cat.buf.zero_()
+    ops.copy_slice(xv, cat.slice(0, 16))
+    ops.spp_pyramid(cat.slice(0, 16), cat.slice(16, 48))
+    ref = torch.cat([x.float()] + [F.max_pool2d(x.float(), k, 1, k // 2) for k in (5, 9, 13)], 1).to(dtype)
+    assert torch.equal(ops.nhwc_to_nchw(cat).cpu(), ref)
+    # nearest x2
+    uv = ops.View.alloc(2, 26, 28, 16, dtype, dev)
+    ops.upsample2x(xv, uv)
+    assert torch.equal(ops.nhwc_to_nchw(uv).cpu(), F.interpolate(x.float(), scale_factor=2.0, mode="nearest").to(dtype))
+    # uint8 ingest with /255 in the output dtype (val.py:358-359)
+    u8 = torch.randint(0, 256, (2, 3, 9, 11), generator=g, dtype=torch.uint8)
+    iv = ops.View.alloc(2, 9, 11, 8, dtype, dev)
+    ops.nchw_to_nhwc(u8.to(dev), iv, 255.0)
+    got = ops.nhwc_to_nchw(iv).cpu()
+    ref = u8.to(dtype) / 255
+    assert torch.equal(got[:, :3], ref) and torch.all(got[:, 3:] == 0)
+
+
+# ------------------------------------------------------------------------------------------------ decode
+@pytest.mark.parametrize("key,dtype,nc", [("nc80-float32", torch.float32, 80), ("nc80-float16", torch.float16, 80), ("nc3-float16", torch.float16, 3)])
+def test_detect_decode_vs_reference_golden(dev, golden_dir, key, dtype, nc):
+    from yolov3_amd import Detect
+
+    gold = torch.load(golden_dir / "decode.pt")[key]
+    no = nc + 5
+    g = torch.Generator().manual_seed(21)
+    xs = [torch.randn(2, 3 * no, s, s + 1, generator=g) * 2.0 for s in gold["sizes"]]
+    anchors = [[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]
+    det = Detect(nc, anchors, ch=(3 * no,) * 3)
+    det.stride = torch.tensor([8.0, 16.0, 32.0])
+    det.anchors /= det.stride.view(-1, 1, 1)
+    for conv in det.m:  # identity head so the decode sees exactly the seeded maps
+        conv.weight.data = torch.eye(3 * no).view(3 * no, 3 * no, 1, 1)
+        conv.bias.data.zero_()
+    det = det.to(dev).to(dtype).eval()
+    z, raw = det([x.to(dev).to(dtype) for x in xs])
+    torch.cuda.synchronize()
+    zc, ref = z.float().cpu(), gold["z"].float()
+    assert z.dtype == gold["z"].dtype and zc.shape == ref.shape
+    for r, x in zip(raw, xs):
+        exp = x.to(dtype).view(2, 3, no, x.shape[2], x.shape[3]).permute(0, 1, 3, 4, 2)
+        assert torch.equal(r.cpu(), exp), "raw (bs,na,ny,nx,no) layout mismatch"
+    if dtype == torch.float32:
+        # sigmoid differs by <= 2 ulp between libm implementations; everything else is exact
+        torch.testing.assert_close(zc, ref, rtol=3e-6, atol=1e-6)
+    else:
+        # every op is rounded through fp16 like torch does; a 1-ulp sigmoid difference may flip a rounding
+        ulp = torch.maximum(ref.abs(), torch.tensor(2.0**-14)) * 2.0**-10
+        diff = (zc - ref).abs()
+        assert (diff > 2 * ulp).sum().item() == 0, f"max diff {diff.max()}"
+        assert (diff > 0).float().mean().item() < 2e-3, "too many fp16 rounding flips"
+
+
+# ------------------------------------------------------------------------------------------------ NMS
+def _cmp_nms(res, gold, what=""):
+    assert len(res) == len(gold)
+    for i, (a, b) in enumerate(zip(res, gold)):
+        a = a.float().cpu()
+        assert a.shape == b.shape, f"{what} image {i}: {tuple(a.shape)} vs {tuple(b.shape)}"
+        assert torch.equal(a, b.float()), f"{what} image {i}: rows differ (first bad row {(a != b.float()).any(1).nonzero()[:1].tolist()})"
+
+
+def test_nms_known_answer(dev, golden_dir):
+    from yolov3_amd import non_max_suppression
+
+    gold = torch.load(golden_dir / "nms.pt")
+    p = torch.tensor(
+        [[[50, 50, 20, 20, 0.9, 0.9, 0.5, 0.0], [200, 200, 30, 30, 0.8, 0.1, 0.2, 0.95], [52, 51, 20, 20, 0.7, 0.8, 0.6, 0.0], [400, 400, 10, 10, 0.0005, 0.9, 0.9, 0.9]]]
+    ).to(dev)
+    _cmp_nms(non_max_suppression(p, 0.001, 0.6, multi_label=True), gold["kat_val"], "kat_val")
+    _cmp_nms(non_max_suppression(p, 0.25, 0.45), gold["kat_det"], "kat_det")
+    _cmp_nms(non_max_suppression(p, 0.25, 0.45, classes=[2]), gold["kat_cls2"], "kat_cls2")
+    _cmp_nms(non_max_suppression(p, 0.25, 0.45, agnostic=True), gold["kat_agn"], "kat_agn")
+    _cmp_nms(non_max_suppression((p, [None]), 0.25, 0.45), gold["kat_det"], "tuple input")
+    with pytest.raises(AssertionError, match="Invalid Confidence threshold"):
+        non_max_suppression(p, 1.5, 0.45)
+    with pytest.raises(AssertionError, match="Invalid IoU"):
+        non_max_suppression(p, 0.5, -0.1)
+
+
+NMS_CASES = ["val_fp32", "det_fp32", "det_agnostic", "det_classes", "val_nc3_maxdet", "single_class", "det_fp16", "all_filtered"]
+
+
+@pytest.mark.parametrize("name", NMS_CASES)
+def test_nms_vs_reference_golden(dev, golden_dir, name):
+    from yolov3_amd import non_max_suppression
+
+    rec = torch.load(golden_dir / "nms.pt")[name]
+    gk = dict(rec["gen"])
+    if "dtype" in gk:
+        gk["dtype"] = getattr(torch, gk["dtype"].split(".")[-1])
+    pred = yo.synth_predictions(**gk)
+    assert checksum(pred) == rec["in_sum"]
+    before = pred.clone()
+    res = non_max_suppression(pred.to(dev), **rec["nms"])
+    _cmp_nms(res, rec["out"], name)
+    assert torch.equal(pred, before)
+    assert all(r.dtype == torch.float32 and r.device.type == "cuda" for r in res)
+
+
+def test_nms_labels_vs_reference_golden(dev, golden_dir):
+    from yolov3_amd import non_max_suppression
+
+    rec = torch.load(golden_dir / "nms.pt")["labels"]
+    pred = yo.synth_predictions(bs=2, n_rows=800, nc=80, seed=10)
+    _cmp_nms(non_max_suppression(pred.to(dev), 0.25, 0.45, labels=rec["lb"]), rec["out"], "labels")
+
+
+@pytest.mark.parametrize(
+    "gen,kw",
+    [
+        (dict(bs=4, n_rows=25200, nc=80, seed=12), dict(conf_thres=0.001, iou_thres=0.6, multi_label=True, max_det=300)),  # val.py:374 regime, full size
+        (dict(bs=4, n_rows=25200, nc=80, seed=13), dict(conf_thres=0.25, iou_thres=0.45, max_det=1000)),  # detect.py:200 regime
+        (dict(bs=2, n_rows=25200, nc=80, seed=14, dtype=torch.float16, hits=0.002), dict(conf_thres=0.25, iou_thres=0.45)),
+        (dict(bs=2, n_rows=6000, nc=80, seed=15, hits=0.5), dict(conf_thres=0.001, iou_thres=0.6, multi_label=True, agnostic=True)),
+        (dict(bs=2, n_rows=100800, nc=365, seed=16, hits=0.01), dict(conf_thres=0.01, iou_thres=0.6, multi_label=True)),  # config 5 head
+    ],
+    ids=["val_full", "detect_full", "detect_fp16", "agnostic_dense", "objects365_1280"],
+)
+def test_nms_vs_oracle_full_size(dev, gen, kw):
+    from yolov3_amd import non_max_suppression
+
+    pred = yo.synth_predictions(**gen)
+    if pred.dtype == torch.float16:  # ties make the reference undefined; the oracle uses the same stable order we do
+        pass
+    ref = yo.non_max_suppression(pred, **kw)
+    res = non_max_suppression(pred.to(dev), **kw)
+    _cmp_nms(res, ref, str(kw))
+
+
+def test_nms_capacity_overflow_retry_and_big_boxes(dev):
+    """(a) > default capacity candidates -> the adapter re-runs with a larger workspace, result still exact;
+    (b) boxes wider than max_wh/2 disable per-class partitioning (cross-class overlap is possible) -> same answer
+    as the oracle's single global NMS; (c) > max_nms candidates are cut in score order."""
+    from yolov3_amd import non_max_suppression
+
+    g = torch.Generator().manual_seed(3)
+    pred = torch.rand(1, 3000, 25, generator=g)
+    pred[..., :2] *= 600
+    pred[..., 2:4] *= 80
+    pred[..., 4] = 0.5 + 0.5 * pred[..., 4]
+    kw = dict(conf_thres=0.001, iou_thres=0.6, multi_label=True, max_det=300)  # 3000*20 = 60k candidates > 16384 and > max_nms
+    _cmp_nms(non_max_suppression(pred.to(dev), **kw), yo.non_max_suppression(pred, **kw), "overflow")
+    big = pred[:, :400].clone()
+    big[0, :50, 2:4] = 9000.0  # spans several class offsets
+    kw = dict(conf_thres=0.3, iou_thres=0.2, multi_label=True, max_det=300)
+    _cmp_nms(non_max_suppression(big.to(dev), **kw), yo.non_max_suppression(big, **kw), "big boxes")
+
+
+def test_nms_properties(dev):
+    """size-independent properties: idempotence (NMS of survivors keeps them all), score order, max_det cap"""
+    from yolov3_amd import non_max_suppression
+
+    pred = yo.synth_predictions(bs=8, n_rows=25200, nc=80, seed=33).to(dev)
+    out = non_max_suppression(pred, 0.25, 0.45, max_det=300)
+    for o in out:
+        assert o.shape[0] <= 300 and o.shape[1] == 6
+        assert torch.all(o[1:, 4] <= o[:-1, 4]), "not in descending score order"
+        if o.shape[0]:
+            # rebuild a prediction tensor from the survivors: nothing more may be suppressed
+            n = o.shape[0]
+            p2 = torch.zeros(1, n, 85, device=dev)
+            p2[0, :, 0] = (o[:, 0] + o[:, 2]) / 2
+            p2[0, :, 1] = (o[:, 1] + o[:, 3]) / 2
+            p2[0, :, 2] = o[:, 2] - o[:, 0]
+            p2[0, :, 3] = o[:, 3] - o[:, 1]
+            p2[0, :, 4] = 1.0
+            p2[0, torch.arange(n), 5 + o[:, 5].long()] = o[:, 4]
+            again = non_max_suppression(p2, 0.25, 0.45, max_det=300)[0]
+            assert again.shape[0] == n, f"idempotence: {n} -> {again.shape[0]}"
+
+
+# ------------------------------------------------------------------------------------------------ full model
+def build_pair(name, nc, seed, dev, dtype):
+    from yolov3_amd import DetectionModel
+
+    d = yaml.safe_load(open(CFG / f"{name}.yaml"))
+    layers, save, anchors, nc_v = yo.parse_cfg(d, 3, nc)
+    strides = yo.model_strides(layers)
+    sd = yo.seeded_state_dict(layers, nc_v, anchors, strides, seed=seed)
+    m = DetectionModel(f"{name}.yaml", nc=nc)
+    m.load_state_dict(sd)
+    m = m.to(dev).to(dtype).eval()
+    return m, (layers, save, sd, strides)
+
+
+@pytest.mark.parametrize("key", ["yolov3-tiny-nc80-64-bs2", "yolov3-nc80-64-bs2", "yolov3-spp-nc80-64-bs1", "yolov3-nc7-96-bs1"])
+def test_model_fp32_vs_reference_golden(dev, golden_dir, key):
+    """fp32 engine (direct HIP kernels) against the UNMODIFIED reference's eval output: 1e-4 on raw logits,
+    1e-4 relative on decoded boxes (north_star tolerance)."""
+    gold = torch.load(golden_dir / "model_fwd.pt")[key]
+    name, nc, hw, bs = key.rsplit("-", 3)
+    nc, hw, bs = int(nc[2:]), int(hw), int(bs[2:])
+    m, _ = build_pair(name, nc, 11, dev, torch.float32)
+    x = torch.rand(bs, 3, hw, hw, generator=torch.Generator().manual_seed(5))
+    assert checksum(x) == gold["x_sum"]
+    pred, raw = m(x.to(dev))
+    torch.cuda.synchronize()
+    for a, b in zip(raw, gold["eval_raw"]):
+        err = (a.cpu() - b).abs().max().item()
+        assert err < 1e-4, f"{key}: raw logits max abs err {err:.3g}"
+    torch.testing.assert_close(pred.cpu(), gold["eval_pred"], rtol=1e-4, atol=1e-4)
+    m.fuse()
+    predf, _ = m(x.to(dev))
+    torch.testing.assert_close(predf.cpu(), gold["fused_pred"], rtol=1e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("name,hw,bs,dtype", [("yolov3-tiny", 416, 4, torch.float16), ("yolov3", 128, 2, torch.float16), ("yolov3-spp", 128, 2, torch.float16), ("yolov3", 128, 2, torch.bfloat16)])
+def test_model_half_vs_fp32_oracle(dev, name, hw, bs, dtype):
+    """MFMA engine (fp16/bf16 storage, fp32 accumulate) against the fp32 CPU oracle with the same weights.
+    75 layers of half-precision storage rounding: compare raw logits with a tolerance relative to the logit scale."""
+    m, (layers, save, sd, strides) = build_pair(name, 80, 21, dev, dtype)
+    x = torch.rand(bs, 3, hw, hw, generator=torch.Generator().manual_seed(6))
+    pred, raw = m(x.to(dev))
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        refp, refraw = yo.forward(layers, save, sd, x, strides, training=False)
+    tol = 0.03 if dtype == torch.float16 else 0.25
+    for a, b in zip(raw, refraw):
+        a = a.float().cpu()
+        rel = (a - b).abs().max().item() / b.abs().max().item()
+        assert rel < tol, f"{name} {dtype}: raw logits rel-to-max err {rel:.4f}"
+        corr = torch.corrcoef(torch.stack((a.flatten(), b.flatten())))[0, 1].item()
+        assert corr > (0.9995 if dtype == torch.float16 else 0.99), f"correlation {corr}"
+    assert pred.shape == refp.shape and pred.dtype == dtype
+
+
+def test_end_to_end_detections_fp32(dev):
+    """fp32 engine forward + HIP NMS == oracle forward + oracle NMS on the HIP prediction tensor (index-exact),
+    and close to the all-oracle pipeline."""
+    from yolov3_amd import non_max_suppression
+
+    m, (layers, save, sd, strides) = build_pair("yolov3-tiny", 80, 23, dev, torch.float32)
+    x = torch.rand(2, 3, 160, 160, generator=torch.Generator().manual_seed(7))
+    pred, _ = m(x.to(dev))
+    res = non_max_suppression(pred, 0.001, 0.6, multi_label=True)
+    ref = yo.non_max_suppression(pred.cpu(), 0.001, 0.6, multi_label=True)
+    _cmp_nms(res, ref, "e2e")

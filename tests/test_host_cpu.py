@@ -1,0 +1,125 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol include/yolov3_hip.h declares,
+argument validation fails loudly without touching a GPU, the module mirror keeps the reference's state_dict
+layout, and the multi-process replica helpers work (gloo, world_size 2)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from yolov3_amd import _lib, build
+
+    build.build(verbose=False)
+    return _lib.lib()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from yolov3_amd import _lib
+
+    header = (ROOT / "include" / "yolov3_hip.h").read_text()
+    declared = set(re.findall(r"\b(y3_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
+    nm = subprocess.check_output(["nm", "-D", "--defined-only", str(_lib.LIB_PATH)], text=True)
+    exported = set(re.findall(r" T (y3_[a-z0-9_]+)", nm))
+    assert declared <= exported, declared - exported
+    assert lib.y3_abi_version() == 1
+
+
+def test_argument_validation_is_loud_and_gpu_free(lib):
+    from yolov3_amd import _lib
+
+    d = _lib.Y3ConvDesc(_lib.Y3_F16, 5, 1, 1, 0, 0, 64, 64)
+    t = _lib.Y3Tensor(1 << 20, 1, 8, 8, 64, 64)
+    assert lib.y3_conv2d_fwd(C.byref(d), C.byref(t), 1 << 20, 1 << 20, None, C.byref(t), None) != 0
+    assert b"ksize 5" in lib.y3_last_error()
+    d.ksize = 3
+    t2 = _lib.Y3Tensor(1 << 20, 1, 8, 8, 32, 32)
+    assert lib.y3_conv2d_fwd(C.byref(d), C.byref(t2), 1 << 20, 1 << 20, None, C.byref(t), None) != 0
+    assert b"channels" in lib.y3_last_error()
+    p = _lib.Y3NmsParams(0.6, 1.5, 1, 0, 300, 30000, 7680.0, 0)
+    assert lib.y3_nms(1 << 20, 0, 1, 10, 80, C.byref(p), None, 1 << 20, 1 << 20, 1 << 20, 0, 1 << 20, 1 << 20, None) != 0
+    assert b"Invalid Confidence threshold" in lib.y3_last_error()
+    assert lib.y3_packed_filter_elems(255, 1024, 1) == 256 * 1024
+    assert lib.y3_packed_filter_elems(32, 8, 3) == 128 * 128
+    p = _lib.Y3NmsParams(0.6, 0.001, 1, 0, 300, 30000, 7680.0, 0)
+    assert lib.y3_nms_workspace_bytes(32, 25200, 80, C.byref(p), 0) > 32 * 16384 * 60
+
+
+def test_product_path_rejects_cpu_tensors():
+    from yolov3_amd import DetectionModel, non_max_suppression
+
+    m = DetectionModel("yolov3-tiny.yaml").eval()
+    with pytest.raises(RuntimeError, match="no CPU"):
+        m(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(RuntimeError, match="no CPU"):
+        non_max_suppression(torch.zeros(1, 10, 85))
+    with pytest.raises(AssertionError, match="Invalid IoU"):
+        non_max_suppression(torch.zeros(1, 10, 85), 0.5, 1.5)
+
+
+def test_product_never_imports_the_oracle():
+    code = "import sys; import yolov3_amd, yolov3_amd.engine, yolov3_amd.general, yolov3_amd.parallel; assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules), 'oracle imported'"
+    subprocess.check_call([sys.executable, "-c", code], cwd=ROOT)
+    for f in (ROOT / "yolov3_amd").glob("*.py"):
+        assert "oracle" not in f.read_text().replace("# oracle", ""), f
+
+
+def test_state_dict_layout_matches_reference_keys(golden_dir):
+    """keys/shapes must equal the reference's: checked against the oracle's seeded state dict, which
+    tests/golden/make_golden.py loads strict=True into the unmodified reference model."""
+    import yaml
+    from oracle import yolo_oracle as yo
+    from yolov3_amd import DetectionModel
+
+    for name, npar in [("yolov3", 61949149), ("yolov3-spp", 62998749), ("yolov3-tiny", 8852366)]:
+        m = DetectionModel(f"{name}.yaml")
+        assert sum(p.numel() for p in m.parameters()) == npar
+        d = yaml.safe_load(open(ROOT / "yolov3_amd" / "cfg" / f"{name}.yaml"))
+        layers, save, anchors, nc = yo.parse_cfg(d)
+        sd = yo.seeded_state_dict(layers, nc, anchors, yo.model_strides(layers), seed=0)
+        own = m.state_dict()
+        assert set(own) == set(sd)
+        assert all(own[k].shape == sd[k].shape for k in sd)
+        assert m.save == save
+    m = DetectionModel("yolov3.yaml", nc=365)
+    assert m.model[-1].no == 370 and m.model[-1].m[0].out_channels == 1110
+    assert m.stride.tolist() == [8.0, 16.0, 32.0]
+    assert torch.allclose(m.model[-1].anchors[0, 0], torch.tensor([10 / 8, 13 / 8]))
+    bn = next(x for x in m.modules() if isinstance(x, torch.nn.BatchNorm2d))
+    assert bn.eps == 1e-3 and bn.momentum == 0.03
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, str(ROOT))
+    from yolov3_amd import parallel
+
+    r, lr, w = parallel.init("gloo")
+    parallel.barrier()
+    mx = parallel.max_over_ranks(1.0 + r)
+    lo, hi = parallel.shard_range(65, r, w)
+    q.put((r, w, mx, lo, hi))
+    parallel.finalize()
+
+
+def test_replica_helpers_world2_gloo():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    [p.join(60) for p in procs]
+    assert [r[:3] for r in res] == [(0, 2, 2.0), (1, 2, 2.0)]
+    assert (res[0][3], res[0][4], res[1][3], res[1][4]) == (0, 33, 33, 65)

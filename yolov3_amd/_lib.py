@@ -61,7 +61,7 @@ _SIGNATURES = {
     "y3_nms_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, _P(Y3NmsParams), C.c_int64]),
     "y3_nms": (
         C.c_int,
-        [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P(Y3NmsParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p],
+        [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P(Y3NmsParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p],
     ),
 }
 

@@ -96,7 +96,7 @@ Y3_DEV bool class_allowed(int c, const int* __restrict__ classes, int ncf) {
 // One wave per 64 consecutive anchor rows of one image.  MODE 0 = count, MODE 1 = emit.
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void nms_candidates_kernel(const T* __restrict__ pred, int bs, int n_rows, int nc, float thr, int multi_label,
-                                                               const int* __restrict__ classes, int ncf, NmsWs ws, int* __restrict__ status) {
+                                                               const int* __restrict__ classes, int ncf, NmsWs ws, int* __restrict__ status, int ord_shift) {
     const int lane = threadIdx.x & 63;
     const int chunks_per_img = (n_rows + 63) / 64;
     const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const T* __restrict
                     const int k = cnt + __builtin_popcountll(m & ((1ull << lane) - 1ull));
                     const long long g = (long long)off + k;
                     if (g < ws.cap) {
-                        const unsigned ord = (unsigned)(g - img_off0);
+                        const unsigned ord = (unsigned)((g - img_off0) >> ord_shift);
                         ws.cbox[g] = box;
                         ws.cscore[g] = conf;
                         ws.ccls[g] = c;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const T* __restrict
             if (MODE == 1 && ok && lane == 0) {
                 const long long g = off;
                 if (g < ws.cap) {
-                    const unsigned ord = (unsigned)(g - img_off0);
+                    const unsigned ord = (unsigned)((g - img_off0) >> ord_shift);
                     ws.cbox[g] = box;
                     ws.cscore[g] = best;
                     ws.ccls[g] = bi;
@@ -381,24 +381,24 @@ size_t carve(NmsWs& ws, unsigned char* base, int bs, long long cap, size_t scan_
 
 template <typename T>
 int run_nms(const void* pred, int bs, int n_rows, int nc, const y3_nms_params* p, const int* classes, float* out_rows, int* out_counts, int* out_status,
-            void* workspace, size_t workspace_bytes, hipStream_t st) {
+            long long capacity, void* workspace, size_t workspace_bytes, hipStream_t st) {
     const size_t scan_n = (size_t)bs * n_rows;
-    // capacity: the default one, or as large as the given workspace allows (the host grows it after an overflow)
-    long long cap = default_capacity(bs, n_rows, nc, p);
-    NmsWs ws;
-    if (carve(ws, nullptr, bs, cap, scan_n) > workspace_bytes) Y3_FAIL("y3_nms: workspace too small (%zu bytes given)", workspace_bytes);
+    long long cap = capacity > 0 ? capacity : default_capacity(bs, n_rows, nc, p);
     const long long worst = worst_capacity(bs, n_rows, nc, p);
-    while (cap < worst) {
-        const long long c2 = cap * 2 > worst ? worst : cap * 2;
-        if (carve(ws, nullptr, bs, c2, scan_n) > workspace_bytes) break;
-        cap = c2;
-    }
+    if (cap > worst) cap = worst;
+    if (cap < 1024) cap = 1024;
+    NmsWs ws;
+    const size_t need = carve(ws, nullptr, bs, cap, scan_n);
+    if (need > workspace_bytes) Y3_FAIL("y3_nms: workspace too small (%zu bytes given, %zu needed for capacity %lld)", workspace_bytes, need, cap);
     if (cap > 0x7ffffff0LL) Y3_FAIL("y3_nms: capacity too large");
     carve(ws, (unsigned char*)workspace, bs, cap, scan_n);
 
     const float thr = (float)(T)(p->conf_thres);              // python scalar -> tensor dtype before the compare
     const int multi = (p->multi_label && nc > 1) ? 1 : 0;       // multi_label &= nc > 1   (utils/general.py:677)
     const int ncf = classes ? p->n_classes_filter : 0;
+    // tie-break ordinal (nonzero order) must fit ORD_BITS; coarser buckets fall back to the radix sort's stability
+    int ord_shift = 0;
+    while ((((long long)n_rows * (multi ? nc : 1)) >> ord_shift) >= (1ll << ORD_BITS)) ++ord_shift;
     const bool one_seg = p->agnostic != 0;
     const int nseg = one_seg ? 1 : nc;
 
@@ -409,11 +409,11 @@ int run_nms(const void* pred, int bs, int n_rows, int nc, const y3_nms_params* p
 
     const long long waves = (long long)bs * ((n_rows + 63) / 64);
     const unsigned cblocks = (unsigned)((waves + 3) / 4);
-    hipLaunchKernelGGL((nms_candidates_kernel<T, 0>), dim3(cblocks), dim3(256), 0, st, (const T*)pred, bs, n_rows, nc, thr, multi, classes, ncf, ws, out_status);
+    hipLaunchKernelGGL((nms_candidates_kernel<T, 0>), dim3(cblocks), dim3(256), 0, st, (const T*)pred, bs, n_rows, nc, thr, multi, classes, ncf, ws, out_status, ord_shift);
     Y3_CHECK_LAUNCH();
     size_t tb = ws.tmp_bytes;
     if (rocprim::exclusive_scan(ws.tmp, tb, ws.row_count, ws.row_off, 0, scan_n + 1, rocprim::plus<int>(), st) != hipSuccess) Y3_FAIL("y3_nms: scan failed");
-    hipLaunchKernelGGL((nms_candidates_kernel<T, 1>), dim3(cblocks), dim3(256), 0, st, (const T*)pred, bs, n_rows, nc, thr, multi, classes, ncf, ws, out_status);
+    hipLaunchKernelGGL((nms_candidates_kernel<T, 1>), dim3(cblocks), dim3(256), 0, st, (const T*)pred, bs, n_rows, nc, thr, multi, classes, ncf, ws, out_status, ord_shift);
     Y3_CHECK_LAUNCH();
     tb = ws.tmp_bytes;
     if (rocprim::radix_sort_pairs(ws.tmp, tb, ws.key_a, ws.key_b, ws.val_a, ws.val_b, (size_t)cap, 0u, 64u, st) != hipSuccess) Y3_FAIL("y3_nms: sort-1 failed");
@@ -445,21 +445,20 @@ extern "C" size_t y3_nms_workspace_bytes(int32_t bs, int32_t n_rows, int32_t nc,
 }
 
 extern "C" int y3_nms(const void* pred, int32_t dtype, int32_t bs, int32_t n_rows, int32_t nc, const y3_nms_params* p, const int32_t* classes, float* out_rows,
-                      int32_t* out_counts, int32_t* out_status, void* workspace, size_t workspace_bytes, void* stream) {
+                      int32_t* out_counts, int32_t* out_status, int64_t capacity, void* workspace, size_t workspace_bytes, void* stream) {
     if (!pred || !p || !out_rows || !out_counts || !out_status || !workspace) Y3_FAIL("y3_nms: null argument");
     if (!(p->conf_thres >= 0.0f && p->conf_thres <= 1.0f)) Y3_FAIL("Invalid Confidence threshold %g, valid values are between 0.0 and 1.0", (double)p->conf_thres);
     if (!(p->iou_thres >= 0.0 && p->iou_thres <= 1.0)) Y3_FAIL("Invalid IoU %g, valid values are between 0.0 and 1.0", p->iou_thres);
     if (bs <= 0 || bs >= (1 << IMG_BITS) - 1) Y3_FAIL("y3_nms: batch size %d unsupported (max %d)", bs, (1 << IMG_BITS) - 2);
     if (nc <= 0 || nc >= (1 << CLS_BITS)) Y3_FAIL("y3_nms: class count %d unsupported", nc);
     if (p->max_nms <= 0 || p->max_nms > (1 << RANK_BITS) - 1) Y3_FAIL("y3_nms: max_nms %d unsupported (max %d)", p->max_nms, (1 << RANK_BITS) - 1);
-    if ((long long)n_rows * (p->multi_label ? nc : 1) >= (1ll << ORD_BITS)) Y3_FAIL("y3_nms: too many candidate slots per image");
     if ((long long)bs * n_rows >= 0x7fffffffLL) Y3_FAIL("y3_nms: too many rows");
     if (p->max_det <= 0) Y3_FAIL("y3_nms: max_det must be positive");
     hipStream_t st = (hipStream_t)stream;
     switch (dtype) {
-        case Y3_F16: return run_nms<f16_t>(pred, bs, n_rows, nc, p, classes, out_rows, out_counts, out_status, workspace, workspace_bytes, st);
-        case Y3_BF16: return run_nms<bf16_t>(pred, bs, n_rows, nc, p, classes, out_rows, out_counts, out_status, workspace, workspace_bytes, st);
-        case Y3_F32: return run_nms<float>(pred, bs, n_rows, nc, p, classes, out_rows, out_counts, out_status, workspace, workspace_bytes, st);
+        case Y3_F16: return run_nms<f16_t>(pred, bs, n_rows, nc, p, classes, out_rows, out_counts, out_status, capacity, workspace, workspace_bytes, st);
+        case Y3_BF16: return run_nms<bf16_t>(pred, bs, n_rows, nc, p, classes, out_rows, out_counts, out_status, capacity, workspace, workspace_bytes, st);
+        case Y3_F32: return run_nms<float>(pred, bs, n_rows, nc, p, classes, out_rows, out_counts, out_status, capacity, workspace, workspace_bytes, st);
     }
     Y3_FAIL("y3_nms: bad dtype %d", dtype);
 }

@@ -1,0 +1,583 @@
+"""Static execution plans for the YOLOv3 graph on MI355X.
+
+The reference walks ``nn.Sequential`` module by module (models/yolo.py:135-147) and lets ATen launch ~220
+kernels per forward with NCHW tensors, separate BN/SiLU passes, ``torch.cat`` and ``nn.Upsample`` copies.
+Here the graph is compiled ONCE per (batch, height, width, dtype) into a flat list of C-ABI launches over
+pre-planned NHWC buffers:
+
+* Conv+BN+SiLU(+residual) is one kernel (BN folded into the packed filter / bias at plan time, fp32 fold);
+* ``Concat`` is zero-copy: producers write into channel slices of the destination buffer;
+* ``nn.Upsample`` disappears: the producing 1x1 conv scatters each pixel to its 2x2 block of the concat slice;
+* ``ZeroPad2d`` + ``MaxPool2d(2,1)`` (yolov3-tiny) is one pooling launch; SPP's three pools are one launch;
+* activation buffers are recycled by lifetime so the working set stays inside the 256 MiB Infinity Cache as
+  far as possible; weights are packed once and stay resident in HBM.
+
+torch is used for device memory and the current stream only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+from dataclasses import dataclass, field
+
+import torch
+from torch import nn
+
+from . import _lib, ops
+from ._lib import Y3ConvDesc, Y3Tensor
+from .common import SPP, Bottleneck, Concat, Conv, MaxPool2d, Upsample, ZeroPad2d
+
+
+# ------------------------------------------------------------------------------------------- shape bookkeeping
+def _conv_hw(hw, k, s):
+    p = k // 2
+    return tuple((v + 2 * p - k) // s + 1 for v in hw)
+
+
+def _sources(i, f):
+    fl = [f] if isinstance(f, int) else list(f)
+    return [i + j if j < 0 else j for j in fl]
+
+
+def graph_hw(model, h, w):
+    """(h, w) of every top-level layer output for an (h, w) input (the reference finds strides by a dry run,
+    models/yolo.py:219-222)."""
+    sizes = []
+    for i, m in enumerate(model.model):
+        src = _sources(i, m.f)
+        hw = (h, w) if src[0] < 0 else sizes[src[0]]
+        mm = m[0] if isinstance(m, nn.Sequential) else m
+        if isinstance(mm, Conv):
+            hw = _conv_hw(hw, mm.conv.kernel_size[0], mm.conv.stride[0])
+        elif isinstance(mm, Upsample):
+            hw = (hw[0] * 2, hw[1] * 2)
+        elif isinstance(mm, MaxPool2d):
+            k, s, p = mm.kernel_size, mm.stride, mm.padding
+            hw = tuple((v + 2 * p - k) // s + 1 for v in hw)
+        elif isinstance(mm, ZeroPad2d):
+            l, r, t, b = mm.padding
+            hw = (hw[0] + t + b, hw[1] + l + r)
+        sizes.append(hw)
+    return sizes
+
+
+def _out_channels(m):
+    mm = m[-1] if isinstance(m, nn.Sequential) else m
+    if isinstance(mm, Conv):
+        return mm.conv.out_channels
+    if isinstance(mm, Bottleneck):
+        return mm.cv2.conv.out_channels
+    if isinstance(mm, SPP):
+        return mm.cv2.conv.out_channels
+    return None
+
+
+# ------------------------------------------------------------------------------------------- symbolic buffers
+class Buf:
+    """A flat activation buffer with a lifetime [first, last] in op indices; storage is assigned at finalize."""
+
+    def __init__(self, numel, name=""):
+        self.numel, self.name = int(numel), name
+        self.first, self.last = None, None
+        self.tensor = None
+
+    def touch(self, t):
+        if self.first is None:
+            self.first = t
+        self.last = t
+
+
+@dataclass
+class SView:
+    buf: Buf
+    n: int
+    h: int
+    w: int
+    c: int
+    pitch: int
+    coff: int = 0
+
+    def slice(self, coff, c):
+        return SView(self.buf, self.n, self.h, self.w, c, self.pitch, self.coff + coff)
+
+    def real(self) -> ops.View:
+        return ops.View(self.buf.tensor, self.n, self.h, self.w, self.c, self.pitch, self.coff)
+
+
+def _pad8(c):
+    return (c + 7) // 8 * 8
+
+
+# ------------------------------------------------------------------------------------------- weights
+class ConvWeights:
+    """Packed filter bank + fp32 bias of one (fused) convolution, resident on the device."""
+
+    def __init__(self, filt, bias, cin, cout, k, s, act):
+        self.filt, self.bias, self.cin, self.cout, self.k, self.s, self.act = filt, bias, cin, cout, k, s, act
+
+
+def _fold(conv: nn.Conv2d, bn):
+    """fp32 (weight OIHW, bias) of conv(+bn): the algebra of upstream fuse_conv_and_bn (reference models/yolo.py:168),
+    evaluated on the device at plan time."""
+    w = conv.weight.detach().float()
+    b = conv.bias.detach().float() if conv.bias is not None else torch.zeros(w.shape[0], device=w.device)
+    if bn is not None:
+        scale = bn.weight.detach().float().div(torch.sqrt(bn.eps + bn.running_var.float()))
+        w = torch.mm(torch.diag(scale), w.view(w.shape[0], -1)).view(w.shape)
+        b_bn = bn.bias.detach().float() - bn.weight.detach().float().mul(bn.running_mean.float()).div(torch.sqrt(bn.running_var.float() + bn.eps))
+        b = torch.mm(torch.diag(scale), b.reshape(-1, 1)).reshape(-1) + b_bn
+    return w, b
+
+
+KEEP_FOLDED = False  # tests set this to keep the fp32 folded (w, b) next to the packed bank
+
+
+def make_conv_weights(conv: nn.Conv2d, bn, act: bool, dtype, cin_pad=None) -> ConvWeights:
+    w, b = _fold(conv, bn)
+    co, ci, k, _ = w.shape
+    cin = cin_pad or _pad8(ci)
+    cout = _pad8(co)
+    filt = ops.pack_filter(w, cout, cin, dtype)
+    bias = torch.zeros(cout, dtype=torch.float32, device=w.device)
+    bias[:co] = b
+    cw = ConvWeights(filt, bias, cin, cout, k, conv.stride[0], act)
+    if KEEP_FOLDED:
+        cw.folded = (w, b)
+    return cw
+
+
+# ------------------------------------------------------------------------------------------- plan
+@dataclass
+class _Launch:
+    fn: object
+    args: tuple
+    keep: tuple = ()  # python objects that must outlive the launch (ctypes structs, tensors)
+    label: str = ""
+    flops: float = 0.0
+    bytes: float = 0.0
+
+
+class Plan:
+    """Compiled forward for fixed (N, H, W, dtype).  ``run`` issues the launches on the current stream."""
+
+    def __init__(self, device, dtype, n, h, w):
+        self.device, self.dtype, self.n, self.h, self.w = device, dtype, n, h, w
+        self.bufs: list[Buf] = []
+        self.steps: list = []  # (kind, payload) symbolic until finalize
+        self.launches: list[_Launch] = []
+        self.detect = None
+        self.input_view = None
+        self.out_views: dict = {}
+        self.param_refs = []
+        self.param_version = 0
+
+    # -- building -----------------------------------------------------------------------------
+    def new_buf(self, n, h, w, pitch, name=""):
+        b = Buf(n * h * w * pitch, name)
+        self.bufs.append(b)
+        return b
+
+    def new_view(self, n, h, w, c, name=""):
+        return SView(self.new_buf(n, h, w, c, name), n, h, w, c, c, 0)
+
+    def add(self, kind, reads, writes, **kw):
+        t = len(self.steps)
+        for v in reads:
+            if v is not None:
+                v.buf.touch(t)
+        for v in writes:
+            v.buf.touch(t)
+        self.steps.append((kind, kw))
+
+    def conv(self, x: SView, wts: ConvWeights, y: SView, residual: SView = None, ups=False, label=""):
+        assert x.c == wts.cin, (label, x.c, wts.cin)
+        assert y.c == wts.cout, (label, y.c, wts.cout)
+        self.add("conv", [x, residual], [y], x=x, w=wts, y=y, res=residual, ups=ups, label=label)
+
+    # -- storage + launch list ----------------------------------------------------------------
+    def finalize(self):
+        # lifetime-based storage assignment: a buffer is recycled once its last reader has been issued
+        esz = torch.empty(0, dtype=self.dtype).element_size()
+        free: list[torch.Tensor] = []
+        by_first = sorted([b for b in self.bufs if b.first is not None], key=lambda b: b.first)
+        releases: dict[int, list[Buf]] = {}
+        for b in by_first:
+            releases.setdefault(b.last, []).append(b)
+        pending = list(by_first)
+        total = 0
+        pi = 0
+        for t in range(len(self.steps) + 1):
+            while pi < len(pending) and pending[pi].first == t:
+                b = pending[pi]
+                pi += 1
+                best = None
+                for k, tns in enumerate(free):
+                    if tns.numel() >= b.numel and (best is None or tns.numel() < free[best].numel()):
+                        best = k
+                if best is not None and free[best].numel() <= 2 * b.numel + 4096:
+                    b.tensor = free.pop(best)
+                else:
+                    b.tensor = torch.empty(b.numel, dtype=self.dtype, device=self.device)
+                    total += b.numel * esz
+            for b in releases.get(t, []):
+                if not getattr(b, "pinned", False):
+                    free.append(b.tensor)
+        self.activation_bytes = total
+        L = _lib.lib()
+        dcode = ops.dtype_code(self.dtype)
+        for kind, kw in self.steps:
+            if kind == "conv":
+                x, y, w, res = kw["x"].real(), kw["y"].real(), kw["w"], kw["res"]
+                d = Y3ConvDesc(dcode, w.k, w.s, _lib.Y3_ACT_SILU if w.act else _lib.Y3_ACT_NONE, int(kw["ups"]), _lib.Y3_ALGO_AUTO, w.cin, w.cout)
+                xt, yt = x.y3(), y.y3()
+                rt = res.real().y3() if res is not None else None
+                ho = (x.h + 2 * (w.k // 2) - w.k) // w.s + 1
+                wo = (x.w + 2 * (w.k // 2) - w.k) // w.s + 1
+                m = x.n * ho * wo
+                self.launches.append(
+                    _Launch(
+                        L.y3_conv2d_fwd,
+                        (C.byref(d), C.byref(xt), w.filt.data_ptr(), w.bias.data_ptr(), C.byref(rt) if rt is not None else None, C.byref(yt)),
+                        keep=(d, xt, yt, rt, w),
+                        label=kw["label"],
+                        flops=2.0 * m * w.cout * w.cin * w.k * w.k,
+                        bytes=esz * (x.n * x.h * x.w * w.cin + m * w.cout * (4 if kw["ups"] else 1) + (m * w.cout if res is not None else 0) + w.cout * w.cin * w.k * w.k),
+                    )
+                )
+            elif kind == "maxpool":
+                xt, yt = kw["x"].real().y3(), kw["y"].real().y3()
+                self.launches.append(_Launch(L.y3_maxpool2d, (C.byref(xt), C.byref(yt), dcode, kw["k"], kw["s"], kw["p"], kw["zr"], kw["zb"]), keep=(xt, yt), label=kw["label"]))
+            elif kind == "spp":
+                xt, yt = kw["x"].real().y3(), kw["y"].real().y3()
+                self.launches.append(_Launch(L.y3_spp_pyramid, (C.byref(xt), C.byref(yt), dcode), keep=(xt, yt), label=kw["label"]))
+            elif kind == "upsample":
+                xt, yt = kw["x"].real().y3(), kw["y"].real().y3()
+                self.launches.append(_Launch(L.y3_upsample2x, (C.byref(xt), C.byref(yt), dcode), keep=(xt, yt), label=kw["label"]))
+            elif kind == "copy":
+                xt, yt = kw["x"].real().y3(), kw["y"].real().y3()
+                self.launches.append(_Launch(L.y3_copy_slice, (C.byref(xt), C.byref(yt), dcode), keep=(xt, yt), label=kw["label"]))
+            else:
+                raise AssertionError(kind)
+        self.trace, self.steps = self.steps, None  # symbolic steps kept for the host-logic tests
+
+    # -- execution -----------------------------------------------------------------------------
+    def run_body(self, stream):
+        for ln in self.launches:
+            st = ln.fn(*ln.args, stream)
+            if st != 0:
+                _lib.check(st, ln.label or "launch")
+
+
+def _param_version(params):
+    return sum(p._version for p in params)
+
+
+# ------------------------------------------------------------------------------------------- graph compiler
+class _Compiler:
+    def __init__(self, plan: Plan, dtype, training=False):
+        self.plan, self.dtype, self.training = plan, dtype, training
+        if training:
+            raise NotImplementedError(
+                "training-mode forward (batch-statistics BatchNorm + backward) is not implemented on the MI355X path yet; "
+                "call model.eval() -- there is no PyTorch fallback"
+            )
+
+    def conv_unit(self, m: Conv, x: SView, y: SView = None, residual=None, ups=False, label="", cin_pad=None):
+        p = self.plan
+        w = make_conv_weights(m.conv, getattr(m, "bn", None), isinstance(m.act, nn.SiLU), self.dtype, cin_pad=cin_pad)
+        if y is None:
+            ho, wo = _conv_hw((x.h, x.w), w.k, w.s)
+            y = p.new_view(x.n, ho, wo, w.cout, label)
+        p.conv(x, w, y, residual, ups, label)
+        return y
+
+    def bottleneck(self, m: Bottleneck, x: SView, y: SView = None, label=""):
+        t = self.conv_unit(m.cv1, x, label=label + ".cv1")
+        return self.conv_unit(m.cv2, t, y=y, residual=x if m.add else None, label=label + ".cv2")
+
+    def spp(self, m: SPP, x: SView, y: SView = None, label=""):
+        p = self.plan
+        c_ = m.cv1.conv.out_channels
+        cat = p.new_view(x.n, x.h, x.w, 4 * c_, label + ".cat")
+        self.conv_unit(m.cv1, x, y=cat.slice(0, c_), label=label + ".cv1")
+        p.add("spp", [cat.slice(0, c_)], [cat.slice(c_, 3 * c_)], x=cat.slice(0, c_), y=cat.slice(c_, 3 * c_), label=label + ".pools")
+        return self.conv_unit(m.cv2, cat, y=y, label=label + ".cv2")
+
+
+def compile_model(model, n, h, w, dtype, device) -> Plan:
+    from .yolo import Detect
+
+    plan = Plan(device, dtype, n, h, w)
+    comp = _Compiler(plan, dtype, training=model.training)
+    layers = list(model.model)
+    nl = len(layers)
+    hw = graph_hw(model, h, w)
+    src = [_sources(i, m.f) for i, m in enumerate(layers)]
+    consumers = {i: [] for i in range(-1, nl)}
+    for i, s in enumerate(src):
+        for j in s:
+            consumers[j].append(i)
+
+    def kind(m):
+        return m[0] if isinstance(m, nn.Sequential) else m
+
+    ch = {}
+    cin0 = _pad8(model.yaml.get("ch", 3))
+    for i, m in enumerate(layers):
+        k = kind(m)
+        oc = _out_channels(m)
+        if oc is None:
+            if isinstance(k, Concat):
+                oc = sum(ch[j] for j in src[i])
+            elif isinstance(k, Detect):
+                oc = 0
+            else:
+                oc = ch[src[i][0]] if src[i][0] >= 0 else cin0
+        ch[i] = oc
+
+    # ---- placement: where each layer's output lives (Concat destinations claim their sources) ----
+    placed: dict[int, SView] = {}
+    extra_copy = []  # (src layer, destination view) when a tensor feeds a second Concat
+    for i, m in enumerate(layers):
+        if isinstance(kind(m), Concat):
+            ctot = ch[i]
+            cbuf = placed.get(i) or plan.new_view(n, hw[i][0], hw[i][1], ctot, f"L{i}.concat")
+            placed[i] = cbuf
+            off = 0
+            for j in src[i]:
+                sl = cbuf.slice(off, ch[j])
+                if j in placed or j < 0 or (ch[j] % 8) or (off % 8):
+                    extra_copy.append((j, i, sl))
+                else:
+                    placed[j] = sl
+                off += ch[j]
+
+    # Upsample fed by a single-consumer Conv: the conv scatters straight into the upsample's home
+    fused_ups = {}
+    for i, m in enumerate(layers):
+        if isinstance(kind(m), Upsample):
+            j = src[i][0]
+            if j >= 0 and isinstance(layers[j], Conv) and consumers[j] == [i] and j not in placed:
+                fused_ups[j] = i
+    # ZeroPad2d consumed only by a MaxPool2d: folded into the pool launch
+    fused_pad = {}
+    for i, m in enumerate(layers):
+        if isinstance(kind(m), ZeroPad2d):
+            cons = consumers[i]
+            if len(cons) == 1 and isinstance(kind(layers[cons[0]]), MaxPool2d) and i not in placed:
+                fused_pad[i] = cons[0]
+            else:
+                raise NotImplementedError("ZeroPad2d is only supported directly in front of a MaxPool2d (yolov3-tiny)")
+
+    def home(i):
+        if i not in placed:
+            placed[i] = plan.new_view(n, hw[i][0], hw[i][1], ch[i], f"L{i}")
+        return placed[i]
+
+    x_in = plan.new_view(n, h, w, cin0, "input")
+    x_in.buf.pinned = True
+    plan.input_view = x_in
+    out = {-1: x_in}
+
+    for i, m in enumerate(layers):
+        k = kind(m)
+        ins = [out[j] for j in src[i]]
+        lab = f"L{i}"
+        if isinstance(k, Detect):
+            heads = []
+            for lvl, xv in enumerate(ins):
+                conv = k.m[lvl]
+                wts = make_conv_weights(conv, None, False, dtype, cin_pad=xv.c)
+                hv = plan.new_view(xv.n, xv.h, xv.w, wts.cout, f"{lab}.head{lvl}")
+                hv.buf.pinned = True
+                plan.conv(xv, wts, hv, label=f"{lab}.m{lvl}")
+                heads.append(hv)
+            plan.detect = (k, heads)
+            continue
+        if isinstance(k, Concat):
+            for (j, ci, sl) in extra_copy:
+                if ci == i:
+                    plan.add("copy", [out[j]], [sl], x=out[j], y=sl, label=f"{lab}.copy{j}")
+            out[i] = placed[i]
+            continue
+        if isinstance(k, Upsample):
+            j = src[i][0]
+            if j in fused_ups:
+                out[i] = home(i)  # already written by the producing conv
+            else:
+                y = home(i)
+                plan.add("upsample", [ins[0]], [y], x=ins[0], y=y, label=lab)
+                out[i] = y
+            continue
+        if isinstance(k, ZeroPad2d):
+            out[i] = ins[0]  # folded into the following pool
+            continue
+        if isinstance(k, MaxPool2d):
+            j = src[i][0]
+            zr = zb = 0
+            if j in fused_pad:
+                zr, zb = kind(layers[j]).padding[1], kind(layers[j]).padding[3]
+            y = home(i)
+            plan.add("maxpool", [ins[0]], [y], x=ins[0], y=y, k=k.kernel_size, s=k.stride, p=k.padding, zr=zr, zb=zb, label=lab)
+            out[i] = y
+            continue
+        # conv-type layers
+        if i in fused_ups:
+            dst = home(fused_ups[i])
+            comp.conv_unit(k, ins[0], y=dst, ups=True, label=lab, cin_pad=ins[0].c)
+            out[i] = None
+            continue
+        y = home(i)
+        if isinstance(m, nn.Sequential):
+            x = ins[0]
+            for r, sub in enumerate(m):
+                last = r == len(m) - 1
+                x = comp.bottleneck(sub, x, y=y if last else None, label=f"{lab}.{r}")
+            out[i] = y
+        elif isinstance(k, Conv):
+            out[i] = comp.conv_unit(k, ins[0], y=y, label=lab, cin_pad=ins[0].c)
+        elif isinstance(k, Bottleneck):
+            out[i] = comp.bottleneck(k, ins[0], y=y, label=lab)
+        elif isinstance(k, SPP):
+            out[i] = comp.spp(k, ins[0], y=y, label=lab)
+        else:
+            raise NotImplementedError(type(k).__name__)
+    plan.out_views = out
+    plan.finalize()
+    plan.param_refs = list(model.parameters()) + list(model.buffers())
+    plan.param_version = _param_version(plan.param_refs)
+    return plan
+
+
+# ------------------------------------------------------------------------------------------- entry points
+def _engine_dtype(model) -> torch.dtype:
+    p = next(model.parameters())
+    if p.dtype not in (torch.float16, torch.bfloat16, torch.float32):
+        raise TypeError(f"unsupported parameter dtype {p.dtype}")
+    return p.dtype
+
+
+def _decode_consts(det, dtype):
+    """Host copies of (anchor w,h in pixels per level, stride per level), rounded through `dtype` exactly as
+    Detect._make_grid does on tensors (reference models/yolo.py:112-123).  Computed once per plan."""
+    stride = det.stride.detach().to("cpu", dtype)
+    anchors_px = (det.anchors.detach().to("cpu", dtype) * stride.view(-1, 1, 1)).float()
+    return [(anchors_px[l].reshape(-1).tolist(), float(stride[l])) for l in range(det.nl)]
+
+
+def _decode_outputs(plan: Plan, det, heads, n, export=False, training=False):
+    dtype, dev = plan.dtype, plan.device
+    na, no = det.na, det.no
+    rows = [na * hv.h * hv.w for hv in heads]
+    total = sum(rows)
+    consts = plan.__dict__.get("decode_consts")
+    if consts is None:
+        consts = plan.decode_consts = _decode_consts(det, dtype)
+    z = None if training else torch.empty(n, total, no, dtype=dtype, device=dev)
+    raws = []
+    off = 0
+    for lvl, hv in enumerate(heads):
+        raw = None if export else torch.empty(n, na, hv.h, hv.w, no, dtype=dtype, device=dev)
+        apx, stride = consts[lvl]
+        ops.detect_decode(hv.real(), na, no, apx, stride, raw, z, off, total)
+        raws.append(raw)
+        off += rows[lvl]
+    if training:
+        return raws
+    return (z,) if export else (z, raws)
+
+
+def run_model(model, x: torch.Tensor, profile=False):
+    ops.require_gpu(x, "DetectionModel.forward")
+    if x.dim() != 4:
+        raise ValueError(f"expected a (bs, ch, h, w) image batch, got shape {tuple(x.shape)}")
+    dtype = _engine_dtype(model)
+    n, c, h, w = x.shape
+    key = (n, h, w, dtype, bool(model.training), x.device.index)
+    plans = model.__dict__.setdefault("_plans", {})
+    plan = plans.get(key)
+    if plan is not None and plan.param_version != _param_version(plan.param_refs):
+        plan = None  # parameters were modified in place since the filters were packed
+    if plan is None:
+        with torch.no_grad():
+            plan = compile_model(model, n, h, w, dtype, x.device)
+        plans[key] = plan
+    stream = ops.stream_ptr()
+    ops.nchw_to_nhwc(x, plan.input_view.real(), 1.0)
+    if profile:
+        _profile(plan, stream)
+    else:
+        plan.run_body(stream)
+    det, heads = plan.detect
+    return _decode_outputs(plan, det, heads, n, export=det.export, training=model.training)
+
+
+def _profile(plan: Plan, stream):
+    """Per-launch timing table (the reference's model(x, profile=True), models/yolo.py:149-161)."""
+    torch.cuda.synchronize()
+    rows = []
+    for ln in plan.launches:
+        t0 = time.perf_counter()
+        for _ in range(10):
+            ln.fn(*ln.args, stream)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 10
+        rows.append((ln.label, dt * 1e3, ln.flops / dt / 1e12 if dt else 0, ln.bytes / dt / 1e9 if dt else 0))
+    print(f"{'launch':>24s} {'ms':>9s} {'TFLOP/s':>9s} {'GB/s':>9s}")
+    for r in rows:
+        print(f"{r[0]:>24s} {r[1]:9.4f} {r[2]:9.1f} {r[3]:9.1f}")
+    print(f"{'total':>24s} {sum(r[1] for r in rows):9.4f}")
+    plan.last_profile = rows
+
+
+def run_detect(det, xs):
+    """Detect.forward on a list of NCHW maps (reference models/yolo.py:89-110)."""
+    dtype = det.m[0].weight.dtype
+    dev = xs[0].device
+    ops.require_gpu(xs[0], "Detect.forward")
+    n = xs[0].shape[0]
+    plan = Plan(dev, dtype, n, 0, 0)
+    heads, ins = [], []
+    with torch.no_grad():
+        for lvl, x in enumerate(xs):
+            _, c, h, w = x.shape
+            xin = plan.new_view(n, h, w, _pad8(c), f"in{lvl}")
+            xin.buf.pinned = True
+            wts = make_conv_weights(det.m[lvl], None, False, dtype, cin_pad=xin.c)
+            hv = plan.new_view(n, h, w, wts.cout, f"head{lvl}")
+            hv.buf.pinned = True
+            plan.conv(xin, wts, hv, label=f"detect.m{lvl}")
+            heads.append(hv)
+            ins.append(xin)
+        plan.finalize()
+    for x, xin in zip(xs, ins):
+        ops.nchw_to_nhwc(x.to(dtype), xin.real(), 1.0)
+    plan.run_body(ops.stream_ptr())
+    return _decode_outputs(plan, det, heads, n, export=det.export, training=det.training)
+
+
+def run_single_layer(module, x: torch.Tensor):
+    """Run one Conv / Bottleneck / SPP alone (NCHW in, NCHW out) through the same kernels (eval semantics)."""
+    ops.require_gpu(x, type(module).__name__ + ".forward")
+    dtype = next(module.parameters()).dtype
+    n, c, h, w = x.shape
+    plan = Plan(x.device, dtype, n, h, w)
+    comp = _Compiler(plan, dtype, training=False)
+    xin = plan.new_view(n, h, w, _pad8(c), "input")
+    xin.buf.pinned = True
+    with torch.no_grad():
+        if isinstance(module, Conv):
+            y = comp.conv_unit(module, xin, label="conv", cin_pad=xin.c)
+        elif isinstance(module, Bottleneck):
+            y = comp.bottleneck(module, xin, label="bottleneck")
+        elif isinstance(module, SPP):
+            y = comp.spp(module, xin, label="spp")
+        else:
+            raise NotImplementedError(type(module).__name__)
+        y.buf.pinned = True
+        plan.finalize()
+    ops.nchw_to_nhwc(x.to(dtype), xin.real(), 1.0)
+    plan.run_body(ops.stream_ptr())
+    full = ops.nhwc_to_nchw(y.real())
+    co = _out_channels(module)
+    return full[:, :co]

@@ -1,0 +1,173 @@
+"""Thin host wrappers over the C ABI (include/yolov3_hip.h): torch supplies device memory and the stream,
+nothing else.  Activations are NHWC views (`View`) over flat torch buffers."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+from ._lib import Y3ConvDesc, Y3NmsParams, Y3Tensor, check
+
+DTYPE_CODE = {torch.float16: _lib.Y3_F16, torch.bfloat16: _lib.Y3_BF16, torch.float32: _lib.Y3_F32, torch.uint8: _lib.Y3_U8}
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    try:
+        return DTYPE_CODE[dt]
+    except KeyError:
+        raise TypeError(f"dtype {dt} is not supported by the MI355X path (float16 / bfloat16 / float32)") from None
+
+
+def require_gpu(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{what}: tensor is on {t.device}; the yolov3_amd hot path runs only on an MI355X (HIP) device. "
+            "There is no CPU / PyTorch fallback."
+        )
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+@dataclass
+class View:
+    """NHWC view: channels [coff, coff+c) of a (n, h, w, pitch) buffer."""
+
+    buf: torch.Tensor  # flat storage, at least n*h*w*pitch elements
+    n: int
+    h: int
+    w: int
+    c: int
+    pitch: int
+    coff: int = 0
+
+    def y3(self) -> Y3Tensor:
+        ptr = self.buf.data_ptr() + self.coff * self.buf.element_size()
+        return Y3Tensor(ptr, self.n, self.h, self.w, self.c, self.pitch)
+
+    def slice(self, coff: int, c: int) -> "View":
+        assert coff + c <= self.c
+        return View(self.buf, self.n, self.h, self.w, c, self.pitch, self.coff + coff)
+
+    def as_nhwc(self) -> torch.Tensor:
+        """torch view (n,h,w,c) for tests/debug."""
+        full = self.buf[: self.n * self.h * self.w * self.pitch].view(self.n, self.h, self.w, self.pitch)
+        return full[..., self.coff : self.coff + self.c]
+
+    @staticmethod
+    def alloc(n, h, w, c, dtype, device, pitch=None) -> "View":
+        pitch = pitch or c
+        return View(torch.empty(n * h * w * pitch, dtype=dtype, device=device), n, h, w, c, pitch, 0)
+
+
+def packed_filter_elems(cout: int, cin: int, k: int) -> int:
+    return int(_lib.lib().y3_packed_filter_elems(cout, cin, k))
+
+
+def pack_filter(w_oihw: torch.Tensor, cout: int, cin: int, dtype: torch.dtype) -> torch.Tensor:
+    """OIHW fp32 weights (device) -> packed filter bank for y3_conv2d_fwd, zero padded to (cout, cin)."""
+    require_gpu(w_oihw, "pack_filter")
+    w = w_oihw.detach().to(torch.float32).contiguous()
+    co, ci, k, _ = w.shape
+    out = torch.empty(packed_filter_elems(cout, cin, k), dtype=dtype, device=w.device)
+    check(_lib.lib().y3_pack_filter(w.data_ptr(), co, ci, k, cout, cin, dtype_code(dtype), out.data_ptr(), stream_ptr()), "y3_pack_filter")
+    return out
+
+
+def conv2d(x: View, filt: torch.Tensor, bias: torch.Tensor, y: View, k: int, stride: int, act: bool, residual: View | None = None, upsample2x: bool = False,
+           algo: int = _lib.Y3_ALGO_AUTO):
+    d = Y3ConvDesc(dtype_code(x.buf.dtype), k, stride, _lib.Y3_ACT_SILU if act else _lib.Y3_ACT_NONE, int(upsample2x), algo, x.c, y.c)
+    xt, yt = x.y3(), y.y3()
+    rt = residual.y3() if residual is not None else None
+    check(
+        _lib.lib().y3_conv2d_fwd(C.byref(d), C.byref(xt), filt.data_ptr(), bias.data_ptr(), C.byref(rt) if rt is not None else None, C.byref(yt), stream_ptr()),
+        "y3_conv2d_fwd",
+    )
+
+
+def nchw_to_nhwc(src: torch.Tensor, out: View, divisor: float = 1.0):
+    require_gpu(src, "nchw_to_nhwc")
+    src = src.contiguous()
+    n, c, h, w = src.shape
+    ot = out.y3()
+    check(_lib.lib().y3_nchw_to_nhwc(src.data_ptr(), dtype_code(src.dtype), n, c, h, w, float(divisor), dtype_code(out.buf.dtype), C.byref(ot), stream_ptr()), "y3_nchw_to_nhwc")
+
+
+def nhwc_to_nchw(src: View) -> torch.Tensor:
+    dst = torch.empty(src.n, src.c, src.h, src.w, dtype=src.buf.dtype, device=src.buf.device)
+    st = src.y3()
+    check(_lib.lib().y3_nhwc_to_nchw(C.byref(st), dtype_code(src.buf.dtype), dst.data_ptr(), stream_ptr()), "y3_nhwc_to_nchw")
+    return dst
+
+
+def maxpool2d(x: View, y: View, k: int, stride: int, pad: int, zpad_r: int = 0, zpad_b: int = 0):
+    xt, yt = x.y3(), y.y3()
+    check(_lib.lib().y3_maxpool2d(C.byref(xt), C.byref(yt), dtype_code(x.buf.dtype), k, stride, pad, zpad_r, zpad_b, stream_ptr()), "y3_maxpool2d")
+
+
+def spp_pyramid(x: View, y3c: View):
+    xt, yt = x.y3(), y3c.y3()
+    check(_lib.lib().y3_spp_pyramid(C.byref(xt), C.byref(yt), dtype_code(x.buf.dtype), stream_ptr()), "y3_spp_pyramid")
+
+
+def upsample2x(x: View, y: View):
+    xt, yt = x.y3(), y.y3()
+    check(_lib.lib().y3_upsample2x(C.byref(xt), C.byref(yt), dtype_code(x.buf.dtype), stream_ptr()), "y3_upsample2x")
+
+
+def copy_slice(x: View, y: View):
+    xt, yt = x.y3(), y.y3()
+    check(_lib.lib().y3_copy_slice(C.byref(xt), C.byref(yt), dtype_code(x.buf.dtype), stream_ptr()), "y3_copy_slice")
+
+
+def detect_decode(head: View, na: int, no: int, anchors_px, stride: float, raw: torch.Tensor | None, z: torch.Tensor | None, row_offset: int, total_rows: int):
+    ht = head.y3()
+    arr = (C.c_float * (na * 2))(*[float(v) for v in anchors_px])
+    check(
+        _lib.lib().y3_detect_decode(
+            C.byref(ht), dtype_code(head.buf.dtype), na, no, arr, float(stride), raw.data_ptr() if raw is not None else None, z.data_ptr() if z is not None else None,
+            row_offset, total_rows, stream_ptr(),
+        ),
+        "y3_detect_decode",
+    )
+
+
+_nms_ws_cache: dict = {}
+
+
+def nms_raw(pred: torch.Tensor, conf_thres: float, iou_thres: float, classes, agnostic: bool, multi_label: bool, max_det: int, max_nms: int = 30000,
+            max_wh: float = 7680.0):
+    """Batched NMS on device.  Returns (rows (bs,max_det,6) fp32, counts list[int]).  One D2H copy (counts+status)."""
+    require_gpu(pred, "non_max_suppression")
+    pred = pred.contiguous()
+    bs, n_rows, no = pred.shape
+    nc = no - 5
+    dev = pred.device
+    cls_t = torch.tensor(list(classes), dtype=torch.int32, device=dev) if classes is not None else None
+    p = Y3NmsParams(float(iou_thres), float(conf_thres), int(bool(multi_label)), int(bool(agnostic)), int(max_det), int(max_nms), float(max_wh),
+                    0 if cls_t is None else cls_t.numel())
+    L = _lib.lib()
+    rows = torch.empty(bs, max_det, 6, dtype=torch.float32, device=dev)
+    meta = torch.empty(bs + 2, dtype=torch.int32, device=dev)
+    capacity = 0
+    for attempt in range(3):
+        need = int(L.y3_nms_workspace_bytes(bs, n_rows, nc, C.byref(p), capacity))
+        key = (dev.index, need)
+        ws = _nms_ws_cache.get(key)
+        if ws is None:
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            if need <= (1 << 30):
+                _nms_ws_cache[key] = ws
+        check(
+            L.y3_nms(pred.data_ptr(), dtype_code(pred.dtype), bs, n_rows, nc, C.byref(p), cls_t.data_ptr() if cls_t is not None else None, rows.data_ptr(),
+                     meta.data_ptr(), meta.data_ptr() + bs * 4, capacity, ws.data_ptr(), need, stream_ptr()),
+            "y3_nms",
+        )
+        m = meta.tolist()  # the single device->host sync of the call
+        if m[bs] == 0:
+            return rows, m[:bs]
+        capacity = max(m[bs + 1], 1)  # overflow: rerun with room for every candidate
+    raise _lib.Y3Error("y3_nms: candidate capacity overflow persisted")
