@@ -120,6 +120,32 @@ int y3_nms(const void* pred, int32_t dtype, int32_t bs, int32_t n_rows, int32_t 
            const int32_t* classes, float* out_rows, int32_t* out_counts, int32_t* out_status, int64_t capacity,
            void* workspace, size_t workspace_bytes, void* stream);
 
+/* ComputeLoss: reference utils/loss.py:98-244 (build_targets :183-244, __call__ :131-181, criteria :104-129,
+ * FocalLoss :31-63 when fl_gamma > 0) with upstream bbox_iou(CIoU) and smooth_bce.
+ * preds: HOST array of nl DEVICE pointers, level i is contiguous (bs, na, ny[i], nx[i], nc+5) of `dtype`;
+ * targets: DEVICE (nt, 6) fp32 [img, cls, x, y, w, h] normalised; anchors in grid units (Detect.anchors).
+ * y3_loss_fwd writes out4 (DEVICE) = [ (lbox+lobj+lcls)*bs, lbox, lobj, lcls ] (gains applied, :176-181).
+ * y3_loss_bwd (same params / preds / targets / workspace as the preceding fwd) overwrites grads[i] (same
+ * shape and dtype as preds[i]) with d(out4[0]) / d preds[i] * grad_out[0] (grad_out: DEVICE scalar or NULL = 1).
+ * Duplicate matches of one cell: tobj takes the LAST match in the reference's list order (CPU index_put), box/cls
+ * gradients accumulate.  gr = 1, autobalance off, sort_obj_iou off (the reference's defaults). */
+typedef struct {
+    int32_t nl, na, nc, bs;
+    int32_t ny[5], nx[5];
+    float anchors[50]; /* [nl][na][2] */
+    float balance[5];  /* reference: {4, 1, 0.4} for nl == 3, else first nl of {4, 1, .25, .06, .02}  (:122) */
+    float anchor_t;    /* hyp['anchor_t'] */
+    float box_gain, obj_gain, cls_gain; /* hyp['box'], hyp['obj'], hyp['cls'] (already scaled, train.py:327-329) */
+    float cls_pw, obj_pw;               /* BCE pos_weight */
+    float cp, cn;                       /* smooth_bce(label_smoothing) */
+    float fl_gamma;                     /* 0 = plain BCE */
+} y3_loss_params;
+size_t y3_loss_workspace_bytes(const y3_loss_params* p, int32_t nt);
+int y3_loss_fwd(const y3_loss_params* p, int32_t dtype, const void* const* preds, const float* targets, int32_t nt,
+                float* out4, void* workspace, size_t workspace_bytes, void* stream);
+int y3_loss_bwd(const y3_loss_params* p, int32_t dtype, const void* const* preds, const float* targets, int32_t nt,
+                const float* grad_out, void* const* grads, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -317,9 +317,9 @@ def build_targets(shapes, targets, anchors_grid, anchor_t=4.0):
         bc, gxy, gwh, a = t.chunk(4, 1)
         a, (b, c) = a.long().view(-1), bc.long().T
         gij = (gxy - offsets).long()
-        gi, gj = gij.T
-        gj = gj.clamp(0, shp[2] - 1)
-        gi = gi.clamp(0, shp[3] - 1)
+        gi, gj = gij.T  # views: the in-place clamps below also change gij, as in the reference (:235-240),
+        gj.clamp_(0, shp[2] - 1)  # so tbox is computed from the CLAMPED cell indices
+        gi.clamp_(0, shp[3] - 1)
         out.append((b, a, gj, gi, torch.cat((gxy - gij, gwh), 1), anchors[a], c))
     return out
 
@@ -460,29 +460,45 @@ def synth_targets(bs, nc, seed=1):
     return torch.cat(rows, 0) if rows else torch.zeros(0, 6)
 
 
+def _pow_int(u, k):
+    """u**k by repeated multiplication (k a power of two): exact IEEE ops only, so the synthetic tensors are
+    bit-identical on every CPU (vectorised exp/log/sigmoid differ in the last bit between ISAs)."""
+    while k > 1:
+        u = u * u
+        k //= 2
+    return u
+
+
 def synth_predictions(bs, n_rows=25200, nc=80, img=640, seed=2, hits=0.03, n_gt=12, dtype=torch.float32):
-    """Decoded prediction tensor (bs, n_rows, 5+nc) for NMS tests/bench, decoupled from the
-    random-weight model: obj logit~N(-9,2.5) background, 3% 'hit' rows jittered
-    around n_gt ground-truth boxes with obj~N(1.5,1.5) and the GT class logit~N(2,1); other class
-    logits~N(-5,1.5).  Values are post-sigmoid, boxes in pixels (xywh)."""
+    """Decoded prediction tensor (bs, n_rows, 5+nc) for NMS tests/bench, decoupled from the random-weight model
+    (a random-weight model's objectness is ~0.003 everywhere).  Built from torch.rand and + - * / only
+    (bit-reproducible across hosts).  Background rows: obj = 0.5*u^32*(0.05+0.95*v^4) (about 20 % pass conf 0.001,
+    a few percent pass 0.25), class scores 0.5*u^64; a `hits` fraction of rows are jittered copies of
+    n_gt ground-truth boxes with obj in [0.3,1] and the GT class score in [0.4,1].  Boxes are xywh pixels."""
     g = torch.Generator().manual_seed(seed)
+    r = lambda *shape: torch.rand(*shape, generator=g)
     out = torch.empty(bs, n_rows, 5 + nc)
     for b in range(bs):
-        gt_xy = torch.rand(n_gt, 2, generator=g) * (img * 0.8) + img * 0.1
-        gt_wh = torch.exp(torch.rand(n_gt, 2, generator=g) * (math.log(0.5) - math.log(0.04)) + math.log(0.04)) * img
+        gt_xy = r(n_gt, 2) * (img * 0.8) + img * 0.1
+        gt_wh = (0.04 + 0.46 * _pow_int(r(n_gt, 2), 2)) * img
         gt_c = torch.randint(0, nc, (n_gt,), generator=g)
-        xy = torch.rand(n_rows, 2, generator=g) * img
-        wh = torch.exp(torch.rand(n_rows, 2, generator=g) * (math.log(0.6) - math.log(0.02)) + math.log(0.02)) * img
-        obj = torch.randn(n_rows, generator=g) * 2.5 - 9.0
-        cls = torch.randn(n_rows, nc, generator=g) * 1.5 - 5.0
-        is_hit = torch.rand(n_rows, generator=g) < hits
-        idx = is_hit.nonzero().view(-1)
+        xy = r(n_rows, 2) * img
+        wh = (0.02 + 0.58 * _pow_int(r(n_rows, 2), 4)) * img
+        obj = 0.5 * _pow_int(r(n_rows), 32) * (0.05 + 0.95 * _pow_int(r(n_rows), 4))
+        cls = 0.5 * _pow_int(r(n_rows, nc), 64)
+        idx = (r(n_rows) < hits).nonzero().view(-1)
         k = torch.randint(0, n_gt, (idx.numel(),), generator=g)
-        xy[idx] = gt_xy[k] + torch.randn(idx.numel(), 2, generator=g) * 0.08 * gt_wh[k]
-        wh[idx] = gt_wh[k] * torch.exp(torch.randn(idx.numel(), 2, generator=g) * 0.15)
-        obj[idx] = torch.randn(idx.numel(), generator=g) * 1.5 + 1.5
-        cls[idx, gt_c[k]] = torch.randn(idx.numel(), generator=g) + 2.0
+        xy[idx] = gt_xy[k] + (r(idx.numel(), 2) - 0.5) * 0.3 * gt_wh[k]
+        wh[idx] = gt_wh[k] * (0.8 + 0.4 * r(idx.numel(), 2))
+        obj[idx] = 0.3 + 0.7 * r(idx.numel())
+        cls[idx, gt_c[k]] = 0.4 + 0.6 * r(idx.numel())
         out[b, :, 0:2], out[b, :, 2:4] = xy, wh
-        out[b, :, 4] = obj.sigmoid()
-        out[b, :, 5:] = cls.sigmoid()
+        out[b, :, 4] = obj
+        out[b, :, 5:] = cls
     return out.to(dtype)
+
+
+def synth_raw_predictions(shapes, seed=31):
+    """Raw head tensors (bs,na,ny,nx,no) for the loss tests: uniform in [-3, 3] from torch.rand only."""
+    g = torch.Generator().manual_seed(seed)
+    return [(torch.rand(*s, generator=g) * 6.0 - 3.0) for s in shapes]

@@ -162,7 +162,7 @@ def gen_nms_goldens(ns):
 
 def gen_loss_goldens(ns):
     out = {}
-    for name, nc, hw, bs, nt_mode in [("yolov3", 80, 128, 3, "synth"), ("yolov3-tiny", 80, 96, 2, "synth"), ("yolov3", 80, 64, 2, "empty"), ("yolov3", 5, 64, 2, "dups")]:
+    for name, nc, hw, bs, nt_mode in [("yolov3", 80, 128, 3, "synth"), ("yolov3-tiny", 80, 96, 2, "synth"), ("yolov3", 80, 64, 2, "empty"), ("yolov3", 5, 64, 2, "dups"), ("yolov3", 5, 64, 2, "edges")]:
         m, sd, layers, save, strides = build_ref_model(ns, name, nc, seed=13)
         hyp = dict(HYP)
         nl = len(strides)
@@ -171,12 +171,16 @@ def gen_loss_goldens(ns):
         hyp["obj"] *= (hw / 640) ** 2 * 3 / nl
         m.hyp = hyp
         crit = ns.ComputeLoss(m)
-        g = torch.Generator().manual_seed(31)
-        p = [torch.randn(bs, 3, hw // s, hw // s, nc + 5, generator=g).requires_grad_(True) for s in strides]
+        p = [t.requires_grad_(True) for t in yo.synth_raw_predictions([(bs, 3, hw // s, hw // s, nc + 5) for s in strides], seed=31)]
         if nt_mode == "synth":
             tg = yo.synth_targets(bs, nc, seed=1)
         elif nt_mode == "empty":
             tg = torch.zeros(0, 6)
+        elif nt_mode == "edges":  # centres on the image border / exact cell edges: clamp + offset corner cases
+            tg = torch.tensor(
+                [[0, 1, 1.0, 1.0, 0.3, 0.3], [0, 2, 0.0, 0.0, 0.2, 0.25], [1, 0, 0.5, 0.5, 0.4, 0.4], [1, 3, 1.0, 0.25, 0.1, 0.12], [0, 4, 0.125, 0.875, 0.05, 0.9]],
+                dtype=torch.float32,
+            )
         else:  # forced duplicate cells: identical centres, different classes / sizes
             tg = torch.tensor(
                 [[0, 1, 0.51, 0.52, 0.2, 0.3], [0, 2, 0.51, 0.52, 0.21, 0.29], [0, 1, 0.515, 0.525, 0.2, 0.3], [1, 4, 0.26, 0.74, 0.5, 0.45], [1, 0, 0.26, 0.74, 0.5, 0.45]],
@@ -186,7 +190,8 @@ def gen_loss_goldens(ns):
         loss.backward()
         out[f"{name}-nc{nc}-{hw}-{nt_mode}"] = {
             "hyp": hyp,
-            "p_sum": sum(checksum(t) for t in p),
+            "p_sum": sum(checksum(t.detach()) for t in p),
+            "bs": bs,
             "targets": tg,
             "loss": loss.detach().clone(),
             "items": items.clone(),

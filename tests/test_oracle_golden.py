@@ -58,6 +58,15 @@ def test_decode_matches_reference(golden_dir, key, dtype, nc):
     assert torch.equal(z, gold["z"])
 
 
+def _canon(t):
+    """rows ordered by (-score, then x1,y1,x2,y2,cls): removes the arbitrary order the reference's unstable argsort
+    gives to EXACT score ties (apriori label rows all have conf 1.0)"""
+    t = t.float().cpu()
+    keys = torch.stack((-t[:, 4], t[:, 0], t[:, 1], t[:, 2], t[:, 3], t[:, 5]), 1).tolist()
+    order = sorted(range(len(keys)), key=lambda i: keys[i])
+    return t[order]
+
+
 def _cmp_nms(res, gold):
     assert len(res) == len(gold)
     for a, b in zip(res, gold):
@@ -99,7 +108,8 @@ def test_nms_matches_reference(golden_dir, name):
 def test_nms_labels_matches_reference(golden_dir):
     rec = torch.load(golden_dir / "nms.pt")["labels"]
     pred = yo.synth_predictions(bs=2, n_rows=800, nc=80, seed=10)
-    _cmp_nms(yo.non_max_suppression(pred, 0.25, 0.45, labels=rec["lb"]), rec["out"])
+    res = yo.non_max_suppression(pred, 0.25, 0.45, labels=rec["lb"])
+    _cmp_nms([_canon(r) for r in res], [_canon(r) for r in rec["out"]])
 
 
 def test_nms_c_equals_numpy():
@@ -115,7 +125,7 @@ def test_nms_c_equals_numpy():
     assert torch.equal(a, b)
 
 
-LOSS_CASES = ["yolov3-nc80-128-synth", "yolov3-tiny-nc80-96-synth", "yolov3-nc80-64-empty", "yolov3-nc5-64-dups"]
+LOSS_CASES = ["yolov3-nc80-128-synth", "yolov3-tiny-nc80-96-synth", "yolov3-nc80-64-empty", "yolov3-nc5-64-dups", "yolov3-nc5-64-edges"]
 
 
 @pytest.mark.parametrize("key", LOSS_CASES)
@@ -124,10 +134,9 @@ def test_loss_matches_reference(golden_dir, key):
     name, nc, hw, mode = key.rsplit("-", 3)
     nc, hw = int(nc[2:]), int(hw)
     layers, save, sd, strides = build(name, nc, 13)
-    bs = {"yolov3-nc80-128-synth": 3}.get(key, 2)
-    g = torch.Generator().manual_seed(31)
-    p = [torch.randn(bs, 3, hw // s, hw // s, nc + 5, generator=g).requires_grad_(True) for s in strides]
-    assert abs(sum(checksum(t) for t in p) - rec["p_sum"]) < 1e-9 * rec["p_sum"]
+    bs = rec["bs"]
+    p = [t.requires_grad_(True) for t in yo.synth_raw_predictions([(bs, 3, hw // s, hw // s, nc + 5) for s in strides], seed=31)]
+    assert sum(checksum(t.detach()) for t in p) == rec["p_sum"]
     loss, items, _ = yo.compute_loss(p, rec["targets"], rec["anchors_grid"], rec["hyp"], nc)
     loss.backward()
     torch.testing.assert_close(loss, rec["loss"], rtol=1e-6, atol=1e-6)

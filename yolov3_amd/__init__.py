@@ -4,10 +4,12 @@ Public surface mirrors the reference's own Python signatures:
     DetectionModel / Model / Detect      (reference models/yolo.py)
     Conv / Bottleneck / SPP / Concat     (reference models/common.py)
     non_max_suppression, scale_boxes     (reference utils/general.py)
+    ComputeLoss                          (reference utils/loss.py)
 Everything executes through libyolov3_hip.so (include/yolov3_hip.h); there is no CPU/PyTorch fallback.
 """
 from .common import SPP, Bottleneck, Concat, Conv  # noqa: F401
 from .general import non_max_suppression, scale_boxes, xywh2xyxy, clip_boxes  # noqa: F401
+from .loss import ComputeLoss  # noqa: F401
 from .yolo import Detect, DetectionModel, Model, parse_model  # noqa: F401
 
 __version__ = "0.1.0"

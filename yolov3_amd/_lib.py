@@ -43,6 +43,28 @@ class Y3NmsParams(C.Structure):
     ]
 
 
+class Y3LossParams(C.Structure):
+    _fields_ = [
+        ("nl", C.c_int32),
+        ("na", C.c_int32),
+        ("nc", C.c_int32),
+        ("bs", C.c_int32),
+        ("ny", C.c_int32 * 5),
+        ("nx", C.c_int32 * 5),
+        ("anchors", C.c_float * 50),
+        ("balance", C.c_float * 5),
+        ("anchor_t", C.c_float),
+        ("box_gain", C.c_float),
+        ("obj_gain", C.c_float),
+        ("cls_gain", C.c_float),
+        ("cls_pw", C.c_float),
+        ("obj_pw", C.c_float),
+        ("cp", C.c_float),
+        ("cn", C.c_float),
+        ("fl_gamma", C.c_float),
+    ]
+
+
 _P = C.POINTER
 # symbol -> (restype, argtypes).  Every symbol include/yolov3_hip.h declares is listed here and is REQUIRED.
 _SIGNATURES = {
@@ -63,6 +85,9 @@ _SIGNATURES = {
         C.c_int,
         [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P(Y3NmsParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p],
     ),
+    "y3_loss_workspace_bytes": (C.c_size_t, [_P(Y3LossParams), C.c_int32]),
+    "y3_loss_fwd": (C.c_int, [_P(Y3LossParams), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "y3_loss_bwd": (C.c_int, [_P(Y3LossParams), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
 }
 
 _lib = None
