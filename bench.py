@@ -38,7 +38,7 @@ def igemm_variant(cin, cout):
     """Mirror of dispatch_igemm() in csrc/conv.hip: which template instance a conv launch lands on."""
     bk = 64 if cin % 64 == 0 else 32
     small = "" if cin % 32 == 0 else "_smallc"
-    tile = "tc128xtp128" if cout > 64 else "tc64xtp256" if cout > 32 else "tc32xtp256"
+    tile = "tc128xtp128" if cout > 64 else "tc64xtp128" if cout > 32 else "tc32xtp256"
     return f"conv_igemm<f16,bk{bk},{tile}{small}>"
 
 
@@ -72,6 +72,19 @@ def per_kernel_times(plan, reps=5):
     return acc
 
 
+def host_threads(cap=32):
+    """Threads for the CPU leg: the cores this process may really use (affinity mask and cgroup quota, not
+    os.cpu_count(), which reports the whole host), capped -- oversubscribed oneDNN convolutions get slower."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
 def cpu_baseline(bs_sample=4):
     """The oracle (torch-CPU fp32 restatement of the reference, fused eval forward + NMS) on the host cores, on a
     bounded sample of the same workload.  kind="port": the reference itself needs /root/reference + stubs and
@@ -80,7 +93,7 @@ def cpu_baseline(bs_sample=4):
 
     from oracle import yolo_oracle as yo
 
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(host_threads())
     d = yaml.safe_load(open(ROOT / "yolov3_amd" / "cfg" / "yolov3.yaml"))
     layers, save, anchors, nc = yo.parse_cfg(d)
     strides = yo.model_strides(layers)

@@ -16,6 +16,8 @@
 //     walks all cout tiles of a pixel tile back-to-back, so the X tile is L2-hot for its siblings.
 #include "y3_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 struct ConvArgs {
@@ -34,6 +36,7 @@ struct ConvArgs {
     int nk;         // K iterations
     int cin_blocks; // Cin / BK (uniform-tap path)
     int n_pt, n_ct;
+    unsigned x_bytes, w_bytes;  // extents for the buffer descriptors (0 = tensor too large: plain-pointer kernel)
 };
 
 template <typename T> struct Mfma;
@@ -281,6 +284,234 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     }
 }
 
+// ---- v2 main loop: branch-free buffer loads (out-of-range lanes read 0 through the descriptor's bounds check, so
+// halo / tail handling costs one v_cndmask instead of a divergent branch) and a two-deep register prefetch: while
+// tile t is multiplied out of LDS, tile t+1 waits in registers and tile t+2 is in flight, so a K-step never
+// stalls on HBM/L2 latency.  The compiler's counted vmcnt keeps the younger batch in flight across the LDS store.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T, int BK, int WAVES_C, int WAVES_P, int MC, int MP, bool SMALLC>
+__global__ __launch_bounds__(256, 2) void conv_igemm_v2_kernel(const ConvArgs p) {
+    constexpr int TC = WAVES_C * MC * 32;
+    constexpr int TP = WAVES_P * MP * 32;
+    constexpr int S = BK / 8;
+    constexpr int WJ = (TC * S + 255) / 256;
+    constexpr int XJ = (TP * S + 255) / 256;
+    constexpr int STAGE_BYTES = (TC + TP) * BK * 2;
+    constexpr int EP = TC + 4;
+    constexpr int EPI_BYTES = TP * EP * 4;
+    constexpr int LDS_BYTES = 2 * STAGE_BYTES > EPI_BYTES ? 2 * STAGE_BYTES : EPI_BYTES;
+    constexpr int ROWSTEP = 256 / S;
+    constexpr bool W_FULL = (TC * S) % 256 == 0, X_FULL = (TP * S) % 256 == 0;  // no partial last chunk -> no row guards
+    static_assert(WAVES_C * WAVES_P == 4, "4 waves");
+    typedef typename Mfma<T>::frag frag;
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
+    const int wc = wv / WAVES_P, wp = wv % WAVES_P;
+
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int pt = L / p.n_ct, ct = L % p.n_ct;
+
+    const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xffffffffu;
+
+    const int slot = tid % S;
+    const int row0 = tid / S;
+
+    int xoff[XJ];  // byte offset of (n, hi0, wi0, 0); may be negative, only used when the tap is inside the image
+    int hi0[XJ], wi0[XJ];
+    bool mvalid[XJ];
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) {
+        const int row = row0 + j * ROWSTEP;
+        const int m = pt * TP + row;
+        const bool v = (X_FULL || row < TP) && (m < p.M);
+        const int mm = v ? m : 0;
+        const int n = mm / (p.Ho * p.Wo);
+        const int rem = mm - n * (p.Ho * p.Wo);
+        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        hi0[j] = ho * p.stride - p.pad;
+        wi0[j] = wo * p.stride - p.pad;
+        xoff[j] = (int)((((long long)(n * p.H + hi0[j]) * p.W + wi0[j]) * p.xpitch) * 2);
+        mvalid[j] = v;
+    }
+    unsigned woff[WJ];
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) {
+        const int row = row0 + j * ROWSTEP;
+        woff[j] = (W_FULL || row < TC) ? (unsigned)(((long long)(ct * TC + row) * p.Kpad + slot * 8) * 2) : OOB;
+    }
+
+    u32x4 xa[XJ], wa[WJ], xb[XJ], wb[WJ];
+
+    auto issue = [&](int it, u32x4 (&xr)[XJ], u32x4 (&wr)[WJ]) {
+        int kh, kw, c0;
+        bool tapok = it < p.nk;
+        if (SMALLC) {
+            const int cg = p.Cin >> 3;
+            const int g = it * S + slot;
+            const int tap = g / cg;
+            c0 = (g - tap * cg) * 8;
+            kh = tap / p.ks;
+            kw = tap - kh * p.ks;
+            tapok = tapok && (tap < p.ks * p.ks);
+        } else {
+            const int tap = it / p.cin_blocks;
+            const int cb = it - tap * p.cin_blocks;
+            kh = tap / p.ks;
+            kw = tap - kh * p.ks;
+            c0 = cb * BK + slot * 8;
+        }
+        const int tapoff = ((kh * p.W + kw) * p.xpitch + c0) * 2;
+#pragma unroll
+        for (int j = 0; j < XJ; ++j) {
+            const int hi = hi0[j] + kh, wi = wi0[j] + kw;
+            const bool ok = tapok && mvalid[j] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            xr[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, ok ? (unsigned)(xoff[j] + tapoff) : OOB, 0, 0);
+        }
+        const unsigned wk = it < p.nk ? (unsigned)(it * BK * 2) : OOB;
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) wr[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (woff[j] == OOB || wk == OOB) ? OOB : woff[j] + wk, 0, 0);
+    };
+    auto stash = [&](int stage, const u32x4 (&xr)[XJ], const u32x4 (&wr)[WJ]) {
+        unsigned char* wl = smem + stage * STAGE_BYTES;
+        unsigned char* xl = wl + TC * BK * 2;
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+            const int row = row0 + j * ROWSTEP;
+            if (W_FULL || row < TC) *(u32x4*)(wl + row * (BK * 2) + ((slot ^ swz<BK>(row)) << 4)) = wr[j];
+        }
+#pragma unroll
+        for (int j = 0; j < XJ; ++j) {
+            const int row = row0 + j * ROWSTEP;
+            if (X_FULL || row < TP) *(u32x4*)(xl + row * (BK * 2) + ((slot ^ swz<BK>(row)) << 4)) = xr[j];
+        }
+    };
+
+    f32x16 acc[MC][MP];
+#pragma unroll
+    for (int a = 0; a < MC; ++a)
+#pragma unroll
+        for (int b = 0; b < MP; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    const int frow = lane & 31;
+    const int fk = lane >> 5;
+
+    auto compute = [&](int stage) {
+        const unsigned char* wl = smem + stage * STAGE_BYTES;
+        const unsigned char* xl = wl + TC * BK * 2;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            frag af[MC], bf[MP];
+            const int ks = kk * 2 + fk;
+#pragma unroll
+            for (int a = 0; a < MC; ++a) {
+                const int row = (wc * MC + a) * 32 + frow;
+                af[a] = *(const frag*)(wl + row * (BK * 2) + ((ks ^ swz<BK>(row)) << 4));
+            }
+#pragma unroll
+            for (int b = 0; b < MP; ++b) {
+                const int row = (wp * MP + b) * 32 + frow;
+                bf[b] = *(const frag*)(xl + row * (BK * 2) + ((ks ^ swz<BK>(row)) << 4));
+            }
+#pragma unroll
+            for (int a = 0; a < MC; ++a)
+#pragma unroll
+                for (int b = 0; b < MP; ++b) acc[a][b] = Mfma<T>::run(af[a], bf[b], acc[a][b]);
+        }
+    };
+
+    issue(0, xa, wa);
+    issue(1, xb, wb);
+    stash(0, xa, wa);
+    __syncthreads();
+    for (int it = 0; it < p.nk; it += 2) {
+        issue(it + 2, xa, wa);       // tile it+2 -> A (in flight during two K-steps)
+        compute(0);                  // tile it
+        stash(1, xb, wb);            // tile it+1 (B was issued one K-step ago)
+        __syncthreads();
+        if (it + 1 >= p.nk) break;
+        issue(it + 3, xb, wb);
+        compute(1);                  // tile it+1
+        stash(0, xa, wa);            // tile it+2
+        __syncthreads();
+    }
+
+    // ---- epilogue (identical to v1) ----
+    float* el = (float*)smem;
+#pragma unroll
+    for (int a = 0; a < MC; ++a) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int cl = (wc * MC + a) * 32 + 8 * g + 4 * fk;
+            const int cgl = ct * TC + cl;
+            float b4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b4[q] = (cgl + q < p.Cout) ? p.bias[cgl + q] : 0.0f;
+#pragma unroll
+            for (int b = 0; b < MP; ++b) {
+                const int pl = (wp * MP + b) * 32 + frow;
+                f32x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float t = acc[a][b][4 * g + q] + b4[q];
+                    if (p.act == Y3_ACT_SILU) t = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));
+                    v[q] = t;
+                }
+                *(f32x4*)(el + pl * EP + cl) = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    constexpr int CR = TC / 8;
+    constexpr int EJ = (TP * CR + 255) / 256;
+    T* __restrict__ yg = (T*)p.y;
+    const T* __restrict__ rg = (const T*)p.res;
+#pragma unroll
+    for (int j = 0; j < EJ; ++j) {
+        const int idx = tid + j * 256;
+        const int row = idx / CR, ch = idx - row * CR;
+        const int m = pt * TP + row;
+        const int c = ct * TC + ch * 8;
+        if (row < TP && m < p.M && c + 8 <= p.Cout) {
+            const f32x4 v0 = *(const f32x4*)(el + row * EP + ch * 8);
+            const f32x4 v1 = *(const f32x4*)(el + row * EP + ch * 8 + 4);
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            const int n = m / (p.Ho * p.Wo);
+            const int rem = m - n * (p.Ho * p.Wo);
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            if (rg) {
+                const uint4 rv = *(const uint4*)(rg + ((long long)(n * p.Ho + ho) * p.Wo + wo) * p.rpitch + c);
+                const T* rp = (const T*)&rv;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] += to_f32<T>(rp[q]);
+            }
+            uint4 ov;
+            T* op = (T*)&ov;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) op[q] = from_f32<T>(v[q]);
+            if (!p.ups) {
+                *(uint4*)(yg + ((long long)(n * p.Ho + ho) * p.Wo + wo) * p.ypitch + c) = ov;
+            } else {
+                const int H2 = p.Ho * 2, W2 = p.Wo * 2;
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx)
+                        *(uint4*)(yg + ((long long)(n * H2 + 2 * ho + dy) * W2 + 2 * wo + dx) * p.ypitch + c) = ov;
+            }
+        }
+    }
+}
+
 // ---- direct (one thread per output element) kernel: fp32 dtype path and debug cross-check -----------
 template <typename T>
 __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs p) {
@@ -352,7 +583,11 @@ int launch_igemm(ConvArgs& a, hipStream_t st) {
     }
     const long long nb = (long long)a.n_ct * a.n_pt;
     if (nb > 0x7fffffffLL) Y3_FAIL("conv grid too large");
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BK, WAVES_C, WAVES_P, MC, MP, SMALLC>), dim3((unsigned)nb), dim3(256), 0, st, a);
+    static const bool force_v1 = getenv("Y3_CONV_V1") != nullptr;
+    if (a.x_bytes && a.w_bytes && !force_v1)
+        hipLaunchKernelGGL((conv_igemm_v2_kernel<T, BK, WAVES_C, WAVES_P, MC, MP, SMALLC>), dim3((unsigned)nb), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<T, BK, WAVES_C, WAVES_P, MC, MP, SMALLC>), dim3((unsigned)nb), dim3(256), 0, st, a);
     Y3_CHECK_LAUNCH();
     return 0;
 }
@@ -364,9 +599,9 @@ template <typename T> int dispatch_igemm(ConvArgs& a, hipStream_t st) {
         if (c32) return launch_igemm<T, 32, 2, 2, 2, 2, false>(a, st);
         return launch_igemm<T, 32, 2, 2, 2, 2, true>(a, st);
     } else if (a.Cout > 32) {
-        if (c64) return launch_igemm<T, 64, 1, 4, 2, 2, false>(a, st);
-        if (c32) return launch_igemm<T, 32, 1, 4, 2, 2, false>(a, st);
-        return launch_igemm<T, 32, 1, 4, 2, 2, true>(a, st);
+        if (c64) return launch_igemm<T, 64, 1, 4, 2, 1, false>(a, st);
+        if (c32) return launch_igemm<T, 32, 1, 4, 2, 1, false>(a, st);
+        return launch_igemm<T, 32, 1, 4, 2, 1, true>(a, st);
     } else {
         if (c64) return launch_igemm<T, 64, 1, 4, 1, 2, false>(a, st);
         if (c32) return launch_igemm<T, 32, 1, 4, 1, 2, false>(a, st);
@@ -437,6 +672,12 @@ extern "C" int y3_conv2d_fwd(const y3_conv_desc* d, const y3_tensor* x, const vo
     a.ks = d->ksize; a.stride = d->stride; a.pad = pad; a.act = d->act; a.ups = d->upsample2x ? 1 : 0;
     a.M = x->n * Ho * Wo;
     a.Kpad = y3_filter_kpad(d->cin, d->ksize);
+    {   // byte extents reachable from the base pointers; buffer descriptors address at most 2^31 bytes here
+        const long long xb = (((long long)x->n * x->h * x->w - 1) * x->pitch + x->c) * esz;
+        const long long wb = (long long)y3_filter_rows(d->cout) * a.Kpad * esz;
+        a.x_bytes = xb < 0x7fffffffLL ? (unsigned)xb : 0u;
+        a.w_bytes = wb < 0x7fffffffLL ? (unsigned)wb : 0u;
+    }
     hipStream_t st = (hipStream_t)stream;
 
     int algo = d->algo;
