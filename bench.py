@@ -36,10 +36,17 @@ HBM_PEAK_GBS = 8000.0
 
 def igemm_variant(cin, cout):
     """Mirror of dispatch_igemm() in csrc/conv.hip: which template instance a conv launch lands on."""
+    var = os.environ.get("Y3_CONV", "v3a")
     bk = 64 if cin % 64 == 0 else 32
+    if var.startswith("v3") and cout > 64 and cin % 32 == 0:
+        if var == "v3b":
+            return "conv_igemm_v3<f16,bk32,tc128xtp256>"
+        if var == "v3c":
+            return "conv_igemm_v3<f16,bk32,tc128xtp128>"
+        return f"conv_igemm_v3<f16,bk{bk},tc128xtp128>"
     small = "" if cin % 32 == 0 else "_smallc"
     tile = "tc128xtp128" if cout > 64 else "tc64xtp128" if cout > 32 else "tc32xtp256"
-    return f"conv_igemm<f16,bk{bk},{tile}{small}>"
+    return f"conv_igemm_{'v1' if var == 'v1' else 'v2'}<f16,bk{bk},{tile}{small}>"
 
 
 def per_kernel_times(plan, reps=5):

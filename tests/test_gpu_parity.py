@@ -449,11 +449,11 @@ def test_loss_vs_oracle_variants(dev, variant):
     p_cpu = yo.synth_raw_predictions([(bs, 3, hw // s, hw // s, nc + 5) for s in (8, 16, 32)], seed=5)
     tg = yo.synth_targets(bs, nc, seed=3)
     dtype = torch.float16 if variant == "fp16" else torch.float32
-    p_ref = [t.to(dtype).float().requires_grad_(True) for t in p_cpu]
+    p_ref = [t.to(dtype).float().clone().requires_grad_(True) for t in p_cpu]
     ref_loss, ref_items, _ = yo.compute_loss(p_ref, tg, m.model[-1].anchors.cpu(), hyp, nc)
     scale = 1024.0 if variant in ("fp32_scaled_grad", "fp16") else 1.0  # GradScaler-style upstream gradient
     (ref_loss * scale).sum().backward()
-    p = [t.to(dev).to(dtype).requires_grad_(True) for t in p_cpu]
+    p = [t.detach().to(dev).to(dtype).requires_grad_(True) for t in p_cpu]
     loss, items = crit(p, tg.to(dev))
     (loss * scale).sum().backward()
     torch.cuda.synchronize()
