@@ -537,6 +537,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_v2_kernel(const ConvArgs p)
 // WAVES 2x2; per-wave tile (MC*32 couts) x (MP*32 pixels).
 template <typename T, int BK, int MC, int MP>
 __global__ __launch_bounds__(256, 2) void conv_igemm_v3_kernel(const ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // device-only builtins (LDS address space, buffer->LDS DMA): the host pass only needs the stub
     constexpr int WAVES_C = 2, WAVES_P = 2;
     constexpr int TC = WAVES_C * MC * 32;
     constexpr int TP = WAVES_P * MP * 32;
@@ -735,6 +736,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_v3_kernel(const ConvArgs p)
         }
         if (h + 1 < WAVES_P) __syncthreads();
     }
+#endif
 }
 
 template <typename T, int BK, int MC, int MP> int launch_v3(ConvArgs& a, hipStream_t st) {
