@@ -34,16 +34,22 @@ MFMA_PEAK_TFLOPS = 2500.0  # dense fp16/bf16, /opt/skills/guides/MI355X_MICROARC
 HBM_PEAK_GBS = 8000.0
 
 
-def igemm_variant(cin, cout):
+def igemm_variant(cin, cout, k=1, m=1 << 30):
     """Mirror of dispatch_igemm() in csrc/conv.hip: which template instance a conv launch lands on."""
-    var = os.environ.get("Y3_CONV", "v3a")
+    var = os.environ.get("Y3_CONV", "auto")
     bk = 64 if cin % 64 == 0 else 32
-    if var.startswith("v3") and cout > 64 and cin % 32 == 0:
+    if (var.startswith("v3") or var == "auto") and cout > 64 and cin % 32 == 0:
         if var == "v3b":
             return "conv_igemm_v3<f16,bk32,tc128xtp256>"
         if var == "v3c":
             return "conv_igemm_v3<f16,bk32,tc128xtp128>"
-        return f"conv_igemm_v3<f16,bk{bk},tc128xtp128>"
+        if var == "v3a":
+            return f"conv_igemm_v3<f16,bk{bk},tc128xtp128>"
+        if bk == 32 or k * k * cin <= 1152:
+            return "conv_igemm_v3<f16,bk32,tc128xtp128>"
+        if m <= 16384:
+            return "conv_igemm_v3<f16,bk32,tc128xtp256>"
+        return "conv_igemm_v3<f16,bk64,tc128xtp128>"
     small = "" if cin % 32 == 0 else "_smallc"
     tile = "tc128xtp128" if cout > 64 else "tc64xtp128" if cout > 32 else "tc32xtp256"
     return f"conv_igemm_{'v1' if var == 'v1' else 'v2'}<f16,bk{bk},{tile}{small}>"
@@ -68,7 +74,7 @@ def per_kernel_times(plan, reps=5):
         for ln, e0, e1 in evs:
             if ln.flops:
                 w = ln.keep[4]
-                key = igemm_variant(w.cin, w.cout)
+                key = igemm_variant(w.cin, w.cout, w.k, int(ln.flops / (2.0 * w.cout * w.cin * w.k * w.k)))
             else:
                 key = ln.label.split(".")[-1]
             a = acc.setdefault(key, [0.0, 0.0, 0.0, 0])

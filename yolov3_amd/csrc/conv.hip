@@ -64,7 +64,7 @@ Y3_DEV int xcd_remap(int b, int nb) {
     return base + i;
 }
 
-// tuning knob for A/B runs: Y3_CONV=v1|v2|v3a|v3b|v3c (default v3a); v3 covers Cout > 64, Cin % 32 == 0
+// tuning knob for A/B runs: Y3_CONV=v1|v2|v3a|v3b|v3c (default: per-shape choice among the v3 tiles); v3 covers Cout > 64, Cin % 32 == 0
 static int conv_variant() {
     static const int v = [] {
         const char* e = getenv("Y3_CONV");
@@ -73,6 +73,7 @@ static int conv_variant() {
         if (!strcmp(e, "v2")) return 2;
         if (!strcmp(e, "v3b")) return 4;
         if (!strcmp(e, "v3c")) return 5;
+        if (!strcmp(e, "v3a")) return 6;
         return 3;
     }();
     return v;
@@ -837,7 +838,13 @@ template <typename T> int dispatch_igemm(ConvArgs& a, hipStream_t st) {
     if (var >= 3 && a.Cout > 64 && c32 && a.x_bytes && a.w_bytes) {
         if (var == 4) return launch_v3<T, 32, 2, 4>(a, st);   // 128c x 256p, BK 32
         if (var == 5) return launch_v3<T, 32, 2, 2>(a, st);   // 128c x 128p, BK 32 (4 blocks / CU)
-        return c64 ? launch_v3<T, 64, 2, 2>(a, st) : launch_v3<T, 32, 2, 2>(a, st);
+        if (var == 6) return c64 ? launch_v3<T, 64, 2, 2>(a, st) : launch_v3<T, 32, 2, 2>(a, st);
+        // auto (measured on MI355X, profiles/r01_conv_variants.md): short K loops want 4 resident blocks per CU
+        // (BK 32), small pixel counts with long K want the 128x256 tile, the rest the BK 64 128x128 tile.
+        const int K = a.ks * a.ks * a.Cin;
+        if (!c64 || K <= 1152) return launch_v3<T, 32, 2, 2>(a, st);
+        if (a.M <= 16384) return launch_v3<T, 32, 2, 4>(a, st);
+        return launch_v3<T, 64, 2, 2>(a, st);
     }
     if (a.Cout > 64) {
         if (c64) return launch_igemm<T, 64, 2, 2, 2, 2, false>(a, st);
