@@ -51,6 +51,9 @@ typedef struct {
     int32_t algo;       /* y3_algo; AUTO = MFMA for F16/BF16, DIRECT for F32 */
     int32_t cin;        /* logical input channels of the packed filter (x->c must equal it) */
     int32_t cout;       /* output channels stored (multiple of 8; pad filters with zero rows) */
+    int32_t in_dilation; /* 0/1 = plain; 2 = x is a virtual zero-interleaved (2h x 2w) image: data-gradient of a
+                            stride-2 conv = stride-1 conv of the dilated output gradient with the flipped, transposed
+                            filter (y3_pack_filter_dgrad); y's height/width then give the gradient's size */
 } y3_conv_desc;
 
 int y3_abi_version(void);
@@ -145,6 +148,38 @@ int y3_loss_fwd(const y3_loss_params* p, int32_t dtype, const void* const* preds
                 float* out4, void* workspace, size_t workspace_bytes, void* stream);
 int y3_loss_bwd(const y3_loss_params* p, int32_t dtype, const void* const* preds, const float* targets, int32_t nt,
                 const float* grad_out, void* const* grads, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------- training
+ * Train-mode `Conv` = act(bn(conv(x))) with BATCH statistics (reference models/common.py:75; BN eps 1e-3 / momentum
+ * 0.03 set at models/yolo.py:229) and the autograd of the graph, decomposed as:
+ *   forward : u = y3_conv2d_fwd(x)            (act NONE, zero bias; u is kept for the backward)
+ *             y3_bn_stats(u) -> y3_bn_finalize -> y = y3_bn_act_fwd(u [, residual])
+ *   backward: du = y3_bn_act_bwd(u, dy)       (also gives dgamma, dbeta)
+ *             dW = y3_conv2d_wgrad(x, du)     (fp32 OIHW, the layout of nn.Conv2d.weight.grad)
+ *             dx (+)= y3_conv2d_fwd(du, filter packed by y3_pack_filter_dgrad [, residual = dx, in_dilation = stride])
+ * `sums` is a caller-owned scratch of 2*C doubles; all per-channel vectors are DEVICE fp32. */
+int y3_bn_stats(const y3_tensor* u, int32_t dtype, double* sums, void* stream);
+int y3_bn_finalize(const double* sums, int64_t count, int32_t channels, const float* gamma, const float* beta, float eps,
+                   float momentum, float* running_mean /* updated in place, may be NULL */, float* running_var,
+                   float* scale, float* shift, float* mean, float* invstd, void* stream);
+int y3_bn_act_fwd(const y3_tensor* u, const float* scale, const float* shift, const y3_tensor* residual /* may be NULL */,
+                  const y3_tensor* y, int32_t dtype, int32_t act, void* stream);
+int y3_bn_act_bwd(const y3_tensor* u, const y3_tensor* dy, const float* scale, const float* shift, const float* mean,
+                  const float* invstd, int32_t dtype, int32_t act, double* sums, const y3_tensor* du,
+                  float* dgamma /* may be NULL */, float* dbeta /* may be NULL */, void* stream);
+/* OIHW fp32 -> filter bank of the data-gradient convolution: `cin` filters over (kh, kw, cout) with flipped taps. */
+int y3_pack_filter_dgrad(const float* w_oihw, int32_t cout_src, int32_t cin_src, int32_t ksize, int32_t cout, int32_t cin,
+                         int32_t dtype, void* packed, void* stream);
+/* filter gradient (and optional bias gradient = per-channel sum of du) of the conv described by `desc`
+ * (dtype, ksize, stride, cin, cout = padded sizes of x / du); dw is (cout_real, cin_real, k, k) fp32, overwritten. */
+int y3_conv2d_wgrad(const y3_conv_desc* desc, const y3_tensor* x, const y3_tensor* du, int32_t cout_real, int32_t cin_real,
+                    float* dw_oihw, float* dbias /* may be NULL */, void* stream);
+/* backward of nn.Upsample(x2, nearest) / nn.MaxPool2d (+ZeroPad2d) / Detect's view+permute (models/yolo.py:98) */
+int y3_upsample2x_bwd(const y3_tensor* dy, const y3_tensor* dx, int32_t dtype, int32_t accumulate, void* stream);
+int y3_maxpool2d_bwd(const y3_tensor* x, const y3_tensor* dy, const y3_tensor* dx, int32_t dtype, int32_t k, int32_t stride,
+                     int32_t pad, int32_t zpad_r, int32_t zpad_b, int32_t accumulate, void* stream);
+int y3_detect_raw_bwd(const void* graw, int32_t dtype, int32_t bs, int32_t na, int32_t ny, int32_t nx, int32_t no,
+                      const y3_tensor* ghead, void* stream);
 
 #ifdef __cplusplus
 }

@@ -27,6 +27,7 @@ class Y3ConvDesc(C.Structure):
         ("algo", C.c_int32),
         ("cin", C.c_int32),
         ("cout", C.c_int32),
+        ("in_dilation", C.c_int32),
     ]
 
 
@@ -88,6 +89,21 @@ _SIGNATURES = {
     "y3_loss_workspace_bytes": (C.c_size_t, [_P(Y3LossParams), C.c_int32]),
     "y3_loss_fwd": (C.c_int, [_P(Y3LossParams), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "y3_loss_bwd": (C.c_int, [_P(Y3LossParams), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "y3_bn_stats": (C.c_int, [_P(Y3Tensor), C.c_int32, C.c_void_p, C.c_void_p]),
+    "y3_bn_finalize": (
+        C.c_int,
+        [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
+    "y3_bn_act_fwd": (C.c_int, [_P(Y3Tensor), C.c_void_p, C.c_void_p, _P(Y3Tensor), _P(Y3Tensor), C.c_int32, C.c_int32, C.c_void_p]),
+    "y3_bn_act_bwd": (
+        C.c_int,
+        [_P(Y3Tensor), _P(Y3Tensor), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, _P(Y3Tensor), C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
+    "y3_pack_filter_dgrad": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "y3_conv2d_wgrad": (C.c_int, [_P(Y3ConvDesc), _P(Y3Tensor), _P(Y3Tensor), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "y3_upsample2x_bwd": (C.c_int, [_P(Y3Tensor), _P(Y3Tensor), C.c_int32, C.c_int32, C.c_void_p]),
+    "y3_maxpool2d_bwd": (C.c_int, [_P(Y3Tensor), _P(Y3Tensor), _P(Y3Tensor), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "y3_detect_raw_bwd": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P(Y3Tensor), C.c_void_p]),
 }
 
 _lib = None

@@ -26,6 +26,7 @@ SOURCES = [
     ("layout_pool.hip", []),
     ("detect_nms.hip", ["-ffp-contract=off"]),
     ("loss.hip", ["-ffp-contract=off"]),
+    ("train.hip", []),
     ("api.cpp", []),
 ]
 

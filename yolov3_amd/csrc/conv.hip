@@ -32,6 +32,7 @@ struct ConvArgs {
     int rpitch;
     int ks, stride, pad;
     int act, ups;
+    int dil_shift;  // 0: plain conv; 1: the input is a virtual zero-interleaved (x2) image (stride-2 dgrad)
     int M;          // N*Ho*Wo
     int Kpad;       // packed filter row length (elements)
     int nk;         // K iterations
@@ -64,12 +65,11 @@ Y3_DEV int xcd_remap(int b, int nb) {
     return base + i;
 }
 
-// tuning knob for A/B runs: Y3_CONV=v1|v2|v3a|v3b|v3c (default: per-shape choice among the v3 tiles); v3 covers Cout > 64, Cin % 32 == 0
+// tuning knob for A/B runs: Y3_CONV=v2|v3a|v3b|v3c (default: per-shape choice among the v3 tiles); v3 covers Cout > 64, Cin % 32 == 0
 static int conv_variant() {
     static const int v = [] {
         const char* e = getenv("Y3_CONV");
         if (!e) return 3;
-        if (!strcmp(e, "v1")) return 1;
         if (!strcmp(e, "v2")) return 2;
         if (!strcmp(e, "v3b")) return 4;
         if (!strcmp(e, "v3c")) return 5;
@@ -79,225 +79,14 @@ static int conv_variant() {
     return v;
 }
 
-template <typename T, int BK, int WAVES_C, int WAVES_P, int MC, int MP, bool SMALLC>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
-    constexpr int TC = WAVES_C * MC * 32;
-    constexpr int TP = WAVES_P * MP * 32;
-    constexpr int S = BK / 8;                 // 16-byte slots per tile row
-    constexpr int WJ = (TC * S + 255) / 256;  // filter chunks per thread per K-step
-    constexpr int XJ = (TP * S + 255) / 256;  // pixel chunks per thread per K-step
-    constexpr int STAGE_BYTES = (TC + TP) * BK * 2;
-    constexpr int EP = TC + 4;                // fp32 epilogue row pitch (floats)
-    constexpr int EPI_BYTES = TP * EP * 4;
-    constexpr int LDS_BYTES = 2 * STAGE_BYTES > EPI_BYTES ? 2 * STAGE_BYTES : EPI_BYTES;
-    static_assert(WAVES_C * WAVES_P == 4, "4 waves");
-    typedef typename Mfma<T>::frag frag;
-
-    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wv = tid >> 6;
-    const int wc = wv / WAVES_P, wp = wv % WAVES_P;
-
-    const int L = xcd_remap(blockIdx.x, gridDim.x);
-    const int pt = L / p.n_ct, ct = L % p.n_ct;
-
-    const T* __restrict__ xg = (const T*)p.x;
-    const T* __restrict__ wg = (const T*)p.w;
-
-    // ---- per-thread gather bookkeeping (fixed 16-byte slot, XJ pixel rows / WJ filter rows) ----
-    const int slot = tid % S;
-    const int row0 = tid / S;                 // rows: row0 + j * (256 / S)
-    constexpr int ROWSTEP = 256 / S;
-
-    long long xbase[XJ];                      // element offset of (n, hi0, wi0, 0); may point outside -> guarded
-    int hi0[XJ], wi0[XJ];
-    bool mvalid[XJ];
-#pragma unroll
-    for (int j = 0; j < XJ; ++j) {
-        const int row = row0 + j * ROWSTEP;
-        const int m = pt * TP + row;
-        const bool v = (row < TP) && (m < p.M);
-        const int mm = v ? m : 0;
-        const int n = mm / (p.Ho * p.Wo);
-        const int rem = mm - n * (p.Ho * p.Wo);
-        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-        hi0[j] = ho * p.stride - p.pad;
-        wi0[j] = wo * p.stride - p.pad;
-        xbase[j] = ((long long)(n * p.H + hi0[j]) * p.W + wi0[j]) * p.xpitch;
-        mvalid[j] = v;
-    }
-    long long wbase[WJ];
-#pragma unroll
-    for (int j = 0; j < WJ; ++j) {
-        const int row = row0 + j * ROWSTEP;
-        wbase[j] = (long long)(ct * TC + (row < TC ? row : 0)) * p.Kpad + slot * 8;
-    }
-
-    uint4 xr[XJ], wr[WJ];
-
-    auto load_tile = [&](int it) {
-        int kh, kw, c0;
-        bool tapok = true;
-        if (SMALLC) {
-            const int cg = p.Cin >> 3;                 // 8-channel groups per tap (1 or 2 or 3)
-            const int g = it * S + slot;
-            const int tap = g / cg;
-            c0 = (g - tap * cg) * 8;
-            kh = tap / p.ks;
-            kw = tap - kh * p.ks;
-            tapok = tap < p.ks * p.ks;
-        } else {
-            const int tap = it / p.cin_blocks;
-            const int cb = it - tap * p.cin_blocks;
-            kh = tap / p.ks;
-            kw = tap - kh * p.ks;
-            c0 = cb * BK + slot * 8;
-        }
-        const long long tapoff = (long long)(kh * p.W + kw) * p.xpitch + c0;
-#pragma unroll
-        for (int j = 0; j < XJ; ++j) {
-            const int hi = hi0[j] + kh, wi = wi0[j] + kw;
-            const bool ok = tapok && mvalid[j] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (ok) v = *(const uint4*)(xg + xbase[j] + tapoff);
-            xr[j] = v;
-        }
-#pragma unroll
-        for (int j = 0; j < WJ; ++j) {
-            const int row = row0 + j * ROWSTEP;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (row < TC) v = *(const uint4*)(wg + wbase[j] + (long long)it * BK);
-            wr[j] = v;
-        }
-    };
-    auto store_tile = [&](int stage) {
-        unsigned char* wl = smem + stage * STAGE_BYTES;
-        unsigned char* xl = wl + TC * BK * 2;
-#pragma unroll
-        for (int j = 0; j < WJ; ++j) {
-            const int row = row0 + j * ROWSTEP;
-            if (row < TC) *(uint4*)(wl + row * (BK * 2) + ((slot ^ swz<BK>(row)) << 4)) = wr[j];
-        }
-#pragma unroll
-        for (int j = 0; j < XJ; ++j) {
-            const int row = row0 + j * ROWSTEP;
-            if (row < TP) *(uint4*)(xl + row * (BK * 2) + ((slot ^ swz<BK>(row)) << 4)) = xr[j];
-        }
-    };
-
-    f32x16 acc[MC][MP];
-#pragma unroll
-    for (int a = 0; a < MC; ++a)
-#pragma unroll
-        for (int b = 0; b < MP; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-
-    const int frow = lane & 31;       // fragment row within a 32-tile
-    const int fk = lane >> 5;         // which 8-wide k half of a 16-wide MFMA step
-
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-
-    for (int it = 0; it < p.nk; ++it) {
-        const int cur = it & 1;
-        if (it + 1 < p.nk) load_tile(it + 1);
-
-        const unsigned char* wl = smem + cur * STAGE_BYTES;
-        const unsigned char* xl = wl + TC * BK * 2;
-#pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            frag af[MC], bf[MP];
-            const int ks = kk * 2 + fk;
-#pragma unroll
-            for (int a = 0; a < MC; ++a) {
-                const int row = (wc * MC + a) * 32 + frow;
-                af[a] = *(const frag*)(wl + row * (BK * 2) + ((ks ^ swz<BK>(row)) << 4));
-            }
-#pragma unroll
-            for (int b = 0; b < MP; ++b) {
-                const int row = (wp * MP + b) * 32 + frow;
-                bf[b] = *(const frag*)(xl + row * (BK * 2) + ((ks ^ swz<BK>(row)) << 4));
-            }
-#pragma unroll
-            for (int a = 0; a < MC; ++a)
-#pragma unroll
-                for (int b = 0; b < MP; ++b) acc[a][b] = Mfma<T>::run(af[a], bf[b], acc[a][b]);
-        }
-
-        if (it + 1 < p.nk) store_tile(cur ^ 1);
-        __syncthreads();
-    }
-
-    // ---- epilogue: bias + activation in registers -> fp32 tile in LDS -> coalesced row stores ----
-    float* el = (float*)smem;
-#pragma unroll
-    for (int a = 0; a < MC; ++a) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int cl = (wc * MC + a) * 32 + 8 * g + 4 * fk;  // cout within tile (4 consecutive)
-            const int cgl = ct * TC + cl;
-            float b4[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) b4[q] = (cgl + q < p.Cout) ? p.bias[cgl + q] : 0.0f;
-#pragma unroll
-            for (int b = 0; b < MP; ++b) {
-                const int pl = (wp * MP + b) * 32 + frow;         // pixel within tile
-                f32x4 v;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float t = acc[a][b][4 * g + q] + b4[q];
-                    if (p.act == Y3_ACT_SILU) t = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));
-                    v[q] = t;
-                }
-                *(f32x4*)(el + pl * EP + cl) = v;
-            }
-        }
-    }
-    __syncthreads();
-
-    constexpr int CR = TC / 8;              // 8-cout chunks per pixel row
-    constexpr int EJ = (TP * CR + 255) / 256;
-    T* __restrict__ yg = (T*)p.y;
-    const T* __restrict__ rg = (const T*)p.res;
-#pragma unroll
-    for (int j = 0; j < EJ; ++j) {
-        const int idx = tid + j * 256;
-        const int row = idx / CR, ch = idx - row * CR;
-        const int m = pt * TP + row;
-        const int c = ct * TC + ch * 8;
-        if (row < TP && m < p.M && c + 8 <= p.Cout) {
-            const f32x4 v0 = *(const f32x4*)(el + row * EP + ch * 8);
-            const f32x4 v1 = *(const f32x4*)(el + row * EP + ch * 8 + 4);
-            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            const int n = m / (p.Ho * p.Wo);
-            const int rem = m - n * (p.Ho * p.Wo);
-            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-            if (rg) {
-                const uint4 rv = *(const uint4*)(rg + ((long long)(n * p.Ho + ho) * p.Wo + wo) * p.rpitch + c);
-                const T* rp = (const T*)&rv;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] += to_f32<T>(rp[q]);
-            }
-            uint4 ov;
-            T* op = (T*)&ov;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) op[q] = from_f32<T>(v[q]);
-            if (!p.ups) {
-                *(uint4*)(yg + ((long long)(n * p.Ho + ho) * p.Wo + wo) * p.ypitch + c) = ov;
-            } else {
-                const int H2 = p.Ho * 2, W2 = p.Wo * 2;
-#pragma unroll
-                for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                    for (int dx = 0; dx < 2; ++dx)
-                        *(uint4*)(yg + ((long long)(n * H2 + 2 * ho + dy) * W2 + 2 * wo + dx) * p.ypitch + c) = ov;
-            }
-        }
-    }
+// Gather helpers shared by the MFMA kernels.  (hi, wi) are coordinates in the (virtually dilated) input image.
+Y3_DEV bool in_image(int hi, int wi, const ConvArgs& p) {
+    const int msk = (1 << p.dil_shift) - 1;
+    return ((hi | wi) & msk) == 0 && (unsigned)(hi >> p.dil_shift) < (unsigned)p.H && (unsigned)(wi >> p.dil_shift) < (unsigned)p.W;
+}
+Y3_DEV int tap_bytes(int hi0, int wi0, int kh, int kw, int c0, const ConvArgs& p) {
+    const int hi = (hi0 + kh) >> p.dil_shift, wi = (wi0 + kw) >> p.dil_shift;
+    return ((hi * p.W + wi) * p.xpitch + c0) * 2;
 }
 
 // ---- v2 main loop: branch-free buffer loads (out-of-range lanes read 0 through the descriptor's bounds check, so
@@ -353,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_v2_kernel(const ConvArgs p)
         const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
         hi0[j] = ho * p.stride - p.pad;
         wi0[j] = wo * p.stride - p.pad;
-        xoff[j] = (int)((((long long)(n * p.H + hi0[j]) * p.W + wi0[j]) * p.xpitch) * 2);
+        xoff[j] = (int)(((long long)n * p.H * p.W * p.xpitch) * 2);  // byte offset of image n
         mvalid[j] = v;
     }
     unsigned woff[WJ];
@@ -383,12 +172,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_v2_kernel(const ConvArgs p)
             kw = tap - kh * p.ks;
             c0 = cb * BK + slot * 8;
         }
-        const int tapoff = ((kh * p.W + kw) * p.xpitch + c0) * 2;
 #pragma unroll
         for (int j = 0; j < XJ; ++j) {
             const int hi = hi0[j] + kh, wi = wi0[j] + kw;
-            const bool ok = tapok && mvalid[j] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            xr[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, ok ? (unsigned)(xoff[j] + tapoff) : OOB, 0, 0);
+            const bool ok = tapok && mvalid[j] && in_image(hi, wi, p);
+            xr[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, ok ? (unsigned)(xoff[j] + tap_bytes(hi0[j], wi0[j], kh, kw, c0, p)) : OOB, 0, 0);
         }
         const unsigned wk = it < p.nk ? (unsigned)(it * BK * 2) : OOB;
 #pragma unroll
@@ -587,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_v3_kernel(const ConvArgs p)
         const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
         hi0[j] = ho * p.stride - p.pad;
         wi0[j] = wo * p.stride - p.pad;
-        xoff[j] = (int)((((long long)(n * p.H + hi0[j]) * p.W + wi0[j]) * p.xpitch) * 2);
+        xoff[j] = (int)(((long long)n * p.H * p.W * p.xpitch) * 2);  // byte offset of image n
         xc0[j] = ((pslot ^ swz<BK>(row)) * 8) * 2;          // byte offset of the logical slot inside the K-step
         mvalid[j] = v;
     }
@@ -602,7 +390,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_v3_kernel(const ConvArgs p)
         const int tap = it / p.cin_blocks;
         const int cb = it - tap * p.cin_blocks;
         const int kh = tap / p.ks, kw = tap - kh * p.ks;
-        const int tapoff = ((kh * p.W + kw) * p.xpitch + cb * BK) * 2;
         unsigned char* wl = smem + stage * STAGE_BYTES;
         unsigned char* xl = wl + W_BYTES;
 #pragma unroll
@@ -611,8 +398,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_v3_kernel(const ConvArgs p)
 #pragma unroll
         for (int j = 0; j < XJ; ++j) {
             const int hi = hi0[j] + kh, wi = wi0[j] + kw;
-            const bool ok = mvalid[j] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(xl + (j * 256 + wv * 64) * 16), 16, ok ? (unsigned)(xoff[j] + tapoff + xc0[j]) : OOB, 0, 0, 0);
+            const bool ok = mvalid[j] && in_image(hi, wi, p);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(xl + (j * 256 + wv * 64) * 16), 16,
+                                                     ok ? (unsigned)(xoff[j] + tap_bytes(hi0[j], wi0[j], kh, kw, cb * BK, p) + xc0[j]) : OOB, 0, 0, 0);
         }
     };
 
@@ -768,11 +556,11 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs p) {
     const T* wg = (const T*)p.w + (long long)c * p.Kpad;
     float acc = 0.0f;
     for (int kh = 0; kh < p.ks; ++kh) {
-        const int hi = ho * p.stride - p.pad + kh;
-        if ((unsigned)hi >= (unsigned)p.H) continue;
+        const int hv = ho * p.stride - p.pad + kh;
         for (int kw = 0; kw < p.ks; ++kw) {
-            const int wi = wo * p.stride - p.pad + kw;
-            if ((unsigned)wi >= (unsigned)p.W) continue;
+            const int wv = wo * p.stride - p.pad + kw;
+            if (!in_image(hv, wv, p)) continue;
+            const int hi = hv >> p.dil_shift, wi = wv >> p.dil_shift;
             const T* xp = xg + ((long long)(n * p.H + hi) * p.W + wi) * p.xpitch;
             const T* wp = wg + (kh * p.ks + kw) * p.Cin;
             for (int ci = 0; ci < p.Cin; ++ci) acc = fmaf(to_f32<T>(xp[ci]), to_f32<T>(wp[ci]), acc);
@@ -824,10 +612,7 @@ int launch_igemm(ConvArgs& a, hipStream_t st) {
     }
     const long long nb = (long long)a.n_ct * a.n_pt;
     if (nb > 0x7fffffffLL) Y3_FAIL("conv grid too large");
-    if (a.x_bytes && a.w_bytes && conv_variant() != 1)
-        hipLaunchKernelGGL((conv_igemm_v2_kernel<T, BK, WAVES_C, WAVES_P, MC, MP, SMALLC>), dim3((unsigned)nb), dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL((conv_igemm_kernel<T, BK, WAVES_C, WAVES_P, MC, MP, SMALLC>), dim3((unsigned)nb), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_igemm_v2_kernel<T, BK, WAVES_C, WAVES_P, MC, MP, SMALLC>), dim3((unsigned)nb), dim3(256), 0, st, a);
     Y3_CHECK_LAUNCH();
     return 0;
 }
@@ -900,8 +685,18 @@ extern "C" int y3_conv2d_fwd(const y3_conv_desc* d, const y3_tensor* x, const vo
     if (x->c != d->cin) Y3_FAIL("y3_conv2d_fwd: x has %d channels, filter expects %d", x->c, d->cin);
     if ((d->cin % 8) || (d->cout % 8)) Y3_FAIL("y3_conv2d_fwd: cin/cout must be multiples of 8 (%d/%d)", d->cin, d->cout);
     const int pad = d->ksize / 2;
-    const int Ho = (x->h + 2 * pad - d->ksize) / d->stride + 1;
-    const int Wo = (x->w + 2 * pad - d->ksize) / d->stride + 1;
+    const int dil = d->in_dilation == 2 ? 2 : 1;
+    if (d->in_dilation != 0 && d->in_dilation != 1 && d->in_dilation != 2) Y3_FAIL("y3_conv2d_fwd: in_dilation %d unsupported", d->in_dilation);
+    if (dil == 2 && (d->stride != 1 || d->upsample2x)) Y3_FAIL("y3_conv2d_fwd: in_dilation 2 needs stride 1 and no upsample");
+    // dilated input (stride-2 dgrad): the output size is the caller's (2h-1 or 2h, the forward conv's input size)
+    int Ho = (x->h + 2 * pad - d->ksize) / d->stride + 1;
+    int Wo = (x->w + 2 * pad - d->ksize) / d->stride + 1;
+    if (dil == 2) {
+        if (y->h != 2 * x->h && y->h != 2 * x->h - 1) Y3_FAIL("y3_conv2d_fwd: dilated output height %d does not match input %d", y->h, x->h);
+        if (y->w != 2 * x->w && y->w != 2 * x->w - 1) Y3_FAIL("y3_conv2d_fwd: dilated output width %d does not match input %d", y->w, x->w);
+        Ho = y->h;
+        Wo = y->w;
+    }
     const int up = d->upsample2x ? 2 : 1;
     if (y->n != x->n || y->h != Ho * up || y->w != Wo * up || y->c != d->cout)
         Y3_FAIL("y3_conv2d_fwd: output is (%d,%d,%d,%d), expected (%d,%d,%d,%d)", y->n, y->h, y->w, y->c, x->n, Ho * up, Wo * up, d->cout);
@@ -922,6 +717,7 @@ extern "C" int y3_conv2d_fwd(const y3_conv_desc* d, const y3_tensor* x, const vo
     a.N = x->n; a.H = x->h; a.W = x->w; a.Cin = d->cin; a.xpitch = x->pitch;
     a.Ho = Ho; a.Wo = Wo; a.Cout = d->cout; a.ypitch = y->pitch; a.rpitch = res ? res->pitch : 0;
     a.ks = d->ksize; a.stride = d->stride; a.pad = pad; a.act = d->act; a.ups = d->upsample2x ? 1 : 0;
+    a.dil_shift = dil == 2 ? 1 : 0;
     a.M = x->n * Ho * Wo;
     a.Kpad = y3_filter_kpad(d->cin, d->ksize);
     {   // byte extents reachable from the base pointers; buffer descriptors address at most 2^31 bytes here

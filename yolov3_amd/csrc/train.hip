@@ -1,0 +1,491 @@
+// Training-side kernels (gfx950): batch-statistics BatchNorm + SiLU forward/backward, filter gradients,
+// data-gradient filter packing, and the backward of the parameter-free layers.
+//
+// Reference semantics: `Conv.forward` in train mode = act(bn(conv(x))) with nn.BatchNorm2d(eps 1e-3, momentum 0.03)
+// using BATCH statistics (models/common.py:75, models/yolo.py:229); autograd of conv2d / batch_norm / silu /
+// upsample_nearest2d / cat / max_pool2d.  The data gradient of a convolution reuses the forward
+// implicit-GEMM kernel (conv.hip) on the output gradient with the flipped+transposed filter bank packed here.
+//
+// Statistics are accumulated in fp64 (per-thread partials -> LDS tree -> one fp64 atomicAdd per channel per block):
+// E[x^2]-E[x]^2 in fp32 would not hold the 1e-4 parity bar, and fp64 makes the atomics' ordering invisible.
+#include "y3_common.h"
+
+namespace {
+
+template <typename T> struct V16 {  // one 16-byte vector of T
+    static constexpr int N = 16 / sizeof(T);
+    T v[N];
+};
+
+Y3_DEV float silu_grad(float z, float s) { return s + z * s * (1.0f - s); }  // d silu(z)/dz with s = sigmoid(z)
+
+unsigned nblk(long long total) { return (unsigned)((total + 255) / 256); }
+int esize(int dtype) { return dtype == Y3_F32 ? 4 : 2; }
+bool vec_ok(const y3_tensor* t, int esz) {
+    const int v = 16 / esz;
+    return (t->c % v) == 0 && (t->pitch % v) == 0 && (((uintptr_t)t->data) & 15) == 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Per-channel reductions over N*H*W.  MODE 0: (sum u, sum u^2).  MODE 1: (sum dz, sum dz*xhat) for the BN+act backward.
+// Thread t owns channel vector (t % CG) on pixel lane (t / CG); CG = C / V (<= 256).
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void channel_reduce_kernel(const T* __restrict__ u, int upitch, const T* __restrict__ dy, int dpitch, long long M, int C,
+                                                               const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd, int act,
+                                                               double* __restrict__ sums) {
+    constexpr int V = V16<T>::N;
+    __shared__ double red[256 * 2];
+    const int CG = C / V;
+    const int PL = 256 / CG;
+    const int tid = threadIdx.x;
+    const int cg = tid % CG, pl = tid / CG;
+    double a0[V], a1[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) a0[q] = a1[q] = 0.0;
+    if (pl < PL) {
+        float sc[V], sh[V], mu[V], is[V];
+        if (MODE == 1) {
+#pragma unroll
+            for (int q = 0; q < V; ++q) { sc[q] = scale[cg * V + q]; sh[q] = shift[cg * V + q]; mu[q] = mean[cg * V + q]; is[q] = invstd[cg * V + q]; }
+        }
+        for (long long m = (long long)blockIdx.x * PL + pl; m < M; m += (long long)gridDim.x * PL) {
+            const V16<T> x = *(const V16<T>*)(u + m * upitch + cg * V);
+            if (MODE == 0) {
+#pragma unroll
+                for (int q = 0; q < V; ++q) { const double f = (double)to_f32<T>(x.v[q]); a0[q] += f; a1[q] += f * f; }
+            } else {
+                const V16<T> g = *(const V16<T>*)(dy + m * dpitch + cg * V);
+#pragma unroll
+                for (int q = 0; q < V; ++q) {
+                    const float uf = to_f32<T>(x.v[q]);
+                    float dz = to_f32<T>(g.v[q]);
+                    if (act == Y3_ACT_SILU) {
+                        const float z = uf * sc[q] + sh[q];
+                        const float s = 1.0f / (1.0f + expf(-z));
+                        dz *= silu_grad(z, s);
+                    }
+                    const float xh = (uf - mu[q]) * is[q];
+                    a0[q] += (double)dz;
+                    a1[q] += (double)dz * (double)xh;
+                }
+            }
+        }
+    }
+    // reduce over pixel lanes: one channel at a time through LDS (keeps LDS at 4 KiB)
+    for (int q = 0; q < V; ++q) {
+        red[tid * 2] = a0[q];
+        red[tid * 2 + 1] = a1[q];
+        __syncthreads();
+        if (pl == 0) {
+            double s0 = 0.0, s1 = 0.0;
+            for (int k = 0; k < PL; ++k) { s0 += red[(k * CG + cg) * 2]; s1 += red[(k * CG + cg) * 2 + 1]; }
+            atomicAdd(&sums[(cg * V + q) * 2], s0);
+            atomicAdd(&sums[(cg * V + q) * 2 + 1], s1);
+        }
+        __syncthreads();
+    }
+}
+
+// sums -> mean / biased var -> (scale, shift) of the normalisation, running-stat update (momentum, unbiased var)
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float eps, float momentum, float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ scale,
+                                   float* __restrict__ shift, float* __restrict__ mean, float* __restrict__ invstd) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double mu = sums[c * 2] / count;
+    double var = sums[c * 2 + 1] / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
+    mean[c] = (float)mu;
+    invstd[c] = is;
+    scale[c] = g * is;
+    shift[c] = b - (float)mu * g * is;
+    if (rmean) rmean[c] = (1.0f - momentum) * rmean[c] + momentum * (float)mu;
+    if (rvar) rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (float)(count > 1.0 ? var * count / (count - 1.0) : var);
+}
+
+// y = act(u*scale + shift) (+ residual)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ u, int upitch, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const T* __restrict__ res, int rpitch, T* __restrict__ y, int ypitch, long long M, int C, int act) {
+    constexpr int V = V16<T>::N;
+    const int cv = C / V;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= M * cv) return;
+    const long long m = idx / cv;
+    const int c0 = (int)(idx - m * cv) * V;
+    const V16<T> x = *(const V16<T>*)(u + m * upitch + c0);
+    V16<T> r;
+    if (res) r = *(const V16<T>*)(res + m * rpitch + c0);
+    V16<T> o;
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+        float z = to_f32<T>(x.v[q]) * scale[c0 + q] + shift[c0 + q];
+        if (act == Y3_ACT_SILU) z = z / (1.0f + expf(-z));
+        if (res) z += to_f32<T>(r.v[q]);
+        o.v[q] = from_f32<T>(z);
+    }
+    *(V16<T>*)(y + m * ypitch + c0) = o;
+}
+
+// du = gamma*invstd * (dz - mean(dz) - xhat*mean(dz*xhat));   dz = dy * act'(z)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restrict__ u, int upitch, const T* __restrict__ dy, int dpitch,
+                                                                 const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd, const double* __restrict__ sums, double count,
+                                                                 T* __restrict__ du, int opitch, long long M, int C, int act) {
+    constexpr int V = V16<T>::N;
+    const int cv = C / V;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= M * cv) return;
+    const long long m = idx / cv;
+    const int c0 = (int)(idx - m * cv) * V;
+    const V16<T> x = *(const V16<T>*)(u + m * upitch + c0);
+    const V16<T> g = *(const V16<T>*)(dy + m * dpitch + c0);
+    V16<T> o;
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+        const int c = c0 + q;
+        const float uf = to_f32<T>(x.v[q]);
+        float dz = to_f32<T>(g.v[q]);
+        if (act == Y3_ACT_SILU) {
+            const float z = uf * scale[c] + shift[c];
+            const float s = 1.0f / (1.0f + expf(-z));
+            dz *= silu_grad(z, s);
+        }
+        const float xh = (uf - mean[c]) * invstd[c];
+        const float m0 = (float)(sums[c * 2] / count), m1 = (float)(sums[c * 2 + 1] / count);
+        o.v[q] = from_f32<T>(scale[c] * (dz - m0 - xh * m1));  // scale = gamma * invstd
+    }
+    *(V16<T>*)(du + m * opitch + c0) = o;
+}
+
+__global__ void bn_param_grads_kernel(const double* __restrict__ sums, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    if (dbeta) dbeta[c] = (float)sums[c * 2];
+    if (dgamma) dgamma[c] = (float)sums[c * 2 + 1];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Filter gradient, direct form: one thread per dW[co][ci][kh][kw] (OIHW fp32, the layout of nn.Conv2d.weight.grad),
+// serial over the pixels of a slice, slices combined with atomicAdd.  Exact-order-free fp32; used for the fp32 parity
+// path and as the cross-check of the MFMA kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_direct_kernel(const T* __restrict__ x, int N, int H, int W, int Cin, int xpitch, const T* __restrict__ du, int Ho,
+                                                             int Wo, int Cout, int dpitch, int ks, int stride, int pad, int cin_real, int cout_real,
+                                                             float* __restrict__ dw, int mslices) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)cout_real * cin_real * ks * ks;
+    if (idx >= total) return;
+    const int kw = (int)(idx % ks);
+    long long t = idx / ks;
+    const int kh = (int)(t % ks);
+    t /= ks;
+    const int ci = (int)(t % cin_real);
+    const int co = (int)(t / cin_real);
+    const long long M = (long long)N * Ho * Wo;
+    const long long per = (M + mslices - 1) / mslices;
+    const long long m0 = (long long)blockIdx.y * per, m1 = m0 + per < M ? m0 + per : M;
+    float acc = 0.0f;
+    for (long long m = m0; m < m1; ++m) {
+        const int n = (int)(m / (Ho * Wo));
+        const int rem = (int)(m - (long long)n * Ho * Wo);
+        const int ho = rem / Wo, wo = rem - ho * Wo;
+        const int hi = ho * stride - pad + kh, wi = wo * stride - pad + kw;
+        if ((unsigned)hi >= (unsigned)H || (unsigned)wi >= (unsigned)W) continue;
+        acc = fmaf(to_f32<T>(du[m * dpitch + co]), to_f32<T>(x[((long long)(n * H + hi) * W + wi) * xpitch + ci]), acc);
+    }
+    atomicAdd(&dw[idx], acc);
+}
+
+// per-channel sum of an NHWC tensor into fp32 (bias gradient of the Detect convs)
+template <typename T>
+__global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ g, int pitch, long long M, int C, float* __restrict__ out) {
+    const int c = blockIdx.x;
+    __shared__ float red[256];
+    float a = 0.0f;
+    for (long long m = threadIdx.x; m < M; m += 256) a += to_f32<T>(g[m * pitch + c]);
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = red[0];
+}
+
+// OIHW fp32 -> data-gradient filter bank: rows = cin, K = (kh', kw', cout) with the taps flipped
+template <typename T>
+__global__ void pack_filter_dgrad_kernel(const float* __restrict__ src, int cout_src, int cin_src, int ks, int cout, int rows, int kpad, T* __restrict__ dst) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)rows * kpad;
+    if (idx >= total) return;
+    const int k = (int)(idx % kpad);
+    const int ci = (int)(idx / kpad);
+    float v = 0.0f;
+    if (ci < cin_src && k < ks * ks * cout) {
+        const int tap = k / cout, co = k - tap * cout;
+        const int kh = ks - 1 - tap / ks, kw = ks - 1 - tap % ks;
+        if (co < cout_src) v = src[(((long long)co * cin_src + ci) * ks + kh) * ks + kw];
+    }
+    dst[idx] = from_f32<T>(v);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// backward of nearest x2 upsampling: dx[h,w] (+)= sum of the 2x2 block of dy
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const T* __restrict__ dy, int N, int H, int W, int C, int dpitch, T* __restrict__ dx, int xpitch,
+                                                               int accumulate) {
+    constexpr int V = V16<T>::N;
+    const int cv = C / V;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)N * H * W * cv) return;
+    const int c0 = (int)(idx % cv) * V;
+    long long t = idx / cv;
+    const int w = (int)(t % W);
+    t /= W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    float a[V];
+    T* o = dx + ((long long)(n * H + h) * W + w) * xpitch + c0;
+    if (accumulate) {
+        const V16<T> prev = *(const V16<T>*)o;
+#pragma unroll
+        for (int q = 0; q < V; ++q) a[q] = to_f32<T>(prev.v[q]);
+    } else {
+#pragma unroll
+        for (int q = 0; q < V; ++q) a[q] = 0.0f;
+    }
+    for (int dy_ = 0; dy_ < 2; ++dy_)
+        for (int dx_ = 0; dx_ < 2; ++dx_) {
+            const V16<T> g = *(const V16<T>*)(dy + ((long long)(n * 2 * H + 2 * h + dy_) * (2 * W) + 2 * w + dx_) * dpitch + c0);
+#pragma unroll
+            for (int q = 0; q < V; ++q) a[q] += to_f32<T>(g.v[q]);
+        }
+    V16<T> out;
+#pragma unroll
+    for (int q = 0; q < V; ++q) out.v[q] = from_f32<T>(a[q]);
+    *(V16<T>*)o = out;
+}
+
+// backward of MaxPool2d(k, s, p) (+ right/bottom zero pad): each output's gradient goes to the FIRST maximal input of
+// its window (row-major scan, as ATen's max_pool2d_with_indices does); one thread per input element gathers.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, int N, int H, int W, int C, int xpitch, const T* __restrict__ dy, int Ho, int Wo,
+                                                            int dpitch, T* __restrict__ dx, int gpitch, int k, int s, int pad, int zr, int zb, int accumulate) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)N * H * W * C) return;
+    const int c = (int)(idx % C);
+    long long t = idx / C;
+    const int w = (int)(t % W);
+    t /= W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    const float mine = to_f32<T>(x[((long long)(n * H + h) * W + w) * xpitch + c]);
+    float g = 0.0f;
+    // outputs whose window contains (h, w)
+    for (int ho = (h + pad - k + s) / s > 0 ? (h + pad - k + s) / s : 0; ho < Ho && ho * s - pad <= h; ++ho) {
+        for (int wo = (w + pad - k + s) / s > 0 ? (w + pad - k + s) / s : 0; wo < Wo && wo * s - pad <= w; ++wo) {
+            // is (h,w) the first maximum of window (ho,wo)?
+            bool first = true;
+            for (int kh = 0; kh < k && first; ++kh) {
+                const int hi = ho * s - pad + kh;
+                if (hi < 0 || hi >= H + zb) continue;
+                for (int kw = 0; kw < k; ++kw) {
+                    const int wi = wo * s - pad + kw;
+                    if (wi < 0 || wi >= W + zr) continue;
+                    const float v = (hi < H && wi < W) ? to_f32<T>(x[((long long)(n * H + hi) * W + wi) * xpitch + c]) : 0.0f;
+                    const bool before = (hi < h) || (hi == h && wi < w);
+                    if (v > mine || (v == mine && before)) { first = false; break; }
+                }
+            }
+            if (first) g += to_f32<T>(dy[((long long)(n * Ho + ho) * Wo + wo) * dpitch + c]);
+        }
+    }
+    T* o = dx + ((long long)(n * H + h) * W + w) * gpitch + c;
+    *o = from_f32<T>(accumulate ? to_f32<T>(*o) + g : g);
+}
+
+// raw-output gradient (bs, na, ny, nx, no) -> head-conv output gradient NHWC (bs, ny, nx, cpad), pad channels = 0
+template <typename T>
+__global__ __launch_bounds__(256) void detect_raw_bwd_kernel(const T* __restrict__ graw, int bs, int na, int ny, int nx, int no, T* __restrict__ ghead, int pitch,
+                                                               int cpad) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)bs * ny * nx * cpad) return;
+    const int ch = (int)(idx % cpad);
+    long long t = idx / cpad;
+    const int x = (int)(t % nx);
+    t /= nx;
+    const int y = (int)(t % ny);
+    const int b = (int)(t / ny);
+    T v = from_f32<T>(0.0f);
+    if (ch < na * no) {
+        const int a = ch / no, o = ch - a * no;
+        v = graw[((((long long)b * na + a) * ny + y) * nx + x) * no + o];
+    }
+    ghead[((long long)(b * ny + y) * nx + x) * pitch + ch] = v;
+}
+
+}  // namespace
+
+#define Y3_DISPATCH_T(dtype, EXPR)                            \
+    switch (dtype) {                                          \
+        case Y3_F16: { typedef f16_t T; EXPR; } break;        \
+        case Y3_BF16: { typedef bf16_t T; EXPR; } break;      \
+        case Y3_F32: { typedef float T; EXPR; } break;        \
+        default: Y3_FAIL("bad dtype %d", (int)(dtype));       \
+    }
+
+static int reduce_geometry(int C, int esz, long long M, unsigned& grid) {
+    const int V = 16 / esz;
+    if (C % V) Y3_FAIL("channel count %d must be a multiple of %d", C, V);
+    const int CG = C / V;
+    if (CG > 256) Y3_FAIL("channel count %d too large for the per-channel reduction (max %d)", C, 256 * V);
+    const int PL = 256 / CG;
+    long long g = (M + (long long)PL * 16 - 1) / ((long long)PL * 16);
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    grid = (unsigned)g;
+    return 0;
+}
+
+extern "C" int y3_bn_stats(const y3_tensor* u, int32_t dtype, double* sums, void* stream) {
+    if (!u || !sums) Y3_FAIL("y3_bn_stats: null argument");
+    if (!vec_ok(u, esize(dtype))) Y3_FAIL("y3_bn_stats: alignment");
+    const long long M = (long long)u->n * u->h * u->w;
+    unsigned grid;
+    if (reduce_geometry(u->c, esize(dtype), M, grid)) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    Y3_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * u->c, st));
+    Y3_DISPATCH_T(dtype, hipLaunchKernelGGL((channel_reduce_kernel<T, 0>), dim3(grid), dim3(256), 0, st, (const T*)u->data, u->pitch, (const T*)nullptr, 0, M, u->c,
+                                            (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, sums));
+    Y3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int y3_bn_finalize(const double* sums, int64_t count, int32_t C, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                              float* running_var, float* scale, float* shift, float* mean, float* invstd, void* stream) {
+    if (!sums || !scale || !shift || !mean || !invstd || count <= 0) Y3_FAIL("y3_bn_finalize: bad argument");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, (double)count, C, gamma, beta, eps, momentum, running_mean,
+                       running_var, scale, shift, mean, invstd);
+    Y3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int y3_bn_act_fwd(const y3_tensor* u, const float* scale, const float* shift, const y3_tensor* residual, const y3_tensor* y, int32_t dtype, int32_t act,
+                             void* stream) {
+    if (!u || !scale || !shift || !y) Y3_FAIL("y3_bn_act_fwd: null argument");
+    if (y->n != u->n || y->h != u->h || y->w != u->w || y->c != u->c) Y3_FAIL("y3_bn_act_fwd: shape mismatch");
+    if (residual && (residual->n != u->n || residual->h != u->h || residual->w != u->w || residual->c != u->c)) Y3_FAIL("y3_bn_act_fwd: residual shape mismatch");
+    const int esz = esize(dtype);
+    if (!vec_ok(u, esz) || !vec_ok(y, esz) || (residual && !vec_ok(residual, esz))) Y3_FAIL("y3_bn_act_fwd: alignment");
+    const long long M = (long long)u->n * u->h * u->w;
+    const long long total = M * (u->c / (16 / esz));
+    Y3_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_fwd_kernel<T>), dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const T*)u->data, u->pitch, scale, shift,
+                                            residual ? (const T*)residual->data : (const T*)nullptr, residual ? residual->pitch : 0, (T*)y->data, y->pitch, M, u->c, act));
+    Y3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int y3_bn_act_bwd(const y3_tensor* u, const y3_tensor* dy, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t dtype,
+                             int32_t act, double* sums, const y3_tensor* du, float* dgamma, float* dbeta, void* stream) {
+    if (!u || !dy || !scale || !shift || !mean || !invstd || !sums || !du) Y3_FAIL("y3_bn_act_bwd: null argument");
+    if (dy->n != u->n || dy->h != u->h || dy->w != u->w || dy->c != u->c || du->c != u->c || du->h != u->h) Y3_FAIL("y3_bn_act_bwd: shape mismatch");
+    const int esz = esize(dtype);
+    if (!vec_ok(u, esz) || !vec_ok(dy, esz) || !vec_ok(du, esz)) Y3_FAIL("y3_bn_act_bwd: alignment");
+    const long long M = (long long)u->n * u->h * u->w;
+    unsigned grid;
+    if (reduce_geometry(u->c, esz, M, grid)) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    Y3_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * u->c, st));
+    Y3_DISPATCH_T(dtype, hipLaunchKernelGGL((channel_reduce_kernel<T, 1>), dim3(grid), dim3(256), 0, st, (const T*)u->data, u->pitch, (const T*)dy->data, dy->pitch, M,
+                                            u->c, scale, shift, mean, invstd, act, sums));
+    Y3_CHECK_LAUNCH();
+    const long long total = M * (u->c / (16 / esz));
+    Y3_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T>), dim3(nblk(total)), dim3(256), 0, st, (const T*)u->data, u->pitch, (const T*)dy->data,
+                                            dy->pitch, scale, shift, mean, invstd, (const double*)sums, (double)M, (T*)du->data, du->pitch, M, u->c, act));
+    Y3_CHECK_LAUNCH();
+    if (dgamma || dbeta) {
+        hipLaunchKernelGGL(bn_param_grads_kernel, dim3((u->c + 255) / 256), dim3(256), 0, st, (const double*)sums, u->c, dgamma, dbeta);
+        Y3_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+extern "C" int y3_pack_filter_dgrad(const float* w, int32_t cout_src, int32_t cin_src, int32_t ks, int32_t cout, int32_t cin, int32_t dtype, void* packed,
+                                    void* stream) {
+    if (!w || !packed) Y3_FAIL("y3_pack_filter_dgrad: null pointer");
+    if (cout < cout_src || cin < cin_src || (cout % 8) != 0 || (cin % 8) != 0) Y3_FAIL("y3_pack_filter_dgrad: bad padded sizes");
+    // the data-gradient convolution has `cin` filters of ks*ks*cout taps: same packed geometry with the roles swapped
+    const int rows = y3_filter_rows(cin), kpad = y3_filter_kpad(cout, ks);
+    const long long total = (long long)rows * kpad;
+    hipStream_t st = (hipStream_t)stream;
+    Y3_DISPATCH_T(dtype, hipLaunchKernelGGL((pack_filter_dgrad_kernel<T>), dim3(nblk(total)), dim3(256), 0, st, w, cout_src, cin_src, ks, cout, rows, kpad, (T*)packed));
+    Y3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int y3_conv2d_wgrad(const y3_conv_desc* d, const y3_tensor* x, const y3_tensor* du, int32_t cout_real, int32_t cin_real, float* dw_oihw, float* dbias,
+                               void* stream) {
+    if (!d || !x || !du || !dw_oihw) Y3_FAIL("y3_conv2d_wgrad: null argument");
+    if (x->c != d->cin || du->c != d->cout) Y3_FAIL("y3_conv2d_wgrad: channel mismatch");
+    const int pad = d->ksize / 2;
+    const int Ho = (x->h + 2 * pad - d->ksize) / d->stride + 1, Wo = (x->w + 2 * pad - d->ksize) / d->stride + 1;
+    if (du->n != x->n || du->h != Ho || du->w != Wo) Y3_FAIL("y3_conv2d_wgrad: gradient is (%d,%d,%d), expected (%d,%d,%d)", du->n, du->h, du->w, x->n, Ho, Wo);
+    if (cout_real > d->cout || cin_real > d->cin) Y3_FAIL("y3_conv2d_wgrad: real sizes exceed padded sizes");
+    hipStream_t st = (hipStream_t)stream;
+    const long long total = (long long)cout_real * cin_real * d->ksize * d->ksize;
+    const long long M = (long long)x->n * Ho * Wo;
+    Y3_HIP(hipMemsetAsync(dw_oihw, 0, (size_t)total * sizeof(float), st));
+    // enough pixel slices to fill the machine when the filter is small
+    long long want = (256LL * 8 * 256 + total - 1) / total;
+    if (want > M / 64) want = M / 64;
+    if (want < 1) want = 1;
+    if (want > 4096) want = 4096;
+    const dim3 grid(nblk(total), (unsigned)want);
+    Y3_DISPATCH_T(d->dtype, hipLaunchKernelGGL((wgrad_direct_kernel<T>), grid, dim3(256), 0, st, (const T*)x->data, x->n, x->h, x->w, d->cin, x->pitch,
+                                               (const T*)du->data, Ho, Wo, d->cout, du->pitch, d->ksize, d->stride, pad, cin_real, cout_real, dw_oihw, (int)want));
+    Y3_CHECK_LAUNCH();
+    if (dbias) {
+        Y3_DISPATCH_T(d->dtype, hipLaunchKernelGGL((channel_sum_kernel<T>), dim3((unsigned)cout_real), dim3(256), 0, st, (const T*)du->data, du->pitch, M, d->cout, dbias));
+        Y3_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+extern "C" int y3_upsample2x_bwd(const y3_tensor* dy, const y3_tensor* dx, int32_t dtype, int32_t accumulate, void* stream) {
+    if (!dy || !dx) Y3_FAIL("y3_upsample2x_bwd: null argument");
+    if (dy->n != dx->n || dy->h != 2 * dx->h || dy->w != 2 * dx->w || dy->c != dx->c) Y3_FAIL("y3_upsample2x_bwd: shape mismatch");
+    const int esz = esize(dtype);
+    if (!vec_ok(dy, esz) || !vec_ok(dx, esz)) Y3_FAIL("y3_upsample2x_bwd: alignment");
+    const long long total = (long long)dx->n * dx->h * dx->w * (dx->c / (16 / esz));
+    Y3_DISPATCH_T(dtype, hipLaunchKernelGGL((upsample2x_bwd_kernel<T>), dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const T*)dy->data, dx->n, dx->h, dx->w,
+                                            dx->c, dy->pitch, (T*)dx->data, dx->pitch, accumulate));
+    Y3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int y3_maxpool2d_bwd(const y3_tensor* x, const y3_tensor* dy, const y3_tensor* dx, int32_t dtype, int32_t k, int32_t stride, int32_t pad, int32_t zr,
+                                int32_t zb, int32_t accumulate, void* stream) {
+    if (!x || !dy || !dx) Y3_FAIL("y3_maxpool2d_bwd: null argument");
+    const int Ho = (x->h + zb + 2 * pad - k) / stride + 1, Wo = (x->w + zr + 2 * pad - k) / stride + 1;
+    if (dy->h != Ho || dy->w != Wo || dy->c != x->c || dx->h != x->h || dx->w != x->w || dx->c != x->c) Y3_FAIL("y3_maxpool2d_bwd: shape mismatch");
+    const long long total = (long long)x->n * x->h * x->w * x->c;
+    Y3_DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x->data, x->n, x->h, x->w, x->c,
+                                            x->pitch, (const T*)dy->data, Ho, Wo, dy->pitch, (T*)dx->data, dx->pitch, k, stride, pad, zr, zb, accumulate));
+    Y3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int y3_detect_raw_bwd(const void* graw, int32_t dtype, int32_t bs, int32_t na, int32_t ny, int32_t nx, int32_t no, const y3_tensor* ghead, void* stream) {
+    if (!graw || !ghead) Y3_FAIL("y3_detect_raw_bwd: null argument");
+    if (ghead->n != bs || ghead->h != ny || ghead->w != nx || ghead->c < na * no) Y3_FAIL("y3_detect_raw_bwd: shape mismatch");
+    const long long total = (long long)bs * ny * nx * ghead->c;
+    Y3_DISPATCH_T(dtype, hipLaunchKernelGGL((detect_raw_bwd_kernel<T>), dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const T*)graw, bs, na, ny, nx, no,
+                                            (T*)ghead->data, ghead->pitch, ghead->c));
+    Y3_CHECK_LAUNCH();
+    return 0;
+}

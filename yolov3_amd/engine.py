@@ -228,7 +228,7 @@ class Plan:
         for kind, kw in self.steps:
             if kind == "conv":
                 x, y, w, res = kw["x"].real(), kw["y"].real(), kw["w"], kw["res"]
-                d = Y3ConvDesc(dcode, w.k, w.s, _lib.Y3_ACT_SILU if w.act else _lib.Y3_ACT_NONE, int(kw["ups"]), _lib.Y3_ALGO_AUTO, w.cin, w.cout)
+                d = Y3ConvDesc(dcode, w.k, w.s, _lib.Y3_ACT_SILU if w.act else _lib.Y3_ACT_NONE, int(kw["ups"]), _lib.Y3_ALGO_AUTO, w.cin, w.cout, 0)
                 xt, yt = x.y3(), y.y3()
                 rt = res.real().y3() if res is not None else None
                 ho = (x.h + 2 * (w.k // 2) - w.k) // w.s + 1
@@ -491,6 +491,10 @@ def run_model(model, x: torch.Tensor, profile=False):
     ops.require_gpu(x, "DetectionModel.forward")
     if x.dim() != 4:
         raise ValueError(f"expected a (bs, ch, h, w) image batch, got shape {tuple(x.shape)}")
+    if model.training:
+        from .train_engine import run_model_train
+
+        return run_model_train(model, x)
     dtype = _engine_dtype(model)
     n, c, h, w = x.shape
     key = (n, h, w, dtype, bool(model.training), x.device.index)

@@ -78,14 +78,35 @@ def pack_filter(w_oihw: torch.Tensor, cout: int, cin: int, dtype: torch.dtype) -
 
 
 def conv2d(x: View, filt: torch.Tensor, bias: torch.Tensor, y: View, k: int, stride: int, act: bool, residual: View | None = None, upsample2x: bool = False,
-           algo: int = _lib.Y3_ALGO_AUTO):
-    d = Y3ConvDesc(dtype_code(x.buf.dtype), k, stride, _lib.Y3_ACT_SILU if act else _lib.Y3_ACT_NONE, int(upsample2x), algo, x.c, y.c)
+           algo: int = _lib.Y3_ALGO_AUTO, in_dilation: int = 0):
+    d = Y3ConvDesc(dtype_code(x.buf.dtype), k, stride, _lib.Y3_ACT_SILU if act else _lib.Y3_ACT_NONE, int(upsample2x), algo, x.c, y.c, in_dilation)
     xt, yt = x.y3(), y.y3()
     rt = residual.y3() if residual is not None else None
     check(
         _lib.lib().y3_conv2d_fwd(C.byref(d), C.byref(xt), filt.data_ptr(), bias.data_ptr(), C.byref(rt) if rt is not None else None, C.byref(yt), stream_ptr()),
         "y3_conv2d_fwd",
     )
+
+
+def pack_filter_dgrad(w_oihw: torch.Tensor, cout: int, cin: int, dtype: torch.dtype) -> torch.Tensor:
+    """OIHW fp32 weights -> filter bank of the data-gradient conv (cin filters over (kh, kw, cout), flipped taps)."""
+    require_gpu(w_oihw, "pack_filter_dgrad")
+    w = w_oihw.detach().to(torch.float32).contiguous()
+    co, ci, k, _ = w.shape
+    out = torch.empty(packed_filter_elems(cin, cout, k), dtype=dtype, device=w.device)
+    check(_lib.lib().y3_pack_filter_dgrad(w.data_ptr(), co, ci, k, cout, cin, dtype_code(dtype), out.data_ptr(), stream_ptr()), "y3_pack_filter_dgrad")
+    return out
+
+
+def conv2d_wgrad(x: View, du: View, k: int, stride: int, cout_real: int, cin_real: int, want_bias: bool = False):
+    """Filter gradient (cout_real, cin_real, k, k) fp32 (+ bias gradient) of a conv with input x and output-gradient du."""
+    d = Y3ConvDesc(dtype_code(x.buf.dtype), k, stride, 0, 0, 0, x.c, du.c, 0)
+    dw = torch.empty(cout_real, cin_real, k, k, dtype=torch.float32, device=x.buf.device)
+    db = torch.empty(cout_real, dtype=torch.float32, device=x.buf.device) if want_bias else None
+    xt, dt = x.y3(), du.y3()
+    check(_lib.lib().y3_conv2d_wgrad(C.byref(d), C.byref(xt), C.byref(dt), cout_real, cin_real, dw.data_ptr(), db.data_ptr() if db is not None else None, stream_ptr()),
+          "y3_conv2d_wgrad")
+    return dw, db
 
 
 def nchw_to_nhwc(src: torch.Tensor, out: View, divisor: float = 1.0):

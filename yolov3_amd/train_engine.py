@@ -1,0 +1,383 @@
+"""Training-mode execution of the YOLOv3 graph on MI355X: forward with batch-statistics BatchNorm and the full
+backward (data gradients, filter gradients, BN parameter gradients) as HIP launches, wrapped in ONE
+torch.autograd.Function so that ``loss.backward()``, torch optimizers and DistributedDataParallel work unchanged
+(the reference's training loop, train.py:402-422, only needs ``model(imgs)`` + autograd).
+
+Reference semantics: models/common.py:75 (Conv = act(bn(conv(x))) with batch stats, eps 1e-3, momentum 0.03),
+:165 (residual add), :428 (cat), nn.Upsample / nn.MaxPool2d, models/yolo.py:96-98 (Detect head conv + view/permute).
+
+Layout/plan: same NHWC activations and zero-copy Concat as the inference engine; every activation (pre-BN ``u`` and
+post-activation ``y``) is kept for the backward -- 288 GB of HBM makes recomputation unnecessary at batch 64.
+Gradient buffers mirror the activation buffers (Concat sources are channel slices of the Concat's gradient buffer),
+are zero-filled at the start of the backward and every producer ACCUMULATES into them, so fan-out (a tensor feeding
+two consumers, residual connections) needs no special casing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch import nn
+
+from . import _lib, ops
+from ._lib import Y3Tensor, check
+from .common import SPP, Bottleneck, Concat, Conv, MaxPool2d, Upsample, ZeroPad2d
+from .engine import _pad8, _sources, graph_hw
+from .ops import View
+
+
+class Act:
+    """An activation tensor and (during backward) its gradient, both NHWC views with identical geometry."""
+
+    def __init__(self, view: View):
+        self.view = view
+        self.g: View | None = None
+
+    def slice(self, coff, c):
+        a = Act(self.view.slice(coff, c))
+        a.parent, a.coff = self, coff
+        return a
+
+    def grad(self) -> View:
+        if self.g is None:
+            parent = getattr(self, "parent", None)
+            if parent is not None:
+                self.g = parent.grad().slice(self.coff, self.view.c)
+            else:
+                v = self.view
+                self.g = View(torch.zeros(v.n * v.h * v.w * v.pitch, dtype=v.buf.dtype, device=v.buf.device), v.n, v.h, v.w, v.c, v.pitch, 0)
+        return self.g
+
+    def drop_grad(self):
+        self.g = None
+
+
+def _f32(t):
+    return t.detach().float().contiguous()
+
+
+class _Unit:
+    def fwd(self):
+        raise NotImplementedError
+
+    def bwd(self, grads: dict):
+        raise NotImplementedError
+
+
+class ConvUnit(_Unit):
+    """conv -> BN(batch stats) -> SiLU (+ residual)."""
+
+    def __init__(self, plan, m: Conv, x: Act, y: Act, res: Act | None, need_dx=True, label=""):
+        self.plan, self.m, self.x, self.y, self.res, self.need_dx, self.label = plan, m, x, y, res, need_dx, label
+        conv = m.conv
+        self.k, self.s = conv.kernel_size[0], conv.stride[0]
+        self.cin, self.cout = x.view.c, _pad8(conv.out_channels)
+        self.co_real, self.ci_real = conv.out_channels, conv.in_channels
+        v = y.view
+        dev, dt = plan.device, plan.dtype
+        self.u = View.alloc(v.n, v.h, v.w, self.cout, dt, dev)
+        C_ = self.cout
+        self.sums = torch.zeros(2 * C_, dtype=torch.float64, device=dev)
+        self.scale, self.shift, self.mean, self.invstd = (torch.empty(C_, dtype=torch.float32, device=dev) for _ in range(4))
+        self.zero_bias = torch.zeros(C_, dtype=torch.float32, device=dev)
+        self.act = _lib.Y3_ACT_SILU if isinstance(m.act, nn.SiLU) else _lib.Y3_ACT_NONE
+        self.count = v.n * v.h * v.w
+
+    def fwd(self):
+        m, bn = self.m, self.m.bn
+        L = _lib.lib()
+        st = ops.stream_ptr()
+        filt = ops.pack_filter(m.conv.weight, self.cout, self.cin, self.plan.dtype)
+        ops.conv2d(self.x.view, filt, self.zero_bias, self.u, self.k, self.s, act=False)
+        ut = self.u.y3()
+        dcode = ops.dtype_code(self.plan.dtype)
+        check(L.y3_bn_stats(C.byref(ut), dcode, self.sums.data_ptr(), st), "y3_bn_stats")
+        if self.cout != self.co_real:
+            raise NotImplementedError("BatchNorm over a channel-padded conv")
+        check(
+            L.y3_bn_finalize(self.sums.data_ptr(), self.count, self.cout, bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps), float(bn.momentum),
+                             bn.running_mean.data_ptr(), bn.running_var.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(), self.mean.data_ptr(),
+                             self.invstd.data_ptr(), st),
+            "y3_bn_finalize",
+        )
+        bn.num_batches_tracked += 1
+        yt = self.y.view.y3()
+        rt = self.res.view.y3() if self.res is not None else None
+        check(L.y3_bn_act_fwd(C.byref(ut), self.scale.data_ptr(), self.shift.data_ptr(), C.byref(rt) if rt is not None else None, C.byref(yt), dcode, self.act, st),
+              "y3_bn_act_fwd")
+
+    def bwd(self, grads):
+        m = self.m
+        L = _lib.lib()
+        st = ops.stream_ptr()
+        dcode = ops.dtype_code(self.plan.dtype)
+        gy = self.y.grad()
+        if self.res is not None:  # out = act(bn(conv)) + res  ->  d res += d out
+            self.plan.add_into(gy, self.res.grad())
+        du = self.plan.scratch_like(self.u)
+        dgamma = torch.empty(self.cout, dtype=torch.float32, device=self.plan.device)
+        dbeta = torch.empty(self.cout, dtype=torch.float32, device=self.plan.device)
+        ut, gt, dt = self.u.y3(), gy.y3(), du.y3()
+        check(
+            L.y3_bn_act_bwd(C.byref(ut), C.byref(gt), self.scale.data_ptr(), self.shift.data_ptr(), self.mean.data_ptr(), self.invstd.data_ptr(), dcode, self.act,
+                            self.sums.data_ptr(), C.byref(dt), dgamma.data_ptr(), dbeta.data_ptr(), st),
+            "y3_bn_act_bwd",
+        )
+        dw, _ = ops.conv2d_wgrad(self.x.view, du, self.k, self.s, self.co_real, self.ci_real)
+        grads[m.conv.weight] = dw
+        grads[m.bn.weight] = dgamma[: self.co_real]
+        grads[m.bn.bias] = dbeta[: self.co_real]
+        if self.need_dx:
+            gx = self.x.grad()
+            filt_d = ops.pack_filter_dgrad(m.conv.weight, self.cout, self.cin, self.plan.dtype)
+            zb = self.plan.zeros_f32(self.cin)
+            ops.conv2d(du, filt_d, zb, gx, self.k, 1, act=False, residual=gx, in_dilation=self.s)
+
+
+class HeadUnit(_Unit):
+    """Detect's 1x1 Conv2d(bias) + view/permute to (bs, na, ny, nx, no) (reference models/yolo.py:96-98)."""
+
+    def __init__(self, plan, conv: nn.Conv2d, det, x: Act, label=""):
+        self.plan, self.conv, self.det, self.x, self.label = plan, conv, det, x, label
+        v = x.view
+        self.cout = _pad8(conv.out_channels)
+        self.head = View.alloc(v.n, v.h, v.w, self.cout, plan.dtype, plan.device)
+        self.raw = None
+
+    def fwd(self):
+        w = self.conv.weight
+        filt = ops.pack_filter(w, self.cout, self.x.view.c, self.plan.dtype)
+        bias = torch.zeros(self.cout, dtype=torch.float32, device=self.plan.device)
+        bias[: self.conv.out_channels] = _f32(self.conv.bias)
+        ops.conv2d(self.x.view, filt, bias, self.head, 1, 1, act=False)
+        v = self.head
+        det = self.det
+        self.raw = torch.empty(v.n, det.na, v.h, v.w, det.no, dtype=self.plan.dtype, device=self.plan.device)
+        ops.detect_decode(self.head, det.na, det.no, [0.0] * (det.na * 2), 1.0, self.raw, None, 0, 0)
+        return self.raw
+
+    def bwd_from(self, graw, grads):
+        L = _lib.lib()
+        det = self.det
+        v = self.head
+        ghead = self.plan.scratch_like(self.head)
+        gt = ghead.y3()
+        graw = graw.contiguous().to(self.plan.dtype)
+        check(L.y3_detect_raw_bwd(graw.data_ptr(), ops.dtype_code(self.plan.dtype), v.n, det.na, v.h, v.w, det.no, C.byref(gt), ops.stream_ptr()), "y3_detect_raw_bwd")
+        dw, db = ops.conv2d_wgrad(self.x.view, ghead, 1, 1, self.conv.out_channels, self.conv.in_channels, want_bias=True)
+        grads[self.conv.weight] = dw
+        grads[self.conv.bias] = db
+        gx = self.x.grad()
+        filt_d = ops.pack_filter_dgrad(self.conv.weight, self.cout, self.x.view.c, self.plan.dtype)
+        ops.conv2d(ghead, filt_d, self.plan.zeros_f32(self.x.view.c), gx, 1, 1, act=False, residual=gx)
+
+
+class UpsampleUnit(_Unit):
+    def __init__(self, plan, x: Act, y: Act):
+        self.plan, self.x, self.y = plan, x, y
+
+    def fwd(self):
+        ops.upsample2x(self.x.view, self.y.view)
+
+    def bwd(self, grads):
+        gy, gx = self.y.grad().y3(), self.x.grad().y3()
+        check(_lib.lib().y3_upsample2x_bwd(C.byref(gy), C.byref(gx), ops.dtype_code(self.plan.dtype), 1, ops.stream_ptr()), "y3_upsample2x_bwd")
+
+
+class MaxPoolUnit(_Unit):
+    def __init__(self, plan, x: Act, y: Act, k, s, p, zr, zb):
+        self.plan, self.x, self.y, self.k, self.s, self.p, self.zr, self.zb = plan, x, y, k, s, p, zr, zb
+
+    def fwd(self):
+        ops.maxpool2d(self.x.view, self.y.view, self.k, self.s, self.p, self.zr, self.zb)
+
+    def bwd(self, grads):
+        xt, gy, gx = self.x.view.y3(), self.y.grad().y3(), self.x.grad().y3()
+        check(
+            _lib.lib().y3_maxpool2d_bwd(C.byref(xt), C.byref(gy), C.byref(gx), ops.dtype_code(self.plan.dtype), self.k, self.s, self.p, self.zr, self.zb, 1, ops.stream_ptr()),
+            "y3_maxpool2d_bwd",
+        )
+
+
+class TrainPlan:
+    def __init__(self, model, n, h, w, dtype, device):
+        from .yolo import Detect
+
+        self.model, self.n, self.h, self.w, self.dtype, self.device = model, n, h, w, dtype, device
+        self.units: list[_Unit] = []
+        self.heads: list[HeadUnit] = []
+        self.acts: list[Act] = []
+        self._zeros: dict = {}
+        self._ones: dict = {}
+        layers = list(model.model)
+        hw = graph_hw(model, h, w)
+        src = [_sources(i, m.f) for i, m in enumerate(layers)]
+
+        def kind(m):
+            return m[0] if isinstance(m, nn.Sequential) else m
+
+        def out_ch(i, m):
+            k = m[-1] if isinstance(m, nn.Sequential) else m
+            if isinstance(k, Conv):
+                return k.conv.out_channels
+            if isinstance(k, Bottleneck):
+                return k.cv2.conv.out_channels
+            if isinstance(k, Concat):
+                return sum(ch[j] for j in src[i])
+            if isinstance(k, SPP):
+                raise NotImplementedError("SPP backward (3 stride-1 max-pools) is not implemented on the MI355X training path yet")
+            return ch[src[i][0]]
+
+        ch = {}
+        for i, m in enumerate(layers):
+            if not isinstance(kind(m), Detect):
+                ch[i] = out_ch(i, m)
+
+        def new_act(i_hw, c):
+            a = Act(View.alloc(n, i_hw[0], i_hw[1], c, dtype, device))
+            self.acts.append(a)
+            return a
+
+        # placement: Concat sources live in slices of the Concat buffer (zero-copy, forward and backward)
+        placed: dict[int, Act] = {}
+        for i, m in enumerate(layers):
+            if isinstance(kind(m), Concat):
+                cat = new_act(hw[i], ch[i])
+                placed[i] = cat
+                off = 0
+                for j in src[i]:
+                    if j in placed or (ch[j] % 8) or (off % 8):
+                        raise NotImplementedError("a tensor feeding two Concats / unaligned Concat offsets is not supported in training")
+                    placed[j] = cat.slice(off, ch[j])
+                    self.acts.append(placed[j])
+                    off += ch[j]
+
+        def home(i):
+            if i not in placed:
+                placed[i] = new_act(hw[i], ch[i])
+            return placed[i]
+
+        cin0 = _pad8(model.yaml.get("ch", 3))
+        self.x_in = Act(View.alloc(n, h, w, cin0, dtype, device))
+        out: dict[int, Act] = {-1: self.x_in}
+        pad_of = {}
+        for i, m in enumerate(layers):
+            k = kind(m)
+            ins = [out[j] for j in src[i]]
+            if isinstance(k, Detect):
+                self.det = k
+                for lvl, a in enumerate(ins):
+                    self.heads.append(HeadUnit(self, k.m[lvl], k, a, f"L{i}.m{lvl}"))
+                continue
+            if isinstance(k, Concat):
+                out[i] = placed[i]
+            elif isinstance(k, Upsample):
+                out[i] = home(i)
+                self.units.append(UpsampleUnit(self, ins[0], out[i]))
+            elif isinstance(k, ZeroPad2d):
+                pad_of[i] = (k.padding[1], k.padding[3])
+                out[i] = ins[0]
+            elif isinstance(k, MaxPool2d):
+                zr, zb = pad_of.get(src[i][0], (0, 0))
+                out[i] = home(i)
+                self.units.append(MaxPoolUnit(self, ins[0], out[i], k.kernel_size, k.stride, k.padding, zr, zb))
+            elif isinstance(m, nn.Sequential) or isinstance(k, Bottleneck):
+                subs = list(m) if isinstance(m, nn.Sequential) else [k]
+                x = ins[0]
+                for r, sub in enumerate(subs):
+                    last = r == len(subs) - 1
+                    t = new_act(hw[i], sub.cv1.conv.out_channels)
+                    self.units.append(ConvUnit(self, sub.cv1, x, t, None, True, f"L{i}.{r}.cv1"))
+                    y = home(i) if last else new_act(hw[i], sub.cv2.conv.out_channels)
+                    self.units.append(ConvUnit(self, sub.cv2, t, y, x if sub.add else None, True, f"L{i}.{r}.cv2"))
+                    x = y
+                out[i] = x
+            elif isinstance(k, Conv):
+                out[i] = home(i)
+                self.units.append(ConvUnit(self, k, ins[0], out[i], None, need_dx=src[i][0] >= 0, label=f"L{i}"))
+            else:
+                raise NotImplementedError(type(k).__name__)
+        self.params = list(model.parameters())
+
+    # -- helpers ---------------------------------------------------------------------------------
+    def zeros_f32(self, c):
+        t = self._zeros.get(c)
+        if t is None:
+            t = self._zeros[c] = torch.zeros(c, dtype=torch.float32, device=self.device)
+        return t
+
+    def ones_f32(self, c):
+        t = self._ones.get(c)
+        if t is None:
+            t = self._ones[c] = torch.ones(c, dtype=torch.float32, device=self.device)
+        return t
+
+    def scratch_like(self, v: View) -> View:
+        return View(torch.empty(v.n * v.h * v.w * v.c, dtype=self.dtype, device=self.device), v.n, v.h, v.w, v.c, v.c, 0)
+
+    def add_into(self, src: View, dst: View):
+        """dst += src (elementwise, NHWC views) through the scale/shift kernel with scale 1, shift 0."""
+        st, dt = src.y3(), dst.y3()
+        check(
+            _lib.lib().y3_bn_act_fwd(C.byref(st), self.ones_f32(src.c).data_ptr(), self.zeros_f32(src.c).data_ptr(), C.byref(dt), C.byref(dt), ops.dtype_code(self.dtype),
+                                     _lib.Y3_ACT_NONE, ops.stream_ptr()),
+            "add_into",
+        )
+
+    # -- execution -------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor):
+        ops.nchw_to_nhwc(x, self.x_in.view, 1.0)
+        with torch.no_grad():
+            for u in self.units:
+                u.fwd()
+            return [hd.fwd() for hd in self.heads]
+
+    def backward(self, graws):
+        grads: dict = {}
+        for a in self.acts:
+            a.drop_grad()
+        with torch.no_grad():
+            for hd, g in zip(self.heads, graws):
+                if g is None:
+                    g = torch.zeros_like(hd.raw)
+                hd.bwd_from(g, grads)
+            for u in reversed(self.units):
+                u.bwd(grads)
+        for a in self.acts:
+            a.drop_grad()
+        out = []
+        for p in self.params:
+            g = grads.get(p)
+            out.append(None if g is None else g.to(p.dtype).reshape(p.shape))
+        return out
+
+
+class _TrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, plan, x, *params):
+        ctx.plan = plan
+        raws = plan.forward(x)
+        return tuple(raws)
+
+    @staticmethod
+    def backward(ctx, *graws):
+        grads = ctx.plan.backward(graws)
+        return (None, None, *grads)
+
+
+def run_model_train(model, x: torch.Tensor):
+    """DetectionModel.forward in training mode: list of raw (bs, na, ny, nx, no) tensors attached to autograd."""
+    ops.require_gpu(x, "DetectionModel.forward")
+    p0 = next(model.parameters())
+    if p0.dtype != torch.float32:
+        raise TypeError("training keeps fp32 master parameters (use torch.autocast for fp16/bf16 activations), as the reference does (train.py:402)")
+    dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else p0.dtype
+    if dtype not in (torch.float16, torch.bfloat16, torch.float32):
+        raise TypeError(f"unsupported training activation dtype {dtype}")
+    n, c, h, w = x.shape
+    key = ("train", n, h, w, dtype, x.device.index)
+    plans = model.__dict__.setdefault("_plans", {})
+    plan = plans.get(key)
+    if plan is None:
+        plan = plans[key] = TrainPlan(model, n, h, w, dtype, x.device)
+    return list(_TrainFn.apply(plan, x, *plan.params))
