@@ -585,3 +585,47 @@ def test_train_step_autocast_fp16(dev):
     with torch.autocast("cuda", dtype=torch.float16):
         loss2, _ = crit(m(x.to(dev)), tg.to(dev))
     assert loss2.item() != loss.item()
+
+
+WGRAD_CASES = [
+    ("3x3s1", (2, 20, 20, 64, 128, 3, 1), {}),
+    ("3x3s2_odd", (2, 23, 19, 128, 256, 3, 2), {}),
+    ("first_layer", (2, 40, 36, 8, 32, 3, 1), {"cin_real": 3}),
+    ("1x1_deep", (2, 10, 10, 1024, 512, 1, 1), {}),
+    ("head_255", (2, 20, 20, 256, 256, 1, 1), {"cout_real": 255}),
+    ("cin32_3x3", (1, 33, 17, 32, 64, 3, 1), {}),
+    ("many_pixels", (4, 80, 80, 64, 64, 3, 1), {}),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("name,shape,kw", WGRAD_CASES, ids=[c[0] for c in WGRAD_CASES])
+def test_conv_wgrad_and_dgrad_vs_autograd(dev, dtype, name, shape, kw):
+    """filter gradient (MFMA kernel for f16/bf16, direct kernel for f32) and data gradient (forward kernel on the
+    flipped filter bank, dilated input for stride 2) against torch autograd in fp32 on the same rounded operands."""
+    _lib, ops = _ops()
+    n, h, w, cin, cout, k, s = shape
+    cin_real, cout_real = kw.get("cin_real", cin), kw.get("cout_real", cout)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, cin_real, h, w, generator=g).to(dtype).float().requires_grad_(True)
+    wt = (torch.randn(cout_real, cin_real, k, k, generator=g) / math.sqrt(cin_real * k * k)).to(dtype).float().requires_grad_(True)
+    y = F.conv2d(x, wt, None, stride=s, padding=k // 2)
+    gy = torch.randn(y.shape, generator=g).to(dtype).float()
+    y.backward(gy)
+    ho, wo = y.shape[2], y.shape[3]
+    xv = ops.View.alloc(n, h, w, cin, dtype, dev)
+    ops.nchw_to_nhwc(x.detach().to(dev), xv)
+    gv = ops.View.alloc(n, ho, wo, cout, dtype, dev)
+    ops.nchw_to_nhwc(gy.to(dev), gv)
+    dw, db = ops.conv2d_wgrad(xv, gv, k, s, cout_real, cin_real, want_bias=True)
+    filt_d = ops.pack_filter_dgrad(wt.detach().to(dev), cout, cin, dtype)
+    gx = ops.View.alloc(n, h, w, cin, dtype, dev)
+    gx.buf.zero_()
+    ops.conv2d(gv, filt_d, torch.zeros(cin, device=dev), gx, k, 1, act=False, residual=gx, in_dilation=s)
+    torch.cuda.synchronize()
+    tol = {torch.float32: 2e-5, torch.float16: 2e-3, torch.bfloat16: 1.5e-2}[dtype]
+    e_w = (dw.cpu() - wt.grad).abs().max().item() / wt.grad.abs().max().item()
+    e_b = (db.cpu() - gy.sum((0, 2, 3))[:cout_real]).abs().max().item() / gy.sum((0, 2, 3)).abs().max().item()
+    dx = gx.as_nhwc().float().cpu().permute(0, 3, 1, 2)[:, :cin_real]
+    e_x = (dx - x.grad).abs().max().item() / x.grad.abs().max().item()
+    assert e_w < tol and e_b < max(tol, 2e-3) and e_x < tol, f"{name} {dtype}: wgrad {e_w:.2e} bias {e_b:.2e} dgrad {e_x:.2e}"

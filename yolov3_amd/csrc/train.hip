@@ -10,6 +10,9 @@
 // E[x^2]-E[x]^2 in fp32 would not hold the 1e-4 parity bar, and fp64 makes the atomics' ordering invisible.
 #include "y3_common.h"
 
+#include <stdlib.h>
+#include <type_traits>
+
 namespace {
 
 template <typename T> struct V16 {  // one 16-byte vector of T
@@ -199,6 +202,164 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(const T* __restrict__
         acc = fmaf(to_f32<T>(du[m * dpitch + co]), to_f32<T>(x[((long long)(n * H + hi) * W + wi) * xpitch + ci]), acc);
     }
     atomicAdd(&dw[idx], acc);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Filter gradient on MFMA:  dW[co][(tap,ci)] = sum_m du[m][co] * x[m@tap][ci]  -- a GEMM whose reduction axis (pixels)
+// is the SLOW axis of both NHWC operands.  Each loader thread therefore fetches 4 consecutive pixels x 8 channels
+// (4 x 16 B, coalesced along channels) and writes them TRANSPOSED into LDS as 8 x ds_write_b64 (4 pixels of one
+// channel each), so that MFMA fragments (8 consecutive pixels of one channel) are again plain ds_read_b128.
+// LDS rows are 32 pixels = 64 B padded to 80 B: conflict-free fragment reads, 2-way (free) transposed writes.
+// Tile 128 co x 128 (tap,ci) columns, 4 waves x (64 x 64), pixels split over gridDim.y slices, fp32 atomicAdd
+// into the zero-initialised OIHW gradient.  Threads 0-127 stage du, 128-255 stage x.
+struct WgradArgs {
+    const void* x;
+    const void* du;
+    float* dw;
+    int N, H, W, Cin, xpitch, Ho, Wo, Cout, dpitch, ks, stride, pad, cin_real, cout_real;
+    long long M;
+    int per_slice;  // pixels per slice, multiple of 32
+    int n_nt;       // column tiles
+    unsigned x_bytes, du_bytes;
+};
+
+Y3_DEV unsigned pack_lo(unsigned a, unsigned b) { return (a & 0xffffu) | (b << 16); }
+Y3_DEV unsigned pack_hi(unsigned a, unsigned b) { return (a >> 16) | (b & 0xffff0000u); }
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int PITCH = 80, TILE = 128 * PITCH, STAGE = 2 * TILE;
+    typedef typename std::conditional<std::is_same<T, f16_t>::value, f16x8, bf16x8>::type frag;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wc = wv >> 1, wn = wv & 1;
+    const int ct = blockIdx.x / p.n_nt, nt = blockIdx.x % p.n_nt;
+    const long long m_begin = (long long)blockIdx.y * p.per_slice;
+    long long m_end = m_begin + p.per_slice;
+    if (m_end > p.M) m_end = p.M;
+    if (m_begin >= m_end) return;
+
+    const bool is_b = tid >= 128;
+    const int t = tid & 127;
+    const int pq = t & 7, g8 = t >> 3;          // pixel quad within the 32-pixel step, 8-channel group (0..15)
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const auto rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)p.du, 0, (int)p.du_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xffffffffu;
+
+    // operand-specific constants
+    int kh = 0, kw = 0, ch0 = 0;
+    bool colok;
+    if (!is_b) {
+        ch0 = ct * 128 + g8 * 8;
+        colok = ch0 < p.Cout;
+    } else {
+        const int n = nt * 128 + g8 * 8;
+        const int tap = n / p.Cin;
+        ch0 = n - tap * p.Cin;
+        kh = tap / p.ks;
+        kw = tap - kh * p.ks;
+        colok = tap < p.ks * p.ks;
+    }
+    // pixel cursor of this thread's first pixel (m_begin + 4*pq), advanced by 32 per step
+    long long m0 = m_begin + 4 * pq;
+    int img = (int)(m0 / ((long long)p.Ho * p.Wo));
+    int rem = (int)(m0 - (long long)img * p.Ho * p.Wo);
+    int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+
+    u32x4 r[4];
+    auto fetch = [&]() {
+        int h = ho, w = wo, n = img;
+        long long m = m0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned off = OOB;
+            if (colok && m < m_end) {
+                if (!is_b) {
+                    off = (unsigned)((m * p.dpitch + ch0) * 2);
+                } else {
+                    const int hi = h * p.stride - p.pad + kh, wi = w * p.stride - p.pad + kw;
+                    if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) off = (unsigned)((((long long)(n * p.H + hi) * p.W + wi) * p.xpitch + ch0) * 2);
+                }
+            }
+            r[i] = is_b ? __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0) : __builtin_amdgcn_raw_buffer_load_b128(rs_d, off, 0, 0);
+            ++m;
+            if (++w == p.Wo) { w = 0; if (++h == p.Ho) { h = 0; ++n; } }
+        }
+    };
+    auto advance = [&]() {
+        m0 += 32;
+        wo += 32;
+        while (wo >= p.Wo) { wo -= p.Wo; if (++ho == p.Ho) { ho = 0; ++img; } }
+    };
+    auto stash = [&](int stage) {
+        unsigned char* base = smem + stage * STAGE + (is_b ? TILE : 0) + (g8 * 8) * PITCH + pq * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int wd = e >> 1;
+            uint2 v;
+            if (e & 1) { v.x = pack_hi(r[0][wd], r[1][wd]); v.y = pack_hi(r[2][wd], r[3][wd]); }
+            else { v.x = pack_lo(r[0][wd], r[1][wd]); v.y = pack_lo(r[2][wd], r[3][wd]); }
+            *(uint2*)(base + e * PITCH) = v;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.0f;
+    const int frow = lane & 31, fk = lane >> 5;
+
+    const int steps = (int)((m_end - m_begin + 31) / 32);
+    fetch();
+    stash(0);
+    __syncthreads();
+    for (int it = 0; it < steps; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < steps) { advance(); fetch(); }
+        const unsigned char* al = smem + cur * STAGE;
+        const unsigned char* bl = al + TILE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            frag af[2], bf[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) af[a] = *(const frag*)(al + ((wc * 2 + a) * 32 + frow) * PITCH + (kk * 2 + fk) * 16);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bf[b] = *(const frag*)(bl + ((wn * 2 + b) * 32 + frow) * PITCH + (kk * 2 + fk) * 16);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    if constexpr (std::is_same<T, f16_t>::value) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+                    else acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+                }
+        }
+        if (it + 1 < steps) stash(cur ^ 1);
+        __syncthreads();
+    }
+
+    // D[row = co][col = (tap,ci)] -> atomicAdd into OIHW
+    const int ntaps = p.ks * p.ks;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int n = nt * 128 + (wn * 2 + b) * 32 + frow;
+        const int tap = n / p.Cin, ci = n - tap * p.Cin;
+        if (tap >= ntaps || ci >= p.cin_real) continue;
+        const int kh_ = tap / p.ks, kw_ = tap - kh_ * p.ks;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int co = ct * 128 + (wc * 2 + a) * 32 + (q & 3) + 8 * (q >> 2) + 4 * fk;
+                if (co < p.cout_real) atomicAdd(&p.dw[(((long long)co * p.cin_real + ci) * p.ks + kh_) * p.ks + kw_], acc[a][b][q]);
+            }
+    }
+#endif
 }
 
 // per-channel sum of an NHWC tensor into fp32 (bias gradient of the Detect convs)
@@ -440,15 +601,41 @@ extern "C" int y3_conv2d_wgrad(const y3_conv_desc* d, const y3_tensor* x, const 
     const long long total = (long long)cout_real * cin_real * d->ksize * d->ksize;
     const long long M = (long long)x->n * Ho * Wo;
     Y3_HIP(hipMemsetAsync(dw_oihw, 0, (size_t)total * sizeof(float), st));
-    // enough pixel slices to fill the machine when the filter is small
-    long long want = (256LL * 8 * 256 + total - 1) / total;
-    if (want > M / 64) want = M / 64;
-    if (want < 1) want = 1;
-    if (want > 4096) want = 4096;
-    const dim3 grid(nblk(total), (unsigned)want);
-    Y3_DISPATCH_T(d->dtype, hipLaunchKernelGGL((wgrad_direct_kernel<T>), grid, dim3(256), 0, st, (const T*)x->data, x->n, x->h, x->w, d->cin, x->pitch,
-                                               (const T*)du->data, Ho, Wo, d->cout, du->pitch, d->ksize, d->stride, pad, cin_real, cout_real, dw_oihw, (int)want));
-    Y3_CHECK_LAUNCH();
+    static const bool force_direct = getenv("Y3_WGRAD") && !strcmp(getenv("Y3_WGRAD"), "direct");
+    const long long xb = (((long long)x->n * x->h * x->w - 1) * x->pitch + x->c) * 2, db_ = ((M - 1) * du->pitch + du->c) * 2;
+    if (d->dtype != Y3_F32 && !force_direct && xb < 0x7fffffffLL && db_ < 0x7fffffffLL) {
+        WgradArgs a;
+        memset(&a, 0, sizeof(a));
+        a.x = x->data; a.du = du->data; a.dw = dw_oihw;
+        a.N = x->n; a.H = x->h; a.W = x->w; a.Cin = d->cin; a.xpitch = x->pitch; a.Ho = Ho; a.Wo = Wo; a.Cout = d->cout; a.dpitch = du->pitch;
+        a.ks = d->ksize; a.stride = d->stride; a.pad = pad; a.cin_real = cin_real; a.cout_real = cout_real; a.M = M;
+        a.x_bytes = (unsigned)xb; a.du_bytes = (unsigned)db_;
+        const int n_ct = y3_ceil_div(d->cout, 128);
+        a.n_nt = y3_ceil_div(d->ksize * d->ksize * d->cin, 128);
+        const long long tiles = (long long)n_ct * a.n_nt;
+        long long slices = (2048 + tiles - 1) / tiles;            // ~8 blocks per CU in flight
+        const long long max_slices = (M + 255) / 256;             // at least 8 K-steps per block
+        if (slices > max_slices) slices = max_slices;
+        if (slices < 1) slices = 1;
+        long long per = (M + slices - 1) / slices;
+        per = (per + 31) / 32 * 32;
+        slices = (M + per - 1) / per;
+        a.per_slice = (int)per;
+        const dim3 grid((unsigned)tiles, (unsigned)slices);
+        if (d->dtype == Y3_F16) hipLaunchKernelGGL((wgrad_mfma_kernel<f16_t>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((wgrad_mfma_kernel<bf16_t>), grid, dim3(256), 0, st, a);
+        Y3_CHECK_LAUNCH();
+    } else {
+        // enough pixel slices to fill the machine when the filter is small
+        long long want = (256LL * 8 * 256 + total - 1) / total;
+        if (want > M / 64) want = M / 64;
+        if (want < 1) want = 1;
+        if (want > 4096) want = 4096;
+        const dim3 grid(nblk(total), (unsigned)want);
+        Y3_DISPATCH_T(d->dtype, hipLaunchKernelGGL((wgrad_direct_kernel<T>), grid, dim3(256), 0, st, (const T*)x->data, x->n, x->h, x->w, d->cin, x->pitch,
+                                                   (const T*)du->data, Ho, Wo, d->cout, du->pitch, d->ksize, d->stride, pad, cin_real, cout_real, dw_oihw, (int)want));
+        Y3_CHECK_LAUNCH();
+    }
     if (dbias) {
         Y3_DISPATCH_T(d->dtype, hipLaunchKernelGGL((channel_sum_kernel<T>), dim3((unsigned)cout_real), dim3(256), 0, st, (const T*)du->data, du->pitch, M, d->cout, dbias));
         Y3_CHECK_LAUNCH();
