@@ -31,6 +31,8 @@ for it in range(args.steps + 1):
     t2 = sync()
     (loss * 1024.0).backward()
     t3 = sync()
+    for p_ in m.parameters():
+        p_.grad.div_(1024.0)  # GradScaler.unscale_
     opt.step(); opt.zero_grad(set_to_none=True)
     t4 = sync()
     if it:

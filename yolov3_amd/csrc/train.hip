@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(const T* __restrict
 #pragma unroll
             for (int q = 0; q < V; ++q) { sc[q] = scale[cg * V + q]; sh[q] = shift[cg * V + q]; mu[q] = mean[cg * V + q]; is[q] = invstd[cg * V + q]; }
         }
+#pragma unroll 4
         for (long long m = (long long)blockIdx.x * PL + pl; m < M; m += (long long)gridDim.x * PL) {
             const V16<T> x = *(const V16<T>*)(u + m * upitch + cg * V);
             if (MODE == 0) {
@@ -109,60 +110,70 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
     if (rvar) rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (float)(count > 1.0 ? var * count / (count - 1.0) : var);
 }
 
-// y = act(u*scale + shift) (+ residual)
+// y = act(u*scale + shift) (+ residual).  Thread (cg, pl) keeps its 8 channels' scale/shift in registers and walks
+// pixels pl, pl+PL*grid, ...: one 16-byte load and store per pixel, no per-element index arithmetic.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ u, int upitch, const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const T* __restrict__ res, int rpitch, T* __restrict__ y, int ypitch, long long M, int C, int act) {
     constexpr int V = V16<T>::N;
-    const int cv = C / V;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= M * cv) return;
-    const long long m = idx / cv;
-    const int c0 = (int)(idx - m * cv) * V;
-    const V16<T> x = *(const V16<T>*)(u + m * upitch + c0);
-    V16<T> r;
-    if (res) r = *(const V16<T>*)(res + m * rpitch + c0);
-    V16<T> o;
+    const int CG = C / V, PL = 256 / CG;
+    const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
+    if (pl >= PL) return;
+    float sc[V], sh[V];
 #pragma unroll
-    for (int q = 0; q < V; ++q) {
-        float z = to_f32<T>(x.v[q]) * scale[c0 + q] + shift[c0 + q];
-        if (act == Y3_ACT_SILU) z = z / (1.0f + expf(-z));
-        if (res) z += to_f32<T>(r.v[q]);
-        o.v[q] = from_f32<T>(z);
+    for (int q = 0; q < V; ++q) { sc[q] = scale[cg * V + q]; sh[q] = shift[cg * V + q]; }
+    for (long long m = (long long)blockIdx.x * PL + pl; m < M; m += (long long)gridDim.x * PL) {
+        const V16<T> x = *(const V16<T>*)(u + m * upitch + cg * V);
+        V16<T> r;
+        if (res) r = *(const V16<T>*)(res + m * rpitch + cg * V);
+        V16<T> o;
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            float z = to_f32<T>(x.v[q]) * sc[q] + sh[q];
+            if (act == Y3_ACT_SILU) z = z / (1.0f + expf(-z));
+            if (res) z += to_f32<T>(r.v[q]);
+            o.v[q] = from_f32<T>(z);
+        }
+        *(V16<T>*)(y + m * ypitch + cg * V) = o;
     }
-    *(V16<T>*)(y + m * ypitch + c0) = o;
 }
 
-// du = gamma*invstd * (dz - mean(dz) - xhat*mean(dz*xhat));   dz = dy * act'(z)
+// du = gamma*invstd * (dz - mean(dz) - xhat*mean(dz*xhat));   dz = dy * act'(z).  Same thread mapping as the forward.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restrict__ u, int upitch, const T* __restrict__ dy, int dpitch,
                                                                  const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd, const double* __restrict__ sums, double count,
                                                                  T* __restrict__ du, int opitch, long long M, int C, int act) {
     constexpr int V = V16<T>::N;
-    const int cv = C / V;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= M * cv) return;
-    const long long m = idx / cv;
-    const int c0 = (int)(idx - m * cv) * V;
-    const V16<T> x = *(const V16<T>*)(u + m * upitch + c0);
-    const V16<T> g = *(const V16<T>*)(dy + m * dpitch + c0);
-    V16<T> o;
+    const int CG = C / V, PL = 256 / CG;
+    const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
+    if (pl >= PL) return;
+    float sc[V], sh[V], mu[V], is[V], m0[V], m1[V];
 #pragma unroll
     for (int q = 0; q < V; ++q) {
-        const int c = c0 + q;
-        const float uf = to_f32<T>(x.v[q]);
-        float dz = to_f32<T>(g.v[q]);
-        if (act == Y3_ACT_SILU) {
-            const float z = uf * scale[c] + shift[c];
-            const float s = 1.0f / (1.0f + expf(-z));
-            dz *= silu_grad(z, s);
-        }
-        const float xh = (uf - mean[c]) * invstd[c];
-        const float m0 = (float)(sums[c * 2] / count), m1 = (float)(sums[c * 2 + 1] / count);
-        o.v[q] = from_f32<T>(scale[c] * (dz - m0 - xh * m1));  // scale = gamma * invstd
+        const int c = cg * V + q;
+        sc[q] = scale[c]; sh[q] = shift[c]; mu[q] = mean[c]; is[q] = invstd[c];
+        m0[q] = (float)(sums[c * 2] / count);
+        m1[q] = (float)(sums[c * 2 + 1] / count);
     }
-    *(V16<T>*)(du + m * opitch + c0) = o;
+    for (long long m = (long long)blockIdx.x * PL + pl; m < M; m += (long long)gridDim.x * PL) {
+        const V16<T> x = *(const V16<T>*)(u + m * upitch + cg * V);
+        const V16<T> g = *(const V16<T>*)(dy + m * dpitch + cg * V);
+        V16<T> o;
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            const float uf = to_f32<T>(x.v[q]);
+            float dz = to_f32<T>(g.v[q]);
+            if (act == Y3_ACT_SILU) {
+                const float z = uf * sc[q] + sh[q];
+                const float sg = 1.0f / (1.0f + expf(-z));
+                dz *= silu_grad(z, sg);
+            }
+            const float xh = (uf - mu[q]) * is[q];
+            o.v[q] = from_f32<T>(sc[q] * (dz - m0[q] - xh * m1[q]));  // scale = gamma * invstd
+        }
+        *(V16<T>*)(du + m * opitch + cg * V) = o;
+    }
 }
 
 __global__ void bn_param_grads_kernel(const double* __restrict__ sums, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
@@ -209,7 +220,8 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(const T* __restrict__
 // is the SLOW axis of both NHWC operands.  Each loader thread therefore fetches 4 consecutive pixels x 8 channels
 // (4 x 16 B, coalesced along channels) and writes them TRANSPOSED into LDS as 8 x ds_write_b64 (4 pixels of one
 // channel each), so that MFMA fragments (8 consecutive pixels of one channel) are again plain ds_read_b128.
-// LDS rows are 32 pixels = 64 B padded to 80 B: conflict-free fragment reads, 2-way (free) transposed writes.
+// K-step 64 pixels, LDS rows padded 128 -> 144 B: conflict-free fragment reads and transposed writes; 2-deep
+// register prefetch (counted vmcnt) so a K-step never waits for HBM/L2.
 // Tile 128 co x 128 (tap,ci) columns, 4 waves x (64 x 64), pixels split over gridDim.y slices, fp32 atomicAdd
 // into the zero-initialised OIHW gradient.  Threads 0-127 stage du, 128-255 stage x.
 struct WgradArgs {
@@ -218,7 +230,7 @@ struct WgradArgs {
     float* dw;
     int N, H, W, Cin, xpitch, Ho, Wo, Cout, dpitch, ks, stride, pad, cin_real, cout_real;
     long long M;
-    int per_slice;  // pixels per slice, multiple of 32
+    int per_slice;  // pixels per slice, multiple of 64
     int n_nt;       // column tiles
     unsigned x_bytes, du_bytes;
 };
@@ -229,7 +241,9 @@ Y3_DEV unsigned pack_hi(unsigned a, unsigned b) { return (a >> 16) | (b & 0xffff
 template <typename T>
 __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int PITCH = 80, TILE = 128 * PITCH, STAGE = 2 * TILE;
+    // K-step = 64 pixels.  LDS rows: 64 pixels = 128 B padded to 144 B (36 dwords: conflict-free ds_read_b128 fragment
+    // reads for the MFMA lane groups; the transposed ds_write_b64 of a 16-lane group covers one whole row).
+    constexpr int BKP = 64, PITCH = 144, TILE = 128 * PITCH, STAGE = 2 * TILE;
     typedef typename std::conditional<std::is_same<T, f16_t>::value, f16x8, bf16x8>::type frag;
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
@@ -242,67 +256,74 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs p) {
     if (m_end > p.M) m_end = p.M;
     if (m_begin >= m_end) return;
 
-    const bool is_b = tid >= 128;
+    const bool is_b = tid >= 128;           // waves 0-1 stage du (A), waves 2-3 stage x (B): wave-uniform
     const int t = tid & 127;
-    const int pq = t & 7, g8 = t >> 3;          // pixel quad within the 32-pixel step, 8-channel group (0..15)
+    const int pq = t & 15, g8 = t >> 4;     // pixel quad (16 x 4 = 64 pixels), 8-channel group 0..7 (+8 on the 2nd pass)
     const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
     const auto rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)p.du, 0, (int)p.du_bytes, 0x00020000);
     constexpr unsigned OOB = 0xffffffffu;
 
-    // operand-specific constants
-    int kh = 0, kw = 0, ch0 = 0;
-    bool colok;
-    if (!is_b) {
-        ch0 = ct * 128 + g8 * 8;
-        colok = ch0 < p.Cout;
-    } else {
-        const int n = nt * 128 + g8 * 8;
-        const int tap = n / p.Cin;
-        ch0 = n - tap * p.Cin;
-        kh = tap / p.ks;
-        kw = tap - kh * p.ks;
-        colok = tap < p.ks * p.ks;
+    int kh[2] = {0, 0}, kw[2] = {0, 0}, ch0[2];
+    bool colok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int g = g8 + 8 * j;
+        if (!is_b) {
+            ch0[j] = ct * 128 + g * 8;
+            colok[j] = ch0[j] < p.Cout;
+        } else {
+            const int n = nt * 128 + g * 8;
+            const int tap = n / p.Cin;
+            ch0[j] = n - tap * p.Cin;
+            kh[j] = tap / p.ks;
+            kw[j] = tap - kh[j] * p.ks;
+            colok[j] = tap < p.ks * p.ks;
+        }
     }
-    // pixel cursor of this thread's first pixel (m_begin + 4*pq), advanced by 32 per step
     long long m0 = m_begin + 4 * pq;
     int img = (int)(m0 / ((long long)p.Ho * p.Wo));
     int rem = (int)(m0 - (long long)img * p.Ho * p.Wo);
     int ho = rem / p.Wo, wo = rem - ho * p.Wo;
 
-    u32x4 r[4];
-    auto fetch = [&]() {
+    auto fetch = [&](u32x4 (&r)[2][4]) {
         int h = ho, w = wo, n = img;
         long long m = m0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            unsigned off = OOB;
-            if (colok && m < m_end) {
-                if (!is_b) {
-                    off = (unsigned)((m * p.dpitch + ch0) * 2);
-                } else {
-                    const int hi = h * p.stride - p.pad + kh, wi = w * p.stride - p.pad + kw;
-                    if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) off = (unsigned)((((long long)(n * p.H + hi) * p.W + wi) * p.xpitch + ch0) * 2);
+            const bool live = m < m_end;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                unsigned off = OOB;
+                if (live && colok[j]) {
+                    if (!is_b) {
+                        off = (unsigned)((m * p.dpitch + ch0[j]) * 2);
+                    } else {
+                        const int hi = h * p.stride - p.pad + kh[j], wi = w * p.stride - p.pad + kw[j];
+                        if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) off = (unsigned)((((long long)(n * p.H + hi) * p.W + wi) * p.xpitch + ch0[j]) * 2);
+                    }
                 }
+                r[j][i] = is_b ? __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0) : __builtin_amdgcn_raw_buffer_load_b128(rs_d, off, 0, 0);
             }
-            r[i] = is_b ? __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0) : __builtin_amdgcn_raw_buffer_load_b128(rs_d, off, 0, 0);
             ++m;
             if (++w == p.Wo) { w = 0; if (++h == p.Ho) { h = 0; ++n; } }
         }
-    };
-    auto advance = [&]() {
-        m0 += 32;
-        wo += 32;
+        // advance the cursor by one K-step
+        m0 += BKP;
+        wo += BKP;
         while (wo >= p.Wo) { wo -= p.Wo; if (++ho == p.Ho) { ho = 0; ++img; } }
     };
-    auto stash = [&](int stage) {
-        unsigned char* base = smem + stage * STAGE + (is_b ? TILE : 0) + (g8 * 8) * PITCH + pq * 8;
+    auto stash = [&](int stage, const u32x4 (&r)[2][4]) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int wd = e >> 1;
-            uint2 v;
-            if (e & 1) { v.x = pack_hi(r[0][wd], r[1][wd]); v.y = pack_hi(r[2][wd], r[3][wd]); }
-            else { v.x = pack_lo(r[0][wd], r[1][wd]); v.y = pack_lo(r[2][wd], r[3][wd]); }
-            *(uint2*)(base + e * PITCH) = v;
+        for (int j = 0; j < 2; ++j) {
+            unsigned char* base = smem + stage * STAGE + (is_b ? TILE : 0) + ((g8 + 8 * j) * 8) * PITCH + pq * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int wd = e >> 1;
+                uint2 v;
+                if (e & 1) { v.x = pack_hi(r[j][0][wd], r[j][1][wd]); v.y = pack_hi(r[j][2][wd], r[j][3][wd]); }
+                else { v.x = pack_lo(r[j][0][wd], r[j][1][wd]); v.y = pack_lo(r[j][2][wd], r[j][3][wd]); }
+                *(uint2*)(base + e * PITCH) = v;
+            }
         }
     };
 
@@ -314,18 +335,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs p) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.0f;
     const int frow = lane & 31, fk = lane >> 5;
-
-    const int steps = (int)((m_end - m_begin + 31) / 32);
-    fetch();
-    stash(0);
-    __syncthreads();
-    for (int it = 0; it < steps; ++it) {
-        const int cur = it & 1;
-        if (it + 1 < steps) { advance(); fetch(); }
-        const unsigned char* al = smem + cur * STAGE;
+    auto compute = [&](int stage) {
+        const unsigned char* al = smem + stage * STAGE;
         const unsigned char* bl = al + TILE;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < BKP / 16; ++kk) {
             frag af[2], bf[2];
 #pragma unroll
             for (int a = 0; a < 2; ++a) af[a] = *(const frag*)(al + ((wc * 2 + a) * 32 + frow) * PITCH + (kk * 2 + fk) * 16);
@@ -339,7 +353,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs p) {
                     else acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
                 }
         }
-        if (it + 1 < steps) stash(cur ^ 1);
+    };
+
+    // two register sets: while step s is multiplied out of LDS, step s+1 sits in registers and step s+2 is in flight
+    const int steps = (int)((m_end - m_begin + BKP - 1) / BKP);
+    u32x4 ra[2][4], rb[2][4];
+    fetch(ra);
+    fetch(rb);
+    stash(0, ra);
+    __syncthreads();
+    for (int it = 0; it < steps; it += 2) {
+        fetch(ra);            // step it+2 (cursor already past m_end -> all lanes OOB -> zeros, no traffic)
+        compute(0);
+        stash(1, rb);         // step it+1
+        __syncthreads();
+        if (it + 1 >= steps) break;
+        fetch(rb);            // step it+3
+        compute(1);
+        stash(0, ra);         // step it+2
         __syncthreads();
     }
 
@@ -507,7 +538,21 @@ static int reduce_geometry(int C, int esz, long long M, unsigned& grid) {
     if (CG > 256) Y3_FAIL("channel count %d too large for the per-channel reduction (max %d)", C, 256 * V);
     const int PL = 256 / CG;
     long long g = (M + (long long)PL * 16 - 1) / ((long long)PL * 16);
-    if (g > 2048) g = 2048;
+    if (g > 512) g = 512;  // every block ends with 2*C fp64 atomics onto the same addresses: keep the fan-in small
+    if (g < 1) g = 1;
+    grid = (unsigned)g;
+    return 0;
+}
+
+// streaming kernels: 4 pixels per thread per pass, capped so the grid stays a few waves deep on 256 CUs
+static int elementwise_geometry(int C, int esz, long long M, unsigned& grid) {
+    const int V = 16 / esz;
+    if (C % V) Y3_FAIL("channel count %d must be a multiple of %d", C, V);
+    const int CG = C / V;
+    if (CG > 256) Y3_FAIL("channel count %d too large (max %d)", C, 256 * V);
+    const int PL = 256 / CG;
+    long long g = (M + (long long)PL * 4 - 1) / ((long long)PL * 4);
+    if (g > 8192) g = 8192;
     if (g < 1) g = 1;
     grid = (unsigned)g;
     return 0;
@@ -544,8 +589,9 @@ extern "C" int y3_bn_act_fwd(const y3_tensor* u, const float* scale, const float
     const int esz = esize(dtype);
     if (!vec_ok(u, esz) || !vec_ok(y, esz) || (residual && !vec_ok(residual, esz))) Y3_FAIL("y3_bn_act_fwd: alignment");
     const long long M = (long long)u->n * u->h * u->w;
-    const long long total = M * (u->c / (16 / esz));
-    Y3_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_fwd_kernel<T>), dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const T*)u->data, u->pitch, scale, shift,
+    unsigned egrid;
+    if (elementwise_geometry(u->c, esz, M, egrid)) return -1;
+    Y3_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_fwd_kernel<T>), dim3(egrid), dim3(256), 0, (hipStream_t)stream, (const T*)u->data, u->pitch, scale, shift,
                                             residual ? (const T*)residual->data : (const T*)nullptr, residual ? residual->pitch : 0, (T*)y->data, y->pitch, M, u->c, act));
     Y3_CHECK_LAUNCH();
     return 0;
@@ -565,8 +611,9 @@ extern "C" int y3_bn_act_bwd(const y3_tensor* u, const y3_tensor* dy, const floa
     Y3_DISPATCH_T(dtype, hipLaunchKernelGGL((channel_reduce_kernel<T, 1>), dim3(grid), dim3(256), 0, st, (const T*)u->data, u->pitch, (const T*)dy->data, dy->pitch, M,
                                             u->c, scale, shift, mean, invstd, act, sums));
     Y3_CHECK_LAUNCH();
-    const long long total = M * (u->c / (16 / esz));
-    Y3_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T>), dim3(nblk(total)), dim3(256), 0, st, (const T*)u->data, u->pitch, (const T*)dy->data,
+    unsigned egrid;
+    if (elementwise_geometry(u->c, esz, M, egrid)) return -1;
+    Y3_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T>), dim3(egrid), dim3(256), 0, st, (const T*)u->data, u->pitch, (const T*)dy->data,
                                             dy->pitch, scale, shift, mean, invstd, (const double*)sums, (double)M, (T*)du->data, du->pitch, M, u->c, act));
     Y3_CHECK_LAUNCH();
     if (dgamma || dbeta) {
@@ -614,11 +661,11 @@ extern "C" int y3_conv2d_wgrad(const y3_conv_desc* d, const y3_tensor* x, const 
         a.n_nt = y3_ceil_div(d->ksize * d->ksize * d->cin, 128);
         const long long tiles = (long long)n_ct * a.n_nt;
         long long slices = (2048 + tiles - 1) / tiles;            // ~8 blocks per CU in flight
-        const long long max_slices = (M + 255) / 256;             // at least 8 K-steps per block
+        const long long max_slices = (M + 511) / 512;             // at least 8 K-steps (of 64 pixels) per block
         if (slices > max_slices) slices = max_slices;
         if (slices < 1) slices = 1;
         long long per = (M + slices - 1) / slices;
-        per = (per + 31) / 32 * 32;
+        per = (per + 63) / 64 * 64;
         slices = (M + per - 1) / per;
         a.per_slice = (int)per;
         const dim3 grid((unsigned)tiles, (unsigned)slices);
