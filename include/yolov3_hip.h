@@ -157,7 +157,9 @@ int y3_loss_bwd(const y3_loss_params* p, int32_t dtype, const void* const* preds
  *   backward: du = y3_bn_act_bwd(u, dy)       (also gives dgamma, dbeta)
  *             dW = y3_conv2d_wgrad(x, du)     (fp32 OIHW, the layout of nn.Conv2d.weight.grad)
  *             dx (+)= y3_conv2d_fwd(du, filter packed by y3_pack_filter_dgrad [, residual = dx, in_dilation = stride])
- * `sums` is a caller-owned scratch of 2*C doubles; all per-channel vectors are DEVICE fp32. */
+ * `sums` is a caller-owned scratch of Y3_BN_SCRATCH_DOUBLES(C) doubles (totals + per-block partial rows; reductions
+ * are atomics-free and deterministic); all per-channel vectors are DEVICE fp32. */
+#define Y3_BN_SCRATCH_DOUBLES(C) ((size_t)(1 + 256) * 2 * (size_t)(C))
 int y3_bn_stats(const y3_tensor* u, int32_t dtype, double* sums, void* stream);
 int y3_bn_finalize(const double* sums, int64_t count, int32_t channels, const float* gamma, const float* beta, float eps,
                    float momentum, float* running_mean /* updated in place, may be NULL */, float* running_var,
@@ -172,8 +174,9 @@ int y3_pack_filter_dgrad(const float* w_oihw, int32_t cout_src, int32_t cin_src,
                          int32_t dtype, void* packed, void* stream);
 /* filter gradient (and optional bias gradient = per-channel sum of du) of the conv described by `desc`
  * (dtype, ksize, stride, cin, cout = padded sizes of x / du); dw is (cout_real, cin_real, k, k) fp32, overwritten. */
+size_t y3_conv2d_wgrad_workspace_bytes(const y3_conv_desc* desc, const y3_tensor* x);
 int y3_conv2d_wgrad(const y3_conv_desc* desc, const y3_tensor* x, const y3_tensor* du, int32_t cout_real, int32_t cin_real,
-                    float* dw_oihw, float* dbias /* may be NULL */, void* stream);
+                    float* dw_oihw, float* dbias /* may be NULL */, void* workspace, size_t workspace_bytes, void* stream);
 /* backward of nn.Upsample(x2, nearest) / nn.MaxPool2d (+ZeroPad2d) / Detect's view+permute (models/yolo.py:98) */
 int y3_upsample2x_bwd(const y3_tensor* dy, const y3_tensor* dx, int32_t dtype, int32_t accumulate, void* stream);
 int y3_maxpool2d_bwd(const y3_tensor* x, const y3_tensor* dy, const y3_tensor* dx, int32_t dtype, int32_t k, int32_t stride,

@@ -6,8 +6,8 @@
 // upsample_nearest2d / cat / max_pool2d.  The data gradient of a convolution reuses the forward
 // implicit-GEMM kernel (conv.hip) on the output gradient with the flipped+transposed filter bank packed here.
 //
-// Statistics are accumulated in fp64 (per-thread partials -> LDS tree -> one fp64 atomicAdd per channel per block):
-// E[x^2]-E[x]^2 in fp32 would not hold the 1e-4 parity bar, and fp64 makes the atomics' ordering invisible.
+// Statistics are accumulated in fp64 (per-thread partials -> LDS tree -> one partial row per block -> fixed-order sum):
+// E[x^2]-E[x]^2 in fp32 would not hold the 1e-4 parity bar; no atomics, so results are run-to-run deterministic.
 #include "y3_common.h"
 
 #include <stdlib.h>
@@ -84,11 +84,21 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(const T* __restrict
         if (pl == 0) {
             double s0 = 0.0, s1 = 0.0;
             for (int k = 0; k < PL; ++k) { s0 += red[(k * CG + cg) * 2]; s1 += red[(k * CG + cg) * 2 + 1]; }
-            atomicAdd(&sums[(cg * V + q) * 2], s0);
-            atomicAdd(&sums[(cg * V + q) * 2 + 1], s1);
+            double* part = sums + (size_t)(1 + blockIdx.x) * 2 * C;   // row 0 = totals, rows 1.. = per-block partials
+            part[(cg * V + q) * 2] = s0;
+            part[(cg * V + q) * 2 + 1] = s1;
         }
         __syncthreads();
     }
+}
+
+// totals[j] = sum over the per-block partial rows (fixed order: deterministic)
+__global__ void reduce_partials_kernel(double* __restrict__ sums, int n2c, int nblocks) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n2c) return;
+    double a = 0.0;
+    for (int b = 0; b < nblocks; ++b) a += sums[(size_t)(1 + b) * n2c + j];
+    sums[j] = a;
 }
 
 // sums -> mean / biased var -> (scale, shift) of the normalisation, running-stat update (momentum, unbiased var)
@@ -222,12 +232,14 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(const T* __restrict__
 // channel each), so that MFMA fragments (8 consecutive pixels of one channel) are again plain ds_read_b128.
 // K-step 64 pixels, LDS rows padded 128 -> 144 B: conflict-free fragment reads and transposed writes; 2-deep
 // register prefetch (counted vmcnt) so a K-step never waits for HBM/L2.
-// Tile 128 co x 128 (tap,ci) columns, 4 waves x (64 x 64), pixels split over gridDim.y slices, fp32 atomicAdd
-// into the zero-initialised OIHW gradient.  Threads 0-127 stage du, 128-255 stage x.
+// Tile 128 co x 128 (tap,ci) columns, 4 waves x (64 x 64), pixels split over gridDim.y slices; every block stores
+// its fp32 tile into the caller's workspace and wgrad_reduce_kernel sums the slices in a fixed order (deterministic,
+// no atomics) into the OIHW gradient.  Threads 0-127 stage du, 128-255 stage x.
 struct WgradArgs {
     const void* x;
     const void* du;
     float* dw;
+    float* part;   // [slice][tile][128 cols][128 rows] fp32 partial tiles
     int N, H, W, Cin, xpitch, Ho, Wo, Cout, dpitch, ks, stride, pad, cin_real, cout_real;
     long long M;
     int per_slice;  // pixels per slice, multiple of 64
@@ -374,23 +386,41 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs p) {
         __syncthreads();
     }
 
-    // D[row = co][col = (tap,ci)] -> atomicAdd into OIHW
-    const int ntaps = p.ks * p.ks;
+    // D[row = co][col = n] -> partial tile [n][co] (each lane owns 4 consecutive co: one 16-byte store)
+    float* tile = p.part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (128 * 128);
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-        const int n = nt * 128 + (wn * 2 + b) * 32 + frow;
-        const int tap = n / p.Cin, ci = n - tap * p.Cin;
-        if (tap >= ntaps || ci >= p.cin_real) continue;
-        const int kh_ = tap / p.ks, kw_ = tap - kh_ * p.ks;
+        const int nl = (wn * 2 + b) * 32 + frow;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int co = ct * 128 + (wc * 2 + a) * 32 + (q & 3) + 8 * (q >> 2) + 4 * fk;
-                if (co < p.cout_real) atomicAdd(&p.dw[(((long long)co * p.cin_real + ci) * p.ks + kh_) * p.ks + kw_], acc[a][b][q]);
+            for (int g = 0; g < 4; ++g) {
+                const int col = (wc * 2 + a) * 32 + 8 * g + 4 * fk;
+                f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
+                *(f32x4*)(tile + nl * 128 + col) = v;
             }
     }
 #endif
+}
+
+// dW (OIHW fp32) = sum over slices of the partial tiles; one thread per filter element, fixed summation order
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int tiles, int n_nt, int slices, int Cin, int ks, int cin_real, int cout_real,
+                                                             float* __restrict__ dw) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)cout_real * cin_real * ks * ks;
+    if (idx >= total) return;
+    const int kw = (int)(idx % ks);
+    long long t = idx / ks;
+    const int kh = (int)(t % ks);
+    t /= ks;
+    const int ci = (int)(t % cin_real);
+    const int co = (int)(t / cin_real);
+    const int n = (kh * ks + kw) * Cin + ci;
+    const int tile = (co >> 7) * n_nt + (n >> 7);
+    const float* src = part + (size_t)tile * (128 * 128) + (n & 127) * 128 + (co & 127);
+    float a = 0.0f;
+    for (int s = 0; s < slices; ++s) a += src[(size_t)s * tiles * (128 * 128)];
+    dw[idx] = a;
 }
 
 // per-channel sum of an NHWC tensor into fp32 (bias gradient of the Detect convs)
@@ -538,7 +568,7 @@ static int reduce_geometry(int C, int esz, long long M, unsigned& grid) {
     if (CG > 256) Y3_FAIL("channel count %d too large for the per-channel reduction (max %d)", C, 256 * V);
     const int PL = 256 / CG;
     long long g = (M + (long long)PL * 16 - 1) / ((long long)PL * 16);
-    if (g > 512) g = 512;  // every block ends with 2*C fp64 atomics onto the same addresses: keep the fan-in small
+    if (g > Y3_BN_PARTIAL_ROWS) g = Y3_BN_PARTIAL_ROWS;  // one partial row of 2*C doubles per block, summed by reduce_partials_kernel
     if (g < 1) g = 1;
     grid = (unsigned)g;
     return 0;
@@ -565,9 +595,10 @@ extern "C" int y3_bn_stats(const y3_tensor* u, int32_t dtype, double* sums, void
     unsigned grid;
     if (reduce_geometry(u->c, esize(dtype), M, grid)) return -1;
     hipStream_t st = (hipStream_t)stream;
-    Y3_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * u->c, st));
     Y3_DISPATCH_T(dtype, hipLaunchKernelGGL((channel_reduce_kernel<T, 0>), dim3(grid), dim3(256), 0, st, (const T*)u->data, u->pitch, (const T*)nullptr, 0, M, u->c,
                                             (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, sums));
+    Y3_CHECK_LAUNCH();
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * u->c + 255) / 256), dim3(256), 0, st, sums, 2 * u->c, (int)grid);
     Y3_CHECK_LAUNCH();
     return 0;
 }
@@ -607,9 +638,10 @@ extern "C" int y3_bn_act_bwd(const y3_tensor* u, const y3_tensor* dy, const floa
     unsigned grid;
     if (reduce_geometry(u->c, esz, M, grid)) return -1;
     hipStream_t st = (hipStream_t)stream;
-    Y3_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * u->c, st));
     Y3_DISPATCH_T(dtype, hipLaunchKernelGGL((channel_reduce_kernel<T, 1>), dim3(grid), dim3(256), 0, st, (const T*)u->data, u->pitch, (const T*)dy->data, dy->pitch, M,
                                             u->c, scale, shift, mean, invstd, act, sums));
+    Y3_CHECK_LAUNCH();
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * u->c + 255) / 256), dim3(256), 0, st, sums, 2 * u->c, (int)grid);
     Y3_CHECK_LAUNCH();
     unsigned egrid;
     if (elementwise_geometry(u->c, esz, M, egrid)) return -1;
@@ -636,8 +668,31 @@ extern "C" int y3_pack_filter_dgrad(const float* w, int32_t cout_src, int32_t ci
     return 0;
 }
 
+static void wgrad_geometry(const y3_conv_desc* d, long long M, int& n_ct, int& n_nt, long long& slices, long long& per) {
+    n_ct = y3_ceil_div(d->cout, 128);
+    n_nt = y3_ceil_div(d->ksize * d->ksize * d->cin, 128);
+    const long long tiles = (long long)n_ct * n_nt;
+    slices = (1024 + tiles - 1) / tiles;                       // ~2 waves of resident blocks (2 per CU)
+    const long long max_slices = (M + 511) / 512;              // at least 8 K-steps (of 64 pixels) per block
+    if (slices > max_slices) slices = max_slices;
+    if (slices < 1) slices = 1;
+    per = (M + slices - 1) / slices;
+    per = (per + 63) / 64 * 64;
+    slices = (M + per - 1) / per;
+}
+
+extern "C" size_t y3_conv2d_wgrad_workspace_bytes(const y3_conv_desc* d, const y3_tensor* x) {
+    if (!d || !x || d->dtype == Y3_F32) return 256;
+    const int pad = d->ksize / 2;
+    const int Ho = (x->h + 2 * pad - d->ksize) / d->stride + 1, Wo = (x->w + 2 * pad - d->ksize) / d->stride + 1;
+    int n_ct, n_nt;
+    long long slices, per;
+    wgrad_geometry(d, (long long)x->n * Ho * Wo, n_ct, n_nt, slices, per);
+    return (size_t)slices * n_ct * n_nt * 128 * 128 * sizeof(float);
+}
+
 extern "C" int y3_conv2d_wgrad(const y3_conv_desc* d, const y3_tensor* x, const y3_tensor* du, int32_t cout_real, int32_t cin_real, float* dw_oihw, float* dbias,
-                               void* stream) {
+                               void* workspace, size_t workspace_bytes, void* stream) {
     if (!d || !x || !du || !dw_oihw) Y3_FAIL("y3_conv2d_wgrad: null argument");
     if (x->c != d->cin || du->c != d->cout) Y3_FAIL("y3_conv2d_wgrad: channel mismatch");
     const int pad = d->ksize / 2;
@@ -647,32 +702,30 @@ extern "C" int y3_conv2d_wgrad(const y3_conv_desc* d, const y3_tensor* x, const 
     hipStream_t st = (hipStream_t)stream;
     const long long total = (long long)cout_real * cin_real * d->ksize * d->ksize;
     const long long M = (long long)x->n * Ho * Wo;
-    Y3_HIP(hipMemsetAsync(dw_oihw, 0, (size_t)total * sizeof(float), st));
     static const bool force_direct = getenv("Y3_WGRAD") && !strcmp(getenv("Y3_WGRAD"), "direct");
     const long long xb = (((long long)x->n * x->h * x->w - 1) * x->pitch + x->c) * 2, db_ = ((M - 1) * du->pitch + du->c) * 2;
     if (d->dtype != Y3_F32 && !force_direct && xb < 0x7fffffffLL && db_ < 0x7fffffffLL) {
         WgradArgs a;
         memset(&a, 0, sizeof(a));
-        a.x = x->data; a.du = du->data; a.dw = dw_oihw;
+        a.x = x->data; a.du = du->data; a.dw = dw_oihw; a.part = (float*)workspace;
         a.N = x->n; a.H = x->h; a.W = x->w; a.Cin = d->cin; a.xpitch = x->pitch; a.Ho = Ho; a.Wo = Wo; a.Cout = d->cout; a.dpitch = du->pitch;
         a.ks = d->ksize; a.stride = d->stride; a.pad = pad; a.cin_real = cin_real; a.cout_real = cout_real; a.M = M;
         a.x_bytes = (unsigned)xb; a.du_bytes = (unsigned)db_;
-        const int n_ct = y3_ceil_div(d->cout, 128);
-        a.n_nt = y3_ceil_div(d->ksize * d->ksize * d->cin, 128);
+        int n_ct;
+        long long slices, per;
+        wgrad_geometry(d, M, n_ct, a.n_nt, slices, per);
         const long long tiles = (long long)n_ct * a.n_nt;
-        long long slices = (2048 + tiles - 1) / tiles;            // ~8 blocks per CU in flight
-        const long long max_slices = (M + 511) / 512;             // at least 8 K-steps (of 64 pixels) per block
-        if (slices > max_slices) slices = max_slices;
-        if (slices < 1) slices = 1;
-        long long per = (M + slices - 1) / slices;
-        per = (per + 63) / 64 * 64;
-        slices = (M + per - 1) / per;
+        if (!workspace || workspace_bytes < (size_t)slices * tiles * 128 * 128 * sizeof(float)) Y3_FAIL("y3_conv2d_wgrad: workspace too small");
         a.per_slice = (int)per;
         const dim3 grid((unsigned)tiles, (unsigned)slices);
         if (d->dtype == Y3_F16) hipLaunchKernelGGL((wgrad_mfma_kernel<f16_t>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((wgrad_mfma_kernel<bf16_t>), grid, dim3(256), 0, st, a);
         Y3_CHECK_LAUNCH();
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk(total)), dim3(256), 0, st, (const float*)workspace, (int)tiles, a.n_nt, (int)slices, d->cin, d->ksize, cin_real,
+                           cout_real, dw_oihw);
+        Y3_CHECK_LAUNCH();
     } else {
+        Y3_HIP(hipMemsetAsync(dw_oihw, 0, (size_t)total * sizeof(float), st));
         // enough pixel slices to fill the machine when the filter is small
         long long want = (256LL * 8 * 256 + total - 1) / total;
         if (want > M / 64) want = M / 64;

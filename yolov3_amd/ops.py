@@ -104,9 +104,20 @@ def conv2d_wgrad(x: View, du: View, k: int, stride: int, cout_real: int, cin_rea
     dw = torch.empty(cout_real, cin_real, k, k, dtype=torch.float32, device=x.buf.device)
     db = torch.empty(cout_real, dtype=torch.float32, device=x.buf.device) if want_bias else None
     xt, dt = x.y3(), du.y3()
-    check(_lib.lib().y3_conv2d_wgrad(C.byref(d), C.byref(xt), C.byref(dt), cout_real, cin_real, dw.data_ptr(), db.data_ptr() if db is not None else None, stream_ptr()),
+    need = int(_lib.lib().y3_conv2d_wgrad_workspace_bytes(C.byref(d), C.byref(xt)))
+    ws = torch.empty(need, dtype=torch.uint8, device=x.buf.device)
+    check(_lib.lib().y3_conv2d_wgrad(C.byref(d), C.byref(xt), C.byref(dt), cout_real, cin_real, dw.data_ptr(), db.data_ptr() if db is not None else None,
+                                     ws.data_ptr(), need, stream_ptr()),
           "y3_conv2d_wgrad")
     return dw, db
+
+
+BN_PARTIAL_ROWS = 256
+
+
+def bn_scratch(c: int, device) -> torch.Tensor:
+    """fp64 scratch for y3_bn_stats / y3_bn_act_bwd: totals + per-block partial rows (Y3_BN_SCRATCH_DOUBLES)."""
+    return torch.zeros((1 + BN_PARTIAL_ROWS) * 2 * c, dtype=torch.float64, device=device)
 
 
 def nchw_to_nhwc(src: torch.Tensor, out: View, divisor: float = 1.0):

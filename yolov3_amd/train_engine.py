@@ -77,7 +77,7 @@ class ConvUnit(_Unit):
         dev, dt = plan.device, plan.dtype
         self.u = View.alloc(v.n, v.h, v.w, self.cout, dt, dev)
         C_ = self.cout
-        self.sums = torch.zeros(2 * C_, dtype=torch.float64, device=dev)
+        self.sums = ops.bn_scratch(C_, dev)
         self.scale, self.shift, self.mean, self.invstd = (torch.empty(C_, dtype=torch.float32, device=dev) for _ in range(4))
         self.zero_bias = torch.zeros(C_, dtype=torch.float32, device=dev)
         self.act = _lib.Y3_ACT_SILU if isinstance(m.act, nn.SiLU) else _lib.Y3_ACT_NONE
