@@ -92,13 +92,17 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(const T* __restrict
     }
 }
 
-// totals[j] = sum over the per-block partial rows (fixed order: deterministic)
-__global__ void reduce_partials_kernel(double* __restrict__ sums, int n2c, int nblocks) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n2c) return;
+// totals[j] = sum over the per-block partial rows: one block per 64 entries, 4 row-lanes each, fixed tree (deterministic)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(double* __restrict__ sums, int n2c, int nblocks) {
+    __shared__ double red[256];
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
     double a = 0.0;
-    for (int b = 0; b < nblocks; ++b) a += sums[(size_t)(1 + b) * n2c + j];
-    sums[j] = a;
+    if (j < n2c)
+        for (int b = rl; b < nblocks; b += 4) a += sums[(size_t)(1 + b) * n2c + j];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (rl == 0 && j < n2c) sums[j] = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
 }
 
 // sums -> mean / biased var -> (scale, shift) of the normalisation, running-stat update (momentum, unbiased var)
@@ -403,24 +407,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs p) {
 #endif
 }
 
-// dW (OIHW fp32) = sum over slices of the partial tiles; one thread per filter element, fixed summation order
+// dW (OIHW fp32) = sum over slices of the partial tiles.  Threads follow the partial layout (co fastest) so every
+// slice is read fully coalesced; the scattered 4-byte OIHW write happens once per element.  Fixed summation order.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int tiles, int n_nt, int slices, int Cin, int ks, int cin_real, int cout_real,
                                                              float* __restrict__ dw) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long total = (long long)cout_real * cin_real * ks * ks;
-    if (idx >= total) return;
-    const int kw = (int)(idx % ks);
-    long long t = idx / ks;
-    const int kh = (int)(t % ks);
-    t /= ks;
-    const int ci = (int)(t % cin_real);
-    const int co = (int)(t / cin_real);
-    const int n = (kh * ks + kw) * Cin + ci;
-    const int tile = (co >> 7) * n_nt + (n >> 7);
-    const float* src = part + (size_t)tile * (128 * 128) + (n & 127) * 128 + (co & 127);
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;   // element of the tile array: (tile, n_local, co_local)
+    if (e >= (long long)tiles * (128 * 128)) return;
+    const int col = (int)(e & 127), nl = (int)((e >> 7) & 127), tile = (int)(e >> 14);
+    const int ct = tile / n_nt, nt = tile - ct * n_nt;
+    const int co = ct * 128 + col, n = nt * 128 + nl;
+    const int tap = n / Cin, ci = n - tap * Cin;
+    if (co >= cout_real || ci >= cin_real || tap >= ks * ks) return;
+    const size_t stride = (size_t)tiles * (128 * 128);
     float a = 0.0f;
-    for (int s = 0; s < slices; ++s) a += src[(size_t)s * tiles * (128 * 128)];
-    dw[idx] = a;
+#pragma unroll 4
+    for (int s = 0; s < slices; ++s) a += part[(size_t)s * stride + e];
+    const int kh = tap / ks, kw = tap - kh * ks;
+    dw[(((long long)co * cin_real + ci) * ks + kh) * ks + kw] = a;
 }
 
 // per-channel sum of an NHWC tensor into fp32 (bias gradient of the Detect convs)
@@ -598,7 +601,7 @@ extern "C" int y3_bn_stats(const y3_tensor* u, int32_t dtype, double* sums, void
     Y3_DISPATCH_T(dtype, hipLaunchKernelGGL((channel_reduce_kernel<T, 0>), dim3(grid), dim3(256), 0, st, (const T*)u->data, u->pitch, (const T*)nullptr, 0, M, u->c,
                                             (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, sums));
     Y3_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * u->c + 255) / 256), dim3(256), 0, st, sums, 2 * u->c, (int)grid);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * u->c + 63) / 64), dim3(256), 0, st, sums, 2 * u->c, (int)grid);
     Y3_CHECK_LAUNCH();
     return 0;
 }
@@ -641,7 +644,7 @@ extern "C" int y3_bn_act_bwd(const y3_tensor* u, const y3_tensor* dy, const floa
     Y3_DISPATCH_T(dtype, hipLaunchKernelGGL((channel_reduce_kernel<T, 1>), dim3(grid), dim3(256), 0, st, (const T*)u->data, u->pitch, (const T*)dy->data, dy->pitch, M,
                                             u->c, scale, shift, mean, invstd, act, sums));
     Y3_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * u->c + 255) / 256), dim3(256), 0, st, sums, 2 * u->c, (int)grid);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * u->c + 63) / 64), dim3(256), 0, st, sums, 2 * u->c, (int)grid);
     Y3_CHECK_LAUNCH();
     unsigned egrid;
     if (elementwise_geometry(u->c, esz, M, egrid)) return -1;
@@ -721,7 +724,7 @@ extern "C" int y3_conv2d_wgrad(const y3_conv_desc* d, const y3_tensor* x, const 
         if (d->dtype == Y3_F16) hipLaunchKernelGGL((wgrad_mfma_kernel<f16_t>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((wgrad_mfma_kernel<bf16_t>), grid, dim3(256), 0, st, a);
         Y3_CHECK_LAUNCH();
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk(total)), dim3(256), 0, st, (const float*)workspace, (int)tiles, a.n_nt, (int)slices, d->cin, d->ksize, cin_real,
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk(tiles * 128 * 128)), dim3(256), 0, st, (const float*)workspace, (int)tiles, a.n_nt, (int)slices, d->cin, d->ksize, cin_real,
                            cout_real, dw_oihw);
         Y3_CHECK_LAUNCH();
     } else {
