@@ -210,6 +210,11 @@ def main():
         fl, by, sec, nl = groups[dom]
         total_conv_flops = sum(g[0] for g in groups.values()) / 5
         total_kernel_s = sum(g[2] for g in groups.values()) / 5
+        pmc = {}
+        try:  # HBM traffic per launch comes from the committed rocprofv3 --pmc passes (bench.py cannot run the profiler)
+            pmc = json.load(open(ROOT / "profiles" / "r01_pmc_summary.json")).get(dom, {})
+        except OSError:
+            pass
         roofline = {
             "kernel": dom,
             "bound": "mfma",
@@ -217,7 +222,9 @@ def main():
             "peak": MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": round(fl / sec / 1e12 / MFMA_PEAK_TFLOPS, 4),
-            "traffic": None,
+            "traffic": round(pmc["hbm_bytes_per_launch"]) if "hbm_bytes_per_launch" in pmc else None,
+            "traffic_source": "profiles/r01_pmc_summary.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, avg per launch)" if pmc else None,
+            "algorithmic_bytes_per_launch": round(by / nl),
             "launches_per_forward": nl // 5,
             "avg_launch_us": round(sec / nl * 1e6, 2),
             "algorithmic_gflop_per_launch": round(fl / nl / 1e9, 3),
