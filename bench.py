@@ -132,6 +132,54 @@ def cpu_baseline(bs_sample=4):
     }
 
 
+def train_main(args, rank, local_rank, world, dev, parallel, yo):
+    """Data-parallel training step (BASELINE configs[2] shape per GPU): forward (batch-stat BN) + ComputeLoss + backward with
+    the gradient all-reduce overlapped (parallel.GradBuckets; RCCL over xGMI) + torch SGD(nesterov).  Weak scaling."""
+    from yolov3_amd import ComputeLoss, DetectionModel
+
+    bs, hw = args.batch, args.imgsz
+    torch.manual_seed(0)
+    model = DetectionModel(f"{args.model}.yaml").to(dev).train()
+    model.hyp = dict(box=0.05, cls=0.5, cls_pw=1.0, obj=1.0, obj_pw=1.0, anchor_t=4.0, fl_gamma=0.0, label_smoothing=0.0)
+    parallel.broadcast_parameters(model)
+    if world > 1:
+        model.grad_sync = parallel.GradBuckets()
+    crit = ComputeLoss(model)
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.937, nesterov=True)
+    x = torch.rand(bs, 3, hw, hw, generator=torch.Generator().manual_seed(rank)).to(dev)
+    tg = yo.synth_targets(bs, 80, seed=1 + rank).to(dev)
+    scale = 1024.0
+
+    def step():
+        with torch.autocast("cuda", dtype=torch.float16 if args.dtype == "fp16" else torch.bfloat16):
+            loss, _ = crit(model(x), tg)
+        (loss * scale * world).backward()  # loss *= WORLD_SIZE (train.py:406): DDP averages, the reference wants the sum
+        for p_ in model.parameters():
+            p_.grad.div_(scale)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    parallel.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    parallel.barrier()
+    dt = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "images/sec (640x640) train step", "value": round(world * bs * args.steps / dt, 2), "unit": "images/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16" if args.dtype == "fp16" else "bf16", "data": "synthetic (seeded uniform images, Poisson(7) targets/img; random-init weights)",
+            "config": {"workload": f"{args.model} train step {hw}x{hw} batch={bs}/GPU autocast {args.dtype}: fwd (batch-stat BN) + ComputeLoss + bwd + grad all-reduce + torch SGD [BASELINE configs[2]]",
+                       "global_batch": world * bs, "parallelism": f"dp{world} (bucketed all-reduce overlapped with backward)"},
+            "final_loss": float(loss),
+        }))
+    parallel.finalize()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,6 +191,7 @@ def main():
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-layers", action="store_true", help="print the per-launch table (rank 0)")
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"], help="train = BASELINE configs[2] per-GPU shape (data-parallel train step)")
     args = ap.parse_args()
 
     from yolov3_amd import parallel
@@ -156,6 +205,9 @@ def main():
 
     from oracle import yolo_oracle as yo  # only for the seeded synthetic inputs + cpu_baseline leg
     from yolov3_amd import DetectionModel, non_max_suppression
+
+    if args.mode == "train":
+        return train_main(args, rank, local_rank, world, dev, parallel, yo)
 
     dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     bs, hw = args.batch, args.imgsz

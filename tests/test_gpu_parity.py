@@ -518,7 +518,7 @@ def test_train_forward_vs_reference_golden(dev, golden_dir, key):
         torch.testing.assert_close(own[k].cpu(), v, rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("name,hw", [("yolov3-tiny", 96), ("yolov3", 64)])
+@pytest.mark.parametrize("name,hw", [("yolov3-tiny", 96), ("yolov3", 64), ("yolov3-spp", 64)])
 def test_train_step_gradients_vs_oracle_autograd(dev, name, hw):
     """forward + ComputeLoss + backward on the GPU (fp32) against torch autograd over the CPU oracle: every parameter
     gradient (75 conv filters, 72 BN gamma/beta, Detect convs) within 2e-3 of the tensor's gradient scale."""

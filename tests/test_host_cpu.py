@@ -123,3 +123,46 @@ def test_replica_helpers_world2_gloo():
     [p.join(60) for p in procs]
     assert [r[:3] for r in res] == [(0, 2, 2.0), (1, 2, 2.0)]
     assert (res[0][3], res[0][4], res[1][3], res[1][4]) == (0, 33, 33, 65)
+
+
+def _ddp_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, str(ROOT))
+    import torch
+    from yolov3_amd import parallel
+
+    parallel.init("gloo")
+    torch.manual_seed(rank)
+    lin = torch.nn.Linear(8, 4)
+    parallel.broadcast_parameters(lin, src=0)
+    gb = parallel.GradBuckets(bucket_bytes=64)  # tiny buckets -> several collectives
+    g = torch.Generator().manual_seed(100 + rank)
+    grads = {name: torch.randn(shape, generator=g) for name, shape in [("a", (3, 5)), ("b", (7,)), ("c", (2, 2, 2)), ("d", (33,))]}
+    for k in ["d", "c", "b", "a"]:  # reverse layer order, like the backward plan
+        gb.add(k, grads[k])
+    out = gb.finish()
+    q.put((rank, {k: v.tolist() for k, v in out.items()}, lin.weight.detach().tolist()))
+    parallel.finalize()
+
+
+def test_gradient_buckets_average_world2_gloo():
+    """the data-parallel exchange step (bucketed all-reduce average, DDP semantics) on 2 CPU ranks"""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted((q.get(timeout=120) for _ in range(2)), key=lambda r: r[0])
+    [p.join(60) for p in procs]
+    exp = {}
+    for name, shape in [("a", (3, 5)), ("b", (7,)), ("c", (2, 2, 2)), ("d", (33,))]:
+        pass
+    gens = [torch.Generator().manual_seed(100 + r) for r in range(2)]
+    per_rank = [{name: torch.randn(shape, generator=g) for name, shape in [("a", (3, 5)), ("b", (7,)), ("c", (2, 2, 2)), ("d", (33,))]} for g in gens]
+    for k in "abcd":
+        mean = (per_rank[0][k] + per_rank[1][k]) / 2
+        for r in range(2):
+            torch.testing.assert_close(torch.tensor(res[r][1][k]), mean)
+    assert res[0][2] == res[1][2]  # parameters broadcast from rank 0

@@ -199,6 +199,24 @@ class MaxPoolUnit(_Unit):
         )
 
 
+class SPPPoolUnit(_Unit):
+    """the 5/9/13 stride-1 max-pools of SPP (reference models/common.py:287-290), one forward launch; the backward is
+    three max-pool backward passes accumulating into the pooled tensor's gradient."""
+
+    def __init__(self, plan, x: Act, y3c: Act):
+        self.plan, self.x, self.y = plan, x, y3c
+
+    def fwd(self):
+        ops.spp_pyramid(self.x.view, self.y.view)
+
+    def bwd(self, grads):
+        c = self.x.view.c
+        xt, gx = self.x.view.y3(), self.x.grad().y3()
+        for j, k in enumerate((5, 9, 13)):
+            gy = self.y.grad().slice(j * c, c).y3()
+            check(_lib.lib().y3_maxpool2d_bwd(C.byref(xt), C.byref(gy), C.byref(gx), ops.dtype_code(self.plan.dtype), k, 1, k // 2, 0, 0, 1, ops.stream_ptr()), "y3_maxpool2d_bwd")
+
+
 class TrainPlan:
     def __init__(self, model, n, h, w, dtype, device):
         from .yolo import Detect
@@ -225,7 +243,7 @@ class TrainPlan:
             if isinstance(k, Concat):
                 return sum(ch[j] for j in src[i])
             if isinstance(k, SPP):
-                raise NotImplementedError("SPP backward (3 stride-1 max-pools) is not implemented on the MI355X training path yet")
+                return k.cv2.conv.out_channels
             return ch[src[i][0]]
 
         ch = {}
@@ -292,6 +310,15 @@ class TrainPlan:
                     self.units.append(ConvUnit(self, sub.cv2, t, y, x if sub.add else None, True, f"L{i}.{r}.cv2"))
                     x = y
                 out[i] = x
+            elif isinstance(k, SPP):
+                c_ = k.cv1.conv.out_channels
+                cat = new_act(hw[i], 4 * c_)
+                s0, s3 = cat.slice(0, c_), cat.slice(c_, 3 * c_)
+                self.acts += [s0, s3]
+                self.units.append(ConvUnit(self, k.cv1, ins[0], s0, None, True, f"L{i}.cv1"))
+                self.units.append(SPPPoolUnit(self, s0, s3))
+                out[i] = home(i)
+                self.units.append(ConvUnit(self, k.cv2, cat, out[i], None, True, f"L{i}.cv2"))
             elif isinstance(k, Conv):
                 out[i] = home(i)
                 self.units.append(ConvUnit(self, k, ins[0], out[i], None, need_dx=src[i][0] >= 0, label=f"L{i}"))
@@ -333,7 +360,8 @@ class TrainPlan:
             return [hd.fwd() for hd in self.heads]
 
     def backward(self, graws):
-        grads: dict = {}
+        sync = getattr(self.model, "grad_sync", None)  # parallel.GradBuckets: overlapped gradient all-reduce
+        grads = _GradSink(sync)
         for a in self.acts:
             a.drop_grad()
         with torch.no_grad():
@@ -345,11 +373,30 @@ class TrainPlan:
                 u.bwd(grads)
         for a in self.acts:
             a.drop_grad()
+        grads = grads.result()
         out = []
         for p in self.params:
             g = grads.get(p)
             out.append(None if g is None else g.to(p.dtype).reshape(p.shape))
         return out
+
+
+class _GradSink(dict):
+    """dict of finished parameter gradients; with a GradBuckets object every gradient is handed to the overlapped
+    all-reduce the moment its kernels have been issued (reverse layer order = the order backward produces them)."""
+
+    def __init__(self, sync=None):
+        super().__init__()
+        self.sync = sync
+
+    def __setitem__(self, key, value):
+        if self.sync is not None:
+            self.sync.add(key, value)
+        else:
+            super().__setitem__(key, value)
+
+    def result(self):
+        return self.sync.finish() if self.sync is not None else self
 
 
 class _TrainFn(torch.autograd.Function):
