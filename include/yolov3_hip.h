@@ -184,6 +184,17 @@ int y3_maxpool2d_bwd(const y3_tensor* x, const y3_tensor* dy, const y3_tensor* d
 int y3_detect_raw_bwd(const void* graw, int32_t dtype, int32_t bs, int32_t na, int32_t ny, int32_t nx, int32_t no,
                       const y3_tensor* ghead, void* stream);
 
+/* Fused optimizer step: GradScaler.unscale_ + inf check, clip_grad_norm_(max_norm), SGD(nesterov)
+ * with per-tensor lr / weight decay (reference utils/torch_utils.py:207-237: three parameter groups) and the ModelEMA
+ * lerp (train.py:414-422), for ALL tensors in three launches.  `tensor_table`: DEVICE array of n_tensors records
+ *   { float* param; const float* grad; float* momentum_buf; float* ema (or NULL); int64 numel; float lr, weight_decay;
+ *     int32 first_chunk; int32 pad; }   (y3_sgd_tensor_record_bytes() == 56; chunks of 16384 elements)
+ * scratch: n_chunks + 2 floats; scratch[0] = unclipped gradient norm, scratch[1] = clip coefficient after the call.
+ * found_inf (device int32) = 1 when a gradient was inf/nan, in which case nothing is updated (GradScaler.step). */
+size_t y3_sgd_tensor_record_bytes(void);
+int y3_sgd_step(const void* tensor_table, int32_t n_tensors, int32_t n_chunks, float inv_scale, float max_norm, float momentum,
+                int32_t nesterov, int32_t first_step, float ema_decay, float* scratch, int32_t* found_inf, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

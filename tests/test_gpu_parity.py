@@ -629,3 +629,51 @@ def test_conv_wgrad_and_dgrad_vs_autograd(dev, dtype, name, shape, kw):
     dx = gx.as_nhwc().float().cpu().permute(0, 3, 1, 2)[:, :cin_real]
     e_x = (dx - x.grad).abs().max().item() / x.grad.abs().max().item()
     assert e_w < tol and e_b < max(tol, 2e-3) and e_x < tol, f"{name} {dtype}: wgrad {e_w:.2e} bias {e_b:.2e} dgrad {e_x:.2e}"
+
+
+def test_fused_sgd_vs_torch_reference(dev):
+    """unscale + clip_grad_norm_(10) + SGD(nesterov, 3 groups) + EMA in the fused kernel vs torch's reference ops (fp32)."""
+    from yolov3_amd.optim import FusedSGD, ModelEMA
+
+    torch.manual_seed(0)
+    shapes = [(64, 32, 3, 3), (64,), (255, 128, 1, 1), (255,), (1000003,)]
+    ps = [torch.nn.Parameter(torch.randn(s, device=dev)) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().cpu().clone()) for p in ps]
+    groups = lambda q: [{"params": [q[1], q[3]], "weight_decay": 0.0}, {"params": [q[0], q[2], q[4]], "weight_decay": 5e-4}]
+    opt = FusedSGD(groups(ps), lr=0.01, momentum=0.937, nesterov=True)
+    topt = torch.optim.SGD(groups(ref), lr=0.01, momentum=0.937, nesterov=True)
+
+    class Holder(torch.nn.Module):
+        def __init__(self, q):
+            super().__init__()
+            self.q = torch.nn.ParameterList(q)
+
+    ema = ModelEMA(Holder(ps))
+    ema_ref = [p.detach().clone() for p in ref]
+    upd = 0
+    for step in range(3):
+        scale = 1024.0
+        for p, r in zip(ps, ref):
+            g = torch.randn(r.shape) * (30.0 if step == 1 else 1.0)  # step 1 exceeds max_norm
+            r.grad = g.clone()
+            p.grad = (g * scale).to(dev)
+        norm_ref = torch.nn.utils.clip_grad_norm_(ref, max_norm=10.0)
+        topt.step()
+        upd += 1
+        d = 0.9999 * (1 - math.exp(-upd / 2000))
+        for e, r in zip(ema_ref, ref):
+            e.mul_(d).add_(r.detach(), alpha=1 - d)
+        opt.step(grad_scale=scale, max_norm=10.0, ema=ema)
+        torch.cuda.synchronize()
+        assert abs(opt.last_norm.item() - norm_ref.item()) / norm_ref.item() < 1e-5
+        for p, r in zip(ps, ref):
+            torch.testing.assert_close(p.detach().cpu(), r.detach(), rtol=1e-5, atol=1e-6)
+        for p, e in zip(ps, ema_ref):
+            torch.testing.assert_close(ema.shadow[p].cpu(), e, rtol=1e-5, atol=1e-6)
+    # inf gradient -> step skipped
+    before = [p.detach().clone() for p in ps]
+    for p in ps:
+        p.grad = torch.full_like(p, float("inf"))
+    opt.step(grad_scale=1.0, max_norm=10.0)
+    torch.cuda.synchronize()
+    assert opt.found_inf.item() == 1 and all(torch.equal(a, b.detach()) for a, b in zip(before, ps))

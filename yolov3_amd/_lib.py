@@ -105,6 +105,8 @@ _SIGNATURES = {
     "y3_upsample2x_bwd": (C.c_int, [_P(Y3Tensor), _P(Y3Tensor), C.c_int32, C.c_int32, C.c_void_p]),
     "y3_maxpool2d_bwd": (C.c_int, [_P(Y3Tensor), _P(Y3Tensor), _P(Y3Tensor), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "y3_detect_raw_bwd": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P(Y3Tensor), C.c_void_p]),
+    "y3_sgd_tensor_record_bytes": (C.c_size_t, []),
+    "y3_sgd_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

@@ -27,6 +27,7 @@ SOURCES = [
     ("detect_nms.hip", ["-ffp-contract=off"]),
     ("loss.hip", ["-ffp-contract=off"]),
     ("train.hip", []),
+    ("optim.hip", ["-ffp-contract=off"]),
     ("api.cpp", []),
 ]
 
