@@ -166,3 +166,45 @@ def test_gradient_buckets_average_world2_gloo():
         for r in range(2):
             torch.testing.assert_close(torch.tensor(res[r][1][k]), mean)
     assert res[0][2] == res[1][2]  # parameters broadcast from rank 0
+
+
+def test_reference_checkpoint_unpickles_into_hip_modules(tmp_path):
+    """a ``.pt`` written by the UNMODIFIED reference (pickled models.yolo.DetectionModel, as train.py:470-488 does)
+    loads through yolov3_amd.compat into MI355X-backed modules with identical parameters.  Needs /root/reference."""
+    from oracle import ref_shim
+
+    if not ref_shim.available():
+        pytest.skip("reference tree not present on this box")
+    ckpt = tmp_path / "ref_tiny.pt"
+    writer = f"""
+import sys, torch
+sys.path.insert(0, {str(ROOT)!r})
+from oracle import ref_shim
+ns = ref_shim.load()
+m = ns.DetectionModel({str(ROOT / 'yolov3_amd' / 'cfg' / 'yolov3-tiny.yaml')!r}, ch=3, nc=80)
+for mod in m.modules():
+    if isinstance(mod, torch.nn.BatchNorm2d):
+        mod.running_mean.normal_(0, 0.1); mod.running_var.uniform_(0.5, 1.5)
+torch.save({{"epoch": 3, "model": m.half(), "ema": None, "optimizer": None}}, {str(ckpt)!r})
+torch.save(m.float().state_dict(), {str(tmp_path / 'sd.pt')!r})
+"""
+    subprocess.check_call([sys.executable, "-c", writer], cwd=tmp_path)
+    reader = f"""
+import sys, torch
+sys.path.insert(0, {str(ROOT)!r})
+from yolov3_amd import compat, DetectionModel, Detect
+from yolov3_amd.common import Conv, MaxPool2d, Upsample, ZeroPad2d
+m = compat.attempt_load({str(ckpt)!r}, device="cpu", fuse=False)
+assert type(m) is DetectionModel and type(m.model[-1]) is Detect and type(m.model[0]) is Conv, type(m)
+assert any(isinstance(x, MaxPool2d) for x in m.model) and any(isinstance(x, Upsample) for x in m.model) and any(isinstance(x, ZeroPad2d) for x in m.model)
+sd = torch.load({str(tmp_path / 'sd.pt')!r})
+own = m.state_dict()
+assert set(own) == set(sd)
+assert all(torch.equal(own[k].float(), sd[k].half().float()) for k in sd if sd[k].is_floating_point())
+assert m.stride.tolist() == [16.0, 32.0] and m.save == [8, 14, 15, 19]
+f = compat.attempt_load({str(ckpt)!r}, device="cpu", fuse=True)
+assert not any('.bn.' in k for k in f.state_dict()) and not f.training
+print("ok")
+"""
+    out = subprocess.check_output([sys.executable, "-c", reader], cwd=tmp_path, text=True)
+    assert out.strip().endswith("ok")
