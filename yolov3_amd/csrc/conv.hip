@@ -74,10 +74,6 @@ static int conv_variant() {
         if (!strcmp(e, "v3b")) return 4;
         if (!strcmp(e, "v3c")) return 5;
         if (!strcmp(e, "v3a")) return 6;
-        if (!strcmp(e, "v4a")) return 7;
-        if (!strcmp(e, "v4b")) return 8;
-        if (!strcmp(e, "v4c")) return 9;
-        if (!strcmp(e, "v3")) return 10;
         return 3;
     }();
     return v;
@@ -328,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_v2_kernel(const ConvArgs p)
 // vmcnt(0) precedes it) and retires the reads of the stage tile t+1 is about to overwrite.  Fragments are
 // double-buffered in registers so the ds_read of k-substep s+1 is in flight under the MFMAs of s.
 // WAVES 2x2; per-wave tile (MC*32 couts) x (MP*32 pixels).
-template <typename T, int BK, int MC, int MP, int PROBE = 0>  // PROBE (profiling only): 1 = no staging after tile 0, 2 = staging only
+template <typename T, int BK, int MC, int MP>
 __global__ __launch_bounds__(256, 2) void conv_igemm_v3_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // device-only builtins (LDS address space, buffer->LDS DMA): the host pass only needs the stub
     constexpr int WAVES_C = 2, WAVES_P = 2;
@@ -444,18 +440,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_v3_kernel(const ConvArgs p)
     dma(0, 0);
     for (int it = 0; it < p.nk; ++it) {
         __syncthreads();  // tile `it` has landed for every wave; stage (it+1)&1 is no longer being read
-        if (PROBE != 1 && it + 1 < p.nk) dma(it + 1, (it + 1) & 1);
+        if (it + 1 < p.nk) dma(it + 1, (it + 1) & 1);
         const int st = it & 1;
-        if (PROBE != 2) {
-            frag a0[MC], b0[MP], a1[MC], b1[MP];
-            load_frags(st, 0, a0, b0);
+        frag a0[MC], b0[MP], a1[MC], b1[MP];
+        load_frags(st, 0, a0, b0);
 #pragma unroll
-            for (int kk = 0; kk < KSUB; kk += 2) {
-                load_frags(st, kk + 1, a1, b1);
-                mma(a0, b0);
-                if (kk + 2 < KSUB) load_frags(st, kk + 2, a0, b0);
-                mma(a1, b1);
-            }
+        for (int kk = 0; kk < KSUB; kk += 2) {
+            load_frags(st, kk + 1, a1, b1);
+            mma(a0, b0);
+            if (kk + 2 < KSUB) load_frags(st, kk + 2, a0, b0);
+            mma(a1, b1);
         }
     }
     __syncthreads();
@@ -532,256 +526,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_v3_kernel(const ConvArgs p)
         if (h + 1 < WAVES_P) __syncthreads();
     }
 #endif
-}
-
-// ---- v4: v3 with an NST-deep LDS ring and COUNTED waits.  The v3 probe runs (profiles/r01_conv_probe.md) showed the
-// staging path to be latency-bound: with one tile in flight per block a CU keeps only 2 x 32 KB outstanding
-// (bytes in flight / ~1.3 us round trip = 47 GB/s per CU, exactly what was measured).  Here NST-1 tiles stay in flight
-// across the barrier: a raw s_barrier (no compiler-inserted vmcnt(0) drain) plus `s_waitcnt vmcnt(N)` that retires only
-// the tile about to be consumed.  One barrier per K-step still covers both hazards: every wave has its own part of tile
-// `it` landed before arriving, and the stage overwritten next (it-1 mod NST) was read before the barrier.
-// Original v3 notes follow.
-// ---- v3: LDS-DMA staging.  `buffer_load_dwordx4 ... lds` moves each wave's 1 KiB chunk straight from L2/HBM into
-// the LDS tile (no VGPR round trip, no ds_write pass); the destination is lane-linear, so the XOR swizzle is applied
-// to the SOURCE address (lane = physical slot, it fetches the logical slot that belongs there) and again on the
-// fragment read.  Out-of-range lanes (halo, tails, K padding) carry offset 0xffffffff: the descriptor's bounds check
-// makes them land as zeros.  Two LDS stages, ONE barrier per K-step: the barrier both publishes tile t (each wave's
-// vmcnt(0) precedes it) and retires the reads of the stage tile t+1 is about to overwrite.  Fragments are
-// double-buffered in registers so the ds_read of k-substep s+1 is in flight under the MFMAs of s.
-// WAVES 2x2; per-wave tile (MC*32 couts) x (MP*32 pixels).
-template <typename T, int BK, int MC, int MP, int NST>
-__global__ __launch_bounds__(256, 2) void conv_igemm_v4_kernel(const ConvArgs p) {
-#if defined(__HIP_DEVICE_COMPILE__)  // device-only builtins (LDS address space, buffer->LDS DMA): the host pass only needs the stub
-    constexpr int WAVES_C = 2, WAVES_P = 2;
-    constexpr int TC = WAVES_C * MC * 32;
-    constexpr int TP = WAVES_P * MP * 32;
-    constexpr int S = BK / 8;
-    constexpr int WJ = TC * S / 256;
-    constexpr int XJ = TP * S / 256;
-    static_assert((TC * S) % 256 == 0 && (TP * S) % 256 == 0, "whole chunks only");
-    constexpr int W_BYTES = TC * BK * 2;
-    constexpr int STAGE_BYTES = (TC + TP) * BK * 2;
-    constexpr int EP = TC + 4;
-    constexpr int EPI_ROWS = MP * 32;                      // one pixel-half (the waves with equal wp) per pass
-    constexpr int EPI_BYTES = EPI_ROWS * EP * 4;
-    constexpr int LDS_BYTES = NST * STAGE_BYTES > EPI_BYTES ? NST * STAGE_BYTES : EPI_BYTES;
-    constexpr int LPT = WJ + XJ;                           // DMA instructions per tile per wave
-    constexpr int ROWSTEP = 256 / S;
-    constexpr int KSUB = BK / 16;
-    typedef typename Mfma<T>::frag frag;
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wc = wv / WAVES_P, wp = wv % WAVES_P;
-
-    const int L = xcd_remap(blockIdx.x, gridDim.x);
-    const int pt = L / p.n_ct, ct = L % p.n_ct;
-
-    const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
-    const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
-    constexpr unsigned OOB = 0xffffffffu;
-
-    const int pslot = tid % S;   // physical 16-byte slot this lane fills in every row it touches
-    const int row0 = tid / S;
-
-    int xoff[XJ], hi0[XJ], wi0[XJ], xc0[XJ];
-    bool mvalid[XJ];
-#pragma unroll
-    for (int j = 0; j < XJ; ++j) {
-        const int row = row0 + j * ROWSTEP;
-        const int m = pt * TP + row;
-        const bool v = m < p.M;
-        const int mm = v ? m : 0;
-        const int n = mm / (p.Ho * p.Wo);
-        const int rem = mm - n * (p.Ho * p.Wo);
-        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-        hi0[j] = ho * p.stride - p.pad;
-        wi0[j] = wo * p.stride - p.pad;
-        xoff[j] = (int)(((long long)n * p.H * p.W * p.xpitch) * 2);  // byte offset of image n
-        xc0[j] = ((pslot ^ swz<BK>(row)) * 8) * 2;          // byte offset of the logical slot inside the K-step
-        mvalid[j] = v;
-    }
-    unsigned woff[WJ];
-#pragma unroll
-    for (int j = 0; j < WJ; ++j) {
-        const int row = row0 + j * ROWSTEP;
-        woff[j] = (unsigned)(((long long)(ct * TC + row) * p.Kpad + (pslot ^ swz<BK>(row)) * 8) * 2);
-    }
-
-    auto dma = [&](int it, int stage) {
-        const int tap = it / p.cin_blocks;
-        const int cb = it - tap * p.cin_blocks;
-        const int kh = tap / p.ks, kw = tap - kh * p.ks;
-        unsigned char* wl = smem + stage * STAGE_BYTES;
-        unsigned char* xl = wl + W_BYTES;
-#pragma unroll
-        for (int j = 0; j < WJ; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(wl + (j * 256 + wv * 64) * 16), 16, woff[j] + (unsigned)(it * BK * 2), 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < XJ; ++j) {
-            const int hi = hi0[j] + kh, wi = wi0[j] + kw;
-            const bool ok = mvalid[j] && in_image(hi, wi, p);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(xl + (j * 256 + wv * 64) * 16), 16,
-                                                     ok ? (unsigned)(xoff[j] + tap_bytes(hi0[j], wi0[j], kh, kw, cb * BK, p) + xc0[j]) : OOB, 0, 0, 0);
-        }
-    };
-
-    f32x16 acc[MC][MP];
-#pragma unroll
-    for (int a = 0; a < MC; ++a)
-#pragma unroll
-        for (int b = 0; b < MP; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-
-    const int frow = lane & 31;
-    const int fk = lane >> 5;
-
-    auto load_frags = [&](int stage, int kk, frag (&af)[MC], frag (&bf)[MP]) {
-        const unsigned char* wl = smem + stage * STAGE_BYTES;
-        const unsigned char* xl = wl + W_BYTES;
-        const int ks = kk * 2 + fk;
-#pragma unroll
-        for (int a = 0; a < MC; ++a) {
-            const int row = (wc * MC + a) * 32 + frow;
-            af[a] = *(const frag*)(wl + row * (BK * 2) + ((ks ^ swz<BK>(row)) << 4));
-        }
-#pragma unroll
-        for (int b = 0; b < MP; ++b) {
-            const int row = (wp * MP + b) * 32 + frow;
-            bf[b] = *(const frag*)(xl + row * (BK * 2) + ((ks ^ swz<BK>(row)) << 4));
-        }
-    };
-    auto mma = [&](const frag (&af)[MC], const frag (&bf)[MP]) {
-#pragma unroll
-        for (int a = 0; a < MC; ++a)
-#pragma unroll
-            for (int b = 0; b < MP; ++b) acc[a][b] = Mfma<T>::run(af[a], bf[b], acc[a][b]);
-    };
-
-    // prologue: NST-1 tiles in flight
-#pragma unroll
-    for (int s_ = 0; s_ < NST - 1; ++s_)
-        if (s_ < p.nk) dma(s_, s_);
-    int stage = 0;
-    for (int it = 0; it < p.nk; ++it) {
-        // retire tile `it` only: the (up to NST-2) younger tiles stay in flight across the barrier
-        const int younger = p.nk - 1 - it < NST - 2 ? p.nk - 1 - it : NST - 2;
-        if (younger >= 2) { if constexpr (NST >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory"); }
-        else if (younger == 1) { if constexpr (NST >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        const int nxt = it + NST - 1;
-        int wstage = stage + NST - 1;
-        if (wstage >= NST) wstage -= NST;
-        if (nxt < p.nk) dma(nxt, wstage);
-        {
-            frag a0[MC], b0[MP], a1[MC], b1[MP];
-            load_frags(stage, 0, a0, b0);
-#pragma unroll
-            for (int kk = 0; kk < KSUB; kk += 2) {
-                load_frags(stage, kk + 1, a1, b1);
-                mma(a0, b0);
-                if (kk + 2 < KSUB) load_frags(stage, kk + 2, a0, b0);
-                mma(a1, b1);
-            }
-        }
-        if (++stage == NST) stage = 0;
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    // ---- epilogue: one pixel-half per pass (the two waves with wp == h own it) ----
-    float* el = (float*)smem;
-    constexpr int CR = TC / 8;
-    constexpr int EJ = (EPI_ROWS * CR + 255) / 256;
-    T* __restrict__ yg = (T*)p.y;
-    const T* __restrict__ rg = (const T*)p.res;
-#pragma unroll
-    for (int h = 0; h < WAVES_P; ++h) {
-        if (wp == h) {
-#pragma unroll
-            for (int a = 0; a < MC; ++a) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int cl = (wc * MC + a) * 32 + 8 * g + 4 * fk;
-                    const int cgl = ct * TC + cl;
-                    float b4[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) b4[q] = (cgl + q < p.Cout) ? p.bias[cgl + q] : 0.0f;
-#pragma unroll
-                    for (int b = 0; b < MP; ++b) {
-                        const int pl = b * 32 + frow;
-                        f32x4 v;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            float t = acc[a][b][4 * g + q] + b4[q];
-                            if (p.act == Y3_ACT_SILU) t = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));
-                            v[q] = t;
-                        }
-                        *(f32x4*)(el + pl * EP + cl) = v;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < EJ; ++j) {
-            const int idx = tid + j * 256;
-            const int row = idx / CR, ch = idx - row * CR;
-            const int m = pt * TP + h * EPI_ROWS + row;
-            const int c = ct * TC + ch * 8;
-            if (row < EPI_ROWS && m < p.M && c + 8 <= p.Cout) {
-                const f32x4 v0 = *(const f32x4*)(el + row * EP + ch * 8);
-                const f32x4 v1 = *(const f32x4*)(el + row * EP + ch * 8 + 4);
-                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                const int n = m / (p.Ho * p.Wo);
-                const int rem = m - n * (p.Ho * p.Wo);
-                const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-                if (rg) {
-                    const uint4 rv = *(const uint4*)(rg + ((long long)(n * p.Ho + ho) * p.Wo + wo) * p.rpitch + c);
-                    const T* rp = (const T*)&rv;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] += to_f32<T>(rp[q]);
-                }
-                uint4 ov;
-                T* op = (T*)&ov;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) op[q] = from_f32<T>(v[q]);
-                if (!p.ups) {
-                    *(uint4*)(yg + ((long long)(n * p.Ho + ho) * p.Wo + wo) * p.ypitch + c) = ov;
-                } else {
-                    const int H2 = p.Ho * 2, W2 = p.Wo * 2;
-#pragma unroll
-                    for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                        for (int dx = 0; dx < 2; ++dx)
-                            *(uint4*)(yg + ((long long)(n * H2 + 2 * ho + dy) * W2 + 2 * wo + dx) * p.ypitch + c) = ov;
-                }
-            }
-        }
-        if (h + 1 < WAVES_P) __syncthreads();
-    }
-#endif
-}
-
-template <typename T, int BK, int MC, int MP, int NST> int launch_v4(ConvArgs& a, hipStream_t st) {
-    constexpr int TC = 2 * MC * 32, TP = 2 * MP * 32;
-    static_assert(NST <= 4, "the counted waits above cover rings of up to 4 stages");
-    a.n_ct = y3_ceil_div(a.Cout, TC);
-    a.n_pt = y3_ceil_div(a.M, TP);
-    a.cin_blocks = a.Cin / BK;
-    a.nk = a.ks * a.ks * a.cin_blocks;
-    const long long nb = (long long)a.n_ct * a.n_pt;
-    if (nb > 0x7fffffffLL) Y3_FAIL("conv grid too large");
-    hipLaunchKernelGGL((conv_igemm_v4_kernel<T, BK, MC, MP, NST>), dim3((unsigned)nb), dim3(256), 0, st, a);
-    Y3_CHECK_LAUNCH();
-    return 0;
 }
 
 template <typename T, int BK, int MC, int MP> int launch_v3(ConvArgs& a, hipStream_t st) {
@@ -792,10 +536,7 @@ template <typename T, int BK, int MC, int MP> int launch_v3(ConvArgs& a, hipStre
     a.nk = a.ks * a.ks * a.cin_blocks;
     const long long nb = (long long)a.n_ct * a.n_pt;
     if (nb > 0x7fffffffLL) Y3_FAIL("conv grid too large");
-    static const int probe = getenv("Y3_CONV_PROBE") ? atoi(getenv("Y3_CONV_PROBE")) : 0;  // profiling experiments only (results are wrong)
-    if (probe == 1) hipLaunchKernelGGL((conv_igemm_v3_kernel<T, BK, MC, MP, 1>), dim3((unsigned)nb), dim3(256), 0, st, a);
-    else if (probe == 2) hipLaunchKernelGGL((conv_igemm_v3_kernel<T, BK, MC, MP, 2>), dim3((unsigned)nb), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv_igemm_v3_kernel<T, BK, MC, MP>), dim3((unsigned)nb), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_igemm_v3_kernel<T, BK, MC, MP>), dim3((unsigned)nb), dim3(256), 0, st, a);
     Y3_CHECK_LAUNCH();
     return 0;
 }
@@ -883,9 +624,6 @@ template <typename T> int dispatch_igemm(ConvArgs& a, hipStream_t st) {
         if (var == 4) return launch_v3<T, 32, 2, 4>(a, st);   // 128c x 256p, BK 32
         if (var == 5) return launch_v3<T, 32, 2, 2>(a, st);   // 128c x 128p, BK 32 (4 blocks / CU)
         if (var == 6) return c64 ? launch_v3<T, 64, 2, 2>(a, st) : launch_v3<T, 32, 2, 2>(a, st);
-        if (var == 7) return launch_v4<T, 32, 2, 2, 4>(a, st);                                                // 128x128 BK32, 4-stage ring, 2 blocks/CU
-        if (var == 8) return c64 ? launch_v4<T, 64, 2, 2, 3>(a, st) : launch_v4<T, 32, 2, 2, 4>(a, st);       // 128x128 BK64, 3-stage ring, 1 block/CU
-        if (var == 9) return launch_v4<T, 32, 2, 4, 4>(a, st);                                                // 128c x 256p BK32, 4-stage ring, 1 block/CU
         // auto (measured on MI355X, profiles/r01_conv_variants.md): short K loops want 4 resident blocks per CU
         // (BK 32), small pixel counts with long K want the 128x256 tile, the rest the BK 64 128x128 tile.
         const int K = a.ks * a.ks * a.Cin;
