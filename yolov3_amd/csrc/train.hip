@@ -52,12 +52,17 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(const T* __restrict
 #pragma unroll
             for (int q = 0; q < V; ++q) { sc[q] = scale[cg * V + q]; sh[q] = shift[cg * V + q]; mu[q] = mean[cg * V + q]; is[q] = invstd[cg * V + q]; }
         }
-#pragma unroll 4
+        // fp32 partials over runs of 8 pixels (relative error ~1e-6 per run), flushed into the fp64 accumulators:
+        // keeps the fp64 VALU work at 1/8 of the element count
+        float f0[V], f1[V];
+#pragma unroll
+        for (int q = 0; q < V; ++q) f0[q] = f1[q] = 0.0f;
+        int run = 0;
         for (long long m = (long long)blockIdx.x * PL + pl; m < M; m += (long long)gridDim.x * PL) {
             const V16<T> x = *(const V16<T>*)(u + m * upitch + cg * V);
             if (MODE == 0) {
 #pragma unroll
-                for (int q = 0; q < V; ++q) { const double f = (double)to_f32<T>(x.v[q]); a0[q] += f; a1[q] += f * f; }
+                for (int q = 0; q < V; ++q) { const float f = to_f32<T>(x.v[q]); f0[q] += f; f1[q] += f * f; }
             } else {
                 const V16<T> g = *(const V16<T>*)(dy + m * dpitch + cg * V);
 #pragma unroll
@@ -70,11 +75,18 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(const T* __restrict
                         dz *= silu_grad(z, s);
                     }
                     const float xh = (uf - mu[q]) * is[q];
-                    a0[q] += (double)dz;
-                    a1[q] += (double)dz * (double)xh;
+                    f0[q] += dz;
+                    f1[q] += dz * xh;
                 }
             }
+            if (++run == 8) {
+                run = 0;
+#pragma unroll
+                for (int q = 0; q < V; ++q) { a0[q] += (double)f0[q]; a1[q] += (double)f1[q]; f0[q] = f1[q] = 0.0f; }
+            }
         }
+#pragma unroll
+        for (int q = 0; q < V; ++q) { a0[q] += (double)f0[q]; a1[q] += (double)f1[q]; }
     }
     // reduce over pixel lanes: one channel at a time through LDS (keeps LDS at 4 KiB)
     for (int q = 0; q < V; ++q) {

@@ -32,6 +32,7 @@ class Act:
     def __init__(self, view: View):
         self.view = view
         self.g: View | None = None
+        self.ready = False  # gradient buffer holds a value (first producer WRITES, later ones accumulate: no memset)
 
     def slice(self, coff, c):
         a = Act(self.view.slice(coff, c))
@@ -42,14 +43,28 @@ class Act:
         if self.g is None:
             parent = getattr(self, "parent", None)
             if parent is not None:
-                self.g = parent.grad().slice(self.coff, self.view.c)
+                pg = parent.grad()
+                if not parent.is_ready():
+                    # a slice is touched before the whole buffer received its first gradient (a consumer of the slice that
+                    # comes later in the graph than the Concat's consumer): fall back to zero-fill + accumulate
+                    pg.buf.zero_()
+                    parent.mark_ready()
+                self.g = pg.slice(self.coff, self.view.c)
             else:
                 v = self.view
-                self.g = View(torch.zeros(v.n * v.h * v.w * v.pitch, dtype=v.buf.dtype, device=v.buf.device), v.n, v.h, v.w, v.c, v.pitch, 0)
+                self.g = View(torch.empty(v.n * v.h * v.w * v.pitch, dtype=v.buf.dtype, device=v.buf.device), v.n, v.h, v.w, v.c, v.pitch, 0)
         return self.g
+
+    def is_ready(self) -> bool:
+        parent = getattr(self, "parent", None)
+        return self.ready or (parent is not None and parent.is_ready())
+
+    def mark_ready(self):
+        self.ready = True
 
     def drop_grad(self):
         self.g = None
+        self.ready = False
 
 
 def _f32(t):
@@ -113,7 +128,7 @@ class ConvUnit(_Unit):
         dcode = ops.dtype_code(self.plan.dtype)
         gy = self.y.grad()
         if self.res is not None:  # out = act(bn(conv)) + res  ->  d res += d out
-            self.plan.add_into(gy, self.res.grad())
+            self.plan.add_into(gy, self.res)
         du = self.plan.scratch_like(self.u)
         dgamma = torch.empty(self.cout, dtype=torch.float32, device=self.plan.device)
         dbeta = torch.empty(self.cout, dtype=torch.float32, device=self.plan.device)
@@ -131,7 +146,8 @@ class ConvUnit(_Unit):
             gx = self.x.grad()
             filt_d = ops.pack_filter_dgrad(m.conv.weight, self.cout, self.cin, self.plan.dtype)
             zb = self.plan.zeros_f32(self.cin)
-            ops.conv2d(du, filt_d, zb, gx, self.k, 1, act=False, residual=gx, in_dilation=self.s)
+            ops.conv2d(du, filt_d, zb, gx, self.k, 1, act=False, residual=gx if self.x.is_ready() else None, in_dilation=self.s)
+            self.x.mark_ready()
 
 
 class HeadUnit(_Unit):
@@ -169,7 +185,8 @@ class HeadUnit(_Unit):
         grads[self.conv.bias] = db
         gx = self.x.grad()
         filt_d = ops.pack_filter_dgrad(self.conv.weight, self.cout, self.x.view.c, self.plan.dtype)
-        ops.conv2d(ghead, filt_d, self.plan.zeros_f32(self.x.view.c), gx, 1, 1, act=False, residual=gx)
+        ops.conv2d(ghead, filt_d, self.plan.zeros_f32(self.x.view.c), gx, 1, 1, act=False, residual=gx if self.x.is_ready() else None)
+        self.x.mark_ready()
 
 
 class UpsampleUnit(_Unit):
@@ -181,7 +198,8 @@ class UpsampleUnit(_Unit):
 
     def bwd(self, grads):
         gy, gx = self.y.grad().y3(), self.x.grad().y3()
-        check(_lib.lib().y3_upsample2x_bwd(C.byref(gy), C.byref(gx), ops.dtype_code(self.plan.dtype), 1, ops.stream_ptr()), "y3_upsample2x_bwd")
+        check(_lib.lib().y3_upsample2x_bwd(C.byref(gy), C.byref(gx), ops.dtype_code(self.plan.dtype), int(self.x.is_ready()), ops.stream_ptr()), "y3_upsample2x_bwd")
+        self.x.mark_ready()
 
 
 class MaxPoolUnit(_Unit):
@@ -194,9 +212,11 @@ class MaxPoolUnit(_Unit):
     def bwd(self, grads):
         xt, gy, gx = self.x.view.y3(), self.y.grad().y3(), self.x.grad().y3()
         check(
-            _lib.lib().y3_maxpool2d_bwd(C.byref(xt), C.byref(gy), C.byref(gx), ops.dtype_code(self.plan.dtype), self.k, self.s, self.p, self.zr, self.zb, 1, ops.stream_ptr()),
+            _lib.lib().y3_maxpool2d_bwd(C.byref(xt), C.byref(gy), C.byref(gx), ops.dtype_code(self.plan.dtype), self.k, self.s, self.p, self.zr, self.zb,
+                                        int(self.x.is_ready()), ops.stream_ptr()),
             "y3_maxpool2d_bwd",
         )
+        self.x.mark_ready()
 
 
 class SPPPoolUnit(_Unit):
@@ -214,7 +234,9 @@ class SPPPoolUnit(_Unit):
         xt, gx = self.x.view.y3(), self.x.grad().y3()
         for j, k in enumerate((5, 9, 13)):
             gy = self.y.grad().slice(j * c, c).y3()
-            check(_lib.lib().y3_maxpool2d_bwd(C.byref(xt), C.byref(gy), C.byref(gx), ops.dtype_code(self.plan.dtype), k, 1, k // 2, 0, 0, 1, ops.stream_ptr()), "y3_maxpool2d_bwd")
+            check(_lib.lib().y3_maxpool2d_bwd(C.byref(xt), C.byref(gy), C.byref(gx), ops.dtype_code(self.plan.dtype), k, 1, k // 2, 0, 0, int(self.x.is_ready()), ops.stream_ptr()),
+                  "y3_maxpool2d_bwd")
+            self.x.mark_ready()
 
 
 class TrainPlan:
@@ -342,14 +364,16 @@ class TrainPlan:
     def scratch_like(self, v: View) -> View:
         return View(torch.empty(v.n * v.h * v.w * v.c, dtype=self.dtype, device=self.device), v.n, v.h, v.w, v.c, v.c, 0)
 
-    def add_into(self, src: View, dst: View):
-        """dst += src (elementwise, NHWC views) through the scale/shift kernel with scale 1, shift 0."""
+    def add_into(self, src: View, dst_act: "Act"):
+        """grad(dst) += src (or = src when nothing has been written yet) through the scale/shift kernel (scale 1, shift 0)."""
+        dst = dst_act.grad()
         st, dt = src.y3(), dst.y3()
         check(
-            _lib.lib().y3_bn_act_fwd(C.byref(st), self.ones_f32(src.c).data_ptr(), self.zeros_f32(src.c).data_ptr(), C.byref(dt), C.byref(dt), ops.dtype_code(self.dtype),
-                                     _lib.Y3_ACT_NONE, ops.stream_ptr()),
+            _lib.lib().y3_bn_act_fwd(C.byref(st), self.ones_f32(src.c).data_ptr(), self.zeros_f32(src.c).data_ptr(), C.byref(dt) if dst_act.is_ready() else None, C.byref(dt),
+                                     ops.dtype_code(self.dtype), _lib.Y3_ACT_NONE, ops.stream_ptr()),
             "add_into",
         )
+        dst_act.mark_ready()
 
     # -- execution -------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor):
