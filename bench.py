@@ -45,6 +45,8 @@ def igemm_variant(cin, cout, k=1, m=1 << 30):
             return "conv_igemm_v3<f16,bk32,tc128xtp128>"
         if var == "v3a":
             return f"conv_igemm_v3<f16,bk{bk},tc128xtp128>"
+        if var == "auto" and bk == 64 and k * k * cin >= 2304 and cout >= 512:
+            return "conv_igemm_v5<f16,bk64,tc256xtp256,8 waves>"
         if bk == 32 or k * k * cin <= 1152:
             return "conv_igemm_v3<f16,bk32,tc128xtp128>"
         if m <= 16384:

@@ -74,6 +74,9 @@ static int conv_variant() {
         if (!strcmp(e, "v3b")) return 4;
         if (!strcmp(e, "v3c")) return 5;
         if (!strcmp(e, "v3a")) return 6;
+        if (!strcmp(e, "v5a")) return 11;
+        if (!strcmp(e, "v5b")) return 12;
+        if (!strcmp(e, "v5c")) return 13;
         return 3;
     }();
     return v;
@@ -528,6 +531,236 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_v3_kernel(const ConvArgs p)
 #endif
 }
 
+// ---- v5: the v3 structure generalised to WAVES_C x WAVES_P waves (8 waves = 512 threads, 256 couts x 256 pixels).
+// Probe runs (profiles/r01_conv_probe.md) showed v3 spending as many issue cycles on `buffer_load ... lds` pieces as on the
+// MFMAs they feed and its MFMA + ds_read half topping out at ~45 %: a 256x256 tile halves the staged bytes (DMA pieces)
+// per MFMA and a 128c x 64p wave tile needs 0.75 fragment reads per MFMA instead of 1.  One block (8 waves) per CU.
+// Original v3 notes follow.
+// ---- v3: LDS-DMA staging.  `buffer_load_dwordx4 ... lds` moves each wave's 1 KiB chunk straight from L2/HBM into
+// the LDS tile (no VGPR round trip, no ds_write pass); the destination is lane-linear, so the XOR swizzle is applied
+// to the SOURCE address (lane = physical slot, it fetches the logical slot that belongs there) and again on the
+// fragment read.  Out-of-range lanes (halo, tails, K padding) carry offset 0xffffffff: the descriptor's bounds check
+// makes them land as zeros.  Two LDS stages, ONE barrier per K-step: the barrier both publishes tile t (each wave's
+// vmcnt(0) precedes it) and retires the reads of the stage tile t+1 is about to overwrite.  Fragments are
+// double-buffered in registers so the ds_read of k-substep s+1 is in flight under the MFMAs of s.
+// WAVES 2x2; per-wave tile (MC*32 couts) x (MP*32 pixels).
+template <typename T, int BK, int WAVES_C, int WAVES_P, int MC, int MP>
+__global__ __launch_bounds__(64 * WAVES_C * WAVES_P, 2) void conv_igemm_v5_kernel(const ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // device-only builtins (LDS address space, buffer->LDS DMA): the host pass only needs the stub
+    constexpr int NT = 64 * WAVES_C * WAVES_P;
+    constexpr int TC = WAVES_C * MC * 32;
+    constexpr int TP = WAVES_P * MP * 32;
+    constexpr int S = BK / 8;
+    constexpr int WJ = TC * S / NT;
+    constexpr int XJ = TP * S / NT;
+    static_assert((TC * S) % NT == 0 && (TP * S) % NT == 0, "whole chunks only");
+    constexpr int W_BYTES = TC * BK * 2;
+    constexpr int STAGE_BYTES = (TC + TP) * BK * 2;
+    constexpr int EP = TC + 4;
+    constexpr int EPI_ROWS = MP * 32;                      // one pixel-half (the waves with equal wp) per pass
+    constexpr int EPI_BYTES = EPI_ROWS * EP * 4;
+    constexpr int LDS_BYTES = 2 * STAGE_BYTES > EPI_BYTES ? 2 * STAGE_BYTES : EPI_BYTES;
+    constexpr int ROWSTEP = NT / S;
+    constexpr int KSUB = BK / 16;
+    typedef typename Mfma<T>::frag frag;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wv / WAVES_P, wp = wv % WAVES_P;
+
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int pt = L / p.n_ct, ct = L % p.n_ct;
+
+    const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xffffffffu;
+
+    const int pslot = tid % S;   // physical 16-byte slot this lane fills in every row it touches
+    const int row0 = tid / S;
+
+    int xoff[XJ], hi0[XJ], wi0[XJ], xc0[XJ];
+    bool mvalid[XJ];
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) {
+        const int row = row0 + j * ROWSTEP;
+        const int m = pt * TP + row;
+        const bool v = m < p.M;
+        const int mm = v ? m : 0;
+        const int n = mm / (p.Ho * p.Wo);
+        const int rem = mm - n * (p.Ho * p.Wo);
+        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        hi0[j] = ho * p.stride - p.pad;
+        wi0[j] = wo * p.stride - p.pad;
+        xoff[j] = (int)(((long long)n * p.H * p.W * p.xpitch) * 2);  // byte offset of image n
+        xc0[j] = ((pslot ^ swz<BK>(row)) * 8) * 2;          // byte offset of the logical slot inside the K-step
+        mvalid[j] = v;
+    }
+    unsigned woff[WJ];
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) {
+        const int row = row0 + j * ROWSTEP;
+        woff[j] = (unsigned)(((long long)(ct * TC + row) * p.Kpad + (pslot ^ swz<BK>(row)) * 8) * 2);
+    }
+
+    auto dma = [&](int it, int stage) {
+        const int tap = it / p.cin_blocks;
+        const int cb = it - tap * p.cin_blocks;
+        const int kh = tap / p.ks, kw = tap - kh * p.ks;
+        unsigned char* wl = smem + stage * STAGE_BYTES;
+        unsigned char* xl = wl + W_BYTES;
+#pragma unroll
+        for (int j = 0; j < WJ; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(wl + (j * NT + wv * 64) * 16), 16, woff[j] + (unsigned)(it * BK * 2), 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < XJ; ++j) {
+            const int hi = hi0[j] + kh, wi = wi0[j] + kw;
+            const bool ok = mvalid[j] && in_image(hi, wi, p);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(xl + (j * NT + wv * 64) * 16), 16,
+                                                     ok ? (unsigned)(xoff[j] + tap_bytes(hi0[j], wi0[j], kh, kw, cb * BK, p) + xc0[j]) : OOB, 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[MC][MP];
+#pragma unroll
+    for (int a = 0; a < MC; ++a)
+#pragma unroll
+        for (int b = 0; b < MP; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    const int frow = lane & 31;
+    const int fk = lane >> 5;
+
+    auto load_frags = [&](int stage, int kk, frag (&af)[MC], frag (&bf)[MP]) {
+        const unsigned char* wl = smem + stage * STAGE_BYTES;
+        const unsigned char* xl = wl + W_BYTES;
+        const int ks = kk * 2 + fk;
+#pragma unroll
+        for (int a = 0; a < MC; ++a) {
+            const int row = (wc * MC + a) * 32 + frow;
+            af[a] = *(const frag*)(wl + row * (BK * 2) + ((ks ^ swz<BK>(row)) << 4));
+        }
+#pragma unroll
+        for (int b = 0; b < MP; ++b) {
+            const int row = (wp * MP + b) * 32 + frow;
+            bf[b] = *(const frag*)(xl + row * (BK * 2) + ((ks ^ swz<BK>(row)) << 4));
+        }
+    };
+    auto mma = [&](const frag (&af)[MC], const frag (&bf)[MP]) {
+#pragma unroll
+        for (int a = 0; a < MC; ++a)
+#pragma unroll
+            for (int b = 0; b < MP; ++b) acc[a][b] = Mfma<T>::run(af[a], bf[b], acc[a][b]);
+    };
+
+    dma(0, 0);
+    for (int it = 0; it < p.nk; ++it) {
+        __syncthreads();  // tile `it` has landed for every wave; stage (it+1)&1 is no longer being read
+        if (it + 1 < p.nk) dma(it + 1, (it + 1) & 1);
+        const int st = it & 1;
+        frag a0[MC], b0[MP], a1[MC], b1[MP];
+        load_frags(st, 0, a0, b0);
+#pragma unroll
+        for (int kk = 0; kk < KSUB; kk += 2) {
+            load_frags(st, kk + 1, a1, b1);
+            mma(a0, b0);
+            if (kk + 2 < KSUB) load_frags(st, kk + 2, a0, b0);
+            mma(a1, b1);
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue: one pixel-half per pass (the two waves with wp == h own it) ----
+    float* el = (float*)smem;
+    constexpr int CR = TC / 8;
+    constexpr int EJ = (EPI_ROWS * CR + NT - 1) / NT;
+    T* __restrict__ yg = (T*)p.y;
+    const T* __restrict__ rg = (const T*)p.res;
+#pragma unroll
+    for (int h = 0; h < WAVES_P; ++h) {
+        if (wp == h) {
+#pragma unroll
+            for (int a = 0; a < MC; ++a) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cl = (wc * MC + a) * 32 + 8 * g + 4 * fk;
+                    const int cgl = ct * TC + cl;
+                    float b4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) b4[q] = (cgl + q < p.Cout) ? p.bias[cgl + q] : 0.0f;
+#pragma unroll
+                    for (int b = 0; b < MP; ++b) {
+                        const int pl = b * 32 + frow;
+                        f32x4 v;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float t = acc[a][b][4 * g + q] + b4[q];
+                            if (p.act == Y3_ACT_SILU) t = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));
+                            v[q] = t;
+                        }
+                        *(f32x4*)(el + pl * EP + cl) = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < EJ; ++j) {
+            const int idx = tid + j * NT;
+            const int row = idx / CR, ch = idx - row * CR;
+            const int m = pt * TP + h * EPI_ROWS + row;
+            const int c = ct * TC + ch * 8;
+            if (row < EPI_ROWS && m < p.M && c + 8 <= p.Cout) {
+                const f32x4 v0 = *(const f32x4*)(el + row * EP + ch * 8);
+                const f32x4 v1 = *(const f32x4*)(el + row * EP + ch * 8 + 4);
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                const int n = m / (p.Ho * p.Wo);
+                const int rem = m - n * (p.Ho * p.Wo);
+                const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                if (rg) {
+                    const uint4 rv = *(const uint4*)(rg + ((long long)(n * p.Ho + ho) * p.Wo + wo) * p.rpitch + c);
+                    const T* rp = (const T*)&rv;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] += to_f32<T>(rp[q]);
+                }
+                uint4 ov;
+                T* op = (T*)&ov;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) op[q] = from_f32<T>(v[q]);
+                if (!p.ups) {
+                    *(uint4*)(yg + ((long long)(n * p.Ho + ho) * p.Wo + wo) * p.ypitch + c) = ov;
+                } else {
+                    const int H2 = p.Ho * 2, W2 = p.Wo * 2;
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 2; ++dx)
+                            *(uint4*)(yg + ((long long)(n * H2 + 2 * ho + dy) * W2 + 2 * wo + dx) * p.ypitch + c) = ov;
+                }
+            }
+        }
+        if (h + 1 < WAVES_P) __syncthreads();
+    }
+#endif
+}
+
+template <typename T, int BK, int WAVES_C, int WAVES_P, int MC, int MP> int launch_v5(ConvArgs& a, hipStream_t st) {
+    constexpr int TC = WAVES_C * MC * 32, TP = WAVES_P * MP * 32;
+    a.n_ct = y3_ceil_div(a.Cout, TC);
+    a.n_pt = y3_ceil_div(a.M, TP);
+    a.cin_blocks = a.Cin / BK;
+    a.nk = a.ks * a.ks * a.cin_blocks;
+    const long long nb = (long long)a.n_ct * a.n_pt;
+    if (nb > 0x7fffffffLL) Y3_FAIL("conv grid too large");
+    hipLaunchKernelGGL((conv_igemm_v5_kernel<T, BK, WAVES_C, WAVES_P, MC, MP>), dim3((unsigned)nb), dim3(64 * WAVES_C * WAVES_P), 0, st, a);
+    Y3_CHECK_LAUNCH();
+    return 0;
+}
+
 template <typename T, int BK, int MC, int MP> int launch_v3(ConvArgs& a, hipStream_t st) {
     constexpr int TC = 2 * MC * 32, TP = 2 * MP * 32;
     a.n_ct = y3_ceil_div(a.Cout, TC);
@@ -624,9 +857,16 @@ template <typename T> int dispatch_igemm(ConvArgs& a, hipStream_t st) {
         if (var == 4) return launch_v3<T, 32, 2, 4>(a, st);   // 128c x 256p, BK 32
         if (var == 5) return launch_v3<T, 32, 2, 2>(a, st);   // 128c x 128p, BK 32 (4 blocks / CU)
         if (var == 6) return c64 ? launch_v3<T, 64, 2, 2>(a, st) : launch_v3<T, 32, 2, 2>(a, st);
-        // auto (measured on MI355X, profiles/r01_conv_variants.md): short K loops want 4 resident blocks per CU
-        // (BK 32), small pixel counts with long K want the 128x256 tile, the rest the BK 64 128x128 tile.
+        if (var >= 11 && var <= 13 && c64 && a.Cout >= 256) {
+            if (var == 11) return launch_v5<T, 64, 2, 4, 4, 2>(a, st);   // 256c x 256p, wave 128c x 64p, BK 64
+            if (var == 12) return launch_v5<T, 64, 4, 2, 2, 4>(a, st);   // 256c x 256p, wave 64c x 128p, BK 64
+            return launch_v5<T, 32, 2, 4, 4, 2>(a, st);                  // 256c x 256p, wave 128c x 64p, BK 32 (2 blocks/CU by LDS)
+        }
+        // auto (measured on MI355X, profiles/r01_conv_variants.md): long-K layers with >= 512 filters want the 8-wave
+        // 256x256 tile (v5), short K loops want 4 resident blocks per CU (BK 32), small pixel counts with long K the
+        // 128x256 tile, the rest the BK 64 128x128 tile.
         const int K = a.ks * a.ks * a.Cin;
+        if (c64 && K >= 2304 && a.Cout >= 512) return launch_v5<T, 64, 4, 2, 2, 4>(a, st);   // 256c x 256p, 8 waves (64c x 128p each)
         if (!c64 || K <= 1152) return launch_v3<T, 32, 2, 2>(a, st);
         if (a.M <= 16384) return launch_v3<T, 32, 2, 4>(a, st);
         return launch_v3<T, 64, 2, 2>(a, st);
