@@ -52,6 +52,8 @@ def igemm_variant(cin, cout, k=1, m=1 << 30):
         if m <= 16384:
             return "conv_igemm_v3<f16,bk32,tc128xtp256>"
         return "conv_igemm_v3<f16,bk64,tc128xtp128>"
+    if var != "v2" and cout <= 64 and cin % 32 == 0:
+        return "conv_igemm_v3<f16,bk32,tc64xtp256>"
     small = "" if cin % 32 == 0 else "_smallc"
     tile = "tc128xtp128" if cout > 64 else "tc64xtp128" if cout > 32 else "tc32xtp256"
     return f"conv_igemm_{'v1' if var == 'v1' else 'v2'}<f16,bk{bk},{tile}{small}>"

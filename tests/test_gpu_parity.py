@@ -677,3 +677,33 @@ def test_fused_sgd_vs_torch_reference(dev):
     opt.step(grad_scale=1.0, max_norm=10.0)
     torch.cuda.synchronize()
     assert opt.found_inf.item() == 1 and all(torch.equal(a, b.detach()) for a, b in zip(before, ps))
+
+
+@pytest.mark.parametrize("name,h,w,bs,dtype", [("yolov3", 96, 160, 1, torch.float32), ("yolov3-tiny", 128, 96, 3, torch.float32), ("yolov3-spp", 160, 96, 2, torch.float16)])
+def test_model_rectangular_and_odd_batches(dev, name, h, w, bs, dtype):
+    """rect inference (val.py pads batches to rectangles, e.g. 640x512), batch sizes that do not fill a pixel tile,
+    export mode and plan re-use across shapes."""
+    m, (layers, save, sd, strides) = build_pair(name, 80, 29, dev, dtype)
+    x = torch.rand(bs, 3, h, w, generator=torch.Generator().manual_seed(4))
+    pred, raw = m(x.to(dev).to(dtype))
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        refp, refraw = yo.forward(layers, save, sd, x, strides, training=False)
+    assert pred.shape == refp.shape
+    for a, b in zip(raw, refraw):
+        a = a.float().cpu()
+        assert a.shape == b.shape
+        if dtype == torch.float32:
+            assert (a - b).abs().max().item() < 1e-4
+        else:
+            assert (a - b).abs().max().item() / b.abs().max().item() < 0.03
+    # a second shape compiles a second plan; the first one is still valid afterwards
+    x2 = torch.rand(bs + 1, 3, h + 32, w, generator=torch.Generator().manual_seed(5))
+    p2, _ = m(x2.to(dev).to(dtype))
+    p1, _ = m(x.to(dev).to(dtype))
+    torch.cuda.synchronize()
+    assert torch.equal(p1, pred) and p2.shape[0] == bs + 1
+    m.model[-1].export = True
+    out = m(x.to(dev).to(dtype))
+    assert isinstance(out, tuple) and len(out) == 1 and torch.equal(out[0], pred)
+    m.model[-1].export = False

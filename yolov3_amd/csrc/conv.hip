@@ -871,6 +871,10 @@ template <typename T> int dispatch_igemm(ConvArgs& a, hipStream_t st) {
         if (a.M <= 16384) return launch_v3<T, 32, 2, 4>(a, st);
         return launch_v3<T, 64, 2, 2>(a, st);
     }
+    // <= 64-filter layers with Cin % 32 == 0 also go to the LDS-DMA kernel (64c x 256p tile): measured 0.42 -> 0.36 ms on
+    // 32->64 s2 @640x640 and 0.44 -> 0.38 ms on 32->64 @320x320 (bs 32); Y3_CONV_SMALL=v2 restores the register-staged kernel
+    static const bool small_v3 = !(getenv("Y3_CONV_SMALL") && !strcmp(getenv("Y3_CONV_SMALL"), "v2"));
+    if (small_v3 && var != 2 && a.Cout <= 64 && c32 && a.x_bytes && a.w_bytes) return launch_v3<T, 32, 1, 4>(a, st);   // 64c x 256p, wave 32c x 128p
     if (a.Cout > 64) {
         if (c64) return launch_igemm<T, 64, 2, 2, 2, 2, false>(a, st);
         if (c32) return launch_igemm<T, 32, 2, 2, 2, 2, false>(a, st);
