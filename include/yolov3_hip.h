@@ -172,6 +172,14 @@ int y3_bn_act_bwd(const y3_tensor* u, const y3_tensor* dy, const float* scale, c
 /* OIHW fp32 -> filter bank of the data-gradient convolution: `cin` filters over (kh, kw, cout) with flipped taps. */
 int y3_pack_filter_dgrad(const float* w_oihw, int32_t cout_src, int32_t cin_src, int32_t ksize, int32_t cout, int32_t cin,
                          int32_t dtype, void* packed, void* stream);
+/* Data gradient of a 3x3 stride-2 pad-1 conv without multiplying the zero taps of the dilated form: four output-parity
+ * classes, each a small stride-1 conv of du (1, 2, 2 and 4 taps) with its own filter bank, written to every second
+ * pixel of gx (+= residual when given; residual may alias gx).  f16/bf16 only. */
+size_t y3_packed_filter_dgrad_s2_elems(int32_t cout, int32_t cin);
+int y3_pack_filter_dgrad_s2(const float* w_oihw, int32_t cout_src, int32_t cin_src, int32_t cout, int32_t cin, int32_t dtype,
+                            void* packed4, void* stream);
+int y3_conv2d_dgrad_s2(int32_t dtype, const y3_tensor* du, const void* packed4, const y3_tensor* residual /* may be NULL */,
+                       const y3_tensor* gx, void* stream);
 /* filter gradient (and optional bias gradient = per-channel sum of du) of the conv described by `desc`
  * (dtype, ksize, stride, cin, cout = padded sizes of x / du); dw is (cout_real, cin_real, k, k) fp32, overwritten. */
 size_t y3_conv2d_wgrad_workspace_bytes(const y3_conv_desc* desc, const y3_tensor* x);

@@ -595,6 +595,8 @@ WGRAD_CASES = [
     ("head_255", (2, 20, 20, 256, 256, 1, 1), {"cout_real": 255}),
     ("cin32_3x3", (1, 33, 17, 32, 64, 3, 1), {}),
     ("many_pixels", (4, 80, 80, 64, 64, 3, 1), {}),
+    ("3x3s2_even_cin32", (2, 32, 48, 32, 64, 3, 2), {}),
+    ("3x3s2_deep", (2, 10, 10, 512, 1024, 3, 2), {}),
 ]
 
 
@@ -624,6 +626,15 @@ def test_conv_wgrad_and_dgrad_vs_autograd(dev, dtype, name, shape, kw):
     ops.conv2d(gv, filt_d, torch.zeros(cin, device=dev), gx, k, 1, act=False, residual=gx, in_dilation=s)
     torch.cuda.synchronize()
     tol = {torch.float32: 2e-5, torch.float16: 2e-3, torch.bfloat16: 1.5e-2}[dtype]
+    if s == 2 and k == 3 and dtype != torch.float32:  # parity-class form of the stride-2 data gradient, write then accumulate
+        g2 = ops.View.alloc(n, h, w, cin, dtype, dev)
+        g2.buf.fill_(float("nan"))
+        ops.conv2d_dgrad_s2(wt.detach().to(dev), gv, g2, accumulate=False)
+        d2 = g2.as_nhwc().float().cpu().permute(0, 3, 1, 2)[:, :cin_real]
+        assert (d2 - x.grad).abs().max().item() / x.grad.abs().max().item() < tol, "dgrad_s2 (write)"
+        ops.conv2d_dgrad_s2(wt.detach().to(dev), gv, g2, accumulate=True)
+        d3 = g2.as_nhwc().float().cpu().permute(0, 3, 1, 2)[:, :cin_real]
+        assert (d3 - 2 * x.grad).abs().max().item() / x.grad.abs().max().item() < 2 * tol, "dgrad_s2 (accumulate)"
     e_w = (dw.cpu() - wt.grad).abs().max().item() / wt.grad.abs().max().item()
     e_b = (db.cpu() - gy.sum((0, 2, 3))[:cout_real]).abs().max().item() / gy.sum((0, 2, 3)).abs().max().item()
     dx = gx.as_nhwc().float().cpu().permute(0, 3, 1, 2)[:, :cin_real]

@@ -98,6 +98,19 @@ def pack_filter_dgrad(w_oihw: torch.Tensor, cout: int, cin: int, dtype: torch.dt
     return out
 
 
+def conv2d_dgrad_s2(w_oihw: torch.Tensor, du: View, gx: View, accumulate: bool):
+    """Data gradient of a 3x3 stride-2 conv through the four output-parity class convolutions (f16/bf16)."""
+    dt = du.buf.dtype
+    L = _lib.lib()
+    w = w_oihw.detach().to(torch.float32).contiguous()
+    co, ci, k, _ = w.shape
+    assert k == 3
+    packed = torch.empty(int(L.y3_packed_filter_dgrad_s2_elems(du.c, gx.c)), dtype=dt, device=w.device)
+    check(L.y3_pack_filter_dgrad_s2(w.data_ptr(), co, ci, du.c, gx.c, dtype_code(dt), packed.data_ptr(), stream_ptr()), "y3_pack_filter_dgrad_s2")
+    dut, gxt = du.y3(), gx.y3()
+    check(L.y3_conv2d_dgrad_s2(dtype_code(dt), C.byref(dut), packed.data_ptr(), C.byref(gxt) if accumulate else None, C.byref(gxt), stream_ptr()), "y3_conv2d_dgrad_s2")
+
+
 def conv2d_wgrad(x: View, du: View, k: int, stride: int, cout_real: int, cin_real: int, want_bias: bool = False):
     """Filter gradient (cout_real, cin_real, k, k) fp32 (+ bias gradient) of a conv with input x and output-gradient du."""
     d = Y3ConvDesc(dtype_code(x.buf.dtype), k, stride, 0, 0, 0, x.c, du.c, 0)

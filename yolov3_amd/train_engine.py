@@ -144,9 +144,12 @@ class ConvUnit(_Unit):
         grads[m.bn.bias] = dbeta[: self.co_real]
         if self.need_dx:
             gx = self.x.grad()
-            filt_d = ops.pack_filter_dgrad(m.conv.weight, self.cout, self.cin, self.plan.dtype)
-            zb = self.plan.zeros_f32(self.cin)
-            ops.conv2d(du, filt_d, zb, gx, self.k, 1, act=False, residual=gx if self.x.is_ready() else None, in_dilation=self.s)
+            if self.s == 2 and self.k == 3 and self.plan.dtype != torch.float32:
+                ops.conv2d_dgrad_s2(m.conv.weight, du, gx, accumulate=self.x.is_ready())   # no zero-tap waste
+            else:
+                filt_d = ops.pack_filter_dgrad(m.conv.weight, self.cout, self.cin, self.plan.dtype)
+                zb = self.plan.zeros_f32(self.cin)
+                ops.conv2d(du, filt_d, zb, gx, self.k, 1, act=False, residual=gx if self.x.is_ready() else None, in_dilation=self.s)
             self.x.mark_ready()
 
 
