@@ -78,7 +78,7 @@ def per_kernel_times(plan, reps=5):
         for ln, e0, e1 in evs:
             if ln.flops:
                 w = ln.keep[4]
-                key = igemm_variant(w.cin, w.cout, w.k, int(ln.flops / (2.0 * w.cout * w.cin * w.k * w.k)))
+                key = igemm_variant(w.cin, w.cout, w.k, int(ln.flops / (2.0 * w.cout * w.cin * w.k * w.k))) + f"/{w.k}x{w.k}"
             else:
                 key = ln.label.split(".")[-1]
             a = acc.setdefault(key, [0.0, 0.0, 0.0, 0])
@@ -268,16 +268,19 @@ def main():
         total_kernel_s = sum(g[2] for g in groups.values()) / 5
         pmc = {}
         try:  # HBM traffic per launch comes from the committed rocprofv3 --pmc passes (bench.py cannot run the profiler)
-            pmc = json.load(open(ROOT / "profiles" / "r01_pmc_summary.json")).get(dom, {})
+            pmc = json.load(open(ROOT / "profiles" / "r01_pmc_summary.json")).get(dom, {})  # keyed "<kernel instance>/<k>x<k>"
         except OSError:
             pass
+        # 3x3 launches with Cin >= 128 are MFMA-bound, the 1x1 / small-channel launches of the same template HBM-bound
+        # (SURVEY Appendix B): groups are split by filter size so that the dominant group has ONE bounding roofline
+        bound = "mfma" if fl / max(by, 1.0) > 312.0 else "hbm"
         roofline = {
             "kernel": dom,
-            "bound": "mfma",
-            "achieved": round(fl / sec / 1e12, 2),
-            "peak": MFMA_PEAK_TFLOPS,
-            "unit": "TFLOP/s",
-            "frac": round(fl / sec / 1e12 / MFMA_PEAK_TFLOPS, 4),
+            "bound": bound,
+            "achieved": round(fl / sec / 1e12, 2) if bound == "mfma" else round(by / sec / 1e9, 1),
+            "peak": MFMA_PEAK_TFLOPS if bound == "mfma" else HBM_PEAK_GBS,
+            "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+            "frac": round(fl / sec / 1e12 / MFMA_PEAK_TFLOPS, 4) if bound == "mfma" else round(by / sec / 1e9 / HBM_PEAK_GBS, 4),
             "traffic": round(pmc["hbm_bytes_per_launch"]) if "hbm_bytes_per_launch" in pmc else None,
             "traffic_source": "profiles/r01_pmc_summary.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, avg per launch)" if pmc else None,
             "algorithmic_bytes_per_launch": round(by / nl),
@@ -289,7 +292,8 @@ def main():
                 "conv_tflops": round(total_conv_flops / total_kernel_s / 1e12, 2),
                 "gflop_per_image": round(total_conv_flops / bs / 1e9, 2),
                 "kernel_ms": round(total_kernel_s * 1e3, 3),
-                "by_kernel_ms": {k: round(g[2] / 5 * 1e3, 3) for k, g in sorted(groups.items(), key=lambda kv: -kv[1][2])},
+                "by_kernel": {k: {"ms": round(g[2] / 5 * 1e3, 3), "launches": g[3] // 5, "tflops": round(g[0] / g[2] / 1e12, 1), "gbs": round(g[1] / g[2] / 1e9, 1)}
+                              for k, g in sorted(groups.items(), key=lambda kv: -kv[1][2])},
             },
         }
         cpu = None if args.no_cpu_baseline else cpu_baseline()

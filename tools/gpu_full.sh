@@ -1,0 +1,5 @@
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu_full.log 2>&1; echo "exit $?" >> gpurun_out/pytest_gpu_full.log
+tail -4 gpurun_out/pytest_gpu_full.log
+timeout 300 python __graft_entry__.py smoke 2>&1 | tail -2
+timeout 900 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; tail -c 2600 gpurun_out/bench_default.json
