@@ -268,7 +268,7 @@ def main():
         total_kernel_s = sum(g[2] for g in groups.values()) / 5
         pmc = {}
         try:  # HBM traffic per launch comes from the committed rocprofv3 --pmc passes (bench.py cannot run the profiler)
-            pmc = json.load(open(ROOT / "profiles" / "r01_pmc_summary.json")).get(dom, {})  # keyed "<kernel instance>/<k>x<k>"
+            pmc = json.load(open(ROOT / "profiles" / "r01_pmc_summary.json")).get(dom.rsplit("/", 1)[0], {})  # PMC averages are per kernel symbol
         except OSError:
             pass
         # 3x3 launches with Cin >= 128 are MFMA-bound, the 1x1 / small-channel launches of the same template HBM-bound
@@ -282,7 +282,7 @@ def main():
             "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
             "frac": round(fl / sec / 1e12 / MFMA_PEAK_TFLOPS, 4) if bound == "mfma" else round(by / sec / 1e9 / HBM_PEAK_GBS, 4),
             "traffic": round(pmc["hbm_bytes_per_launch"]) if "hbm_bytes_per_launch" in pmc else None,
-            "traffic_source": "profiles/r01_pmc_summary.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, avg per launch)" if pmc else None,
+            "traffic_source": "profiles/r01_pmc_summary.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, avg per launch of this kernel symbol)" if pmc else None,
             "algorithmic_bytes_per_launch": round(by / nl),
             "launches_per_forward": nl // 5,
             "avg_launch_us": round(sec / nl * 1e6, 2),

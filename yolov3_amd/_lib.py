@@ -3,10 +3,11 @@ missing or a symbol is absent this module raises -- the product path never route
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "lib" / "libyolov3_hip.so"
+LIB_PATH = Path(os.environ["Y3_LIB"]) if os.environ.get("Y3_LIB") else _PKG / "lib" / "libyolov3_hip.so"  # Y3_LIB: instrumented debug builds (tools/timeline.py)
 
 Y3_F16, Y3_BF16, Y3_F32, Y3_U8 = 0, 1, 2, 3
 Y3_ACT_NONE, Y3_ACT_SILU = 0, 1

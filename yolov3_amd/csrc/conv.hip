@@ -17,6 +17,7 @@
 #include "y3_common.h"
 
 #include <stdlib.h>
+#include <type_traits>
 #include <string.h>
 
 namespace {
@@ -39,13 +40,23 @@ struct ConvArgs {
     int cin_blocks; // Cin / BK (uniform-tap path)
     int n_pt, n_ct;
     unsigned x_bytes, w_bytes;  // extents for the buffer descriptors (0 = tensor too large: plain-pointer kernel)
+    unsigned y_bytes, r_bytes;  // output / residual extents (the LDS-DMA kernels store through bounds-checked descriptors)
     // tap table: input row/col offset of K-loop tap t is (hi0 + tdh[t], wi0 + tdw[t]) with hi0 = ho*stride - pad.
     // A plain k x k conv lists (kh, kw); the parity classes of a stride-2 data gradient list 1, 2 or 4 taps.
     int ntaps;
     signed char tdh[12], tdw[12];
     // output addressing: conv pixel (n, ho, wo) lands at (n, ho*omul + ooh, wo*omul + oow) of an (oH, oW) image
     int oH, oW, omul, ooh, oow;
+#ifdef Y3_TIMELINE  // debug build only (tools/timeline.py): per-block wall-clock stamps
+    unsigned long long* tl;
+#endif
 };
+#ifdef Y3_TIMELINE
+static unsigned long long* g_timeline = nullptr;
+#define Y3_STAMP(i) do { if (p.tl && threadIdx.x == 0) p.tl[(long long)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define Y3_STAMP(i) do { } while (0)
+#endif
 
 template <typename T> struct Mfma;
 template <> struct Mfma<f16_t> {
@@ -329,6 +340,106 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_v2_kernel(const ConvArgs p)
     }
 }
 
+// ---- epilogue of the LDS-DMA kernels (v3 / v5): per-wave transpose through LDS --------------------------------------------
+// A 32x32 MFMA tile leaves lane (pixel = lane & 31, fk = lane >> 5) with filters 8g + 4fk + q (g, q < 4) of that pixel.
+// All waves apply bias + SiLU to their own accumulators at once; one v_permlane32_swap per register pair then gives every lane
+// 8 CONSECUTIVE filters of its pixel, which it rounds to T and drops as one 16-byte chunk into the wave's PRIVATE slice of
+// the (now idle) stage buffers, laid out [pixel][MC*32 filters] with the K-loop's XOR chunk swizzle.  Reading the slice back
+// row-major gives each store instruction whole MC*64-byte runs of a pixel's NHWC row; the residual rows are fetched with
+// the same coalesced pattern before the arithmetic starts and added in fp32.  One block barrier (the stage buffers must be
+// idle), no idle waves.  (The block-wide fp32 transpose this replaces cost 8-17 us per block with half of the waves parked
+// during the exp/rcp pass; a register-only variant with 32-byte runs lost on the residual layers: profiles/r01_conv_timeline.md.)
+template <typename T, int MC, int MP>
+Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MP], unsigned char* wl, int c_base, int m_base, int lane) {
+    typedef typename Mfma<T>::frag vec8;   // 8 x T = one 16-byte chunk
+    constexpr int CH = MC * 4;          // 16-byte chunks per pixel row of this wave's slice
+    constexpr int RB = CH * 16;         // row bytes
+    constexpr int PPI = 64 / CH;        // pixels per load/store instruction
+    constexpr int NI = MP * 32 / PPI;   // instructions per lane
+    constexpr unsigned OOB = 0xffffffffu;
+    const int frow = lane & 31, fk = lane >> 5;
+    const int rp = lane / CH, ch = lane % CH;
+    const bool has_res = p.res != nullptr;
+    // bounds-checked descriptors: lanes beyond M / Cout carry offset 0xffffffff (loads return 0, stores are dropped)
+    const auto rsrc_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)p.y_bytes, 0x00020000);
+    const auto rsrc_r = __builtin_amdgcn_make_buffer_rsrc((void*)(has_res ? p.res : p.y), 0, has_res ? (int)p.r_bytes : 0, 0x00020000);
+
+    // output pixel index of the MFMA pixels this lane owns (-1: beyond M), then re-distributed to the store layout
+    int opx[MP];
+#pragma unroll
+    for (int b = 0; b < MP; ++b) {
+        const int m = m_base + b * 32 + frow;
+        const int mm = m < p.M ? m : 0;
+        const int n = mm / (p.Ho * p.Wo);
+        const int rem = mm - n * (p.Ho * p.Wo);
+        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        const int o = p.ups ? ((n * p.Ho * 2 + 2 * ho) * (p.Wo * 2) + 2 * wo) : (int)out_pix(n, ho, wo, p);
+        opx[b] = m < p.M ? o : -1;
+    }
+    const int c = c_base + ch * 8;
+    const bool cv = c + 8 <= p.Cout;
+    unsigned yoff[NI];
+    u32x4 rres[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int pl = i * PPI + rp;    // pixel (row of the slice) this lane stores in step i
+        const int spx = __builtin_amdgcn_ds_bpermute((pl & 31) << 2, opx[(i * PPI) / 32]);
+        const bool ok = cv && spx >= 0;
+        yoff[i] = ok ? (unsigned)(spx * p.ypitch + c) * 2u : OOB;
+        if (has_res) rres[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, ok ? (unsigned)(spx * p.rpitch + c) * 2u : OOB, 0, 0);
+    }
+
+    auto stash = [&](auto silu) {   // activation + filter-pair swap + 16-byte chunk into the slice
+#pragma unroll
+        for (int a = 0; a < MC; ++a)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp)
+#pragma unroll
+                for (int b = 0; b < MP; ++b) {
+                    vec8 ov;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float t0 = acc[a][b][8 * gp + q];        // filter 16gp + 4fk + q
+                        float t1 = acc[a][b][8 * gp + 4 + q];    // filter 16gp + 8 + 4fk + q
+                        if (decltype(silu)::value) {
+                            t0 = t0 * __builtin_amdgcn_rcpf(1.0f + __expf(-t0));
+                            t1 = t1 * __builtin_amdgcn_rcpf(1.0f + __expf(-t1));
+                        }
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, t0), __builtin_bit_cast(unsigned, t1), false, false);
+                        ov[q] = from_f32<T>(__builtin_bit_cast(float, (unsigned)sw[0]));
+                        ov[4 + q] = from_f32<T>(__builtin_bit_cast(float, (unsigned)sw[1]));
+                    }
+                    const int pl = b * 32 + frow;
+                    const int chunk = a * 4 + gp * 2 + fk;
+                    *(vec8*)(wl + pl * RB + ((chunk ^ swz<MC * 32>(pl)) << 4)) = ov;
+                }
+    };
+    if (p.act == Y3_ACT_SILU) stash(std::true_type{}); else stash(std::false_type{});
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int pl = i * PPI + rp;
+        vec8 ov = *(const vec8*)(wl + pl * RB + ((ch ^ swz<MC * 32>(pl)) << 4));
+        if (has_res) {
+            const vec8 rr = __builtin_bit_cast(vec8, rres[i]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ov[q] = from_f32<T>(to_f32<T>(ov[q]) + to_f32<T>(rr[q]));
+        }
+        const u32x4 raw = __builtin_bit_cast(u32x4, ov);
+        if (!p.ups) {
+            __builtin_amdgcn_raw_buffer_store_b128(raw, rsrc_y, yoff[i], 0, 0);
+        } else {
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx)
+                    __builtin_amdgcn_raw_buffer_store_b128(raw, rsrc_y, yoff[i] == OOB ? OOB : yoff[i] + (unsigned)((dy * p.Wo * 2 + dx) * p.ypitch) * 2u, 0, 0);
+        }
+    }
+}
+
 // ---- v3: LDS-DMA staging.  `buffer_load_dwordx4 ... lds` moves each wave's 1 KiB chunk straight from L2/HBM into
 // the LDS tile (no VGPR round trip, no ds_write pass); the destination is lane-linear, so the XOR swizzle is applied
 // to the SOURCE address (lane = physical slot, it fetches the logical slot that belongs there) and again on the
@@ -338,7 +449,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_v2_kernel(const ConvArgs p)
 // double-buffered in registers so the ds_read of k-substep s+1 is in flight under the MFMAs of s.
 // WAVES 2x2; per-wave tile (MC*32 couts) x (MP*32 pixels).
 template <typename T, int BK, int MC, int MP>
-__global__ __launch_bounds__(256, 2) void conv_igemm_v3_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(256, (BK == 32 && MC * MP <= 4 ? 4 : 2)) void conv_igemm_v3_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // device-only builtins (LDS address space, buffer->LDS DMA): the host pass only needs the stub
     constexpr int WAVES_C = 2, WAVES_P = 2;
     constexpr int TC = WAVES_C * MC * 32;
@@ -349,10 +460,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_v3_kernel(const ConvArgs p)
     static_assert((TC * S) % 256 == 0 && (TP * S) % 256 == 0, "whole chunks only");
     constexpr int W_BYTES = TC * BK * 2;
     constexpr int STAGE_BYTES = (TC + TP) * BK * 2;
-    constexpr int EP = TC + 4;
-    constexpr int EPI_ROWS = MP * 32;                      // one pixel-half (the waves with equal wp) per pass
-    constexpr int EPI_BYTES = EPI_ROWS * EP * 4;
-    constexpr int LDS_BYTES = 2 * STAGE_BYTES > EPI_BYTES ? 2 * STAGE_BYTES : EPI_BYTES;
+    constexpr int LDS_BYTES = 2 * STAGE_BYTES > TC * TP * 2 ? 2 * STAGE_BYTES : TC * TP * 2;  // K-loop stages, re-used as the epilogue's T-typed output tile
     constexpr int ROWSTEP = 256 / S;
     constexpr int KSUB = BK / 16;
     typedef typename Mfma<T>::frag frag;
@@ -360,6 +468,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_v3_kernel(const ConvArgs p)
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
+    Y3_STAMP(0);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -417,16 +526,24 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_v3_kernel(const ConvArgs p)
         }
     };
 
+    const int frow = lane & 31;
+    const int fk = lane >> 5;
+
+    // the accumulators start at the bias of their filter (lane holds filters 8g + 4fk + q of each 32-filter tile): the
+    // loads overlap the first tile's flight and the epilogue has no bias pass
     f32x16 acc[MC][MP];
 #pragma unroll
     for (int a = 0; a < MC; ++a)
 #pragma unroll
-        for (int b = 0; b < MP; ++b)
+        for (int g = 0; g < 4; ++g) {
+            const int cb = ct * TC + (wc * MC + a) * 32 + 8 * g + 4 * fk;
+            f32x4 bz = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias && cb + 4 <= p.Cout) bz = *(const f32x4*)(p.bias + cb);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-
-    const int frow = lane & 31;
-    const int fk = lane >> 5;
+            for (int b = 0; b < MP; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[a][b][4 * g + q] = bz[q];
+        }
 
     auto load_frags = [&](int stage, int kk, frag (&af)[MC], frag (&bf)[MP]) {
         const unsigned char* wl = smem + stage * STAGE_BYTES;
@@ -451,8 +568,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_v3_kernel(const ConvArgs p)
     };
 
     dma(0, 0);
+    Y3_STAMP(1);
     for (int it = 0; it < p.nk; ++it) {
         __syncthreads();  // tile `it` has landed for every wave; stage (it+1)&1 is no longer being read
+        if (it == 0) Y3_STAMP(2);
         if (it + 1 < p.nk) dma(it + 1, (it + 1) & 1);
         const int st = it & 1;
         frag a0[MC], b0[MP], a1[MC], b1[MP];
@@ -465,79 +584,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_v3_kernel(const ConvArgs p)
             mma(a1, b1);
         }
     }
-    __syncthreads();
+    Y3_STAMP(3);
 
-    // ---- epilogue: one pixel-half per pass (the two waves with wp == h own it) ----
-    float* el = (float*)smem;
-    constexpr int CR = TC / 8;
-    constexpr int EJ = (EPI_ROWS * CR + 255) / 256;
-    T* __restrict__ yg = (T*)p.y;
-    const T* __restrict__ rg = (const T*)p.res;
-#pragma unroll
-    for (int h = 0; h < WAVES_P; ++h) {
-        if (wp == h) {
-#pragma unroll
-            for (int a = 0; a < MC; ++a) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int cl = (wc * MC + a) * 32 + 8 * g + 4 * fk;
-                    const int cgl = ct * TC + cl;
-                    float b4[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) b4[q] = (p.bias && cgl + q < p.Cout) ? p.bias[cgl + q] : 0.0f;
-#pragma unroll
-                    for (int b = 0; b < MP; ++b) {
-                        const int pl = b * 32 + frow;
-                        f32x4 v;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            float t = acc[a][b][4 * g + q] + b4[q];
-                            if (p.act == Y3_ACT_SILU) t = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));
-                            v[q] = t;
-                        }
-                        *(f32x4*)(el + pl * EP + cl) = v;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < EJ; ++j) {
-            const int idx = tid + j * 256;
-            const int row = idx / CR, ch = idx - row * CR;
-            const int m = pt * TP + h * EPI_ROWS + row;
-            const int c = ct * TC + ch * 8;
-            if (row < EPI_ROWS && m < p.M && c + 8 <= p.Cout) {
-                const f32x4 v0 = *(const f32x4*)(el + row * EP + ch * 8);
-                const f32x4 v1 = *(const f32x4*)(el + row * EP + ch * 8 + 4);
-                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                const int n = m / (p.Ho * p.Wo);
-                const int rem = m - n * (p.Ho * p.Wo);
-                const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-                if (rg) {
-                    const uint4 rv = *(const uint4*)(rg + out_pix(n, ho, wo, p) * p.rpitch + c);
-                    const T* rp = (const T*)&rv;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] += to_f32<T>(rp[q]);
-                }
-                uint4 ov;
-                T* op = (T*)&ov;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) op[q] = from_f32<T>(v[q]);
-                if (!p.ups) {
-                    *(uint4*)(yg + out_pix(n, ho, wo, p) * p.ypitch + c) = ov;
-                } else {
-                    const int H2 = p.Ho * 2, W2 = p.Wo * 2;
-#pragma unroll
-                    for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                        for (int dx = 0; dx < 2; ++dx)
-                            *(uint4*)(yg + ((long long)(n * H2 + 2 * ho + dy) * W2 + 2 * wo + dx) * p.ypitch + c) = ov;
-                }
-            }
-        }
-        if (h + 1 < WAVES_P) __syncthreads();
-    }
+    __syncthreads();  // every wave is done with the stage buffers: they become the per-wave transpose slices
+    epilogue_wave<T, MC, MP>(p, acc, smem + wv * (MP * 32 * MC * 64), ct * TC + wc * MC * 32, pt * TP + wp * MP * 32, lane);
+    Y3_STAMP(4);
 #endif
 }
 
@@ -566,10 +617,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, 2) void conv_igemm_v5_kerne
     static_assert((TC * S) % NT == 0 && (TP * S) % NT == 0, "whole chunks only");
     constexpr int W_BYTES = TC * BK * 2;
     constexpr int STAGE_BYTES = (TC + TP) * BK * 2;
-    constexpr int EP = TC + 4;
-    constexpr int EPI_ROWS = MP * 32;                      // one pixel-half (the waves with equal wp) per pass
-    constexpr int EPI_BYTES = EPI_ROWS * EP * 4;
-    constexpr int LDS_BYTES = 2 * STAGE_BYTES > EPI_BYTES ? 2 * STAGE_BYTES : EPI_BYTES;
+    constexpr int LDS_BYTES = 2 * STAGE_BYTES > TC * TP * 2 ? 2 * STAGE_BYTES : TC * TP * 2;  // K-loop stages, re-used as the epilogue's T-typed output tile
     constexpr int ROWSTEP = NT / S;
     constexpr int KSUB = BK / 16;
     typedef typename Mfma<T>::frag frag;
@@ -577,6 +625,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, 2) void conv_igemm_v5_kerne
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
+    Y3_STAMP(0);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -634,16 +683,24 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, 2) void conv_igemm_v5_kerne
         }
     };
 
+    const int frow = lane & 31;
+    const int fk = lane >> 5;
+
+    // the accumulators start at the bias of their filter (lane holds filters 8g + 4fk + q of each 32-filter tile): the
+    // loads overlap the first tile's flight and the epilogue has no bias pass
     f32x16 acc[MC][MP];
 #pragma unroll
     for (int a = 0; a < MC; ++a)
 #pragma unroll
-        for (int b = 0; b < MP; ++b)
+        for (int g = 0; g < 4; ++g) {
+            const int cb = ct * TC + (wc * MC + a) * 32 + 8 * g + 4 * fk;
+            f32x4 bz = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias && cb + 4 <= p.Cout) bz = *(const f32x4*)(p.bias + cb);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-
-    const int frow = lane & 31;
-    const int fk = lane >> 5;
+            for (int b = 0; b < MP; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[a][b][4 * g + q] = bz[q];
+        }
 
     auto load_frags = [&](int stage, int kk, frag (&af)[MC], frag (&bf)[MP]) {
         const unsigned char* wl = smem + stage * STAGE_BYTES;
@@ -668,8 +725,10 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, 2) void conv_igemm_v5_kerne
     };
 
     dma(0, 0);
+    Y3_STAMP(1);
     for (int it = 0; it < p.nk; ++it) {
         __syncthreads();  // tile `it` has landed for every wave; stage (it+1)&1 is no longer being read
+        if (it == 0) Y3_STAMP(2);
         if (it + 1 < p.nk) dma(it + 1, (it + 1) & 1);
         const int st = it & 1;
         frag a0[MC], b0[MP], a1[MC], b1[MP];
@@ -682,79 +741,11 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, 2) void conv_igemm_v5_kerne
             mma(a1, b1);
         }
     }
-    __syncthreads();
+    Y3_STAMP(3);
 
-    // ---- epilogue: one pixel-half per pass (the two waves with wp == h own it) ----
-    float* el = (float*)smem;
-    constexpr int CR = TC / 8;
-    constexpr int EJ = (EPI_ROWS * CR + NT - 1) / NT;
-    T* __restrict__ yg = (T*)p.y;
-    const T* __restrict__ rg = (const T*)p.res;
-#pragma unroll
-    for (int h = 0; h < WAVES_P; ++h) {
-        if (wp == h) {
-#pragma unroll
-            for (int a = 0; a < MC; ++a) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int cl = (wc * MC + a) * 32 + 8 * g + 4 * fk;
-                    const int cgl = ct * TC + cl;
-                    float b4[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) b4[q] = (p.bias && cgl + q < p.Cout) ? p.bias[cgl + q] : 0.0f;
-#pragma unroll
-                    for (int b = 0; b < MP; ++b) {
-                        const int pl = b * 32 + frow;
-                        f32x4 v;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            float t = acc[a][b][4 * g + q] + b4[q];
-                            if (p.act == Y3_ACT_SILU) t = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));
-                            v[q] = t;
-                        }
-                        *(f32x4*)(el + pl * EP + cl) = v;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < EJ; ++j) {
-            const int idx = tid + j * NT;
-            const int row = idx / CR, ch = idx - row * CR;
-            const int m = pt * TP + h * EPI_ROWS + row;
-            const int c = ct * TC + ch * 8;
-            if (row < EPI_ROWS && m < p.M && c + 8 <= p.Cout) {
-                const f32x4 v0 = *(const f32x4*)(el + row * EP + ch * 8);
-                const f32x4 v1 = *(const f32x4*)(el + row * EP + ch * 8 + 4);
-                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                const int n = m / (p.Ho * p.Wo);
-                const int rem = m - n * (p.Ho * p.Wo);
-                const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-                if (rg) {
-                    const uint4 rv = *(const uint4*)(rg + out_pix(n, ho, wo, p) * p.rpitch + c);
-                    const T* rp = (const T*)&rv;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] += to_f32<T>(rp[q]);
-                }
-                uint4 ov;
-                T* op = (T*)&ov;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) op[q] = from_f32<T>(v[q]);
-                if (!p.ups) {
-                    *(uint4*)(yg + out_pix(n, ho, wo, p) * p.ypitch + c) = ov;
-                } else {
-                    const int H2 = p.Ho * 2, W2 = p.Wo * 2;
-#pragma unroll
-                    for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                        for (int dx = 0; dx < 2; ++dx)
-                            *(uint4*)(yg + ((long long)(n * H2 + 2 * ho + dy) * W2 + 2 * wo + dx) * p.ypitch + c) = ov;
-                }
-            }
-        }
-        if (h + 1 < WAVES_P) __syncthreads();
-    }
+    __syncthreads();  // every wave is done with the stage buffers: they become the per-wave transpose slices
+    epilogue_wave<T, MC, MP>(p, acc, smem + wv * (MP * 32 * MC * 64), ct * TC + wc * MC * 32, pt * TP + wp * MP * 32, lane);
+    Y3_STAMP(4);
 #endif
 }
 
@@ -863,7 +854,8 @@ int launch_igemm(ConvArgs& a, hipStream_t st) {
 template <typename T> int dispatch_igemm(ConvArgs& a, hipStream_t st) {
     const bool c64 = (a.Cin % 64) == 0, c32 = (a.Cin % 32) == 0;
     const int var = conv_variant();
-    if (var >= 3 && a.Cout > 64 && c32 && a.x_bytes && a.w_bytes) {
+    const bool dma_ok = a.x_bytes && a.w_bytes && a.y_bytes && (!a.res || a.r_bytes);   // every tensor addressable through a 2 GiB descriptor
+    if (var >= 3 && a.Cout > 64 && c32 && dma_ok) {
         if (var == 4) return launch_v3<T, 32, 2, 4>(a, st);   // 128c x 256p, BK 32
         if (var == 5) return launch_v3<T, 32, 2, 2>(a, st);   // 128c x 128p, BK 32 (4 blocks / CU)
         if (var == 6) return c64 ? launch_v3<T, 64, 2, 2>(a, st) : launch_v3<T, 32, 2, 2>(a, st);
@@ -884,7 +876,7 @@ template <typename T> int dispatch_igemm(ConvArgs& a, hipStream_t st) {
     // <= 64-filter layers with Cin % 32 == 0 also go to the LDS-DMA kernel (64c x 256p tile): measured 0.42 -> 0.36 ms on
     // 32->64 s2 @640x640 and 0.44 -> 0.38 ms on 32->64 @320x320 (bs 32); Y3_CONV_SMALL=v2 restores the register-staged kernel
     static const bool small_v3 = !(getenv("Y3_CONV_SMALL") && !strcmp(getenv("Y3_CONV_SMALL"), "v2"));
-    if (small_v3 && var != 2 && a.Cout <= 64 && c32 && a.x_bytes && a.w_bytes) return launch_v3<T, 32, 1, 4>(a, st);   // 64c x 256p, wave 32c x 128p
+    if (small_v3 && var != 2 && a.Cout <= 64 && c32 && dma_ok) return launch_v3<T, 32, 1, 4>(a, st);   // 64c x 256p, wave 32c x 128p
     if (a.Cout > 64) {
         if (c64) return launch_igemm<T, 64, 2, 2, 2, 2, false>(a, st);
         if (c32) return launch_igemm<T, 32, 2, 2, 2, 2, false>(a, st);
@@ -963,7 +955,7 @@ extern "C" int y3_conv2d_fwd(const y3_conv_desc* d, const y3_tensor* x, const vo
             (res && ((uintptr_t)res->data & 15)) || ((uintptr_t)filt & 15))
             Y3_FAIL("y3_conv2d_fwd: tensors must be 16-byte aligned with pitch %% %d == 0", vec);
     }
-    if ((long long)x->n * Ho * Wo > 0x7fffffffLL) Y3_FAIL("y3_conv2d_fwd: too many output pixels");
+    if ((long long)x->n * Ho * Wo * (d->upsample2x ? 4 : 1) > 0x7fffffffLL) Y3_FAIL("y3_conv2d_fwd: too many output pixels");
 
     ConvArgs a;
     memset(&a, 0, sizeof(a));
@@ -982,8 +974,15 @@ extern "C" int y3_conv2d_fwd(const y3_conv_desc* d, const y3_tensor* x, const vo
         const long long wb = (long long)y3_filter_rows(d->cout) * a.Kpad * esz;
         a.x_bytes = xb < 0x7fffffffLL ? (unsigned)xb : 0u;
         a.w_bytes = wb < 0x7fffffffLL ? (unsigned)wb : 0u;
+        const long long opx = (long long)x->n * Ho * Wo * (d->upsample2x ? 4 : 1);
+        const long long yb = ((opx - 1) * y->pitch + y->c) * esz, rb = res ? ((opx - 1) * res->pitch + res->c) * esz : 0;
+        a.y_bytes = yb < 0x7fffffffLL ? (unsigned)yb : 0u;
+        a.r_bytes = rb < 0x7fffffffLL ? (unsigned)rb : 0u;
     }
     hipStream_t st = (hipStream_t)stream;
+#ifdef Y3_TIMELINE
+    a.tl = g_timeline;
+#endif
 
     int algo = d->algo;
     if (algo == Y3_ALGO_AUTO) algo = (d->dtype == Y3_F32) ? Y3_ALGO_DIRECT : Y3_ALGO_MFMA;
@@ -1036,6 +1035,10 @@ __global__ void pack_dgrad_s2_kernel(const float* __restrict__ src, int cout_src
 }
 }  // namespace
 
+#ifdef Y3_TIMELINE
+extern "C" void y3_debug_timeline(void* buf) { g_timeline = (unsigned long long*)buf; }
+#endif
+
 extern "C" size_t y3_packed_filter_dgrad_s2_elems(int32_t cout, int32_t cin) {
     return s2_bank_elems(cout, cin, 1) + 2 * s2_bank_elems(cout, cin, 2) + s2_bank_elems(cout, cin, 4);
 }
@@ -1072,6 +1075,7 @@ extern "C" int y3_conv2d_dgrad_s2(int32_t dtype, const y3_tensor* du, const void
     if ((du->c % 8) || (gx->c % 8) || (du->pitch % 8) || (gx->pitch % 8) || ((uintptr_t)du->data & 15) || ((uintptr_t)gx->data & 15) || ((uintptr_t)packed4 & 15))
         Y3_FAIL("y3_conv2d_dgrad_s2: alignment");
     if (residual && (residual->h != H || residual->w != W || residual->c != gx->c || (residual->pitch % 8))) Y3_FAIL("y3_conv2d_dgrad_s2: residual shape");
+    if ((long long)gx->n * H * W > 0x7fffffffLL) Y3_FAIL("y3_conv2d_dgrad_s2: too many gradient pixels");
     hipStream_t st = (hipStream_t)stream;
     const int cout = du->c, cin = gx->c;
     static float* zero_bias = nullptr;  // bias-free: the kernels read Cout floats; a static zero page is enough
@@ -1101,7 +1105,10 @@ extern "C" int y3_conv2d_dgrad_s2(int32_t dtype, const y3_tensor* du, const void
                 const long long xb = (((long long)du->n * du->h * du->w - 1) * du->pitch + du->c) * 2, wb = (long long)bank * 2;
                 a.x_bytes = xb < 0x7fffffffLL ? (unsigned)xb : 0u;
                 a.w_bytes = wb < 0x7fffffffLL ? (unsigned)wb : 0u;
-                if (!a.x_bytes || !a.w_bytes) Y3_FAIL("y3_conv2d_dgrad_s2: tensor too large");
+                const long long yb = (((long long)gx->n * H * W - 1) * gx->pitch + gx->c) * 2, rb = residual ? (((long long)gx->n * H * W - 1) * residual->pitch + residual->c) * 2 : 0;
+                a.y_bytes = yb < 0x7fffffffLL ? (unsigned)yb : 0u;
+                a.r_bytes = rb < 0x7fffffffLL ? (unsigned)rb : 0u;
+                if (!a.x_bytes || !a.w_bytes || !a.y_bytes || (residual && !a.r_bytes)) Y3_FAIL("y3_conv2d_dgrad_s2: tensor too large");
                 const int rc = dtype == Y3_F16 ? dispatch_igemm<f16_t>(a, st) : dispatch_igemm<bf16_t>(a, st);
                 if (rc) return rc;
             }
