@@ -47,11 +47,11 @@ def igemm_variant(cin, cout, k=1, m=1 << 30):
             return f"conv_igemm_v3<f16,bk{bk},tc128xtp128>"
         if var == "auto" and bk == 64 and k * k * cin >= 2304 and cout >= 512:
             return "conv_igemm_v5<f16,bk64,tc256xtp256,8 waves>"
-        if bk == 32 or k * k * cin <= 1152:
-            return "conv_igemm_v3<f16,bk32,tc128xtp128>"
-        if m <= 16384:
-            return "conv_igemm_v3<f16,bk32,tc128xtp256>"
-        return "conv_igemm_v3<f16,bk64,tc128xtp128>"
+        if var == "auto" and bk == 64 and k == 1 and cout >= 256 and 16384 < m <= 65536:
+            return "conv_igemm_v5<f16,bk64,tc256xtp256,8 waves>"
+        if bk == 64 and ((k > 1 and k * k * cin >= 1152) or (k == 1 and cin >= 256 and m <= 16384)):
+            return "conv_igemm_v3<f16,bk64,tc128xtp128>"
+        return "conv_igemm_v3<f16,bk32,tc128xtp128>"
     if var != "v2" and cout <= 64 and cin % 32 == 0:
         return "conv_igemm_v3<f16,bk32,tc64xtp256>"
     small = "" if cin % 32 == 0 else "_smallc"

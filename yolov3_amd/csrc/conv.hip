@@ -39,7 +39,7 @@ struct ConvArgs {
     int nk;         // K iterations
     int cin_blocks; // Cin / BK (uniform-tap path)
     int n_pt, n_ct;
-    unsigned x_bytes, w_bytes;  // extents for the buffer descriptors (0 = tensor too large: plain-pointer kernel)
+    unsigned x_bytes, w_bytes;  // extents for the buffer descriptors (0 = tensor beyond 2 GiB: the MFMA path refuses it)
     unsigned y_bytes, r_bytes;  // output / residual extents (the LDS-DMA kernels store through bounds-checked descriptors)
     // tap table: input row/col offset of K-loop tap t is (hi0 + tdh[t], wi0 + tdw[t]) with hi0 = ho*stride - pad.
     // A plain k x k conv lists (kh, kw); the parity classes of a stride-2 data gradient list 1, 2 or 4 taps.
@@ -113,234 +113,9 @@ Y3_DEV int tap_bytes(int hi0, int wi0, int kh, int kw, int c0, const ConvArgs& p
     return ((hi * p.W + wi) * p.xpitch + c0) * 2;
 }
 
-// ---- v2 main loop: branch-free buffer loads (out-of-range lanes read 0 through the descriptor's bounds check, so
-// halo / tail handling costs one v_cndmask instead of a divergent branch) and a two-deep register prefetch: while
-// tile t is multiplied out of LDS, tile t+1 waits in registers and tile t+2 is in flight, so a K-step never
-// stalls on HBM/L2 latency.  The compiler's counted vmcnt keeps the younger batch in flight across the LDS store.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <typename T, int BK, int WAVES_C, int WAVES_P, int MC, int MP, bool SMALLC>
-__global__ __launch_bounds__(256, 2) void conv_igemm_v2_kernel(const ConvArgs p) {
-    constexpr int TC = WAVES_C * MC * 32;
-    constexpr int TP = WAVES_P * MP * 32;
-    constexpr int S = BK / 8;
-    constexpr int WJ = (TC * S + 255) / 256;
-    constexpr int XJ = (TP * S + 255) / 256;
-    constexpr int STAGE_BYTES = (TC + TP) * BK * 2;
-    constexpr int EP = TC + 4;
-    constexpr int EPI_BYTES = TP * EP * 4;
-    constexpr int LDS_BYTES = 2 * STAGE_BYTES > EPI_BYTES ? 2 * STAGE_BYTES : EPI_BYTES;
-    constexpr int ROWSTEP = 256 / S;
-    constexpr bool W_FULL = (TC * S) % 256 == 0, X_FULL = (TP * S) % 256 == 0;  // no partial last chunk -> no row guards
-    static_assert(WAVES_C * WAVES_P == 4, "4 waves");
-    typedef typename Mfma<T>::frag frag;
-
-    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wv = tid >> 6;
-    const int wc = wv / WAVES_P, wp = wv % WAVES_P;
-
-    const int L = xcd_remap(blockIdx.x, gridDim.x);
-    const int pt = L / p.n_ct, ct = L % p.n_ct;
-
-    const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
-    const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
-    constexpr unsigned OOB = 0xffffffffu;
-
-    const int slot = tid % S;
-    const int row0 = tid / S;
-
-    int xoff[XJ];  // byte offset of (n, hi0, wi0, 0); may be negative, only used when the tap is inside the image
-    int hi0[XJ], wi0[XJ];
-    bool mvalid[XJ];
-#pragma unroll
-    for (int j = 0; j < XJ; ++j) {
-        const int row = row0 + j * ROWSTEP;
-        const int m = pt * TP + row;
-        const bool v = (X_FULL || row < TP) && (m < p.M);
-        const int mm = v ? m : 0;
-        const int n = mm / (p.Ho * p.Wo);
-        const int rem = mm - n * (p.Ho * p.Wo);
-        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-        hi0[j] = ho * p.stride - p.pad;
-        wi0[j] = wo * p.stride - p.pad;
-        xoff[j] = (int)(((long long)n * p.H * p.W * p.xpitch) * 2);  // byte offset of image n
-        mvalid[j] = v;
-    }
-    unsigned woff[WJ];
-#pragma unroll
-    for (int j = 0; j < WJ; ++j) {
-        const int row = row0 + j * ROWSTEP;
-        woff[j] = (W_FULL || row < TC) ? (unsigned)(((long long)(ct * TC + row) * p.Kpad + slot * 8) * 2) : OOB;
-    }
-
-    u32x4 xa[XJ], wa[WJ], xb[XJ], wb[WJ];
-
-    auto issue = [&](int it, u32x4 (&xr)[XJ], u32x4 (&wr)[WJ]) {
-        int kh, kw, c0;
-        bool tapok = it < p.nk;
-        if (SMALLC) {
-            const int cg = p.Cin >> 3;
-            const int g = it * S + slot;
-            const int tap = g / cg;
-            c0 = (g - tap * cg) * 8;
-            tapok = tapok && (tap < p.ntaps);
-            kh = p.tdh[tapok ? tap : 0];
-            kw = p.tdw[tapok ? tap : 0];
-        } else {
-            const int tap = it / p.cin_blocks;
-            const int cb = it - tap * p.cin_blocks;
-            kh = p.tdh[tap < p.ntaps ? tap : 0];
-            kw = p.tdw[tap < p.ntaps ? tap : 0];
-            c0 = cb * BK + slot * 8;
-        }
-#pragma unroll
-        for (int j = 0; j < XJ; ++j) {
-            const int hi = hi0[j] + kh, wi = wi0[j] + kw;
-            const bool ok = tapok && mvalid[j] && in_image(hi, wi, p);
-            xr[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, ok ? (unsigned)(xoff[j] + tap_bytes(hi0[j], wi0[j], kh, kw, c0, p)) : OOB, 0, 0);
-        }
-        const unsigned wk = it < p.nk ? (unsigned)(it * BK * 2) : OOB;
-#pragma unroll
-        for (int j = 0; j < WJ; ++j) wr[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (woff[j] == OOB || wk == OOB) ? OOB : woff[j] + wk, 0, 0);
-    };
-    auto stash = [&](int stage, const u32x4 (&xr)[XJ], const u32x4 (&wr)[WJ]) {
-        unsigned char* wl = smem + stage * STAGE_BYTES;
-        unsigned char* xl = wl + TC * BK * 2;
-#pragma unroll
-        for (int j = 0; j < WJ; ++j) {
-            const int row = row0 + j * ROWSTEP;
-            if (W_FULL || row < TC) *(u32x4*)(wl + row * (BK * 2) + ((slot ^ swz<BK>(row)) << 4)) = wr[j];
-        }
-#pragma unroll
-        for (int j = 0; j < XJ; ++j) {
-            const int row = row0 + j * ROWSTEP;
-            if (X_FULL || row < TP) *(u32x4*)(xl + row * (BK * 2) + ((slot ^ swz<BK>(row)) << 4)) = xr[j];
-        }
-    };
-
-    f32x16 acc[MC][MP];
-#pragma unroll
-    for (int a = 0; a < MC; ++a)
-#pragma unroll
-        for (int b = 0; b < MP; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-
-    const int frow = lane & 31;
-    const int fk = lane >> 5;
-
-    auto compute = [&](int stage) {
-        const unsigned char* wl = smem + stage * STAGE_BYTES;
-        const unsigned char* xl = wl + TC * BK * 2;
-#pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            frag af[MC], bf[MP];
-            const int ks = kk * 2 + fk;
-#pragma unroll
-            for (int a = 0; a < MC; ++a) {
-                const int row = (wc * MC + a) * 32 + frow;
-                af[a] = *(const frag*)(wl + row * (BK * 2) + ((ks ^ swz<BK>(row)) << 4));
-            }
-#pragma unroll
-            for (int b = 0; b < MP; ++b) {
-                const int row = (wp * MP + b) * 32 + frow;
-                bf[b] = *(const frag*)(xl + row * (BK * 2) + ((ks ^ swz<BK>(row)) << 4));
-            }
-#pragma unroll
-            for (int a = 0; a < MC; ++a)
-#pragma unroll
-                for (int b = 0; b < MP; ++b) acc[a][b] = Mfma<T>::run(af[a], bf[b], acc[a][b]);
-        }
-    };
-
-    issue(0, xa, wa);
-    issue(1, xb, wb);
-    stash(0, xa, wa);
-    __syncthreads();
-    for (int it = 0; it < p.nk; it += 2) {
-        issue(it + 2, xa, wa);       // tile it+2 -> A (in flight during two K-steps)
-        compute(0);                  // tile it
-        stash(1, xb, wb);            // tile it+1 (B was issued one K-step ago)
-        __syncthreads();
-        if (it + 1 >= p.nk) break;
-        issue(it + 3, xb, wb);
-        compute(1);                  // tile it+1
-        stash(0, xa, wa);            // tile it+2
-        __syncthreads();
-    }
-
-    // ---- epilogue (identical to v1) ----
-    float* el = (float*)smem;
-#pragma unroll
-    for (int a = 0; a < MC; ++a) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int cl = (wc * MC + a) * 32 + 8 * g + 4 * fk;
-            const int cgl = ct * TC + cl;
-            float b4[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) b4[q] = (p.bias && cgl + q < p.Cout) ? p.bias[cgl + q] : 0.0f;
-#pragma unroll
-            for (int b = 0; b < MP; ++b) {
-                const int pl = (wp * MP + b) * 32 + frow;
-                f32x4 v;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float t = acc[a][b][4 * g + q] + b4[q];
-                    if (p.act == Y3_ACT_SILU) t = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));
-                    v[q] = t;
-                }
-                *(f32x4*)(el + pl * EP + cl) = v;
-            }
-        }
-    }
-    __syncthreads();
-
-    constexpr int CR = TC / 8;
-    constexpr int EJ = (TP * CR + 255) / 256;
-    T* __restrict__ yg = (T*)p.y;
-    const T* __restrict__ rg = (const T*)p.res;
-#pragma unroll
-    for (int j = 0; j < EJ; ++j) {
-        const int idx = tid + j * 256;
-        const int row = idx / CR, ch = idx - row * CR;
-        const int m = pt * TP + row;
-        const int c = ct * TC + ch * 8;
-        if (row < TP && m < p.M && c + 8 <= p.Cout) {
-            const f32x4 v0 = *(const f32x4*)(el + row * EP + ch * 8);
-            const f32x4 v1 = *(const f32x4*)(el + row * EP + ch * 8 + 4);
-            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            const int n = m / (p.Ho * p.Wo);
-            const int rem = m - n * (p.Ho * p.Wo);
-            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-            if (rg) {
-                const uint4 rv = *(const uint4*)(rg + out_pix(n, ho, wo, p) * p.rpitch + c);
-                const T* rp = (const T*)&rv;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] += to_f32<T>(rp[q]);
-            }
-            uint4 ov;
-            T* op = (T*)&ov;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) op[q] = from_f32<T>(v[q]);
-            if (!p.ups) {
-                *(uint4*)(yg + out_pix(n, ho, wo, p) * p.ypitch + c) = ov;
-            } else {
-                const int H2 = p.Ho * 2, W2 = p.Wo * 2;
-#pragma unroll
-                for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                    for (int dx = 0; dx < 2; ++dx)
-                        *(uint4*)(yg + ((long long)(n * H2 + 2 * ho + dy) * W2 + 2 * wo + dx) * p.ypitch + c) = ov;
-            }
-        }
-    }
-}
-
-// ---- epilogue of the LDS-DMA kernels (v3 / v5): per-wave transpose through LDS --------------------------------------------
+// ---- epilogue of the MFMA kernels: per-wave transpose through LDS ---------------------------------------------------------
 // A 32x32 MFMA tile leaves lane (pixel = lane & 31, fk = lane >> 5) with filters 8g + 4fk + q (g, q < 4) of that pixel.
 // All waves apply bias + SiLU to their own accumulators at once; one v_permlane32_swap per register pair then gives every lane
 // 8 CONSECUTIVE filters of its pixel, which it rounds to T and drops as one 16-byte chunk into the wave's PRIVATE slice of
@@ -438,6 +213,172 @@ Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MP], unsigned cha
                     __builtin_amdgcn_raw_buffer_store_b128(raw, rsrc_y, yoff[i] == OOB ? OOB : yoff[i] + (unsigned)((dy * p.Wo * 2 + dx) * p.ypitch) * 2u, 0, 0);
         }
     }
+}
+
+// ---- v2 main loop: branch-free buffer loads (out-of-range lanes read 0 through the descriptor's bounds check, so
+// halo / tail handling costs one v_cndmask instead of a divergent branch) and a two-deep register prefetch: while
+// tile t is multiplied out of LDS, tile t+1 waits in registers and tile t+2 is in flight, so a K-step never
+// stalls on HBM/L2 latency.  The compiler's counted vmcnt keeps the younger batch in flight across the LDS store.
+
+template <typename T, int BK, int WAVES_C, int WAVES_P, int MC, int MP, bool SMALLC>
+__global__ __launch_bounds__(256, 2) void conv_igemm_v2_kernel(const ConvArgs p) {
+    constexpr int TC = WAVES_C * MC * 32;
+    constexpr int TP = WAVES_P * MP * 32;
+    constexpr int S = BK / 8;
+    constexpr int WJ = (TC * S + 255) / 256;
+    constexpr int XJ = (TP * S + 255) / 256;
+    constexpr int STAGE_BYTES = (TC + TP) * BK * 2;
+    constexpr int LDS_BYTES = 2 * STAGE_BYTES > TC * TP * 2 ? 2 * STAGE_BYTES : TC * TP * 2;  // K-loop stages, re-used as the epilogue's T-typed output tile
+    constexpr int ROWSTEP = 256 / S;
+    constexpr bool W_FULL = (TC * S) % 256 == 0, X_FULL = (TP * S) % 256 == 0;  // no partial last chunk -> no row guards
+    static_assert(WAVES_C * WAVES_P == 4, "4 waves");
+    typedef typename Mfma<T>::frag frag;
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
+    const int wc = wv / WAVES_P, wp = wv % WAVES_P;
+
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int pt = L / p.n_ct, ct = L % p.n_ct;
+
+    const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xffffffffu;
+
+    const int slot = tid % S;
+    const int row0 = tid / S;
+
+    int xoff[XJ];  // byte offset of (n, hi0, wi0, 0); may be negative, only used when the tap is inside the image
+    int hi0[XJ], wi0[XJ];
+    bool mvalid[XJ];
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) {
+        const int row = row0 + j * ROWSTEP;
+        const int m = pt * TP + row;
+        const bool v = (X_FULL || row < TP) && (m < p.M);
+        const int mm = v ? m : 0;
+        const int n = mm / (p.Ho * p.Wo);
+        const int rem = mm - n * (p.Ho * p.Wo);
+        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        hi0[j] = ho * p.stride - p.pad;
+        wi0[j] = wo * p.stride - p.pad;
+        xoff[j] = (int)(((long long)n * p.H * p.W * p.xpitch) * 2);  // byte offset of image n
+        mvalid[j] = v;
+    }
+    unsigned woff[WJ];
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) {
+        const int row = row0 + j * ROWSTEP;
+        woff[j] = (W_FULL || row < TC) ? (unsigned)(((long long)(ct * TC + row) * p.Kpad + slot * 8) * 2) : OOB;
+    }
+
+    u32x4 xa[XJ], wa[WJ], xb[XJ], wb[WJ];
+
+    auto issue = [&](int it, u32x4 (&xr)[XJ], u32x4 (&wr)[WJ]) {
+        int kh, kw, c0;
+        bool tapok = it < p.nk;
+        if (SMALLC) {
+            const int cg = p.Cin >> 3;
+            const int g = it * S + slot;
+            const int tap = g / cg;
+            c0 = (g - tap * cg) * 8;
+            tapok = tapok && (tap < p.ntaps);
+            kh = p.tdh[tapok ? tap : 0];
+            kw = p.tdw[tapok ? tap : 0];
+        } else {
+            const int tap = it / p.cin_blocks;
+            const int cb = it - tap * p.cin_blocks;
+            kh = p.tdh[tap < p.ntaps ? tap : 0];
+            kw = p.tdw[tap < p.ntaps ? tap : 0];
+            c0 = cb * BK + slot * 8;
+        }
+#pragma unroll
+        for (int j = 0; j < XJ; ++j) {
+            const int hi = hi0[j] + kh, wi = wi0[j] + kw;
+            const bool ok = tapok && mvalid[j] && in_image(hi, wi, p);
+            xr[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, ok ? (unsigned)(xoff[j] + tap_bytes(hi0[j], wi0[j], kh, kw, c0, p)) : OOB, 0, 0);
+        }
+        const unsigned wk = it < p.nk ? (unsigned)(it * BK * 2) : OOB;
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) wr[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (woff[j] == OOB || wk == OOB) ? OOB : woff[j] + wk, 0, 0);
+    };
+    auto stash = [&](int stage, const u32x4 (&xr)[XJ], const u32x4 (&wr)[WJ]) {
+        unsigned char* wl = smem + stage * STAGE_BYTES;
+        unsigned char* xl = wl + TC * BK * 2;
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+            const int row = row0 + j * ROWSTEP;
+            if (W_FULL || row < TC) *(u32x4*)(wl + row * (BK * 2) + ((slot ^ swz<BK>(row)) << 4)) = wr[j];
+        }
+#pragma unroll
+        for (int j = 0; j < XJ; ++j) {
+            const int row = row0 + j * ROWSTEP;
+            if (X_FULL || row < TP) *(u32x4*)(xl + row * (BK * 2) + ((slot ^ swz<BK>(row)) << 4)) = xr[j];
+        }
+    };
+
+    const int frow = lane & 31;
+    const int fk = lane >> 5;
+
+    f32x16 acc[MC][MP];   // start at the bias of the lane's filters (see epilogue_wave)
+#pragma unroll
+    for (int a = 0; a < MC; ++a)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int cb = ct * TC + (wc * MC + a) * 32 + 8 * g + 4 * fk;
+            f32x4 bz = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias && cb + 4 <= p.Cout) bz = *(const f32x4*)(p.bias + cb);
+#pragma unroll
+            for (int b = 0; b < MP; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[a][b][4 * g + q] = bz[q];
+        }
+
+    auto compute = [&](int stage) {
+        const unsigned char* wl = smem + stage * STAGE_BYTES;
+        const unsigned char* xl = wl + TC * BK * 2;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            frag af[MC], bf[MP];
+            const int ks = kk * 2 + fk;
+#pragma unroll
+            for (int a = 0; a < MC; ++a) {
+                const int row = (wc * MC + a) * 32 + frow;
+                af[a] = *(const frag*)(wl + row * (BK * 2) + ((ks ^ swz<BK>(row)) << 4));
+            }
+#pragma unroll
+            for (int b = 0; b < MP; ++b) {
+                const int row = (wp * MP + b) * 32 + frow;
+                bf[b] = *(const frag*)(xl + row * (BK * 2) + ((ks ^ swz<BK>(row)) << 4));
+            }
+#pragma unroll
+            for (int a = 0; a < MC; ++a)
+#pragma unroll
+                for (int b = 0; b < MP; ++b) acc[a][b] = Mfma<T>::run(af[a], bf[b], acc[a][b]);
+        }
+    };
+
+    issue(0, xa, wa);
+    issue(1, xb, wb);
+    stash(0, xa, wa);
+    __syncthreads();
+    for (int it = 0; it < p.nk; it += 2) {
+        issue(it + 2, xa, wa);       // tile it+2 -> A (in flight during two K-steps)
+        compute(0);                  // tile it
+        stash(1, xb, wb);            // tile it+1 (B was issued one K-step ago)
+        __syncthreads();
+        if (it + 1 >= p.nk) break;
+        issue(it + 3, xb, wb);
+        compute(1);                  // tile it+1
+        stash(0, xa, wa);            // tile it+2
+        __syncthreads();
+    }
+
+    // the last K-step's barrier has passed: the stage buffers are idle and become the per-wave transpose slices
+    epilogue_wave<T, MC, MP>(p, acc, smem + wv * (MP * 32 * MC * 64), ct * TC + wc * MC * 32, pt * TP + wp * MP * 32, lane);
 }
 
 // ---- v3: LDS-DMA staging.  `buffer_load_dwordx4 ... lds` moves each wave's 1 KiB chunk straight from L2/HBM into
@@ -854,7 +795,9 @@ int launch_igemm(ConvArgs& a, hipStream_t st) {
 template <typename T> int dispatch_igemm(ConvArgs& a, hipStream_t st) {
     const bool c64 = (a.Cin % 64) == 0, c32 = (a.Cin % 32) == 0;
     const int var = conv_variant();
-    const bool dma_ok = a.x_bytes && a.w_bytes && a.y_bytes && (!a.res || a.r_bytes);   // every tensor addressable through a 2 GiB descriptor
+    if (!(a.x_bytes && a.w_bytes && a.y_bytes && (!a.res || a.r_bytes)))
+        Y3_FAIL("conv: a tensor exceeds the 2 GiB reach of a buffer descriptor (split the batch)");
+    const bool dma_ok = true;
     if (var >= 3 && a.Cout > 64 && c32 && dma_ok) {
         if (var == 4) return launch_v3<T, 32, 2, 4>(a, st);   // 128c x 256p, BK 32
         if (var == 5) return launch_v3<T, 32, 2, 2>(a, st);   // 128c x 128p, BK 32 (4 blocks / CU)
@@ -867,11 +810,12 @@ template <typename T> int dispatch_igemm(ConvArgs& a, hipStream_t st) {
         // auto (measured on MI355X, profiles/r01_conv_variants.md): long-K layers with >= 512 filters want the 8-wave
         // 256x256 tile (v5), short K loops want 4 resident blocks per CU (BK 32), small pixel counts with long K the
         // 128x256 tile, the rest the BK 64 128x128 tile.
+        // (re-measured after the epilogue rewrite, gpurun_out/variants2.log -> profiles/r01_conv_variants.md)
         const int K = a.ntaps * a.Cin;
         if (c64 && K >= 2304 && a.Cout >= 512) return launch_v5<T, 64, 4, 2, 2, 4>(a, st);   // 256c x 256p, 8 waves (64c x 128p each)
-        if (!c64 || K <= 1152) return launch_v3<T, 32, 2, 2>(a, st);
-        if (a.M <= 16384) return launch_v3<T, 32, 2, 4>(a, st);
-        return launch_v3<T, 64, 2, 2>(a, st);
+        if (c64 && a.ntaps == 1 && a.Cout >= 256 && a.M > 16384 && a.M <= 65536) return launch_v5<T, 64, 4, 2, 2, 4>(a, st);   // 1x1 @40x40
+        if (c64 && ((a.ntaps > 1 && K >= 1152) || (a.ntaps == 1 && K >= 256 && a.M <= 16384))) return launch_v3<T, 64, 2, 2>(a, st);
+        return launch_v3<T, 32, 2, 2>(a, st);
     }
     // <= 64-filter layers with Cin % 32 == 0 also go to the LDS-DMA kernel (64c x 256p tile): measured 0.42 -> 0.36 ms on
     // 32->64 s2 @640x640 and 0.44 -> 0.38 ms on 32->64 @320x320 (bs 32); Y3_CONV_SMALL=v2 restores the register-staged kernel
