@@ -41,10 +41,13 @@ struct ConvArgs {
     int n_pt, n_ct;
     unsigned x_bytes, w_bytes;  // extents for the buffer descriptors (0 = tensor beyond 2 GiB: the MFMA path refuses it)
     unsigned y_bytes, r_bytes;  // output / residual extents (the LDS-DMA kernels store through bounds-checked descriptors)
+    // multiply-shift reciprocals of Ho*Wo, Wo and n_ct (host: set_divisors): q = n / d for 0 <= n < 2^31 as umulhi(n, mul) >> (sh - 1); mul == 0 means d == 1
+    unsigned dv_hw_mul, dv_hw_sh, dv_w_mul, dv_w_sh, dv_ct_mul, dv_ct_sh;
     // tap table: input row/col offset of K-loop tap t is (hi0 + tdh[t], wi0 + tdw[t]) with hi0 = ho*stride - pad.
     // A plain k x k conv lists (kh, kw); the parity classes of a stride-2 data gradient list 1, 2 or 4 taps.
     int ntaps;
     signed char tdh[12], tdw[12];
+    unsigned long long tap_lo, tap_hi;   // the same table packed for scalar extraction: tap t -> byte t, (dh + 8) | (dw + 8) << 4  (host: pack_taps)
     // output addressing: conv pixel (n, ho, wo) lands at (n, ho*omul + ooh, wo*omul + oow) of an (oH, oW) image
     int oH, oW, omul, ooh, oow;
 #ifdef Y3_TIMELINE  // debug build only (tools/timeline.py): per-block wall-clock stamps
@@ -99,6 +102,42 @@ static int conv_variant() {
     return v;
 }
 
+Y3_DEV int fdiv(int n, unsigned mul, unsigned sh) { return mul ? (int)(__umulhi((unsigned)n, mul) >> (sh - 1)) : n; }
+// output pixel m -> (image, row, column)
+Y3_DEV void pix_coords(int m, const ConvArgs& p, int& n, int& ho, int& wo) {
+    n = fdiv(m, p.dv_hw_mul, p.dv_hw_sh);
+    const int rem = m - n * (p.Ho * p.Wo);
+    ho = fdiv(rem, p.dv_w_mul, p.dv_w_sh);
+    wo = rem - ho * p.Wo;
+}
+static void magic_u31(int d, unsigned& mul, unsigned& sh) {   // host side of fdiv
+    if (d <= 1) { mul = 0; sh = 1; return; }
+    unsigned s = 0;
+    while ((1ll << s) < d) ++s;
+    mul = (unsigned)(((1ull << (31 + s)) / (unsigned long long)d) + 1ull);
+    sh = s;
+}
+static void pack_taps(ConvArgs& a) {
+    a.tap_lo = a.tap_hi = 0;
+    for (int t = 0; t < a.ntaps; ++t) {
+        const unsigned long long b = (unsigned long long)((a.tdh[t] + 8) & 15) | ((unsigned long long)((a.tdw[t] + 8) & 15) << 4);
+        if (t < 8) a.tap_lo |= b << (8 * t); else a.tap_hi |= b << (8 * (t - 8));
+    }
+}
+// (dh, dw) of tap t from the packed table; t is wave-uniform, so this stays on the scalar unit (indexing tdh[]/tdw[] with a
+// run-time tap costs a vector load from the kernarg segment in front of every K-step's gather)
+Y3_DEV void tap_offsets(const ConvArgs& p, int t, int& dh, int& dw) {
+    const unsigned long long w = t < 8 ? p.tap_lo >> (8 * t) : p.tap_hi >> (8 * (t - 8));
+    dh = (int)(w & 15) - 8;
+    dw = (int)((w >> 4) & 15) - 8;
+}
+static void set_divisors(ConvArgs& a) {
+    pack_taps(a);
+    magic_u31(a.Ho * a.Wo, a.dv_hw_mul, a.dv_hw_sh);
+    magic_u31(a.Wo, a.dv_w_mul, a.dv_w_sh);
+    magic_u31(a.n_ct, a.dv_ct_mul, a.dv_ct_sh);
+}
+
 Y3_DEV long long out_pix(int n, int ho, int wo, const ConvArgs& p) {
     return (long long)(n * p.oH + ho * p.omul + p.ooh) * p.oW + wo * p.omul + p.oow;
 }
@@ -106,7 +145,7 @@ Y3_DEV long long out_pix(int n, int ho, int wo, const ConvArgs& p) {
 // Gather helpers shared by the MFMA kernels.  (hi, wi) are coordinates in the (virtually dilated) input image.
 Y3_DEV bool in_image(int hi, int wi, const ConvArgs& p) {
     const int msk = (1 << p.dil_shift) - 1;
-    return ((hi | wi) & msk) == 0 && (unsigned)(hi >> p.dil_shift) < (unsigned)p.H && (unsigned)(wi >> p.dil_shift) < (unsigned)p.W;
+    return (int)(((hi | wi) & msk) == 0) & (int)((unsigned)(hi >> p.dil_shift) < (unsigned)p.H) & (int)((unsigned)(wi >> p.dil_shift) < (unsigned)p.W);
 }
 Y3_DEV int tap_bytes(int hi0, int wi0, int kh, int kw, int c0, const ConvArgs& p) {
     const int hi = (hi0 + kh) >> p.dil_shift, wi = (wi0 + kw) >> p.dil_shift;
@@ -145,9 +184,8 @@ Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MP], unsigned cha
     for (int b = 0; b < MP; ++b) {
         const int m = m_base + b * 32 + frow;
         const int mm = m < p.M ? m : 0;
-        const int n = mm / (p.Ho * p.Wo);
-        const int rem = mm - n * (p.Ho * p.Wo);
-        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        int n, ho, wo;
+        pix_coords(mm, p, n, ho, wo);
         const int o = p.ups ? ((n * p.Ho * 2 + 2 * ho) * (p.Wo * 2) + 2 * wo) : (int)out_pix(n, ho, wo, p);
         opx[b] = m < p.M ? o : -1;
     }
@@ -242,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_v2_kernel(const ConvArgs p)
     const int wc = wv / WAVES_P, wp = wv % WAVES_P;
 
     const int L = xcd_remap(blockIdx.x, gridDim.x);
-    const int pt = L / p.n_ct, ct = L % p.n_ct;
+    const int pt = fdiv(L, p.dv_ct_mul, p.dv_ct_sh), ct = L - pt * p.n_ct;
 
     const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
     const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
@@ -260,9 +298,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_v2_kernel(const ConvArgs p)
         const int m = pt * TP + row;
         const bool v = (X_FULL || row < TP) && (m < p.M);
         const int mm = v ? m : 0;
-        const int n = mm / (p.Ho * p.Wo);
-        const int rem = mm - n * (p.Ho * p.Wo);
-        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        int n, ho, wo;
+        pix_coords(mm, p, n, ho, wo);
         hi0[j] = ho * p.stride - p.pad;
         wi0[j] = wo * p.stride - p.pad;
         xoff[j] = (int)(((long long)n * p.H * p.W * p.xpitch) * 2);  // byte offset of image n
@@ -277,6 +314,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_v2_kernel(const ConvArgs p)
 
     u32x4 xa[XJ], wa[WJ], xb[XJ], wb[WJ];
 
+    int nx_tap = 0, nx_cb = 0, nx_kh, nx_kw;
+    tap_offsets(p, 0, nx_kh, nx_kw);
     auto issue = [&](int it, u32x4 (&xr)[XJ], u32x4 (&wr)[WJ]) {
         int kh, kw, c0;
         bool tapok = it < p.nk;
@@ -286,19 +325,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_v2_kernel(const ConvArgs p)
             const int tap = g / cg;
             c0 = (g - tap * cg) * 8;
             tapok = tapok && (tap < p.ntaps);
-            kh = p.tdh[tapok ? tap : 0];
-            kw = p.tdw[tapok ? tap : 0];
+            tap_offsets(p, tapok ? tap : 0, kh, kw);
         } else {
-            const int tap = it / p.cin_blocks;
-            const int cb = it - tap * p.cin_blocks;
-            kh = p.tdh[tap < p.ntaps ? tap : 0];
-            kw = p.tdw[tap < p.ntaps ? tap : 0];
+            const int cb = nx_cb;   // K-steps are requested strictly in order
+            kh = nx_kh; kw = nx_kw;
+            if (++nx_cb == p.cin_blocks) { nx_cb = 0; ++nx_tap; tap_offsets(p, nx_tap < p.ntaps ? nx_tap : 0, nx_kh, nx_kw); }
             c0 = cb * BK + slot * 8;
         }
 #pragma unroll
         for (int j = 0; j < XJ; ++j) {
             const int hi = hi0[j] + kh, wi = wi0[j] + kw;
-            const bool ok = tapok && mvalid[j] && in_image(hi, wi, p);
+            const bool ok = (int)tapok & (int)mvalid[j] & (int)in_image(hi, wi, p);
             xr[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, ok ? (unsigned)(xoff[j] + tap_bytes(hi0[j], wi0[j], kh, kw, c0, p)) : OOB, 0, 0);
         }
         const unsigned wk = it < p.nk ? (unsigned)(it * BK * 2) : OOB;
@@ -416,7 +453,7 @@ __global__ __launch_bounds__(256, (BK == 32 && MC * MP <= 4 ? 4 : 2)) void conv_
     const int wc = wv / WAVES_P, wp = wv % WAVES_P;
 
     const int L = xcd_remap(blockIdx.x, gridDim.x);
-    const int pt = L / p.n_ct, ct = L % p.n_ct;
+    const int pt = fdiv(L, p.dv_ct_mul, p.dv_ct_sh), ct = L - pt * p.n_ct;
 
     const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
     const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
@@ -433,9 +470,8 @@ __global__ __launch_bounds__(256, (BK == 32 && MC * MP <= 4 ? 4 : 2)) void conv_
         const int m = pt * TP + row;
         const bool v = m < p.M;
         const int mm = v ? m : 0;
-        const int n = mm / (p.Ho * p.Wo);
-        const int rem = mm - n * (p.Ho * p.Wo);
-        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        int n, ho, wo;
+        pix_coords(mm, p, n, ho, wo);
         hi0[j] = ho * p.stride - p.pad;
         wi0[j] = wo * p.stride - p.pad;
         xoff[j] = (int)(((long long)n * p.H * p.W * p.xpitch) * 2);  // byte offset of image n
@@ -449,10 +485,11 @@ __global__ __launch_bounds__(256, (BK == 32 && MC * MP <= 4 ? 4 : 2)) void conv_
         woff[j] = (unsigned)(((long long)(ct * TC + row) * p.Kpad + (pslot ^ swz<BK>(row)) * 8) * 2);
     }
 
+    int nx_tap = 0, nx_cb = 0, nx_kh, nx_kw;   // (tap, channel block) of the next tile to be requested: K-steps are issued strictly in order
+    tap_offsets(p, 0, nx_kh, nx_kw);
     auto dma = [&](int it, int stage) {
-        const int tap = it / p.cin_blocks;
-        const int cb = it - tap * p.cin_blocks;
-        const int kh = p.tdh[tap], kw = p.tdw[tap];
+        const int cb = nx_cb, kh = nx_kh, kw = nx_kw;
+        if (++nx_cb == p.cin_blocks) { nx_cb = 0; ++nx_tap; tap_offsets(p, nx_tap, nx_kh, nx_kw); }
         unsigned char* wl = smem + stage * STAGE_BYTES;
         unsigned char* xl = wl + W_BYTES;
 #pragma unroll
@@ -461,7 +498,7 @@ __global__ __launch_bounds__(256, (BK == 32 && MC * MP <= 4 ? 4 : 2)) void conv_
 #pragma unroll
         for (int j = 0; j < XJ; ++j) {
             const int hi = hi0[j] + kh, wi = wi0[j] + kw;
-            const bool ok = mvalid[j] && in_image(hi, wi, p);
+            const bool ok = (int)mvalid[j] & (int)in_image(hi, wi, p);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(xl + (j * 256 + wv * 64) * 16), 16,
                                                      ok ? (unsigned)(xoff[j] + tap_bytes(hi0[j], wi0[j], kh, kw, cb * BK, p) + xc0[j]) : OOB, 0, 0, 0);
         }
@@ -573,7 +610,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, 2) void conv_igemm_v5_kerne
     const int wc = wv / WAVES_P, wp = wv % WAVES_P;
 
     const int L = xcd_remap(blockIdx.x, gridDim.x);
-    const int pt = L / p.n_ct, ct = L % p.n_ct;
+    const int pt = fdiv(L, p.dv_ct_mul, p.dv_ct_sh), ct = L - pt * p.n_ct;
 
     const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
     const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
@@ -590,9 +627,8 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, 2) void conv_igemm_v5_kerne
         const int m = pt * TP + row;
         const bool v = m < p.M;
         const int mm = v ? m : 0;
-        const int n = mm / (p.Ho * p.Wo);
-        const int rem = mm - n * (p.Ho * p.Wo);
-        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        int n, ho, wo;
+        pix_coords(mm, p, n, ho, wo);
         hi0[j] = ho * p.stride - p.pad;
         wi0[j] = wo * p.stride - p.pad;
         xoff[j] = (int)(((long long)n * p.H * p.W * p.xpitch) * 2);  // byte offset of image n
@@ -606,10 +642,11 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, 2) void conv_igemm_v5_kerne
         woff[j] = (unsigned)(((long long)(ct * TC + row) * p.Kpad + (pslot ^ swz<BK>(row)) * 8) * 2);
     }
 
+    int nx_tap = 0, nx_cb = 0, nx_kh, nx_kw;   // (tap, channel block) of the next tile to be requested: K-steps are issued strictly in order
+    tap_offsets(p, 0, nx_kh, nx_kw);
     auto dma = [&](int it, int stage) {
-        const int tap = it / p.cin_blocks;
-        const int cb = it - tap * p.cin_blocks;
-        const int kh = p.tdh[tap], kw = p.tdw[tap];
+        const int cb = nx_cb, kh = nx_kh, kw = nx_kw;
+        if (++nx_cb == p.cin_blocks) { nx_cb = 0; ++nx_tap; tap_offsets(p, nx_tap, nx_kh, nx_kw); }
         unsigned char* wl = smem + stage * STAGE_BYTES;
         unsigned char* xl = wl + W_BYTES;
 #pragma unroll
@@ -618,7 +655,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, 2) void conv_igemm_v5_kerne
 #pragma unroll
         for (int j = 0; j < XJ; ++j) {
             const int hi = hi0[j] + kh, wi = wi0[j] + kw;
-            const bool ok = mvalid[j] && in_image(hi, wi, p);
+            const bool ok = (int)mvalid[j] & (int)in_image(hi, wi, p);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(xl + (j * NT + wv * 64) * 16), 16,
                                                      ok ? (unsigned)(xoff[j] + tap_bytes(hi0[j], wi0[j], kh, kw, cb * BK, p) + xc0[j]) : OOB, 0, 0, 0);
         }
@@ -694,6 +731,7 @@ template <typename T, int BK, int WAVES_C, int WAVES_P, int MC, int MP> int laun
     constexpr int TC = WAVES_C * MC * 32, TP = WAVES_P * MP * 32;
     a.n_ct = y3_ceil_div(a.Cout, TC);
     a.n_pt = y3_ceil_div(a.M, TP);
+    set_divisors(a);
     a.cin_blocks = a.Cin / BK;
     a.nk = a.ntaps * a.cin_blocks;
     const long long nb = (long long)a.n_ct * a.n_pt;
@@ -707,6 +745,7 @@ template <typename T, int BK, int MC, int MP> int launch_v3(ConvArgs& a, hipStre
     constexpr int TC = 2 * MC * 32, TP = 2 * MP * 32;
     a.n_ct = y3_ceil_div(a.Cout, TC);
     a.n_pt = y3_ceil_div(a.M, TP);
+    set_divisors(a);
     a.cin_blocks = a.Cin / BK;
     a.nk = a.ntaps * a.cin_blocks;
     const long long nb = (long long)a.n_ct * a.n_pt;
@@ -778,6 +817,7 @@ int launch_igemm(ConvArgs& a, hipStream_t st) {
     constexpr int TC = WAVES_C * MC * 32, TP = WAVES_P * MP * 32;
     a.n_ct = y3_ceil_div(a.Cout, TC);
     a.n_pt = y3_ceil_div(a.M, TP);
+    set_divisors(a);
     if (SMALLC) {
         a.nk = y3_ceil_div(a.ntaps * a.Cin, BK);
         a.cin_blocks = 1;
