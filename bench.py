@@ -45,10 +45,10 @@ def igemm_variant(cin, cout, k=1, m=1 << 30):
             return "conv_igemm_v3<f16,bk32,tc128xtp128>"
         if var == "v3a":
             return f"conv_igemm_v3<f16,bk{bk},tc128xtp128>"
-        if var == "auto" and bk == 64 and k * k * cin >= 2304 and cout >= 512:
-            return "conv_igemm_v5<f16,bk64,tc256xtp256,8 waves>"
+        if var == "auto" and k * k * cin >= 2304 and cout >= 512:
+            return "conv_igemm_v6<f16,bk32,tc256xtp256,8 waves staggered>"
         if var == "auto" and bk == 64 and k == 1 and cout >= 256 and 16384 < m <= 65536:
-            return "conv_igemm_v5<f16,bk64,tc256xtp256,8 waves>"
+            return "conv_igemm_v6<f16,bk32,tc256xtp256,8 waves staggered>"
         if bk == 64 and ((k > 1 and k * k * cin >= 1152) or (k == 1 and cin >= 256 and m <= 16384)):
             return "conv_igemm_v3<f16,bk64,tc128xtp128>"
         return "conv_igemm_v3<f16,bk32,tc128xtp128>"

@@ -97,6 +97,8 @@ static int conv_variant() {
         if (!strcmp(e, "v5a")) return 11;
         if (!strcmp(e, "v5b")) return 12;
         if (!strcmp(e, "v5c")) return 13;
+        if (!strcmp(e, "v6a")) return 14;
+        if (!strcmp(e, "v6b")) return 15;
         return 3;
     }();
     return v;
@@ -583,7 +585,15 @@ __global__ __launch_bounds__(256, (BK == 32 && MC * MP <= 4 ? 4 : 2)) void conv_
 // vmcnt(0) precedes it) and retires the reads of the stage tile t+1 is about to overwrite.  Fragments are
 // double-buffered in registers so the ds_read of k-substep s+1 is in flight under the MFMAs of s.
 // WAVES 2x2; per-wave tile (MC*32 couts) x (MP*32 pixels).
-template <typename T, int BK, int WAVES_C, int WAVES_P, int MC, int MP>
+//
+// SCHED 1 ("v6"): the two halves of the block (waves 0-3 / 4-7 = one wave of each half on every SIMD) run ONE barrier interval
+// apart, so while one half multiplies the other half requests tiles and reads fragments -- the MFMA pipe of a SIMD always
+// has the other wave's memory phase to hide.  Per K-tile (BK 32) a wave does MEM(t) = { request tile t+2 (4 DMA pieces),
+// read the 12 fragments of tile t, s_waitcnt vmcnt(4) } | barrier | MMA(t) = { 16 MFMAs } | barrier.  Four LDS stages:
+// tile t+2 lands in the stage of tile t-2, whose last reads retired two intervals ago.  A tile is first read (by the
+// leading half) in the interval after every wave's counted vmcnt retired its pieces of that tile and passed a barrier:
+// the wait sits at the end of MEM(t-1), the reads in MEM(t).  Waits never drain to 0 in the steady state.
+template <typename T, int BK, int WAVES_C, int WAVES_P, int MC, int MP, int SCHED = 0>
 __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, 2) void conv_igemm_v5_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // device-only builtins (LDS address space, buffer->LDS DMA): the host pass only needs the stub
     constexpr int NT = 64 * WAVES_C * WAVES_P;
@@ -595,7 +605,9 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, 2) void conv_igemm_v5_kerne
     static_assert((TC * S) % NT == 0 && (TP * S) % NT == 0, "whole chunks only");
     constexpr int W_BYTES = TC * BK * 2;
     constexpr int STAGE_BYTES = (TC + TP) * BK * 2;
-    constexpr int LDS_BYTES = 2 * STAGE_BYTES > TC * TP * 2 ? 2 * STAGE_BYTES : TC * TP * 2;  // K-loop stages, re-used as the epilogue's T-typed output tile
+    constexpr int NST = SCHED == 1 ? 4 : 2;
+    static_assert(SCHED == 0 || (NT == 512 && BK == 32 && WJ + XJ == 4), "the staggered schedule is written for 8 waves, BK 32, 4 DMA pieces per wave and tile");
+    constexpr int LDS_BYTES = NST * STAGE_BYTES > TC * TP * 2 ? NST * STAGE_BYTES : TC * TP * 2;  // K-loop stages, re-used as the epilogue's T-typed output tile
     constexpr int ROWSTEP = NT / S;
     constexpr int KSUB = BK / 16;
     typedef typename Mfma<T>::frag frag;
@@ -702,32 +714,63 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, 2) void conv_igemm_v5_kerne
             for (int b = 0; b < MP; ++b) acc[a][b] = Mfma<T>::run(af[a], bf[b], acc[a][b]);
     };
 
-    dma(0, 0);
-    Y3_STAMP(1);
-    for (int it = 0; it < p.nk; ++it) {
-        __syncthreads();  // tile `it` has landed for every wave; stage (it+1)&1 is no longer being read
-        if (it == 0) Y3_STAMP(2);
-        if (it + 1 < p.nk) dma(it + 1, (it + 1) & 1);
-        const int st = it & 1;
-        frag a0[MC], b0[MP], a1[MC], b1[MP];
-        load_frags(st, 0, a0, b0);
-#pragma unroll
-        for (int kk = 0; kk < KSUB; kk += 2) {
-            load_frags(st, kk + 1, a1, b1);
+    if constexpr (SCHED == 1) {
+        const int half = wv >> 2;   // 0: leading half, 1: trailing half (one barrier interval behind)
+        dma(0, 0);
+        if (p.nk > 1) dma(1, 1);
+        Y3_STAMP(1);
+        if (p.nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // tile 0 is visible to everyone
+        Y3_STAMP(2);
+        if (half) __builtin_amdgcn_s_barrier();   // stagger
+        for (int it = 0; it < p.nk; ++it) {
+            // ---- MEM(it): request tile it+2, read the fragments of tile it, retire this wave's pieces of tile it+1 ----
+            const bool more = it + 2 < p.nk;
+            if (more) dma(it + 2, (it + 2) & 3);
+            frag a0[MC], b0[MP], a1[MC], b1[MP];
+            load_frags(it & 3, 0, a0, b0);
+            load_frags(it & 3, 1, a1, b1);
+            if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- MMA(it) ----
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
             mma(a0, b0);
-            if (kk + 2 < KSUB) load_frags(st, kk + 2, a0, b0);
             mma(a1, b1);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
         }
+        if (!half) __builtin_amdgcn_s_barrier();  // re-align: every wave has now passed 2 nk + 2 barriers and retired all its fragment reads
+        Y3_STAMP(3);
+    } else {
+        dma(0, 0);
+        Y3_STAMP(1);
+        for (int it = 0; it < p.nk; ++it) {
+            __syncthreads();  // tile `it` has landed for every wave; stage (it+1)&1 is no longer being read
+            if (it == 0) Y3_STAMP(2);
+            if (it + 1 < p.nk) dma(it + 1, (it + 1) & 1);
+            const int st = it & 1;
+            frag a0[MC], b0[MP], a1[MC], b1[MP];
+            load_frags(st, 0, a0, b0);
+#pragma unroll
+            for (int kk = 0; kk < KSUB; kk += 2) {
+                load_frags(st, kk + 1, a1, b1);
+                mma(a0, b0);
+                if (kk + 2 < KSUB) load_frags(st, kk + 2, a0, b0);
+                mma(a1, b1);
+            }
+        }
+        Y3_STAMP(3);
+        __syncthreads();  // every wave is done with the stage buffers: they become the per-wave transpose slices
     }
-    Y3_STAMP(3);
-
-    __syncthreads();  // every wave is done with the stage buffers: they become the per-wave transpose slices
     epilogue_wave<T, MC, MP>(p, acc, smem + wv * (MP * 32 * MC * 64), ct * TC + wc * MC * 32, pt * TP + wp * MP * 32, lane);
     Y3_STAMP(4);
 #endif
 }
 
-template <typename T, int BK, int WAVES_C, int WAVES_P, int MC, int MP> int launch_v5(ConvArgs& a, hipStream_t st) {
+template <typename T, int BK, int WAVES_C, int WAVES_P, int MC, int MP, int SCHED = 0> int launch_v5(ConvArgs& a, hipStream_t st) {
     constexpr int TC = WAVES_C * MC * 32, TP = WAVES_P * MP * 32;
     a.n_ct = y3_ceil_div(a.Cout, TC);
     a.n_pt = y3_ceil_div(a.M, TP);
@@ -736,7 +779,7 @@ template <typename T, int BK, int WAVES_C, int WAVES_P, int MC, int MP> int laun
     a.nk = a.ntaps * a.cin_blocks;
     const long long nb = (long long)a.n_ct * a.n_pt;
     if (nb > 0x7fffffffLL) Y3_FAIL("conv grid too large");
-    hipLaunchKernelGGL((conv_igemm_v5_kernel<T, BK, WAVES_C, WAVES_P, MC, MP>), dim3((unsigned)nb), dim3(64 * WAVES_C * WAVES_P), 0, st, a);
+    hipLaunchKernelGGL((conv_igemm_v5_kernel<T, BK, WAVES_C, WAVES_P, MC, MP, SCHED>), dim3((unsigned)nb), dim3(64 * WAVES_C * WAVES_P), 0, st, a);
     Y3_CHECK_LAUNCH();
     return 0;
 }
@@ -842,6 +885,8 @@ template <typename T> int dispatch_igemm(ConvArgs& a, hipStream_t st) {
         if (var == 4) return launch_v3<T, 32, 2, 4>(a, st);   // 128c x 256p, BK 32
         if (var == 5) return launch_v3<T, 32, 2, 2>(a, st);   // 128c x 128p, BK 32 (4 blocks / CU)
         if (var == 6) return c64 ? launch_v3<T, 64, 2, 2>(a, st) : launch_v3<T, 32, 2, 2>(a, st);
+        if (var == 14 && a.Cout >= 256) return launch_v5<T, 32, 2, 4, 4, 2, 1>(a, st);   // staggered halves, wave 128c x 64p
+        if (var == 15 && a.Cout >= 256) return launch_v5<T, 32, 4, 2, 2, 4, 1>(a, st);   // staggered halves, wave 64c x 128p
         if (var >= 11 && var <= 13 && c64 && a.Cout >= 256) {
             if (var == 11) return launch_v5<T, 64, 2, 4, 4, 2>(a, st);   // 256c x 256p, wave 128c x 64p, BK 64
             if (var == 12) return launch_v5<T, 64, 4, 2, 2, 4>(a, st);   // 256c x 256p, wave 64c x 128p, BK 64
@@ -852,8 +897,8 @@ template <typename T> int dispatch_igemm(ConvArgs& a, hipStream_t st) {
         // 128x256 tile, the rest the BK 64 128x128 tile.
         // (re-measured after the epilogue rewrite, gpurun_out/variants2.log -> profiles/r01_conv_variants.md)
         const int K = a.ntaps * a.Cin;
-        if (c64 && K >= 2304 && a.Cout >= 512) return launch_v5<T, 64, 4, 2, 2, 4>(a, st);   // 256c x 256p, 8 waves (64c x 128p each)
-        if (c64 && a.ntaps == 1 && a.Cout >= 256 && a.M > 16384 && a.M <= 65536) return launch_v5<T, 64, 4, 2, 2, 4>(a, st);   // 1x1 @40x40
+        if (K >= 2304 && a.Cout >= 512) return launch_v5<T, 32, 4, 2, 2, 4, 1>(a, st);   // 256c x 256p, 8 waves (64c x 128p each), staggered halves
+        if (c64 && a.ntaps == 1 && a.Cout >= 256 && a.M > 16384 && a.M <= 65536) return launch_v5<T, 32, 4, 2, 2, 4, 1>(a, st);   // 1x1 @40x40
         if (c64 && ((a.ntaps > 1 && K >= 1152) || (a.ntaps == 1 && K >= 256 && a.M <= 16384))) return launch_v3<T, 64, 2, 2>(a, st);
         return launch_v3<T, 32, 2, 2>(a, st);
     }

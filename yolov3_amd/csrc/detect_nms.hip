@@ -23,6 +23,9 @@ namespace {
 
 // ------------------------------------------------------------------------------------------------ decode
 template <typename T>
+Y3_DEV float decode_one(float v, int o, int x, int y, float stride, float aw, float ah);
+
+template <typename T>
 __global__ __launch_bounds__(256) void decode_kernel(const T* __restrict__ head, int bs, int ny, int nx, int pitch, int na, int no, float aw0, float ah0,
                                                        float aw1, float ah1, float aw2, float ah2, float aw3, float ah3, float aw4, float ah4, float stride,
                                                        T* __restrict__ raw, T* __restrict__ z, long long row_offset, long long total_rows) {
@@ -41,23 +44,65 @@ __global__ __launch_bounds__(256) void decode_kernel(const T* __restrict__ head,
     const long long cell = ((long long)(b * na + a) * ny + y) * nx + x;  // (bs,na,ny,nx) index
     if (raw) raw[cell * no + o] = hv;
     if (z) {
-        const float v = to_f32<T>(hv);
-        const float s = rt<T>(1.0f / (1.0f + expf(-v)));
-        float r;
-        if (o < 2) {
-            const float g = rt<T>((o == 0 ? (float)x : (float)y) - 0.5f);
-            r = rt<T>(rt<T>(rt<T>(s * 2.0f) + g) * rt<T>(stride));
-        } else if (o < 4) {
-            const float aw = a == 0 ? aw0 : a == 1 ? aw1 : a == 2 ? aw2 : a == 3 ? aw3 : aw4;
-            const float ah = a == 0 ? ah0 : a == 1 ? ah1 : a == 2 ? ah2 : a == 3 ? ah3 : ah4;
-            const float d = rt<T>(s * 2.0f);
-            r = rt<T>(rt<T>(d * d) * (o == 2 ? aw : ah));
-        } else {
-            r = s;
-        }
+        const float aw = a == 0 ? aw0 : a == 1 ? aw1 : a == 2 ? aw2 : a == 3 ? aw3 : aw4;
+        const float ah = a == 0 ? ah0 : a == 1 ? ah1 : a == 2 ? ah2 : a == 3 ? ah3 : ah4;
+        const float r = decode_one<T>(to_f32<T>(hv), o, x, y, stride, aw, ah);
         const long long row = row_offset + ((long long)a * ny + y) * nx + x;
         z[((long long)b * total_rows + row) * no + o] = from_f32<T>(r);
     }
+}
+
+// One decoded element: the reference's op order with a round-to-T after every op (models/yolo.py:104-108 run in T).
+template <typename T>
+Y3_DEV float decode_one(float v, int o, int x, int y, float stride, float aw, float ah) {
+    const float s = rt<T>(1.0f / (1.0f + expf(-v)));
+    if (o < 2) {
+        const float g = rt<T>((o == 0 ? (float)x : (float)y) - 0.5f);
+        return rt<T>(rt<T>(rt<T>(s * 2.0f) + g) * rt<T>(stride));
+    }
+    if (o < 4) {
+        const float d = rt<T>(s * 2.0f);
+        return rt<T>(rt<T>(d * d) * (o == 2 ? aw : ah));
+    }
+    return s;
+}
+
+// 2-byte dtypes, 16-byte aligned blocks: within one (image, anchor) block both outputs are ONE contiguous run of ny*nx*no
+// elements (raw: (bs,na,ny,nx,no); z: rows [row_offset + a*ny*nx, +ny*nx) of (bs,total_rows,no)), so a thread produces 8
+// consecutive elements = one 16-byte store per output; the matching head elements (pixel p, channel a*no + o) are at most
+// two pixels' runs.  The element-per-thread kernel above ran at 1.1 TB/s (2-byte accesses, three 64-bit divisions each).
+template <typename T>
+__global__ __launch_bounds__(256) void decode_vec_kernel(const T* __restrict__ head, int bs, int ny, int nx, int pitch, int na, int no, float aw0, float ah0,
+                                                           float aw1, float ah1, float aw2, float ah2, float aw3, float ah3, float aw4, float ah4, float stride,
+                                                           T* __restrict__ raw, T* __restrict__ z, long long row_offset, long long total_rows) {
+    const int P = ny * nx;
+    const int chunks = P * no / 8;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)bs * na * chunks) return;
+    const int ba = (int)(idx / chunks), chunk = (int)(idx - (long long)ba * chunks);
+    const int b = ba / na, a = ba - b * na;
+    const int f0 = chunk * 8;
+    int pix = f0 / no, o = f0 - pix * no;
+    int y = pix / nx, x = pix - y * nx;
+    const float aw = a == 0 ? aw0 : a == 1 ? aw1 : a == 2 ? aw2 : a == 3 ? aw3 : aw4;
+    const float ah = a == 0 ? ah0 : a == 1 ? ah1 : a == 2 ? ah2 : a == 3 ? ah3 : ah4;
+    const T* hp = head + ((long long)b * P + pix) * pitch + a * no;
+    typedef T vec8 __attribute__((ext_vector_type(8)));
+    vec8 rv, zv;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const T hv = hp[o];
+        rv[e] = hv;
+        zv[e] = from_f32<T>(decode_one<T>(to_f32<T>(hv), o, x, y, stride, aw, ah));
+        if (++o == no) {   // next pixel (no >= 8: at most once per thread)
+            o = 0;
+            hp += pitch;
+            if (++x == nx) { x = 0; ++y; }
+        }
+    }
+    const long long f = (long long)ba * P * no + f0;
+    if (raw) *(vec8*)(raw + f) = rv;
+    if (z) *(vec8*)(z + ((long long)b * total_rows + row_offset + (long long)a * P) * no + f0) = zv;
 }
 
 // ------------------------------------------------------------------------------------------------ NMS
@@ -471,8 +516,21 @@ extern "C" int y3_detect_decode(const y3_tensor* head, int32_t dtype, int32_t na
     float a[10] = {0};
     for (int i = 0; i < na * 2; ++i) a[i] = anchors_px[i];
     const long long total = (long long)head->n * head->h * head->w * na * no;
-    const dim3 grid((unsigned)((total + 255) / 256));
     hipStream_t st = (hipStream_t)stream;
+    const long long P = (long long)head->h * head->w;
+    const bool vec = dtype != Y3_F32 && no >= 8 && (P * no) % 8 == 0 && (total_rows * no) % 8 == 0 && (row_offset * no) % 8 == 0 &&
+                     !((uintptr_t)raw & 15) && !((uintptr_t)z & 15) && P * no < 0x7fffffffLL;
+    if (vec) {
+        const dim3 vgrid((unsigned)((total / 8 + 255) / 256));
+#define Y3_DECODE_V(T)                                                                                                                                           \
+    hipLaunchKernelGGL((decode_vec_kernel<T>), vgrid, dim3(256), 0, st, (const T*)head->data, head->n, head->h, head->w, head->pitch, na, no, a[0], a[1], a[2], a[3], \
+                       a[4], a[5], a[6], a[7], a[8], a[9], stride, (T*)raw, (T*)z, (long long)row_offset, (long long)total_rows)
+        if (dtype == Y3_F16) Y3_DECODE_V(f16_t); else Y3_DECODE_V(bf16_t);
+#undef Y3_DECODE_V
+        Y3_CHECK_LAUNCH();
+        return 0;
+    }
+    const dim3 grid((unsigned)((total + 255) / 256));
 #define Y3_DECODE(T)                                                                                                                                        \
     hipLaunchKernelGGL((decode_kernel<T>), grid, dim3(256), 0, st, (const T*)head->data, head->n, head->h, head->w, head->pitch, na, no, a[0], a[1], a[2], a[3], \
                        a[4], a[5], a[6], a[7], a[8], a[9], stride, (T*)raw, (T*)z, (long long)row_offset, (long long)total_rows)
