@@ -76,7 +76,9 @@ def per_kernel_times(plan, reps=5):
             evs.append((ln, e0, e1))
         torch.cuda.synchronize()
         for ln, e0, e1 in evs:
-            if ln.flops:
+            if getattr(ln, "kernel", ""):
+                key = ln.kernel + "/3x3"
+            elif ln.flops:
                 w = ln.keep[4]
                 key = igemm_variant(w.cin, w.cout, w.k, int(ln.flops / (2.0 * w.cout * w.cin * w.k * w.k))) + f"/{w.k}x{w.k}"
             else:

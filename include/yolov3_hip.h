@@ -70,6 +70,15 @@ int y3_pack_filter(const float* w_oihw, int32_t cout_src, int32_t cin_src, int32
 int y3_conv2d_fwd(const y3_conv_desc* desc, const y3_tensor* x, const void* packed_filter, const float* bias,
                   const y3_tensor* residual /* may be NULL */, const y3_tensor* y, void* stream);
 
+/* Stem convolution: the first layer `Conv(ch<=4, 32|64, 3, 1)` (reference models/yolov3.yaml:16, models/common.py:57-81) computed
+ * straight from the caller's NCHW image, fused with the ingest (`im.half(); im /= 255`, val.py:354-360): no NHWC copy of the
+ * image is made.  `packed` comes from y3_pack_filter_stem ([cout_pad32][3][16] in `dtype`, BN folded by the caller),
+ * y is the NHWC output view (n, h, w, cout), stride 1 / pad 1 only; src_dtype u8 / f16 / bf16 / f32, compute f16 / bf16. */
+size_t y3_packed_filter_stem_elems(int32_t cout);
+int y3_pack_filter_stem(const float* w_oihw, int32_t cout_src, int32_t cin_src, int32_t cout, int32_t dtype, void* packed, void* stream);
+int y3_stem_conv_fwd(const void* x_nchw, int32_t src_dtype, int32_t n, int32_t cin, int32_t h, int32_t w, float divisor, const void* packed,
+                     const float* bias, int32_t dtype, int32_t act, const y3_tensor* y, void* stream);
+
 /* NCHW (u8 / f16 / bf16 / f32) image batch -> NHWC `out_dtype`: cast, then true-divide by `divisor`
  * (1.0 = none) in the output dtype, channels zero-padded to out->c.
  * Replaces `im.half()/float(); im /= 255` of reference val.py:354-360 / train.py:380 when src is u8. */

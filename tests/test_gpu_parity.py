@@ -134,6 +134,72 @@ def test_conv_mfma_matches_direct_kernel(dev):
 
 
 # ------------------------------------------------------------------------------------------------ pooling / layout
+STEM_CASES = [
+    # name, (n, cin, h, w, cout), source dtype, divisor, act
+    ("yolov3_l0", (2, 3, 40, 72, 32), torch.float16, 1.0, True),
+    ("ragged_hw", (1, 3, 37, 131, 32), torch.float16, 1.0, True),        # H % 8 != 0, W % 64 != 0
+    ("u8_div255", (2, 3, 24, 64, 32), torch.uint8, 255.0, True),         # val.py:354-360 ingest fused in
+    ("f32_source", (1, 3, 16, 70, 32), torch.float32, 1.0, True),
+    ("tiny_cout16", (2, 3, 32, 32, 16), torch.float16, 1.0, True),       # models/yolov3-tiny.yaml first layer
+    ("cout64_noact", (1, 3, 19, 65, 64), torch.float16, 1.0, False),
+    ("cin1", (1, 1, 16, 64, 32), torch.float16, 1.0, True),
+    ("cin4", (1, 4, 9, 33, 24), torch.float16, 1.0, True),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name,shape,sdt,div,act", STEM_CASES, ids=[c[0] for c in STEM_CASES])
+def test_stem_conv_vs_fp32_reference(dev, dtype, name, shape, sdt, div, act):
+    """csrc/stem.hip (layer 0 straight from the NCHW image) against conv2d(+SiLU) on the SAME rounded operands; tolerance =
+    one output rounding + fp32 accumulation-order noise, as for the generic conv kernels."""
+    _lib, ops = _ops()
+    n, cin, h, w, cout = shape
+    g = torch.Generator().manual_seed(11)
+    if sdt == torch.uint8:
+        x = torch.randint(0, 256, (n, cin, h, w), generator=g, dtype=torch.uint8)
+    else:
+        x = torch.rand(n, cin, h, w, generator=g).to(sdt)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g) * 0.5
+    xq = (x.float() / div).to(dtype).float()      # the kernel rounds the (divided) image to the compute dtype, like y3_nchw_to_nhwc
+    ref = F.conv2d(xq, wt.to(dtype).float(), b, stride=1, padding=1)
+    if act:
+        ref = F.silu(ref)
+    cpad = (cout + 7) // 8 * 8
+    big = ops.View.alloc(n, h, w, cpad + 16, dtype, dev)   # write into a channel slice: the kernel must respect the pitch
+    big.buf.fill_(3.0)
+    yv = big.slice(8, cpad)
+    filt = ops.pack_filter_stem(wt.to(dev), cpad, dtype)
+    bias = torch.zeros(cpad, device=dev)
+    bias[:cout] = b.to(dev)
+    ops.stem_conv(x.to(dev), filt, bias, yv, act, div)
+    torch.cuda.synchronize()
+    full = big.as_nhwc().float().cpu()
+    assert torch.all(full[..., :8] == 3.0) and torch.all(full[..., 8 + cpad :] == 3.0), "stem wrote outside its channel slice"
+    out = full[..., 8 : 8 + cout].permute(0, 3, 1, 2)
+    eps = 2.0**-10 if dtype == torch.float16 else 2.0**-7
+    err = (out - ref).abs()
+    tol = eps * ref.abs() + (2e-3 if dtype == torch.float16 else 1.5e-2)
+    bad = (err > tol).sum().item()
+    assert bad == 0, f"{name} {dtype}: {bad}/{err.numel()} outside tolerance, max abs err {err.max():.4g}"
+
+
+def test_stem_matches_generic_first_layer(dev, monkeypatch):
+    """The same model with and without the stem kernel (Y3_STEM=0 = ingest + generic conv): identical up to fp32 summation order."""
+    x = torch.rand(2, 3, 64, 96, generator=torch.Generator().manual_seed(3)).to(dev).half()
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("Y3_STEM", flag)
+        m, _ = build_pair("yolov3", 80, 5, dev, torch.float16)
+        with torch.no_grad():
+            pred = m(x)[0]
+        plan = next(iter(m._plans.values()))
+        assert (plan.stem_x is not None) == (flag == "1")
+        outs.append(pred.float().cpu())
+    d = (outs[0] - outs[1]).abs()
+    assert d.max().item() <= 2.0**-8 * max(1.0, outs[1].abs().max().item()), d.max().item()
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
 def test_layout_and_pool_kernels(dev, dtype):
     _lib, ops = _ops()

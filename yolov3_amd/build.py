@@ -23,6 +23,7 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno
 # (source, extra flags).  detect_nms must round like the reference's CPU code: no FMA contraction.
 SOURCES = [
     ("conv.hip", []),
+    ("stem.hip", []),
     ("layout_pool.hip", []),
     ("detect_nms.hip", ["-ffp-contract=off"]),
     ("loss.hip", ["-ffp-contract=off"]),

@@ -1,0 +1,228 @@
+// Stem convolution: the network's first layer (3x3, stride 1, pad 1, <= 4 input channels, 32 or 64 filters) computed
+// straight from the caller's NCHW image -- models/common.py:57-81 `Conv(3, 32, 3, 1)` (models/yolov3.yaml:16) together
+// with the `im.half()` / `im /= 255` ingest of val.py:354-360.  It replaces y3_nchw_to_nhwc + the generic implicit-GEMM launch
+// for that layer: the generic path stages K = 9 taps x 8 padded channels = 72 -> 96 and spends its time in per-block
+// prologue / epilogue (0.43 ms at 2.4 TB/s for 640x640 bs 32); here a block keeps a 10 x 68 pixel patch of the image in
+// LDS as 4-channel pixels, a 32-pixel MFMA tile needs three 16-byte fragment reads (one per filter row: 4 pixels x 4
+// channels = 16 k-values, the 4th pixel meets zero weights) and three v_mfma_f32_32x32x16, and the 64-byte NHWC rows of
+// consecutive pixels leave as fully contiguous 1 KiB stores.
+#include "../../include/yolov3_hip.h"
+#include "y3_common.h"
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+namespace {
+
+struct StemArgs {
+    const void* x;      // (N, Cin, H, W) source image
+    const void* w;      // packed filters [cout_pad32][3 (kh)][16 (kw*4 + c)]
+    const float* bias;  // cout floats or null
+    void* y;            // NHWC output view
+    int N, Cin, H, W;
+    int ypitch, Cout;
+    int act;
+    int tiles_w, tiles_h;
+    float divisor;
+};
+
+constexpr int TR = 8, TW = 64;   // output rows x columns per block
+constexpr int PR = TR + 2;       // patch rows (one halo row above and below)
+constexpr int PW = TW + 4;       // patch columns: one halo column left, one right, and the 4th pixel of the widest fragment read
+
+template <typename T> struct Mfma16;
+template <> struct Mfma16<f16_t> {
+    typedef f16x8 frag;
+    static Y3_DEV f32x16 run(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mfma16<bf16_t> {
+    typedef bf16x8 frag;
+    static Y3_DEV f32x16 run(frag a, frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+
+template <typename S> Y3_DEV float src_f32(S v) { return (float)v; }
+
+template <typename T, typename S, int MC>
+__global__ __launch_bounds__(256) void stem_conv_kernel(const StemArgs p) {
+    typedef typename Mfma16<T>::frag frag;
+    typedef T vec4 __attribute__((ext_vector_type(4)));
+    constexpr int CH = MC * 4;         // 16-byte chunks per output pixel
+    constexpr int RB = CH * 16;        // bytes per output pixel (MC * 32 filters)
+    constexpr int PPI = 64 / CH;       // pixels per store instruction
+    constexpr int NI = 32 / PPI;
+    __shared__ __attribute__((aligned(16))) unsigned char patch[PR * PW * 8];
+    __shared__ __attribute__((aligned(16))) unsigned char slices[4 * 32 * RB];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int b = blockIdx.x;
+    const int tw = b % p.tiles_w; b /= p.tiles_w;
+    const int th = b % p.tiles_h;
+    const int n = b / p.tiles_h;
+    const int row0 = th * TR, col0 = tw * TW;
+
+    // ---- image patch -> LDS as 4-channel pixels (channel 3 = 0), zero outside the image ----
+    const S* __restrict__ xs = (const S*)p.x + (long long)n * p.Cin * p.H * p.W;
+    for (int e = tid; e < PR * PW; e += 256) {
+        const int pr = e / PW, pc = e - pr * PW;
+        const int gh = row0 + pr - 1, gw = col0 + pc - 1;
+        vec4 v = {(T)0.0f, (T)0.0f, (T)0.0f, (T)0.0f};
+        if ((unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W) {
+            const long long o = (long long)gh * p.W + gw;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                if (c < p.Cin) v[c] = from_f32<T>(src_f32<S>(xs[(long long)c * p.H * p.W + o]) / p.divisor);
+            if (p.Cin > 3) v[3] = from_f32<T>(src_f32<S>(xs[3ll * p.H * p.W + o]) / p.divisor);
+        }
+        *(vec4*)(patch + e * 8) = v;
+    }
+
+    // ---- filters: lane (filter = lane & 31, fk = lane >> 5) holds k = 8 fk + j of each filter row ----
+    const int frow = lane & 31, fk = lane >> 5;
+    frag af[MC][3];
+#pragma unroll
+    for (int a = 0; a < MC; ++a)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) af[a][kh] = *(const frag*)((const T*)p.w + ((a * 32 + frow) * 3 + kh) * 16 + fk * 8);
+    f32x4 bz[MC][4];
+#pragma unroll
+    for (int a = 0; a < MC; ++a)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int cb = a * 32 + 8 * g + 4 * fk;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            bz[a][g] = (p.bias && cb + 4 <= p.Cout) ? *(const f32x4*)(p.bias + cb) : z;
+        }
+    __syncthreads();
+
+    unsigned char* wl = slices + wv * (32 * RB);
+    T* __restrict__ yg = (T*)p.y;
+    const int rp = lane / CH, ch = lane % CH;
+    for (int t = wv; t < TR * TW / 32; t += 4) {
+        const int trow = t / (TW / 32), j0 = (t % (TW / 32)) * 32;
+        f32x16 acc[MC];
+#pragma unroll
+        for (int a = 0; a < MC; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[a][4 * g + q] = bz[a][g][q];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            // pixel j0 + frow, taps kw = 2 fk and 2 fk + 1 (+ channel pad): 16 bytes at an 8-byte aligned address
+            const unsigned char* src = patch + (((trow + kh) * PW + j0 + frow + 2 * fk) * 8);
+            typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+            u64x2 raw;
+            raw[0] = *(const unsigned long long*)src;
+            raw[1] = *(const unsigned long long*)(src + 8);
+            const frag bf = __builtin_bit_cast(frag, raw);
+#pragma unroll
+            for (int a = 0; a < MC; ++a) acc[a] = Mfma16<T>::run(af[a][kh], bf, acc[a]);
+        }
+        // ---- activation, filter-pair swap (8 consecutive filters per lane), transpose through the wave's slice ----
+#pragma unroll
+        for (int a = 0; a < MC; ++a)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                frag ov;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float t0 = acc[a][8 * gp + q], t1 = acc[a][8 * gp + 4 + q];
+                    if (p.act == Y3_ACT_SILU) {
+                        t0 = t0 * __builtin_amdgcn_rcpf(1.0f + __expf(-t0));
+                        t1 = t1 * __builtin_amdgcn_rcpf(1.0f + __expf(-t1));
+                    }
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, t0), __builtin_bit_cast(unsigned, t1), false, false);
+                    ov[q] = from_f32<T>(__builtin_bit_cast(float, (unsigned)sw[0]));
+                    ov[4 + q] = from_f32<T>(__builtin_bit_cast(float, (unsigned)sw[1]));
+                }
+                const int chunk = a * 4 + gp * 2 + fk;
+                *(frag*)(wl + frow * RB + ((chunk ^ (frow & (CH - 1))) << 4)) = ov;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int grow = row0 + trow;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int pl = i * PPI + rp;
+            const frag ov = *(const frag*)(wl + pl * RB + ((ch ^ (pl & (CH - 1))) << 4));
+            const int gcol = col0 + j0 + pl;
+            if (grow < p.H && gcol < p.W && ch * 8 + 8 <= p.Cout) *(frag*)(yg + ((long long)(n * p.H + grow) * p.W + gcol) * p.ypitch + ch * 8) = ov;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // the slice is rewritten by the next tile
+    }
+}
+
+template <typename T>
+__global__ void pack_stem_kernel(const float* __restrict__ src, int cout_src, int cin_src, int rows, T* __restrict__ dst) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * 48) return;
+    const int k = idx % 16, kh = (idx / 16) % 3, co = idx / 48;
+    const int kw = k >> 2, c = k & 3;
+    float v = 0.0f;
+    if (co < cout_src && kw < 3 && c < cin_src) v = src[(((long long)co * cin_src + c) * 3 + kh) * 3 + kw];
+    dst[idx] = from_f32<T>(v);
+}
+
+template <typename T, typename S> int launch_stem(const StemArgs& a, hipStream_t st) {
+    const dim3 grid((unsigned)((long long)a.tiles_w * a.tiles_h * a.N));
+    if (a.Cout <= 32)
+        hipLaunchKernelGGL((stem_conv_kernel<T, S, 1>), grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((stem_conv_kernel<T, S, 2>), grid, dim3(256), 0, st, a);
+    Y3_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename T> int dispatch_src(const StemArgs& a, int sdt, hipStream_t st) {
+    switch (sdt) {
+        case Y3_F16: return launch_stem<T, f16_t>(a, st);
+        case Y3_BF16: return launch_stem<T, bf16_t>(a, st);
+        case Y3_F32: return launch_stem<T, float>(a, st);
+        case Y3_U8: return launch_stem<T, unsigned char>(a, st);
+    }
+    Y3_FAIL("y3_stem_conv_fwd: bad source dtype %d", sdt);
+}
+
+}  // namespace
+
+extern "C" size_t y3_packed_filter_stem_elems(int32_t cout) { return (size_t)((cout + 31) / 32) * 32 * 48; }
+
+extern "C" int y3_pack_filter_stem(const float* w, int32_t cout_src, int32_t cin_src, int32_t cout, int32_t dtype, void* packed, void* stream) {
+    if (!w || !packed) Y3_FAIL("y3_pack_filter_stem: null pointer");
+    if (cin_src < 1 || cin_src > 4 || cout < cout_src) Y3_FAIL("y3_pack_filter_stem: needs 1..4 input channels and cout >= cout_src");
+    const int rows = (cout + 31) / 32 * 32;
+    const dim3 grid((unsigned)((rows * 48 + 255) / 256));
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case Y3_F16: hipLaunchKernelGGL((pack_stem_kernel<f16_t>), grid, dim3(256), 0, st, w, cout_src, cin_src, rows, (f16_t*)packed); break;
+        case Y3_BF16: hipLaunchKernelGGL((pack_stem_kernel<bf16_t>), grid, dim3(256), 0, st, w, cout_src, cin_src, rows, (bf16_t*)packed); break;
+        default: Y3_FAIL("y3_pack_filter_stem: f16/bf16 only");
+    }
+    Y3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int y3_stem_conv_fwd(const void* x_nchw, int32_t src_dtype, int32_t n, int32_t cin, int32_t h, int32_t w, float divisor, const void* packed,
+                                const float* bias, int32_t dtype, int32_t act, const y3_tensor* y, void* stream) {
+    if (!x_nchw || !packed || !y || !y->data) Y3_FAIL("y3_stem_conv_fwd: null argument");
+    if (cin < 1 || cin > 4) Y3_FAIL("y3_stem_conv_fwd: %d input channels (1..4 supported)", cin);
+    if (y->n != n || y->h != h || y->w != w) Y3_FAIL("y3_stem_conv_fwd: output must be (%d,%d,%d,*) for a stride-1 pad-1 3x3", n, h, w);
+    if ((y->c % 8) || y->c > 64 || (y->pitch % 8) || ((uintptr_t)y->data & 15) || ((uintptr_t)packed & 15)) Y3_FAIL("y3_stem_conv_fwd: 8..64 filters (multiple of 8), 16-byte aligned views");
+    if (!(divisor > 0.0f)) Y3_FAIL("y3_stem_conv_fwd: divisor must be positive");
+    if ((long long)n * h * w > 0x7fffffffLL) Y3_FAIL("y3_stem_conv_fwd: too many pixels");
+    StemArgs a;
+    a.x = x_nchw; a.w = packed; a.bias = bias; a.y = y->data;
+    a.N = n; a.Cin = cin; a.H = h; a.W = w; a.ypitch = y->pitch; a.Cout = y->c; a.act = act;
+    a.tiles_w = (w + TW - 1) / TW; a.tiles_h = (h + TR - 1) / TR;
+    a.divisor = divisor;
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case Y3_F16: return dispatch_src<f16_t>(a, src_dtype, st);
+        case Y3_BF16: return dispatch_src<bf16_t>(a, src_dtype, st);
+    }
+    Y3_FAIL("y3_stem_conv_fwd: f16/bf16 compute only");
+}

@@ -88,6 +88,27 @@ def conv2d(x: View, filt: torch.Tensor, bias: torch.Tensor, y: View, k: int, str
     )
 
 
+def pack_filter_stem(w_oihw: torch.Tensor, cout: int, dtype: torch.dtype) -> torch.Tensor:
+    """OIHW fp32 weights (cin <= 4, 3x3) -> the stem kernel's [cout_pad32][3][16] bank."""
+    require_gpu(w_oihw, "pack_filter_stem")
+    w = w_oihw.detach().to(torch.float32).contiguous()
+    co, ci, k, _ = w.shape
+    assert k == 3 and ci <= 4
+    out = torch.empty(int(_lib.lib().y3_packed_filter_stem_elems(cout)), dtype=dtype, device=w.device)
+    check(_lib.lib().y3_pack_filter_stem(w.data_ptr(), co, ci, cout, dtype_code(dtype), out.data_ptr(), stream_ptr()), "y3_pack_filter_stem")
+    return out
+
+
+def stem_conv(x_nchw: torch.Tensor, filt: torch.Tensor, bias: torch.Tensor, y: View, act: bool, divisor: float = 1.0):
+    """First-layer 3x3 s1 conv straight from the NCHW image (u8 / f16 / bf16 / f32) into the NHWC view y."""
+    require_gpu(x_nchw, "stem_conv")
+    x = x_nchw.contiguous()
+    n, c, h, w = x.shape
+    yt = y.y3()
+    check(_lib.lib().y3_stem_conv_fwd(x.data_ptr(), dtype_code(x.dtype), n, c, h, w, float(divisor), filt.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                      dtype_code(y.buf.dtype), _lib.Y3_ACT_SILU if act else _lib.Y3_ACT_NONE, C.byref(yt), stream_ptr()), "y3_stem_conv_fwd")
+
+
 def pack_filter_dgrad(w_oihw: torch.Tensor, cout: int, cin: int, dtype: torch.dtype) -> torch.Tensor:
     """OIHW fp32 weights -> filter bank of the data-gradient conv (cin filters over (kh, kw, cout), flipped taps)."""
     require_gpu(w_oihw, "pack_filter_dgrad")
