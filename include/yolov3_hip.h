@@ -168,7 +168,7 @@ int y3_loss_bwd(const y3_loss_params* p, int32_t dtype, const void* const* preds
  *             dx (+)= y3_conv2d_fwd(du, filter packed by y3_pack_filter_dgrad [, residual = dx, in_dilation = stride])
  * `sums` is a caller-owned scratch of Y3_BN_SCRATCH_DOUBLES(C) doubles (totals + per-block partial rows; reductions
  * are atomics-free and deterministic); all per-channel vectors are DEVICE fp32. */
-#define Y3_BN_SCRATCH_DOUBLES(C) ((size_t)(1 + 256) * 2 * (size_t)(C))
+#define Y3_BN_SCRATCH_DOUBLES(C) ((size_t)(1 + 512) * 2 * (size_t)(C))
 int y3_bn_stats(const y3_tensor* u, int32_t dtype, double* sums, void* stream);
 int y3_bn_finalize(const double* sums, int64_t count, int32_t channels, const float* gamma, const float* beta, float eps,
                    float momentum, float* running_mean /* updated in place, may be NULL */, float* running_var,

@@ -21,6 +21,8 @@ template <typename T> struct V16 {  // one 16-byte vector of T
 };
 
 Y3_DEV float silu_grad(float z, float s) { return s + z * s * (1.0f - s); }  // d silu(z)/dz with s = sigmoid(z)
+// v_exp_f32 + v_rcp_f32 (1-2 ulp each): the elementwise BN kernels were VALU-bound on expf() + an IEEE divide per element
+Y3_DEV float sigmoid_fast(float z) { return __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }
 
 unsigned nblk(long long total) { return (unsigned)((total + 255) / 256); }
 int esize(int dtype) { return dtype == Y3_F32 ? 4 : 2; }
@@ -57,29 +59,43 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(const T* __restrict
         float f0[V], f1[V];
 #pragma unroll
         for (int q = 0; q < V; ++q) f0[q] = f1[q] = 0.0f;
+        // 4 pixels per trip with all loads issued before the arithmetic (one 16-byte load in flight per thread left the
+        // reductions at 1.5-1.8 TB/s); fp32 partials are flushed into the fp64 accumulators every 2 trips = 8 pixels
+        const long long stride = (long long)gridDim.x * PL;
         int run = 0;
-        for (long long m = (long long)blockIdx.x * PL + pl; m < M; m += (long long)gridDim.x * PL) {
-            const V16<T> x = *(const V16<T>*)(u + m * upitch + cg * V);
-            if (MODE == 0) {
+        for (long long m0 = (long long)blockIdx.x * PL + pl; m0 < M; m0 += 4 * stride) {
+            V16<T> xs[4], gs[4];
 #pragma unroll
-                for (int q = 0; q < V; ++q) { const float f = to_f32<T>(x.v[q]); f0[q] += f; f1[q] += f * f; }
-            } else {
-                const V16<T> g = *(const V16<T>*)(dy + m * dpitch + cg * V);
-#pragma unroll
-                for (int q = 0; q < V; ++q) {
-                    const float uf = to_f32<T>(x.v[q]);
-                    float dz = to_f32<T>(g.v[q]);
-                    if (act == Y3_ACT_SILU) {
-                        const float z = uf * sc[q] + sh[q];
-                        const float s = 1.0f / (1.0f + expf(-z));
-                        dz *= silu_grad(z, s);
-                    }
-                    const float xh = (uf - mu[q]) * is[q];
-                    f0[q] += dz;
-                    f1[q] += dz * xh;
+            for (int j = 0; j < 4; ++j) {
+                const long long m = m0 + j * stride;
+                if (m < M) {
+                    xs[j] = *(const V16<T>*)(u + m * upitch + cg * V);
+                    if (MODE == 1) gs[j] = *(const V16<T>*)(dy + m * dpitch + cg * V);
                 }
             }
-            if (++run == 8) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (m0 + j * stride >= M) break;
+                if (MODE == 0) {
+#pragma unroll
+                    for (int q = 0; q < V; ++q) { const float f = to_f32<T>(xs[j].v[q]); f0[q] += f; f1[q] += f * f; }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < V; ++q) {
+                        const float uf = to_f32<T>(xs[j].v[q]);
+                        float dz = to_f32<T>(gs[j].v[q]);
+                        if (act == Y3_ACT_SILU) {
+                            const float z = uf * sc[q] + sh[q];
+                            const float s = sigmoid_fast(z);
+                            dz *= silu_grad(z, s);
+                        }
+                        const float xh = (uf - mu[q]) * is[q];
+                        f0[q] += dz;
+                        f1[q] += dz * xh;
+                    }
+                }
+            }
+            if (++run == 2) {
                 run = 0;
 #pragma unroll
                 for (int q = 0; q < V; ++q) { a0[q] += (double)f0[q]; a1[q] += (double)f1[q]; f0[q] = f1[q] = 0.0f; }
@@ -104,17 +120,22 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(const T* __restrict
     }
 }
 
-// totals[j] = sum over the per-block partial rows: one block per 64 entries, 4 row-lanes each, fixed tree (deterministic)
+// totals[j] = sum over the per-block partial rows: one block per 16 entries, 16 row-lanes each, fixed tree (deterministic)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(double* __restrict__ sums, int n2c, int nblocks) {
     __shared__ double red[256];
-    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int rl = threadIdx.x >> 6;
+    const int j = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int rl = threadIdx.x >> 4;
     double a = 0.0;
     if (j < n2c)
-        for (int b = rl; b < nblocks; b += 4) a += sums[(size_t)(1 + b) * n2c + j];
+        for (int b = rl; b < nblocks; b += 16) a += sums[(size_t)(1 + b) * n2c + j];
     red[threadIdx.x] = a;
     __syncthreads();
-    if (rl == 0 && j < n2c) sums[j] = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+#pragma unroll
+    for (int s = 8; s >= 1; s >>= 1) {
+        if (rl < s) red[threadIdx.x] += red[threadIdx.x + s * 16];
+        __syncthreads();
+    }
+    if (rl == 0 && j < n2c) sums[j] = red[threadIdx.x];
 }
 
 // sums -> mean / biased var -> (scale, shift) of the normalisation, running-stat update (momentum, unbiased var)
@@ -156,7 +177,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ u
 #pragma unroll
         for (int q = 0; q < V; ++q) {
             float z = to_f32<T>(x.v[q]) * sc[q] + sh[q];
-            if (act == Y3_ACT_SILU) z = z / (1.0f + expf(-z));
+            if (act == Y3_ACT_SILU) z = z * sigmoid_fast(z);
             if (res) z += to_f32<T>(r.v[q]);
             o.v[q] = from_f32<T>(z);
         }
@@ -192,7 +213,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
             float dz = to_f32<T>(g.v[q]);
             if (act == Y3_ACT_SILU) {
                 const float z = uf * sc[q] + sh[q];
-                const float sg = 1.0f / (1.0f + expf(-z));
+                const float sg = sigmoid_fast(z);
                 dz *= silu_grad(z, sg);
             }
             const float xh = (uf - mu[q]) * is[q];
@@ -613,7 +634,7 @@ extern "C" int y3_bn_stats(const y3_tensor* u, int32_t dtype, double* sums, void
     Y3_DISPATCH_T(dtype, hipLaunchKernelGGL((channel_reduce_kernel<T, 0>), dim3(grid), dim3(256), 0, st, (const T*)u->data, u->pitch, (const T*)nullptr, 0, M, u->c,
                                             (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, sums));
     Y3_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * u->c + 63) / 64), dim3(256), 0, st, sums, 2 * u->c, (int)grid);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * u->c + 15) / 16), dim3(256), 0, st, sums, 2 * u->c, (int)grid);
     Y3_CHECK_LAUNCH();
     return 0;
 }
@@ -656,7 +677,7 @@ extern "C" int y3_bn_act_bwd(const y3_tensor* u, const y3_tensor* dy, const floa
     Y3_DISPATCH_T(dtype, hipLaunchKernelGGL((channel_reduce_kernel<T, 1>), dim3(grid), dim3(256), 0, st, (const T*)u->data, u->pitch, (const T*)dy->data, dy->pitch, M,
                                             u->c, scale, shift, mean, invstd, act, sums));
     Y3_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * u->c + 63) / 64), dim3(256), 0, st, sums, 2 * u->c, (int)grid);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * u->c + 15) / 16), dim3(256), 0, st, sums, 2 * u->c, (int)grid);
     Y3_CHECK_LAUNCH();
     unsigned egrid;
     if (elementwise_geometry(u->c, esz, M, egrid)) return -1;

@@ -51,7 +51,7 @@ template <typename T> Y3_DEV float rt(float v) { return to_f32<T>(from_f32<T>(v)
 Y3_DEV float silu_f32(float v) { return v / (1.0f + __expf(-v)); }
 
 // rows of per-block partial sums behind the 2*C totals of y3_bn_stats / y3_bn_act_bwd scratch buffers
-#define Y3_BN_PARTIAL_ROWS 256
+#define Y3_BN_PARTIAL_ROWS 512
 
 static inline int y3_ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline size_t y3_round_up(size_t a, size_t b) { return (a + b - 1) / b * b; }

@@ -146,7 +146,7 @@ def conv2d_wgrad(x: View, du: View, k: int, stride: int, cout_real: int, cin_rea
     return dw, db
 
 
-BN_PARTIAL_ROWS = 256
+BN_PARTIAL_ROWS = 512
 
 
 def bn_scratch(c: int, device) -> torch.Tensor:
