@@ -282,6 +282,7 @@ struct WgradArgs {
     int per_slice;  // pixels per slice, multiple of 64
     int n_nt;       // column tiles
     unsigned x_bytes, du_bytes;
+    y3_divisor dv_hw, dv_w;   // Ho*Wo, Wo
 };
 
 Y3_DEV unsigned pack_lo(unsigned a, unsigned b) { return (a & 0xffffu) | (b << 16); }
@@ -424,6 +425,142 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs p) {
     }
 
     // D[row = co][col = n] -> partial tile [n][co] (each lane owns 4 consecutive co: one 16-byte store)
+    float* tile = p.part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (128 * 128);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int nl = (wn * 2 + b) * 32 + frow;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = (wc * 2 + a) * 32 + 8 * g + 4 * fk;
+                f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
+                *(f32x4*)(tile + nl * 128 + col) = v;
+            }
+    }
+#endif
+}
+
+// ---- wgrad, LDS-DMA + transposing LDS reads (gfx950 ds_read_b64_tr_b16) -------------------------------------------------
+// Same GEMM and tiling as wgrad_mfma_kernel (128 filters x 128 (tap, channel) columns per block, K-step = 64 pixels,
+// partial tiles per pixel slice), but the operands are staged in their NATURAL layout: a K-step of du is 64 rows of 128
+// filters, a K-step of the im2col'd x is 64 rows of 128 columns, both pixel-major exactly as NHWC stores them, so
+// `buffer_load ... lds` fills the stage buffers directly (no VGPR round trip, no 32 pack + 16 ds_write_b64 per thread and
+// K-step as in the register-transposing kernel above).  The MFMA wants the pixel (= reduction) index contiguous per lane:
+// ds_read_b64_tr_b16 delivers exactly that -- a 16-lane group reads a [4 pixels][16 channels] block and lane i gets
+// channel i's 4 pixels; two such reads make one 8-k fragment.  Bank conflicts are avoided with an XOR on the 16-byte slot
+// index, physical = logical ^ 4 (row & 3), applied on the DMA source side (the 4 rows of a read group land on 4
+// different quarter-rows = all 64 banks once per 32-lane pass).
+template <typename T>
+__global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BKP = 64, ROWB = 256, TILE = BKP * ROWB, STAGE = 2 * TILE;   // 16 KiB per operand and stage
+    typedef typename std::conditional<std::is_same<T, f16_t>::value, f16x8, bf16x8>::type frag;
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef __attribute__((address_space(3))) s16x4* lds_s4_t;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wv >> 1, wn = wv & 1;
+    const int ct = blockIdx.x / p.n_nt, nt = blockIdx.x % p.n_nt;
+    const long long m_begin = (long long)blockIdx.y * p.per_slice;
+    long long m_end = m_begin + p.per_slice;
+    if (m_end > p.M) m_end = p.M;
+    if (m_begin >= m_end) return;
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const auto rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)p.du, 0, (int)p.du_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xffffffffu;
+
+    // staging role: wave w fills rows 16w .. 16w+15 of both operands, 4 rows (one 1 KiB piece) per instruction;
+    // lane -> (row within the piece = lane / 16, physical slot = lane % 16); row & 3 is the same for all of a lane's rows
+    const int prow = lane >> 4, pslot = lane & 15;
+    const int lslot = pslot ^ (4 * prow);
+    const int a_ch = ct * 128 + lslot * 8;                 // filter group this lane copies from du
+    const bool a_ok = a_ch < p.Cout;
+    const int ncol = nt * 128 + lslot * 8;                 // im2col column group this lane copies from x
+    const int b_tap = ncol / p.Cin, b_ci = ncol - b_tap * p.Cin;
+    const int b_kh = b_tap / p.ks, b_kw = b_tap - b_kh * p.ks;
+    const bool b_ok = b_tap < p.ks * p.ks;
+
+    auto dma = [&](int it, int stage) {
+        unsigned char* al = smem + stage * STAGE;
+        unsigned char* bl = al + TILE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = wv * 16 + j * 4 + prow;
+            const long long m = m_begin + (long long)it * BKP + row;
+            const bool live = m < m_end;
+            const int mm = live ? (int)m : 0;
+            const int n = y3_fdiv(mm, p.dv_hw);
+            const int rem = mm - n * (p.Ho * p.Wo);
+            const int ho = y3_fdiv(rem, p.dv_w), wo = rem - ho * p.Wo;
+            const unsigned aoff = (live && a_ok) ? (unsigned)(((long long)mm * p.dpitch + a_ch) * 2) : OOB;
+            const int hi = ho * p.stride - p.pad + b_kh, wi = wo * p.stride - p.pad + b_kw;
+            const bool inb = live && b_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const unsigned boff = inb ? (unsigned)((((long long)(n * p.H + hi) * p.W + wi) * p.xpitch + b_ci) * 2) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (lds_ptr_t)(al + (wv * 16 + j * 4) * ROWB), 16, aoff, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(bl + (wv * 16 + j * 4) * ROWB), 16, boff, 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.0f;
+
+    // fragment role: 16-lane group g = lane >> 4: channel block 16 (g & 1) of the 32-wide MFMA tile, k-group g >> 1;
+    // lane i of the group reads pixel row (i >> 2), channels 4 (i & 3) .. +3 of the block
+    const int gi = lane & 15, gg = lane >> 4;
+    const int krow0 = (gg >> 1) * 8 + (gi >> 2);            // + 16 kk + 4 t
+    const int chan0 = (gg & 1) * 16 + 4 * (gi & 3);         // + 32 (tile index) within the 128-wide operand tile
+    auto tr_frag = [&](const unsigned char* tile, int tile32, int kk) -> frag {
+        const int ch = tile32 * 32 + chan0;
+        s16x8 r;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int k = kk * 16 + t * 4 + krow0;
+            const unsigned char* a = tile + k * ROWB + (((ch >> 3) ^ (4 * (k & 3))) << 4) + (ch & 4) * 2;
+            const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)a);
+            r[4 * t] = v[0]; r[4 * t + 1] = v[1]; r[4 * t + 2] = v[2]; r[4 * t + 3] = v[3];
+        }
+        return __builtin_bit_cast(frag, r);
+    };
+    auto compute = [&](int stage) {
+        const unsigned char* al = smem + stage * STAGE;
+        const unsigned char* bl = al + TILE;
+#pragma unroll
+        for (int kk = 0; kk < BKP / 16; ++kk) {
+            frag af[2], bf[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) af[a] = tr_frag(al, wc * 2 + a, kk);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bf[b] = tr_frag(bl, wn * 2 + b, kk);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    if constexpr (std::is_same<T, f16_t>::value) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+                    else acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+                }
+        }
+    };
+
+    const int steps = (int)((m_end - m_begin + BKP - 1) / BKP);
+    dma(0, 0);
+    for (int it = 0; it < steps; ++it) {
+        __syncthreads();   // step `it` has landed for every wave; the other stage is no longer being read
+        if (it + 1 < steps) dma(it + 1, (it + 1) & 1);
+        compute(it & 1);
+    }
+
+    // D[row = co][col = n] -> partial tile [n][co] (each lane owns 4 consecutive co: one 16-byte store)
+    const int frow = lane & 31, fk = lane >> 5;
     float* tile = p.part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (128 * 128);
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -747,6 +884,8 @@ extern "C" int y3_conv2d_wgrad(const y3_conv_desc* d, const y3_tensor* x, const 
         a.N = x->n; a.H = x->h; a.W = x->w; a.Cin = d->cin; a.xpitch = x->pitch; a.Ho = Ho; a.Wo = Wo; a.Cout = d->cout; a.dpitch = du->pitch;
         a.ks = d->ksize; a.stride = d->stride; a.pad = pad; a.cin_real = cin_real; a.cout_real = cout_real; a.M = M;
         a.x_bytes = (unsigned)xb; a.du_bytes = (unsigned)db_;
+        a.dv_hw = y3_make_divisor(Ho * Wo); a.dv_w = y3_make_divisor(Wo);
+        if (M > 0x7fffffffLL) Y3_FAIL("y3_conv2d_wgrad: too many pixels");
         int n_ct;
         long long slices, per;
         wgrad_geometry(d, M, n_ct, a.n_nt, slices, per);
@@ -754,8 +893,14 @@ extern "C" int y3_conv2d_wgrad(const y3_conv_desc* d, const y3_tensor* x, const 
         if (!workspace || workspace_bytes < (size_t)slices * tiles * 128 * 128 * sizeof(float)) Y3_FAIL("y3_conv2d_wgrad: workspace too small");
         a.per_slice = (int)per;
         const dim3 grid((unsigned)tiles, (unsigned)slices);
-        if (d->dtype == Y3_F16) hipLaunchKernelGGL((wgrad_mfma_kernel<f16_t>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((wgrad_mfma_kernel<bf16_t>), grid, dim3(256), 0, st, a);
+        static const bool reg_staged = getenv("Y3_WGRAD") && !strcmp(getenv("Y3_WGRAD"), "regs");   // A/B: the register-transposing kernel
+        if (reg_staged) {
+            if (d->dtype == Y3_F16) hipLaunchKernelGGL((wgrad_mfma_kernel<f16_t>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((wgrad_mfma_kernel<bf16_t>), grid, dim3(256), 0, st, a);
+        } else {
+            if (d->dtype == Y3_F16) hipLaunchKernelGGL((wgrad_dma_kernel<f16_t>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((wgrad_dma_kernel<bf16_t>), grid, dim3(256), 0, st, a);
+        }
         Y3_CHECK_LAUNCH();
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk(tiles * 128 * 128)), dim3(256), 0, st, (const float*)workspace, (int)tiles, a.n_nt, (int)slices, d->cin, d->ksize, cin_real,
                            cout_real, dw_oihw);

@@ -53,6 +53,21 @@ Y3_DEV float silu_f32(float v) { return v / (1.0f + __expf(-v)); }
 // rows of per-block partial sums behind the 2*C totals of y3_bn_stats / y3_bn_act_bwd scratch buffers
 #define Y3_BN_PARTIAL_ROWS 512
 
+// q = n / d for 0 <= n < 2^31 as umulhi(n, mul) >> (sh - 1); mul == 0 encodes d == 1.  Host side fills (mul, sh) once per launch.
+struct y3_divisor {
+    unsigned mul, sh;
+};
+static inline y3_divisor y3_make_divisor(int d) {
+    y3_divisor r;
+    if (d <= 1) { r.mul = 0; r.sh = 1; return r; }
+    unsigned s = 0;
+    while ((1ll << s) < d) ++s;
+    r.mul = (unsigned)(((1ull << (31 + s)) / (unsigned long long)d) + 1ull);
+    r.sh = s;
+    return r;
+}
+Y3_DEV int y3_fdiv(int n, y3_divisor d) { return d.mul ? (int)(__umulhi((unsigned)n, d.mul) >> (d.sh - 1)) : n; }
+
 static inline int y3_ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline size_t y3_round_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 
