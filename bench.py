@@ -140,7 +140,7 @@ def cpu_baseline(bs_sample=4):
 
 def train_main(args, rank, local_rank, world, dev, parallel, yo):
     """Data-parallel training step (BASELINE configs[2] shape per GPU): forward (batch-stat BN) + ComputeLoss + backward with
-    the gradient all-reduce overlapped (parallel.GradBuckets; RCCL over xGMI) + torch SGD(nesterov).  Weak scaling."""
+    the gradient all-reduce overlapped (parallel.GradBuckets; RCCL over xGMI) + the fused optimizer step.  Weak scaling."""
     from yolov3_amd import ComputeLoss, DetectionModel
 
     bs, hw = args.batch, args.imgsz
@@ -151,7 +151,12 @@ def train_main(args, rank, local_rank, world, dev, parallel, yo):
     if world > 1:
         model.grad_sync = parallel.GradBuckets()
     crit = ComputeLoss(model)
-    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.937, nesterov=True)
+    # the reference's optimizer step (train.py:414-422): unscale_ + clip_grad_norm_(10) + SGD(nesterov, 3 param groups) + EMA (rank 0),
+    # here the fused 3-launch kernel; weight decay scaled by total batch / 64 (train.py:236-237)
+    from yolov3_amd.optim import FusedSGD, ModelEMA, smart_param_groups
+
+    opt = FusedSGD(smart_param_groups(model, 0.01, 5e-4 * bs * world / 64), momentum=0.937, nesterov=True)
+    ema = ModelEMA(model) if rank == 0 else None
     x = torch.rand(bs, 3, hw, hw, generator=torch.Generator().manual_seed(rank)).to(dev)
     tg = yo.synth_targets(bs, 80, seed=1 + rank).to(dev)
     scale = 1024.0
@@ -160,9 +165,7 @@ def train_main(args, rank, local_rank, world, dev, parallel, yo):
         with torch.autocast("cuda", dtype=torch.float16 if args.dtype == "fp16" else torch.bfloat16):
             loss, _ = crit(model(x), tg)
         (loss * scale * world).backward()  # loss *= WORLD_SIZE (train.py:406): DDP averages, the reference wants the sum
-        for p_ in model.parameters():
-            p_.grad.div_(scale)
-        opt.step()
+        opt.step(grad_scale=scale, max_norm=10.0, ema=ema)
         opt.zero_grad(set_to_none=True)
         return loss
 
@@ -179,7 +182,7 @@ def train_main(args, rank, local_rank, world, dev, parallel, yo):
             "metric": "images/sec (640x640) train step", "value": round(world * bs * args.steps / dt, 2), "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16" if args.dtype == "fp16" else "bf16", "data": "synthetic (seeded uniform images, Poisson(7) targets/img; random-init weights)",
-            "config": {"workload": f"{args.model} train step {hw}x{hw} batch={bs}/GPU autocast {args.dtype}: fwd (batch-stat BN) + ComputeLoss + bwd + grad all-reduce + torch SGD [BASELINE configs[2]]",
+            "config": {"workload": f"{args.model} train step {hw}x{hw} batch={bs}/GPU autocast {args.dtype}: fwd (batch-stat BN) + ComputeLoss + bwd + grad all-reduce + fused unscale/clip/SGD-nesterov/EMA [BASELINE configs[2]]",
                        "global_batch": world * bs, "parallelism": f"dp{world} (bucketed all-reduce overlapped with backward)"},
             "final_loss": float(loss),
         }))

@@ -162,7 +162,7 @@ int y3_loss_bwd(const y3_loss_params* p, int32_t dtype, const void* const* preds
  * Train-mode `Conv` = act(bn(conv(x))) with BATCH statistics (reference models/common.py:75; BN eps 1e-3 / momentum
  * 0.03 set at models/yolo.py:229) and the autograd of the graph, decomposed as:
  *   forward : u = y3_conv2d_fwd(x)            (act NONE, zero bias; u is kept for the backward)
- *             y3_bn_stats(u) -> y3_bn_finalize -> y = y3_bn_act_fwd(u [, residual])
+ *             y3_bn_stats(u) -> y3_bn_finalize (or y3_bn_stats_finalize) -> y = y3_bn_act_fwd(u [, residual])
  *   backward: du = y3_bn_act_bwd(u, dy)       (also gives dgamma, dbeta)
  *             dW = y3_conv2d_wgrad(x, du)     (fp32 OIHW, the layout of nn.Conv2d.weight.grad)
  *             dx (+)= y3_conv2d_fwd(du, filter packed by y3_pack_filter_dgrad [, residual = dx, in_dilation = stride])
@@ -173,6 +173,10 @@ int y3_bn_stats(const y3_tensor* u, int32_t dtype, double* sums, void* stream);
 int y3_bn_finalize(const double* sums, int64_t count, int32_t channels, const float* gamma, const float* beta, float eps,
                    float momentum, float* running_mean /* updated in place, may be NULL */, float* running_var,
                    float* scale, float* shift, float* mean, float* invstd, void* stream);
+/* y3_bn_stats followed by y3_bn_finalize (count = n*h*w of u) with the partial-row sum and the finalize in one launch */
+int y3_bn_stats_finalize(const y3_tensor* u, int32_t dtype, double* sums, const float* gamma, const float* beta, float eps,
+                         float momentum, float* running_mean /* may be NULL */, float* running_var, float* scale, float* shift,
+                         float* mean, float* invstd, void* stream);
 int y3_bn_act_fwd(const y3_tensor* u, const float* scale, const float* shift, const y3_tensor* residual /* may be NULL */,
                   const y3_tensor* y, int32_t dtype, int32_t act, void* stream);
 int y3_bn_act_bwd(const y3_tensor* u, const y3_tensor* dy, const float* scale, const float* shift, const float* mean,

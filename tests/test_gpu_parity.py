@@ -708,6 +708,41 @@ def test_conv_wgrad_and_dgrad_vs_autograd(dev, dtype, name, shape, kw):
     assert e_w < tol and e_b < max(tol, 2e-3) and e_x < tol, f"{name} {dtype}: wgrad {e_w:.2e} bias {e_b:.2e} dgrad {e_x:.2e}"
 
 
+BIG_WGRAD_CASES = [
+    ("3x3s1_80", (4, 80, 80, 128, 256, 3, 1)),        # 5 column tiles (4.5 used), slices chosen for one round of 256 blocks
+    ("3x3s2_odd", (16, 67, 63, 128, 256, 3, 2)),      # stride 2, odd extents: halo + ragged last K-step
+    ("3x3s1_20_deep", (44, 20, 20, 256, 512, 3, 1)),  # small maps: the 32-pixel K-step spans rows and images (cursor wraps)
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name,shape", BIG_WGRAD_CASES, ids=[c[0] for c in BIG_WGRAD_CASES])
+def test_conv_wgrad_256_tile_vs_autograd(dev, dtype, name, shape):
+    """the 8-wave 256x256-tile filter-gradient kernel (Cout % 256 == 0, K >= 1152, >= 16384 pixels: the shapes it is
+    dispatched for) against torch autograd in fp32 on the same rounded operands."""
+    _lib, ops = _ops()
+    n, h, w, cin, cout, k, s = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, cin, h, w, generator=g).to(dtype).float()
+    wt = (torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)).requires_grad_(True)
+    y = F.conv2d(x, wt, None, stride=s, padding=k // 2)
+    gy = torch.randn(y.shape, generator=g).to(dtype).float()
+    y.backward(gy)
+    ho, wo = y.shape[2], y.shape[3]
+    assert n * ho * wo >= 16384
+    xv = ops.View.alloc(n, h, w, cin, dtype, dev)
+    ops.nchw_to_nhwc(x.to(dev), xv)
+    gv = ops.View.alloc(n, ho, wo, cout, dtype, dev)
+    ops.nchw_to_nhwc(gy.to(dev), gv)
+    dw, _ = ops.conv2d_wgrad(xv, gv, k, s, cout, cin)
+    dw2, _ = ops.conv2d_wgrad(xv, gv, k, s, cout, cin)
+    torch.cuda.synchronize()
+    assert torch.equal(dw, dw2), "filter gradient is not run-to-run deterministic"
+    tol = {torch.float16: 2e-3, torch.bfloat16: 1.5e-2}[dtype]
+    e_w = (dw.cpu() - wt.grad).abs().max().item() / wt.grad.abs().max().item()
+    assert e_w < tol, f"{name} {dtype}: wgrad {e_w:.2e}"
+
+
 def test_fused_sgd_vs_torch_reference(dev):
     """unscale + clip_grad_norm_(10) + SGD(nesterov, 3 groups) + EMA in the fused kernel vs torch's reference ops (fp32)."""
     from yolov3_amd.optim import FusedSGD, ModelEMA

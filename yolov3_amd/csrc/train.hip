@@ -120,8 +120,38 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(const T* __restrict
     }
 }
 
-// totals[j] = sum over the per-block partial rows: one block per 16 entries, 16 row-lanes each, fixed tree (deterministic)
-__global__ __launch_bounds__(256) void reduce_partials_kernel(double* __restrict__ sums, int n2c, int nblocks) {
+// totals[j] = sum over the per-block partial rows: one block per 16 entries, 16 row-lanes each, fixed tree (deterministic).
+// The consumers of the totals ride along (one launch instead of two or three ~5 us launches per conv unit and pass):
+//   MODE 1: + BatchNorm finalize (mean / biased var -> scale, shift, running statistics) for the block's 8 channels
+//   MODE 2: + (dbeta, dgamma) of the BN backward        MODE 3: + fp32 copy of the even entries (bias gradient)
+struct BnFinalizeArgs {
+    double count;
+    const float* gamma;
+    const float* beta;
+    float eps, momentum;
+    float* rmean;
+    float* rvar;
+    float* scale;
+    float* shift;
+    float* mean;
+    float* invstd;
+};
+Y3_DEV void bn_finalize_channel(int c, double s0, double s1, const BnFinalizeArgs& f) {
+    const double mu = s0 / f.count;
+    double var = s1 / f.count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)f.eps));
+    const float g = f.gamma ? f.gamma[c] : 1.0f, b = f.beta ? f.beta[c] : 0.0f;
+    f.mean[c] = (float)mu;
+    f.invstd[c] = is;
+    f.scale[c] = g * is;
+    f.shift[c] = b - (float)mu * g * is;
+    if (f.rmean) f.rmean[c] = (1.0f - f.momentum) * f.rmean[c] + f.momentum * (float)mu;
+    if (f.rvar) f.rvar[c] = (1.0f - f.momentum) * f.rvar[c] + f.momentum * (float)(f.count > 1.0 ? var * f.count / (f.count - 1.0) : var);
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void reduce_partials_kernel(double* __restrict__ sums, int n2c, int nblocks, BnFinalizeArgs f, float* __restrict__ o0, float* __restrict__ o1,
+                                                                int c_out) {
     __shared__ double red[256];
     const int j = blockIdx.x * 16 + (threadIdx.x & 15);
     const int rl = threadIdx.x >> 4;
@@ -135,26 +165,23 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(double* __restrict
         if (rl < s) red[threadIdx.x] += red[threadIdx.x + s * 16];
         __syncthreads();
     }
-    if (rl == 0 && j < n2c) sums[j] = red[threadIdx.x];
+    if (rl == 0 && j < n2c) {
+        sums[j] = red[threadIdx.x];
+        if (MODE != 0 && (j & 1) == 0) {   // entries (2c, 2c+1) of channel c sit in neighbouring lanes of row-lane 0
+            const int c = j >> 1;
+            const double s0 = red[threadIdx.x], s1 = red[threadIdx.x + 1];
+            if (MODE == 1) bn_finalize_channel(c, s0, s1, f);
+            if (MODE == 2) { if (o0) o0[c] = (float)s0; if (o1) o1[c] = (float)s1; }
+            if (MODE == 3) { if (c < c_out) o0[c] = (float)s0; }
+        }
+    }
 }
 
 // sums -> mean / biased var -> (scale, shift) of the normalisation, running-stat update (momentum, unbiased var)
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, int C, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float eps, float momentum, float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ scale,
-                                   float* __restrict__ shift, float* __restrict__ mean, float* __restrict__ invstd) {
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, int C, BnFinalizeArgs f) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
-    const double mu = sums[c * 2] / count;
-    double var = sums[c * 2 + 1] / count - mu * mu;
-    if (var < 0.0) var = 0.0;
-    const float is = (float)(1.0 / sqrt(var + (double)eps));
-    const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
-    mean[c] = (float)mu;
-    invstd[c] = is;
-    scale[c] = g * is;
-    shift[c] = b - (float)mu * g * is;
-    if (rmean) rmean[c] = (1.0f - momentum) * rmean[c] + momentum * (float)mu;
-    if (rvar) rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (float)(count > 1.0 ? var * count / (count - 1.0) : var);
+    bn_finalize_channel(c, sums[c * 2], sums[c * 2 + 1], f);
 }
 
 // y = act(u*scale + shift) (+ residual).  Thread (cg, pl) keeps its 8 channels' scale/shift in registers and walks
@@ -169,19 +196,32 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ u
     float sc[V], sh[V];
 #pragma unroll
     for (int q = 0; q < V; ++q) { sc[q] = scale[cg * V + q]; sh[q] = shift[cg * V + q]; }
-    for (long long m = (long long)blockIdx.x * PL + pl; m < M; m += (long long)gridDim.x * PL) {
-        const V16<T> x = *(const V16<T>*)(u + m * upitch + cg * V);
-        V16<T> r;
-        if (res) r = *(const V16<T>*)(res + m * rpitch + cg * V);
-        V16<T> o;
+    // 4 pixels per trip with every load issued before the arithmetic (one load in flight per thread left this pass at 3.9 TB/s)
+    const long long stride = (long long)gridDim.x * PL;
+    for (long long m0 = (long long)blockIdx.x * PL + pl; m0 < M; m0 += 4 * stride) {
+        V16<T> xs[4], rs[4];
 #pragma unroll
-        for (int q = 0; q < V; ++q) {
-            float z = to_f32<T>(x.v[q]) * sc[q] + sh[q];
-            if (act == Y3_ACT_SILU) z = z * sigmoid_fast(z);
-            if (res) z += to_f32<T>(r.v[q]);
-            o.v[q] = from_f32<T>(z);
+        for (int j = 0; j < 4; ++j) {
+            const long long m = m0 + j * stride;
+            if (m < M) {
+                xs[j] = *(const V16<T>*)(u + m * upitch + cg * V);
+                if (res) rs[j] = *(const V16<T>*)(res + m * rpitch + cg * V);
+            }
         }
-        *(V16<T>*)(y + m * ypitch + cg * V) = o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long m = m0 + j * stride;
+            if (m >= M) break;
+            V16<T> o;
+#pragma unroll
+            for (int q = 0; q < V; ++q) {
+                float z = to_f32<T>(xs[j].v[q]) * sc[q] + sh[q];
+                if (act == Y3_ACT_SILU) z = z * sigmoid_fast(z);
+                if (res) z += to_f32<T>(rs[j].v[q]);
+                o.v[q] = from_f32<T>(z);
+            }
+            *(V16<T>*)(y + m * ypitch + cg * V) = o;
+        }
     }
 }
 
@@ -221,13 +261,6 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
         }
         *(V16<T>*)(du + m * opitch + cg * V) = o;
     }
-}
-
-__global__ void bn_param_grads_kernel(const double* __restrict__ sums, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    if (dbeta) dbeta[c] = (float)sums[c * 2];
-    if (dgamma) dgamma[c] = (float)sums[c * 2 + 1];
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -283,6 +316,7 @@ struct WgradArgs {
     int n_nt;       // column tiles
     unsigned x_bytes, du_bytes;
     y3_divisor dv_hw, dv_w;   // Ho*Wo, Wo
+    int step_n, step_q, step_r;   // a K-step of the 256-tile kernel (32 pixels) as (images, rows, columns): 32 = (step_n*Ho + step_q)*Wo + step_r
 };
 
 Y3_DEV unsigned pack_lo(unsigned a, unsigned b) { return (a & 0xffffu) | (b << 16); }
@@ -441,6 +475,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs p) {
 #endif
 }
 
+// Transposing LDS read as inline asm.  Through the builtin the compiler treats the read as possibly aliasing every pending
+// `buffer_load ... lds` and puts `s_waitcnt vmcnt(0)` in front of the first fragment read of each K-step: the tile requested a
+// moment earlier is then awaited before any MFMA is issued (no load/compute overlap inside a wave -- seen in the ISA of the
+// first version of these kernels).  As asm the read is opaque: the kernels order DMA vs. reads themselves (counted vmcnt +
+// barrier) and wait for the read data with explicit lgkmcnt(0) statements that carry the fragments as operands.
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+template <int OFF> Y3_DEV s16x4_t lds_read_tr16(unsigned addr) {
+    s16x4_t v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+template <typename F> Y3_DEV void lds_wait4(F& a, F& b, F& c, F& d) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory"); }
+template <typename F> Y3_DEV void lds_wait6(F& a, F& b, F& c, F& d, F& e, F& f) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : : "memory");
+}
+
 // ---- wgrad, LDS-DMA + transposing LDS reads (gfx950 ds_read_b64_tr_b16) -------------------------------------------------
 // Same GEMM and tiling as wgrad_mfma_kernel (128 filters x 128 (tap, channel) columns per block, K-step = 64 pixels,
 // partial tiles per pixel slice), but the operands are staged in their NATURAL layout: a K-step of du is 64 rows of 128
@@ -456,10 +507,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BKP = 64, ROWB = 256, TILE = BKP * ROWB, STAGE = 2 * TILE;   // 16 KiB per operand and stage
     typedef typename std::conditional<std::is_same<T, f16_t>::value, f16x8, bf16x8>::type frag;
-    typedef short s16x4 __attribute__((ext_vector_type(4)));
-    typedef short s16x8 __attribute__((ext_vector_type(8)));
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    typedef __attribute__((address_space(3))) s16x4* lds_s4_t;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -515,48 +563,71 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs p) {
             for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.0f;
 
     // fragment role: 16-lane group g = lane >> 4: channel block 16 (g & 1) of the 32-wide MFMA tile, k-group g >> 1;
-    // lane i of the group reads pixel row (i >> 2), channels 4 (i & 3) .. +3 of the block
+    // lane i of the group reads pixel row (i >> 2), channels 4 (i & 3) .. +3 of the block.  The row's swizzle key k & 3 is
+    // (i >> 2) for every fragment of the lane (all other row terms are multiples of 4), so the per-lane LDS address of MFMA
+    // tile t32 is one VGPR and (stage, kk, t) are immediate offsets.
     const int gi = lane & 15, gg = lane >> 4;
     const int krow0 = (gg >> 1) * 8 + (gi >> 2);            // + 16 kk + 4 t
     const int chan0 = (gg & 1) * 16 + 4 * (gi & 3);         // + 32 (tile index) within the 128-wide operand tile
-    auto tr_frag = [&](const unsigned char* tile, int tile32, int kk) -> frag {
-        const int ch = tile32 * 32 + chan0;
-        s16x8 r;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+    unsigned fa[2], fb[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int k = kk * 16 + t * 4 + krow0;
-            const unsigned char* a = tile + k * ROWB + (((ch >> 3) ^ (4 * (k & 3))) << 4) + (ch & 4) * 2;
-            const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)a);
-            r[4 * t] = v[0]; r[4 * t + 1] = v[1]; r[4 * t + 2] = v[2]; r[4 * t + 3] = v[3];
-        }
+    for (int i = 0; i < 2; ++i) {
+        const int cha = (wc * 2 + i) * 32 + chan0, chb = (wn * 2 + i) * 32 + chan0;
+        fa[i] = lds0 + krow0 * ROWB + (((cha >> 3) ^ (4 * (krow0 & 3))) << 4) + (cha & 4) * 2;
+        fb[i] = lds0 + TILE + krow0 * ROWB + (((chb >> 3) ^ (4 * (krow0 & 3))) << 4) + (chb & 4) * 2;
+    }
+    auto tr_frag = [&](unsigned base, auto stage_kk) -> frag {   // stage_kk: integral_constant<int, stage * 4 + kk>
+        constexpr int SK = decltype(stage_kk)::value;
+        constexpr int OFF = (SK >> 2) * STAGE + (SK & 3) * 16 * ROWB;
+        const s16x4_t v0 = lds_read_tr16<OFF>(base), v1 = lds_read_tr16<OFF + 4 * ROWB>(base);
+        const s16x8_t r = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         return __builtin_bit_cast(frag, r);
     };
-    auto compute = [&](int stage) {
-        const unsigned char* al = smem + stage * STAGE;
-        const unsigned char* bl = al + TILE;
+    auto mma = [&](const frag (&af)[2], const frag (&bf)[2]) {
 #pragma unroll
-        for (int kk = 0; kk < BKP / 16; ++kk) {
-            frag af[2], bf[2];
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int a = 0; a < 2; ++a) af[a] = tr_frag(al, wc * 2 + a, kk);
-#pragma unroll
-            for (int b = 0; b < 2; ++b) bf[b] = tr_frag(bl, wn * 2 + b, kk);
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    if constexpr (std::is_same<T, f16_t>::value) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
-                    else acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
-                }
-        }
+            for (int b = 0; b < 2; ++b) {
+                if constexpr (std::is_same<T, f16_t>::value) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+                else acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+            }
+    };
+    // the reads of k-substep kk+1 are in flight under the MFMAs of kk; the lgkmcnt(0) behind the MFMAs finds them landed
+    auto compute = [&](auto stage_c) {
+        constexpr int ST = decltype(stage_c)::value;
+        frag a0[2], b0[2], a1[2], b1[2];
+        auto rd = [&](auto kk_c, frag (&af)[2], frag (&bf)[2]) {
+            constexpr int SK = ST * 4 + decltype(kk_c)::value;
+            af[0] = tr_frag(fa[0], std::integral_constant<int, SK>{}); af[1] = tr_frag(fa[1], std::integral_constant<int, SK>{});
+            bf[0] = tr_frag(fb[0], std::integral_constant<int, SK>{}); bf[1] = tr_frag(fb[1], std::integral_constant<int, SK>{});
+        };
+        rd(std::integral_constant<int, 0>{}, a0, b0);
+        lds_wait4(a0[0], a0[1], b0[0], b0[1]);
+        rd(std::integral_constant<int, 1>{}, a1, b1);
+        mma(a0, b0);
+        lds_wait4(a1[0], a1[1], b1[0], b1[1]);
+        rd(std::integral_constant<int, 2>{}, a0, b0);
+        mma(a1, b1);
+        lds_wait4(a0[0], a0[1], b0[0], b0[1]);
+        rd(std::integral_constant<int, 3>{}, a1, b1);
+        mma(a0, b0);
+        lds_wait4(a1[0], a1[1], b1[0], b1[1]);
+        mma(a1, b1);
     };
 
     const int steps = (int)((m_end - m_begin + BKP - 1) / BKP);
     dma(0, 0);
-    for (int it = 0; it < steps; ++it) {
-        __syncthreads();   // step `it` has landed for every wave; the other stage is no longer being read
-        if (it + 1 < steps) dma(it + 1, (it + 1) & 1);
-        compute(it & 1);
+    for (int it = 0; it < steps; it += 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // step `it` has landed for every wave; the other stage is no longer being read
+        if (it + 1 < steps) dma(it + 1, 1);
+        compute(std::integral_constant<int, 0>{});
+        if (it + 1 >= steps) break;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (it + 2 < steps) dma(it + 2, 0);
+        compute(std::integral_constant<int, 1>{});
     }
 
     // D[row = co][col = n] -> partial tile [n][co] (each lane owns 4 consecutive co: one 16-byte store)
@@ -577,18 +648,195 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs p) {
 #endif
 }
 
+// ---- wgrad, 256 filters x 256 (tap, channel) columns per block: the conv v6 schedule on the filter-gradient GEMM ---------------
+// The 128x128 kernel above reaches ~560 TFLOP/s on the K >= 1152 layers (32 launches, 14 ms of a batch-64 step) against 800-1060
+// for the forward kernels on the same FLOPs: per MFMA it stages twice the bytes and issues twice the fragment reads of a
+// 256x256 tile, recomputes every row's pixel decomposition in each K-step, and all four waves drain their loads at one barrier.
+// Here: 8 waves (64 filters x 128 columns each: 12 transposed fragments for 16 MFMAs per 16 pixels), K-step = 32 pixels, rows of
+// 256 channels (512 B) staged in the natural NHWC layout by `buffer_load ... lds` with the XOR slot swizzle of the kernel above
+// (it only touches slot bits 2-3, so the bank argument is unchanged), FOUR stages, the two wave halves one barrier interval apart
+// (MEM = request tile t+2 + transposed fragment reads of tile t | MMA = 16 MFMAs under s_setprio), counted vmcnt(4), and an
+// incremental (image, row, column) cursor per staged row instead of two multiply-shift divisions per row and K-step.
+template <typename T>
+__global__ __launch_bounds__(512, 2) void wgrad_big_kernel(const WgradArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BKP = 32, ROWB = 512, TILE = BKP * ROWB, STAGE = 2 * TILE, NST = 4;   // 16 KiB per operand and stage, 128 KiB in all
+    typedef typename std::conditional<std::is_same<T, f16_t>::value, f16x8, bf16x8>::type frag;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NST * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wv >> 1, wn = wv & 1;      // 4 x 2 waves: 64 filters x 128 columns each
+    const int ct = blockIdx.x / p.n_nt, nt = blockIdx.x % p.n_nt;
+    const long long m_begin = (long long)blockIdx.y * p.per_slice;
+    long long m_end = m_begin + p.per_slice;
+    if (m_end > p.M) m_end = p.M;
+    if (m_begin >= m_end) return;
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const auto rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)p.du, 0, (int)p.du_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xffffffffu;
+
+    // staging role: wave w fills rows 4w .. 4w+3 of both operands, 2 rows (one 1 KiB piece) per instruction;
+    // lane -> (row within the piece = lane / 32, physical slot = lane % 32); piece j holds rows 4w + 2j, 4w + 2j + 1
+    const int prow = lane >> 5, pslot = lane & 31;
+    int a_ch[2], b_ci[2], b_kh[2], b_kw[2];
+    bool a_ok[2], b_ok[2];
+    int cm[2], cn[2], cho[2], cwo[2];    // pixel cursor of the lane's row in piece j: flat index, image, output row, output column
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = 2 * j + prow;                    // row & 3 (4w is a multiple of 4)
+        const int lslot = pslot ^ (4 * row);
+        a_ch[j] = ct * 256 + lslot * 8;
+        a_ok[j] = a_ch[j] < p.Cout;
+        const int ncol = nt * 256 + lslot * 8;
+        const int tap = ncol / p.Cin;
+        b_ci[j] = ncol - tap * p.Cin;
+        b_kh[j] = tap / p.ks;
+        b_kw[j] = tap - b_kh[j] * p.ks;
+        b_ok[j] = tap < p.ks * p.ks;
+        const long long m = m_begin + wv * 4 + row;
+        const int mm = (int)(m < p.M ? m : p.M - 1);
+        cm[j] = (int)m;
+        cn[j] = y3_fdiv(mm, p.dv_hw);
+        const int rem = mm - cn[j] * (p.Ho * p.Wo);
+        cho[j] = y3_fdiv(rem, p.dv_w);
+        cwo[j] = rem - cho[j] * p.Wo;
+    }
+    const int m_end_i = (int)m_end;
+
+    auto dma = [&](int stage) {   // K-steps are requested strictly in order: the cursors advance by 32 pixels per call
+        unsigned char* al = smem + stage * STAGE;
+        unsigned char* bl = al + TILE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool live = cm[j] < m_end_i;
+            const unsigned aoff = (live && a_ok[j]) ? ((unsigned)cm[j] * (unsigned)p.dpitch + (unsigned)a_ch[j]) * 2u : OOB;
+            const int hi = cho[j] * p.stride - p.pad + b_kh[j], wi = cwo[j] * p.stride - p.pad + b_kw[j];
+            const bool inb = live && b_ok[j] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const unsigned boff = inb ? (unsigned)(((cn[j] * p.H + hi) * p.W + wi) * p.xpitch + b_ci[j]) * 2u : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (lds_ptr_t)(al + (wv * 4 + j * 2) * ROWB), 16, aoff, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(bl + (wv * 4 + j * 2) * ROWB), 16, boff, 0, 0, 0);
+            cm[j] += BKP;
+            cn[j] += p.step_n;
+            cwo[j] += p.step_r;
+            cho[j] += p.step_q;
+            if (cwo[j] >= p.Wo) { cwo[j] -= p.Wo; ++cho[j]; }
+            if (cho[j] >= p.Ho) { cho[j] -= p.Ho; ++cn[j]; }   // step_q <= Ho - 1: one wrap is enough
+        }
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.0f;
+
+    // fragment role (see wgrad_dma_kernel): 16-lane group g = lane >> 4 reads channel block 16 (g & 1) of a 32-wide MFMA tile for
+    // k-group g >> 1; lane i of the group addresses pixel row (i >> 2), channels 4 (i & 3) .. +3 and receives channel i's 4 pixels.
+    // One address VGPR per MFMA tile of the wave (2 filter tiles, 4 column tiles); (kk, t) are immediate offsets, the stage base
+    // is added per K-step (4 x 32 KiB does not fit the 16-bit offset field).
+    const int gi = lane & 15, gg = lane >> 4;
+    const int krow0 = (gg >> 1) * 8 + (gi >> 2);            // + 16 kk + 4 t
+    const int chan0 = (gg & 1) * 16 + 4 * (gi & 3);         // + 32 (tile index) within the 256-wide operand tile
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
+    unsigned fa[2], fb[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ch = (wc * 2 + i) * 32 + chan0;
+        fa[i] = lds0 + krow0 * ROWB + (((ch >> 3) ^ (4 * (krow0 & 3))) << 4) + (ch & 4) * 2;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = (wn * 4 + i) * 32 + chan0;
+        fb[i] = lds0 + TILE + krow0 * ROWB + (((ch >> 3) ^ (4 * (krow0 & 3))) << 4) + (ch & 4) * 2;
+    }
+    auto tr_frag = [&](unsigned addr, auto kk_c) -> frag {
+        constexpr int OFF = decltype(kk_c)::value * 16 * ROWB;
+        const s16x4_t v0 = lds_read_tr16<OFF>(addr), v1 = lds_read_tr16<OFF + 4 * ROWB>(addr);
+        const s16x8_t r = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        return __builtin_bit_cast(frag, r);
+    };
+    auto load_frags = [&](int stage, auto kk_c, frag (&af)[2], frag (&bf)[4]) {
+        const unsigned sb = (unsigned)(stage * STAGE);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) af[a] = tr_frag(fa[a] + sb, kk_c);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) bf[b] = tr_frag(fb[b] + sb, kk_c);
+    };
+    auto mma = [&](const frag (&af)[2], const frag (&bf)[4]) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if constexpr (std::is_same<T, f16_t>::value) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+                else acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+            }
+    };
+
+    const int steps = (m_end_i - (int)m_begin + BKP - 1) / BKP;
+    const int half = wv >> 2;   // 0: leading half, 1: trailing half (one barrier interval behind)
+    dma(0);
+    if (steps > 1) dma(1);
+    if (steps > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // tile 0 is visible to everyone
+    if (half) __builtin_amdgcn_s_barrier();   // stagger
+    for (int it = 0; it < steps; ++it) {
+        // ---- MEM(it): request tile it+2, read the fragments of tile it, retire this wave's pieces of tile it+1 ----
+        const bool more = it + 2 < steps;
+        if (more) dma((it + 2) & 3);
+        frag a0[2], b0[4], a1[2], b1[4];
+        load_frags(it & 3, std::integral_constant<int, 0>{}, a0, b0);
+        load_frags(it & 3, std::integral_constant<int, 1>{}, a1, b1);
+        if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- MMA(it) ----
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        lds_wait6(a0[0], a0[1], b0[0], b0[1], b0[2], b0[3]);   // the fragment reads landed while the wave sat at the barrier
+        lds_wait6(a1[0], a1[1], b1[0], b1[1], b1[2], b1[3]);
+        mma(a0, b0);
+        mma(a1, b1);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (!half) __builtin_amdgcn_s_barrier();  // re-align: every wave has passed 2 steps + 2 barriers
+
+    // D[row = co][col = n] -> partial tile [n][co] (each lane owns 4 consecutive co: one 16-byte store)
+    const int frow = lane & 31, fk = lane >> 5;
+    float* tile = p.part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (256 * 256);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int nl = (wn * 4 + b) * 32 + frow;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = (wc * 2 + a) * 32 + 8 * g + 4 * fk;
+                f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
+                *(f32x4*)(tile + nl * 256 + col) = v;
+            }
+    }
+#endif
+}
+
 // dW (OIHW fp32) = sum over slices of the partial tiles.  Threads follow the partial layout (co fastest) so every
 // slice is read fully coalesced; the scattered 4-byte OIHW write happens once per element.  Fixed summation order.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int tiles, int n_nt, int slices, int Cin, int ks, int cin_real, int cout_real,
-                                                             float* __restrict__ dw) {
+                                                             float* __restrict__ dw, int tsh) {   // tile edge = 1 << tsh (128 or 256)
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;   // element of the tile array: (tile, n_local, co_local)
-    if (e >= (long long)tiles * (128 * 128)) return;
-    const int col = (int)(e & 127), nl = (int)((e >> 7) & 127), tile = (int)(e >> 14);
+    const int ts = 1 << tsh;
+    if (e >= (long long)tiles << (2 * tsh)) return;
+    const int col = (int)(e & (ts - 1)), nl = (int)((e >> tsh) & (ts - 1)), tile = (int)(e >> (2 * tsh));
     const int ct = tile / n_nt, nt = tile - ct * n_nt;
-    const int co = ct * 128 + col, n = nt * 128 + nl;
+    const int co = ct * ts + col, n = nt * ts + nl;
     const int tap = n / Cin, ci = n - tap * Cin;
     if (co >= cout_real || ci >= cin_real || tap >= ks * ks) return;
-    const size_t stride = (size_t)tiles * (128 * 128);
+    const size_t stride = (size_t)tiles << (2 * tsh);
     float a = 0.0f;
 #pragma unroll 4
     for (int s = 0; s < slices; ++s) a += part[(size_t)s * stride + e];
@@ -761,17 +1009,22 @@ static int elementwise_geometry(int C, int esz, long long M, unsigned& grid) {
     return 0;
 }
 
-extern "C" int y3_bn_stats(const y3_tensor* u, int32_t dtype, double* sums, void* stream) {
-    if (!u || !sums) Y3_FAIL("y3_bn_stats: null argument");
+static int bn_stats_launch(const y3_tensor* u, int32_t dtype, double* sums, hipStream_t st, unsigned& grid) {
     if (!vec_ok(u, esize(dtype))) Y3_FAIL("y3_bn_stats: alignment");
     const long long M = (long long)u->n * u->h * u->w;
-    unsigned grid;
     if (reduce_geometry(u->c, esize(dtype), M, grid)) return -1;
-    hipStream_t st = (hipStream_t)stream;
     Y3_DISPATCH_T(dtype, hipLaunchKernelGGL((channel_reduce_kernel<T, 0>), dim3(grid), dim3(256), 0, st, (const T*)u->data, u->pitch, (const T*)nullptr, 0, M, u->c,
                                             (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, sums));
     Y3_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * u->c + 15) / 16), dim3(256), 0, st, sums, 2 * u->c, (int)grid);
+    return 0;
+}
+
+extern "C" int y3_bn_stats(const y3_tensor* u, int32_t dtype, double* sums, void* stream) {
+    if (!u || !sums) Y3_FAIL("y3_bn_stats: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    unsigned grid;
+    if (bn_stats_launch(u, dtype, sums, st, grid)) return -1;
+    hipLaunchKernelGGL(reduce_partials_kernel<0>, dim3((2 * u->c + 15) / 16), dim3(256), 0, st, sums, 2 * u->c, (int)grid, BnFinalizeArgs{}, (float*)nullptr, (float*)nullptr, 0);
     Y3_CHECK_LAUNCH();
     return 0;
 }
@@ -779,8 +1032,23 @@ extern "C" int y3_bn_stats(const y3_tensor* u, int32_t dtype, double* sums, void
 extern "C" int y3_bn_finalize(const double* sums, int64_t count, int32_t C, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                               float* running_var, float* scale, float* shift, float* mean, float* invstd, void* stream) {
     if (!sums || !scale || !shift || !mean || !invstd || count <= 0) Y3_FAIL("y3_bn_finalize: bad argument");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, (double)count, C, gamma, beta, eps, momentum, running_mean,
-                       running_var, scale, shift, mean, invstd);
+    const BnFinalizeArgs f{(double)count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd};
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, C, f);
+    Y3_CHECK_LAUNCH();
+    return 0;
+}
+
+// y3_bn_stats + y3_bn_finalize in two launches (the partial-row sum and the finalize share one kernel)
+extern "C" int y3_bn_stats_finalize(const y3_tensor* u, int32_t dtype, double* sums, const float* gamma, const float* beta, float eps, float momentum,
+                                    float* running_mean, float* running_var, float* scale, float* shift, float* mean, float* invstd, void* stream) {
+    if (!u || !sums || !scale || !shift || !mean || !invstd) Y3_FAIL("y3_bn_stats_finalize: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    unsigned grid;
+    if (bn_stats_launch(u, dtype, sums, st, grid)) return -1;
+    const long long M = (long long)u->n * u->h * u->w;
+    if (M <= 0) Y3_FAIL("y3_bn_stats_finalize: empty tensor");
+    const BnFinalizeArgs f{(double)M, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd};
+    hipLaunchKernelGGL(reduce_partials_kernel<1>, dim3((2 * u->c + 15) / 16), dim3(256), 0, st, sums, 2 * u->c, (int)grid, f, (float*)nullptr, (float*)nullptr, 0);
     Y3_CHECK_LAUNCH();
     return 0;
 }
@@ -814,17 +1082,14 @@ extern "C" int y3_bn_act_bwd(const y3_tensor* u, const y3_tensor* dy, const floa
     Y3_DISPATCH_T(dtype, hipLaunchKernelGGL((channel_reduce_kernel<T, 1>), dim3(grid), dim3(256), 0, st, (const T*)u->data, u->pitch, (const T*)dy->data, dy->pitch, M,
                                             u->c, scale, shift, mean, invstd, act, sums));
     Y3_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * u->c + 15) / 16), dim3(256), 0, st, sums, 2 * u->c, (int)grid);
+    // partial rows -> totals (the apply pass reads them) + (dbeta, dgamma) in the same launch
+    hipLaunchKernelGGL(reduce_partials_kernel<2>, dim3((2 * u->c + 15) / 16), dim3(256), 0, st, sums, 2 * u->c, (int)grid, BnFinalizeArgs{}, dbeta, dgamma, 0);
     Y3_CHECK_LAUNCH();
     unsigned egrid;
     if (elementwise_geometry(u->c, esz, M, egrid)) return -1;
     Y3_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T>), dim3(egrid), dim3(256), 0, st, (const T*)u->data, u->pitch, (const T*)dy->data,
                                             dy->pitch, scale, shift, mean, invstd, (const double*)sums, (double)M, (T*)du->data, du->pitch, M, u->c, act));
     Y3_CHECK_LAUNCH();
-    if (dgamma || dbeta) {
-        hipLaunchKernelGGL(bn_param_grads_kernel, dim3((u->c + 255) / 256), dim3(256), 0, st, (const double*)sums, u->c, dgamma, dbeta);
-        Y3_CHECK_LAUNCH();
-    }
     return 0;
 }
 
@@ -841,7 +1106,52 @@ extern "C" int y3_pack_filter_dgrad(const float* w, int32_t cout_src, int32_t ci
     return 0;
 }
 
-static void wgrad_geometry(const y3_conv_desc* d, long long M, int& n_ct, int& n_nt, long long& slices, long long& per) {
+// Y3_WGRAD=regs|dma: force the 128x128 kernels; =big: the 256x256 kernel whenever the shape allows it (tests); default: per shape
+static int wgrad_mode() {
+    static const int v = [] {
+        const char* e = getenv("Y3_WGRAD");
+        if (!e) return 0;
+        if (!strcmp(e, "regs")) return 1;
+        if (!strcmp(e, "dma")) return 2;
+        if (!strcmp(e, "big")) return 3;
+        if (!strcmp(e, "direct")) return 4;
+        return 0;
+    }();
+    return v;
+}
+// 256x256 tiles (one 8-wave block per CU): whole 256-filter tiles, a long reduction and enough columns to fill the tile
+static bool wgrad_use_big(const y3_conv_desc* d, long long M) {
+    const int mode = wgrad_mode();
+    if (d->dtype == Y3_F32 || mode == 1 || mode == 2 || mode == 4) return false;
+    const bool shape_ok = (d->cout % 256) == 0 && d->ksize * d->ksize * d->cin >= 1024 && M >= 256;
+    if (mode == 3) return shape_ok;
+    return shape_ok && d->ksize * d->ksize * d->cin >= 1152 && M >= 16384;
+}
+static void wgrad_geometry(const y3_conv_desc* d, long long M, int& n_ct, int& n_nt, long long& slices, long long& per, int& tsh) {
+    if (wgrad_use_big(d, M)) {
+        tsh = 8;
+        n_ct = y3_ceil_div(d->cout, 256);
+        n_nt = y3_ceil_div(d->ksize * d->ksize * d->cin, 256);
+        const long long tiles = (long long)n_ct * n_nt;
+        // one block per CU: pick the slice count with the fewest (rounds of 256 blocks) x (pixels per block + a fixed
+        // prologue/epilogue cost of ~8 K-steps); every slice writes a 256 KiB partial tile, so ties go to fewer slices
+        long long smax = M / 256;   // at least 8 K-steps (of 32 pixels) per block
+        if (smax < 1) smax = 1;
+        if (smax > 512) smax = 512;
+        long long best = 1, best_cost = -1;
+        for (long long sl = 1; sl <= smax; ++sl) {
+            const long long rounds = (tiles * sl + 255) / 256;
+            const long long len = ((M + sl - 1) / sl + 31) / 32 * 32 + 256;
+            const long long cost = rounds * len;
+            if (best_cost < 0 || cost < best_cost) { best = sl; best_cost = cost; }
+        }
+        slices = best;
+        per = (M + slices - 1) / slices;
+        per = (per + 31) / 32 * 32;
+        slices = (M + per - 1) / per;
+        return;
+    }
+    tsh = 7;
     n_ct = y3_ceil_div(d->cout, 128);
     n_nt = y3_ceil_div(d->ksize * d->ksize * d->cin, 128);
     const long long tiles = (long long)n_ct * n_nt;
@@ -858,10 +1168,10 @@ extern "C" size_t y3_conv2d_wgrad_workspace_bytes(const y3_conv_desc* d, const y
     if (!d || !x || d->dtype == Y3_F32) return 256;
     const int pad = d->ksize / 2;
     const int Ho = (x->h + 2 * pad - d->ksize) / d->stride + 1, Wo = (x->w + 2 * pad - d->ksize) / d->stride + 1;
-    int n_ct, n_nt;
+    int n_ct, n_nt, tsh;
     long long slices, per;
-    wgrad_geometry(d, (long long)x->n * Ho * Wo, n_ct, n_nt, slices, per);
-    return (size_t)slices * n_ct * n_nt * 128 * 128 * sizeof(float);
+    wgrad_geometry(d, (long long)x->n * Ho * Wo, n_ct, n_nt, slices, per, tsh);
+    return ((size_t)slices * n_ct * n_nt * sizeof(float)) << (2 * tsh);
 }
 
 extern "C" int y3_conv2d_wgrad(const y3_conv_desc* d, const y3_tensor* x, const y3_tensor* du, int32_t cout_real, int32_t cin_real, float* dw_oihw, float* dbias,
@@ -875,7 +1185,7 @@ extern "C" int y3_conv2d_wgrad(const y3_conv_desc* d, const y3_tensor* x, const 
     hipStream_t st = (hipStream_t)stream;
     const long long total = (long long)cout_real * cin_real * d->ksize * d->ksize;
     const long long M = (long long)x->n * Ho * Wo;
-    static const bool force_direct = getenv("Y3_WGRAD") && !strcmp(getenv("Y3_WGRAD"), "direct");
+    const bool force_direct = wgrad_mode() == 4;
     const long long xb = (((long long)x->n * x->h * x->w - 1) * x->pitch + x->c) * 2, db_ = ((M - 1) * du->pitch + du->c) * 2;
     if (d->dtype != Y3_F32 && !force_direct && xb < 0x7fffffffLL && db_ < 0x7fffffffLL) {
         WgradArgs a;
@@ -885,16 +1195,19 @@ extern "C" int y3_conv2d_wgrad(const y3_conv_desc* d, const y3_tensor* x, const 
         a.ks = d->ksize; a.stride = d->stride; a.pad = pad; a.cin_real = cin_real; a.cout_real = cout_real; a.M = M;
         a.x_bytes = (unsigned)xb; a.du_bytes = (unsigned)db_;
         a.dv_hw = y3_make_divisor(Ho * Wo); a.dv_w = y3_make_divisor(Wo);
+        a.step_n = 32 / (Ho * Wo); a.step_q = (32 % (Ho * Wo)) / Wo; a.step_r = (32 % (Ho * Wo)) % Wo;
         if (M > 0x7fffffffLL) Y3_FAIL("y3_conv2d_wgrad: too many pixels");
-        int n_ct;
+        int n_ct, tsh;
         long long slices, per;
-        wgrad_geometry(d, M, n_ct, a.n_nt, slices, per);
+        wgrad_geometry(d, M, n_ct, a.n_nt, slices, per, tsh);
         const long long tiles = (long long)n_ct * a.n_nt;
-        if (!workspace || workspace_bytes < (size_t)slices * tiles * 128 * 128 * sizeof(float)) Y3_FAIL("y3_conv2d_wgrad: workspace too small");
+        if (!workspace || workspace_bytes < (((size_t)slices * tiles * sizeof(float)) << (2 * tsh))) Y3_FAIL("y3_conv2d_wgrad: workspace too small");
         a.per_slice = (int)per;
         const dim3 grid((unsigned)tiles, (unsigned)slices);
-        static const bool reg_staged = getenv("Y3_WGRAD") && !strcmp(getenv("Y3_WGRAD"), "regs");   // A/B: the register-transposing kernel
-        if (reg_staged) {
+        if (tsh == 8) {
+            if (d->dtype == Y3_F16) hipLaunchKernelGGL((wgrad_big_kernel<f16_t>), grid, dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((wgrad_big_kernel<bf16_t>), grid, dim3(512), 0, st, a);
+        } else if (wgrad_mode() == 1) {   // A/B: the register-transposing kernel
             if (d->dtype == Y3_F16) hipLaunchKernelGGL((wgrad_mfma_kernel<f16_t>), grid, dim3(256), 0, st, a);
             else hipLaunchKernelGGL((wgrad_mfma_kernel<bf16_t>), grid, dim3(256), 0, st, a);
         } else {
@@ -902,8 +1215,8 @@ extern "C" int y3_conv2d_wgrad(const y3_conv_desc* d, const y3_tensor* x, const 
             else hipLaunchKernelGGL((wgrad_dma_kernel<bf16_t>), grid, dim3(256), 0, st, a);
         }
         Y3_CHECK_LAUNCH();
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk(tiles * 128 * 128)), dim3(256), 0, st, (const float*)workspace, (int)tiles, a.n_nt, (int)slices, d->cin, d->ksize, cin_real,
-                           cout_real, dw_oihw);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk(tiles << (2 * tsh))), dim3(256), 0, st, (const float*)workspace, (int)tiles, a.n_nt, (int)slices, d->cin, d->ksize, cin_real,
+                           cout_real, dw_oihw, tsh);
         Y3_CHECK_LAUNCH();
     } else {
         Y3_HIP(hipMemsetAsync(dw_oihw, 0, (size_t)total * sizeof(float), st));
@@ -918,8 +1231,29 @@ extern "C" int y3_conv2d_wgrad(const y3_conv_desc* d, const y3_tensor* x, const 
         Y3_CHECK_LAUNCH();
     }
     if (dbias) {
-        Y3_DISPATCH_T(d->dtype, hipLaunchKernelGGL((channel_sum_kernel<T>), dim3((unsigned)cout_real), dim3(256), 0, st, (const T*)du->data, du->pitch, M, d->cout, dbias));
-        Y3_CHECK_LAUNCH();
+        // bias gradient = per-channel sum of du.  The filter-gradient workspace is idle again (stream order): it holds the
+        // per-block partial rows of the BN reduction kernel, summed in a fixed order (one strided block per channel ran
+        // at 0.35 ms per head on batch 64)
+        const int esz = esize(d->dtype);
+        unsigned grid = 0;
+        const size_t row_bytes = (size_t)2 * d->cout * sizeof(double);
+        if (vec_ok(du, esz) && d->cout / (16 / esz) <= 256 && workspace && workspace_bytes >= 3 * row_bytes && (((uintptr_t)workspace) & 7) == 0) {
+            if (reduce_geometry(d->cout, esz, M, grid)) return -1;
+            const size_t fit = workspace_bytes / row_bytes - 1;
+            if (grid > fit) grid = (unsigned)fit;
+        }
+        if (grid) {
+            double* sums = (double*)workspace;
+            Y3_DISPATCH_T(d->dtype, hipLaunchKernelGGL((channel_reduce_kernel<T, 0>), dim3(grid), dim3(256), 0, st, (const T*)du->data, du->pitch, (const T*)nullptr, 0, M, d->cout,
+                                                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, sums));
+            Y3_CHECK_LAUNCH();
+            hipLaunchKernelGGL(reduce_partials_kernel<3>, dim3((2 * d->cout + 15) / 16), dim3(256), 0, st, sums, 2 * d->cout, (int)grid, BnFinalizeArgs{}, dbias, (float*)nullptr,
+                               cout_real);
+            Y3_CHECK_LAUNCH();
+        } else {
+            Y3_DISPATCH_T(d->dtype, hipLaunchKernelGGL((channel_sum_kernel<T>), dim3((unsigned)cout_real), dim3(256), 0, st, (const T*)du->data, du->pitch, M, d->cout, dbias));
+            Y3_CHECK_LAUNCH();
+        }
     }
     return 0;
 }

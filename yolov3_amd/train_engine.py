@@ -106,16 +106,14 @@ class ConvUnit(_Unit):
         ops.conv2d(self.x.view, filt, self.zero_bias, self.u, self.k, self.s, act=False)
         ut = self.u.y3()
         dcode = ops.dtype_code(self.plan.dtype)
-        check(L.y3_bn_stats(C.byref(ut), dcode, self.sums.data_ptr(), st), "y3_bn_stats")
         if self.cout != self.co_real:
             raise NotImplementedError("BatchNorm over a channel-padded conv")
         check(
-            L.y3_bn_finalize(self.sums.data_ptr(), self.count, self.cout, bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps), float(bn.momentum),
-                             bn.running_mean.data_ptr(), bn.running_var.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(), self.mean.data_ptr(),
-                             self.invstd.data_ptr(), st),
-            "y3_bn_finalize",
+            L.y3_bn_stats_finalize(C.byref(ut), dcode, self.sums.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps), float(bn.momentum),
+                                   bn.running_mean.data_ptr(), bn.running_var.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(), self.mean.data_ptr(),
+                                   self.invstd.data_ptr(), st),
+            "y3_bn_stats_finalize",
         )
-        bn.num_batches_tracked += 1
         yt = self.y.view.y3()
         rt = self.res.view.y3() if self.res is not None else None
         check(L.y3_bn_act_fwd(C.byref(ut), self.scale.data_ptr(), self.shift.data_ptr(), C.byref(rt) if rt is not None else None, C.byref(yt), dcode, self.act, st),
@@ -350,6 +348,7 @@ class TrainPlan:
             else:
                 raise NotImplementedError(type(k).__name__)
         self.params = list(model.parameters())
+        self._bn_counters = [u.m.bn.num_batches_tracked for u in self.units if isinstance(u, ConvUnit) and u.m.bn.num_batches_tracked is not None]
 
     # -- helpers ---------------------------------------------------------------------------------
     def zeros_f32(self, c):
@@ -384,6 +383,8 @@ class TrainPlan:
         with torch.no_grad():
             for u in self.units:
                 u.fwd()
+            if self._bn_counters:   # nn.BatchNorm2d.num_batches_tracked += 1, one launch for all 72 counters
+                torch._foreach_add_(self._bn_counters, 1)
             return [hd.fwd() for hd in self.heads]
 
     def backward(self, graws):
