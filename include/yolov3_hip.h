@@ -132,6 +132,21 @@ int y3_nms(const void* pred, int32_t dtype, int32_t bs, int32_t n_rows, int32_t 
            const int32_t* classes, float* out_rows, int32_t* out_counts, int32_t* out_status, int64_t capacity,
            void* workspace, size_t workspace_bytes, void* stream);
 
+/* Output edge after NMS, batched (csrc/val_edge.hip).
+ * y3_scale_boxes: reference utils/general.py:613-626 scale_boxes + upstream clip_boxes (callers val.py:397,403, detect.py:223),
+ * in place on fp32 xyxy rows: row r of image i starts at rows + i*img_stride + r*row_stride (floats; row_stride >= 4 so both the
+ * (bs, max_det, 6) NMS output and an (n, 4) view work).  counts (DEVICE, may be NULL = max_rows rows per image); params: DEVICE
+ * (bs, 5) fp32 {gain, pad_x, pad_y, w0, h0} computed by the caller exactly as the reference does (ratio_pad or the shapes).
+ * y3_match_detections: reference val.py:147-188 process_batch with upstream box_iou, for every image: dets as above
+ * ([x1,y1,x2,y2,conf,cls], row_stride >= 6), labels DEVICE (nl, 5) fp32 [cls,x1,y1,x2,y2] grouped by image through
+ * label_offsets (DEVICE, bs+1 int32), iouv DEVICE (niou) fp32; correct: DEVICE (bs, max_det, niou) bytes (0/1), rows beyond
+ * counts[i] are 0.  max_det <= 4096. */
+int y3_scale_boxes(float* rows, int64_t img_stride, int32_t row_stride, const int32_t* counts, int32_t bs, int32_t max_rows,
+                   const float* params, void* stream);
+int y3_match_detections(const float* dets, int64_t img_stride, int32_t row_stride, const int32_t* counts, int32_t bs,
+                        int32_t max_det, const float* labels, const int32_t* label_offsets, const float* iouv, int32_t niou,
+                        uint8_t* correct, void* stream);
+
 /* ComputeLoss: reference utils/loss.py:98-244 (build_targets :183-244, __call__ :131-181, criteria :104-129,
  * FocalLoss :31-63 when fl_gamma > 0) with upstream bbox_iou(CIoU) and smooth_bce.
  * preds: HOST array of nl DEVICE pointers, level i is contiguous (bs, na, ny[i], nx[i], nc+5) of `dtype`;

@@ -502,3 +502,85 @@ def synth_raw_predictions(shapes, seed=31):
     """Raw head tensors (bs,na,ny,nx,no) for the loss tests: uniform in [-3, 3] from torch.rand only."""
     g = torch.Generator().manual_seed(seed)
     return [(torch.rand(*s, generator=g) * 6.0 - 3.0) for s in shapes]
+
+
+# =========================================================================== output edge (val.py / detect.py after NMS)
+def scale_boxes(img1_shape, boxes, img0_shape, ratio_pad=None):
+    """Restates reference utils/general.py:613-626 (+ upstream clip_boxes): boxes (.., 4+) xyxy in letterboxed
+    img1 space -> native img0 space, in place."""
+    if ratio_pad is None:
+        gain = min(img1_shape[0] / img0_shape[0], img1_shape[1] / img0_shape[1])
+        pad = (img1_shape[1] - img0_shape[1] * gain) / 2, (img1_shape[0] - img0_shape[0] * gain) / 2
+    else:
+        gain = ratio_pad[0][0]
+        pad = ratio_pad[1]
+    boxes[..., [0, 2]] -= pad[0]
+    boxes[..., [1, 3]] -= pad[1]
+    boxes[..., :4] /= gain
+    upstream.clip_boxes(boxes, img0_shape)
+    return boxes
+
+
+def process_batch(detections, labels, iouv):
+    """Restates reference val.py:147-188: (N,6) [xyxy,conf,cls] x (M,5) [cls,xyxy] x (T,) -> bool (N,T).
+    Same numpy calls as the reference (argsort()[::-1], np.unique(return_index)); exact IoU ties are therefore
+    as undefined here as there beyond 16 candidate pairs."""
+    import numpy as np
+
+    correct = np.zeros((detections.shape[0], iouv.shape[0])).astype(bool)
+    iou = upstream.box_iou(labels[:, 1:], detections[:, :4])
+    correct_class = labels[:, 0:1] == detections[:, 5]
+    for i in range(len(iouv)):
+        x = torch.where((iou >= iouv[i]) & correct_class)
+        if x[0].shape[0]:
+            matches = torch.cat((torch.stack(x, 1), iou[x[0], x[1]][:, None]), 1).cpu().numpy()
+            if x[0].shape[0] > 1:
+                matches = matches[matches[:, 2].argsort()[::-1]]
+                matches = matches[np.unique(matches[:, 1], return_index=True)[1]]
+                matches = matches[np.unique(matches[:, 0], return_index=True)[1]]
+            correct[matches[:, 1].astype(int), i] = True
+    return torch.tensor(correct, dtype=torch.bool)
+
+
+def synth_val_case(seed, n_lab=12, n_det=60, nc=5, img=(480, 640), dup=0.5):
+    """One image's (detections (n_det,6), labels (n_lab,5)) in native pixel space for the matching tests, from torch.rand
+    and + - * / only.  Labels: random boxes; detections: jittered copies of labels (IoU spread over 0.3-0.98, so every
+    threshold of linspace(.5,.95,10) separates some), a `dup` share of labels is hit by several detections (the reference
+    keeps the lowest-index one), some with a wrong class, plus background boxes; sorted by descending confidence as NMS
+    returns them."""
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *shape: torch.rand(*shape, generator=g)
+    h, w = img
+    wh = (0.08 + 0.4 * r(n_lab, 2)) * torch.tensor([w, h], dtype=torch.float32)
+    c = (0.1 + 0.8 * r(n_lab, 2)) * torch.tensor([w, h], dtype=torch.float32)
+    lab_xyxy = torch.cat((c - wh / 2, c + wh / 2), 1)
+    lab_cls = torch.randint(0, nc, (n_lab, 1), generator=g).float()
+    labels = torch.cat((lab_cls, lab_xyxy), 1)
+    n_hit = int(n_det * 0.7) if n_lab else 0
+    if n_lab:
+        k = torch.randint(0, min(n_lab, max(1, int(n_lab * dup) + 1)), (n_hit,), generator=g) if dup > 0 else torch.randint(0, n_lab, (n_hit,), generator=g)
+        k2 = torch.randint(0, n_lab, (n_hit,), generator=g)
+        k = torch.where(r(n_hit) < 0.5, k, k2)
+        jit = (r(n_hit, 4) - 0.5) * (0.02 + 0.5 * r(n_hit, 1)) * torch.cat((wh[k], wh[k]), 1)
+        hit_box = lab_xyxy[k] + jit
+        hit_cls = torch.where(r(n_hit, 1) < 0.85, lab_cls[k], torch.randint(0, nc, (n_hit, 1), generator=g).float())
+    else:
+        hit_box, hit_cls = torch.zeros(0, 4), torch.zeros(0, 1)
+    n_bg = n_det - n_hit
+    bwh = (0.05 + 0.3 * r(n_bg, 2)) * torch.tensor([w, h], dtype=torch.float32)
+    bc = r(n_bg, 2) * torch.tensor([w, h], dtype=torch.float32)
+    bg_box = torch.cat((bc - bwh / 2, bc + bwh / 2), 1)
+    bg_cls = torch.randint(0, nc, (n_bg, 1), generator=g).float()
+    box = torch.cat((hit_box, bg_box), 0)
+    cls = torch.cat((hit_cls, bg_cls), 0)
+    conf = 0.05 + 0.95 * r(n_det, 1)
+    det = torch.cat((box, conf, cls), 1)
+    det = det[det[:, 4].argsort(descending=True, stable=True)]
+    return det.contiguous(), labels.contiguous()
+
+
+def synth_scale_case(img1_shape, seed=12, n=400):
+    """(n, 6) rows [x1,y1,x2,y2,conf,cls] in letterboxed img1 space (boxes partly outside the image so that the clip
+    matters), from synth_predictions: the scale_boxes test input."""
+    pred = synth_predictions(bs=1, n_rows=n, nc=3, img=img1_shape[1], seed=seed)[0]
+    return torch.cat((pred[:, 0:2] - pred[:, 2:4] / 2, pred[:, 0:2] + pred[:, 2:4] / 2, pred[:, 4:6]), 1).contiguous()

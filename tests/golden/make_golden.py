@@ -202,12 +202,65 @@ def gen_loss_goldens(ns):
     torch.save(out, OUT / "loss.pt")
 
 
+VAL_MATCH_CASES = {
+    # name: synth_val_case kwargs
+    "coco_like": dict(seed=0, n_lab=12, n_det=60, nc=5),
+    "crowded_dups": dict(seed=1, n_lab=30, n_det=300, nc=3, dup=0.3),
+    "single_class": dict(seed=2, n_lab=8, n_det=40, nc=1, dup=1.0),
+    "few_labels": dict(seed=3, n_lab=1, n_det=25, nc=4),
+    "no_labels": dict(seed=4, n_lab=0, n_det=10, nc=4),
+    "one_det": dict(seed=5, n_lab=6, n_det=1, nc=2),
+    "many_classes": dict(seed=6, n_lab=40, n_det=200, nc=80),
+}
+VAL_SCALE_CASES = {
+    # name: (img1_shape, img0_shape, ratio_pad)
+    "landscape": ((640, 640), (480, 640), None),
+    "portrait_hd": ((640, 640), (1280, 720), None),
+    "rect_val": ((384, 640), (427, 640), ((0.9, 0.9), (0.0, 0.15))),       # val.py:397 passes shapes[si][1] = (ratio, pad)
+    "upscaled": ((640, 640), (200, 333), ((1.92, 1.92), (0.3199999, 128.0))),
+}
+
+
+def gen_val_edge_goldens(ns):
+    """Output edge after NMS: the unmodified reference's val.process_batch (val.py:147-188) and utils.general.scale_boxes
+    (:613-626) on the seeded cases of oracle.yolo_oracle.synth_val_case / synth_predictions."""
+    import importlib
+
+    val = importlib.import_module("val")  # reference val.py (imports resolve through the shim)
+    from utils.general import scale_boxes  # type: ignore
+
+    out = {"match": {}, "scale": {}}
+    iouv = torch.linspace(0.5, 0.95, 10)  # val.py:262
+    for name, kw in VAL_MATCH_CASES.items():
+        det, lab = yo.synth_val_case(**kw)
+        if det.shape[0] == 0 or lab.shape[0] == 0:
+            # the reference never calls process_batch without labels (val.py:386-395 short-cuts) -- zeros by its own convention
+            correct = torch.zeros(det.shape[0], iouv.numel(), dtype=torch.bool)
+        else:
+            correct = val.process_batch(det.clone(), lab.clone(), iouv)
+        out["match"][name] = {"gen": kw, "in_sum": checksum(det) + checksum(lab), "correct": correct.clone()}
+        print("match", name, tuple(det.shape), tuple(lab.shape), correct.sum(0).tolist())
+    for name, (s1, s0, rp) in VAL_SCALE_CASES.items():
+        boxes = yo.synth_scale_case(s1)
+        ref = scale_boxes(s1, boxes.clone()[:, :4], s0, rp)
+        out["scale"][name] = {"img1": s1, "img0": s0, "ratio_pad": rp, "in_sum": checksum(boxes), "out": ref.clone()}
+        print("scale", name, float(ref.min()), float(ref.max()))
+    torch.save(out, OUT / "val_edge.pt")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ns = ref_shim.load()
-    gen_model_goldens(ns)
-    gen_decode_goldens(ns)
-    gen_nms_goldens(ns)
-    gen_loss_goldens(ns)
+    which = set(sys.argv[1:]) or {"model", "decode", "nms", "loss", "val_edge"}  # python make_golden.py [model decode nms loss val_edge]
+    if "model" in which:
+        gen_model_goldens(ns)
+    if "decode" in which:
+        gen_decode_goldens(ns)
+    if "nms" in which:
+        gen_nms_goldens(ns)
+    if "loss" in which:
+        gen_loss_goldens(ns)
+    if "val_edge" in which:
+        gen_val_edge_goldens(ns)
     print("golden files:", [(p.name, p.stat().st_size) for p in OUT.glob("*.pt")])

@@ -819,3 +819,92 @@ def test_model_rectangular_and_odd_batches(dev, name, h, w, bs, dtype):
     out = m(x.to(dev).to(dtype))
     assert isinstance(out, tuple) and len(out) == 1 and torch.equal(out[0], pred)
     m.model[-1].export = False
+
+
+# ------------------------------------------------------------------------------------------------ output edge after NMS
+def test_process_batch_vs_reference_golden(dev, golden_dir):
+    """y3_match_detections behind the reference signature process_batch(detections, labels, iouv): bit-exact boolean
+    matrices against the unmodified reference (val.py:147-188) on every seeded case, one image at a time and all images in
+    one batched launch (ragged counts, per-image label ranges)."""
+    from yolov3_amd import process_batch, process_batch_batched
+
+    gold = torch.load(golden_dir / "val_edge.pt")["match"]
+    iouv = torch.linspace(0.5, 0.95, 10)
+    cases = [(name, *yo.synth_val_case(**rec["gen"]), rec["correct"]) for name, rec in gold.items()]
+    for name, det, lab, want in cases:
+        got = process_batch(det.to(dev), lab.to(dev), iouv.to(dev))
+        assert got.dtype == torch.bool and got.shape == want.shape and torch.equal(got.cpu(), want), name
+    max_det = max(c[1].shape[0] for c in cases)
+    rows = torch.full((len(cases), max_det, 6), float("nan"))
+    counts, offs, labs = [], [0], []
+    for i, (_, det, lab, _) in enumerate(cases):
+        rows[i, : det.shape[0]] = det
+        counts.append(det.shape[0])
+        labs.append(lab)
+        offs.append(offs[-1] + lab.shape[0])
+    correct = process_batch_batched(rows.to(dev), torch.tensor(counts, dtype=torch.int32, device=dev), torch.cat(labs).to(dev), torch.tensor(offs, dtype=torch.int32), iouv)
+    torch.cuda.synchronize()
+    for i, (name, det, _, want) in enumerate(cases):
+        assert torch.equal(correct[i, : det.shape[0]].bool().cpu(), want), f"batched {name}"
+        assert int(correct[i, det.shape[0] :].sum()) == 0, f"batched {name}: rows beyond the count must be 0"
+
+
+def test_scale_boxes_vs_reference_golden(dev, golden_dir):
+    """y3_scale_boxes behind scale_boxes(img1_shape, boxes, img0_shape, ratio_pad): bit-exact fp32 against the reference
+    (utils/general.py:613-626) on a column view of (n, 6) rows (the call shape of val.py:397), confidences/classes untouched;
+    and the batched form over images with different native shapes in one launch."""
+    from yolov3_amd import scale_boxes, scale_boxes_batched
+
+    gold = torch.load(golden_dir / "val_edge.pt")["scale"]
+    for name, rec in gold.items():
+        rows = yo.synth_scale_case(rec["img1"]).to(dev)
+        keep = rows.clone()
+        out = scale_boxes(rec["img1"], rows[:, :4], rec["img0"], rec["ratio_pad"])
+        torch.cuda.synchronize()
+        assert torch.equal(rows[:, :4].cpu(), rec["out"]) and torch.equal(out.cpu(), rec["out"]), name
+        assert torch.equal(rows[:, 4:], keep[:, 4:]), name
+    same = [(n, r) for n, r in gold.items() if tuple(r["img1"]) == (640, 640)]
+    rows = torch.stack([yo.synth_scale_case(r["img1"]) for _, r in same]).to(dev)
+    counts = torch.tensor([400, 123, 0][: len(same)], dtype=torch.int32, device=dev)
+    before = rows.clone()
+    scale_boxes_batched((640, 640), rows, counts, [r["img0"] for _, r in same], [r["ratio_pad"] for _, r in same])
+    torch.cuda.synchronize()
+    for i, (name, r) in enumerate(same):
+        c = int(counts[i])
+        assert torch.equal(rows[i, :c, :4].cpu(), r["out"][:c]), f"batched {name}"
+        assert torch.equal(rows[i, c:], before[i, c:]) and torch.equal(rows[i, :, 4:], before[i, :, 4:]), f"batched {name}: untouched parts"
+
+
+def test_val_edge_pipeline_full_size_vs_oracle(dev):
+    """NMS (val settings) -> scale_boxes -> process_batch on a full-size batch (8 x 25200 x 85 fp16), everything batched on the
+    device, against the oracle run image by image: identical correct-matrices."""
+    from yolov3_amd import non_max_suppression_batched, process_batch_batched, scale_boxes_batched
+
+    bs = 8
+    pred = yo.synth_predictions(bs=bs, n_rows=25200, nc=80, seed=41, dtype=torch.float16)
+    shapes = [(480, 640), (640, 480), (720, 1280), (333, 500), (640, 640), (500, 375), (1080, 1920), (427, 640)]
+    iouv = torch.linspace(0.5, 0.95, 10)
+    ref = yo.non_max_suppression(pred, 0.001, 0.6, multi_label=True, max_det=300)
+    want_rows = []
+    labels, offs = [], [0]
+    g = torch.Generator().manual_seed(9)
+    for i in range(bs):
+        w = ref[i].clone()
+        yo.scale_boxes((640, 640), w[:, :4], shapes[i])
+        want_rows.append(w)
+        # ground truth = every 7th detection, jittered (IoU spread over the thresholds), so that the matrices are not all zero
+        pick = w[::7]
+        lab = torch.cat((pick[:, 5:6], pick[:, :4] * (0.9 + 0.2 * torch.rand(pick.shape[0], 4, generator=g))), 1)
+        labels.append(lab)
+        offs.append(offs[-1] + lab.shape[0])
+    rows, counts_t, counts = non_max_suppression_batched(pred.to(dev), 0.001, 0.6, multi_label=True, max_det=300)
+    scale_boxes_batched((640, 640), rows, counts_t, shapes)
+    correct = process_batch_batched(rows, counts_t, torch.cat(labels), torch.tensor(offs, dtype=torch.int32), iouv)
+    torch.cuda.synchronize()
+    hits = 0
+    for i in range(bs):
+        assert counts[i] == want_rows[i].shape[0] and torch.equal(rows[i, : counts[i]].cpu(), want_rows[i]), f"image {i}: scaled rows"
+        want = yo.process_batch(want_rows[i], labels[i], iouv) if want_rows[i].shape[0] else torch.zeros(0, 10, dtype=torch.bool)
+        assert torch.equal(correct[i, : counts[i]].bool().cpu(), want), f"image {i}: correct matrix"
+        hits += int(want.sum())
+    assert hits > 50, "the test input should produce matches"

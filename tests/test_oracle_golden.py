@@ -143,3 +143,25 @@ def test_loss_matches_reference(golden_dir, key):
     torch.testing.assert_close(items, rec["items"], rtol=1e-6, atol=1e-6)
     for a, b in zip(p, rec["grads"]):
         torch.testing.assert_close(a.grad, b, rtol=1e-5, atol=1e-8)
+
+
+# ------------------------------------------------------------------------------------------------ output edge after NMS
+def test_process_batch_matches_reference(golden_dir):
+    """oracle.process_batch (restated val.py:147-188) against the unmodified reference's output, all seeded cases."""
+    gold = torch.load(golden_dir / "val_edge.pt")["match"]
+    iouv = torch.linspace(0.5, 0.95, 10)
+    for name, rec in gold.items():
+        det, lab = yo.synth_val_case(**rec["gen"])
+        assert checksum(det) + checksum(lab) == rec["in_sum"], name
+        got = yo.process_batch(det, lab, iouv) if det.shape[0] and lab.shape[0] else torch.zeros(det.shape[0], 10, dtype=torch.bool)
+        assert torch.equal(got, rec["correct"]), name
+
+
+def test_scale_boxes_matches_reference(golden_dir):
+    """oracle.scale_boxes (restated utils/general.py:613-626 + upstream clip_boxes) bit-exact against the reference."""
+    gold = torch.load(golden_dir / "val_edge.pt")["scale"]
+    for name, rec in gold.items():
+        boxes = yo.synth_scale_case(rec["img1"])
+        assert checksum(boxes) == rec["in_sum"], name
+        got = yo.scale_boxes(rec["img1"], boxes.clone()[:, :4], rec["img0"], rec["ratio_pad"])
+        assert torch.equal(got, rec["out"]), name

@@ -1,0 +1,12 @@
+mkdir -p gpurun_out
+R=$PWD
+timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x -k "wgrad or train or sgd or conv_mfma" > gpurun_out/g_pytest.log 2>&1; echo "exit $?" >> gpurun_out/g_pytest.log
+tail -6 gpurun_out/g_pytest.log
+timeout 300 python tools/train_bench.py --batch 64 --steps 3 --fused > gpurun_out/g_train_phases.log 2>&1; tail -1 gpurun_out/g_train_phases.log
+cd /tmp && export TMPDIR=/tmp
+timeout 400 rocprofv3 --kernel-trace -d $R/gpurun_out/g_prof -o t -- python $R/tools/train_bench.py --batch 64 --steps 1 --fused > $R/gpurun_out/g_prof.log 2>&1
+cd $R
+python tools/ktrace.py gpurun_out/g_prof > gpurun_out/g_trace.txt 2>&1
+python tools/kstats.py gpurun_out/g_prof "rocprofv3 --kernel-trace: tools/train_bench.py --batch 64 --steps 1 --fused (2 steps incl. warm-up)" > gpurun_out/g_kstats.md 2>&1
+rm -rf gpurun_out/g_prof
+head -22 gpurun_out/g_kstats.md | cut -c1-150

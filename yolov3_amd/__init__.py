@@ -3,13 +3,15 @@
 Public surface mirrors the reference's own Python signatures:
     DetectionModel / Model / Detect      (reference models/yolo.py)
     Conv / Bottleneck / SPP / Concat     (reference models/common.py)
-    non_max_suppression, scale_boxes     (reference utils/general.py)
+    non_max_suppression, scale_boxes     (reference utils/general.py; + batched forms)
+    process_batch                        (reference val.py:147-188; + batched form)
     ComputeLoss                          (reference utils/loss.py)
     DetectMultiBackend (.pt branch), attempt_load   (reference models/common.py, models/experimental.py)
 Everything executes through libyolov3_hip.so (include/yolov3_hip.h); there is no CPU/PyTorch fallback.
 """
 from .common import SPP, Bottleneck, Concat, Conv  # noqa: F401
-from .general import non_max_suppression, scale_boxes, xywh2xyxy, clip_boxes  # noqa: F401
+from .general import non_max_suppression, non_max_suppression_batched, scale_boxes, scale_boxes_batched, xywh2xyxy, clip_boxes  # noqa: F401
+from .val import process_batch, process_batch_batched  # noqa: F401
 from .backend import DetectMultiBackend  # noqa: F401
 from .compat import attempt_load  # noqa: F401
 from .loss import ComputeLoss  # noqa: F401

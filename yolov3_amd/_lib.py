@@ -87,6 +87,11 @@ _SIGNATURES = {
         C.c_int,
         [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P(Y3NmsParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p],
     ),
+    "y3_scale_boxes": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "y3_match_detections": (
+        C.c_int,
+        [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p],
+    ),
     "y3_loss_workspace_bytes": (C.c_size_t, [_P(Y3LossParams), C.c_int32]),
     "y3_loss_fwd": (C.c_int, [_P(Y3LossParams), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "y3_loss_bwd": (C.c_int, [_P(Y3LossParams), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

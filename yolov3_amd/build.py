@@ -26,6 +26,7 @@ SOURCES = [
     ("stem.hip", []),
     ("layout_pool.hip", []),
     ("detect_nms.hip", ["-ffp-contract=off"]),
+    ("val_edge.hip", ["-ffp-contract=off"]),
     ("loss.hip", ["-ffp-contract=off"]),
     ("train.hip", []),
     ("optim.hip", ["-ffp-contract=off"]),

@@ -898,6 +898,7 @@ template <typename T> int dispatch_igemm(ConvArgs& a, hipStream_t st) {
         // (re-measured after the epilogue rewrite, gpurun_out/variants2.log -> profiles/r01_conv_variants.md)
         const int K = a.ntaps * a.Cin;
         if (K >= 2304 && a.Cout >= 512) return launch_v5<T, 32, 4, 2, 2, 4, 1>(a, st);   // 256c x 256p, 8 waves (64c x 128p each), staggered halves
+        if (K >= 4608 && a.Cout >= 256 && a.M >= 65536) return launch_v5<T, 32, 4, 2, 2, 4, 1>(a, st);   // data gradient of the 256 -> 512 layers (one filter tile)
         if (c64 && a.ntaps == 1 && a.Cout >= 256 && a.M > 16384 && a.M <= 65536) return launch_v5<T, 32, 4, 2, 2, 4, 1>(a, st);   // 1x1 @40x40
         if (c64 && ((a.ntaps > 1 && K >= 1152) || (a.ntaps == 1 && K >= 256 && a.M <= 16384))) return launch_v3<T, 64, 2, 2>(a, st);
         return launch_v3<T, 32, 2, 2>(a, st);

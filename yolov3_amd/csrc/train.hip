@@ -60,11 +60,11 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(const T* __restrict
 #pragma unroll
         for (int q = 0; q < V; ++q) f0[q] = f1[q] = 0.0f;
         // 4 pixels per trip with all loads issued before the arithmetic (one 16-byte load in flight per thread left the
-        // reductions at 1.5-1.8 TB/s); fp32 partials are flushed into the fp64 accumulators every 2 trips = 8 pixels
+        // reductions at 1.5-1.8 TB/s), and the NEXT trip's loads issued before this trip's arithmetic (two register sets: with
+        // 8 waves per CU the sigmoid / fp64 work of MODE 1 otherwise runs behind an idle memory pipe: 3.4 TB/s);
+        // fp32 partials are flushed into the fp64 accumulators every 2 trips = 8 pixels
         const long long stride = (long long)gridDim.x * PL;
-        int run = 0;
-        for (long long m0 = (long long)blockIdx.x * PL + pl; m0 < M; m0 += 4 * stride) {
-            V16<T> xs[4], gs[4];
+        auto fetch = [&](long long m0, V16<T> (&xs)[4], V16<T> (&gs)[4]) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const long long m = m0 + j * stride;
@@ -73,6 +73,8 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(const T* __restrict
                     if (MODE == 1) gs[j] = *(const V16<T>*)(dy + m * dpitch + cg * V);
                 }
             }
+        };
+        auto accumulate = [&](long long m0, const V16<T> (&xs)[4], const V16<T> (&gs)[4]) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (m0 + j * stride >= M) break;
@@ -95,11 +97,23 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(const T* __restrict
                     }
                 }
             }
-            if (++run == 2) {
-                run = 0;
+        };
+        auto flush = [&]() {
 #pragma unroll
-                for (int q = 0; q < V; ++q) { a0[q] += (double)f0[q]; a1[q] += (double)f1[q]; f0[q] = f1[q] = 0.0f; }
-            }
+            for (int q = 0; q < V; ++q) { a0[q] += (double)f0[q]; a1[q] += (double)f1[q]; f0[q] = f1[q] = 0.0f; }
+        };
+        V16<T> xa[4], ga[4], xb[4], gb[4];
+        long long m0 = (long long)blockIdx.x * PL + pl;
+        fetch(m0, xa, ga);
+        while (m0 < M) {
+            fetch(m0 + 4 * stride, xb, gb);
+            accumulate(m0, xa, ga);
+            m0 += 4 * stride;
+            if (m0 >= M) break;
+            fetch(m0 + 4 * stride, xa, ga);
+            accumulate(m0, xb, gb);
+            m0 += 4 * stride;
+            flush();
         }
 #pragma unroll
         for (int q = 0; q < V; ++q) { a0[q] += (double)f0[q]; a1[q] += (double)f1[q]; }
@@ -196,32 +210,20 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ u
     float sc[V], sh[V];
 #pragma unroll
     for (int q = 0; q < V; ++q) { sc[q] = scale[cg * V + q]; sh[q] = shift[cg * V + q]; }
-    // 4 pixels per trip with every load issued before the arithmetic (one load in flight per thread left this pass at 3.9 TB/s)
-    const long long stride = (long long)gridDim.x * PL;
-    for (long long m0 = (long long)blockIdx.x * PL + pl; m0 < M; m0 += 4 * stride) {
-        V16<T> xs[4], rs[4];
+    // (a 4-pixel unroll with all loads issued first measured slower here: 6.2 -> 6.9 ms per batch-64 step)
+    for (long long m = (long long)blockIdx.x * PL + pl; m < M; m += (long long)gridDim.x * PL) {
+        const V16<T> x = *(const V16<T>*)(u + m * upitch + cg * V);
+        V16<T> r;
+        if (res) r = *(const V16<T>*)(res + m * rpitch + cg * V);
+        V16<T> o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const long long m = m0 + j * stride;
-            if (m < M) {
-                xs[j] = *(const V16<T>*)(u + m * upitch + cg * V);
-                if (res) rs[j] = *(const V16<T>*)(res + m * rpitch + cg * V);
-            }
+        for (int q = 0; q < V; ++q) {
+            float z = to_f32<T>(x.v[q]) * sc[q] + sh[q];
+            if (act == Y3_ACT_SILU) z = z * sigmoid_fast(z);
+            if (res) z += to_f32<T>(r.v[q]);
+            o.v[q] = from_f32<T>(z);
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const long long m = m0 + j * stride;
-            if (m >= M) break;
-            V16<T> o;
-#pragma unroll
-            for (int q = 0; q < V; ++q) {
-                float z = to_f32<T>(xs[j].v[q]) * sc[q] + sh[q];
-                if (act == Y3_ACT_SILU) z = z * sigmoid_fast(z);
-                if (res) z += to_f32<T>(rs[j].v[q]);
-                o.v[q] = from_f32<T>(z);
-            }
-            *(V16<T>*)(y + m * ypitch + cg * V) = o;
-        }
+        *(V16<T>*)(y + m * ypitch + cg * V) = o;
     }
 }
 

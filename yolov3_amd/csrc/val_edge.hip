@@ -1,0 +1,112 @@
+// Output edge of the validation / detection loop on gfx950: what the reference does per image in
+// Python right after non_max_suppression --
+//   * scale_boxes + clip_boxes   (reference utils/general.py:613-626, upstream ultralytics.utils.ops.clip_boxes; callers val.py:397,403
+//     and detect.py:223): undo the letterbox gain / padding and clamp to the native image, and
+//   * process_batch              (reference val.py:147-188, upstream ultralytics.utils.metrics.box_iou): the (detections x IoU
+//     thresholds) "correct" matrix behind mAP --
+// for the whole batch in one launch each, reading the batched NMS output (bs, max_det, 6) + counts where it lies.
+// fp32 arithmetic in the reference's operation order (built with -ffp-contract=off; IEEE division as torch's CPU kernels).
+#include "y3_common.h"
+
+namespace {
+
+// rows[img][r][0..3] = clip((xyxy - pad) / gain); params[img] = {gain, pad_x, pad_y, w0, h0}
+__global__ __launch_bounds__(256) void scale_boxes_kernel(float* __restrict__ rows, long long img_stride, int row_stride, const int* __restrict__ counts, int bs, int max_rows,
+                                                            const float* __restrict__ params) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)bs * max_rows) return;
+    const int img = (int)(idx / max_rows), r = (int)(idx - (long long)img * max_rows);
+    if (counts && r >= counts[img]) return;
+    const float gain = params[img * 5], px = params[img * 5 + 1], py = params[img * 5 + 2], w0 = params[img * 5 + 3], h0 = params[img * 5 + 4];
+    float* b = rows + img * img_stride + (long long)r * row_stride;
+    // boxes[..., [0, 2]] -= pad[0]; boxes[..., [1, 3]] -= pad[1]; boxes[..., :4] /= gain; clamp_(0, w0 | h0)
+    const float x1 = (b[0] - px) / gain, y1 = (b[1] - py) / gain, x2 = (b[2] - px) / gain, y2 = (b[3] - py) / gain;
+    b[0] = fminf(fmaxf(x1, 0.0f), w0);
+    b[1] = fminf(fmaxf(y1, 0.0f), h0);
+    b[2] = fminf(fmaxf(x2, 0.0f), w0);
+    b[3] = fminf(fmaxf(y2, 0.0f), h0);
+}
+
+// upstream box_iou(labels, detections)[l][d]: inter / (area_l + area_d - inter + eps), eps = 1e-7
+Y3_DEV float pair_iou(const float* lb, const float* dt) {
+    const float iw = fmaxf(fminf(lb[2], dt[2]) - fmaxf(lb[0], dt[0]), 0.0f);
+    const float ih = fmaxf(fminf(lb[3], dt[3]) - fmaxf(lb[1], dt[1]), 0.0f);
+    const float inter = iw * ih;
+    const float a1 = (lb[2] - lb[0]) * (lb[3] - lb[1]), a2 = (dt[2] - dt[0]) * (dt[3] - dt[1]);
+    return inter / (a1 + a2 - inter + 1e-7f);
+}
+
+// One block per image.  The reference, per threshold t: pairs (label, detection) with IoU >= t and equal class, sorted by IoU
+// descending; every detection keeps its best label (first np.unique), then every label keeps the LOWEST-INDEX detection among
+// those (second np.unique on the detection-ordered list; the re-sort by IoU in between is commented out, val.py:185).
+// A detection's best label does not depend on t (it is the class-matched label of maximal IoU, valid while that IoU >= t), so:
+//   correct[d][t] = biou[d] >= t  and no d' < d with the same best label has biou[d'] >= t.
+// Exact IoU ties between two labels of one detection resolve to the larger label index (numpy's reversed argsort for <= 16
+// candidate pairs; undefined in the reference beyond that).
+constexpr int MATCH_CAP = 4096;
+__global__ __launch_bounds__(256) void match_detections_kernel(const float* __restrict__ dets, long long img_stride, int row_stride, const int* __restrict__ counts, int max_det,
+                                                                 const float* __restrict__ labels, const int* __restrict__ offs, const float* __restrict__ iouv, int niou,
+                                                                 unsigned char* __restrict__ correct) {
+    __shared__ int bl[MATCH_CAP];
+    __shared__ float biou[MATCH_CAP];
+    const int img = blockIdx.x;
+    int n = counts ? counts[img] : max_det;
+    if (n > max_det) n = max_det;
+    const int l0 = offs[img], l1 = offs[img + 1];
+    const float* D = dets + img * img_stride;
+    for (int d = threadIdx.x; d < n; d += 256) {
+        const float* dt = D + (long long)d * row_stride;
+        const float cls = dt[5];
+        int best = -1;
+        float bv = -1.0f;
+        for (int l = l0; l < l1; ++l) {
+            const float* lb = labels + (long long)l * 5;
+            if (lb[0] != cls) continue;
+            const float v = pair_iou(lb + 1, dt);
+            if (v >= bv) { bv = v; best = l; }
+        }
+        bl[d] = best;
+        biou[d] = bv;
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < max_det; d += 256) {
+        unsigned char* out = correct + ((long long)img * max_det + d) * niou;
+        if (d >= n || bl[d] < 0) {
+            for (int t = 0; t < niou; ++t) out[t] = 0;
+            continue;
+        }
+        const int b = bl[d];
+        const float v = biou[d];
+        float earlier = -1.0f;   // best IoU among lower-index detections that chose the same label
+        for (int e = 0; e < d; ++e)
+            if (bl[e] == b) earlier = fmaxf(earlier, biou[e]);
+        for (int t = 0; t < niou; ++t) {
+            const float thr = iouv[t];
+            out[t] = (unsigned char)((v >= thr) && !(earlier >= thr));
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int y3_scale_boxes(float* rows, int64_t img_stride, int32_t row_stride, const int32_t* counts, int32_t bs, int32_t max_rows, const float* params, void* stream) {
+    if (!rows || !params) Y3_FAIL("y3_scale_boxes: null argument");
+    if (bs < 0 || max_rows < 0 || row_stride < 4) Y3_FAIL("y3_scale_boxes: bad geometry (bs %d, rows %d, row stride %d)", bs, max_rows, row_stride);
+    const long long total = (long long)bs * max_rows;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(scale_boxes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows, (long long)img_stride, row_stride, counts, bs, max_rows, params);
+    Y3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int y3_match_detections(const float* dets, int64_t img_stride, int32_t row_stride, const int32_t* counts, int32_t bs, int32_t max_det, const float* labels,
+                                   const int32_t* label_offsets, const float* iouv, int32_t niou, uint8_t* correct, void* stream) {
+    if (!dets || !label_offsets || !iouv || !correct) Y3_FAIL("y3_match_detections: null argument");
+    if (bs < 0 || niou < 1 || row_stride < 6) Y3_FAIL("y3_match_detections: bad geometry (bs %d, niou %d, row stride %d)", bs, niou, row_stride);
+    if (max_det < 0 || max_det > MATCH_CAP) Y3_FAIL("y3_match_detections: max_det %d unsupported (max %d)", max_det, MATCH_CAP);
+    if (bs == 0 || max_det == 0) return 0;
+    hipLaunchKernelGGL(match_detections_kernel, dim3((unsigned)bs), dim3(256), 0, (hipStream_t)stream, dets, (long long)img_stride, row_stride, counts, max_det, labels, label_offsets, iouv,
+                       niou, correct);
+    Y3_CHECK_LAUNCH();
+    return 0;
+}

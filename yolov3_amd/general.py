@@ -27,19 +27,62 @@ def clip_boxes(boxes, shape):
     return boxes
 
 
-def scale_boxes(img1_shape, boxes, img0_shape, ratio_pad=None):
-    """Undo letterbox scaling/padding (reference utils/general.py:613-626)."""
+def _gain_pad(img1_shape, img0_shape, ratio_pad):
+    """(gain, pad_x, pad_y) exactly as reference utils/general.py:615-620 computes them (Python floats)."""
     if ratio_pad is None:
         gain = min(img1_shape[0] / img0_shape[0], img1_shape[1] / img0_shape[1])
         pad = (img1_shape[1] - img0_shape[1] * gain) / 2, (img1_shape[0] - img0_shape[0] * gain) / 2
     else:
         gain = ratio_pad[0][0]
         pad = ratio_pad[1]
-    boxes[..., [0, 2]] -= pad[0]
-    boxes[..., [1, 3]] -= pad[1]
+    return float(gain), float(pad[0]), float(pad[1])
+
+
+def scale_boxes(img1_shape, boxes, img0_shape, ratio_pad=None):
+    """Undo letterbox scaling/padding and clip, in place (reference utils/general.py:613-626).  fp32 boxes on the MI355X
+    (an (n, 4+) tensor or a column view such as ``predn[:, :4]``) go through y3_scale_boxes; anything else (CPU label
+    tensors, half boxes) keeps the reference's tensor arithmetic."""
+    if isinstance(boxes, torch.Tensor) and boxes.is_cuda and boxes.dtype == torch.float32 and boxes.dim() == 2 and boxes.shape[1] >= 4 and boxes.stride(1) == 1:
+        if boxes.shape[0]:
+            gain, px, py = _gain_pad(img1_shape, img0_shape, ratio_pad)
+            params = torch.tensor([gain, px, py, float(img0_shape[1]), float(img0_shape[0])], dtype=torch.float32, device=boxes.device)
+            ops.scale_boxes_raw(boxes, boxes.shape[0] * boxes.stride(0), boxes.stride(0), None, 1, boxes.shape[0], params)
+        return boxes
+    gain, px, py = _gain_pad(img1_shape, img0_shape, ratio_pad)
+    boxes[..., [0, 2]] -= px
+    boxes[..., [1, 3]] -= py
     boxes[..., :4] /= gain
     clip_boxes(boxes, img0_shape)
     return boxes
+
+
+def scale_boxes_batched(img1_shape, rows, counts, img0_shapes, ratio_pads=None):
+    """scale_boxes for a whole batch in ONE launch: ``rows`` is the (bs, max_det, 6) fp32 tensor and ``counts`` the device
+    int32 counts of `non_max_suppression_batched` (or None); ``img0_shapes[i]`` / ``ratio_pads[i]`` are the per-image arguments the
+    reference passes at val.py:397 / detect.py:223.  In place; returns ``rows``."""
+    ops.require_gpu(rows, "scale_boxes_batched")
+    if rows.dtype != torch.float32 or rows.dim() != 3 or not rows.is_contiguous():
+        raise TypeError("scale_boxes_batched expects the contiguous (bs, max_det, 6) fp32 NMS output")
+    bs = rows.shape[0]
+    tab = []
+    for i in range(bs):
+        gain, px, py = _gain_pad(img1_shape, img0_shapes[i], None if ratio_pads is None else ratio_pads[i])
+        tab.append([gain, px, py, float(img0_shapes[i][1]), float(img0_shapes[i][0])])
+    params = torch.tensor(tab, dtype=torch.float32).to(rows.device, non_blocking=True)
+    ops.scale_boxes_raw(rows, rows.stride(0), rows.stride(1), counts, bs, rows.shape[1], params)
+    return rows
+
+
+def non_max_suppression_batched(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, max_det=300):
+    """`non_max_suppression` without the Python list: returns (rows (bs, max_det, 6) fp32, counts device int32 (bs), counts list)
+    so that scale_boxes_batched / process_batch_batched can consume the result where it lies."""
+    assert 0 <= conf_thres <= 1, f"Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0"
+    assert 0 <= iou_thres <= 1, f"Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0"
+    if isinstance(prediction, (list, tuple)):
+        prediction = prediction[0]
+    ops.require_gpu(prediction, "non_max_suppression")
+    rows, counts = ops.nms_raw(prediction, conf_thres, iou_thres, classes, agnostic, multi_label, max_det)
+    return rows, torch.tensor(counts, dtype=torch.int32).to(rows.device, non_blocking=True), counts
 
 
 def non_max_suppression(

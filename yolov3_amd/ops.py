@@ -237,3 +237,19 @@ def nms_raw(pred: torch.Tensor, conf_thres: float, iou_thres: float, classes, ag
             return rows, m[:bs]
         capacity = max(m[bs + 1], 1)  # overflow: rerun with room for every candidate
     raise _lib.Y3Error("y3_nms: candidate capacity overflow persisted")
+
+
+def scale_boxes_raw(rows: torch.Tensor, img_stride: int, row_stride: int, counts: torch.Tensor | None, bs: int, max_rows: int, params: torch.Tensor):
+    require_gpu(rows, "scale_boxes")
+    check(_lib.lib().y3_scale_boxes(rows.data_ptr(), int(img_stride), int(row_stride), counts.data_ptr() if counts is not None else None, int(bs), int(max_rows),
+                                    params.data_ptr(), stream_ptr()), "y3_scale_boxes")
+
+
+def match_detections_raw(dets: torch.Tensor, img_stride: int, row_stride: int, counts: torch.Tensor | None, bs: int, max_det: int, labels: torch.Tensor,
+                         offsets: torch.Tensor, iouv: torch.Tensor) -> torch.Tensor:
+    require_gpu(dets, "process_batch")
+    correct = torch.empty(bs, max_det, iouv.numel(), dtype=torch.uint8, device=dets.device)
+    check(_lib.lib().y3_match_detections(dets.data_ptr(), int(img_stride), int(row_stride), counts.data_ptr() if counts is not None else None, int(bs), int(max_det),
+                                         labels.data_ptr() if labels.numel() else None, offsets.data_ptr(), iouv.data_ptr(), int(iouv.numel()), correct.data_ptr(), stream_ptr()),
+          "y3_match_detections")
+    return correct

@@ -92,18 +92,23 @@ class ConvUnit(_Unit):
         dev, dt = plan.device, plan.dtype
         self.u = View.alloc(v.n, v.h, v.w, self.cout, dt, dev)
         C_ = self.cout
-        self.sums = ops.bn_scratch(C_, dev)
+        self.sums = plan.bn_sums(C_)   # shared by every unit of the plan: each pass consumes its sums before the next launch is queued (one stream)
         self.scale, self.shift, self.mean, self.invstd = (torch.empty(C_, dtype=torch.float32, device=dev) for _ in range(4))
         self.zero_bias = torch.zeros(C_, dtype=torch.float32, device=dev)
         self.act = _lib.Y3_ACT_SILU if isinstance(m.act, nn.SiLU) else _lib.Y3_ACT_NONE
         self.count = v.n * v.h * v.w
+        self.use_stem = False
 
     def fwd(self):
         m, bn = self.m, self.m.bn
         L = _lib.lib()
         st = ops.stream_ptr()
-        filt = ops.pack_filter(m.conv.weight, self.cout, self.cin, self.plan.dtype)
-        ops.conv2d(self.x.view, filt, self.zero_bias, self.u, self.k, self.s, act=False)
+        if self.use_stem and self.plan.x_nchw is not None:
+            # layer 0 straight from the caller's NCHW image (csrc/stem.hip); the NHWC copy is still made for the filter gradient
+            ops.stem_conv(self.plan.x_nchw, ops.pack_filter_stem(m.conv.weight, self.cout, self.plan.dtype), self.zero_bias, self.u, act=False)
+        else:
+            filt = ops.pack_filter(m.conv.weight, self.cout, self.cin, self.plan.dtype)
+            ops.conv2d(self.x.view, filt, self.zero_bias, self.u, self.k, self.s, act=False)
         ut = self.u.y3()
         dcode = ops.dtype_code(self.plan.dtype)
         if self.cout != self.co_real:
@@ -138,8 +143,8 @@ class ConvUnit(_Unit):
         )
         dw, _ = ops.conv2d_wgrad(self.x.view, du, self.k, self.s, self.co_real, self.ci_real)
         grads[m.conv.weight] = dw
-        grads[m.bn.weight] = dgamma[: self.co_real]
-        grads[m.bn.bias] = dbeta[: self.co_real]
+        grads[m.bn.weight] = dgamma   # cout == co_real (checked in fwd): whole tensors, so autograd takes them without a copy
+        grads[m.bn.bias] = dbeta
         if self.need_dx:
             gx = self.x.grad()
             if self.s == 2 and self.k == 3 and self.plan.dtype != torch.float32:
@@ -273,6 +278,7 @@ class TrainPlan:
         for i, m in enumerate(layers):
             if not isinstance(kind(m), Detect):
                 ch[i] = out_ch(i, m)
+        self._max_c = max(_pad8(mod.out_channels) for mod in model.modules() if isinstance(mod, nn.Conv2d))
 
         def new_act(i_hw, c):
             a = Act(View.alloc(n, i_hw[0], i_hw[1], c, dtype, device))
@@ -348,9 +354,25 @@ class TrainPlan:
             else:
                 raise NotImplementedError(type(k).__name__)
         self.params = list(model.parameters())
+        self.x_nchw = None
+        import os
+
+        u0 = self.units[0] if self.units else None
+        if (isinstance(u0, ConvUnit) and u0.x is self.x_in and u0.k == 3 and u0.s == 1 and u0.ci_real <= 4 and u0.cout <= 64 and u0.cout % 8 == 0
+                and dtype in (torch.float16, torch.bfloat16) and os.environ.get("Y3_STEM", "1") != "0"):
+            u0.use_stem = True
         self._bn_counters = [u.m.bn.num_batches_tracked for u in self.units if isinstance(u, ConvUnit) and u.m.bn.num_batches_tracked is not None]
 
     # -- helpers ---------------------------------------------------------------------------------
+    def bn_sums(self, c):
+        """fp64 scratch of the BatchNorm reductions (totals + per-block partial rows), one buffer for the whole plan."""
+        t = getattr(self, "_bn_sums", None)
+        if t is None or t.numel() < (1 + ops.BN_PARTIAL_ROWS) * 2 * c:
+            if t is not None:
+                raise RuntimeError("bn_sums must be sized by the widest layer first")
+            t = self._bn_sums = ops.bn_scratch(self._max_c, self.device)
+        return t
+
     def zeros_f32(self, c):
         t = self._zeros.get(c)
         if t is None:
@@ -380,6 +402,7 @@ class TrainPlan:
     # -- execution -------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor):
         ops.nchw_to_nhwc(x, self.x_in.view, 1.0)
+        self.x_nchw = x if x.dtype in (torch.float32, torch.float16, torch.bfloat16, torch.uint8) else None
         with torch.no_grad():
             for u in self.units:
                 u.fwd()
