@@ -141,6 +141,12 @@ int y3_nms(const void* pred, int32_t dtype, int32_t bs, int32_t n_rows, int32_t 
  * ([x1,y1,x2,y2,conf,cls], row_stride >= 6), labels DEVICE (nl, 5) fp32 [cls,x1,y1,x2,y2] grouped by image through
  * label_offsets (DEVICE, bs+1 int32), iouv DEVICE (niou) fp32; correct: DEVICE (bs, max_det, niou) bytes (0/1), rows beyond
  * counts[i] are 0.  max_det <= 4096. */
+/* Input edge: reference utils/augmentations.py:104-134 letterbox(auto=False) -- cv2.resize(INTER_LINEAR) to (new_h, new_w),
+ * cv2.copyMakeBorder(color) to (H1, W1) -- fused with the HWC -> CHW transpose of models/common.py:867, one image per call.
+ * src: DEVICE (h0, w0, cs) uint8, cs >= 3 interleaved channels (the first 3 are used); dst_batch: DEVICE (n, 3, H1, W1) uint8,
+ * image `index` is written.  new_h/new_w/top/left are computed by the caller exactly as the reference does (Python round()). */
+int y3_letterbox_u8(const uint8_t* src, int32_t h0, int32_t w0, int32_t cs, uint8_t* dst_batch, int32_t index, int32_t H1,
+                    int32_t W1, int32_t new_h, int32_t new_w, int32_t top, int32_t left, int32_t color, void* stream);
 int y3_scale_boxes(float* rows, int64_t img_stride, int32_t row_stride, const int32_t* counts, int32_t bs, int32_t max_rows,
                    const float* params, void* stream);
 int y3_match_detections(const float* dets, int64_t img_stride, int32_t row_stride, const int32_t* counts, int32_t bs,

@@ -584,3 +584,76 @@ def synth_scale_case(img1_shape, seed=12, n=400):
     matters), from synth_predictions: the scale_boxes test input."""
     pred = synth_predictions(bs=1, n_rows=n, nc=3, img=img1_shape[1], seed=seed)[0]
     return torch.cat((pred[:, 0:2] - pred[:, 2:4] / 2, pred[:, 0:2] + pred[:, 2:4] / 2, pred[:, 4:6]), 1).contiguous()
+
+
+# =========================================================================== input edge (letterbox)
+def resize_linear_u8(im, new_w, new_h):
+    """cv2.resize(im, (new_w, new_h), interpolation=cv2.INTER_LINEAR) for uint8 HWC images, restated from OpenCV's
+    resize.cpp (8-bit fixed-point path: HResizeLinear + VResizeLinear<uchar,int,short>).  cv2 itself is absent in this
+    image (un-vendored dependency, `opencv-python>=4.1.1` in the reference's requirements.txt): PARITY UNPINNED.
+    Anchor: reference utils/augmentations.py:130."""
+    import numpy as np
+
+    h0, w0 = im.shape[:2]
+    sx_scale, sy_scale = 1.0 / (new_w / w0), 1.0 / (new_h / h0)
+
+    def coefs(n, scale, size, clamp_frac):
+        f = ((np.arange(n, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = f - s.astype(np.float32)
+        if clamp_frac:
+            lo, hi = s < 0, s >= size - 1
+            f = np.where(lo | hi, np.float32(0), f)
+            s = np.where(lo, 0, np.where(hi, size - 1, s))
+        c0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64)
+        c1 = np.rint(f * np.float32(2048)).astype(np.int64)
+        return s, c0, c1
+
+    sx, a0, a1 = coefs(new_w, sx_scale, w0, True)
+    sy, b0, b1 = coefs(new_h, sy_scale, h0, False)
+    sx1 = np.minimum(sx + 1, w0 - 1)
+    r0, r1 = np.clip(sy, 0, h0 - 1), np.clip(sy + 1, 0, h0 - 1)
+    src = im.astype(np.int64)
+    hor = src[:, sx] * a0[None, :, None] + src[:, sx1] * a1[None, :, None]          # (h0, new_w, c) int
+    out = (((b0[:, None, None] * (hor[r0] >> 4)) >> 16) + ((b1[:, None, None] * (hor[r1] >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def letterbox(im, new_shape=(640, 640), color=(114, 114, 114), auto=False, scaleup=True, stride=32):
+    """Restates reference utils/augmentations.py:104-134 (cv2.resize / cv2.copyMakeBorder restated, see above)."""
+    import numpy as np
+
+    shape = im.shape[:2]
+    if isinstance(new_shape, int):
+        new_shape = (new_shape, new_shape)
+    r = min(new_shape[0] / shape[0], new_shape[1] / shape[1])
+    if not scaleup:
+        r = min(r, 1.0)
+    ratio = r, r
+    new_unpad = round(shape[1] * r), round(shape[0] * r)
+    dw, dh = new_shape[1] - new_unpad[0], new_shape[0] - new_unpad[1]
+    if auto:
+        dw, dh = np.mod(dw, stride), np.mod(dh, stride)
+    dw /= 2
+    dh /= 2
+    if shape[::-1] != new_unpad:
+        im = resize_linear_u8(im, new_unpad[0], new_unpad[1])
+    top, bottom = round(dh - 0.1), round(dh + 0.1)
+    left, right = round(dw - 0.1), round(dw + 0.1)
+    out = np.empty((im.shape[0] + top + bottom, im.shape[1] + left + right, im.shape[2]), dtype=np.uint8)
+    out[...] = np.asarray(color, dtype=np.uint8)
+    out[top : top + im.shape[0], left : left + im.shape[1]] = im
+    return out, ratio, (dw, dh)
+
+
+def synth_image_u8(h, w, seed=0):
+    """Smooth-ish uint8 RGB test image (h, w, 3): sums of coarse random blocks at three scales + fine noise, integer math only."""
+    import numpy as np
+
+    g = torch.Generator().manual_seed(seed)
+    acc = torch.zeros(h, w, 3)
+    for cell, amp in ((64, 110), (16, 80), (4, 40), (1, 25)):
+        gh, gw = (h + cell - 1) // cell, (w + cell - 1) // cell
+        blk = torch.randint(0, amp + 1, (gh, gw, 3), generator=g).float()
+        acc += blk.repeat_interleave(cell, 0).repeat_interleave(cell, 1)[:h, :w]
+    return acc.clamp(0, 255).to(torch.uint8).numpy()

@@ -908,3 +908,68 @@ def test_val_edge_pipeline_full_size_vs_oracle(dev):
         assert torch.equal(correct[i, : counts[i]].bool().cpu(), want), f"image {i}: correct matrix"
         hits += int(want.sum())
     assert hits > 50, "the test input should produce matches"
+
+
+# ------------------------------------------------------------------------------------------------ input edge: letterbox / AutoShape
+LETTERBOX_CASES = [
+    ("pad_only", (480, 640), (640, 640)),        # r = 1: no resize, 80-row borders
+    ("downscale_hd", (720, 1280), (640, 640)),
+    ("upscale_odd", (333, 500), (640, 640)),
+    ("portrait_rect", (1080, 810), (640, 480)),
+    ("tiny_x12", (37, 53), (448, 640)),
+    ("half_pixel_pad", (375, 500), (512, 672)),  # odd padding: top/bottom and left/right differ by one (round(d -/+ 0.1))
+]
+
+
+@pytest.mark.parametrize("name,shape0,shape1", LETTERBOX_CASES, ids=[c[0] for c in LETTERBOX_CASES])
+def test_letterbox_u8_vs_oracle(dev, name, shape0, shape1):
+    """y3_letterbox_u8 (cv2.resize INTER_LINEAR + copyMakeBorder(114) + HWC->CHW in one pass) bit-exact against the oracle's
+    restatement of reference utils/augmentations.py:104-134 (cv2's 8-bit fixed-point resize restated; cv2 parity unpinned)."""
+    from yolov3_amd import letterbox_batch
+
+    im = yo.synth_image_u8(shape0[0], shape0[1], seed=3)
+    want, _, _ = yo.letterbox(im, shape1, auto=False)
+    assert want.shape[:2] == tuple(shape1)
+    got = letterbox_batch([im, im[:, ::-1].copy()], shape1, dev)
+    torch.cuda.synchronize()
+    assert got.dtype == torch.uint8 and tuple(got.shape) == (2, 3, *shape1)
+    assert torch.equal(got[0].cpu(), torch.from_numpy(want).permute(2, 0, 1)), name
+    want2, _, _ = yo.letterbox(im[:, ::-1].copy(), shape1, auto=False)
+    assert torch.equal(got[1].cpu(), torch.from_numpy(want2).permute(2, 0, 1)), name + " (second image of the batch)"
+
+
+def test_autoshape_numpy_images_vs_oracle_pipeline(dev):
+    """AutoShape on raw numpy images of different sizes (reference models/common.py:819-874): device letterbox == oracle
+    letterbox (bit-exact), uint8 ingest with the /255 inside the first kernel == oracle forward on x/255 (fp32, 1e-4 on
+    logits-derived boxes), and the returned per-image detections == oracle NMS + oracle scale_boxes on the same predictions
+    (row-exact)."""
+    import numpy as np
+
+    from yolov3_amd import AutoShape, letterbox_batch
+
+    m, (layers, save, sd, strides) = build_pair("yolov3-tiny", 80, 23, dev, torch.float32)
+    ims = [yo.synth_image_u8(240, 320, seed=1), yo.synth_image_u8(300, 200, seed=2), yo.synth_image_u8(96, 128, seed=3)]
+    size = 320
+    a = AutoShape(m)
+    a.conf, a.iou, a.multi_label, a.max_det = 0.0, 0.45, False, 300   # conf 0: a random-weight model's objectness is ~0.003 everywhere
+    det = a([im.copy() for im in ims], size=size)
+    torch.cuda.synchronize()
+    # the reference's shape logic (models/common.py:861-865)
+    shape1 = [[int(y * size / max(im.shape[:2])) for y in im.shape[:2]] for im in ims]
+    shape1 = [int(np.ceil(v / 32) * 32) for v in np.array(shape1).max(0)]
+    assert det.s == (3, 3, *shape1) and det.n == 3
+    x_ref = np.stack([yo.letterbox(im, shape1, auto=False)[0] for im in ims]).transpose(0, 3, 1, 2)
+    x_dev = letterbox_batch(ims, shape1, dev)
+    assert torch.equal(x_dev.cpu(), torch.from_numpy(np.ascontiguousarray(x_ref)))
+    m.model[-1].export = False
+    pred, _ = m(x_dev)   # uint8 in: divided by 255 inside the ingest
+    with torch.no_grad():
+        pred_ref, _ = yo.forward(layers, save, sd, torch.from_numpy(np.ascontiguousarray(x_ref)).float() / 255, strides, training=False)
+    err = (pred.cpu() - pred_ref).abs().max().item() / pred_ref.abs().max().item()
+    assert err < 1e-4, f"uint8-ingest forward differs from the oracle by {err:.2e} (relative to max)"
+    ref = yo.non_max_suppression(pred.cpu(), 0.0, 0.45, multi_label=False, max_det=300)
+    for i, r in enumerate(ref):
+        yo.scale_boxes(shape1, r[:, :4], ims[i].shape[:2])
+        assert det.pred[i].shape == r.shape and torch.equal(det.pred[i].cpu(), r), f"image {i}: detections differ from oracle NMS + scale_boxes"
+    assert sum(p.shape[0] for p in det.pred) > 0
+    assert torch.allclose(det.xywhn[0][:, :4].cpu(), (torch.cat(((ref[0][:, :2] + ref[0][:, 2:4]) / 2, ref[0][:, 2:4] - ref[0][:, :2]), 1) / torch.tensor([320.0, 240.0, 320.0, 240.0])), atol=1e-6)

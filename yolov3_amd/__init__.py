@@ -6,13 +6,14 @@ Public surface mirrors the reference's own Python signatures:
     non_max_suppression, scale_boxes     (reference utils/general.py; + batched forms)
     process_batch                        (reference val.py:147-188; + batched form)
     ComputeLoss                          (reference utils/loss.py)
-    DetectMultiBackend (.pt branch), attempt_load   (reference models/common.py, models/experimental.py)
+    DetectMultiBackend (.pt branch), attempt_load, AutoShape   (reference models/common.py, models/experimental.py)
 Everything executes through libyolov3_hip.so (include/yolov3_hip.h); there is no CPU/PyTorch fallback.
 """
 from .common import SPP, Bottleneck, Concat, Conv  # noqa: F401
 from .general import non_max_suppression, non_max_suppression_batched, scale_boxes, scale_boxes_batched, xywh2xyxy, clip_boxes  # noqa: F401
 from .val import process_batch, process_batch_batched  # noqa: F401
 from .backend import DetectMultiBackend  # noqa: F401
+from .autoshape import AutoShape, Detections, letterbox_batch  # noqa: F401
 from .compat import attempt_load  # noqa: F401
 from .loss import ComputeLoss  # noqa: F401
 from .yolo import Detect, DetectionModel, Model, parse_model  # noqa: F401

@@ -87,6 +87,10 @@ _SIGNATURES = {
         C.c_int,
         [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P(Y3NmsParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p],
     ),
+    "y3_letterbox_u8": (
+        C.c_int,
+        [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
+    ),
     "y3_scale_boxes": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "y3_match_detections": (
         C.c_int,

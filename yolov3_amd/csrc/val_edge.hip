@@ -1,5 +1,5 @@
-// Output edge of the validation / detection loop on gfx950: what the reference does per image in
-// Python right after non_max_suppression --
+// Input and output edges of the validation / detection loop on gfx950.  Input: letterbox (below).
+// Output: what the reference does per image in Python right after non_max_suppression --
 //   * scale_boxes + clip_boxes   (reference utils/general.py:613-626, upstream ultralytics.utils.ops.clip_boxes; callers val.py:397,403
 //     and detect.py:223): undo the letterbox gain / padding and clamp to the native image, and
 //   * process_batch              (reference val.py:147-188, upstream ultralytics.utils.metrics.box_iou): the (detections x IoU
@@ -34,6 +34,55 @@ Y3_DEV float pair_iou(const float* lb, const float* dt) {
     const float inter = iw * ih;
     const float a1 = (lb[2] - lb[0]) * (lb[3] - lb[1]), a2 = (dt[2] - dt[0]) * (dt[3] - dt[1]);
     return inter / (a1 + a2 - inter + 1e-7f);
+}
+
+// ---- input edge: letterbox ---------------------------------------------------------------------------------------------
+// reference utils/augmentations.py:104-134 with auto=False (the call of models/common.py:866): cv2.resize(INTER_LINEAR) to
+// new_unpad, cv2.copyMakeBorder(constant 114) to (H1, W1), then the BHWC -> BCHW transpose of :867 -- one pass, one thread per
+// output pixel.  cv2 is an un-vendored dependency (absent here: "parity unpinned"): the 8-bit INTER_LINEAR path is restated
+// from OpenCV's resize.cpp (HResizeLinear / VResizeLinear<uchar, int, short>): source coordinate f = (d + 0.5) * scale - 0.5
+// in double, cast to float; coefficients saturate_cast<short>(w * 2048) (round half to even); horizontal taps in int32, vertical
+// blend ((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2; columns left of 0 / right of w0 - 1 take the border pixel
+// with weight 2048, rows are clamped with their fractional weights kept.
+struct LetterboxArgs {
+    const unsigned char* src;
+    unsigned char* dst;      // image `index` of the (n, 3, H1, W1) batch
+    int h0, w0, cs, H1, W1, nh, nw, top, left, color;
+    double scale_x, scale_y; // 1 / (nw / w0), 1 / (nh / h0) as cv2 computes them
+};
+Y3_DEV void lb_coef(int d, double scale, int size, bool clamp_frac, int& s, int& c0, int& c1) {
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    s = (int)floorf(f);
+    f -= (float)s;
+    if (clamp_frac) {   // x axis: outside columns read one pixel with full weight
+        if (s < 0) { f = 0.0f; s = 0; }
+        if (s >= size - 1) { f = 0.0f; s = size - 1; }
+    }
+    c0 = (int)(short)__float2int_rn((1.0f - f) * 2048.0f);
+    c1 = (int)(short)__float2int_rn(f * 2048.0f);
+}
+__global__ __launch_bounds__(256) void letterbox_u8_kernel(const LetterboxArgs p) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= p.W1 || y >= p.H1) return;
+    const long long plane = (long long)p.H1 * p.W1, o = (long long)y * p.W1 + x;
+    const int dx = x - p.left, dy = y - p.top;
+    if (dx < 0 || dx >= p.nw || dy < 0 || dy >= p.nh) {
+        for (int c = 0; c < 3; ++c) p.dst[c * plane + o] = (unsigned char)p.color;
+        return;
+    }
+    int sx, a0, a1, sy, b0, b1;
+    lb_coef(dx, p.scale_x, p.w0, true, sx, a0, a1);
+    lb_coef(dy, p.scale_y, p.h0, false, sy, b0, b1);
+    const int sx1 = sx + 1 < p.w0 ? sx + 1 : sx;   // weight 0 whenever it would fall outside
+    const int r0 = sy < 0 ? 0 : (sy > p.h0 - 1 ? p.h0 - 1 : sy), r1 = sy + 1 < 0 ? 0 : (sy + 1 > p.h0 - 1 ? p.h0 - 1 : sy + 1);
+    const unsigned char* q0 = p.src + ((long long)r0 * p.w0) * p.cs;
+    const unsigned char* q1 = p.src + ((long long)r1 * p.w0) * p.cs;
+    for (int c = 0; c < 3; ++c) {
+        const int h0v = (int)q0[sx * p.cs + c] * a0 + (int)q0[sx1 * p.cs + c] * a1;
+        const int h1v = (int)q1[sx * p.cs + c] * a0 + (int)q1[sx1 * p.cs + c] * a1;
+        const int v = (((b0 * (h0v >> 4)) >> 16) + ((b1 * (h1v >> 4)) >> 16) + 2) >> 2;
+        p.dst[c * plane + o] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
 }
 
 // One block per image.  The reference, per threshold t: pairs (label, detection) with IoU >= t and equal class, sorted by IoU
@@ -107,6 +156,22 @@ extern "C" int y3_match_detections(const float* dets, int64_t img_stride, int32_
     if (bs == 0 || max_det == 0) return 0;
     hipLaunchKernelGGL(match_detections_kernel, dim3((unsigned)bs), dim3(256), 0, (hipStream_t)stream, dets, (long long)img_stride, row_stride, counts, max_det, labels, label_offsets, iouv,
                        niou, correct);
+    Y3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int y3_letterbox_u8(const uint8_t* src, int32_t h0, int32_t w0, int32_t cs, uint8_t* dst_batch, int32_t index, int32_t H1, int32_t W1, int32_t new_h, int32_t new_w,
+                               int32_t top, int32_t left, int32_t color, void* stream) {
+    if (!src || !dst_batch) Y3_FAIL("y3_letterbox_u8: null argument");
+    if (h0 < 1 || w0 < 1 || cs < 3 || H1 < 1 || W1 < 1 || new_h < 1 || new_w < 1 || index < 0) Y3_FAIL("y3_letterbox_u8: bad geometry");
+    if (top < 0 || left < 0 || top + new_h > H1 || left + new_w > W1) Y3_FAIL("y3_letterbox_u8: the resized image (%dx%d at %d,%d) does not fit %dx%d", new_w, new_h, left, top, W1, H1);
+    LetterboxArgs a;
+    a.src = src;
+    a.dst = dst_batch + (size_t)index * 3 * H1 * W1;
+    a.h0 = h0; a.w0 = w0; a.cs = cs; a.H1 = H1; a.W1 = W1; a.nh = new_h; a.nw = new_w; a.top = top; a.left = left; a.color = color;
+    a.scale_x = 1.0 / ((double)new_w / (double)w0);
+    a.scale_y = 1.0 / ((double)new_h / (double)h0);
+    hipLaunchKernelGGL(letterbox_u8_kernel, dim3((unsigned)((W1 + 63) / 64), (unsigned)((H1 + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
     Y3_CHECK_LAUNCH();
     return 0;
 }

@@ -249,12 +249,12 @@ class Plan:
             elif kind == "stem":
                 w, yv = kw["w"], kw["y"].real()
                 yt = yv.y3()
-                self.stem_x, self.stem_sdt = C.c_void_p(0), C.c_int32(0)
+                self.stem_x, self.stem_sdt, self.stem_div = C.c_void_p(0), C.c_int32(0), C.c_float(1.0)
                 m = yv.n * yv.h * yv.w
                 self.launches.append(
                     _Launch(
                         L.y3_stem_conv_fwd,
-                        (self.stem_x, self.stem_sdt, yv.n, kw["cin"], yv.h, yv.w, C.c_float(1.0), w.filt.data_ptr(), w.bias.data_ptr(), dcode,
+                        (self.stem_x, self.stem_sdt, yv.n, kw["cin"], yv.h, yv.w, self.stem_div, w.filt.data_ptr(), w.bias.data_ptr(), dcode,
                          _lib.Y3_ACT_SILU if w.act else _lib.Y3_ACT_NONE, C.byref(yt)),
                         keep=(yt, w),
                         label=kw["label"],
@@ -547,12 +547,15 @@ def run_model(model, x: torch.Tensor, profile=False):
             plan = compile_model(model, n, h, w, dtype, x.device)
         plans[key] = plan
     stream = ops.stream_ptr()
+    # uint8 images are normalised inside the first kernel: the `im.half(); im /= 255` of reference val.py:358-359 / detect.py:187-189 /
+    # models/common.py:868 without a separate pass over the batch
+    div = 255.0 if x.dtype == torch.uint8 else 1.0
     if plan.stem_x is not None:
         xc = x.contiguous()
         plan.stem_keep = xc  # the launch reads the caller's tensor directly
-        plan.stem_x.value, plan.stem_sdt.value = xc.data_ptr(), ops.dtype_code(xc.dtype)
+        plan.stem_x.value, plan.stem_sdt.value, plan.stem_div.value = xc.data_ptr(), ops.dtype_code(xc.dtype), div
     else:
-        ops.nchw_to_nhwc(x, plan.input_view.real(), 1.0)
+        ops.nchw_to_nhwc(x, plan.input_view.real(), div)
     if profile:
         _profile(plan, stream)
     else:

@@ -253,3 +253,13 @@ def match_detections_raw(dets: torch.Tensor, img_stride: int, row_stride: int, c
                                          labels.data_ptr() if labels.numel() else None, offsets.data_ptr(), iouv.data_ptr(), int(iouv.numel()), correct.data_ptr(), stream_ptr()),
           "y3_match_detections")
     return correct
+
+
+def letterbox_u8(src_hwc: torch.Tensor, dst_batch: torch.Tensor, index: int, new_h: int, new_w: int, top: int, left: int, color: int = 114):
+    """One image (h0, w0, >=3) uint8 on the device -> image `index` of the (n, 3, H1, W1) uint8 batch (resize + pad + transpose)."""
+    require_gpu(src_hwc, "letterbox")
+    if src_hwc.dtype != torch.uint8 or dst_batch.dtype != torch.uint8 or src_hwc.dim() != 3 or dst_batch.dim() != 4 or not src_hwc.is_contiguous() or not dst_batch.is_contiguous():
+        raise TypeError("letterbox expects a contiguous (h, w, c) uint8 image and a contiguous (n, 3, H, W) uint8 batch")
+    h0, w0, cs = src_hwc.shape
+    check(_lib.lib().y3_letterbox_u8(src_hwc.data_ptr(), h0, w0, cs, dst_batch.data_ptr(), int(index), dst_batch.shape[2], dst_batch.shape[3], int(new_h), int(new_w), int(top),
+                                     int(left), int(color), stream_ptr()), "y3_letterbox_u8")
