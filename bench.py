@@ -47,6 +47,8 @@ def igemm_variant(cin, cout, k=1, m=1 << 30):
             return f"conv_igemm_v3<f16,bk{bk},tc128xtp128>"
         if var == "auto" and k * k * cin >= 2304 and cout >= 512:
             return "conv_igemm_v6<f16,bk32,tc256xtp256,8 waves staggered>"
+        if var == "auto" and k * k * cin >= 4608 and cout >= 256 and m >= 65536:
+            return "conv_igemm_v6<f16,bk32,tc256xtp256,8 waves staggered>"
         if var == "auto" and bk == 64 and k == 1 and cout >= 256 and 16384 < m <= 65536:
             return "conv_igemm_v6<f16,bk32,tc256xtp256,8 waves staggered>"
         if bk == 64 and ((k > 1 and k * k * cin >= 1152) or (k == 1 and cin >= 256 and m <= 16384)):
@@ -145,7 +147,7 @@ def train_main(args, rank, local_rank, world, dev, parallel, yo):
 
     bs, hw = args.batch, args.imgsz
     torch.manual_seed(0)
-    model = DetectionModel(f"{args.model}.yaml").to(dev).train()
+    model = DetectionModel(f"{args.model}.yaml", nc=args.nc).to(dev).train()
     model.hyp = dict(box=0.05, cls=0.5, cls_pw=1.0, obj=1.0, obj_pw=1.0, anchor_t=4.0, fl_gamma=0.0, label_smoothing=0.0)
     parallel.broadcast_parameters(model)
     if world > 1:
@@ -158,7 +160,7 @@ def train_main(args, rank, local_rank, world, dev, parallel, yo):
     opt = FusedSGD(smart_param_groups(model, 0.01, 5e-4 * bs * world / 64), momentum=0.937, nesterov=True)
     ema = ModelEMA(model) if rank == 0 else None
     x = torch.rand(bs, 3, hw, hw, generator=torch.Generator().manual_seed(rank)).to(dev)
-    tg = yo.synth_targets(bs, 80, seed=1 + rank).to(dev)
+    tg = yo.synth_targets(bs, args.nc, seed=1 + rank).to(dev)
     scale = 1024.0
 
     def step():
@@ -197,6 +199,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--imgsz", type=int, default=640)
     ap.add_argument("--model", default="yolov3")
+    ap.add_argument("--nc", type=int, default=80, help="classes (365 = the Objects365 head of BASELINE configs[4])")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-layers", action="store_true", help="print the per-launch table (rank 0)")
@@ -221,7 +224,7 @@ def main():
     dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     bs, hw = args.batch, args.imgsz
     torch.manual_seed(0)
-    model = DetectionModel(f"{args.model}.yaml")
+    model = DetectionModel(f"{args.model}.yaml", nc=args.nc)
     for m in model.modules():  # well-conditioned BN statistics so activations stay O(1) through 75 layers
         if isinstance(m, torch.nn.BatchNorm2d):
             m.weight.data.uniform_(0.5, 1.5)
@@ -231,7 +234,7 @@ def main():
     model = model.to(dev).to(dtype).eval()
     x = torch.rand(bs, 3, hw, hw, generator=torch.Generator().manual_seed(rank)).to(dev).to(dtype)
     n_rows = sum(3 * (hw // s) ** 2 for s in (8, 16, 32)) if args.model != "yolov3-tiny" else sum(3 * (hw // s) ** 2 for s in (16, 32))
-    pred_synth = yo.synth_predictions(bs=bs, n_rows=n_rows, nc=80, seed=2 + rank, img=hw).to(dev).to(dtype)
+    pred_synth = yo.synth_predictions(bs=bs, n_rows=n_rows, nc=args.nc, seed=2 + rank, img=hw).to(dev).to(dtype)
     nms_kw = dict(conf_thres=0.001, iou_thres=0.6, multi_label=True, max_det=300)
 
     def step():
@@ -317,7 +320,7 @@ def main():
             "dtype": "f16" if dtype == torch.float16 else "bf16",
             "data": "synthetic (seeded uniform images; random-init weights with conditioned BN stats; NMS leg on the seeded synthetic prediction tensor of SURVEY 8d)",
             "config": {
-                "workload": f"{args.model} inference {hw}x{hw} batch={bs}/GPU {args.dtype} + NMS(conf 0.001, iou 0.6, multi_label, max_det 300) [BASELINE configs[1]]",
+                "workload": f"{args.model} inference {hw}x{hw} batch={bs}/GPU {args.dtype} nc={args.nc} + NMS(conf 0.001, iou 0.6, multi_label, max_det 300)" + (" [BASELINE configs[1]]" if (args.model, hw, bs, args.dtype, args.nc) == ("yolov3", 640, 32, "fp16", 80) else ""),
                 "global_batch": world * bs,
                 "parallelism": f"replicas x{world} (no data-path collective)",
             },

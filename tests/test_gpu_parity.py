@@ -973,3 +973,43 @@ def test_autoshape_numpy_images_vs_oracle_pipeline(dev):
         assert det.pred[i].shape == r.shape and torch.equal(det.pred[i].cpu(), r), f"image {i}: detections differ from oracle NMS + scale_boxes"
     assert sum(p.shape[0] for p in det.pred) > 0
     assert torch.allclose(det.xywhn[0][:, :4].cpu(), (torch.cat(((ref[0][:, :2] + ref[0][:, 2:4]) / 2, ref[0][:, 2:4] - ref[0][:, :2]), 1) / torch.tensor([320.0, 240.0, 320.0, 240.0])), atol=1e-6)
+
+
+def test_config5_1280_objects365_bf16_vs_fp32_engine(dev):
+    """BASELINE configs[4] geometry on one GPU: yolov3, 1280x1280, Objects365 head (nc 365 -> 370 outputs per anchor, head convs
+    1110 channels, 100800 rows), bf16 MFMA engine against the fp32 direct-kernel engine (itself pinned to the reference
+    goldens at 1e-4) on the same weights: the large-activation regime (L0 output 105 MB per image) through every kernel
+    family, then batched NMS on the (1, 100800, 370) prediction tensor against the oracle (row-exact)."""
+    from yolov3_amd import non_max_suppression
+
+    m32, _ = build_pair("yolov3", 365, 29, dev, torch.float32)
+    x = torch.rand(1, 3, 1280, 1280, generator=torch.Generator().manual_seed(12))
+    with torch.no_grad():
+        p32, raw32 = m32(x.to(dev))
+        mb = m32.to(torch.bfloat16)
+        pb, rawb = mb(x.to(dev).to(torch.bfloat16))
+    torch.cuda.synchronize()
+    assert tuple(pb.shape) == (1, 100800, 370) and pb.dtype == torch.bfloat16
+    for a, b in zip(rawb, raw32):
+        a, b = a.float().cpu(), b.cpu()
+        rel = (a - b).abs().max().item() / b.abs().max().item()
+        corr = torch.corrcoef(torch.stack((a.flatten(), b.flatten())))[0, 1].item()
+        assert rel < 0.25 and corr > 0.99, f"bf16 vs fp32 engine: rel-to-max {rel:.3f}, correlation {corr:.5f}"
+    got = non_max_suppression(pb, 0.001, 0.6, multi_label=True, max_det=300)
+    want = yo.non_max_suppression(pb.cpu(), 0.001, 0.6, multi_label=True, max_det=300)
+    _cmp_nms(got, want, "1280/365")
+
+
+@pytest.mark.parametrize("n,h,w,c", [(3, 20, 20, 512), (2, 40, 40, 512), (1, 15, 23, 40), (1, 80, 80, 64)], ids=["640_spp", "1280_spp", "odd_rect_cg1", "direct_fallback"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_spp_pyramid_shapes(dev, dtype, n, h, w, c):
+    """SPP 5/9/13 pyramid (reference models/common.py:287-290) on the shapes of yolov3-spp at 640 / 1280 and on maps that force
+    the narrow-group and the direct (no LDS) variants: bit-exact against three nn.MaxPool2d(k, 1, k // 2)."""
+    _lib, ops = _ops()
+    x = torch.randn(n, c, h, w, generator=torch.Generator().manual_seed(2)).to(dtype)
+    cat = ops.View.alloc(n, h, w, 4 * c, dtype, dev)
+    cat.buf.zero_()
+    ops.nchw_to_nhwc(x.to(dev), cat.slice(0, c))
+    ops.spp_pyramid(cat.slice(0, c), cat.slice(c, 3 * c))
+    ref = torch.cat([x.float()] + [F.max_pool2d(x.float(), k, 1, k // 2) for k in (5, 9, 13)], 1).to(dtype)
+    assert torch.equal(ops.nhwc_to_nchw(cat).cpu(), ref)

@@ -1,0 +1,62 @@
+"""Fold the rocprofv3 --pmc passes of tools/gpu_pmc.sh into profiles/<round>_pmc_summary.json (keys = bench.py's kernel-instance
+names, see bench.igemm_variant).  python tools/pmc_summary.py <dir with pmc_*/ sub-dirs> <out.json>
+
+Per MI355X_MICROARCH.md (HBM / rocprofv3 section): one counter group per pass; FETCH_SIZE / WRITE_SIZE are reported in KiB;
+on gfx950 FETCH_SIZE counts 128-byte requests as 64 B -> read bytes = FETCH_SIZE x 1024 x 2; WRITE_SIZE x 1024 as is."""
+import glob
+import json
+import re
+import sqlite3
+import sys
+
+NAMES = [  # (regex on the kernel symbol, bench.py name)
+    (r"conv_igemm_v5_kernelIDF16_Li32ELi4ELi2ELi2ELi4ELi1E", "conv_igemm_v6<f16,bk32,tc256xtp256,8 waves staggered>"),
+    (r"conv_igemm_v3_kernelIDF16_Li64ELi2ELi2E", "conv_igemm_v3<f16,bk64,tc128xtp128>"),
+    (r"conv_igemm_v3_kernelIDF16_Li32ELi2ELi2E", "conv_igemm_v3<f16,bk32,tc128xtp128>"),
+    (r"conv_igemm_v3_kernelIDF16_Li32ELi1ELi4E", "conv_igemm_v3<f16,bk32,tc64xtp256>"),
+    (r"conv_igemm_v2_kernelIDF16_Li32ELi1ELi4ELi1ELi2ELb1E", "conv_igemm_v2<f16,bk32,tc32xtp256_smallc>"),
+    (r"stem_conv_kernel", "stem_conv"),
+    (r"decode_vec_kernel", "decode_vec"),
+    (r"nms_candidates_kernel", "nms_candidates"),
+    (r"nms_greedy_kernel", "nms_greedy"),
+]
+
+
+def main(root, out):
+    res = {}
+    for d in sorted(glob.glob(root + "/pmc_*/")):
+        dbs = glob.glob(d + "**/*.db", recursive=True)
+        if not dbs:
+            continue
+        db = sqlite3.connect(dbs[0])
+        tables = [r[0] for r in db.execute("select name from sqlite_master where type in ('table','view')")]
+        if "counters_collection" not in tables:
+            continue
+        for k, c, n, s, a in db.execute("select kernel_name, counter_name, count(*), sum(value), avg(value) from counters_collection group by kernel_name, counter_name"):
+            for pat, name in NAMES:
+                if re.search(pat, k):
+                    rec = res.setdefault(name, {"symbol": re.sub(r"\(anonymous namespace\)::|_ZN12_GLOBAL__N_1\d+", "", k)[:90]})
+                    rec[c] = {"dispatches": n, "avg": a}
+                    break
+    for name, rec in res.items():
+        if "FETCH_SIZE" in rec and "WRITE_SIZE" in rec:
+            rec["hbm_read_bytes_per_launch"] = rec["FETCH_SIZE"]["avg"] * 1024 * 2
+            rec["hbm_write_bytes_per_launch"] = rec["WRITE_SIZE"]["avg"] * 1024
+            rec["hbm_bytes_per_launch"] = rec["hbm_read_bytes_per_launch"] + rec["hbm_write_bytes_per_launch"]
+        if "TCC_HIT_sum" in rec and "TCC_MISS_sum" in rec:
+            h, m = rec["TCC_HIT_sum"]["avg"], rec["TCC_MISS_sum"]["avg"]
+            rec["l2_hit_rate"] = h / (h + m) if h + m else None
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in rec and "GRBM_GUI_ACTIVE" in rec and rec["GRBM_GUI_ACTIVE"]["avg"]:
+            # busy cycles are summed over the chip's 1024 SIMDs; GRBM_GUI_ACTIVE is wall cycles of the dispatch
+            rec["mfma_busy_frac_of_simd_cycles"] = rec["SQ_VALU_MFMA_BUSY_CYCLES"]["avg"] / (rec["GRBM_GUI_ACTIVE"]["avg"] * 1024)
+    res["_doc"] = ("rocprofv3 --kernel-trace --pmc <one counter group per pass> -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline (MI355X, tools/gpu_pmc.sh + "
+                   "tools/pmc_summary.py).  Averages per dispatch of the kernel SYMBOL (all filter sizes that symbol serves).  FETCH_SIZE/WRITE_SIZE in KiB as reported; "
+                   "hbm_read_bytes applies the gfx950 correction of MI355X_MICROARCH.md (128-B requests counted as 64 B -> x2).  Keys are bench.py's kernel-instance names.")
+    json.dump(res, open(out, "w"), indent=1)
+    for k, v in res.items():
+        if isinstance(v, dict):
+            print(k, {c: round(v[c], 3) if isinstance(v[c], float) else v[c] for c in ("hbm_bytes_per_launch", "l2_hit_rate", "mfma_busy_frac_of_simd_cycles") if c in v})
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])

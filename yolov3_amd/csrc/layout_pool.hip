@@ -4,6 +4,8 @@
 // L2 does not already capture (pool windows overlap along W/H inside one XCD's L2 working set).
 #include "y3_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 template <typename T> struct Vec {  // 16 bytes of T
@@ -102,6 +104,57 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ x, i
 
 // SPP pyramid, k = 5 / 9 / 13, stride 1, "same" (-inf) padding, all three windows in one pass over the
 // 13x13 neighbourhood (the 5- and 9-windows are its centred sub-windows), written to three channel slices.
+// SPP pyramid through LDS: max-pool is separable and 5 -> 9 -> 13 cascades (pool5 of pool5 = pool9, pool5 of pool9 = pool13,
+// with the -inf padding of nn.MaxPool2d reproduced by skipping out-of-image taps), so one block keeps an image's H x W plane of
+// CG 16-byte channel groups in LDS and makes three (row max5, column max5) passes: 30 LDS reads per element instead of the 169
+// global loads of the direct kernel below (0.28 ms for 32 x 20 x 20 x 512, 4 % of the yolov3-spp forward).
+template <typename T>
+__global__ __launch_bounds__(256) void spp_lds_kernel(const T* __restrict__ x, int H, int W, int C, int xpitch, T* __restrict__ y, int ypitch, int CG) {
+    constexpr int V = Vec<T>::N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char spp_smem[];
+    const int P = H * W;
+    Vec<T>* A = (Vec<T>*)spp_smem;
+    Vec<T>* B = A + (size_t)P * CG;
+    const int groups = C / (V * CG);
+    const int n = blockIdx.x / groups, g = blockIdx.x % groups;
+    const int cg = threadIdx.x % CG, pl = threadIdx.x / CG, PL = 256 / CG;
+    const int c0 = (g * CG + cg) * V;
+    const T* xin = x + (long long)n * P * xpitch + c0;
+    T* yout = y + (long long)n * P * ypitch + c0;
+    if (pl < PL)
+        for (int p = pl; p < P; p += PL) A[p * CG + cg] = *(const Vec<T>*)(xin + (long long)p * xpitch);
+    __syncthreads();
+    for (int stage = 0; stage < 3; ++stage) {
+        if (pl < PL)
+            for (int p = pl; p < P; p += PL) {   // rows: B = max over w-2 .. w+2 of A
+                const int h = p / W, w = p - h * W;
+                const int lo = w - 2 < 0 ? 0 : w - 2, hi = w + 2 >= W ? W - 1 : w + 2;
+                Vec<T> m = A[(h * W + lo) * CG + cg];
+                for (int q = lo + 1; q <= hi; ++q) {
+                    const Vec<T> v = A[(h * W + q) * CG + cg];
+#pragma unroll
+                    for (int e = 0; e < V; ++e) m.v[e] = to_f32<T>(v.v[e]) > to_f32<T>(m.v[e]) ? v.v[e] : m.v[e];
+                }
+                B[p * CG + cg] = m;
+            }
+        __syncthreads();
+        if (pl < PL)
+            for (int p = pl; p < P; p += PL) {   // columns: A = max over h-2 .. h+2 of B, and the stage's output slice
+                const int h = p / W, w = p - h * W;
+                const int lo = h - 2 < 0 ? 0 : h - 2, hi = h + 2 >= H ? H - 1 : h + 2;
+                Vec<T> m = B[(lo * W + w) * CG + cg];
+                for (int q = lo + 1; q <= hi; ++q) {
+                    const Vec<T> v = B[(q * W + w) * CG + cg];
+#pragma unroll
+                    for (int e = 0; e < V; ++e) m.v[e] = to_f32<T>(v.v[e]) > to_f32<T>(m.v[e]) ? v.v[e] : m.v[e];
+                }
+                A[p * CG + cg] = m;
+                *(Vec<T>*)(yout + (long long)p * ypitch + stage * C) = m;
+            }
+        __syncthreads();
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void spp_kernel(const T* __restrict__ x, int N, int H, int W, int C, int xpitch, T* __restrict__ y, int ypitch) {
     constexpr int V = Vec<T>::N;
@@ -236,6 +289,20 @@ extern "C" int y3_spp_pyramid(const y3_tensor* x, const y3_tensor* y, int32_t dt
     if (!x || !y) Y3_FAIL("y3_spp_pyramid: null argument");
     if (y->n != x->n || y->h != x->h || y->w != x->w || y->c != 3 * x->c) Y3_FAIL("y3_spp_pyramid: output slice must be 3x the input channels");
     if (!vec_ok(x, esize(dtype)) || !vec_ok(y, esize(dtype))) Y3_FAIL("y3_spp_pyramid: alignment");
+    {   // LDS path: two H x W planes of CG 16-byte channel groups must fit 64 KiB (CG = 4 -> 64-byte runs per pixel)
+        const int vecs = x->c / (16 / esize(dtype));
+        const long long P = (long long)x->h * x->w;
+        int CG = 4;
+        while (CG > 1 && (vecs % CG || 2 * P * CG * 16 > 65536)) CG >>= 1;
+        static const bool direct = getenv("Y3_SPP") && !strcmp(getenv("Y3_SPP"), "direct");
+        if (!direct && 2 * P * CG * 16 <= 65536 && (long long)x->n * (vecs / CG) < 0x7fffffffLL) {
+            const size_t lds = (size_t)(2 * P * CG * 16);
+            Y3_DISPATCH_FLOAT(dtype, hipLaunchKernelGGL((spp_lds_kernel<T>), dim3((unsigned)(x->n * (vecs / CG))), dim3(256), lds, (hipStream_t)stream, (const T*)x->data, x->h, x->w,
+                                                        x->c, x->pitch, (T*)y->data, y->pitch, CG));
+            Y3_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     const long long total = (long long)x->n * x->h * x->w * (x->c / (16 / esize(dtype)));
     Y3_DISPATCH_FLOAT(dtype, hipLaunchKernelGGL((spp_kernel<T>), dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x->data, x->n, x->h, x->w, x->c,
                                                 x->pitch, (T*)y->data, y->pitch));
