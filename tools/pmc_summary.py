@@ -47,8 +47,9 @@ def main(root, out):
             h, m = rec["TCC_HIT_sum"]["avg"], rec["TCC_MISS_sum"]["avg"]
             rec["l2_hit_rate"] = h / (h + m) if h + m else None
         if "SQ_VALU_MFMA_BUSY_CYCLES" in rec and "GRBM_GUI_ACTIVE" in rec and rec["GRBM_GUI_ACTIVE"]["avg"]:
-            # busy cycles are summed over the chip's 1024 SIMDs; GRBM_GUI_ACTIVE is wall cycles of the dispatch
-            rec["mfma_busy_frac_of_simd_cycles"] = rec["SQ_VALU_MFMA_BUSY_CYCLES"]["avg"] / (rec["GRBM_GUI_ACTIVE"]["avg"] * 1024)
+            # busy cycles are summed over the chip's 1024 SIMDs (32 per v_mfma_f32_32x32x16: checked against the launch FLOPs);
+            # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (value / 8 = the dispatch's wall cycles: 94 us -> 234k)
+            rec["mfma_busy_frac_of_simd_cycles"] = rec["SQ_VALU_MFMA_BUSY_CYCLES"]["avg"] / (rec["GRBM_GUI_ACTIVE"]["avg"] / 8 * 1024)
     res["_doc"] = ("rocprofv3 --kernel-trace --pmc <one counter group per pass> -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline (MI355X, tools/gpu_pmc.sh + "
                    "tools/pmc_summary.py).  Averages per dispatch of the kernel SYMBOL (all filter sizes that symbol serves).  FETCH_SIZE/WRITE_SIZE in KiB as reported; "
                    "hbm_read_bytes applies the gfx950 correction of MI355X_MICROARCH.md (128-B requests counted as 64 B -> x2).  Keys are bench.py's kernel-instance names.")
