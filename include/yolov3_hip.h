@@ -194,6 +194,17 @@ int y3_bn_stats(const y3_tensor* u, int32_t dtype, double* sums, void* stream);
 int y3_bn_finalize(const double* sums, int64_t count, int32_t channels, const float* gamma, const float* beta, float eps,
                    float momentum, float* running_mean /* updated in place, may be NULL */, float* running_var,
                    float* scale, float* shift, float* mean, float* invstd, void* stream);
+/* Training forward with the BatchNorm statistics taken in the conv epilogue (f16/bf16 MFMA path, no residual / upsample):
+ * y3_conv2d_fwd plus, per (pixel tile, pixel wave) of the dispatched tile variant, one row [cout][2] fp32 of (sum, sum of
+ * squares) of the STORED output values in stat_rows; *n_rows = rows written (query: y3_conv2d_fwd_stats_rows, -1 on error).
+ * y3_bn_finalize_rows sums the rows in fp64 (fixed order; `sums` is a Y3_BN_SCRATCH_DOUBLES(C) scratch, totals land in its first
+ * 2*C entries) and finalizes like y3_bn_finalize (count = n*h*w). */
+int64_t y3_conv2d_fwd_stats_rows(const y3_conv_desc* desc, const y3_tensor* x, const y3_tensor* y);
+int y3_conv2d_fwd_stats(const y3_conv_desc* desc, const y3_tensor* x, const void* packed_filter, const float* bias,
+                        const y3_tensor* y, float* stat_rows, int64_t capacity_rows, int64_t* n_rows, void* stream);
+int y3_bn_finalize_rows(const float* stat_rows, int64_t n_rows, int64_t count, int32_t channels, double* sums, const float* gamma,
+                        const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* scale,
+                        float* shift, float* mean, float* invstd, void* stream);
 /* y3_bn_stats followed by y3_bn_finalize (count = n*h*w of u) with the partial-row sum and the finalize in one launch */
 int y3_bn_stats_finalize(const y3_tensor* u, int32_t dtype, double* sums, const float* gamma, const float* beta, float eps,
                          float momentum, float* running_mean /* may be NULL */, float* running_var, float* scale, float* shift,
@@ -203,6 +214,11 @@ int y3_bn_act_fwd(const y3_tensor* u, const float* scale, const float* shift, co
 int y3_bn_act_bwd(const y3_tensor* u, const y3_tensor* dy, const float* scale, const float* shift, const float* mean,
                   const float* invstd, int32_t dtype, int32_t act, double* sums, const y3_tensor* du,
                   float* dgamma /* may be NULL */, float* dbeta /* may be NULL */, void* stream);
+/* y3_bn_act_bwd for a unit with a residual input (`out = act(bn(conv(x))) + residual`, Bottleneck with shortcut): also writes
+ * (gres_accumulate = 0) or accumulates (1) dy into the residual's gradient on the pass that reads dy anyway. */
+int y3_bn_act_bwd_res(const y3_tensor* u, const y3_tensor* dy, const float* scale, const float* shift, const float* mean,
+                      const float* invstd, int32_t dtype, int32_t act, double* sums, const y3_tensor* du, float* dgamma,
+                      float* dbeta, const y3_tensor* gres, int32_t gres_accumulate, void* stream);
 /* OIHW fp32 -> filter bank of the data-gradient convolution: `cin` filters over (kh, kw, cout) with flipped taps. */
 int y3_pack_filter_dgrad(const float* w_oihw, int32_t cout_src, int32_t cin_src, int32_t ksize, int32_t cout, int32_t cin,
                          int32_t dtype, void* packed, void* stream);

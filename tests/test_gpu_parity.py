@@ -1013,3 +1013,62 @@ def test_spp_pyramid_shapes(dev, dtype, n, h, w, c):
     ops.spp_pyramid(cat.slice(0, c), cat.slice(c, 3 * c))
     ref = torch.cat([x.float()] + [F.max_pool2d(x.float(), k, 1, k // 2) for k in (5, 9, 13)], 1).to(dtype)
     assert torch.equal(ops.nhwc_to_nchw(cat).cpu(), ref)
+
+
+STAT_CASES = [
+    ("v3_bk64", (2, 40, 40, 128, 256, 3, 1)),
+    ("v6_ragged_last_tile", (4, 20, 20, 512, 512, 3, 1)),
+    ("cout64_odd_pixels", (2, 33, 17, 32, 64, 3, 1)),
+    ("1x1", (2, 40, 40, 256, 128, 1, 1)),
+    ("stride2_odd", (2, 41, 37, 64, 128, 3, 2)),
+    ("v2_small_cin", (1, 20, 20, 16, 32, 3, 1)),
+    ("cout_not_tile_multiple", (2, 24, 24, 64, 200, 3, 1)),
+    ("many_rows_two_level_sum", (8, 96, 96, 32, 64, 3, 1)),   # 576 rows > 512: first-level sums into the fp64 partial rows
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name,shape", STAT_CASES, ids=[c[0] for c in STAT_CASES])
+def test_conv_epilogue_bn_statistics(dev, dtype, name, shape):
+    """y3_conv2d_fwd_stats: same output as y3_conv2d_fwd (bit-exact) and per-(tile, wave) rows whose fp64 sum equals the
+    per-channel (sum, sum of squares) of the STORED output (1e-5 relative: fp32 partial sums over <= 128 pixels), for every
+    tile variant incl. ragged pixel / filter tiles; then y3_bn_finalize_rows against nn.BatchNorm2d's batch statistics."""
+    _lib, ops = _ops()
+    n, h, w, cin, cout, k, s = shape
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(n, cin, h, w, generator=g).to(dtype)
+    wt = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    xv = ops.View.alloc(n, h, w, cin, dtype, dev)
+    ops.nchw_to_nhwc(x.to(dev), xv)
+    ho, wo = (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
+    filt = ops.pack_filter(wt.to(dev), cout, cin, dtype)
+    zb = torch.zeros(cout, device=dev)
+    y0 = ops.View.alloc(n, ho, wo, cout, dtype, dev)
+    ops.conv2d(xv, filt, zb, y0, k, s, act=False)
+    y1 = ops.View.alloc(n, ho, wo, cout, dtype, dev)
+    rows = ops.conv2d_stats_rows(xv, y1, k, s)
+    buf = torch.full((rows * 2 * cout,), float("nan"), device=dev)
+    got_rows = ops.conv2d_stats(xv, filt, zb, y1, k, s, buf, rows)
+    torch.cuda.synchronize()
+    assert got_rows == rows and torch.equal(y0.buf, y1.buf)
+    u = y1.as_nhwc().double().cpu().reshape(-1, cout)
+    tot = buf.view(rows, cout, 2).double().sum(0).cpu()
+    assert torch.isfinite(tot).all(), "a statistics row was not written"
+    ref0, ref1 = u.sum(0), (u * u).sum(0)
+    assert (tot[:, 0] - ref0).abs().max().item() <= 1e-5 * u.abs().sum(0).max().item(), "sum"
+    assert (tot[:, 1] - ref1).abs().max().item() <= 1e-5 * ref1.max().item(), "sum of squares"
+    # finalize from the rows == BatchNorm2d(eps 1e-3, momentum 0.03) batch statistics of the stored tensor
+    sums = ops.bn_scratch(cout, dev)
+    gamma, beta = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev)
+    rm, rv = torch.zeros(cout, device=dev), torch.ones(cout, device=dev)
+    scale, shift, mean, invstd = (torch.empty(cout, device=dev) for _ in range(4))
+    cnt = n * ho * wo
+    _lib.check(_lib.lib().y3_bn_finalize_rows(buf.data_ptr(), rows, cnt, cout, sums.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-3, 0.03, rm.data_ptr(), rv.data_ptr(),
+                                              scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), ops.stream_ptr()), "y3_bn_finalize_rows")
+    torch.cuda.synchronize()
+    mu, var = u.mean(0), u.var(0, unbiased=False)
+    torch.testing.assert_close(mean.double().cpu(), mu, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(invstd.double().cpu(), 1.0 / torch.sqrt(var + 1e-3), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rm.double().cpu(), 0.03 * mu, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rv.double().cpu(), 0.97 + 0.03 * u.var(0, unbiased=True), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(scale.double().cpu(), gamma.double().cpu() / torch.sqrt(var + 1e-3), rtol=1e-4, atol=1e-5)

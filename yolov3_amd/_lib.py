@@ -104,6 +104,13 @@ _SIGNATURES = {
         C.c_int,
         [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     ),
+    "y3_conv2d_fwd_stats_rows": (C.c_int64, [_P(Y3ConvDesc), _P(Y3Tensor), _P(Y3Tensor)]),
+    "y3_conv2d_fwd_stats": (C.c_int, [_P(Y3ConvDesc), _P(Y3Tensor), C.c_void_p, C.c_void_p, _P(Y3Tensor), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "y3_bn_finalize_rows": (
+        C.c_int,
+        [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+         C.c_void_p],
+    ),
     "y3_bn_stats_finalize": (
         C.c_int,
         [_P(Y3Tensor), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
@@ -112,6 +119,11 @@ _SIGNATURES = {
     "y3_bn_act_bwd": (
         C.c_int,
         [_P(Y3Tensor), _P(Y3Tensor), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, _P(Y3Tensor), C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
+    "y3_bn_act_bwd_res": (
+        C.c_int,
+        [_P(Y3Tensor), _P(Y3Tensor), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, _P(Y3Tensor), C.c_void_p, C.c_void_p, _P(Y3Tensor), C.c_int32,
+         C.c_void_p],
     ),
     "y3_pack_filter_dgrad": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "y3_packed_filter_dgrad_s2_elems": (C.c_size_t, [C.c_int32, C.c_int32]),

@@ -50,6 +50,12 @@ struct ConvArgs {
     unsigned long long tap_lo, tap_hi;   // the same table packed for scalar extraction: tap t -> byte t, (dh + 8) | (dw + 8) << 4  (host: pack_taps)
     // output addressing: conv pixel (n, ho, wo) lands at (n, ho*omul + ooh, wo*omul + oow) of an (oH, oW) image
     int oH, oW, omul, ooh, oow;
+    // BatchNorm statistics of the output, taken in the epilogue (training forward): every wave writes the per-filter (sum, sum of
+    // squares) of the <= MP*32 pixels it owns -- of the values as STORED (rounded to T) -- into row (pixel tile * stat_wp + its
+    // pixel-wave index) of `stats` ([rows][Cout][2] fp32); a fixed-order fp64 sum over the rows follows (train.hip)
+    float* stats;
+    int stat_wp;   // waves along the pixel axis of the launched variant
+    int dry;       // geometry only (y3_conv2d_fwd_stats_rows): fill n_pt / stat_wp, launch nothing
 #ifdef Y3_TIMELINE  // debug build only (tools/timeline.py): per-block wall-clock stamps
     unsigned long long* tl;
 #endif
@@ -166,7 +172,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // idle), no idle waves.  (The block-wide fp32 transpose this replaces cost 8-17 us per block with half of the waves parked
 // during the exp/rcp pass; a register-only variant with 32-byte runs lost on the residual layers: profiles/r01_conv_timeline.md.)
 template <typename T, int MC, int MP>
-Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MP], unsigned char* wl, int c_base, int m_base, int lane) {
+Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MP], unsigned char* wl, int c_base, int m_base, int lane, int stat_row = -1) {
     typedef typename Mfma<T>::frag vec8;   // 8 x T = one 16-byte chunk
     constexpr int CH = MC * 4;          // 16-byte chunks per pixel row of this wave's slice
     constexpr int RB = CH * 16;         // row bytes
@@ -233,10 +239,18 @@ Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MP], unsigned cha
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const bool want_stats = p.stats != nullptr;   // kernel-uniform
+    float st0[8], st1[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) st0[q] = st1[q] = 0.0f;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int pl = i * PPI + rp;
         vec8 ov = *(const vec8*)(wl + pl * RB + ((ch ^ swz<MC * 32>(pl)) << 4));
+        if (want_stats && yoff[i] != OOB) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const float f = to_f32<T>(ov[q]); st0[q] += f; st1[q] += f * f; }
+        }
         if (has_res) {
             const vec8 rr = __builtin_bit_cast(vec8, rres[i]);
 #pragma unroll
@@ -251,6 +265,18 @@ Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MP], unsigned cha
 #pragma unroll
                 for (int dx = 0; dx < 2; ++dx)
                     __builtin_amdgcn_raw_buffer_store_b128(raw, rsrc_y, yoff[i] == OOB ? OOB : yoff[i] + (unsigned)((dy * p.Wo * 2 + dx) * p.ypitch) * 2u, 0, 0);
+        }
+    }
+    if (want_stats) {
+        // lanes rp * CH + ch (rp < PPI) hold partial sums of the same 8 filters: butterfly over the rp bits, lane ch writes the row
+#pragma unroll
+        for (int off = CH; off < 64; off <<= 1)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { st0[q] += __shfl_xor(st0[q], off, 64); st1[q] += __shfl_xor(st1[q], off, 64); }
+        if (rp == 0 && cv) {
+            float* row = p.stats + ((long long)stat_row * p.Cout + c) * 2;
+#pragma unroll
+            for (int q = 0; q < 8; q += 2) *(f32x4*)(row + q * 2) = f32x4{st0[q], st1[q], st0[q + 1], st1[q + 1]};
         }
     }
 }
@@ -417,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_v2_kernel(const ConvArgs p)
     }
 
     // the last K-step's barrier has passed: the stage buffers are idle and become the per-wave transpose slices
-    epilogue_wave<T, MC, MP>(p, acc, smem + wv * (MP * 32 * MC * 64), ct * TC + wc * MC * 32, pt * TP + wp * MP * 32, lane);
+    epilogue_wave<T, MC, MP>(p, acc, smem + wv * (MP * 32 * MC * 64), ct * TC + wc * MC * 32, pt * TP + wp * MP * 32, lane, pt * WAVES_P + wp);
 }
 
 // ---- v3: LDS-DMA staging.  `buffer_load_dwordx4 ... lds` moves each wave's 1 KiB chunk straight from L2/HBM into
@@ -567,7 +593,7 @@ __global__ __launch_bounds__(256, (BK == 32 && MC * MP <= 4 ? 4 : 2)) void conv_
     Y3_STAMP(3);
 
     __syncthreads();  // every wave is done with the stage buffers: they become the per-wave transpose slices
-    epilogue_wave<T, MC, MP>(p, acc, smem + wv * (MP * 32 * MC * 64), ct * TC + wc * MC * 32, pt * TP + wp * MP * 32, lane);
+    epilogue_wave<T, MC, MP>(p, acc, smem + wv * (MP * 32 * MC * 64), ct * TC + wc * MC * 32, pt * TP + wp * MP * 32, lane, pt * WAVES_P + wp);
     Y3_STAMP(4);
 #endif
 }
@@ -765,7 +791,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, 2) void conv_igemm_v5_kerne
         Y3_STAMP(3);
         __syncthreads();  // every wave is done with the stage buffers: they become the per-wave transpose slices
     }
-    epilogue_wave<T, MC, MP>(p, acc, smem + wv * (MP * 32 * MC * 64), ct * TC + wc * MC * 32, pt * TP + wp * MP * 32, lane);
+    epilogue_wave<T, MC, MP>(p, acc, smem + wv * (MP * 32 * MC * 64), ct * TC + wc * MC * 32, pt * TP + wp * MP * 32, lane, pt * WAVES_P + wp);
     Y3_STAMP(4);
 #endif
 }
@@ -779,6 +805,8 @@ template <typename T, int BK, int WAVES_C, int WAVES_P, int MC, int MP, int SCHE
     a.nk = a.ntaps * a.cin_blocks;
     const long long nb = (long long)a.n_ct * a.n_pt;
     if (nb > 0x7fffffffLL) Y3_FAIL("conv grid too large");
+    a.stat_wp = WAVES_P;
+    if (a.dry) return 0;
     hipLaunchKernelGGL((conv_igemm_v5_kernel<T, BK, WAVES_C, WAVES_P, MC, MP, SCHED>), dim3((unsigned)nb), dim3(64 * WAVES_C * WAVES_P), 0, st, a);
     Y3_CHECK_LAUNCH();
     return 0;
@@ -793,6 +821,8 @@ template <typename T, int BK, int MC, int MP> int launch_v3(ConvArgs& a, hipStre
     a.nk = a.ntaps * a.cin_blocks;
     const long long nb = (long long)a.n_ct * a.n_pt;
     if (nb > 0x7fffffffLL) Y3_FAIL("conv grid too large");
+    a.stat_wp = 2;
+    if (a.dry) return 0;
     hipLaunchKernelGGL((conv_igemm_v3_kernel<T, BK, MC, MP>), dim3((unsigned)nb), dim3(256), 0, st, a);
     Y3_CHECK_LAUNCH();
     return 0;
@@ -870,6 +900,8 @@ int launch_igemm(ConvArgs& a, hipStream_t st) {
     }
     const long long nb = (long long)a.n_ct * a.n_pt;
     if (nb > 0x7fffffffLL) Y3_FAIL("conv grid too large");
+    a.stat_wp = WAVES_P;
+    if (a.dry) return 0;
     hipLaunchKernelGGL((conv_igemm_v2_kernel<T, BK, WAVES_C, WAVES_P, MC, MP, SMALLC>), dim3((unsigned)nb), dim3(256), 0, st, a);
     Y3_CHECK_LAUNCH();
     return 0;
@@ -953,8 +985,8 @@ extern "C" int y3_pack_filter(const float* w, int32_t cout_src, int32_t cin_src,
     return 0;
 }
 
-extern "C" int y3_conv2d_fwd(const y3_conv_desc* d, const y3_tensor* x, const void* filt, const float* bias,
-                             const y3_tensor* res, const y3_tensor* y, void* stream) {
+static int conv_fwd_impl(const y3_conv_desc* d, const y3_tensor* x, const void* filt, const float* bias, const y3_tensor* res, const y3_tensor* y, float* stats,
+                         int64_t stat_capacity_rows, int64_t* stat_rows, int dry, void* stream) {
     if (!d || !x || !filt || !bias || !y) Y3_FAIL("y3_conv2d_fwd: null argument");
     if (d->ksize != 1 && d->ksize != 3) Y3_FAIL("y3_conv2d_fwd: ksize %d unsupported", d->ksize);
     if (d->stride != 1 && d->stride != 2) Y3_FAIL("y3_conv2d_fwd: stride %d unsupported", d->stride);
@@ -1016,6 +1048,18 @@ extern "C" int y3_conv2d_fwd(const y3_conv_desc* d, const y3_tensor* x, const vo
 
     int algo = d->algo;
     if (algo == Y3_ALGO_AUTO) algo = (d->dtype == Y3_F32) ? Y3_ALGO_DIRECT : Y3_ALGO_MFMA;
+    if (stat_rows) {   // BatchNorm statistics in the epilogue: MFMA kernels only; two passes decide the rows, then launch
+        if (algo != Y3_ALGO_MFMA || d->dtype == Y3_F32) Y3_FAIL("y3_conv2d_fwd_stats: the epilogue statistics need the f16/bf16 MFMA path");
+        if (d->upsample2x) Y3_FAIL("y3_conv2d_fwd_stats: upsample2x unsupported");
+        ConvArgs g = a;
+        g.dry = 1;
+        const int rc = d->dtype == Y3_F16 ? dispatch_igemm<f16_t>(g, st) : dispatch_igemm<bf16_t>(g, st);
+        if (rc) return rc;
+        *stat_rows = (int64_t)g.n_pt * g.stat_wp;
+        if (dry) return 0;
+        if (!stats || stat_capacity_rows < *stat_rows) Y3_FAIL("y3_conv2d_fwd_stats: statistics buffer holds %lld rows, the launch writes %lld", (long long)stat_capacity_rows, (long long)*stat_rows);
+        a.stats = stats;
+    }
     if (algo == Y3_ALGO_MFMA) {
         if (d->dtype == Y3_F16) return dispatch_igemm<f16_t>(a, st);
         if (d->dtype == Y3_BF16) return dispatch_igemm<bf16_t>(a, st);
@@ -1027,6 +1071,24 @@ extern "C" int y3_conv2d_fwd(const y3_conv_desc* d, const y3_tensor* x, const vo
         case Y3_F32: return launch_direct<float>(a, st);
     }
     Y3_FAIL("y3_conv2d_fwd: bad dtype %d", d->dtype);
+}
+
+extern "C" int y3_conv2d_fwd(const y3_conv_desc* d, const y3_tensor* x, const void* filt, const float* bias, const y3_tensor* res, const y3_tensor* y, void* stream) {
+    return conv_fwd_impl(d, x, filt, bias, res, y, nullptr, 0, nullptr, 0, stream);
+}
+
+// rows of the statistics buffer the launch described by (desc, x, y) would write (depends on the tile variant dispatched)
+extern "C" int64_t y3_conv2d_fwd_stats_rows(const y3_conv_desc* d, const y3_tensor* x, const y3_tensor* y) {
+    int64_t rows = 0;
+    alignas(16) static const float dummy[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // geometry only: never dereferenced
+    if (conv_fwd_impl(d, x, (const void*)dummy, dummy, nullptr, y, nullptr, 0, &rows, 1, nullptr)) return -1;
+    return rows;
+}
+
+extern "C" int y3_conv2d_fwd_stats(const y3_conv_desc* d, const y3_tensor* x, const void* filt, const float* bias, const y3_tensor* y, float* stat_rows, int64_t capacity_rows,
+                                   int64_t* n_rows, void* stream) {
+    if (!n_rows) Y3_FAIL("y3_conv2d_fwd_stats: null row count");
+    return conv_fwd_impl(d, x, filt, bias, nullptr, y, stat_rows, capacity_rows, n_rows, 0, stream);
 }
 
 

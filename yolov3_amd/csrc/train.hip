@@ -163,15 +163,21 @@ Y3_DEV void bn_finalize_channel(int c, double s0, double s1, const BnFinalizeArg
     if (f.rmean) f.rmean[c] = (1.0f - f.momentum) * f.rmean[c] + f.momentum * (float)mu;
     if (f.rvar) f.rvar[c] = (1.0f - f.momentum) * f.rvar[c] + f.momentum * (float)(f.count > 1.0 ? var * f.count / (f.count - 1.0) : var);
 }
-template <int MODE>
+// TIN = double: rows 1.. of `sums` (the reduction kernels' partial rows); TIN = float: the rows the conv epilogue wrote (`part`)
+template <int MODE, typename TIN = double>
 __global__ __launch_bounds__(256) void reduce_partials_kernel(double* __restrict__ sums, int n2c, int nblocks, BnFinalizeArgs f, float* __restrict__ o0, float* __restrict__ o1,
-                                                                int c_out) {
+                                                                int c_out, const TIN* __restrict__ part = nullptr) {
     __shared__ double red[256];
     const int j = blockIdx.x * 16 + (threadIdx.x & 15);
     const int rl = threadIdx.x >> 4;
     double a = 0.0;
-    if (j < n2c)
-        for (int b = rl; b < nblocks; b += 16) a += sums[(size_t)(1 + b) * n2c + j];
+    if (j < n2c) {
+        if constexpr (std::is_same<TIN, double>::value) {
+            for (int b = rl; b < nblocks; b += 16) a += sums[(size_t)(1 + b) * n2c + j];
+        } else {
+            for (int b = rl; b < nblocks; b += 16) a += (double)part[(size_t)b * n2c + j];
+        }
+    }
     red[threadIdx.x] = a;
     __syncthreads();
 #pragma unroll
@@ -232,7 +238,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restrict__ u, int upitch, const T* __restrict__ dy, int dpitch,
                                                                  const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd, const double* __restrict__ sums, double count,
-                                                                 T* __restrict__ du, int opitch, long long M, int C, int act) {
+                                                                 T* __restrict__ du, int opitch, long long M, int C, int act, T* __restrict__ gres, int gpitch,
+                                                                 int gres_acc) {
     constexpr int V = V16<T>::N;
     const int CG = C / V, PL = 256 / CG;
     const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
@@ -262,6 +269,15 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
             o.v[q] = from_f32<T>(sc[q] * (dz - m0[q] - xh * m1[q]));  // scale = gamma * invstd
         }
         *(V16<T>*)(du + m * opitch + cg * V) = o;
+        if (gres) {   // out = act(bn(conv)) + residual: the residual's gradient (+)= dy, on the pass that reads dy anyway
+            V16<T> r = g;
+            if (gres_acc) {
+                const V16<T> old = *(const V16<T>*)(gres + m * gpitch + cg * V);
+#pragma unroll
+                for (int q = 0; q < V; ++q) r.v[q] = from_f32<T>(to_f32<T>(g.v[q]) + to_f32<T>(old.v[q]));
+            }
+            *(V16<T>*)(gres + m * gpitch + cg * V) = r;
+        }
     }
 }
 
@@ -1040,6 +1056,39 @@ extern "C" int y3_bn_finalize(const double* sums, int64_t count, int32_t C, cons
     return 0;
 }
 
+// first level of the row sum when a launch wrote many rows (the 320x320 layers at batch 64 write 51200): block b adds rows
+// [b*per, (b+1)*per) into fp64 partial row 1+b of `sums`, all 2C entries, coalesced along the row
+__global__ __launch_bounds__(256) void stat_rows_to_partials_kernel(const float* __restrict__ rows, long long n_rows, int n2c, int per, double* __restrict__ sums) {
+    const long long r0 = (long long)blockIdx.x * per;
+    long long r1 = r0 + per;
+    if (r1 > n_rows) r1 = n_rows;
+    for (int j = threadIdx.x; j < n2c; j += 256) {
+        double a = 0.0;
+        for (long long r = r0; r < r1; ++r) a += (double)rows[r * n2c + j];
+        sums[(size_t)(1 + blockIdx.x) * n2c + j] = a;
+    }
+}
+
+// BatchNorm finalize from the (sum, sum of squares) rows a y3_conv2d_fwd_stats launch wrote: fixed-order fp64 sum over the rows
+// + finalize in one launch (replaces the statistics pass over u)
+extern "C" int y3_bn_finalize_rows(const float* stat_rows, int64_t n_rows, int64_t count, int32_t C, double* sums, const float* gamma, const float* beta, float eps,
+                                   float momentum, float* running_mean, float* running_var, float* scale, float* shift, float* mean, float* invstd, void* stream) {
+    if (!stat_rows || !sums || !scale || !shift || !mean || !invstd || count <= 0 || n_rows <= 0 || n_rows > 0x7fffffffLL) Y3_FAIL("y3_bn_finalize_rows: bad argument");
+    const BnFinalizeArgs f{(double)count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd};
+    hipStream_t st = (hipStream_t)stream;
+    if (n_rows > Y3_BN_PARTIAL_ROWS) {   // `sums` is a Y3_BN_SCRATCH_DOUBLES(C) buffer: two levels through its partial rows
+        const int per = (int)((n_rows + Y3_BN_PARTIAL_ROWS - 1) / Y3_BN_PARTIAL_ROWS);
+        const int blocks = (int)((n_rows + per - 1) / per);
+        hipLaunchKernelGGL(stat_rows_to_partials_kernel, dim3((unsigned)blocks), dim3(256), 0, st, stat_rows, (long long)n_rows, 2 * C, per, sums);
+        Y3_CHECK_LAUNCH();
+        hipLaunchKernelGGL((reduce_partials_kernel<1, double>), dim3((2 * C + 15) / 16), dim3(256), 0, st, sums, 2 * C, blocks, f, (float*)nullptr, (float*)nullptr, 0, (const double*)nullptr);
+    } else {
+        hipLaunchKernelGGL((reduce_partials_kernel<1, float>), dim3((2 * C + 15) / 16), dim3(256), 0, st, sums, 2 * C, (int)n_rows, f, (float*)nullptr, (float*)nullptr, 0, stat_rows);
+    }
+    Y3_CHECK_LAUNCH();
+    return 0;
+}
+
 // y3_bn_stats + y3_bn_finalize in two launches (the partial-row sum and the finalize share one kernel)
 extern "C" int y3_bn_stats_finalize(const y3_tensor* u, int32_t dtype, double* sums, const float* gamma, const float* beta, float eps, float momentum,
                                     float* running_mean, float* running_var, float* scale, float* shift, float* mean, float* invstd, void* stream) {
@@ -1071,12 +1120,14 @@ extern "C" int y3_bn_act_fwd(const y3_tensor* u, const float* scale, const float
     return 0;
 }
 
-extern "C" int y3_bn_act_bwd(const y3_tensor* u, const y3_tensor* dy, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t dtype,
-                             int32_t act, double* sums, const y3_tensor* du, float* dgamma, float* dbeta, void* stream) {
+static int bn_act_bwd_impl(const y3_tensor* u, const y3_tensor* dy, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t dtype,
+                           int32_t act, double* sums, const y3_tensor* du, float* dgamma, float* dbeta, const y3_tensor* gres, int32_t gres_accumulate, void* stream) {
     if (!u || !dy || !scale || !shift || !mean || !invstd || !sums || !du) Y3_FAIL("y3_bn_act_bwd: null argument");
     if (dy->n != u->n || dy->h != u->h || dy->w != u->w || dy->c != u->c || du->c != u->c || du->h != u->h) Y3_FAIL("y3_bn_act_bwd: shape mismatch");
     const int esz = esize(dtype);
     if (!vec_ok(u, esz) || !vec_ok(dy, esz) || !vec_ok(du, esz)) Y3_FAIL("y3_bn_act_bwd: alignment");
+    if (gres && (gres->n != u->n || gres->h != u->h || gres->w != u->w || gres->c != u->c || !vec_ok(gres, esz))) Y3_FAIL("y3_bn_act_bwd: residual gradient shape / alignment");
+    if (gres && gres->data == dy->data) Y3_FAIL("y3_bn_act_bwd: the residual gradient must not alias dy");
     const long long M = (long long)u->n * u->h * u->w;
     unsigned grid;
     if (reduce_geometry(u->c, esz, M, grid)) return -1;
@@ -1090,9 +1141,22 @@ extern "C" int y3_bn_act_bwd(const y3_tensor* u, const y3_tensor* dy, const floa
     unsigned egrid;
     if (elementwise_geometry(u->c, esz, M, egrid)) return -1;
     Y3_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T>), dim3(egrid), dim3(256), 0, st, (const T*)u->data, u->pitch, (const T*)dy->data,
-                                            dy->pitch, scale, shift, mean, invstd, (const double*)sums, (double)M, (T*)du->data, du->pitch, M, u->c, act));
+                                            dy->pitch, scale, shift, mean, invstd, (const double*)sums, (double)M, (T*)du->data, du->pitch, M, u->c, act,
+                                            gres ? (T*)gres->data : (T*)nullptr, gres ? gres->pitch : 0, gres_accumulate));
     Y3_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int y3_bn_act_bwd(const y3_tensor* u, const y3_tensor* dy, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t dtype,
+                             int32_t act, double* sums, const y3_tensor* du, float* dgamma, float* dbeta, void* stream) {
+    return bn_act_bwd_impl(u, dy, scale, shift, mean, invstd, dtype, act, sums, du, dgamma, dbeta, nullptr, 0, stream);
+}
+
+// ... and the gradient of the residual input of `out = act(bn(conv(x))) + residual` (reference models/common.py:165): gres (+)= dy
+extern "C" int y3_bn_act_bwd_res(const y3_tensor* u, const y3_tensor* dy, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t dtype,
+                                 int32_t act, double* sums, const y3_tensor* du, float* dgamma, float* dbeta, const y3_tensor* gres, int32_t gres_accumulate, void* stream) {
+    if (!gres) Y3_FAIL("y3_bn_act_bwd_res: null residual gradient");
+    return bn_act_bwd_impl(u, dy, scale, shift, mean, invstd, dtype, act, sums, du, dgamma, dbeta, gres, gres_accumulate, stream);
 }
 
 extern "C" int y3_pack_filter_dgrad(const float* w, int32_t cout_src, int32_t cin_src, int32_t ks, int32_t cout, int32_t cin, int32_t dtype, void* packed,

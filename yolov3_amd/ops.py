@@ -263,3 +263,23 @@ def letterbox_u8(src_hwc: torch.Tensor, dst_batch: torch.Tensor, index: int, new
     h0, w0, cs = src_hwc.shape
     check(_lib.lib().y3_letterbox_u8(src_hwc.data_ptr(), h0, w0, cs, dst_batch.data_ptr(), int(index), dst_batch.shape[2], dst_batch.shape[3], int(new_h), int(new_w), int(top),
                                      int(left), int(color), stream_ptr()), "y3_letterbox_u8")
+
+
+def conv2d_stats_rows(x: View, y: View, k: int, stride: int) -> int:
+    """rows of the statistics buffer a conv2d_stats launch of this shape writes (depends on the dispatched tile variant)."""
+    d = Y3ConvDesc(dtype_code(x.buf.dtype), k, stride, _lib.Y3_ACT_NONE, 0, _lib.Y3_ALGO_AUTO, x.c, y.c, 0)
+    xt, yt = x.y3(), y.y3()
+    rows = int(_lib.lib().y3_conv2d_fwd_stats_rows(C.byref(d), C.byref(xt), C.byref(yt)))
+    if rows < 0:
+        check(-1, "y3_conv2d_fwd_stats_rows")
+    return rows
+
+
+def conv2d_stats(x: View, filt: torch.Tensor, bias: torch.Tensor, y: View, k: int, stride: int, stat_rows: torch.Tensor, capacity_rows: int) -> int:
+    """y = conv(x) (no activation) + per-(pixel tile, wave) rows of (sum, sum of squares) per filter in stat_rows (fp32)."""
+    d = Y3ConvDesc(dtype_code(x.buf.dtype), k, stride, _lib.Y3_ACT_NONE, 0, _lib.Y3_ALGO_AUTO, x.c, y.c, 0)
+    xt, yt = x.y3(), y.y3()
+    n = C.c_int64(0)
+    check(_lib.lib().y3_conv2d_fwd_stats(C.byref(d), C.byref(xt), filt.data_ptr(), bias.data_ptr(), C.byref(yt), stat_rows.data_ptr(), int(capacity_rows), C.byref(n), stream_ptr()),
+          "y3_conv2d_fwd_stats")
+    return int(n.value)

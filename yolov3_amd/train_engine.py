@@ -98,27 +98,44 @@ class ConvUnit(_Unit):
         self.act = _lib.Y3_ACT_SILU if isinstance(m.act, nn.SiLU) else _lib.Y3_ACT_NONE
         self.count = v.n * v.h * v.w
         self.use_stem = False
+        self.stat_rows = None
 
     def fwd(self):
         m, bn = self.m, self.m.bn
         L = _lib.lib()
         st = ops.stream_ptr()
+        if self.cout != self.co_real:
+            raise NotImplementedError("BatchNorm over a channel-padded conv")
+        dcode = ops.dtype_code(self.plan.dtype)
+        ut = self.u.y3()
+        stats_in_epilogue = False
         if self.use_stem and self.plan.x_nchw is not None:
             # layer 0 straight from the caller's NCHW image (csrc/stem.hip); the NHWC copy is still made for the filter gradient
             ops.stem_conv(self.plan.x_nchw, ops.pack_filter_stem(m.conv.weight, self.cout, self.plan.dtype), self.zero_bias, self.u, act=False)
         else:
             filt = ops.pack_filter(m.conv.weight, self.cout, self.cin, self.plan.dtype)
-            ops.conv2d(self.x.view, filt, self.zero_bias, self.u, self.k, self.s, act=False)
-        ut = self.u.y3()
-        dcode = ops.dtype_code(self.plan.dtype)
-        if self.cout != self.co_real:
-            raise NotImplementedError("BatchNorm over a channel-padded conv")
-        check(
-            L.y3_bn_stats_finalize(C.byref(ut), dcode, self.sums.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps), float(bn.momentum),
-                                   bn.running_mean.data_ptr(), bn.running_var.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(), self.mean.data_ptr(),
-                                   self.invstd.data_ptr(), st),
-            "y3_bn_stats_finalize",
-        )
+            if self.plan.epilogue_stats:
+                # BatchNorm statistics taken in the conv epilogue (per-tile rows of sum / sum of squares): no separate pass over u
+                if self.stat_rows is None:
+                    self.stat_rows = ops.conv2d_stats_rows(self.x.view, self.u, self.k, self.s)
+                buf = self.plan.stat_buffer(self.stat_rows * 2 * self.cout)
+                n_rows = ops.conv2d_stats(self.x.view, filt, self.zero_bias, self.u, self.k, self.s, buf, self.stat_rows)
+                check(
+                    L.y3_bn_finalize_rows(buf.data_ptr(), n_rows, self.count, self.cout, self.sums.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps),
+                                          float(bn.momentum), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
+                                          self.mean.data_ptr(), self.invstd.data_ptr(), st),
+                    "y3_bn_finalize_rows",
+                )
+                stats_in_epilogue = True
+            else:
+                ops.conv2d(self.x.view, filt, self.zero_bias, self.u, self.k, self.s, act=False)
+        if not stats_in_epilogue:
+            check(
+                L.y3_bn_stats_finalize(C.byref(ut), dcode, self.sums.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps), float(bn.momentum),
+                                       bn.running_mean.data_ptr(), bn.running_var.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(), self.mean.data_ptr(),
+                                       self.invstd.data_ptr(), st),
+                "y3_bn_stats_finalize",
+            )
         yt = self.y.view.y3()
         rt = self.res.view.y3() if self.res is not None else None
         check(L.y3_bn_act_fwd(C.byref(ut), self.scale.data_ptr(), self.shift.data_ptr(), C.byref(rt) if rt is not None else None, C.byref(yt), dcode, self.act, st),
@@ -130,17 +147,25 @@ class ConvUnit(_Unit):
         st = ops.stream_ptr()
         dcode = ops.dtype_code(self.plan.dtype)
         gy = self.y.grad()
-        if self.res is not None:  # out = act(bn(conv)) + res  ->  d res += d out
-            self.plan.add_into(gy, self.res)
         du = self.plan.scratch_like(self.u)
         dgamma = torch.empty(self.cout, dtype=torch.float32, device=self.plan.device)
         dbeta = torch.empty(self.cout, dtype=torch.float32, device=self.plan.device)
         ut, gt, dt = self.u.y3(), gy.y3(), du.y3()
-        check(
-            L.y3_bn_act_bwd(C.byref(ut), C.byref(gt), self.scale.data_ptr(), self.shift.data_ptr(), self.mean.data_ptr(), self.invstd.data_ptr(), dcode, self.act,
-                            self.sums.data_ptr(), C.byref(dt), dgamma.data_ptr(), dbeta.data_ptr(), st),
-            "y3_bn_act_bwd",
-        )
+        if self.res is not None:  # out = act(bn(conv)) + res  ->  d res (+)= d out, written by the pass that reads d out anyway
+            gr = self.res.grad()
+            grt = gr.y3()
+            check(
+                L.y3_bn_act_bwd_res(C.byref(ut), C.byref(gt), self.scale.data_ptr(), self.shift.data_ptr(), self.mean.data_ptr(), self.invstd.data_ptr(), dcode, self.act,
+                                    self.sums.data_ptr(), C.byref(dt), dgamma.data_ptr(), dbeta.data_ptr(), C.byref(grt), int(self.res.is_ready()), st),
+                "y3_bn_act_bwd_res",
+            )
+            self.res.mark_ready()
+        else:
+            check(
+                L.y3_bn_act_bwd(C.byref(ut), C.byref(gt), self.scale.data_ptr(), self.shift.data_ptr(), self.mean.data_ptr(), self.invstd.data_ptr(), dcode, self.act,
+                                self.sums.data_ptr(), C.byref(dt), dgamma.data_ptr(), dbeta.data_ptr(), st),
+                "y3_bn_act_bwd",
+            )
         dw, _ = ops.conv2d_wgrad(self.x.view, du, self.k, self.s, self.co_real, self.ci_real)
         grads[m.conv.weight] = dw
         grads[m.bn.weight] = dgamma   # cout == co_real (checked in fwd): whole tensors, so autograd takes them without a copy
@@ -357,6 +382,9 @@ class TrainPlan:
         self.x_nchw = None
         import os
 
+        # Y3_BN_EPILOGUE=0: statistics by a separate reduction pass over u (A/B runs); fp32 plans always take that path
+        self.epilogue_stats = dtype in (torch.float16, torch.bfloat16) and os.environ.get("Y3_BN_EPILOGUE", "1") != "0"
+
         u0 = self.units[0] if self.units else None
         if (isinstance(u0, ConvUnit) and u0.x is self.x_in and u0.k == 3 and u0.s == 1 and u0.ci_real <= 4 and u0.cout <= 64 and u0.cout % 8 == 0
                 and dtype in (torch.float16, torch.bfloat16) and os.environ.get("Y3_STEM", "1") != "0"):
@@ -371,6 +399,13 @@ class TrainPlan:
             if t is not None:
                 raise RuntimeError("bn_sums must be sized by the widest layer first")
             t = self._bn_sums = ops.bn_scratch(self._max_c, self.device)
+        return t
+
+    def stat_buffer(self, n_floats):
+        """fp32 scratch for the conv epilogue's statistics rows, shared by all units (stream-ordered reuse)."""
+        t = getattr(self, "_stat_buf", None)
+        if t is None or t.numel() < n_floats:
+            t = self._stat_buf = torch.empty(n_floats, dtype=torch.float32, device=self.device)
         return t
 
     def zeros_f32(self, c):
