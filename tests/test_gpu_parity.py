@@ -1072,3 +1072,21 @@ def test_conv_epilogue_bn_statistics(dev, dtype, name, shape):
     torch.testing.assert_close(rm.double().cpu(), 0.03 * mu, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(rv.double().cpu(), 0.97 + 0.03 * u.var(0, unbiased=True), rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(scale.double().cpu(), gamma.double().cpu() / torch.sqrt(var + 1e-3), rtol=1e-4, atol=1e-5)
+
+
+def test_detect_batches_overlapped_equals_sequential(dev):
+    """val.detect_batches (NMS of batch i on a second stream beside the forward of batch i+1) returns, batch by batch, exactly
+    the detections of the sequential model -> non_max_suppression pair."""
+    from yolov3_amd import detect_batches, non_max_suppression
+
+    m, _ = build_pair("yolov3-tiny", 80, 23, dev, torch.float16)
+    g = torch.Generator().manual_seed(3)
+    batches = [torch.rand(4, 3, 160, 160, generator=g).to(dev).half() for _ in range(5)]
+    kw = dict(conf_thres=0.0, iou_thres=0.45, max_det=100)
+    want = [non_max_suppression(m(x)[0], **kw) for x in batches]
+    got = list(detect_batches(m, batches, **kw))
+    torch.cuda.synchronize()
+    assert len(got) == len(want)
+    for b, (a_list, w_list) in enumerate(zip(got, want)):
+        _cmp_nms(a_list, [w.cpu() for w in w_list], f"batch {b}")
+    assert sum(d.shape[0] for dets in got for d in dets) > 0

@@ -11,7 +11,7 @@ Everything executes through libyolov3_hip.so (include/yolov3_hip.h); there is no
 """
 from .common import SPP, Bottleneck, Concat, Conv  # noqa: F401
 from .general import non_max_suppression, non_max_suppression_batched, scale_boxes, scale_boxes_batched, xywh2xyxy, clip_boxes  # noqa: F401
-from .val import process_batch, process_batch_batched  # noqa: F401
+from .val import detect_batches, process_batch, process_batch_batched  # noqa: F401
 from .backend import DetectMultiBackend  # noqa: F401
 from .autoshape import AutoShape, Detections, letterbox_batch  # noqa: F401
 from .compat import attempt_load  # noqa: F401

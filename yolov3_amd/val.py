@@ -43,3 +43,36 @@ def process_batch_batched(rows, counts, labels, label_offsets, iouv):
         raise ValueError("label_offsets must hold bs + 1 entries")
     thr = iouv.to(dev, torch.float32).contiguous()
     return ops.match_detections_raw(rows, rows.stride(0), rows.stride(1), counts, rows.shape[0], rows.shape[1], lab, offs, thr)
+
+
+def detect_batches(model, batches, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, max_det=300):
+    """Throughput form of the `model(im)` -> `non_max_suppression(preds)` pair of reference val.py:364-376 / detect.py:196-200
+    over a stream of batches: the NMS of batch i (a chain of small launches ending in the one device->host copy of the counts)
+    runs on a second HIP stream while the forward of batch i+1 fills the CUs on the current stream.  Yields, in order and one
+    batch late, the list of (n, 6) detections of every batch -- the same tensors the sequential pair returns."""
+    from .general import non_max_suppression
+
+    cur = torch.cuda.current_stream()
+    side = torch.cuda.Stream(device=cur.device)
+    pending = None
+
+    def finish(p):
+        pred, ev = p
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            dets = non_max_suppression(pred, conf_thres, iou_thres, classes, agnostic, multi_label, max_det=max_det)
+        for d in dets:
+            d.record_stream(cur)  # allocated on the side stream, consumed by the caller on the current one
+        cur.wait_stream(side)
+        return dets
+
+    for x in batches:
+        out = model(x)
+        pred = out[0] if isinstance(out, (list, tuple)) else out
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        if pending is not None:
+            yield finish(pending)
+        pending = (pred, ev)
+    if pending is not None:
+        yield finish(pending)
