@@ -98,7 +98,11 @@ class GradBuckets:
         if self.world == 1:
             self._out[key] = grad
             return
-        self._pending.append((key, grad))
+        ev = None
+        if grad.is_cuda:   # producers may sit on different streams (filter gradients come from the engine's side stream)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(grad.device))
+        self._pending.append((key, grad, ev))
         self._bytes += grad.numel() * grad.element_size()
         if self._bytes >= self.bucket_bytes:
             self._launch()
@@ -106,14 +110,18 @@ class GradBuckets:
     def _launch(self):
         if not self._pending:
             return
-        keys = [k for k, _ in self._pending]
-        tensors = [g for _, g in self._pending]
+        keys = [k for k, _, _ in self._pending]
+        tensors = [g for _, g, _ in self._pending]
+        events = [e for _, _, e in self._pending if e is not None]
         self._pending, self._bytes = [], 0
         dev = tensors[0].device
         side = self._stream(dev)
         wire = self.wire_dtype or torch.float32
         if side is not None:
-            side.wait_stream(torch.cuda.current_stream(dev))  # the bucket's producers have been issued on the compute stream
+            for e in events:   # every gradient of the bucket has been produced (whatever stream issued it)
+                side.wait_event(e)
+            for t in tensors:
+                t.record_stream(side)
             with torch.cuda.stream(side):
                 flat = torch.cat([t.reshape(-1).to(wire) for t in tensors])
                 work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
