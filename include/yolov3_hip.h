@@ -78,6 +78,13 @@ size_t y3_packed_filter_stem_elems(int32_t cout);
 int y3_pack_filter_stem(const float* w_oihw, int32_t cout_src, int32_t cin_src, int32_t cout, int32_t dtype, void* packed, void* stream);
 int y3_stem_conv_fwd(const void* x_nchw, int32_t src_dtype, int32_t n, int32_t cin, int32_t h, int32_t w, float divisor, const void* packed,
                      const float* bias, int32_t dtype, int32_t act, const y3_tensor* y, void* stream);
+/* Layers 0 + 1 of yolov3 / yolov3-spp in one kernel (models/yolov3.yaml:16-17: Conv(3,32,3,1) -> Conv(32,64,3,2)): layer 0's
+ * output (the largest tensor of the network, single consumer) stays in LDS.  packed0 / bias0: 32 filters in the stem format
+ * (y3_pack_filter_stem); packed1 / bias1: 64 filters over 32 channels in the generic format (y3_pack_filter); y: NHWC
+ * (n, (h-1)/2+1, (w-1)/2+1, 64). */
+int y3_stem_pair_fwd(const void* x_nchw, int32_t src_dtype, int32_t n, int32_t cin, int32_t h, int32_t w, float divisor,
+                     const void* packed0, const float* bias0, int32_t act0, const void* packed1, const float* bias1, int32_t act1,
+                     int32_t dtype, const y3_tensor* y, void* stream);
 
 /* NCHW (u8 / f16 / bf16 / f32) image batch -> NHWC `out_dtype`: cast, then true-divide by `divisor`
  * (1.0 = none) in the output dtype, channels zero-padded to out->c.

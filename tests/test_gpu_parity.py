@@ -1090,3 +1090,64 @@ def test_detect_batches_overlapped_equals_sequential(dev):
     for b, (a_list, w_list) in enumerate(zip(got, want)):
         _cmp_nms(a_list, [w.cpu() for w in w_list], f"batch {b}")
     assert sum(d.shape[0] for dets in got for d in dets) > 0
+
+
+PAIR_CASES = [
+    ("square", (2, 64, 64), torch.float16, 1.0),
+    ("odd_rect", (1, 37, 53), torch.float16, 1.0),
+    ("wide_multi_tile", (3, 96, 160), torch.float16, 1.0),
+    ("smaller_than_a_tile", (1, 5, 7), torch.float16, 1.0),
+    ("u8_div255", (2, 48, 80), torch.uint8, 255.0),
+    ("fp32_source", (1, 40, 72), torch.float32, 1.0),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name,shape,sdt,div", PAIR_CASES, ids=[c[0] for c in PAIR_CASES])
+def test_stem_pair_vs_fp32_reference(dev, dtype, name, shape, sdt, div):
+    """y3_stem_pair_fwd (layers 0 + 1 of yolov3 in one kernel, layer 0 kept in LDS) against torch fp32 convolutions on the same
+    rounded operands, layer 0's output rounded to the storage dtype in between as the unfused path stores it; borders (layer 1's
+    zero padding applies to layer 0's OUTPUT), odd sizes, images smaller than a tile, uint8 / fp32 sources."""
+    _lib, ops = _ops()
+    n, h, w = shape
+    g = torch.Generator().manual_seed(11)
+    if sdt == torch.uint8:
+        x = torch.randint(0, 256, (n, 3, h, w), generator=g, dtype=torch.uint8)
+        xr = (x.to(dtype) / 255).float()
+    else:
+        x = torch.rand(n, 3, h, w, generator=g).to(sdt)
+        xr = x.to(dtype).float()
+    w0 = (torch.randn(32, 3, 3, 3, generator=g) / math.sqrt(27)).to(dtype).float()
+    b0 = torch.randn(32, generator=g) * 0.1
+    w1 = (torch.randn(64, 32, 3, 3, generator=g) / math.sqrt(288)).to(dtype).float()
+    b1 = torch.randn(64, generator=g) * 0.1
+    y0 = F.silu(F.conv2d(xr, w0, b0, stride=1, padding=1)).to(dtype).float()
+    ref = F.silu(F.conv2d(y0, w1, b1, stride=2, padding=1))
+    ho, wo = ref.shape[2], ref.shape[3]
+    f0 = ops.pack_filter_stem(w0.to(dev), 32, dtype)
+    f1 = ops.pack_filter(w1.to(dev), 64, 32, dtype)
+    yv = ops.View.alloc(n, ho, wo, 64, dtype, dev)
+    yv.buf.fill_(float("nan"))
+    ops.stem_pair(x.to(dev), f0, b0.to(dev), True, f1, b1.to(dev), True, yv, div)
+    torch.cuda.synchronize()
+    got = yv.as_nhwc().float().cpu().permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all(), "an output pixel was not written"
+    tol = 2.0**-8 if dtype == torch.float16 else 2.0**-5
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err < tol, f"{name} {dtype}: {err:.2e}"
+
+
+def test_stem_pair_matches_unfused_model(dev, monkeypatch):
+    """yolov3 forward with layers 0 + 1 fused against the same model with Y3_STEM_PAIR=0 (stem kernel + generic layer 1):
+    identical raw head tensors up to fp32 summation order (2^-9 of the logit range)."""
+    x = torch.rand(2, 3, 96, 128, generator=torch.Generator().manual_seed(4))
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("Y3_STEM_PAIR", flag)
+        m, _ = build_pair("yolov3", 80, 21, dev, torch.float16)
+        pred, raw = m(x.to(dev).half())
+        kinds = [ln.kernel for ln in next(iter(m._plans.values())).launches]
+        assert ("stem_pair" in kinds) == (flag == "1")
+        outs.append([r.float().cpu() for r in raw])
+    for a, b in zip(*outs):
+        assert (a - b).abs().max().item() <= 2.0**-9 * b.abs().max().item()

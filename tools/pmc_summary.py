@@ -15,6 +15,7 @@ NAMES = [  # (regex on the kernel symbol, bench.py name)
     (r"conv_igemm_v3_kernelIDF16_Li32ELi2ELi2E", "conv_igemm_v3<f16,bk32,tc128xtp128>"),
     (r"conv_igemm_v3_kernelIDF16_Li32ELi1ELi4E", "conv_igemm_v3<f16,bk32,tc64xtp256>"),
     (r"conv_igemm_v2_kernelIDF16_Li32ELi1ELi4ELi1ELi2ELb1E", "conv_igemm_v2<f16,bk32,tc32xtp256_smallc>"),
+    (r"stem_pair_kernel", "stem_pair"),
     (r"stem_conv_kernel", "stem_conv"),
     (r"decode_vec_kernel", "decode_vec"),
     (r"nms_candidates_kernel", "nms_candidates"),

@@ -156,6 +156,216 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemArgs p) {
     }
 }
 
+// ---- layers 0 + 1 in one kernel --------------------------------------------------------------------------------------------
+// models/yolov3.yaml:16-17: Conv(3, 32, 3, 1) -> Conv(32, 64, 3, 2).  Layer 0's output is the largest tensor of the network
+// (64 B per input pixel: 839 MB at 640x640 batch 32) and has exactly one consumer; written and read back it costs 1.7 GB of
+// HBM traffic around 0.5 GB of useful input + output (stem 0.29 ms + layer 1 0.33 ms of a 7.4 ms forward).  Here a block owns a
+// 4 x 32 tile of LAYER-1 output pixels: it stages the 11 x 67 image patch as the stem kernel does, computes the 9 x 65 layer-0
+// pixels the tile needs (bias + SiLU, rounded to T exactly as the stored tensor would be; positions outside the image are
+// layer 1's zero padding) into LDS as [pixel][32 channels] rows, and runs layer 1 as an implicit GEMM out of LDS: wave (filter
+// tile of 32, row pair) keeps its 18 filter fragments (9 taps x 32 channels) in registers for the block's whole life
+// (persistent blocks, tiles in a grid-stride loop) and reads one 16-byte pixel fragment per MFMA.  Layer 0 is recomputed for
+// the one-pixel overlap between tiles (585 pixels for 512 fresh ones: 14 % of a layer that is 1 % of the network's FLOPs).
+struct PairArgs {
+    const void* x;      // (N, Cin, H, W) source image
+    const void* w0;     // stem-packed layer-0 filters [32][3][16]
+    const float* b0;    // 32 floats
+    const void* w1;     // generic packed layer-1 bank [>= 64 rows][kpad1], k = (kh * 3 + kw) * 32 + ci
+    const float* b1;    // 64 floats
+    void* y;            // NHWC (N, Ho, Wo, 64) view
+    int N, Cin, H, W, Ho, Wo, ypitch, act0, act1, kpad1;
+    int tiles_w, tiles_h, n_tiles;
+    float divisor;
+};
+constexpr int QR = 4, QW = 32;                    // layer-1 output rows x columns per tile
+constexpr int R0 = 2 * QR + 1, C0 = 2 * QW + 1;   // layer-0 pixels needed: 9 x 65
+constexpr int XR = R0 + 2, XW = C0 + 3;           // image patch: one halo row/column each side + the 4th pixel of the widest fragment read
+constexpr int L0P = 80;                           // bytes per layer-0 pixel row in LDS (64 + 16: stride-2 fragment reads spread over the banks)
+
+template <typename T, typename S>
+__global__ __launch_bounds__(256, 2) void stem_pair_kernel(const PairArgs p) {
+    typedef typename Mfma16<T>::frag frag;
+    typedef T vec4 __attribute__((ext_vector_type(4)));
+    constexpr int PATCH_BYTES = XR * XW * 8, SLICE_BYTES = 4 * 32 * 64;
+    constexpr int SCR = PATCH_BYTES > SLICE_BYTES ? PATCH_BYTES : SLICE_BYTES;   // the output slices reuse the patch (dead after layer 0)
+    __shared__ __attribute__((aligned(16))) unsigned char scratch[SCR];
+    __shared__ __attribute__((aligned(16))) unsigned char l0buf[R0 * C0 * L0P];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 31, fk = lane >> 5;
+    const int wc = wv >> 1, wp = wv & 1;   // layer 1: filter tile, row pair
+
+    // ---- per-block constants: layer-0 fragments + bias, this wave's 18 layer-1 fragments + bias ----
+    frag a0f[3];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) a0f[kh] = *(const frag*)((const T*)p.w0 + (frow * 3 + kh) * 16 + fk * 8);
+    f32x4 bz0[4], bz1[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        bz0[g] = *(const f32x4*)(p.b0 + 8 * g + 4 * fk);
+        bz1[g] = *(const f32x4*)(p.b1 + wc * 32 + 8 * g + 4 * fk);
+    }
+    frag a1f[18];
+#pragma unroll
+    for (int t = 0; t < 18; ++t) a1f[t] = *(const frag*)((const T*)p.w1 + (long long)(wc * 32 + frow) * p.kpad1 + t * 16 + fk * 8);
+
+    T* __restrict__ yg = (T*)p.y;
+    // image patch of a tile: every thread owns up to 3 patch pixels (x 3-4 channels).  The loads of tile i+1 are issued before
+    // layer 1 of tile i runs and land in registers behind its MFMAs (a block's phases are a serial chain and only two blocks fit a
+    // CU: without the prefetch every tile started with a full HBM round trip, 11 us per tile)
+    constexpr int NPX = (XR * XW + 255) / 256;
+    S raw[NPX][4];
+    bool rin[NPX];
+    auto fetch = [&](int tile) {
+        int b = tile;
+        const int tw = b % p.tiles_w; b /= p.tiles_w;
+        const int th = b % p.tiles_h;
+        const int n = b / p.tiles_h;
+        const int gh0 = 2 * th * QR - 1, gw0 = 2 * tw * QW - 1;
+        const S* __restrict__ xs = (const S*)p.x + (long long)n * p.Cin * p.H * p.W;
+#pragma unroll
+        for (int j = 0; j < NPX; ++j) {
+            const int e = tid + j * 256;
+            const int pr = e / XW, pc = e - pr * XW;
+            const int gh = gh0 + pr - 1, gw = gw0 + pc - 1;
+            rin[j] = e < XR * XW && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W;
+            if (rin[j]) {
+                const long long o = (long long)gh * p.W + gw;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < p.Cin) raw[j][c] = xs[(long long)c * p.H * p.W + o];
+            }
+        }
+    };
+    auto stash = [&]() {   // registers -> LDS as 4-channel pixels (channel 3 = 0 unless Cin = 4), zero outside the image
+#pragma unroll
+        for (int j = 0; j < NPX; ++j) {
+            const int e = tid + j * 256;
+            if (e < XR * XW) {
+                vec4 v = {(T)0.0f, (T)0.0f, (T)0.0f, (T)0.0f};
+                if (rin[j]) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c < p.Cin) v[c] = from_f32<T>(src_f32<S>(raw[j][c]) / p.divisor);
+                }
+                *(vec4*)(scratch + e * 8) = v;
+            }
+        }
+    };
+    if ((int)blockIdx.x < p.n_tiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+        int b = tile;
+        const int tw = b % p.tiles_w; b /= p.tiles_w;
+        const int th = b % p.tiles_h;
+        const int n = b / p.tiles_h;
+        const int oh0 = th * QR, ow0 = tw * QW;           // layer-1 tile origin
+        const int gh0 = 2 * oh0 - 1, gw0 = 2 * ow0 - 1;   // layer-0 (= image) coordinates of region pixel (0, 0)
+
+        stash();   // this tile's patch (requested one tile ago)
+        __syncthreads();
+
+        // ---- layer 0 on the 9 x 65 region (flattened, 32 pixels per MFMA tile) -> l0buf[pixel][32 channels] ----
+        for (int t = wv; t < (R0 * C0 + 31) / 32; t += 4) {
+            int q = t * 32 + frow;
+            const bool live = q < R0 * C0;
+            if (!live) q = R0 * C0 - 1;
+            const int r = q / C0, c = q - r * C0;
+            f32x16 acc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[4 * g + e] = bz0[g][e];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const unsigned char* src = scratch + (((r + kh) * XW + c + 2 * fk) * 8);
+                typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+                u64x2 raw;
+                raw[0] = *(const unsigned long long*)src;
+                raw[1] = *(const unsigned long long*)(src + 8);
+                acc = Mfma16<T>::run(a0f[kh], __builtin_bit_cast(frag, raw), acc);
+            }
+            const bool inside = live && (unsigned)(gh0 + r) < (unsigned)p.H && (unsigned)(gw0 + c) < (unsigned)p.W;
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                frag ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t0 = acc[8 * gp + e], t1 = acc[8 * gp + 4 + e];
+                    if (p.act0 == Y3_ACT_SILU) {
+                        t0 = t0 * __builtin_amdgcn_rcpf(1.0f + __expf(-t0));
+                        t1 = t1 * __builtin_amdgcn_rcpf(1.0f + __expf(-t1));
+                    }
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, t0), __builtin_bit_cast(unsigned, t1), false, false);
+                    ov[e] = from_f32<T>(inside ? __builtin_bit_cast(float, (unsigned)sw[0]) : 0.0f);
+                    ov[4 + e] = from_f32<T>(inside ? __builtin_bit_cast(float, (unsigned)sw[1]) : 0.0f);
+                }
+                if (live) *(frag*)(l0buf + q * L0P + (gp * 2 + fk) * 16) = ov;
+            }
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < p.n_tiles) fetch(tile + gridDim.x);   // next tile's image loads fly under layer 1
+
+        // ---- layer 1: D[32 filters of tile wc][32 columns] for rows 2 wp and 2 wp + 1, K = 9 taps x 32 channels out of l0buf ----
+        f32x16 acc1[2];
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc1[b2][4 * g + e] = bz1[g][e];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kh = tap / 3, kw = tap - 3 * (tap / 3);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int b2 = 0; b2 < 2; ++b2) {
+                    const int lr = 2 * wp + b2;
+                    const frag bf = *(const frag*)(l0buf + ((2 * lr + kh) * C0 + 2 * frow + kw) * L0P + (ks * 2 + fk) * 16);
+                    acc1[b2] = Mfma16<T>::run(a1f[tap * 2 + ks], bf, acc1[b2]);
+                }
+        }
+        // ---- activation, 8 consecutive filters per lane, transpose through the wave's slice, 64-byte runs per pixel ----
+        unsigned char* wl = scratch + wv * (32 * 64);
+        const int rp = lane >> 2, ch = lane & 3;
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2) {
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                frag ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t0 = acc1[b2][8 * gp + e], t1 = acc1[b2][8 * gp + 4 + e];
+                    if (p.act1 == Y3_ACT_SILU) {
+                        t0 = t0 * __builtin_amdgcn_rcpf(1.0f + __expf(-t0));
+                        t1 = t1 * __builtin_amdgcn_rcpf(1.0f + __expf(-t1));
+                    }
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, t0), __builtin_bit_cast(unsigned, t1), false, false);
+                    ov[e] = from_f32<T>(__builtin_bit_cast(float, (unsigned)sw[0]));
+                    ov[4 + e] = from_f32<T>(__builtin_bit_cast(float, (unsigned)sw[1]));
+                }
+                const int chunk = gp * 2 + fk;
+                *(frag*)(wl + frow * 64 + ((chunk ^ (frow & 3)) << 4)) = ov;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int oh = oh0 + 2 * wp + b2;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int pl = i * 16 + rp;
+                const frag ov = *(const frag*)(wl + pl * 64 + ((ch ^ (pl & 3)) << 4));
+                const int ow = ow0 + pl;
+                if (oh < p.Ho && ow < p.Wo) *(frag*)(yg + ((long long)(n * p.Ho + oh) * p.Wo + ow) * p.ypitch + wc * 32 + ch * 8) = ov;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();   // the slice is rewritten by the next row
+        }
+        __syncthreads();   // scratch (slices) and l0buf are rewritten by the next tile
+    }
+}
+
 template <typename T>
 __global__ void pack_stem_kernel(const float* __restrict__ src, int cout_src, int cin_src, int rows, T* __restrict__ dst) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -225,4 +435,46 @@ extern "C" int y3_stem_conv_fwd(const void* x_nchw, int32_t src_dtype, int32_t n
         case Y3_BF16: return dispatch_src<bf16_t>(a, src_dtype, st);
     }
     Y3_FAIL("y3_stem_conv_fwd: f16/bf16 compute only");
+}
+
+namespace {
+template <typename T> int dispatch_pair(const PairArgs& a, int sdt, int blocks, hipStream_t st) {
+    switch (sdt) {
+        case Y3_F16: hipLaunchKernelGGL((stem_pair_kernel<T, f16_t>), dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+        case Y3_BF16: hipLaunchKernelGGL((stem_pair_kernel<T, bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+        case Y3_F32: hipLaunchKernelGGL((stem_pair_kernel<T, float>), dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+        case Y3_U8: hipLaunchKernelGGL((stem_pair_kernel<T, unsigned char>), dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+        default: Y3_FAIL("y3_stem_pair_fwd: bad source dtype %d", sdt);
+    }
+    Y3_CHECK_LAUNCH();
+    return 0;
+}
+}  // namespace
+
+extern "C" int y3_stem_pair_fwd(const void* x_nchw, int32_t src_dtype, int32_t n, int32_t cin, int32_t h, int32_t w, float divisor, const void* packed0, const float* bias0,
+                                int32_t act0, const void* packed1, const float* bias1, int32_t act1, int32_t dtype, const y3_tensor* y, void* stream) {
+    if (!x_nchw || !packed0 || !bias0 || !packed1 || !bias1 || !y || !y->data) Y3_FAIL("y3_stem_pair_fwd: null argument");
+    if (cin < 1 || cin > 4) Y3_FAIL("y3_stem_pair_fwd: %d input channels (1..4 supported)", cin);
+    const int Ho = (h - 1) / 2 + 1, Wo = (w - 1) / 2 + 1;   // 3x3, stride 2, pad 1
+    if (y->n != n || y->h != Ho || y->w != Wo || y->c != 64) Y3_FAIL("y3_stem_pair_fwd: output must be (%d,%d,%d,64)", n, Ho, Wo);
+    if ((y->pitch % 8) || ((uintptr_t)y->data & 15) || ((uintptr_t)packed0 & 15) || ((uintptr_t)packed1 & 15) || ((uintptr_t)bias0 & 15) || ((uintptr_t)bias1 & 15))
+        Y3_FAIL("y3_stem_pair_fwd: 16-byte aligned views");
+    if (!(divisor > 0.0f)) Y3_FAIL("y3_stem_pair_fwd: divisor must be positive");
+    if ((long long)n * h * w > 0x7fffffffLL) Y3_FAIL("y3_stem_pair_fwd: too many pixels");
+    PairArgs a;
+    a.x = x_nchw; a.w0 = packed0; a.b0 = bias0; a.w1 = packed1; a.b1 = bias1; a.y = y->data;
+    a.N = n; a.Cin = cin; a.H = h; a.W = w; a.Ho = Ho; a.Wo = Wo; a.ypitch = y->pitch; a.act0 = act0; a.act1 = act1;
+    a.kpad1 = y3_filter_kpad(32, 3);
+    a.tiles_w = (Wo + QW - 1) / QW; a.tiles_h = (Ho + QR - 1) / QR;
+    const long long tiles = (long long)a.tiles_w * a.tiles_h * n;
+    if (tiles > 0x7fffffffLL) Y3_FAIL("y3_stem_pair_fwd: too many tiles");
+    a.n_tiles = (int)tiles;
+    a.divisor = divisor;
+    const int blocks = tiles < 512 ? (int)tiles : 512;   // persistent: 2 blocks per CU, tiles in a grid-stride loop
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case Y3_F16: return dispatch_pair<f16_t>(a, src_dtype, blocks, st);
+        case Y3_BF16: return dispatch_pair<bf16_t>(a, src_dtype, blocks, st);
+    }
+    Y3_FAIL("y3_stem_pair_fwd: f16/bf16 compute only");
 }

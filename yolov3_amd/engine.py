@@ -263,6 +263,24 @@ class Plan:
                         kernel="stem_conv",
                     )
                 )
+            elif kind == "stem_pair":
+                w0, w1, yv = kw["w0"], kw["w1"], kw["y"].real()
+                yt = yv.y3()
+                self.stem_x, self.stem_sdt, self.stem_div = C.c_void_p(0), C.c_int32(0), C.c_float(1.0)
+                m1 = yv.n * yv.h * yv.w
+                m0 = yv.n * kw["h"] * kw["w"]
+                self.launches.append(
+                    _Launch(
+                        L.y3_stem_pair_fwd,
+                        (self.stem_x, self.stem_sdt, yv.n, kw["cin"], kw["h"], kw["w"], self.stem_div, w0.filt.data_ptr(), w0.bias.data_ptr(),
+                         _lib.Y3_ACT_SILU if w0.act else _lib.Y3_ACT_NONE, w1.filt.data_ptr(), w1.bias.data_ptr(), _lib.Y3_ACT_SILU if w1.act else _lib.Y3_ACT_NONE, dcode, C.byref(yt)),
+                        keep=(yt, w0, w1),
+                        label=kw["label"],
+                        flops=2.0 * m0 * w0.cout * _pad8(kw["cin"]) * 9 + 2.0 * m1 * w1.cout * w1.cin * 9,   # counted like the two generic launches
+                        bytes=esz * (m0 * kw["cin"] + m1 * w1.cout + w0.cout * kw["cin"] * 9 + w1.cout * w1.cin * 9),
+                        kernel="stem_pair",
+                    )
+                )
             elif kind == "maxpool":
                 xt, yt = kw["x"].real().y3(), kw["y"].real().y3()
                 self.launches.append(_Launch(L.y3_maxpool2d, (C.byref(xt), C.byref(yt), dcode, kw["k"], kw["s"], kw["p"], kw["zr"], kw["zb"]), keep=(xt, yt), label=kw["label"]))
@@ -332,6 +350,21 @@ def _stem_eligible(m, dtype, srcs, input_consumers) -> bool:
     return (os.environ.get("Y3_STEM", "1") != "0" and dtype in (torch.float16, torch.bfloat16) and list(srcs) == [-1] and list(input_consumers) == [0]
             and c.in_channels <= 4 and c.out_channels <= 64 and c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1)
             and c.dilation == (1, 1) and c.groups == 1)
+
+
+def _stem_pair_eligible(layers, src, consumers, placed, fused_ups) -> bool:
+    """Layers 0 and 1 = Conv(<=4, 32, 3, 1) -> Conv(32, 64, 3, 2), layer 0 consumed by layer 1 alone: csrc/stem.hip computes both
+    with layer 0's output kept in LDS.  Y3_STEM_PAIR=0 restores stem + generic conv (A/B runs)."""
+    import os
+
+    if os.environ.get("Y3_STEM_PAIR", "1") == "0" or len(layers) < 2:
+        return False
+    m0, m1 = layers[0], layers[1]
+    if not (isinstance(m0, Conv) and isinstance(m1, Conv)) or list(src[1]) != [0] or list(consumers[0]) != [1] or 0 in placed or 1 in fused_ups or 0 in fused_ups:
+        return False
+    c0, c1 = m0.conv, m1.conv
+    return (c0.out_channels == 32 and c1.in_channels == 32 and c1.out_channels == 64 and c1.kernel_size == (3, 3) and c1.stride == (2, 2) and c1.padding == (1, 1)
+            and c1.dilation == (1, 1) and c1.groups == 1 and isinstance(m0.act, (nn.SiLU, nn.Identity)) and isinstance(m1.act, (nn.SiLU, nn.Identity)))
 
 
 def compile_model(model, n, h, w, dtype, device) -> Plan:
@@ -409,6 +442,8 @@ def compile_model(model, n, h, w, dtype, device) -> Plan:
     plan.input_view = x_in
     out = {-1: x_in}
 
+    pair = None   # layer-0 weights while layers 0 + 1 are emitted as one stem_pair launch
+    pair_ok = not model.training and _stem_pair_eligible(layers, src, consumers, placed, fused_ups)   # before home() claims a buffer for layer 0
     for i, m in enumerate(layers):
         k = kind(m)
         ins = [out[j] for j in src[i]]
@@ -464,6 +499,11 @@ def compile_model(model, n, h, w, dtype, device) -> Plan:
                 last = r == len(m) - 1
                 x = comp.bottleneck(sub, x, y=y if last else None, label=f"{lab}.{r}")
             out[i] = y
+        elif isinstance(k, Conv) and i == 1 and pair:
+            w0 = pair
+            w1 = make_conv_weights(k.conv, getattr(k, "bn", None), isinstance(k.act, nn.SiLU), dtype, cin_pad=32)
+            plan.add("stem_pair", [], [y], w0=w0, w1=w1, y=y, cin=w0.cin, h=h, w=w, label="L0+L1")
+            out[i] = y
         elif isinstance(k, Conv) and i == 0 and _stem_eligible(k, dtype, src[0], consumers[-1]):
             cw, cb = _fold(k.conv, getattr(k, "bn", None))
             co = cw.shape[0]
@@ -472,8 +512,12 @@ def compile_model(model, n, h, w, dtype, device) -> Plan:
             wts = ConvWeights(ops.pack_filter_stem(cw, _pad8(co), dtype), bias, cw.shape[1], _pad8(co), 3, 1, isinstance(k.act, nn.SiLU))
             if KEEP_FOLDED:
                 wts.folded = (cw, cb)
-            plan.add("stem", [], [y], w=wts, y=y, cin=cw.shape[1], label=lab)
-            out[i] = y
+            if pair_ok:
+                pair = wts          # emitted together with layer 1
+                out[i] = None
+            else:
+                plan.add("stem", [], [y], w=wts, y=y, cin=cw.shape[1], label=lab)
+                out[i] = y
         elif isinstance(k, Conv):
             out[i] = comp.conv_unit(k, ins[0], y=y, label=lab, cin_pad=ins[0].c)
         elif isinstance(k, Bottleneck):

@@ -283,3 +283,14 @@ def conv2d_stats(x: View, filt: torch.Tensor, bias: torch.Tensor, y: View, k: in
     check(_lib.lib().y3_conv2d_fwd_stats(C.byref(d), C.byref(xt), filt.data_ptr(), bias.data_ptr(), C.byref(yt), stat_rows.data_ptr(), int(capacity_rows), C.byref(n), stream_ptr()),
           "y3_conv2d_fwd_stats")
     return int(n.value)
+
+
+def stem_pair(x_nchw: torch.Tensor, filt0: torch.Tensor, bias0: torch.Tensor, act0: bool, filt1: torch.Tensor, bias1: torch.Tensor, act1: bool, y: View, divisor: float = 1.0):
+    """Conv(3->32, 3, 1) -> Conv(32->64, 3, 2) straight from the NCHW image into the NHWC view y (layer 0's output stays in LDS)."""
+    require_gpu(x_nchw, "stem_pair")
+    x = x_nchw.contiguous()
+    n, c, h, w = x.shape
+    yt = y.y3()
+    check(_lib.lib().y3_stem_pair_fwd(x.data_ptr(), dtype_code(x.dtype), n, c, h, w, float(divisor), filt0.data_ptr(), bias0.data_ptr(), _lib.Y3_ACT_SILU if act0 else _lib.Y3_ACT_NONE,
+                                      filt1.data_ptr(), bias1.data_ptr(), _lib.Y3_ACT_SILU if act1 else _lib.Y3_ACT_NONE, dtype_code(y.buf.dtype), C.byref(yt), stream_ptr()),
+          "y3_stem_pair_fwd")
