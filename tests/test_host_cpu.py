@@ -208,3 +208,54 @@ print("ok")
 """
     out = subprocess.check_output([sys.executable, "-c", reader], cwd=tmp_path, text=True)
     assert out.strip().endswith("ok")
+
+
+# ------------------------------------------------------------------------------------------------ host logic of the val / detect edges
+def test_letterbox_geometry_matches_oracle_letterbox():
+    """autoshape.letterbox_geometry (what the device letterbox is launched with) against the oracle's restatement of reference
+    utils/augmentations.py:104-134 on many shapes: output size, resized size, top/left border, ratio and (dw, dh)."""
+    import numpy as np
+
+    from oracle import yolo_oracle as yo
+    from yolov3_amd.autoshape import letterbox_geometry
+
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        h0, w0 = int(rng.integers(8, 900)), int(rng.integers(8, 900))
+        s = int(rng.choice([320, 416, 640]))
+        g = s / max(h0, w0)
+        shape1 = [int(np.ceil(int(v * g) / 32) * 32) for v in (h0, w0)]   # AutoShape's inference shape for a single image
+        im = np.zeros((h0, w0, 3), np.uint8)
+        im[...] = 7
+        want, ratio, pad = yo.letterbox(im, shape1, auto=False)
+        nh, nw, top, left, r, dwdh, full = letterbox_geometry((h0, w0), shape1)
+        assert tuple(full) == want.shape[:2] == tuple(shape1)
+        assert r == ratio and dwdh == pad
+        inner = want[top : top + nh, left : left + nw]
+        assert inner.shape[:2] == (nh, nw) and (inner == 7).all(), "resized image is not where the geometry says"
+        border = want.copy()
+        border[top : top + nh, left : left + nw] = 114
+        assert (border == 114).all()
+
+
+def test_scale_boxes_cpu_path_and_gain_pad_match_oracle():
+    """general.scale_boxes on CPU tensors (the reference's tensor arithmetic, kept for label tensors) and general._gain_pad
+    (the parameters handed to y3_scale_boxes) against the oracle."""
+    import torch
+
+    from oracle import yolo_oracle as yo
+    from yolov3_amd import general
+
+    boxes = yo.synth_scale_case((640, 640))
+    for s0, rp in [((480, 640), None), ((1280, 720), None), ((427, 640), ((0.9, 0.9), (0.0, 0.15)))]:
+        want = yo.scale_boxes((640, 640), boxes.clone()[:, :4], s0, rp)
+        got = general.scale_boxes((640, 640), boxes.clone()[:, :4], s0, rp)
+        assert torch.equal(got, want)
+        gain, px, py = general._gain_pad((640, 640), s0, rp)
+        manual = boxes.clone()[:, :4]
+        manual[:, [0, 2]] -= px
+        manual[:, [1, 3]] -= py
+        manual /= gain
+        manual[:, [0, 2]] = manual[:, [0, 2]].clamp(0, s0[1])
+        manual[:, [1, 3]] = manual[:, [1, 3]].clamp(0, s0[0])
+        assert torch.equal(manual, want)
