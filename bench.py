@@ -336,7 +336,7 @@ def main():
                               for k, g in sorted(groups.items(), key=lambda kv: -kv[1][2])},
             },
         }
-        cpu = None if args.no_cpu_baseline else cpu_baseline()
+        cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()   # rank 0 at N = 1 only
         value = world * bs * args.steps / dt
         out = {
             "metric": "images/sec (640x640) inference+NMS",
