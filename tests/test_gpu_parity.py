@@ -661,6 +661,7 @@ def test_train_step_autocast_fp16(dev, name, hw, adt):
         c = torch.nn.functional.cosine_similarity(g.flatten(), ref.flatten(), dim=0).item()
         if c < cos_min:
             cos_min, worst = c, k
+    print(f"[autocast {name} {adt}] loss rel err {abs(loss.item() - loss_ref.item()) / loss_ref.item():.4f}, min gradient cosine {cos_min:.4f} at {worst}")
     assert cos_min > (0.98 if adt == torch.float16 else 0.85), f"gradient direction: cosine {cos_min:.4f} at {worst}"
     for p in m.parameters():
         p.grad /= 128.0
