@@ -259,3 +259,63 @@ def test_scale_boxes_cpu_path_and_gain_pad_match_oracle():
         manual[:, [0, 2]] = manual[:, [0, 2]].clamp(0, s0[1])
         manual[:, [1, 3]] = manual[:, [1, 3]].clamp(0, s0[0])
         assert torch.equal(manual, want)
+
+
+# ------------------------------------------------------------------------------------------------ launch geometry through the C ABI (no GPU needed)
+def _desc(dtype_code, k, s, cin, cout):
+    from yolov3_amd._lib import Y3ConvDesc
+
+    return Y3ConvDesc(dtype_code, k, s, 0, 0, 0, cin, cout, 0)
+
+
+def test_conv_dispatch_geometry_matches_bench_mirror():
+    """y3_conv2d_fwd_stats_rows is a dry run of the conv dispatcher (no launch): the statistic rows it reports are
+    (pixel tiles of the chosen variant) x (its pixel waves), which pins the per-shape tile choice that bench.py's
+    igemm_variant() mirrors for the roofline grouping -- checked on every conv shape of yolov3 at batch 32 and 64."""
+    import ctypes as C
+    import re
+
+    import bench
+    from yolov3_amd import _lib
+    from yolov3_amd._lib import Y3Tensor
+
+    L = _lib.lib()
+    shapes = [(32, 64, 3, 2, 640), (64, 32, 1, 1, 320), (32, 64, 3, 1, 320), (64, 128, 3, 2, 320), (128, 64, 1, 1, 160), (64, 128, 3, 1, 160), (128, 256, 3, 2, 160),
+              (256, 128, 1, 1, 80), (128, 256, 3, 1, 80), (256, 512, 3, 2, 80), (512, 256, 1, 1, 40), (256, 512, 3, 1, 40), (512, 1024, 3, 2, 40), (1024, 512, 1, 1, 20),
+              (512, 1024, 3, 1, 20), (768, 256, 1, 1, 40), (384, 128, 1, 1, 80), (256, 256, 1, 1, 80), (512, 256, 1, 1, 20)]
+    for bs in (32, 64):
+        for cin, cout, k, s, hin in shapes:
+            ho = (hin + 2 * (k // 2) - k) // s + 1
+            x = Y3Tensor(4096, bs, hin, hin, cin, cin)      # fake, 16-byte aligned device addresses: a dry run never dereferences them
+            y = Y3Tensor(8192, bs, ho, ho, cout, cout)
+            rows = L.y3_conv2d_fwd_stats_rows(C.byref(_desc(_lib.Y3_F16, k, s, cin, cout)), C.byref(x), C.byref(y))
+            assert rows > 0, _lib.lib().y3_last_error()
+            m = bs * ho * ho
+            name = bench.igemm_variant(cin, cout, k, m)
+            tp = int(re.search(r"xtp(\d+)", name).group(1))
+            assert rows == -(-m // tp) * 2, f"{cin}->{cout} k{k} s{s} @{hin} bs{bs}: {rows} rows, mirror says {name}"
+
+
+def test_wgrad_geometry_fills_whole_rounds():
+    """y3_conv2d_wgrad_workspace_bytes exposes the filter-gradient launch geometry: the 256x256-tile kernel is chosen for the
+    long-K layers of yolov3 at batch 64 and its (tiles x pixel slices) fills 1 or 2 rounds of 256 CUs to >= 98 %; the other
+    layers keep 128x128 tiles (64 KiB partial tiles)."""
+    import ctypes as C
+
+    from yolov3_amd import _lib
+    from yolov3_amd._lib import Y3Tensor
+
+    L = _lib.lib()
+    big = {(128, 256, 80): 5, (256, 512, 40): 18, (512, 1024, 20): 72}      # (cin, cout, map) -> 256x256 tiles
+    for (cin, cout, hw), tiles in big.items():
+        x = Y3Tensor(4096, 64, hw, hw, cin, cin)
+        nbytes = L.y3_conv2d_wgrad_workspace_bytes(C.byref(_desc(_lib.Y3_F16, 3, 1, cin, cout)), C.byref(x))
+        blocks = nbytes // (256 * 256 * 4)
+        assert nbytes % (256 * 256 * 4) == 0 and blocks % tiles == 0, (cin, cout, hw, nbytes)
+        rounds = -(-blocks // 256)
+        assert rounds <= 2 and blocks / (256 * rounds) >= 0.98, f"{cin}->{cout}@{hw}: {blocks} blocks"
+    for cin, cout, k, hw in [(64, 128, 3, 160), (256, 128, 1, 80), (32, 64, 3, 320), (1024, 512, 1, 20)]:
+        x = Y3Tensor(4096, 64, hw, hw, cin, cin)
+        nbytes = L.y3_conv2d_wgrad_workspace_bytes(C.byref(_desc(_lib.Y3_F16, k, 1, cin, cout)), C.byref(x))
+        tiles = -(-cout // 128) * -(-(k * k * cin) // 128)
+        assert nbytes % (128 * 128 * 4 * tiles) == 0, (cin, cout, k, hw)
