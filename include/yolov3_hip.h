@@ -229,6 +229,9 @@ int y3_bn_act_bwd_res(const y3_tensor* u, const y3_tensor* dy, const float* scal
 /* OIHW fp32 -> filter bank of the data-gradient convolution: `cin` filters over (kh, kw, cout) with flipped taps. */
 int y3_pack_filter_dgrad(const float* w_oihw, int32_t cout_src, int32_t cin_src, int32_t ksize, int32_t cout, int32_t cin,
                          int32_t dtype, void* packed, void* stream);
+/* y3_pack_filter (forward bank) and y3_pack_filter_dgrad (data-gradient bank) of one layer in one launch (f16/bf16). */
+int y3_pack_filter_pair(const float* w_oihw, int32_t cout_src, int32_t cin_src, int32_t ksize, int32_t cout, int32_t cin,
+                        int32_t dtype, void* packed_fwd, void* packed_dgrad, void* stream);
 /* Data gradient of a 3x3 stride-2 pad-1 conv without multiplying the zero taps of the dilated form: four output-parity
  * classes, each a small stride-1 conv of du (1, 2, 2 and 4 taps) with its own filter bank, written to every second
  * pixel of gx (+= residual when given; residual may alias gx).  f16/bf16 only. */

@@ -172,11 +172,18 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(double* __restrict
     const int rl = threadIdx.x >> 4;
     double a = 0.0;
     if (j < n2c) {
-        if constexpr (std::is_same<TIN, double>::value) {
-            for (int b = rl; b < nblocks; b += 16) a += sums[(size_t)(1 + b) * n2c + j];
-        } else {
-            for (int b = rl; b < nblocks; b += 16) a += (double)part[(size_t)b * n2c + j];
+        // 8 independent loads in flight per trip, added in row order (same sum as the plain loop: the launch is a chain of up to
+        // 32 dependent-latency round trips otherwise -- 11-13 us for a kernel that moves a few hundred KB, 288 times per step)
+        const TIN* src = std::is_same<TIN, double>::value ? (const TIN*)(sums + n2c) : part;
+        int b = rl;
+        for (; b + 7 * 16 < nblocks; b += 8 * 16) {
+            TIN v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = src[(size_t)(b + q * 16) * n2c + j];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a += (double)v[q];
         }
+        for (; b < nblocks; b += 16) a += (double)src[(size_t)b * n2c + j];
     }
     red[threadIdx.x] = a;
     __syncthreads();
@@ -895,6 +902,34 @@ __global__ void pack_filter_dgrad_kernel(const float* __restrict__ src, int cout
     dst[idx] = from_f32<T>(v);
 }
 
+// both filter banks of a training step from the fp32 master weights in one launch: the forward bank [cout][kh][kw][cin] and the
+// data-gradient bank [cin][kh'][kw'][cout] (flipped taps) -- 145 ~7 us pack launches per step become 75
+template <typename T>
+__global__ void pack_filter_pair_kernel(const float* __restrict__ src, int cout_src, int cin_src, int ks, int cout, int cin, int rows_f, int kpad_f, int rows_d, int kpad_d,
+                                        T* __restrict__ dst_f, T* __restrict__ dst_d) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx < (long long)rows_f * kpad_f) {
+        const int k = (int)(idx % kpad_f), co = (int)(idx / kpad_f);
+        float v = 0.0f;
+        if (co < cout_src && k < ks * ks * cin) {
+            const int tap = k / cin, ci = k - tap * cin;
+            const int kh = tap / ks, kw = tap - kh * ks;
+            if (ci < cin_src) v = src[(((long long)co * cin_src + ci) * ks + kh) * ks + kw];
+        }
+        dst_f[idx] = from_f32<T>(v);
+    }
+    if (idx < (long long)rows_d * kpad_d) {
+        const int k = (int)(idx % kpad_d), ci = (int)(idx / kpad_d);
+        float v = 0.0f;
+        if (ci < cin_src && k < ks * ks * cout) {
+            const int tap = k / cout, co = k - tap * cout;
+            const int kh = ks - 1 - tap / ks, kw = ks - 1 - tap % ks;
+            if (co < cout_src) v = src[(((long long)co * cin_src + ci) * ks + kh) * ks + kw];
+        }
+        dst_d[idx] = from_f32<T>(v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // backward of nearest x2 upsampling: dx[h,w] (+)= sum of the 2x2 block of dy
 template <typename T>
@@ -1064,7 +1099,15 @@ __global__ __launch_bounds__(256) void stat_rows_to_partials_kernel(const float*
     if (r1 > n_rows) r1 = n_rows;
     for (int j = threadIdx.x; j < n2c; j += 256) {
         double a = 0.0;
-        for (long long r = r0; r < r1; ++r) a += (double)rows[r * n2c + j];
+        long long r = r0;
+        for (; r + 7 < r1; r += 8) {   // 8 loads in flight, added in row order
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = rows[(r + q) * n2c + j];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a += (double)v[q];
+        }
+        for (; r < r1; ++r) a += (double)rows[r * n2c + j];
         sums[(size_t)(1 + blockIdx.x) * n2c + j] = a;
     }
 }
@@ -1168,6 +1211,21 @@ extern "C" int y3_pack_filter_dgrad(const float* w, int32_t cout_src, int32_t ci
     const long long total = (long long)rows * kpad;
     hipStream_t st = (hipStream_t)stream;
     Y3_DISPATCH_T(dtype, hipLaunchKernelGGL((pack_filter_dgrad_kernel<T>), dim3(nblk(total)), dim3(256), 0, st, w, cout_src, cin_src, ks, cout, rows, kpad, (T*)packed));
+    Y3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int y3_pack_filter_pair(const float* w, int32_t cout_src, int32_t cin_src, int32_t ks, int32_t cout, int32_t cin, int32_t dtype, void* packed_fwd, void* packed_dgrad,
+                                   void* stream) {
+    if (!w || !packed_fwd || !packed_dgrad) Y3_FAIL("y3_pack_filter_pair: null pointer");
+    if (cout < cout_src || cin < cin_src || (cout % 8) != 0 || (cin % 8) != 0) Y3_FAIL("y3_pack_filter_pair: bad padded sizes");
+    if (dtype != Y3_F16 && dtype != Y3_BF16) Y3_FAIL("y3_pack_filter_pair: f16/bf16 only");
+    const int rows_f = y3_filter_rows(cout), kpad_f = y3_filter_kpad(cin, ks), rows_d = y3_filter_rows(cin), kpad_d = y3_filter_kpad(cout, ks);
+    const long long tf = (long long)rows_f * kpad_f, td = (long long)rows_d * kpad_d;
+    const long long total = tf > td ? tf : td;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == Y3_F16) hipLaunchKernelGGL((pack_filter_pair_kernel<f16_t>), dim3(nblk(total)), dim3(256), 0, st, w, cout_src, cin_src, ks, cout, cin, rows_f, kpad_f, rows_d, kpad_d, (f16_t*)packed_fwd, (f16_t*)packed_dgrad);
+    else hipLaunchKernelGGL((pack_filter_pair_kernel<bf16_t>), dim3(nblk(total)), dim3(256), 0, st, w, cout_src, cin_src, ks, cout, cin, rows_f, kpad_f, rows_d, kpad_d, (bf16_t*)packed_fwd, (bf16_t*)packed_dgrad);
     Y3_CHECK_LAUNCH();
     return 0;
 }

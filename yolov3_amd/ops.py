@@ -294,3 +294,14 @@ def stem_pair(x_nchw: torch.Tensor, filt0: torch.Tensor, bias0: torch.Tensor, ac
     check(_lib.lib().y3_stem_pair_fwd(x.data_ptr(), dtype_code(x.dtype), n, c, h, w, float(divisor), filt0.data_ptr(), bias0.data_ptr(), _lib.Y3_ACT_SILU if act0 else _lib.Y3_ACT_NONE,
                                       filt1.data_ptr(), bias1.data_ptr(), _lib.Y3_ACT_SILU if act1 else _lib.Y3_ACT_NONE, dtype_code(y.buf.dtype), C.byref(yt), stream_ptr()),
           "y3_stem_pair_fwd")
+
+
+def pack_filter_pair(w_oihw: torch.Tensor, cout: int, cin: int, dtype: torch.dtype):
+    """(forward bank, data-gradient bank) of one layer from its OIHW fp32 weights in one launch (training step)."""
+    require_gpu(w_oihw, "pack_filter_pair")
+    w = w_oihw.detach().to(torch.float32).contiguous()
+    co, ci, k, _ = w.shape
+    fwd = torch.empty(packed_filter_elems(cout, cin, k), dtype=dtype, device=w.device)
+    dg = torch.empty(packed_filter_elems(cin, cout, k), dtype=dtype, device=w.device)
+    check(_lib.lib().y3_pack_filter_pair(w.data_ptr(), co, ci, k, cout, cin, dtype_code(dtype), fwd.data_ptr(), dg.data_ptr(), stream_ptr()), "y3_pack_filter_pair")
+    return fwd, dg

@@ -99,6 +99,9 @@ class ConvUnit(_Unit):
         self.count = v.n * v.h * v.w
         self.use_stem = False
         self.stat_rows = None
+        self.filt_d = None
+        # the data gradient of this unit runs through the generic dgrad bank (not the stride-2 parity-class banks, not layer 0)
+        self.pair_pack = need_dx and plan.dtype in (torch.float16, torch.bfloat16) and not (self.s == 2 and self.k == 3)
 
     def fwd(self):
         m, bn = self.m, self.m.bn
@@ -113,7 +116,10 @@ class ConvUnit(_Unit):
             # layer 0 straight from the caller's NCHW image (csrc/stem.hip); the NHWC copy is still made for the filter gradient
             ops.stem_conv(self.plan.x_nchw, ops.pack_filter_stem(m.conv.weight, self.cout, self.plan.dtype), self.zero_bias, self.u, act=False)
         else:
-            filt = ops.pack_filter(m.conv.weight, self.cout, self.cin, self.plan.dtype)
+            if self.pair_pack:   # forward and data-gradient banks in one launch; the weights do not change before the backward
+                filt, self.filt_d = ops.pack_filter_pair(m.conv.weight, self.cout, self.cin, self.plan.dtype)
+            else:
+                filt = ops.pack_filter(m.conv.weight, self.cout, self.cin, self.plan.dtype)
             if self.plan.epilogue_stats:
                 # BatchNorm statistics taken in the conv epilogue (per-tile rows of sum / sum of squares): no separate pass over u
                 if self.stat_rows is None:
@@ -174,7 +180,9 @@ class ConvUnit(_Unit):
             if self.s == 2 and self.k == 3 and self.plan.dtype != torch.float32:
                 ops.conv2d_dgrad_s2(m.conv.weight, du, gx, accumulate=self.x.is_ready())   # no zero-tap waste
             else:
-                filt_d = ops.pack_filter_dgrad(m.conv.weight, self.cout, self.cin, self.plan.dtype)
+                filt_d, self.filt_d = self.filt_d, None
+                if filt_d is None:
+                    filt_d = ops.pack_filter_dgrad(m.conv.weight, self.cout, self.cin, self.plan.dtype)
                 zb = self.plan.zeros_f32(self.cin)
                 ops.conv2d(du, filt_d, zb, gx, self.k, 1, act=False, residual=gx if self.x.is_ready() else None, in_dilation=self.s)
             self.x.mark_ready()
