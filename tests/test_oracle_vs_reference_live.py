@@ -1,0 +1,70 @@
+"""Where the reference tree is present (the build container), run the UNMODIFIED reference side by side with the oracle on
+fresh seeded inputs -- a wider pin than the committed golden files (which only hold a handful of cases).  Skipped on the GPU
+box (/root/reference does not exist there).  CPU only."""
+import importlib
+
+import pytest
+import torch
+
+from oracle import ref_shim, yolo_oracle as yo
+
+pytestmark = pytest.mark.skipif(not ref_shim.available(), reason="/root/reference not present")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    ns = ref_shim.load()
+    ns.val = importlib.import_module("val")
+    from utils.general import scale_boxes  # type: ignore
+
+    ns.scale_boxes = scale_boxes
+    return ns
+
+
+def test_process_batch_oracle_equals_reference_on_many_cases(ref):
+    """val.process_batch (reference val.py:147-188) == oracle.process_batch on 120 seeded images: label counts 1-29, 20-139
+    detections, 1-6 classes, three duplicate regimes (several detections per label)."""
+    iouv = torch.linspace(0.5, 0.95, 10)
+    checked = 0
+    for seed in range(120):
+        det, lab = yo.synth_val_case(seed + 1000, n_lab=1 + seed % 29, n_det=20 + seed, nc=1 + seed % 6, dup=(seed % 3) / 2)
+        want = ref.val.process_batch(det.clone(), lab.clone(), iouv)
+        got = yo.process_batch(det, lab, iouv)
+        assert torch.equal(got, want), f"seed {seed}"
+        checked += int(want.sum())
+    assert checked > 1000
+
+
+def test_scale_boxes_oracle_equals_reference_on_many_shapes(ref):
+    """utils.general.scale_boxes (reference :613-626) == oracle.scale_boxes, bit-exact, over letterbox geometries derived the way
+    val.py / detect.py derive them (ratio_pad None and the dataloader's (ratio, pad) form)."""
+    g = torch.Generator().manual_seed(0)
+    for i in range(60):
+        h0, w0 = int(torch.randint(120, 1400, (1,), generator=g)), int(torch.randint(120, 1400, (1,), generator=g))
+        s1 = (int(torch.randint(5, 21, (1,), generator=g)) * 32, int(torch.randint(5, 21, (1,), generator=g)) * 32)
+        boxes = yo.synth_scale_case(s1, seed=20 + i, n=64)
+        rp = None
+        if i % 2:
+            r = min(s1[0] / h0, s1[1] / w0)
+            rp = ((r, r), ((s1[1] - round(w0 * r)) / 2, (s1[0] - round(h0 * r)) / 2))
+        want = ref.scale_boxes(s1, boxes.clone()[:, :4], (h0, w0), rp)
+        got = yo.scale_boxes(s1, boxes.clone()[:, :4], (h0, w0), rp)
+        assert torch.equal(got, want), (i, s1, (h0, w0), rp)
+
+
+def test_nms_oracle_equals_reference_on_fresh_seeds(ref):
+    """non_max_suppression (reference utils/general.py:630-750, with the restated torchvision nms) == oracle on seeds the golden
+    files do not hold: both regimes, agnostic and class-filtered."""
+    cases = [
+        (dict(bs=2, n_rows=1800, nc=80, seed=101), dict(conf_thres=0.001, iou_thres=0.6, multi_label=True, max_det=300)),
+        (dict(bs=2, n_rows=1800, nc=80, seed=102), dict(conf_thres=0.25, iou_thres=0.45)),
+        (dict(bs=1, n_rows=1500, nc=20, seed=103, hits=0.1), dict(conf_thres=0.05, iou_thres=0.5, agnostic=True)),
+        (dict(bs=1, n_rows=1500, nc=8, seed=104, n_gt=30), dict(conf_thres=0.1, iou_thres=0.45, classes=[1, 4])),
+    ]
+    for gk, nk in cases:
+        pred = yo.synth_predictions(**gk)
+        want = ref.non_max_suppression(pred.clone(), **nk)
+        got = yo.non_max_suppression(pred, **nk)
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            assert a.shape == b.shape and torch.equal(a, b), (gk, nk)
