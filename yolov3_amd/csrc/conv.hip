@@ -1170,9 +1170,6 @@ extern "C" int y3_conv2d_dgrad_s2(int32_t dtype, const y3_tensor* du, const void
     if ((long long)gx->n * H * W > 0x7fffffffLL) Y3_FAIL("y3_conv2d_dgrad_s2: too many gradient pixels");
     hipStream_t st = (hipStream_t)stream;
     const int cout = du->c, cin = gx->c;
-    static float* zero_bias = nullptr;  // bias-free: the kernels read Cout floats; a static zero page is enough
-    static int zero_len = 0;
-    (void)zero_bias; (void)zero_len;
     size_t off = 0;
     for (int ph = 0; ph < 2; ++ph)
         for (int pw = 0; pw < 2; ++pw) {
