@@ -136,9 +136,10 @@ class AutoShape(nn.Module):
         shape1 = [make_divisible(x, stride) for x in np.array(shape1).max(0)]
         x = letterbox_batch(ims, shape1, p.device)  # uint8; the model's first kernel divides by 255
         t1 = time.perf_counter()
-        y = self.model(x, augment=augment)
+        net = self.model.model if self.dmb else self.model   # the DetectionModel itself: it takes the uint8 batch (a DetectMultiBackend would cast it to half without the /255)
+        y = net(x, augment=augment)
         t2 = time.perf_counter()
-        rows, counts_t, counts = non_max_suppression_batched(y if self.dmb else y[0], self.conf, self.iou, self.classes, self.agnostic, self.multi_label, max_det=self.max_det)
+        rows, counts_t, counts = non_max_suppression_batched(y[0], self.conf, self.iou, self.classes, self.agnostic, self.multi_label, max_det=self.max_det)
         scale_boxes_batched(shape1, rows, counts_t, shape0)
         pred = [rows[i, :c] for i, c in enumerate(counts)]
         t3 = time.perf_counter()

@@ -27,6 +27,15 @@ def clip_boxes(boxes, shape):
     return boxes
 
 
+def box_iou(box1, box2, eps=1e-7):
+    """Pairwise IoU of xyxy boxes (N,4) x (M,4) -> (N,M) (upstream ultralytics.utils.metrics.box_iou; reference val.py:176,
+    utils/general.py:737).  Plain tensor arithmetic: the hot use of it -- process_batch -- runs in csrc/val_edge.hip."""
+    a1, a2 = box1.float().unsqueeze(1).chunk(2, 2)
+    b1, b2 = box2.float().unsqueeze(0).chunk(2, 2)
+    inter = (torch.min(a2, b2) - torch.max(a1, b1)).clamp_(0).prod(2)
+    return inter / ((a2 - a1).prod(2) + (b2 - b1).prod(2) - inter + eps)
+
+
 def _gain_pad(img1_shape, img0_shape, ratio_pad):
     """(gain, pad_x, pad_y) exactly as reference utils/general.py:615-620 computes them (Python floats)."""
     if ratio_pad is None:
