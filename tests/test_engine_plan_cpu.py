@@ -101,3 +101,25 @@ def test_fuse_matches_unfused_plan_weights(monkeypatch):
         if k1 == "conv":
             torch.testing.assert_close(a["w"].folded[0], b["w"].folded[0], rtol=1e-6, atol=1e-7)
             torch.testing.assert_close(a["w"].folded[1], b["w"].folded[1], rtol=1e-6, atol=1e-6)
+
+
+def test_stem_pair_eligibility(monkeypatch):
+    """Layers 0 + 1 are fused only for the Conv(<=4, 32, 3, 1) -> Conv(32, 64, 3, 2) opening of yolov3 / yolov3-spp with layer 0
+    consumed by layer 1 alone; yolov3-tiny (Conv(3, 16) + MaxPool) keeps the stem kernel; Y3_STEM_PAIR=0 switches it off."""
+    from yolov3_amd import DetectionModel
+    from yolov3_amd import engine as e
+
+    def eligible(name):
+        m = DetectionModel(f"{name}.yaml").eval()
+        layers = list(m.model)
+        src = [e._sources(i, l.f) for i, l in enumerate(layers)]
+        consumers = {i: [] for i in range(-1, len(layers))}
+        for i, s in enumerate(src):
+            for j in s:
+                consumers[j].append(i)
+        return e._stem_pair_eligible(layers, src, consumers, {}, {})
+
+    monkeypatch.delenv("Y3_STEM_PAIR", raising=False)
+    assert eligible("yolov3") and eligible("yolov3-spp") and not eligible("yolov3-tiny")
+    monkeypatch.setenv("Y3_STEM_PAIR", "0")
+    assert not eligible("yolov3")
