@@ -34,33 +34,6 @@ MFMA_PEAK_TFLOPS = 2500.0  # dense fp16/bf16, /opt/skills/guides/MI355X_MICROARC
 HBM_PEAK_GBS = 8000.0
 
 
-def igemm_variant(cin, cout, k=1, m=1 << 30):
-    """Mirror of dispatch_igemm() in csrc/conv.hip: which template instance a conv launch lands on."""
-    var = os.environ.get("Y3_CONV", "auto")
-    bk = 64 if cin % 64 == 0 else 32
-    if (var.startswith("v3") or var == "auto") and cout > 64 and cin % 32 == 0:
-        if var == "v3b":
-            return "conv_igemm_v3<f16,bk32,tc128xtp256>"
-        if var == "v3c":
-            return "conv_igemm_v3<f16,bk32,tc128xtp128>"
-        if var == "v3a":
-            return f"conv_igemm_v3<f16,bk{bk},tc128xtp128>"
-        if var == "auto" and k * k * cin >= 2304 and cout >= 512:
-            return "conv_igemm_v6<f16,bk32,tc256xtp256,8 waves staggered>"
-        if var == "auto" and k * k * cin >= 4608 and cout >= 256 and m >= 65536:
-            return "conv_igemm_v6<f16,bk32,tc256xtp256,8 waves staggered>"
-        if var == "auto" and bk == 64 and k == 1 and cout >= 256 and 16384 < m <= 65536:
-            return "conv_igemm_v6<f16,bk32,tc256xtp256,8 waves staggered>"
-        if bk == 64 and ((k > 1 and k * k * cin >= 1152) or (k == 1 and cin >= 256 and m <= 16384)):
-            return "conv_igemm_v3<f16,bk64,tc128xtp128>"
-        return "conv_igemm_v3<f16,bk32,tc128xtp128>"
-    if var != "v2" and cout <= 64 and cin % 32 == 0:
-        return "conv_igemm_v3<f16,bk32,tc64xtp256>"
-    small = "" if cin % 32 == 0 else "_smallc"
-    tile = "tc128xtp128" if cout > 64 else "tc64xtp128" if cout > 32 else "tc32xtp256"
-    return f"conv_igemm_{'v1' if var == 'v1' else 'v2'}<f16,bk{bk},{tile}{small}>"
-
-
 def per_kernel_times(plan, reps=5):
     """HIP-event timing of every launch of the compiled plan on the stream the kernels run on (torch's current
     stream).  Returns {variant: [flops, bytes, seconds, launches]} averaged over `reps` passes."""
@@ -82,7 +55,7 @@ def per_kernel_times(plan, reps=5):
                 key = ln.kernel + "/3x3"
             elif ln.flops:
                 w = ln.keep[4]
-                key = igemm_variant(w.cin, w.cout, w.k, int(ln.flops / (2.0 * w.cout * w.cin * w.k * w.k))) + f"/{w.k}x{w.k}"
+                key = f"conv_igemm_{plan.conv_variant(ln)}/{w.k}x{w.k}"   # the variant name comes from the library's own dispatcher (y3_conv2d_fwd_variant)
             else:
                 key = ln.label.split(".")[-1]
             a = acc.setdefault(key, [0.0, 0.0, 0.0, 0])

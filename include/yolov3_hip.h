@@ -69,6 +69,19 @@ int y3_pack_filter(const float* w_oihw, int32_t cout_src, int32_t cin_src, int32
 
 int y3_conv2d_fwd(const y3_conv_desc* desc, const y3_tensor* x, const void* packed_filter, const float* bias,
                   const y3_tensor* residual /* may be NULL */, const y3_tensor* y, void* stream);
+/* The same call with a caller-owned scratch buffer of y3_conv_workspace_bytes() bytes (256-byte aligned, ZERO-FILLED ONCE when it
+ * is allocated, used by one stream at a time): unlocks the persistent stream-K kernel for the 3x3 / stride-1 layers with
+ * cout % 256 == 0 (models/common.py:150-165 Bottleneck.cv2, the 3x3 convs of the head) -- the block grid is the CU count, tiles
+ * cut by a block's share of the K loop are completed through fp32 partial tiles in the workspace.  Results are deterministic
+ * (fixed split, fixed summation order).  Layers the kernel does not cover run exactly as y3_conv2d_fwd. */
+size_t y3_conv_workspace_bytes(void);
+int y3_conv2d_fwd_ws(const y3_conv_desc* desc, const y3_tensor* x, const void* packed_filter, const float* bias,
+                     const y3_tensor* residual /* may be NULL */, const y3_tensor* y, void* workspace, size_t workspace_bytes,
+                     void* stream);
+/* Which kernel variant the dispatcher picks for this problem ("v7", "v6", "v3_bk64_128x128", ..., "direct"); launches nothing.
+ * The parity tests assert it so that a tolerance is always attached to the kernel that actually ran. */
+int y3_conv2d_fwd_variant(const y3_conv_desc* desc, const y3_tensor* x, const y3_tensor* y, int32_t has_residual,
+                          size_t workspace_bytes, char* name, size_t name_capacity);
 
 /* Stem convolution: the first layer `Conv(ch<=4, 32|64, 3, 1)` (reference models/yolov3.yaml:16, models/common.py:57-81) computed
  * straight from the caller's NCHW image, fused with the ingest (`im.half(); im /= 255`, val.py:354-360): no NHWC copy of the

@@ -40,8 +40,21 @@ def checksum(t):
 
 
 # ------------------------------------------------------------------------------------------------ conv
-def run_conv(dev, dtype, n, h, w, cin, cout, k, s, act=True, residual=False, ups=False, sliced=False, algo=0, seed=0, cin_real=None, cout_real=None):
-    """Returns (hip output NCHW fp32 cpu, reference NCHW fp32 cpu computed from the SAME rounded operands)."""
+_WS = {}
+
+
+def conv_ws(dev):
+    """one stream-K workspace for the whole test session (zero-filled once, re-armed by every launch)"""
+    _lib, ops = _ops()
+    if dev not in _WS:
+        _WS[dev] = ops.conv_workspace(dev)
+    return _WS[dev]
+
+
+def run_conv(dev, dtype, n, h, w, cin, cout, k, s, act=True, residual=False, ups=False, sliced=False, algo=0, seed=0, cin_real=None, cout_real=None, ws=False, expect=None,
+             repeat=1):
+    """Returns (hip output NCHW fp32 cpu, reference NCHW fp32 cpu computed from the SAME rounded operands).  ws: call through
+    y3_conv2d_fwd_ws; expect: assert the kernel variant the dispatcher picks (so a tolerance is tied to the kernel that ran)."""
     _lib, ops = _ops()
     g = torch.Generator().manual_seed(seed)
     cin_real = cin_real or cin
@@ -77,8 +90,25 @@ def run_conv(dev, dtype, n, h, w, cin, cout, k, s, act=True, residual=False, ups
         rv = ops.View.alloc(n, ho, wo, cout, dtype, dev)
         rv.buf.zero_()
         ops.nchw_to_nhwc(res.to(dev), rv)
-    ops.conv2d(xv, filt, bias, yv, k, s, act, rv, ups, algo)
-    torch.cuda.synchronize()
+    wsp = conv_ws(dev) if ws else None
+    if expect is not None:
+        got = ops.conv_variant(xv, yv, k, s, residual, ups, algo, workspace_bytes=wsp.numel() if ws else 0)
+        assert got == expect, f"dispatcher picked {got}, the test is written for {expect}"
+    first = None
+    for r in range(repeat):   # same workspace, back-to-back launches: flags / ticket must re-arm, results must be bit-identical
+        if r:
+            yv.buf.fill_(-3.0)
+        ops.conv2d(xv, filt, bias, yv, k, s, act, rv, ups, algo, workspace=wsp)
+        torch.cuda.synchronize()
+        cur = yv.as_nhwc().clone()
+        if first is None:
+            first = cur
+        else:
+            assert torch.equal(first, cur), f"launch {r} differs from launch 0 (non-deterministic or stale workspace state)"
+    if ws:
+        hdr = wsp[:64].view(torch.int32)
+        assert hdr[2].item() == 0, "stream-K kernel reported a lost producer (spin bound hit)"
+        assert hdr[0].item() == 0 and hdr[1].item() == 0 and int(wsp[64:64 + 4096].view(torch.int32).abs().sum()) == 0, "workspace control words not re-armed"
     out = yv.as_nhwc().float().cpu().permute(0, 3, 1, 2)[:, :cout_real]
     if sliced:
         full = big.as_nhwc().float().cpu()
@@ -117,6 +147,85 @@ def test_conv_mfma_vs_fp32_reference(dev, dtype, name, shape, kw):
     tol = eps * ref.abs() + 2e-3 if dtype == torch.float16 else eps * ref.abs() + 1.5e-2
     bad = (err > tol).sum().item()
     assert bad == 0, f"{name} {dtype}: {bad}/{err.numel()} outside tolerance, max abs err {err.max():.4g}, ref max {ref.abs().max():.3g}"
+
+
+def _conv_tol_check(name, dtype, out, ref):
+    eps = 2.0**-10 if dtype == torch.float16 else 2.0**-7
+    err = (out - ref).abs()
+    tol = eps * ref.abs() + (2e-3 if dtype == torch.float16 else 1.5e-2)
+    bad = (err > tol).sum().item()
+    assert bad == 0, f"{name} {dtype}: {bad}/{err.numel()} outside tolerance, max abs err {err.max():.4g}, ref max {ref.abs().max():.3g}"
+
+
+# The persistent stream-K / halo-patch kernel (csrc/conv_v7.h) at small sizes chosen to hit its edge logic: ragged last pixel tile,
+# image borders inside a tile, several images per tile, every patch depth (XP 3/4/5 by image width), one-unit-per-block splits
+# (a tile summed from many slabs), residual / no activation / channel-slice output.
+V7_CASES = [   # every case has >= 32 (tile, channel block) units, the dispatcher's floor for the persistent kernel
+    ("w20_two_ct", (6, 20, 20, 64, 512, 3, 1), {}),
+    ("w13_ragged", (40, 11, 13, 96, 256, 3, 1), {"residual": True}),
+    ("w40_noact", (2, 40, 40, 128, 256, 3, 1), {"act": False}),
+    ("w80_xp4", (1, 33, 80, 128, 256, 3, 1), {"residual": True}),
+    ("w160_xp5", (1, 30, 160, 64, 256, 3, 1), {}),
+    ("w190_xp5_max", (1, 24, 190, 64, 256, 3, 1), {}),
+    ("deep_k_split", (2, 20, 20, 512, 1024, 3, 1), {"residual": True}),
+    ("sliced_out", (8, 24, 20, 128, 256, 3, 1), {"sliced": True}),
+    ("h1_rows", (40, 1, 70, 96, 256, 3, 1), {}),
+    ("w1_cols", (30, 90, 1, 96, 256, 3, 1), {}),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name,shape,kw", V7_CASES, ids=[c[0] for c in V7_CASES])
+def test_conv_v7_streamk_vs_fp32_reference(dev, dtype, name, shape, kw):
+    out, ref = run_conv(dev, dtype, *shape, algo=1, ws=True, expect="v7", repeat=3, **kw)
+    _conv_tol_check(name, dtype, out, ref)
+
+
+def test_conv_v7_grid_sweep(dev, monkeypatch):
+    """the same problem under different block counts (different K splits, down to whole tiles): every split sums the same
+    products in fp32, so the results agree to accumulation-order noise and each one is inside the conv tolerance"""
+    outs = []
+    for grid in ("-1", "7", "24", "61", "0"):
+        monkeypatch.setenv("Y3_V7_GRID", grid)
+        out, ref = run_conv(dev, torch.float16, 4, 20, 20, 256, 512, 3, 1, algo=1, ws=True, expect="v7", repeat=2, residual=True)
+        _conv_tol_check(f"grid{grid}", torch.float16, out, ref)
+        outs.append(out)
+    for o in outs[1:]:
+        assert (o - outs[0]).abs().max().item() <= 2.0**-9 * max(1.0, outs[0].abs().max().item())
+
+
+# BASELINE.json configs[1] / configs[3] / configs[4] layer shapes at their benchmarked batch: the branches of dispatch_igemm that the
+# bench actually runs (multi-round grids, XCD remap at 200-3200 blocks, ragged last tiles at M = 12800 / 51200 / 204800).
+BASELINE_CONV_CASES = [
+    # name, (n,h,w,cin,cout,k,s), kwargs, variant with workspace
+    ("L6cv2_128_256_80", (32, 80, 80, 128, 256, 3, 1), {"residual": True}, "v7"),
+    ("L8cv2_256_512_40", (32, 40, 40, 256, 512, 3, 1), {"residual": True}, "v7"),
+    ("L10cv2_512_1024_20", (32, 20, 20, 512, 1024, 3, 1), {"residual": True}, "v7"),
+    ("L7_256_512_s2", (32, 80, 80, 256, 512, 3, 2), {}, "v6"),
+    ("L9_512_1024_s2", (32, 40, 40, 512, 1024, 3, 2), {}, "v6"),
+    ("L8cv1_512_256_40", (32, 40, 40, 512, 256, 1, 1), {}, "v6"),
+    ("L10cv1_1024_512_20", (32, 20, 20, 1024, 512, 1, 1), {}, "v3_bk64_128x128"),
+    ("L6cv1_256_128_80", (32, 80, 80, 256, 128, 1, 1), {}, "v3_bk32_128x128"),
+    ("L4cv2_64_128_160", (32, 160, 160, 64, 128, 3, 1), {"residual": True}, "v3_bk32_128x128"),
+    ("head255_20", (32, 20, 20, 1024, 256, 1, 1), {"cout_real": 255, "act": False}, "v3_bk64_128x128"),
+    ("head255_80", (32, 80, 80, 256, 256, 1, 1), {"cout_real": 255, "act": False}, "v3_bk32_128x128"),
+    ("head1110_40_c5", (8, 40, 40, 1024, 1112, 1, 1), {"cout_real": 1110, "act": False}, None),
+    ("c5_128_256_160", (8, 160, 160, 128, 256, 3, 1), {"residual": True}, "v7"),
+    ("ups_route_20", (32, 20, 20, 512, 256, 1, 1), {"ups": True}, None),
+]
+
+
+@pytest.mark.parametrize("name,shape,kw,variant", BASELINE_CONV_CASES, ids=[c[0] for c in BASELINE_CONV_CASES])
+def test_conv_baseline_shapes_fp16(dev, name, shape, kw, variant):
+    out, ref = run_conv(dev, torch.float16, *shape, algo=1, ws=True, expect=variant, **kw)
+    _conv_tol_check(name, torch.float16, out, ref)
+
+
+@pytest.mark.parametrize("name,shape,kw,variant", [c for c in BASELINE_CONV_CASES if c[0] in ("L8cv2_256_512_40", "L9_512_1024_s2", "head1110_40_c5", "c5_128_256_160")],
+                         ids=["L8cv2_256_512_40", "L9_512_1024_s2", "head1110_40_c5", "c5_128_256_160"])
+def test_conv_baseline_shapes_bf16(dev, name, shape, kw, variant):
+    out, ref = run_conv(dev, torch.bfloat16, *shape, algo=1, ws=True, expect=variant, **kw)
+    _conv_tol_check(name, torch.bfloat16, out, ref)
 
 
 @pytest.mark.parametrize("name,shape,kw", CONV_CASES[:8], ids=[c[0] for c in CONV_CASES[:8]])

@@ -268,32 +268,46 @@ def _desc(dtype_code, k, s, cin, cout):
     return Y3ConvDesc(dtype_code, k, s, 0, 0, 0, cin, cout, 0)
 
 
-def test_conv_dispatch_geometry_matches_bench_mirror():
-    """y3_conv2d_fwd_stats_rows is a dry run of the conv dispatcher (no launch): the statistic rows it reports are
-    (pixel tiles of the chosen variant) x (its pixel waves), which pins the per-shape tile choice that bench.py's
-    igemm_variant() mirrors for the roofline grouping -- checked on every conv shape of yolov3 at batch 32 and 64."""
+def test_conv_dispatch_variant_names_and_stat_rows():
+    """y3_conv2d_fwd_variant / y3_conv2d_fwd_stats_rows are dry runs of the conv dispatcher (no launch).  The variant name is what
+    bench.py groups its roofline by and what the GPU parity tests assert; the statistic rows must equal (pixel tiles of that
+    variant) x (its rows per tile) -- checked on every conv shape of yolov3 at batch 32 and 64, with and without a workspace."""
     import ctypes as C
-    import re
 
-    import bench
     from yolov3_amd import _lib
     from yolov3_amd._lib import Y3Tensor
 
     L = _lib.lib()
+    ws = L.y3_conv_workspace_bytes()
+    assert ws == 64 + 4096 + 256 * 256 * 256 * 4
+    tile_px = {"v7": (256, 4), "v6": (256, 2), "v3_bk64_128x128": (128, 2), "v3_bk32_128x128": (128, 2), "v3_bk32_128x256": (256, 2), "v3_bk32_64x256": (256, 2)}
     shapes = [(32, 64, 3, 2, 640), (64, 32, 1, 1, 320), (32, 64, 3, 1, 320), (64, 128, 3, 2, 320), (128, 64, 1, 1, 160), (64, 128, 3, 1, 160), (128, 256, 3, 2, 160),
               (256, 128, 1, 1, 80), (128, 256, 3, 1, 80), (256, 512, 3, 2, 80), (512, 256, 1, 1, 40), (256, 512, 3, 1, 40), (512, 1024, 3, 2, 40), (1024, 512, 1, 1, 20),
               (512, 1024, 3, 1, 20), (768, 256, 1, 1, 40), (384, 128, 1, 1, 80), (256, 256, 1, 1, 80), (512, 256, 1, 1, 20)]
+    v7_shapes = {(128, 256, 3, 1, 80), (256, 512, 3, 1, 40), (512, 1024, 3, 1, 20)}   # 3x3, stride 1, cout % 256 == 0: the persistent stream-K kernel
     for bs in (32, 64):
         for cin, cout, k, s, hin in shapes:
             ho = (hin + 2 * (k // 2) - k) // s + 1
             x = Y3Tensor(4096, bs, hin, hin, cin, cin)      # fake, 16-byte aligned device addresses: a dry run never dereferences them
             y = Y3Tensor(8192, bs, ho, ho, cout, cout)
-            rows = L.y3_conv2d_fwd_stats_rows(C.byref(_desc(_lib.Y3_F16, k, s, cin, cout)), C.byref(x), C.byref(y))
-            assert rows > 0, _lib.lib().y3_last_error()
+            d = _desc(_lib.Y3_F16, k, s, cin, cout)
+            name = C.create_string_buffer(64)
+            assert L.y3_conv2d_fwd_variant(C.byref(d), C.byref(x), C.byref(y), 0, 0, name, 64) == 0, L.y3_last_error()
+            plain = name.value.decode()
+            assert plain in tile_px and plain != "v7", plain
+            rows = L.y3_conv2d_fwd_stats_rows(C.byref(d), C.byref(x), C.byref(y))
+            assert rows > 0, L.y3_last_error()
+            tp, per = tile_px[plain]
             m = bs * ho * ho
-            name = bench.igemm_variant(cin, cout, k, m)
-            tp = int(re.search(r"xtp(\d+)", name).group(1))
-            assert rows == -(-m // tp) * 2, f"{cin}->{cout} k{k} s{s} @{hin} bs{bs}: {rows} rows, mirror says {name}"
+            assert rows == -(-m // tp) * per, f"{cin}->{cout} k{k} s{s} @{hin} bs{bs}: {rows} rows for {plain}"
+            assert L.y3_conv2d_fwd_variant(C.byref(d), C.byref(x), C.byref(y), 0, ws, name, 64) == 0
+            with_ws = name.value.decode()
+            assert with_ws == ("v7" if (cin, cout, k, s, hin) in v7_shapes else plain), (cin, cout, k, s, hin, with_ws)
+    # fp32 -> the direct kernel; a too-small workspace never selects the persistent kernel
+    x, y = Y3Tensor(4096, 2, 20, 20, 512, 512), Y3Tensor(8192, 2, 20, 20, 1024, 1024)
+    name = C.create_string_buffer(64)
+    assert L.y3_conv2d_fwd_variant(C.byref(_desc(_lib.Y3_F32, 3, 1, 512, 1024)), C.byref(x), C.byref(y), 0, ws, name, 64) == 0 and name.value == b"direct"
+    assert L.y3_conv2d_fwd_variant(C.byref(_desc(_lib.Y3_F16, 3, 1, 512, 1024)), C.byref(x), C.byref(y), 0, 4096, name, 64) == 0 and name.value == b"v6"
 
 
 def test_wgrad_geometry_fills_whole_rounds():

@@ -1,0 +1,102 @@
+"""A/B timing of conv kernel variants on the BASELINE layer shapes (one MI355X, one process, interleaved rounds).
+
+    python tools/conv_lab.py [--rounds 7] [--reps 20] [--batch 32] [--only 3x3]
+
+Arms per shape: "ws" = y3_conv2d_fwd_ws (the dispatcher may pick the persistent stream-K kernel v7), "nows" = y3_conv2d_fwd
+(round-1 kernels), plus v7 under Y3_V7_GRID=-1 (whole tiles per block: isolates the halo-patch main loop from the stream-K split).
+Prints median / min microseconds per launch and TFLOP/s.  Inputs are random (DVFS: never time on zeros)."""
+import argparse
+import math
+import os
+import statistics
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+
+SHAPES = [
+    # name, h, w, cin, cout, k, s, residual
+    ("L4.cv2 64->128 @160", 160, 160, 64, 128, 3, 1, True),
+    ("L6.cv2 128->256 @80", 80, 80, 128, 256, 3, 1, True),
+    ("L8.cv2 256->512 @40", 40, 40, 256, 512, 3, 1, True),
+    ("L10.cv2 512->1024 @20", 20, 20, 512, 1024, 3, 1, True),
+    ("L13 512->1024 @20 nores", 20, 20, 512, 1024, 3, 1, False),
+    ("L7 256->512 s2 @80", 80, 80, 256, 512, 3, 2, False),
+    ("L9 512->1024 s2 @40", 40, 40, 512, 1024, 3, 2, False),
+    ("L6.cv1 256->128 @80", 80, 80, 256, 128, 1, 1, False),
+    ("L8.cv1 512->256 @40", 40, 40, 512, 256, 1, 1, False),
+    ("L10.cv1 1024->512 @20", 20, 20, 1024, 512, 1, 1, False),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--dtype", default="fp16")
+    args = ap.parse_args()
+    from yolov3_amd import ops
+
+    dev = torch.device("cuda:0")
+    dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
+    ws = ops.conv_workspace(dev)
+    g = torch.Generator().manual_seed(0)
+    print(f"{'shape':28s} {'arm':10s} {'variant':18s} {'med us':>9s} {'min us':>9s} {'TF/s(med)':>10s} {'TF/s(min)':>10s}")
+    for name, h, w, cin, cout, k, s, res in SHAPES:
+        if args.only and args.only not in name:
+            continue
+        n = args.batch
+        ho, wo = (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
+        x = torch.randn(n, cin, h, w, generator=g)
+        xv = ops.View.alloc(n, h, w, cin, dtype, dev)
+        ops.nchw_to_nhwc(x.to(dev), xv)
+        wt = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+        filt = ops.pack_filter(wt.to(dev), cout, cin, dtype)
+        bias = torch.randn(cout, generator=g).to(dev)
+        yv = ops.View.alloc(n, ho, wo, cout, dtype, dev)
+        rv = None
+        if res:
+            rv = ops.View.alloc(n, ho, wo, cout, dtype, dev)
+            rv.buf.copy_(torch.randn(rv.buf.numel(), generator=g).to(dev).to(dtype))
+        flops = 2.0 * n * ho * wo * cout * cin * k * k
+        arms = [("nows", None, {}), ("ws", ws, {})]
+        if ops.conv_variant(xv, yv, k, s, res, workspace_bytes=ws.numel()) == "v7":
+            arms.append(("ws tiles", ws, {"Y3_V7_GRID": "-1"}))
+        times = {a[0]: [] for a in arms}
+        outs = {}
+        for rnd in range(args.rounds + 1):
+            for arm, wsp, env in arms:
+                for kk, vv in env.items():
+                    os.environ[kk] = vv
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.reps):
+                    ops.conv2d(xv, filt, bias, yv, k, s, True, rv, workspace=wsp)
+                e1.record()
+                torch.cuda.synchronize()
+                for kk in env:
+                    os.environ.pop(kk)
+                if rnd:   # round 0 = warm-up
+                    times[arm].append(e0.elapsed_time(e1) * 1e3 / args.reps)
+                else:
+                    outs[arm] = yv.as_nhwc().float().clone()
+        for arm, wsp, env in arms:
+            for kk, vv in env.items():
+                os.environ[kk] = vv
+            var = ops.conv_variant(xv, yv, k, s, res, workspace_bytes=wsp.numel() if wsp is not None else 0)
+            for kk in env:
+                os.environ.pop(kk)
+            med, mn = statistics.median(times[arm]), min(times[arm])
+            diff = (outs[arm] - outs["nows"]).abs().max().item()
+            print(f"{name:28s} {arm:10s} {var:18s} {med:9.1f} {mn:9.1f} {flops / med / 1e6:10.1f} {flops / mn / 1e6:10.1f}   max|d vs nows| {diff:.3g}")
+        sys.stdout.flush()
+    hdr = ws[:64].view(torch.int32).tolist()
+    print("workspace ctl words (ticket, finished, error):", hdr[:3])
+
+
+if __name__ == "__main__":
+    main()

@@ -56,6 +56,8 @@ struct ConvArgs {
     float* stats;
     int stat_wp;   // waves along the pixel axis of the launched variant
     int dry;       // geometry only (y3_conv2d_fwd_stats_rows): fill n_pt / stat_wp, launch nothing
+    void* ws;      // scratch of the persistent stream-K kernel (conv_v7.h): control words, arrival flags, fp32 partial tiles; may be null
+    size_t ws_bytes;
 #ifdef Y3_TIMELINE  // debug build only (tools/timeline.py): per-block wall-clock stamps
     unsigned long long* tl;
 #endif
@@ -66,6 +68,8 @@ static unsigned long long* g_timeline = nullptr;
 #else
 #define Y3_STAMP(i) do { } while (0)
 #endif
+
+static thread_local const char* g_last_variant = "";   // kernel variant the last dispatch on this thread chose (y3_conv2d_fwd_variant)
 
 template <typename T> struct Mfma;
 template <> struct Mfma<f16_t> {
@@ -806,6 +810,7 @@ template <typename T, int BK, int WAVES_C, int WAVES_P, int MC, int MP, int SCHE
     const long long nb = (long long)a.n_ct * a.n_pt;
     if (nb > 0x7fffffffLL) Y3_FAIL("conv grid too large");
     a.stat_wp = WAVES_P;
+    g_last_variant = SCHED == 1 ? "v6" : (BK == 64 ? "v5_bk64" : "v5_bk32");
     if (a.dry) return 0;
     hipLaunchKernelGGL((conv_igemm_v5_kernel<T, BK, WAVES_C, WAVES_P, MC, MP, SCHED>), dim3((unsigned)nb), dim3(64 * WAVES_C * WAVES_P), 0, st, a);
     Y3_CHECK_LAUNCH();
@@ -822,6 +827,7 @@ template <typename T, int BK, int MC, int MP> int launch_v3(ConvArgs& a, hipStre
     const long long nb = (long long)a.n_ct * a.n_pt;
     if (nb > 0x7fffffffLL) Y3_FAIL("conv grid too large");
     a.stat_wp = 2;
+    g_last_variant = BK == 64 ? "v3_bk64_128x128" : (MC == 1 ? "v3_bk32_64x256" : (MP == 4 ? "v3_bk32_128x256" : "v3_bk32_128x128"));
     if (a.dry) return 0;
     hipLaunchKernelGGL((conv_igemm_v3_kernel<T, BK, MC, MP>), dim3((unsigned)nb), dim3(256), 0, st, a);
     Y3_CHECK_LAUNCH();
@@ -901,11 +907,14 @@ int launch_igemm(ConvArgs& a, hipStream_t st) {
     const long long nb = (long long)a.n_ct * a.n_pt;
     if (nb > 0x7fffffffLL) Y3_FAIL("conv grid too large");
     a.stat_wp = WAVES_P;
+    g_last_variant = SMALLC ? "v2_smallc" : "v2";
     if (a.dry) return 0;
     hipLaunchKernelGGL((conv_igemm_v2_kernel<T, BK, WAVES_C, WAVES_P, MC, MP, SMALLC>), dim3((unsigned)nb), dim3(256), 0, st, a);
     Y3_CHECK_LAUNCH();
     return 0;
 }
+
+#include "conv_v7.h"
 
 template <typename T> int dispatch_igemm(ConvArgs& a, hipStream_t st) {
     const bool c64 = (a.Cin % 64) == 0, c32 = (a.Cin % 32) == 0;
@@ -913,6 +922,7 @@ template <typename T> int dispatch_igemm(ConvArgs& a, hipStream_t st) {
     if (!(a.x_bytes && a.w_bytes && a.y_bytes && (!a.res || a.r_bytes)))
         Y3_FAIL("conv: a tensor exceeds the 2 GiB reach of a buffer descriptor (split the batch)");
     const bool dma_ok = true;
+    if (var == 3 && v7_eligible(a)) return launch_v7<T>(a, st);
     if (var >= 3 && a.Cout > 64 && c32 && dma_ok) {
         if (var == 4) return launch_v3<T, 32, 2, 4>(a, st);   // 128c x 256p, BK 32
         if (var == 5) return launch_v3<T, 32, 2, 2>(a, st);   // 128c x 128p, BK 32 (4 blocks / CU)
@@ -986,7 +996,7 @@ extern "C" int y3_pack_filter(const float* w, int32_t cout_src, int32_t cin_src,
 }
 
 static int conv_fwd_impl(const y3_conv_desc* d, const y3_tensor* x, const void* filt, const float* bias, const y3_tensor* res, const y3_tensor* y, float* stats,
-                         int64_t stat_capacity_rows, int64_t* stat_rows, int dry, void* stream) {
+                         int64_t stat_capacity_rows, int64_t* stat_rows, int dry, void* stream, void* ws = nullptr, size_t ws_bytes = 0) {
     if (!d || !x || !filt || !bias || !y) Y3_FAIL("y3_conv2d_fwd: null argument");
     if (d->ksize != 1 && d->ksize != 3) Y3_FAIL("y3_conv2d_fwd: ksize %d unsupported", d->ksize);
     if (d->stride != 1 && d->stride != 2) Y3_FAIL("y3_conv2d_fwd: stride %d unsupported", d->stride);
@@ -1022,6 +1032,8 @@ static int conv_fwd_impl(const y3_conv_desc* d, const y3_tensor* x, const void* 
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x->data; a.w = filt; a.bias = bias; a.res = res ? res->data : nullptr; a.y = y->data;
+    a.ws = ws; a.ws_bytes = ws ? ws_bytes : 0;
+    a.dry = dry && !stat_rows ? 1 : 0;
     a.N = x->n; a.H = x->h; a.W = x->w; a.Cin = d->cin; a.xpitch = x->pitch;
     a.Ho = Ho; a.Wo = Wo; a.Cout = d->cout; a.ypitch = y->pitch; a.rpitch = res ? res->pitch : 0;
     a.ks = d->ksize; a.stride = d->stride; a.pad = pad; a.act = d->act; a.ups = d->upsample2x ? 1 : 0;
@@ -1065,6 +1077,8 @@ static int conv_fwd_impl(const y3_conv_desc* d, const y3_tensor* x, const void* 
         if (d->dtype == Y3_BF16) return dispatch_igemm<bf16_t>(a, st);
         Y3_FAIL("y3_conv2d_fwd: MFMA path needs f16/bf16");
     }
+    g_last_variant = "direct";
+    if (a.dry) return 0;
     switch (d->dtype) {
         case Y3_F16: return launch_direct<f16_t>(a, st);
         case Y3_BF16: return launch_direct<bf16_t>(a, st);
@@ -1075,6 +1089,29 @@ static int conv_fwd_impl(const y3_conv_desc* d, const y3_tensor* x, const void* 
 
 extern "C" int y3_conv2d_fwd(const y3_conv_desc* d, const y3_tensor* x, const void* filt, const float* bias, const y3_tensor* res, const y3_tensor* y, void* stream) {
     return conv_fwd_impl(d, x, filt, bias, res, y, nullptr, 0, nullptr, 0, stream);
+}
+
+// ---- the same convolution with a scratch buffer: unlocks the persistent stream-K kernel (conv_v7.h) where it applies ----
+extern "C" size_t y3_conv_workspace_bytes(void) { return V7_HDR_BYTES + (size_t)V7_MAX_BLOCKS * V7_SLAB_BYTES; }
+
+extern "C" int y3_conv2d_fwd_ws(const y3_conv_desc* d, const y3_tensor* x, const void* filt, const float* bias, const y3_tensor* res, const y3_tensor* y, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    if (workspace && ((uintptr_t)workspace & 255)) Y3_FAIL("y3_conv2d_fwd_ws: the workspace must be 256-byte aligned");
+    return conv_fwd_impl(d, x, filt, bias, res, y, nullptr, 0, nullptr, 0, stream, workspace, workspace_bytes);
+}
+
+// name of the kernel variant the dispatcher picks for this problem (nothing is launched): "v7", "v6", "v3_bk64_128x128", ...
+extern "C" int y3_conv2d_fwd_variant(const y3_conv_desc* d, const y3_tensor* x, const y3_tensor* y, int32_t has_residual, size_t workspace_bytes, char* name, size_t name_cap) {
+    if (!name || name_cap < 2) Y3_FAIL("y3_conv2d_fwd_variant: no room for the name");
+    alignas(256) static const float dummy[64] = {0.0f};   // geometry only: never dereferenced
+    y3_tensor r;
+    if (has_residual && y) { r = *y; if (d && d->upsample2x) { r.h /= 2; r.w /= 2; } r.data = (void*)dummy; }
+    g_last_variant = "direct";
+    const int rc = conv_fwd_impl(d, x, (const void*)dummy, dummy, has_residual ? &r : nullptr, y, nullptr, 0, nullptr, 1, nullptr, workspace_bytes ? (void*)dummy : nullptr, workspace_bytes);
+    if (rc) return rc;
+    strncpy(name, g_last_variant, name_cap - 1);
+    name[name_cap - 1] = 0;
+    return 0;
 }
 
 // rows of the statistics buffer the launch described by (desc, x, y) would write (depends on the tile variant dispatched)

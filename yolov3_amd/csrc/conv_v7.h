@@ -1,0 +1,421 @@
+// conv_v7.h -- included by conv.hip INSIDE its anonymous namespace (shares ConvArgs, Mfma, epilogue_wave, ...).
+//
+// v7: persistent, stream-K, halo-patch implicit GEMM for the 3x3 / stride 1 / pad 1 convolutions with Cout % 256 == 0
+// (reference models/common.py:57-81 Conv inside Bottleneck.cv2, models/yolov3.yaml:23-31 and the 3x3 convs of the head) --
+// 24 of the 29 equal-FLOP 3x3 launches of a yolov3 forward, and the data gradients of the same layers.
+//
+// What v6 (conv_igemm_v5_kernel<SCHED 1>) left on the table at the BASELINE shapes (profiles/r01_*):
+//   (1) 200 / 400 / 800 tiles of 256x256 on 256 CUs: every launch pays for whole CU-rounds it fills to 78 %;
+//   (2) every one of the 9 taps re-stages the SAME input pixels (shifted by one row / column) from L2 into LDS: per 32-channel
+//       block 9 x 16 KiB of activations + 9 x 16 KiB of filters = 288 `buffer_load ... lds` pieces, and the MEM phase of a
+//       wave (4 pieces + their address arithmetic + 12 fragment reads) is longer than the 16 MFMAs it has to hide behind.
+// v7:
+//   * halo patch: for a 32-channel block the tile's input is staged ONCE as the flattened pixel range
+//     [m0 - W - 1, m0 + 256 + W + 1) x 32 channels (XP x 8 KiB, XP = 3..5); tap (dh, dw) reads its B fragments at row offset
+//     dh * W + dw of that patch.  Pixels whose tap falls outside the image (left / right / top / bottom edge -- in the flattened
+//     index those neighbours are real pixels of the previous / next row or image) read a 64-byte zero block instead: one
+//     v_cndmask on the LDS address per fragment, no data masking.  DMA pieces per block of 32 channels: 144 (filters) + 8 XP
+//     instead of 288; per wave and K-step 2 filter pieces (+ 1 patch piece in XP of the 9 steps) instead of 4.
+//   * persistent grid (one 8-wave block per CU) over the linearised (tile, channel block) space, split EVENLY (stream-K): a block
+//     owns a contiguous range of units and walks it from the END.  A tile cut by a range boundary is finished by the block that
+//     owns its LAST channel block: that block reaches the tile at the end of its walk, while the owners of the tile's head computed
+//     their part FIRST and published it as an fp32 partial slab (256 KiB; agent-scope release / acquire, guide G16).  Block ids
+//     come from an atomic ticket and a consumer only waits for EARLIER tickets of its own group, i.e. for blocks that are already
+//     running and publish before anything else: no residency or dispatch-order assumption, no deadlock.
+//   * K-loop schedule = v6's: the two wave halves run one barrier interval apart (MEM of one half beside MMA of the other),
+//     4-stage filter ring, counted vmcnt, patch double-buffered per channel block.
+//
+// LDS: [4 x 16 KiB filter ring][2 x XP x 8 KiB patch][64 B zeros]; the epilogue re-uses [0, 128 KiB) as per-wave transpose slices.
+
+#include <utility>
+
+constexpr int V7_W_STAGE = 256 * 32 * 2;       // one filter stage: 256 filters x 32 k x 2 B
+constexpr int V7_RING = 4 * V7_W_STAGE;
+constexpr int V7_MAX_BLOCKS = 256;
+constexpr size_t V7_HDR_BYTES = 64 + 4 * 1024;                 // control words + arrival flags
+constexpr size_t V7_SLAB_BYTES = (size_t)256 * 256 * 4;        // one fp32 accumulator tile
+
+struct V7Ctl {
+    unsigned ticket, finished, error, pad[13];
+};
+
+template <int I> struct IC {
+    static constexpr int value = I;
+};
+template <typename F, int... Is> Y3_DEV void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(IC<Is>{}), ...); }
+template <int N, typename F> Y3_DEV void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+Y3_DEV void wait_vm(int n) {   // n is wave-uniform; the immediate must be a literal
+    if (n >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <typename T, int XP>
+__global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int MC = 2, MP = 4;
+    constexpr int PATCH_BYTES = XP * 8 * 1024;
+    constexpr int PATCH_OFF = V7_RING;
+    constexpr int ZOFF = (V7_RING + 2 * PATCH_BYTES) > 131072 ? (V7_RING + 2 * PATCH_BYTES) : 131072;
+    constexpr int LDS_BYTES = ZOFF + 64;
+    typedef typename Mfma<T>::frag frag;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+    __shared__ __attribute__((aligned(64))) unsigned char smem[LDS_BYTES];   // the ONLY LDS object (guide: a second one de-pipelines the DMA waits)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wv >> 1, wp = wv & 1;   // 4 filter waves x 2 pixel waves, wave tile 64 filters x 128 pixels
+    const int half = wv >> 2;              // 0: leading half, 1: trailing half (one barrier interval behind)
+    const int G = gridDim.x;
+
+    V7Ctl* ctl = (V7Ctl*)p.ws;
+    unsigned* flags = (unsigned*)((char*)p.ws + 64);
+    float* slabs = (float*)((char*)p.ws + V7_HDR_BYTES);
+
+    // Work assignment.  Blocks take a ticket in START order.  Ticket t belongs to group t % NG (the XCD the dispatcher is
+    // observed to place it on: speed only) and is block t / NG of that group.  A group owns a contiguous range of whole tiles
+    // (ct fastest, so its pixel tiles' patches stay in ITS L2 across the filter tiles); inside a group the (tile, channel block)
+    // units are split evenly over its blocks.  Dependencies never cross groups and only point at EARLIER tickets (see the item
+    // loop), so progress needs no residency assumption.
+    if (tid == 0) *(unsigned*)smem = atomicAdd(&ctl->ticket, 1u);
+    __syncthreads();
+    const int ticket = __builtin_amdgcn_readfirstlane(*(const unsigned*)smem);
+    __syncthreads();
+    if (tid < 4) *(u32x4*)(smem + ZOFF + tid * 16) = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    const int NG = G < 8 ? G : 8;
+    const int xg = ticket % NG, ig = ticket / NG;
+    const int nblk = G / NG + (xg < G % NG ? 1 : 0);
+    const int ncb = p.cin_blocks;
+    const int tiles = p.n_pt * p.n_ct;
+    const int t0 = (int)((long long)tiles * xg / NG), t1 = (int)((long long)tiles * (xg + 1) / NG);
+    const int Ug = (t1 - t0) * ncb;                       // units of this group
+    const int u_lo = (int)((long long)Ug * ig / nblk);    // this block's range, group-local
+    int hi = (int)((long long)Ug * (ig + 1) / nblk);
+
+    const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+
+    // Items are visited from the END of the range to its start: a tile whose tail belongs to the next block is computed FIRST and
+    // published as an fp32 partial slab; a tile whose head belongs to previous blocks is computed LAST and completed with their
+    // slabs, which were published when those (earlier-ticket) blocks started.
+    while (hi > u_lo) {
+        const int tl = (hi - 1) / ncb;                    // group-local tile
+        const int lo = max(u_lo, tl * ncb);
+        const int cb0 = lo - tl * ncb;
+        const int ncbs = hi - lo;
+        const bool final_part = hi == (tl + 1) * ncb;     // this item ends the tile's K range: it owns the epilogue (and the bias)
+        const int tile = t0 + tl;
+        const int pt = fdiv(tile, p.dv_ct_mul, p.dv_ct_sh), ct = tile - pt * p.n_ct;
+        const int m0 = pt * 256;
+
+        // ---- per-item lane constants (also the tile-independent ones: kept kernel-wide they are what the register allocator spills) ----
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const int frow = lane_o & 31, fk = lane_o >> 5;
+        int aoff[MC];   // byte offset of this lane's kk = 0 filter fragment inside a ring stage (kk = 1: ^ 32)
+#pragma unroll
+        for (int a = 0; a < MC; ++a) {
+            const int row = (wc * MC + a) * 32 + frow;
+            aoff[a] = row * 64 + ((fk ^ ((row >> 2) & 3)) << 4);
+        }
+        const int prow0 = wp * 128 + frow;   // patch row of this lane's first pixel for tap (0, 0)
+        unsigned xpre[XP];   // byte offset of this lane's 16 bytes of patch piece j at channel block 0 (0x80000000: outside the tensor -> zeros)
+#pragma unroll
+        for (int j = 0; j < XP; ++j) {
+            const int r = (j * 8 + wv) * 16 + (lane >> 2);
+            const int g = m0 - (p.W + 1) + r;
+            const int lsl = (lane & 3) ^ ((r >> 2) & 3);
+            xpre[j] = (g >= 0 && g < p.M) ? (unsigned)((g * p.xpitch + lsl * 8) * 2) : 0x80000000u;
+        }
+        unsigned woff[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = (j * 8 + wv) * 16 + (lane >> 2);
+            const int lsl = (lane & 3) ^ ((row >> 2) & 3);
+            woff[j] = (unsigned)(((long long)(ct * 256 + row) * p.Kpad + lsl * 8) * 2);
+        }
+        int ef[MP];   // edge flags of the lane's pixels: 1 top row, 2 bottom row, 4 left column, 8 right column
+#pragma unroll
+        for (int b = 0; b < MP; ++b) {
+            const int m = m0 + wp * 128 + b * 32 + frow;
+            int n, h, w;
+            pix_coords(m < p.M ? m : p.M - 1, p, n, h, w);
+            ef[b] = (int)(h == 0) | ((int)(h == p.H - 1) << 1) | ((int)(w == 0) << 2) | ((int)(w == p.W - 1) << 3);
+        }
+
+        f32x16 acc[MC][MP];
+#pragma unroll
+        for (int a = 0; a < MC; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cb = ct * 256 + (wc * MC + a) * 32 + 8 * g + 4 * fk;
+                f32x4 bz = {0.f, 0.f, 0.f, 0.f};
+                if (final_part && p.bias && cb + 4 <= p.Cout) bz = *(const f32x4*)(p.bias + cb);   // the bias enters once: with the item that owns the epilogue
+#pragma unroll
+                for (int b = 0; b < MP; ++b)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[a][b][4 * g + q] = bz[q];
+            }
+
+        auto dma_w = [&](int kbyte, int stage) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(smem + stage * V7_W_STAGE + (j * 8 + wv) * 1024), 16, woff[j] + (unsigned)kbyte, 0, 0, 0);
+        };
+        auto dma_x = [&](int j, int cb, int buf) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(smem + PATCH_OFF + buf * PATCH_BYTES + (j * 8 + wv) * 1024), 16, xpre[j] + (unsigned)(cb * 64), 0, 0, 0);
+        };
+        auto mma = [&](const frag (&af)[MC], const frag (&bf)[MP]) {
+#pragma unroll
+            for (int a = 0; a < MC; ++a)
+#pragma unroll
+                for (int b = 0; b < MP; ++b) acc[a][b] = Mfma<T>::run(af[a], bf[b], acc[a][b]);
+        };
+
+        // ---- prologue: patch of the first channel block, filter tiles of steps 0 and 1 ----
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores of the previous item's epilogue share the counter
+#pragma unroll
+        for (int j = 0; j < XP; ++j) dma_x(j, cb0, 0);
+        dma_w((0 * p.Cin + cb0 * 32) * 2, 0);
+        dma_w((1 * p.Cin + cb0 * 32) * 2, 1);
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // patch + filter tile 0 visible to everyone (and the zero block)
+        if (half) __builtin_amdgcn_s_barrier();    // stagger
+        int s = 0;
+        for (int cbi = 0; cbi < ncbs; ++cbi) {
+            const int cb = cb0 + cbi;
+            const int buf = cbi & 1;
+            const bool more_cb = cbi + 1 < ncbs;
+            static_for<9>([&](auto TAP) {
+                constexpr int tap = decltype(TAP)::value;
+                constexpr int dh = tap / 3, dw = tap % 3;
+                constexpr int MASK = (dh == 0 ? 1 : dh == 2 ? 2 : 0) | (dw == 0 ? 4 : dw == 2 ? 8 : 0);
+                // ---- MEM(s): request patch piece / filter tile s + 2, read the fragments of step s, retire this wave's pieces of step s + 1 ----
+                int issued = 0;
+                if constexpr (tap >= 1 && tap <= XP) {
+                    if (more_cb) { dma_x(tap - 1, cb + 1, buf ^ 1); issued += 1; }
+                }
+                if (more_cb || tap + 2 < 9) {
+                    constexpr int tap2 = (tap + 2) % 9;
+                    const int cb2 = cb + (tap + 2 >= 9 ? 1 : 0);
+                    dma_w((tap2 * p.Cin + cb2 * 32) * 2, (s + 2) & 3);
+                    issued += 2;
+                }
+                frag a0[MC], a1[MC], b0[MP], b1[MP];
+                {
+                    const unsigned char* wl = smem + (s & 3) * V7_W_STAGE;
+#pragma unroll
+                    for (int a = 0; a < MC; ++a) {
+                        a0[a] = *(const frag*)(wl + aoff[a]);
+                        a1[a] = *(const frag*)(wl + (aoff[a] ^ 32));
+                    }
+                    // (the asm statements keep these per-step: hoisted out of the channel-block loop, the 9 x 4 addresses and lane masks of
+                    //  all taps would cost ~40 VGPRs + ~64 SGPRs and spill -- scratch traffic would also break the counted vmcnt)
+                    int rowv = prow0;
+                    asm volatile("" : "+v"(rowv));
+                    const int row = rowv + dh * p.W + dw;
+                    const int pa = PATCH_OFF + buf * PATCH_BYTES + row * 64 + ((fk ^ ((row >> 2) & 3)) << 4);
+#pragma unroll
+                    for (int b = 0; b < MP; ++b) {
+                        int ab = pa + b * 2048;
+                        if constexpr (MASK != 0) {
+                            int e = ef[b];
+                            asm volatile("" : "+v"(e));
+                            if ((e & MASK) != 0) ab = ZOFF;
+                        }
+                        b0[b] = *(const frag*)(smem + ab);
+                        b1[b] = *(const frag*)(smem + (ab ^ 32));
+                    }
+                }
+                wait_vm(issued);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                // ---- MMA(s) ----
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+                mma(a0, b0);
+                mma(a1, b1);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                ++s;
+            });
+        }
+        if (!half) __builtin_amdgcn_s_barrier();   // re-align the halves: every fragment read has retired, no DMA is in flight
+
+        auto finish = [&](f32x16 (&r)[MC][MP]) {
+            // two passes of 64 pixels per wave: half the residual / offset registers of one 128-pixel pass, and the 8 x 8 KiB
+            // transpose slices stay inside the filter ring
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                f32x16 part[MC][2];
+#pragma unroll
+                for (int a = 0; a < MC; ++a) { part[a][0] = r[a][2 * hb]; part[a][1] = r[a][2 * hb + 1]; }
+                epilogue_wave<T, MC, 2>(p, part, smem + wv * (2 * 32 * MC * 64), ct * 256 + wc * MC * 32, m0 + wp * 128 + hb * 64, lane, (pt * 2 + wp) * 2 + hb);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();   // the slice is private to the wave: its reads of pass 0 precede the writes of pass 1
+            }
+            __syncthreads();   // the slices are free again before the next item's DMA lands
+        };
+
+        if (cb0 == 0 && final_part) {
+            finish(acc);   // whole tile in one item: straight from the registers
+        } else {
+            // ---- a share of a tile: the fp32 partial goes to this block's slab (buffer stores with scalar offsets: 32 flat pointers per
+            //      lane would cost 64 VGPRs) ----
+            const auto rsrc_own = __builtin_amdgcn_make_buffer_rsrc((void*)(slabs + (size_t)ticket * 65536), 0, (int)V7_SLAB_BYTES, 0x00020000);
+#pragma unroll
+            for (int a = 0; a < MC; ++a)
+#pragma unroll
+                for (int b = 0; b < MP; ++b)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc_own, tid * 16, ((a * MP + b) * 4 + g) * 8192, 0);
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (!final_part) {
+                // the tile continues in the next block: publish (guide G16: stores drained by every wave, barrier, one-lane release, flag)
+                if (tid == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(&flags[ticket], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                // the tile ends here: its head belongs to the blocks before this one (tickets - NG, - 2 NG, ...), published when they
+                // started.  Sum own + their slabs in a fixed order, then the normal epilogue.  (Adding the slabs into the live K-loop
+                // accumulators instead made the compiler keep two copies of the tile and spill ~300 registers.)
+                const int t_start = tl * ncb;
+                int j_last = ig;   // first (lowest) contributing block
+                for (int j = ig - 1; j >= 0; --j) {
+                    const int uj1 = (int)((long long)Ug * (j + 1) / nblk);
+                    if (uj1 <= t_start) break;
+                    j_last = j;
+                }
+                if (tid == 0) {
+                    for (int j = ig - 1; j >= j_last; --j) {
+                        const int uj0 = (int)((long long)Ug * j / nblk), uj1 = (int)((long long)Ug * (j + 1) / nblk);
+                        if (uj0 == uj1) continue;
+                        unsigned spins = 0;
+                        while (__hip_atomic_load(&flags[j * NG + xg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                            __builtin_amdgcn_s_sleep(8);
+                            if (++spins > (1u << 22)) { ctl->error = 1u; break; }   // bounded: a lost producer must not hang the GPU
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                __syncthreads();
+                f32x16 r[MC][MP];
+#pragma unroll
+                for (int a = 0; a < MC; ++a)
+#pragma unroll
+                    for (int b = 0; b < MP; ++b)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_own, tid * 16, ((a * MP + b) * 4 + g) * 8192, 0));
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) r[a][b][4 * g + q] = v[q];
+                        }
+                for (int j = ig - 1; j >= j_last; --j) {
+                    const int uj0 = (int)((long long)Ug * j / nblk), uj1 = (int)((long long)Ug * (j + 1) / nblk);
+                    if (uj0 == uj1) continue;
+                    const auto rsrc_s = __builtin_amdgcn_make_buffer_rsrc((void*)(slabs + (size_t)(j * NG + xg) * 65536), 0, (int)V7_SLAB_BYTES, 0x00020000);
+#pragma unroll
+                    for (int a = 0; a < MC; ++a)
+#pragma unroll
+                        for (int b = 0; b < MP; ++b)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, tid * 16, ((a * MP + b) * 4 + g) * 8192, 0));
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) r[a][b][4 * g + q] += v[q];
+                            }
+                }
+                __syncthreads();
+                if (tid == 0)
+                    for (int j = ig - 1; j >= j_last; --j) __hip_atomic_store(&flags[j * NG + xg], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
+                finish(r);
+            }
+        }
+        hi = lo;
+    }
+
+    // last block out re-arms the ticket for the next launch on this workspace
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned done = atomicAdd(&ctl->finished, 1u);
+        if (done == (unsigned)G - 1u) {
+            __hip_atomic_store(&ctl->finished, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctl->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+#endif
+}
+
+static int v7_cu_count() {
+    static const int n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        return cus;
+    }();
+    return n;
+}
+
+// patch pieces per wave for an image width (rows needed: 256 + 2 W + 2, one piece = 16 rows, 8 waves): 0 = too wide for v7
+static int v7_xp(int W) {
+    const int rows = 258 + 2 * W;
+    const int xp = (rows + 127) / 128;
+    return xp < 3 ? 3 : (xp <= 5 ? xp : 0);
+}
+
+static bool v7_eligible(const ConvArgs& a) {
+    const char* sw = getenv("Y3_CONV_V7");   // read per call: the lab / tests flip it inside one process
+    const bool off = sw && !strcmp(sw, "0");
+    if (off || a.ups || !a.ws || a.ws_bytes < V7_HDR_BYTES + V7_SLAB_BYTES) return false;
+    if (a.ks != 3 || a.stride != 1 || a.pad != 1 || a.dil_shift != 0 || a.ntaps != 9 || a.omul != 1 || a.ooh != 0 || a.oow != 0) return false;
+    if (a.H != a.Ho || a.W != a.Wo || a.oH != a.Ho || a.oW != a.Wo) return false;
+    if ((a.Cin % 32) != 0 || (a.Cout % 256) != 0 || v7_xp(a.W) == 0) return false;
+    if (!a.x_bytes || !a.w_bytes || !a.y_bytes || (a.res && !a.r_bytes)) return false;
+    for (int t = 0; t < 9; ++t)
+        if (a.tdh[t] != t / 3 || a.tdw[t] != t % 3) return false;
+    const long long units = (long long)y3_ceil_div(a.M, 256) * (a.Cout / 256) * (a.Cin / 32);
+    return units >= 32 && units < 0x7fffffffLL;   // tiny problems stay on the one-tile-per-block kernels
+}
+
+template <typename T> int launch_v7(ConvArgs& a, hipStream_t st) {
+    a.n_ct = a.Cout / 256;
+    a.n_pt = y3_ceil_div(a.M, 256);
+    set_divisors(a);
+    a.cin_blocks = a.Cin / 32;
+    a.nk = 9 * a.cin_blocks;
+    a.stat_wp = 4;   // statistics rows per pixel tile: 2 pixel waves x 2 epilogue passes
+    g_last_variant = "v7";
+    if (a.dry) return 0;
+    const long long units = (long long)a.n_ct * a.n_pt * a.cin_blocks;
+    long long g = v7_cu_count();
+    if (g > V7_MAX_BLOCKS) g = V7_MAX_BLOCKS;
+    const long long cap = (long long)((a.ws_bytes - V7_HDR_BYTES) / V7_SLAB_BYTES);
+    if (g > cap) g = cap;
+    if (g > units / 4) g = units / 4 > 0 ? units / 4 : 1;   // at least 4 channel blocks (36 K-steps) per block: below that the slab traffic outweighs the parallelism
+    if (const char* e = getenv("Y3_V7_GRID")) {   // A/B knob: N > 0 caps the grid; -1 = one whole tile per block while the tiles fit (no slabs)
+        const int g_env = atoi(e);
+        if (g_env > 0 && g_env < g) g = g_env;
+        if (g_env < 0) {
+            const long long tiles = (long long)a.n_ct * a.n_pt;
+            if (tiles < g) g = tiles;
+        }
+    }
+    const int xp = v7_xp(a.W);
+    const dim3 grid((unsigned)g), block(512);
+    if (xp == 3) hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 3>), grid, block, 0, st, a);
+    else if (xp == 4) hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 4>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 5>), grid, block, 0, st, a);
+    Y3_CHECK_LAUNCH();
+    return 0;
+}

@@ -227,6 +227,9 @@ class Plan:
         self.activation_bytes = total
         L = _lib.lib()
         dcode = ops.dtype_code(self.dtype)
+        # scratch of the persistent stream-K conv kernel: one per plan (the plan's launches run in order on one stream)
+        self.workspace = ops.conv_workspace(self.device) if self.dtype != torch.float32 and any(k == "conv" for k, _ in self.steps) else None
+        ws_ptr, ws_bytes = (self.workspace.data_ptr(), self.workspace.numel()) if self.workspace is not None else (None, 0)
         for kind, kw in self.steps:
             if kind == "conv":
                 x, y, w, res = kw["x"].real(), kw["y"].real(), kw["w"], kw["res"]
@@ -238,8 +241,8 @@ class Plan:
                 m = x.n * ho * wo
                 self.launches.append(
                     _Launch(
-                        L.y3_conv2d_fwd,
-                        (C.byref(d), C.byref(xt), w.filt.data_ptr(), w.bias.data_ptr(), C.byref(rt) if rt is not None else None, C.byref(yt)),
+                        L.y3_conv2d_fwd_ws,
+                        (C.byref(d), C.byref(xt), w.filt.data_ptr(), w.bias.data_ptr(), C.byref(rt) if rt is not None else None, C.byref(yt), ws_ptr, ws_bytes),
                         keep=(d, xt, yt, rt, w),
                         label=kw["label"],
                         flops=2.0 * m * w.cout * w.cin * w.k * w.k,
@@ -296,6 +299,14 @@ class Plan:
             else:
                 raise AssertionError(kind)
         self.trace, self.steps = self.steps, None  # symbolic steps kept for the host-logic tests
+
+    def conv_variant(self, ln) -> str:
+        """kernel variant the library dispatches a conv launch of this plan to (asked from the library, nothing is launched)"""
+        d, xt, yt, rt, _w = ln.keep
+        name = C.create_string_buffer(64)
+        _lib.check(_lib.lib().y3_conv2d_fwd_variant(C.byref(d), C.byref(xt), C.byref(yt), int(rt is not None), self.workspace.numel() if self.workspace is not None else 0, name, 64),
+                   "y3_conv2d_fwd_variant")
+        return name.value.decode()
 
     # -- execution -----------------------------------------------------------------------------
     def run_body(self, stream):

@@ -77,15 +77,38 @@ def pack_filter(w_oihw: torch.Tensor, cout: int, cin: int, dtype: torch.dtype) -
     return out
 
 
+def conv_workspace(device) -> torch.Tensor:
+    """Scratch of the persistent stream-K conv kernel (y3_conv2d_fwd_ws): zero-filled once here, owned by whoever runs convs on ONE
+    stream at a time (a compiled plan keeps its own)."""
+    return torch.zeros(int(_lib.lib().y3_conv_workspace_bytes()), dtype=torch.uint8, device=device)
+
+
 def conv2d(x: View, filt: torch.Tensor, bias: torch.Tensor, y: View, k: int, stride: int, act: bool, residual: View | None = None, upsample2x: bool = False,
-           algo: int = _lib.Y3_ALGO_AUTO, in_dilation: int = 0):
+           algo: int = _lib.Y3_ALGO_AUTO, in_dilation: int = 0, workspace: torch.Tensor | None = None):
     d = Y3ConvDesc(dtype_code(x.buf.dtype), k, stride, _lib.Y3_ACT_SILU if act else _lib.Y3_ACT_NONE, int(upsample2x), algo, x.c, y.c, in_dilation)
     xt, yt = x.y3(), y.y3()
     rt = residual.y3() if residual is not None else None
+    if workspace is not None:
+        check(
+            _lib.lib().y3_conv2d_fwd_ws(C.byref(d), C.byref(xt), filt.data_ptr(), bias.data_ptr(), C.byref(rt) if rt is not None else None, C.byref(yt), workspace.data_ptr(),
+                                        workspace.numel(), stream_ptr()),
+            "y3_conv2d_fwd_ws",
+        )
+        return
     check(
         _lib.lib().y3_conv2d_fwd(C.byref(d), C.byref(xt), filt.data_ptr(), bias.data_ptr(), C.byref(rt) if rt is not None else None, C.byref(yt), stream_ptr()),
         "y3_conv2d_fwd",
     )
+
+
+def conv_variant(x: View, y: View, k: int, stride: int, residual: bool = False, upsample2x: bool = False, algo: int = _lib.Y3_ALGO_AUTO, in_dilation: int = 0,
+                 workspace_bytes: int = 0) -> str:
+    """Name of the kernel variant the library's dispatcher picks for this problem (nothing is launched)."""
+    d = Y3ConvDesc(dtype_code(x.buf.dtype), k, stride, _lib.Y3_ACT_NONE, int(upsample2x), algo, x.c, y.c, in_dilation)
+    xt, yt = x.y3(), y.y3()
+    name = C.create_string_buffer(64)
+    check(_lib.lib().y3_conv2d_fwd_variant(C.byref(d), C.byref(xt), C.byref(yt), int(residual), workspace_bytes, name, 64), "y3_conv2d_fwd_variant")
+    return name.value.decode()
 
 
 def pack_filter_stem(w_oihw: torch.Tensor, cout: int, dtype: torch.dtype) -> torch.Tensor:
