@@ -97,7 +97,7 @@ def run_conv(dev, dtype, n, h, w, cin, cout, k, s, act=True, residual=False, ups
     first = None
     for r in range(repeat):   # same workspace, back-to-back launches: flags / ticket must re-arm, results must be bit-identical
         if r:
-            yv.buf.fill_(-3.0)
+            yv.as_nhwc().fill_(-3.0)
         ops.conv2d(xv, filt, bias, yv, k, s, act, rv, ups, algo, workspace=wsp)
         torch.cuda.synchronize()
         cur = yv.as_nhwc().clone()

@@ -279,7 +279,7 @@ def test_conv_dispatch_variant_names_and_stat_rows():
 
     L = _lib.lib()
     ws = L.y3_conv_workspace_bytes()
-    assert ws == 64 + 4096 + 256 * 256 * 256 * 4
+    assert ws == 64 + 4096 + 2 * 256 * 256 * 256 * 4
     tile_px = {"v7": (256, 4), "v6": (256, 2), "v3_bk64_128x128": (128, 2), "v3_bk32_128x128": (128, 2), "v3_bk32_128x256": (256, 2), "v3_bk32_64x256": (256, 2)}
     shapes = [(32, 64, 3, 2, 640), (64, 32, 1, 1, 320), (32, 64, 3, 1, 320), (64, 128, 3, 2, 320), (128, 64, 1, 1, 160), (64, 128, 3, 1, 160), (128, 256, 3, 2, 160),
               (256, 128, 1, 1, 80), (128, 256, 3, 1, 80), (256, 512, 3, 2, 80), (512, 256, 1, 1, 40), (256, 512, 3, 1, 40), (512, 1024, 3, 2, 40), (1024, 512, 1, 1, 20),

@@ -65,7 +65,7 @@ def main():
         flops = 2.0 * n * ho * wo * cout * cin * k * k
         arms = [("nows", None, {}), ("ws", ws, {})]
         if ops.conv_variant(xv, yv, k, s, res, workspace_bytes=ws.numel()) == "v7":
-            arms.append(("ws tiles", ws, {"Y3_V7_GRID": "-1"}))
+            arms += [("ws s0", ws, {"Y3_V7_SCHED": "0"}), ("tiles s1", ws, {"Y3_V7_GRID": "-1"}), ("tiles s0", ws, {"Y3_V7_GRID": "-1", "Y3_V7_SCHED": "0"})]
         times = {a[0]: [] for a in arms}
         outs = {}
         for rnd in range(args.rounds + 1):

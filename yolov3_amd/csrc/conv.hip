@@ -58,6 +58,7 @@ struct ConvArgs {
     int dry;       // geometry only (y3_conv2d_fwd_stats_rows): fill n_pt / stat_wp, launch nothing
     void* ws;      // scratch of the persistent stream-K kernel (conv_v7.h): control words, arrival flags, fp32 partial tiles; may be null
     size_t ws_bytes;
+    int v7_whole;  // conv_v7.h: blocks own whole tiles (no stream-K split)
 #ifdef Y3_TIMELINE  // debug build only (tools/timeline.py): per-block wall-clock stamps
     unsigned long long* tl;
 #endif
@@ -1092,7 +1093,7 @@ extern "C" int y3_conv2d_fwd(const y3_conv_desc* d, const y3_tensor* x, const vo
 }
 
 // ---- the same convolution with a scratch buffer: unlocks the persistent stream-K kernel (conv_v7.h) where it applies ----
-extern "C" size_t y3_conv_workspace_bytes(void) { return V7_HDR_BYTES + (size_t)V7_MAX_BLOCKS * V7_SLAB_BYTES; }
+extern "C" size_t y3_conv_workspace_bytes(void) { return V7_HDR_BYTES + 2 * (size_t)V7_MAX_BLOCKS * V7_SLAB_BYTES; }   // a published + a private slab per block
 
 extern "C" int y3_conv2d_fwd_ws(const y3_conv_desc* d, const y3_tensor* x, const void* filt, const float* bias, const y3_tensor* res, const y3_tensor* y, void* workspace,
                                 size_t workspace_bytes, void* stream) {

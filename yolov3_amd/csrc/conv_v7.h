@@ -52,7 +52,11 @@ Y3_DEV void wait_vm(int n) {   // n is wave-uniform; the immediate must be a lit
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <typename T, int XP>
+// SCHED 0: the DMA requests of a K-step are issued at the head of the wave's MEM phase (v6's placement).
+// SCHED 1: they are issued BETWEEN the MFMAs of the MMA phase, one step further ahead (filter tile s + 3 during MMA(s)): a
+//          `buffer_load ... lds` costs 60-185 issue cycles, which made MEM (~800 cycles) longer than the 16 MFMAs (512) it hides behind;
+//          inside the MFMA stream the same requests fill issue slots the matrix pipe leaves free.
+template <typename T, int XP, int SCHED>
 __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int MC = 2, MP = 4;
@@ -94,8 +98,12 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p)
     const int tiles = p.n_pt * p.n_ct;
     const int t0 = (int)((long long)tiles * xg / NG), t1 = (int)((long long)tiles * (xg + 1) / NG);
     const int Ug = (t1 - t0) * ncb;                       // units of this group
-    const int u_lo = (int)((long long)Ug * ig / nblk);    // this block's range, group-local
+    int u_lo = (int)((long long)Ug * ig / nblk);          // this block's range, group-local
     int hi = (int)((long long)Ug * (ig + 1) / nblk);
+    if (p.v7_whole) {                                     // whole tiles only: no tile is shared between blocks, no slabs
+        u_lo = (int)((long long)(t1 - t0) * ig / nblk) * ncb;
+        hi = (int)((long long)(t1 - t0) * (ig + 1) / nblk) * ncb;
+    }
 
     const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
     const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
@@ -177,13 +185,23 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p)
                 for (int b = 0; b < MP; ++b) acc[a][b] = Mfma<T>::run(af[a], bf[b], acc[a][b]);
         };
 
-        // ---- prologue: patch of the first channel block, filter tiles of steps 0 and 1 ----
+        // ---- prologue: patch of the first channel block, filter tiles of the first 2 (SCHED 0) / 3 (SCHED 1) steps ----
+        const int nsteps = 9 * ncbs;
+        auto kbyte_of = [&](int step) {   // byte offset inside a packed filter row of K-step `step` of this item: k = tap * Cin + cb * 32
+            const int cbi_ = step / 9, tap_ = step - cbi_ * 9;
+            return (tap_ * p.Cin + (cb0 + cbi_) * 32) * 2;
+        };
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores of the previous item's epilogue share the counter
 #pragma unroll
         for (int j = 0; j < XP; ++j) dma_x(j, cb0, 0);
-        dma_w((0 * p.Cin + cb0 * 32) * 2, 0);
-        dma_w((1 * p.Cin + cb0 * 32) * 2, 1);
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        dma_w(kbyte_of(0), 0);
+        dma_w(kbyte_of(1), 1);
+        if constexpr (SCHED == 1) {
+            dma_w(kbyte_of(2), 2);   // nsteps >= 9
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();              // patch + filter tile 0 visible to everyone (and the zero block)
         if (half) __builtin_amdgcn_s_barrier();    // stagger
         int s = 0;
@@ -195,16 +213,24 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p)
                 constexpr int tap = decltype(TAP)::value;
                 constexpr int dh = tap / 3, dw = tap % 3;
                 constexpr int MASK = (dh == 0 ? 1 : dh == 2 ? 2 : 0) | (dw == 0 ? 4 : dw == 2 ? 8 : 0);
-                // ---- MEM(s): request patch piece / filter tile s + 2, read the fragments of step s, retire this wave's pieces of step s + 1 ----
-                int issued = 0;
-                if constexpr (tap >= 1 && tap <= XP) {
-                    if (more_cb) { dma_x(tap - 1, cb + 1, buf ^ 1); issued += 1; }
-                }
-                if (more_cb || tap + 2 < 9) {
-                    constexpr int tap2 = (tap + 2) % 9;
-                    const int cb2 = cb + (tap + 2 >= 9 ? 1 : 0);
-                    dma_w((tap2 * p.Cin + cb2 * 32) * 2, (s + 2) & 3);
-                    issued += 2;
+                // ---- MEM(s): [SCHED 0: request patch piece / filter tile s + 2,] read the fragments of step s, retire this wave's pieces of step s + 1 ----
+                int issued = 0;   // requests younger than filter tile s + 1: they may stay in flight
+                if constexpr (SCHED == 0) {
+                    if constexpr (tap >= 1 && tap <= XP) {
+                        if (more_cb) { dma_x(tap - 1, cb + 1, buf ^ 1); issued += 1; }
+                    }
+                    if (more_cb || tap + 2 < 9) {
+                        constexpr int tap2 = (tap + 2) % 9;
+                        const int cb2 = cb + (tap + 2 >= 9 ? 1 : 0);
+                        dma_w((tap2 * p.Cin + cb2 * 32) * 2, (s + 2) & 3);
+                        issued += 2;
+                    }
+                } else {
+                    // issued during MMA(s - 1): filter tile s + 2, and a patch piece when step s - 1 was one of the first XP taps of this channel block
+                    if (s + 2 < nsteps) issued += 2;
+                    if constexpr (tap >= 1 && tap <= XP) {
+                        if (more_cb) issued += 1;
+                    }
                 }
                 frag a0[MC], a1[MC], b0[MP], b1[MP];
                 {
@@ -238,8 +264,35 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p)
                 // ---- MMA(s) ----
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(1);
-                mma(a0, b0);
-                mma(a1, b1);
+                if constexpr (SCHED == 0) {
+                    mma(a0, b0);
+                    mma(a1, b1);
+                } else {
+                    // 4 groups of 4 MFMAs; the requests for step s + 3 (2 filter pieces) and, in the first XP taps, one piece of the next channel
+                    // block's patch go between the groups.  Stage (s + 3) & 3 held tile s - 1, whose last fragment reads retired two barriers ago.
+                    const bool more_w = s + 3 < nsteps;
+                    constexpr int tap3 = (tap + 3) % 9;
+                    const int kb3 = (tap3 * p.Cin + (cb + (tap + 3 >= 9 ? 1 : 0)) * 32) * 2;
+#pragma unroll
+                    for (int b = 0; b < MP; ++b) acc[0][b] = Mfma<T>::run(a0[0], b0[b], acc[0][b]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more_w) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(smem + ((s + 3) & 3) * V7_W_STAGE + wv * 1024), 16, woff[0] + (unsigned)kb3, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int b = 0; b < MP; ++b) acc[1][b] = Mfma<T>::run(a0[1], b0[b], acc[1][b]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more_w) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(smem + ((s + 3) & 3) * V7_W_STAGE + (8 + wv) * 1024), 16, woff[1] + (unsigned)kb3, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int b = 0; b < MP; ++b) acc[0][b] = Mfma<T>::run(a1[0], b1[b], acc[0][b]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (tap < XP) {
+                        if (more_cb) dma_x(tap, cb + 1, buf ^ 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int b = 0; b < MP; ++b) acc[1][b] = Mfma<T>::run(a1[1], b1[b], acc[1][b]);
+                }
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
@@ -268,7 +321,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p)
         } else {
             // ---- a share of a tile: the fp32 partial goes to this block's slab (buffer stores with scalar offsets: 32 flat pointers per
             //      lane would cost 64 VGPRs) ----
-            const auto rsrc_own = __builtin_amdgcn_make_buffer_rsrc((void*)(slabs + (size_t)ticket * 65536), 0, (int)V7_SLAB_BYTES, 0x00020000);
+            // a block can be the producer of one tile (first item) AND the finisher of another (last item): the finisher's own share
+            // goes to a second, private slab so that the published one is never overwritten
+            const auto rsrc_own = __builtin_amdgcn_make_buffer_rsrc((void*)(slabs + (size_t)(final_part ? V7_MAX_BLOCKS + ticket : ticket) * 65536), 0, (int)V7_SLAB_BYTES, 0x00020000);
 #pragma unroll
             for (int a = 0; a < MC; ++a)
 #pragma unroll
@@ -377,7 +432,7 @@ static int v7_xp(int W) {
 static bool v7_eligible(const ConvArgs& a) {
     const char* sw = getenv("Y3_CONV_V7");   // read per call: the lab / tests flip it inside one process
     const bool off = sw && !strcmp(sw, "0");
-    if (off || a.ups || !a.ws || a.ws_bytes < V7_HDR_BYTES + V7_SLAB_BYTES) return false;
+    if (off || a.ups || !a.ws || a.ws_bytes < V7_HDR_BYTES + 2 * V7_MAX_BLOCKS * V7_SLAB_BYTES) return false;
     if (a.ks != 3 || a.stride != 1 || a.pad != 1 || a.dil_shift != 0 || a.ntaps != 9 || a.omul != 1 || a.ooh != 0 || a.oow != 0) return false;
     if (a.H != a.Ho || a.W != a.Wo || a.oH != a.Ho || a.oW != a.Wo) return false;
     if ((a.Cin % 32) != 0 || (a.Cout % 256) != 0 || v7_xp(a.W) == 0) return false;
@@ -400,22 +455,30 @@ template <typename T> int launch_v7(ConvArgs& a, hipStream_t st) {
     const long long units = (long long)a.n_ct * a.n_pt * a.cin_blocks;
     long long g = v7_cu_count();
     if (g > V7_MAX_BLOCKS) g = V7_MAX_BLOCKS;
-    const long long cap = (long long)((a.ws_bytes - V7_HDR_BYTES) / V7_SLAB_BYTES);
-    if (g > cap) g = cap;
     if (g > units / 4) g = units / 4 > 0 ? units / 4 : 1;   // at least 4 channel blocks (36 K-steps) per block: below that the slab traffic outweighs the parallelism
-    if (const char* e = getenv("Y3_V7_GRID")) {   // A/B knob: N > 0 caps the grid; -1 = one whole tile per block while the tiles fit (no slabs)
+    a.v7_whole = 0;
+    if (const char* e = getenv("Y3_V7_GRID")) {   // A/B knob: N > 0 caps the grid; -1 = whole tiles per block (no tile shared between blocks, no slabs)
         const int g_env = atoi(e);
         if (g_env > 0 && g_env < g) g = g_env;
         if (g_env < 0) {
+            a.v7_whole = 1;
             const long long tiles = (long long)a.n_ct * a.n_pt;
             if (tiles < g) g = tiles;
         }
     }
     const int xp = v7_xp(a.W);
     const dim3 grid((unsigned)g), block(512);
-    if (xp == 3) hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 3>), grid, block, 0, st, a);
-    else if (xp == 4) hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 4>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 5>), grid, block, 0, st, a);
+    int sched = 1;
+    if (const char* e = getenv("Y3_V7_SCHED")) sched = atoi(e);
+    if (sched == 0) {
+        if (xp == 3) hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 3, 0>), grid, block, 0, st, a);
+        else if (xp == 4) hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 4, 0>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 5, 0>), grid, block, 0, st, a);
+    } else {
+        if (xp == 3) hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 3, 1>), grid, block, 0, st, a);
+        else if (xp == 4) hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 4, 1>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 5, 1>), grid, block, 0, st, a);
+    }
     Y3_CHECK_LAUNCH();
     return 0;
 }
