@@ -176,7 +176,9 @@ V7_CASES = [   # every case has >= 32 (tile, channel block) units, the dispatche
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("name,shape,kw", V7_CASES, ids=[c[0] for c in V7_CASES])
-def test_conv_v7_streamk_vs_fp32_reference(dev, dtype, name, shape, kw):
+def test_conv_v7_streamk_vs_fp32_reference(dev, dtype, name, shape, kw, monkeypatch):
+    monkeypatch.setenv("Y3_CONV_V7", "all")    # also the Cin < 256 shapes the dispatcher leaves to the 128x128 kernels
+    monkeypatch.setenv("Y3_V7_GRID", "-2")     # even K split whatever the tile count: every case crosses tile boundaries inside blocks
     out, ref = run_conv(dev, dtype, *shape, algo=1, ws=True, expect="v7", repeat=3, **kw)
     _conv_tol_check(name, dtype, out, ref)
 
@@ -185,7 +187,7 @@ def test_conv_v7_grid_sweep(dev, monkeypatch):
     """the same problem under different block counts (different K splits, down to whole tiles): every split sums the same
     products in fp32, so the results agree to accumulation-order noise and each one is inside the conv tolerance"""
     outs = []
-    for grid in ("-1", "7", "24", "61", "0"):
+    for grid in ("-1", "-2", "7", "24", "61"):
         monkeypatch.setenv("Y3_V7_GRID", grid)
         out, ref = run_conv(dev, torch.float16, 4, 20, 20, 256, 512, 3, 1, algo=1, ws=True, expect="v7", repeat=2, residual=True)
         _conv_tol_check(f"grid{grid}", torch.float16, out, ref)
@@ -198,7 +200,7 @@ def test_conv_v7_grid_sweep(dev, monkeypatch):
 # bench actually runs (multi-round grids, XCD remap at 200-3200 blocks, ragged last tiles at M = 12800 / 51200 / 204800).
 BASELINE_CONV_CASES = [
     # name, (n,h,w,cin,cout,k,s), kwargs, variant with workspace
-    ("L6cv2_128_256_80", (32, 80, 80, 128, 256, 3, 1), {"residual": True}, "v7"),
+    ("L6cv2_128_256_80", (32, 80, 80, 128, 256, 3, 1), {"residual": True}, "v3_bk64_128x128"),
     ("L8cv2_256_512_40", (32, 40, 40, 256, 512, 3, 1), {"residual": True}, "v7"),
     ("L10cv2_512_1024_20", (32, 20, 20, 512, 1024, 3, 1), {"residual": True}, "v7"),
     ("L7_256_512_s2", (32, 80, 80, 256, 512, 3, 2), {}, "v6"),
@@ -210,7 +212,8 @@ BASELINE_CONV_CASES = [
     ("head255_20", (32, 20, 20, 1024, 256, 1, 1), {"cout_real": 255, "act": False}, "v3_bk64_128x128"),
     ("head255_80", (32, 80, 80, 256, 256, 1, 1), {"cout_real": 255, "act": False}, "v3_bk32_128x128"),
     ("head1110_40_c5", (8, 40, 40, 1024, 1112, 1, 1), {"cout_real": 1110, "act": False}, None),
-    ("c5_128_256_160", (8, 160, 160, 128, 256, 3, 1), {"residual": True}, "v7"),
+    ("c5_128_256_160", (8, 160, 160, 128, 256, 3, 1), {"residual": True}, "v3_bk64_128x128"),
+    ("c5_256_512_80", (8, 80, 80, 256, 512, 3, 1), {"residual": True}, "v7"),
     ("ups_route_20", (32, 20, 20, 512, 256, 1, 1), {"ups": True}, None),
 ]
 
@@ -221,8 +224,8 @@ def test_conv_baseline_shapes_fp16(dev, name, shape, kw, variant):
     _conv_tol_check(name, torch.float16, out, ref)
 
 
-@pytest.mark.parametrize("name,shape,kw,variant", [c for c in BASELINE_CONV_CASES if c[0] in ("L8cv2_256_512_40", "L9_512_1024_s2", "head1110_40_c5", "c5_128_256_160")],
-                         ids=["L8cv2_256_512_40", "L9_512_1024_s2", "head1110_40_c5", "c5_128_256_160"])
+@pytest.mark.parametrize("name,shape,kw,variant", [c for c in BASELINE_CONV_CASES if c[0] in ("L8cv2_256_512_40", "L9_512_1024_s2", "head1110_40_c5", "c5_256_512_80")],
+                         ids=["L8cv2_256_512_40", "L9_512_1024_s2", "head1110_40_c5", "c5_256_512_80"])
 def test_conv_baseline_shapes_bf16(dev, name, shape, kw, variant):
     out, ref = run_conv(dev, torch.bfloat16, *shape, algo=1, ws=True, expect=variant, **kw)
     _conv_tol_check(name, torch.bfloat16, out, ref)

@@ -284,7 +284,7 @@ def test_conv_dispatch_variant_names_and_stat_rows():
     shapes = [(32, 64, 3, 2, 640), (64, 32, 1, 1, 320), (32, 64, 3, 1, 320), (64, 128, 3, 2, 320), (128, 64, 1, 1, 160), (64, 128, 3, 1, 160), (128, 256, 3, 2, 160),
               (256, 128, 1, 1, 80), (128, 256, 3, 1, 80), (256, 512, 3, 2, 80), (512, 256, 1, 1, 40), (256, 512, 3, 1, 40), (512, 1024, 3, 2, 40), (1024, 512, 1, 1, 20),
               (512, 1024, 3, 1, 20), (768, 256, 1, 1, 40), (384, 128, 1, 1, 80), (256, 256, 1, 1, 80), (512, 256, 1, 1, 20)]
-    v7_shapes = {(128, 256, 3, 1, 80), (256, 512, 3, 1, 40), (512, 1024, 3, 1, 20)}   # 3x3, stride 1, cout % 256 == 0: the persistent stream-K kernel
+    v7_shapes = {(256, 512, 3, 1, 40), (512, 1024, 3, 1, 20)}   # 3x3, stride 1, cin >= 256, cout % 256 == 0: the persistent halo-patch kernel
     for bs in (32, 64):
         for cin, cout, k, s, hin in shapes:
             ho = (hin + 2 * (k // 2) - k) // s + 1

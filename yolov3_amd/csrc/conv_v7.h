@@ -56,9 +56,18 @@ Y3_DEV void wait_vm(int n) {   // n is wave-uniform; the immediate must be a lit
 // SCHED 1: they are issued BETWEEN the MFMAs of the MMA phase, one step further ahead (filter tile s + 3 during MMA(s)): a
 //          `buffer_load ... lds` costs 60-185 issue cycles, which made MEM (~800 cycles) longer than the 16 MFMAs (512) it hides behind;
 //          inside the MFMA stream the same requests fill issue slots the matrix pipe leaves free.
+#ifdef Y3_TIMELINE   // debug build (tools/v7_probe.py): per-wave cycle sums of the four intervals of a K-step
+#define V7_T(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tsum[i] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define V7_T(i) do { } while (0)
+#endif
+
 template <typename T, int XP, int SCHED>
 __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+#ifdef Y3_TIMELINE
+    unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+#endif
     constexpr int MC = 2, MP = 4;
     constexpr int PATCH_BYTES = XP * 8 * 1024;
     constexpr int PATCH_OFF = V7_RING;
@@ -205,6 +214,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p)
         __builtin_amdgcn_s_barrier();              // patch + filter tile 0 visible to everyone (and the zero block)
         if (half) __builtin_amdgcn_s_barrier();    // stagger
         int s = 0;
+#ifdef Y3_TIMELINE
+        tprev = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
         for (int cbi = 0; cbi < ncbs; ++cbi) {
             const int cb = cb0 + cbi;
             const int buf = cbi & 1;
@@ -258,9 +271,12 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p)
                         b1[b] = *(const frag*)(smem + (ab ^ 32));
                     }
                 }
+                V7_T(0);   // MEM issue (requests + fragment reads issued, reads landed)
                 wait_vm(issued);
+                V7_T(1);   // vmcnt wait
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
+                V7_T(2);   // barrier after MEM
                 // ---- MMA(s) ----
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(1);
@@ -295,7 +311,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p)
                 }
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
+                V7_T(3);   // MMA issue (the last MFMAs may still be in the pipe)
                 __builtin_amdgcn_s_barrier();
+                V7_T(4);   // barrier after MMA
                 ++s;
             });
         }
@@ -401,6 +419,12 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p)
         hi = lo;
     }
 
+#ifdef Y3_TIMELINE
+    if (p.tl && lane == 0 && blockIdx.x < 64) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) p.tl[((long long)blockIdx.x * 8 + wv) * 8 + i] = tsum[i];
+    }
+#endif
     // last block out re-arms the ticket for the next launch on this workspace
     __syncthreads();
     if (tid == 0) {
@@ -436,6 +460,7 @@ static bool v7_eligible(const ConvArgs& a) {
     if (a.ks != 3 || a.stride != 1 || a.pad != 1 || a.dil_shift != 0 || a.ntaps != 9 || a.omul != 1 || a.ooh != 0 || a.oow != 0) return false;
     if (a.H != a.Ho || a.W != a.Wo || a.oH != a.Ho || a.oW != a.Wo) return false;
     if ((a.Cin % 32) != 0 || (a.Cout % 256) != 0 || v7_xp(a.W) == 0) return false;
+    if (a.Cin < 256 && !(sw && !strcmp(sw, "all"))) return false;   // K = 1152 (4 channel blocks per tile): the per-tile prologue / epilogue outweighs the faster main loop (169 vs 153 us @80x80)
     if (!a.x_bytes || !a.w_bytes || !a.y_bytes || (a.res && !a.r_bytes)) return false;
     for (int t = 0; t < 9; ++t)
         if (a.tdh[t] != t / 3 || a.tdw[t] != t % 3) return false;
@@ -456,19 +481,22 @@ template <typename T> int launch_v7(ConvArgs& a, hipStream_t st) {
     long long g = v7_cu_count();
     if (g > V7_MAX_BLOCKS) g = V7_MAX_BLOCKS;
     if (g > units / 4) g = units / 4 > 0 ? units / 4 : 1;   // at least 4 channel blocks (36 K-steps) per block: below that the slab traffic outweighs the parallelism
-    a.v7_whole = 0;
-    if (const char* e = getenv("Y3_V7_GRID")) {   // A/B knob: N > 0 caps the grid; -1 = whole tiles per block (no tile shared between blocks, no slabs)
+    // Whole tiles per block unless the launch has too few tiles to occupy the chip.  Measured on MI355X (profiles/r02_conv_v7.md): at
+    // 200-800 tiles the fp32 slab round trips of an even K split (256 KiB per cut tile through a CU's ~25 GB/s store path) cost more
+    // than the 22 % of idle CU-rounds they recover (172 vs 120 us on 512->1024 @20x20, batch 32); with a handful of tiles (small
+    // batches) the split is what puts every CU to work.
+    const long long tiles = (long long)a.n_ct * a.n_pt;
+    a.v7_whole = tiles >= 64 ? 1 : 0;
+    if (const char* e = getenv("Y3_V7_GRID")) {   // A/B knob: N > 0 caps the grid; -1 = whole tiles; -2 = even K split (stream-K) whatever the tile count
         const int g_env = atoi(e);
         if (g_env > 0 && g_env < g) g = g_env;
-        if (g_env < 0) {
-            a.v7_whole = 1;
-            const long long tiles = (long long)a.n_ct * a.n_pt;
-            if (tiles < g) g = tiles;
-        }
+        if (g_env == -1) a.v7_whole = 1;
+        if (g_env == -2) a.v7_whole = 0;
     }
+    if (a.v7_whole && tiles < g) g = tiles;
     const int xp = v7_xp(a.W);
     const dim3 grid((unsigned)g), block(512);
-    int sched = 1;
+    int sched = 0;   // SCHED 1 measured 2-6 % slower (profiles/r02_conv_v7.md); kept for A/B
     if (const char* e = getenv("Y3_V7_SCHED")) sched = atoi(e);
     if (sched == 0) {
         if (xp == 3) hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 3, 0>), grid, block, 0, st, a);
