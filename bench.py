@@ -46,7 +46,7 @@ def per_kernel_times(plan, reps=5):
         for ln in plan.launches:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            ln.fn(*ln.args, stream)
+            ln.fn(*plan.resolved_args(ln), stream)
             e1.record()
             evs.append((ln, e0, e1))
         torch.cuda.synchronize()

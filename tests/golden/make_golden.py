@@ -248,11 +248,59 @@ def gen_val_edge_goldens(ns):
     torch.save(out, OUT / "val_edge.pt")
 
 
+def gen_big_goldens(ns):
+    """The benchmarked resolutions (416x416 tiny = BASELINE configs[0], 640x640 yolov3 = configs[1]/[3]): eval output of the
+    unmodified reference.  Fixtures stay small: every STEP-th prediction row + whole-tensor statistics (sum |.|, max |.|)."""
+    out = {}
+    for name, nc, hw, bs, step in [("yolov3-tiny", 80, 416, 2, 4), ("yolov3", 80, 640, 1, 16), ("yolov3-spp", 80, 640, 1, 16)]:
+        m, sd, layers, save, strides = build_ref_model(ns, name, nc, seed=11)
+        x = torch.rand(bs, 3, hw, hw, generator=torch.Generator().manual_seed(5))
+        m.eval()
+        with torch.no_grad():
+            pred, raw = m(x)
+        out[f"{name}-nc{nc}-{hw}-bs{bs}"] = {
+            "x_sum": checksum(x), "step": step, "pred_rows": pred[:, ::step].clone(), "pred_sum": checksum(pred), "pred_max": float(pred.abs().max()),
+            "raw_sum": [checksum(t) for t in raw], "raw_max": [float(t.abs().max()) for t in raw],
+            "raw_rows": [t.reshape(t.shape[0], -1, t.shape[-1])[:, ::step].clone() for t in raw],
+        }
+        print("big", name, hw, tuple(pred.shape), out[f"{name}-nc{nc}-{hw}-bs{bs}"]["pred_sum"])
+    torch.save(out, OUT / "model_fwd_big.pt")
+
+
+def gen_ckpt_fixture(ns):
+    """A checkpoint pickled by the UNMODIFIED reference exactly as train.py:470-488 saves it ({'model': deepcopy(model).half(), ...}),
+    for a width-0.25 yolov3-tiny (0.56 M parameters -> ~1.2 MB), plus the reference's own eval output of that checkpoint loaded the way
+    models/experimental.py:88-136 attempt_load does (float, fuse, eval) on a rectangular batch."""
+    from copy import deepcopy
+
+    d = yaml.safe_load(open(CFG / "yolov3-tiny.yaml"))
+    d["width_multiple"] = 0.25
+    torch.manual_seed(7)
+    m = ns.DetectionModel(d, ch=3, nc=80)
+    g = torch.Generator().manual_seed(8)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.weight.data = torch.rand(mod.weight.shape, generator=g) + 0.5
+            mod.bias.data = torch.randn(mod.bias.shape, generator=g) * 0.1
+            mod.running_mean = torch.randn(mod.running_mean.shape, generator=g) * 0.1
+            mod.running_var = torch.rand(mod.running_var.shape, generator=g) + 0.5
+    m.names = {i: f"c{i}" for i in range(80)}
+    ckpt = {"epoch": 5, "best_fitness": None, "model": deepcopy(m).half(), "ema": None, "updates": None, "optimizer": None, "opt": {}, "git": None, "date": "2026-09-21"}
+    torch.save(ckpt, OUT / "ref_tiny_w025_fp16.pt")
+    loaded = torch.load(OUT / "ref_tiny_w025_fp16.pt", map_location="cpu", weights_only=False)["model"].float().fuse().eval()   # attempt_load's steps
+    x = torch.rand(2, 3, 96, 160, generator=torch.Generator().manual_seed(9))
+    with torch.no_grad():
+        pred, raw = loaded(x)
+    torch.save({"x_sum": checksum(x), "pred": pred.clone(), "raw": [t.clone() for t in raw], "n_params": sum(p.numel() for p in m.parameters()),
+                "stride": [float(s) for s in m.stride]}, OUT / "ref_tiny_w025_eval.pt")
+    print("ckpt", (OUT / "ref_tiny_w025_fp16.pt").stat().st_size, tuple(pred.shape))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ns = ref_shim.load()
-    which = set(sys.argv[1:]) or {"model", "decode", "nms", "loss", "val_edge"}  # python make_golden.py [model decode nms loss val_edge]
+    which = set(sys.argv[1:]) or {"model", "decode", "nms", "loss", "val_edge", "big", "ckpt"}  # python make_golden.py [model decode nms loss val_edge big ckpt]
     if "model" in which:
         gen_model_goldens(ns)
     if "decode" in which:
@@ -263,4 +311,8 @@ if __name__ == "__main__":
         gen_loss_goldens(ns)
     if "val_edge" in which:
         gen_val_edge_goldens(ns)
+    if "big" in which:
+        gen_big_goldens(ns)
+    if "ckpt" in which:
+        gen_ckpt_fixture(ns)
     print("golden files:", [(p.name, p.stat().st_size) for p in OUT.glob("*.pt")])

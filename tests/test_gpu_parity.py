@@ -557,14 +557,74 @@ def test_model_half_vs_fp32_oracle(dev, name, hw, bs, dtype):
     torch.cuda.synchronize()
     with torch.no_grad():
         refp, refraw = yo.forward(layers, save, sd, x, strides, training=False)
-    tol = 0.03 if dtype == torch.float16 else 0.25
-    for a, b in zip(raw, refraw):
-        a = a.float().cpu()
-        rel = (a - b).abs().max().item() / b.abs().max().item()
-        assert rel < tol, f"{name} {dtype}: raw logits rel-to-max err {rel:.4f}"
-        corr = torch.corrcoef(torch.stack((a.flatten(), b.flatten())))[0, 1].item()
-        assert corr > (0.9995 if dtype == torch.float16 else 0.99), f"correlation {corr}"
+    bnd = HALF_BOUNDS[dtype]
+    for lvl, (a, b) in enumerate(zip(raw, refraw)):
+        rms, mx, corr = _rel_errors(a.float().cpu(), b)
+        print(f"[half-vs-oracle {name} {hw} {dtype}] level {lvl}: rel RMS {rms:.5f}  max/range {mx:.5f}  corr {corr:.6f}")
+        assert rms < bnd["rms"] and mx < bnd["mx"] and corr > bnd["corr"], f"{name} {dtype} level {lvl}: rms {rms:.4g} max {mx:.4g} corr {corr:.6f}"
     assert pred.shape == refp.shape and pred.dtype == dtype
+
+
+@pytest.mark.parametrize("key", ["yolov3-tiny-nc80-416-bs2", "yolov3-nc80-640-bs1", "yolov3-spp-nc80-640-bs1"])
+def test_model_fp32_vs_reference_golden_benchmark_resolutions(dev, golden_dir, key):
+    """fp32 engine against the UNMODIFIED reference at 416x416 (BASELINE configs[0]) and 640x640 (configs[1] / [3]): sampled raw logits
+    within 1e-4, decoded boxes 1e-4 relative, whole-tensor |.| sums 1e-5 relative (north_star tolerance)."""
+    gold = torch.load(golden_dir / "model_fwd_big.pt")[key]
+    name, nc, hw, bs = key.rsplit("-", 3)
+    nc, hw, bs = int(nc[2:]), int(hw), int(bs[2:])
+    m, _ = build_pair(name, nc, 11, dev, torch.float32)
+    x = torch.rand(bs, 3, hw, hw, generator=torch.Generator().manual_seed(5))
+    assert checksum(x) == gold["x_sum"]
+    pred, raw = m(x.to(dev))
+    torch.cuda.synchronize()
+    st = gold["step"]
+    for a, rows, sm in zip(raw, gold["raw_rows"], gold["raw_sum"]):
+        a = a.cpu()
+        err = (a.reshape(a.shape[0], -1, a.shape[-1])[:, ::st] - rows).abs().max().item()
+        assert err < 1e-4, f"{key}: raw logits max abs err {err:.3g}"
+        assert abs(checksum(a) - sm) < 1e-5 * sm
+    torch.testing.assert_close(pred.cpu()[:, ::st], gold["pred_rows"], rtol=1e-4, atol=1e-4)
+    assert abs(checksum(pred.cpu()) - gold["pred_sum"]) < 1e-5 * gold["pred_sum"]
+
+
+def _rel_errors(a, b):
+    """(relative RMS error, max abs error / max |b|, Pearson correlation) of a against the reference b"""
+    a, b = a.double().flatten(), b.double().flatten()
+    rms = ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
+    mx = ((a - b).abs().max() / b.abs().max()).item()
+    corr = torch.corrcoef(torch.stack((a, b)))[0, 1].item()
+    return rms, mx, corr
+
+
+# Bounds for the half-precision engines against the fp32 oracle with the same weights, raw logits of every level.  Model: each of the
+# ~75 stored tensors is rounded once (relative 2^-11 fp16 / 2^-8 bf16, uniform), errors of successive layers add in quadrature and the
+# residual trunk carries them forward: relative RMS ~ sqrt(75) * eps / sqrt(3) = 0.24 % fp16 / 2.0 % bf16.  Measured on MI355X (round 2):
+# see DESIGN.md section 5; the asserted bounds sit ~2x above the measurements, not at "looks similar" levels.
+HALF_BOUNDS = {torch.float16: dict(rms=0.006, mx=0.03, corr=0.99995), torch.bfloat16: dict(rms=0.04, mx=0.12, corr=0.9985)}
+
+
+@pytest.mark.parametrize("name,hw,bs,dtype", [("yolov3", 640, 12, torch.float16), ("yolov3-spp", 640, 12, torch.float16), ("yolov3", 640, 4, torch.bfloat16),
+                                              ("yolov3", 1280, 2, torch.bfloat16)])
+def test_model_half_vs_fp32_oracle_benchmark_shapes(dev, name, hw, bs, dtype):
+    """The BENCHMARKED engines at their own resolution (640x640 fp16 yolov3 / yolov3-spp = configs[1] / [3]; bf16 at 640 and 1280 =
+    configs[4]'s dtype and map sizes) against the fp32 CPU oracle: every conv launch goes through the variants the bench runs
+    (v7 / v6 / v3 with multi-round grids), and the error is bounded per level in relative RMS, max-abs and correlation."""
+    nc = 80 if hw == 640 else 365
+    m, (layers, save, sd, strides) = build_pair(name, nc, 21, dev, dtype)
+    x = torch.rand(bs, 3, hw, hw, generator=torch.Generator().manual_seed(6))
+    pred, raw = m(x.to(dev).to(dtype))
+    torch.cuda.synchronize()
+    plan = next(iter(m._plans.values()))
+    variants = {plan.conv_variant(ln) for ln in plan.launches if ln.flops and not ln.kernel}
+    assert "v7" in variants and "direct" not in variants, variants
+    with torch.no_grad():
+        refp, refraw = yo.forward(layers, save, sd, x[: min(bs, 4)], strides, training=False)   # the oracle on the first images (CPU time)
+    b = HALF_BOUNDS[dtype]
+    for lvl, (a, r) in enumerate(zip(raw, refraw)):
+        rms, mx, corr = _rel_errors(a[: r.shape[0]].float().cpu(), r)
+        print(f"[half-vs-oracle {name} {hw} {dtype}] level {lvl}: rel RMS {rms:.5f}  max/range {mx:.5f}  corr {corr:.6f}")
+        assert rms < b["rms"] and mx < b["mx"] and corr > b["corr"], f"{name} {hw} {dtype} level {lvl}: rms {rms:.4g} max {mx:.4g} corr {corr:.6f}"
+    assert pred.shape[0] == bs and pred.dtype == dtype and torch.isfinite(pred.float()).all()
 
 
 def test_end_to_end_detections_fp32(dev):
@@ -1281,3 +1341,238 @@ def test_stem_pair_matches_unfused_model(dev, monkeypatch):
         outs.append([r.float().cpu() for r in raw])
     for a, b in zip(*outs):
         assert (a - b).abs().max().item() <= 2.0**-9 * b.abs().max().item()
+
+
+# ------------------------------------------------------------------------------------------------ round 2: plans, scaling traps, exchange step, checkpoints
+def test_plans_survive_deepcopy_and_checkpoint_roundtrip(dev, tmp_path):
+    """After a real forward (plans + packed filters exist) the reference's checkpoint path must work: deepcopy(model) (ModelEMA),
+    torch.save({'model': deepcopy(model).half()}) (train.py:470-488) and loading it back through compat.attempt_load /
+    DetectMultiBackend; the reloaded fp16 model reproduces the original's fp16 output bit for bit."""
+    import copy
+
+    from yolov3_amd import DetectMultiBackend
+
+    m, _ = build_pair("yolov3-tiny", 80, 29, dev, torch.float32)
+    x = torch.rand(2, 3, 96, 128, generator=torch.Generator().manual_seed(1)).to(dev)
+    with torch.no_grad():
+        p32 = m(x)[0]
+    assert len(m._plans) == 1
+    ema = copy.deepcopy(m)                      # used to raise: cannot pickle 'CArgObject'
+    assert len(ema._plans) == 0
+    with torch.no_grad():
+        assert torch.equal(ema(x)[0], p32)
+    ck = tmp_path / "last.pt"
+    torch.save({"epoch": 0, "model": copy.deepcopy(m).half(), "ema": None, "optimizer": None}, ck)
+    back = DetectMultiBackend(str(ck), device=dev, fp16=True, fuse=False)
+    mh = copy.deepcopy(m).half()
+    with torch.no_grad():
+        a = back(x)[0]
+        b = mh(x.half())[0]
+    assert a.dtype == torch.float16 and torch.equal(a, b)
+
+
+def test_reference_checkpoint_fixture_runs_on_gpu(dev, golden_dir):
+    """a .pt pickled by the UNMODIFIED reference (tests/golden/ref_tiny_w025_fp16.pt, written by make_golden.py as
+    train.py:470-488 does) through DetectMultiBackend(weights, fp16=...) (models/common.py:471-476 -> attempt_load -> fuse -> eval):
+    fp32 within 1e-4 of the reference's own eval output of that checkpoint, fp16 within the half-precision bounds."""
+    from yolov3_amd import DetectMultiBackend
+
+    gold = torch.load(golden_dir / "ref_tiny_w025_eval.pt")
+    x = torch.rand(2, 3, 96, 160, generator=torch.Generator().manual_seed(9))
+    assert checksum(x) == gold["x_sum"]
+    m32 = DetectMultiBackend(str(golden_dir / "ref_tiny_w025_fp16.pt"), device=dev, fp16=False)
+    assert not any(".bn." in k for k in m32.model.state_dict()) and m32.stride == 32 and m32.names[3] == "c3"
+    y = m32(x.to(dev))
+    assert isinstance(y, list)
+    torch.testing.assert_close(y[0].cpu(), gold["pred"], rtol=1e-4, atol=2e-4)
+    m16 = DetectMultiBackend(str(golden_dir / "ref_tiny_w025_fp16.pt"), device=dev, fp16=True)
+    y16 = m16(x.to(dev))   # fp32 images are cast to half like the reference's forward does (models/common.py:650-651)
+    assert y16[0].dtype == torch.float16
+    for lvl, (a, b) in enumerate(zip(y16[1], gold["raw"])):
+        rms, mx, corr = _rel_errors(a.float().cpu(), b)
+        assert rms < HALF_BOUNDS[torch.float16]["rms"] and corr > 0.9999, (lvl, rms, mx, corr)
+
+
+def test_rect_batches_share_packed_filters_and_plans_are_bounded(dev):
+    """val.py's rect batches give dozens of (h, w) shapes (utils/dataloaders.py:548-570).  Every shape gets a plan (activations,
+    workspace) but the packed filter banks are shared: filter memory stays constant after the first shape and at most
+    PlanCache.MAX_EVAL plans stay alive."""
+    from yolov3_amd.engine import PlanCache, plan_cache
+
+    m, _ = build_pair("yolov3-tiny", 80, 31, dev, torch.float16)
+    pc = plan_cache(m)
+    shapes = [(96, 160), (128, 160), (160, 160), (160, 128), (160, 96), (64, 160), (160, 64), (96, 96), (128, 128), (192, 128), (128, 192), (224, 160)]
+    n_banks, ptrs = None, None
+    outs = {}
+    for h, w in shapes:
+        x = torch.rand(2, 3, h, w, generator=torch.Generator().manual_seed(h * 1000 + w)).to(dev).half()
+        with torch.no_grad():
+            outs[(h, w)] = m(x)[0].float().cpu()
+        banks = sorted(cw.filt.data_ptr() for cw in pc.weights.values())
+        if n_banks is None:
+            n_banks, ptrs = len(banks), banks
+        assert len(banks) == n_banks and banks == ptrs, "a new input shape re-packed the filters"
+        assert len(pc.plans) <= PlanCache.MAX_EVAL
+    assert len(pc.plans) == min(len(shapes), PlanCache.MAX_EVAL)
+    # an evicted shape compiles again and gives the same answer
+    h, w = shapes[0]
+    x = torch.rand(2, 3, h, w, generator=torch.Generator().manual_seed(h * 1000 + w)).to(dev).half()
+    with torch.no_grad():
+        assert torch.equal(m(x)[0].float().cpu(), outs[(h, w)])
+    # in-place parameter updates (an optimizer step) invalidate the banks
+    with torch.no_grad():
+        next(m.parameters()).mul_(1.5)
+        again = m(x)[0].float().cpu()
+    assert not torch.equal(again, outs[(h, w)]) and len(pc.plans) == 1
+
+
+def test_conv_beyond_2gib_output(dev):
+    """VERDICT r1 'scaling traps': a conv whose output exceeds the 2^31-byte reach of a buffer descriptor (batch 128 @640x640 layer 1,
+    batch 32 @1280x1280) runs as several launches over image ranges; checked on the first / boundary / last images against conv2d."""
+    _lib, ops = _ops()
+    n, h, w, cin, cout = 40, 320, 320, 32, 256        # output 40 x 320 x 320 x 256 x 2 B = 2.1 GB
+    g = torch.Generator().manual_seed(5)
+    dtype = torch.float16
+    wt = torch.randn(cout, cin, 1, 1, generator=g) / math.sqrt(cin)
+    b = torch.randn(cout, generator=g) * 0.5
+    filt = ops.pack_filter(wt.to(dev), cout, cin, dtype)
+    xv = ops.View.alloc(n, h, w, cin, dtype, dev)
+    xv.buf.copy_((torch.rand(xv.buf.numel(), generator=g) * 2 - 1).to(dev).to(dtype))
+    yv = ops.View.alloc(n, h, w, cout, dtype, dev)
+    assert yv.buf.numel() * 2 > 2**31
+    ops.conv2d(xv, filt, b.to(dev), yv, 1, 1, True, None, workspace=conv_ws(dev))
+    torch.cuda.synchronize()
+    for img in (0, 19, 20, 39):
+        xi = xv.as_nhwc()[img].float().cpu().permute(2, 0, 1)[None]
+        ref = F.silu(F.conv2d(xi, wt.to(dtype).float(), b))
+        out = yv.as_nhwc()[img].float().cpu().permute(2, 0, 1)[None]
+        _conv_tol_check(f"img{img}", dtype, out, ref)
+
+
+def test_train_two_outstanding_forwards_keep_their_activations(dev):
+    """two train-mode forwards of one shape before a backward (micro-batches whose losses are summed) used to share the
+    saved activations of ONE static plan -> silently wrong gradients.  Each outstanding forward now owns a plan; gradients of
+    loss(x1) + loss(x2) equal the sum of the separately computed ones, and a forward whose state was overwritten raises."""
+    from yolov3_amd import ComputeLoss
+
+    hyp = dict(box=0.05, cls=0.5, cls_pw=1.0, obj=1.0, obj_pw=1.0, anchor_t=4.0, fl_gamma=0.0, label_smoothing=0.0)
+    m, _ = build_pair("yolov3-tiny", 80, 37, dev, torch.float32)
+    m.train()
+    m.hyp = hyp
+    crit = ComputeLoss(m)
+    for mod in m.modules():   # frozen running statistics: the three runs below must see the same BatchNorm state
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.momentum = 0.0
+    xs = [torch.rand(2, 3, 96, 96, generator=torch.Generator().manual_seed(s)).to(dev) for s in (1, 2)]
+    tgs = [yo.synth_targets(2, 80, seed=s).to(dev) for s in (3, 4)]
+    sep = []
+    for x, tg in zip(xs, tgs):
+        m.zero_grad(set_to_none=True)
+        crit(m(x), tg)[0].backward()
+        sep.append([p.grad.clone() for p in m.parameters()])
+    m.zero_grad(set_to_none=True)
+    l1 = crit(m(xs[0]), tgs[0])[0]
+    with torch.no_grad():
+        m(xs[1])                                  # a no_grad train-mode pass in between must not disturb the saved state either
+    l2 = crit(m(xs[1]), tgs[1])[0]
+    (l1 + l2).backward()
+    torch.cuda.synchronize()
+    for p, a, b in zip(m.parameters(), sep[0], sep[1]):
+        torch.testing.assert_close(p.grad, a + b, rtol=1e-4, atol=1e-6)
+    # more outstanding forwards than plans: the oldest one's backward must fail loudly, not compute garbage
+    m.zero_grad(set_to_none=True)
+    held = [crit(m(xs[0]), tgs[0])[0] for _ in range(3)]
+    with pytest.raises(RuntimeError, match="overwritten by a later forward"):
+        held[0].backward()
+    held[2].backward()
+
+
+def test_gradient_exchange_over_rccl_one_rank(dev):
+    """the data-parallel exchange step on a DEVICE: parallel.init('nccl') (RCCL communicator), GradBuckets with
+    the bucket / side-stream / event machinery forced on at world size 1, gradients written into the backward's flat arena and
+    all-reduced (AVG) in place.  With one rank the average is the identity, so every parameter gradient must equal the one computed
+    without grad_sync bit for bit; at least two collectives were issued and they ran on arena ranges (no flatten copies)."""
+    import torch.distributed as dist
+
+    from yolov3_amd import ComputeLoss, parallel
+
+    hyp = dict(box=0.05, cls=0.5, cls_pw=1.0, obj=1.0, obj_pw=1.0, anchor_t=4.0, fl_gamma=0.0, label_smoothing=0.0)
+    m, _ = build_pair("yolov3-tiny", 80, 41, dev, torch.float32)
+    m.train()
+    m.hyp = hyp
+    crit = ComputeLoss(m)
+    x = torch.rand(4, 3, 128, 128, generator=torch.Generator().manual_seed(1)).to(dev)
+    tg = yo.synth_targets(4, 80, seed=2).to(dev)
+
+    def grads():
+        m.zero_grad(set_to_none=True)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.momentum = 0.0
+        with torch.autocast("cuda", dtype=torch.float16):
+            loss, _ = crit(m(x), tg)
+        (loss * 64.0).backward()
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in m.parameters()]
+
+    base = grads()
+    try:
+        parallel.init("nccl", force=True)
+        assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == 1
+        parallel.broadcast_parameters(m)
+        gb = parallel.GradBuckets(bucket_bytes=8 << 20, force=True)
+        launches = []
+        orig = gb._reduce
+        gb._reduce = lambda flat: (launches.append((flat.numel(), flat._base is not None)), orig(flat))[1]
+        m.grad_sync = gb
+        synced = grads()
+        assert len(launches) >= 2 and all(in_arena for _, in_arena in launches), launches
+        for a, b in zip(base, synced):
+            assert torch.equal(a, b)
+        assert parallel.max_over_ranks(1.5, dev) == 1.5
+    finally:
+        m.grad_sync = None
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (the round-end 8-GPU node; the 1-GPU test box skips it)")
+def test_gradient_exchange_over_rccl_two_ranks(tmp_path):
+    """two ranks, one GPU each, through torch.distributed.run: both ranks end with the same averaged gradients = mean of the two
+    single-rank gradients (the same check the gloo test makes on CPU tensors, on device buffers over RCCL)"""
+    import subprocess
+    import sys
+
+    script = tmp_path / "two_rank.py"
+    script.write_text(f"""
+import sys, torch, yaml
+sys.path.insert(0, {str(ROOT)!r})
+from yolov3_amd import ComputeLoss, DetectionModel, parallel
+from oracle import yolo_oracle as yo
+rank, local_rank, world = parallel.init("nccl")
+dev = torch.device("cuda", local_rank)
+torch.manual_seed(0)
+m = DetectionModel("yolov3-tiny.yaml", nc=80).to(dev).train()
+m.hyp = dict(box=0.05, cls=0.5, cls_pw=1.0, obj=1.0, obj_pw=1.0, anchor_t=4.0, fl_gamma=0.0, label_smoothing=0.0)
+parallel.broadcast_parameters(m)
+crit = ComputeLoss(m)
+x = torch.rand(4, 3, 128, 128, generator=torch.Generator().manual_seed(10 + rank)).to(dev)
+tg = yo.synth_targets(4, 80, seed=20 + rank).to(dev)
+def grads(sync):
+    m.grad_sync = parallel.GradBuckets(bucket_bytes=8 << 20) if sync else None
+    m.zero_grad(set_to_none=True)
+    crit(m(x), tg)[0].backward()
+    torch.cuda.synchronize()
+    return torch.cat([p.grad.flatten() for p in m.parameters()])
+own = grads(False)
+avg = grads(True)
+both = [torch.empty_like(own) for _ in range(world)]
+torch.distributed.all_gather(both, own)
+ref = sum(both) / world
+assert torch.allclose(avg, ref, rtol=1e-5, atol=1e-7), float((avg - ref).abs().max())
+print("rank", rank, "ok")
+parallel.finalize()
+""")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.count("ok") == 2, out.stdout + out.stderr

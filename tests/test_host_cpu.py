@@ -268,6 +268,39 @@ def _desc(dtype_code, k, s, cin, cout):
     return Y3ConvDesc(dtype_code, k, s, 0, 0, 0, cin, cout, 0)
 
 
+def test_plans_live_outside_the_module_and_are_bounded():
+    """compiled plans hold ctypes blocks + device memory and must never be part of the module's copied / pickled state
+    (deepcopy(model), torch.save of the model, ModelEMA: reference train.py:470-488); the cache is LRU-bounded per mode."""
+    import copy
+    import io
+
+    import torch
+
+    from yolov3_amd import DetectionModel
+    from yolov3_amd.engine import PlanCache, plan_cache
+
+    m = DetectionModel("yolov3-tiny.yaml", nc=3)
+    pc = plan_cache(m)
+    import ctypes as C
+    for i in range(PlanCache.MAX_EVAL + 3):
+        pc.put(("eval", 1, 32 * (i + 1), 32, torch.float16, 0, 0), C.byref(C.c_int(i)))   # un-picklable, like a real plan's argument blocks
+    for s_ in range(4):
+        pc.put(("train", 1, 64, 64, torch.float16, 0, s_), object())
+    kinds = [k[0] for k in pc.plans]
+    assert kinds.count("eval") == PlanCache.MAX_EVAL and kinds.count("train") == PlanCache.MAX_TRAIN
+    assert ("eval", 1, 32, 32, torch.float16, 0, 0) not in pc.plans            # the oldest went first
+    assert len(m._plans) == len(pc.plans) and "_plans" not in m.__dict__
+    m2 = copy.deepcopy(m)                                                       # used to raise: cannot pickle 'CArgObject'
+    assert len(m2._plans) == 0
+    buf = io.BytesIO()
+    torch.save({"model": copy.deepcopy(m).half(), "ema": None}, buf)          # the reference's checkpoint layout
+    m.fuse()
+    assert len(m._plans) == 0                                                   # fuse / .to() / .half() drop plans and packed filters
+    pc.put(("eval", 1, 32, 32, torch.float16, 0, 0), object())
+    m.half()
+    assert len(m._plans) == 0
+
+
 def test_conv_dispatch_variant_names_and_stat_rows():
     """y3_conv2d_fwd_variant / y3_conv2d_fwd_stats_rows are dry runs of the conv dispatcher (no launch).  The variant name is what
     bench.py groups its roofline by and what the GPU parity tests assert; the statistic rows must equal (pixel tiles of that

@@ -44,6 +44,46 @@ def test_model_forward_matches_reference(golden_dir, key):
     torch.testing.assert_close(predf, gold["fused_pred"], rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("key", ["yolov3-tiny-nc80-416-bs2", "yolov3-nc80-640-bs1", "yolov3-spp-nc80-640-bs1"])
+def test_model_forward_matches_reference_at_benchmark_resolutions(golden_dir, key):
+    """the oracle at 416x416 (BASELINE configs[0]) and 640x640 (configs[1] / [3]) against the unmodified reference: every STEP-th
+    prediction / raw row within 1e-5 (+ rounding of the big box coordinates), whole-tensor |.| sums within 1e-6 relative"""
+    gold = torch.load(golden_dir / "model_fwd_big.pt")[key]
+    name, nc, hw, bs = key.rsplit("-", 3)
+    nc, hw, bs = int(nc[2:]), int(hw), int(bs[2:])
+    layers, save, sd, strides = build(name, nc, 11)
+    x = torch.rand(bs, 3, hw, hw, generator=torch.Generator().manual_seed(5))
+    assert checksum(x) == gold["x_sum"]
+    with torch.no_grad():
+        pred, raw = yo.forward(layers, save, sd, x, strides, training=False)
+    st = gold["step"]
+    torch.testing.assert_close(pred[:, ::st], gold["pred_rows"], rtol=1e-5, atol=1e-4)
+    assert abs(checksum(pred) - gold["pred_sum"]) < 1e-6 * gold["pred_sum"]
+    for a, rows, sm in zip(raw, gold["raw_rows"], gold["raw_sum"]):
+        torch.testing.assert_close(a.reshape(a.shape[0], -1, a.shape[-1])[:, ::st], rows, rtol=1e-5, atol=1e-5)
+        assert abs(checksum(a) - sm) < 1e-6 * sm
+
+
+def test_reference_checkpoint_fixture_loads_without_the_reference(golden_dir):
+    """tests/golden/ref_tiny_w025_fp16.pt was pickled by the UNMODIFIED reference the way train.py:470-488 saves checkpoints.  It must
+    unpickle through yolov3_amd.compat alone (no /root/reference on the GPU box) into our module classes, and the oracle fed its
+    state dict must reproduce the reference's own eval output stored next to it."""
+    from yolov3_amd import DetectionModel, compat
+
+    m = compat.attempt_load(golden_dir / "ref_tiny_w025_fp16.pt", device="cpu", fuse=False)
+    gold = torch.load(golden_dir / "ref_tiny_w025_eval.pt")
+    assert type(m) is DetectionModel and not m.training and next(m.parameters()).dtype == torch.float32
+    assert sum(p.numel() for p in m.parameters()) == gold["n_params"] and [float(s) for s in m.stride] == gold["stride"]
+    d = yaml.safe_load(open(CFG / "yolov3-tiny.yaml"))
+    d["width_multiple"] = 0.25
+    layers, save, anchors, nc_v = yo.parse_cfg(d, 3, 80)
+    x = torch.rand(2, 3, 96, 160, generator=torch.Generator().manual_seed(9))
+    assert checksum(x) == gold["x_sum"]
+    with torch.no_grad():
+        pred, raw = yo.forward(layers, save, m.state_dict(), x, yo.model_strides(layers), training=False)
+    torch.testing.assert_close(pred, gold["pred"], rtol=1e-4, atol=2e-4)   # the reference output is of the FUSED model: BN folded in fp32
+
+
 @pytest.mark.parametrize("key,dtype,nc", [("nc80-float32", torch.float32, 80), ("nc80-float16", torch.float16, 80), ("nc3-float16", torch.float16, 3)])
 def test_decode_matches_reference(golden_dir, key, dtype, nc):
     gold = torch.load(golden_dir / "decode.pt")[key]

@@ -66,7 +66,7 @@ def _adopt(model: nn.Module) -> nn.Module:
             m.k = ks
         if isinstance(m, nn.SiLU):
             m.inplace = True
-    model.__dict__["_plans"] = {}
+    model.__dict__.pop("_plans", None)   # checkpoints written before the plan cache moved out of the module
     return model
 
 

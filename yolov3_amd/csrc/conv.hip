@@ -1044,48 +1044,78 @@ static int conv_fwd_impl(const y3_conv_desc* d, const y3_tensor* x, const void* 
     a.oH = Ho; a.oW = Wo; a.omul = 1; a.ooh = 0; a.oow = 0;
     a.M = x->n * Ho * Wo;
     a.Kpad = y3_filter_kpad(d->cin, d->ksize);
-    {   // byte extents reachable from the base pointers; buffer descriptors address at most 2^31 bytes here
-        const long long xb = (((long long)x->n * x->h * x->w - 1) * x->pitch + x->c) * esz;
-        const long long wb = (long long)y3_filter_rows(d->cout) * a.Kpad * esz;
-        a.x_bytes = xb < 0x7fffffffLL ? (unsigned)xb : 0u;
-        a.w_bytes = wb < 0x7fffffffLL ? (unsigned)wb : 0u;
-        const long long opx = (long long)x->n * Ho * Wo * (d->upsample2x ? 4 : 1);
-        const long long yb = ((opx - 1) * y->pitch + y->c) * esz, rb = res ? ((opx - 1) * res->pitch + res->c) * esz : 0;
-        a.y_bytes = yb < 0x7fffffffLL ? (unsigned)yb : 0u;
-        a.r_bytes = rb < 0x7fffffffLL ? (unsigned)rb : 0u;
-    }
     hipStream_t st = (hipStream_t)stream;
 #ifdef Y3_TIMELINE
     a.tl = g_timeline;
 #endif
-
     int algo = d->algo;
     if (algo == Y3_ALGO_AUTO) algo = (d->dtype == Y3_F32) ? Y3_ALGO_DIRECT : Y3_ALGO_MFMA;
-    if (stat_rows) {   // BatchNorm statistics in the epilogue: MFMA kernels only; two passes decide the rows, then launch
+    if (stat_rows) {
         if (algo != Y3_ALGO_MFMA || d->dtype == Y3_F32) Y3_FAIL("y3_conv2d_fwd_stats: the epilogue statistics need the f16/bf16 MFMA path");
         if (d->upsample2x) Y3_FAIL("y3_conv2d_fwd_stats: upsample2x unsupported");
-        ConvArgs g = a;
-        g.dry = 1;
-        const int rc = d->dtype == Y3_F16 ? dispatch_igemm<f16_t>(g, st) : dispatch_igemm<bf16_t>(g, st);
-        if (rc) return rc;
-        *stat_rows = (int64_t)g.n_pt * g.stat_wp;
-        if (dry) return 0;
-        if (!stats || stat_capacity_rows < *stat_rows) Y3_FAIL("y3_conv2d_fwd_stats: statistics buffer holds %lld rows, the launch writes %lld", (long long)stat_capacity_rows, (long long)*stat_rows);
-        a.stats = stats;
     }
+
+    // The MFMA kernels address every tensor through a buffer descriptor (bounds-checked loads are what makes halo / tail lanes free),
+    // and a descriptor reaches 2^31 bytes.  Images are independent, so a batch whose input, output or residual exceeds that is run
+    // as several launches over image ranges (batch 128 @640x640 and batch 32 @1280x1280 need it for the first layers); the
+    // reference has no such limit (ATen indexes with 64 bits).
+    const long long opx_img = (long long)Ho * Wo * (d->upsample2x ? 4 : 1);
+    const long long img_x = (long long)x->h * x->w * x->pitch * esz, img_y = opx_img * y->pitch * esz, img_r = res ? opx_img * res->pitch * esz : 0;
+    const long long LIM = 0x7fffffffLL - 65536;
+    const long long wb = (long long)y3_filter_rows(d->cout) * a.Kpad * esz;
+    if (wb >= LIM) Y3_FAIL("y3_conv2d_fwd: filter bank beyond 2 GiB");
+    int chunk = x->n;
     if (algo == Y3_ALGO_MFMA) {
-        if (d->dtype == Y3_F16) return dispatch_igemm<f16_t>(a, st);
-        if (d->dtype == Y3_BF16) return dispatch_igemm<bf16_t>(a, st);
-        Y3_FAIL("y3_conv2d_fwd: MFMA path needs f16/bf16");
+        if (img_x >= LIM || img_y >= LIM || img_r >= LIM) Y3_FAIL("y3_conv2d_fwd: one image exceeds the 2 GiB reach of a buffer descriptor");
+        while (chunk > 1 && ((long long)chunk * img_x >= LIM || (long long)chunk * img_y >= LIM || (long long)chunk * img_r >= LIM)) chunk = (chunk + 1) / 2;
     }
-    g_last_variant = "direct";
-    if (a.dry) return 0;
-    switch (d->dtype) {
-        case Y3_F16: return launch_direct<f16_t>(a, st);
-        case Y3_BF16: return launch_direct<bf16_t>(a, st);
-        case Y3_F32: return launch_direct<float>(a, st);
+    if (stat_rows) *stat_rows = 0;
+    int64_t rows_done = 0;
+    for (int n0 = 0; n0 < x->n; n0 += chunk) {
+        ConvArgs c = a;
+        c.N = x->n - n0 < chunk ? x->n - n0 : chunk;
+        c.M = c.N * Ho * Wo;
+        c.x = (const char*)a.x + (long long)n0 * img_x;
+        c.y = (char*)a.y + (long long)n0 * img_y;
+        if (res) c.res = (const char*)a.res + (long long)n0 * img_r;
+        const long long xb = (((long long)c.N * x->h * x->w - 1) * x->pitch + x->c) * esz;
+        const long long yb = (((long long)c.N * opx_img - 1) * y->pitch + y->c) * esz, rb = res ? (((long long)c.N * opx_img - 1) * res->pitch + res->c) * esz : 0;
+        c.x_bytes = xb < 0x7fffffffLL ? (unsigned)xb : 0u;   // only the fp32 direct kernel (64-bit indexing) ever sees a 0 here
+        c.w_bytes = (unsigned)wb;
+        c.y_bytes = yb < 0x7fffffffLL ? (unsigned)yb : 0u;
+        c.r_bytes = rb < 0x7fffffffLL ? (unsigned)rb : 0u;
+        if (stat_rows) {   // BatchNorm statistics in the epilogue: a dry pass of the dispatcher decides the rows of this launch
+            ConvArgs g = c;
+            g.dry = 1;
+            const int rc = d->dtype == Y3_F16 ? dispatch_igemm<f16_t>(g, st) : dispatch_igemm<bf16_t>(g, st);
+            if (rc) return rc;
+            const int64_t rows = (int64_t)g.n_pt * g.stat_wp;
+            *stat_rows += rows;
+            if (dry) continue;
+            if (!stats || stat_capacity_rows < rows_done + rows)
+                Y3_FAIL("y3_conv2d_fwd_stats: statistics buffer holds %lld rows, the launch writes %lld", (long long)stat_capacity_rows, (long long)(rows_done + rows));
+            c.stats = stats + rows_done * (int64_t)d->cout * 2;
+            rows_done += rows;
+        }
+        int rc;
+        if (algo == Y3_ALGO_MFMA) {
+            if (d->dtype == Y3_F16) rc = dispatch_igemm<f16_t>(c, st);
+            else if (d->dtype == Y3_BF16) rc = dispatch_igemm<bf16_t>(c, st);
+            else Y3_FAIL("y3_conv2d_fwd: MFMA path needs f16/bf16");
+        } else {
+            g_last_variant = "direct";
+            if (c.dry) return 0;
+            switch (d->dtype) {
+                case Y3_F16: rc = launch_direct<f16_t>(c, st); break;
+                case Y3_BF16: rc = launch_direct<bf16_t>(c, st); break;
+                case Y3_F32: rc = launch_direct<float>(c, st); break;
+                default: Y3_FAIL("y3_conv2d_fwd: bad dtype %d", d->dtype);
+            }
+        }
+        if (rc) return rc;
+        if (c.dry) return 0;   // variant query: the first image range decides
     }
-    Y3_FAIL("y3_conv2d_fwd: bad dtype %d", d->dtype);
+    return 0;
 }
 
 extern "C" int y3_conv2d_fwd(const y3_conv_desc* d, const y3_tensor* x, const void* filt, const float* bias, const y3_tensor* res, const y3_tensor* y, void* stream) {

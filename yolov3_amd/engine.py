@@ -17,7 +17,11 @@ torch is used for device memory and the current stream only.
 from __future__ import annotations
 
 import ctypes as C
+import os
+import threading
 import time
+import weakref
+from collections import OrderedDict
 from dataclasses import dataclass, field
 
 import torch
@@ -132,7 +136,19 @@ def _fold(conv: nn.Conv2d, bn):
 KEEP_FOLDED = False  # tests set this to keep the fp32 folded (w, b) next to the packed bank
 
 
-def make_conv_weights(conv: nn.Conv2d, bn, act: bool, dtype, cin_pad=None) -> ConvWeights:
+def make_conv_weights(conv: nn.Conv2d, bn, act: bool, dtype, cin_pad=None, cache: dict | None = None) -> ConvWeights:
+    """Fold + pack one conv.  `cache` (PlanCache.weights) shares the packed bank between the plans of a model: rect-batch
+    validation compiles dozens of (h, w) shapes (reference utils/dataloaders.py:548-570) and each used to re-pack 124 MB."""
+    key = (id(conv), id(bn), bool(act), dtype, cin_pad)
+    if cache is not None and key in cache:
+        return cache[key]
+    cw = _make_conv_weights(conv, bn, act, dtype, cin_pad)
+    if cache is not None:
+        cache[key] = cw
+    return cw
+
+
+def _make_conv_weights(conv: nn.Conv2d, bn, act: bool, dtype, cin_pad=None) -> ConvWeights:
     w, b = _fold(conv, bn)
     co, ci, k, _ = w.shape
     cin = cin_pad or _pad8(ci)
@@ -171,7 +187,8 @@ class Plan:
         self.out_views: dict = {}
         self.param_refs = []
         self.param_version = 0
-        self.stem_x = None  # ctypes cells patched per call when layer 0 runs as the stem kernel (reads the caller's NCHW tensor)
+        self.stem_x = None  # not None when layer 0 runs as the stem kernel and reads the caller's NCHW tensor (arguments are built per call)
+        self.lock = threading.Lock()  # launches of one plan are enqueued atomically (its buffers are ordered by ONE stream)
 
     # -- building -----------------------------------------------------------------------------
     def new_buf(self, n, h, w, pitch, name=""):
@@ -252,12 +269,12 @@ class Plan:
             elif kind == "stem":
                 w, yv = kw["w"], kw["y"].real()
                 yt = yv.y3()
-                self.stem_x, self.stem_sdt, self.stem_div = C.c_void_p(0), C.c_int32(0), C.c_float(1.0)
+                self.stem_x = True
                 m = yv.n * yv.h * yv.w
                 self.launches.append(
                     _Launch(
                         L.y3_stem_conv_fwd,
-                        (self.stem_x, self.stem_sdt, yv.n, kw["cin"], yv.h, yv.w, self.stem_div, w.filt.data_ptr(), w.bias.data_ptr(), dcode,
+                        (_STEM_X, _STEM_SDT, yv.n, kw["cin"], yv.h, yv.w, _STEM_DIV, w.filt.data_ptr(), w.bias.data_ptr(), dcode,
                          _lib.Y3_ACT_SILU if w.act else _lib.Y3_ACT_NONE, C.byref(yt)),
                         keep=(yt, w),
                         label=kw["label"],
@@ -269,13 +286,13 @@ class Plan:
             elif kind == "stem_pair":
                 w0, w1, yv = kw["w0"], kw["w1"], kw["y"].real()
                 yt = yv.y3()
-                self.stem_x, self.stem_sdt, self.stem_div = C.c_void_p(0), C.c_int32(0), C.c_float(1.0)
+                self.stem_x = True
                 m1 = yv.n * yv.h * yv.w
                 m0 = yv.n * kw["h"] * kw["w"]
                 self.launches.append(
                     _Launch(
                         L.y3_stem_pair_fwd,
-                        (self.stem_x, self.stem_sdt, yv.n, kw["cin"], kw["h"], kw["w"], self.stem_div, w0.filt.data_ptr(), w0.bias.data_ptr(),
+                        (_STEM_X, _STEM_SDT, yv.n, kw["cin"], kw["h"], kw["w"], _STEM_DIV, w0.filt.data_ptr(), w0.bias.data_ptr(),
                          _lib.Y3_ACT_SILU if w0.act else _lib.Y3_ACT_NONE, w1.filt.data_ptr(), w1.bias.data_ptr(), _lib.Y3_ACT_SILU if w1.act else _lib.Y3_ACT_NONE, dcode, C.byref(yt)),
                         keep=(yt, w0, w1),
                         label=kw["label"],
@@ -309,11 +326,27 @@ class Plan:
         return name.value.decode()
 
     # -- execution -----------------------------------------------------------------------------
-    def run_body(self, stream):
-        for ln in self.launches:
-            st = ln.fn(*ln.args, stream)
-            if st != 0:
-                _lib.check(st, ln.label or "launch")
+    def run_body(self, stream, stem=None):
+        """Enqueue every launch on `stream`.  `stem` = (pointer, dtype code, divisor) of the caller's NCHW image for the stem
+        kernels: substituted per call, so nothing shared is mutated (two threads may hold the same plan object)."""
+        with self.lock:
+            self.last_stem = stem   # profiling tools replay single launches (bench.per_kernel_times, _profile)
+            for ln in self.launches:
+                st = ln.fn(*self.resolved_args(ln, stem), stream)
+                if st != 0:
+                    _lib.check(st, ln.label or "launch")
+
+    def resolved_args(self, ln, stem=None):
+        """argument tuple of a launch with the per-call stem placeholders filled in"""
+        if ln.kernel not in ("stem_conv", "stem_pair"):
+            return ln.args
+        stem = stem if stem is not None else getattr(self, "last_stem", None)
+        if stem is None:
+            raise RuntimeError("stem launch replayed before the plan ran once")
+        return tuple(stem[0] if a is _STEM_X else stem[1] if a is _STEM_SDT else stem[2] if a is _STEM_DIV else a for a in ln.args)
+
+
+_STEM_X, _STEM_SDT, _STEM_DIV = object(), object(), object()   # placeholders in a stem launch's argument tuple (filled per call)
 
 
 def _param_version(params):
@@ -322,8 +355,8 @@ def _param_version(params):
 
 # ------------------------------------------------------------------------------------------- graph compiler
 class _Compiler:
-    def __init__(self, plan: Plan, dtype, training=False):
-        self.plan, self.dtype, self.training = plan, dtype, training
+    def __init__(self, plan: Plan, dtype, training=False, wcache=None):
+        self.plan, self.dtype, self.training, self.wcache = plan, dtype, training, wcache
         if training:
             raise NotImplementedError(
                 "training-mode forward (batch-statistics BatchNorm + backward) is not implemented on the MI355X path yet; "
@@ -332,7 +365,7 @@ class _Compiler:
 
     def conv_unit(self, m: Conv, x: SView, y: SView = None, residual=None, ups=False, label="", cin_pad=None):
         p = self.plan
-        w = make_conv_weights(m.conv, getattr(m, "bn", None), isinstance(m.act, nn.SiLU), self.dtype, cin_pad=cin_pad)
+        w = make_conv_weights(m.conv, getattr(m, "bn", None), isinstance(m.act, nn.SiLU), self.dtype, cin_pad=cin_pad, cache=self.wcache)
         if y is None:
             ho, wo = _conv_hw((x.h, x.w), w.k, w.s)
             y = p.new_view(x.n, ho, wo, w.cout, label)
@@ -378,11 +411,11 @@ def _stem_pair_eligible(layers, src, consumers, placed, fused_ups) -> bool:
             and c1.dilation == (1, 1) and c1.groups == 1 and isinstance(m0.act, (nn.SiLU, nn.Identity)) and isinstance(m1.act, (nn.SiLU, nn.Identity)))
 
 
-def compile_model(model, n, h, w, dtype, device) -> Plan:
+def compile_model(model, n, h, w, dtype, device, wcache=None) -> Plan:
     from .yolo import Detect
 
     plan = Plan(device, dtype, n, h, w)
-    comp = _Compiler(plan, dtype, training=model.training)
+    comp = _Compiler(plan, dtype, training=model.training, wcache=wcache)
     layers = list(model.model)
     nl = len(layers)
     hw = graph_hw(model, h, w)
@@ -463,7 +496,7 @@ def compile_model(model, n, h, w, dtype, device) -> Plan:
             heads = []
             for lvl, xv in enumerate(ins):
                 conv = k.m[lvl]
-                wts = make_conv_weights(conv, None, False, dtype, cin_pad=xv.c)
+                wts = make_conv_weights(conv, None, False, dtype, cin_pad=xv.c, cache=wcache)
                 hv = plan.new_view(xv.n, xv.h, xv.w, wts.cout, f"{lab}.head{lvl}")
                 hv.buf.pinned = True
                 plan.conv(xv, wts, hv, label=f"{lab}.m{lvl}")
@@ -512,22 +545,27 @@ def compile_model(model, n, h, w, dtype, device) -> Plan:
             out[i] = y
         elif isinstance(k, Conv) and i == 1 and pair:
             w0 = pair
-            w1 = make_conv_weights(k.conv, getattr(k, "bn", None), isinstance(k.act, nn.SiLU), dtype, cin_pad=32)
+            w1 = make_conv_weights(k.conv, getattr(k, "bn", None), isinstance(k.act, nn.SiLU), dtype, cin_pad=32, cache=wcache)
             plan.add("stem_pair", [], [y], w0=w0, w1=w1, y=y, cin=w0.cin, h=h, w=w, label="L0+L1")
             out[i] = y
         elif isinstance(k, Conv) and i == 0 and _stem_eligible(k, dtype, src[0], consumers[-1]):
-            cw, cb = _fold(k.conv, getattr(k, "bn", None))
-            co = cw.shape[0]
-            bias = torch.zeros(_pad8(co), dtype=torch.float32, device=cw.device)
-            bias[:co] = cb
-            wts = ConvWeights(ops.pack_filter_stem(cw, _pad8(co), dtype), bias, cw.shape[1], _pad8(co), 3, 1, isinstance(k.act, nn.SiLU))
-            if KEEP_FOLDED:
-                wts.folded = (cw, cb)
+            skey = ("stem", id(k.conv), id(getattr(k, "bn", None)), dtype)
+            wts = wcache.get(skey) if wcache is not None else None
+            if wts is None:
+                cw, cb = _fold(k.conv, getattr(k, "bn", None))
+                co = cw.shape[0]
+                bias = torch.zeros(_pad8(co), dtype=torch.float32, device=cw.device)
+                bias[:co] = cb
+                wts = ConvWeights(ops.pack_filter_stem(cw, _pad8(co), dtype), bias, cw.shape[1], _pad8(co), 3, 1, isinstance(k.act, nn.SiLU))
+                if KEEP_FOLDED:
+                    wts.folded = (cw, cb)
+                if wcache is not None:
+                    wcache[skey] = wts
             if pair_ok:
                 pair = wts          # emitted together with layer 1
                 out[i] = None
             else:
-                plan.add("stem", [], [y], w=wts, y=y, cin=cw.shape[1], label=lab)
+                plan.add("stem", [], [y], w=wts, y=y, cin=wts.cin, label=lab)
                 out[i] = y
         elif isinstance(k, Conv):
             out[i] = comp.conv_unit(k, ins[0], y=y, label=lab, cin_pad=ins[0].c)
@@ -582,51 +620,116 @@ def _decode_outputs(plan: Plan, det, heads, n, export=False, training=False):
     return (z,) if export else (z, raws)
 
 
+class PlanCache:
+    """Compiled plans of ONE model, kept OUT of the module (a plan holds ctypes argument blocks and tens of MB of activations:
+    in `model.__dict__` it broke `deepcopy(model)` / `torch.save` / ModelEMA -- the reference's checkpoint path, train.py:470-488).
+    Plans are keyed by (batch, h, w, dtype, mode, device, stream) and evicted least-recently-used; the packed filter banks are
+    shared by all eval plans and live as long as the parameters are not modified."""
+
+    MAX_EVAL = int(os.environ.get("Y3_MAX_PLANS", "6"))
+    MAX_TRAIN = int(os.environ.get("Y3_MAX_TRAIN_PLANS", "2"))
+
+    def __init__(self):
+        self.plans: "OrderedDict" = OrderedDict()
+        self.weights: dict = {}
+        self.weights_version = None
+        self.lock = threading.Lock()
+
+    def clear(self):
+        with self.lock:
+            self.plans.clear()
+            self.weights.clear()
+            self.weights_version = None
+
+    def get(self, key):
+        plan = self.plans.get(key)
+        if plan is not None:
+            self.plans.move_to_end(key)
+        return plan
+
+    def put(self, key, plan):
+        self.plans[key] = plan
+        train = key[0] == "train"
+        same = [k for k in self.plans if (k[0] == "train") == train]
+        cap = self.MAX_TRAIN if train else self.MAX_EVAL
+        for k in same[: max(0, len(same) - cap)]:
+            del self.plans[k]   # the activation pool / workspace go back to torch's allocator once the last launch that uses them has run
+
+
+_PLAN_CACHES: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+_PLAN_CACHES_LOCK = threading.Lock()
+
+
+def plan_cache(model) -> PlanCache:
+    with _PLAN_CACHES_LOCK:
+        pc = _PLAN_CACHES.get(model)
+        if pc is None:
+            pc = _PLAN_CACHES[model] = PlanCache()
+        return pc
+
+
+def drop_plans(model):
+    """forget compiled plans and packed filters (weights moved / re-typed / fused)"""
+    with _PLAN_CACHES_LOCK:
+        pc = _PLAN_CACHES.get(model)
+    if pc is not None:
+        pc.clear()
+
+
 def run_model(model, x: torch.Tensor, profile=False):
     ops.require_gpu(x, "DetectionModel.forward")
     if x.dim() != 4:
         raise ValueError(f"expected a (bs, ch, h, w) image batch, got shape {tuple(x.shape)}")
+    ch = model.yaml.get("ch", 3) if isinstance(getattr(model, "yaml", None), dict) else None
+    if ch is not None and x.shape[1] != ch:   # the stem kernel is handed the raw pointer: a wrong channel count would read past the buffer
+        raise ValueError(f"expected {ch} input channels, got a batch of shape {tuple(x.shape)}")
     if model.training:
         from .train_engine import run_model_train
 
         return run_model_train(model, x)
     dtype = _engine_dtype(model)
     n, c, h, w = x.shape
-    key = (n, h, w, dtype, bool(model.training), x.device.index)
-    plans = model.__dict__.setdefault("_plans", {})
-    plan = plans.get(key)
-    if plan is not None and plan.param_version != _param_version(plan.param_refs):
-        plan = None  # parameters were modified in place since the filters were packed
-    if plan is None:
-        with torch.no_grad():
-            plan = compile_model(model, n, h, w, dtype, x.device)
-        plans[key] = plan
     stream = ops.stream_ptr()
+    pc = plan_cache(model)
+    key = ("eval", n, h, w, dtype, x.device.index, stream)
+    with pc.lock:
+        refs = list(model.parameters()) + list(model.buffers())
+        version = (_param_version(refs), len(refs))
+        if pc.weights_version != version:   # parameters were modified in place (or replaced) since the filters were packed
+            pc.plans.clear()
+            pc.weights.clear()
+            pc.weights_version = version
+        plan = pc.get(key)
+        if plan is None:
+            with torch.no_grad():
+                plan = compile_model(model, n, h, w, dtype, x.device, wcache=pc.weights)
+            pc.put(key, plan)
     # uint8 images are normalised inside the first kernel: the `im.half(); im /= 255` of reference val.py:358-359 / detect.py:187-189 /
     # models/common.py:868 without a separate pass over the batch
     div = 255.0 if x.dtype == torch.uint8 else 1.0
+    stem = None
     if plan.stem_x is not None:
-        xc = x.contiguous()
-        plan.stem_keep = xc  # the launch reads the caller's tensor directly
-        plan.stem_x.value, plan.stem_sdt.value, plan.stem_div.value = xc.data_ptr(), ops.dtype_code(xc.dtype), div
+        xc = x.contiguous()   # the launch reads the caller's tensor directly (stream-ordered: xc stays alive until its kernels are enqueued)
+        stem = (C.c_void_p(xc.data_ptr()), C.c_int32(ops.dtype_code(xc.dtype)), C.c_float(div))
     else:
         ops.nchw_to_nhwc(x, plan.input_view.real(), div)
     if profile:
-        _profile(plan, stream)
+        _profile(plan, stream, stem)
     else:
-        plan.run_body(stream)
+        plan.run_body(stream, stem)
     det, heads = plan.detect
     return _decode_outputs(plan, det, heads, n, export=det.export, training=model.training)
 
 
-def _profile(plan: Plan, stream):
+def _profile(plan: Plan, stream, stem=None):
     """Per-launch timing table (the reference's model(x, profile=True), models/yolo.py:149-161)."""
     torch.cuda.synchronize()
     rows = []
     for ln in plan.launches:
+        args = plan.resolved_args(ln, stem)
         t0 = time.perf_counter()
         for _ in range(10):
-            ln.fn(*ln.args, stream)
+            ln.fn(*args, stream)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 10
         rows.append((ln.label, dt * 1e3, ln.flops / dt / 1e12 if dt else 0, ln.bytes / dt / 1e9 if dt else 0))

@@ -155,11 +155,15 @@ def conv2d_dgrad_s2(w_oihw: torch.Tensor, du: View, gx: View, accumulate: bool):
     check(L.y3_conv2d_dgrad_s2(dtype_code(dt), C.byref(dut), packed.data_ptr(), C.byref(gxt) if accumulate else None, C.byref(gxt), stream_ptr()), "y3_conv2d_dgrad_s2")
 
 
-def conv2d_wgrad(x: View, du: View, k: int, stride: int, cout_real: int, cin_real: int, want_bias: bool = False):
-    """Filter gradient (cout_real, cin_real, k, k) fp32 (+ bias gradient) of a conv with input x and output-gradient du."""
+def conv2d_wgrad(x: View, du: View, k: int, stride: int, cout_real: int, cin_real: int, want_bias: bool = False, alloc=None):
+    """Filter gradient (cout_real, cin_real, k, k) fp32 (+ bias gradient) of a conv with input x and output-gradient du.
+    `alloc(shape)` supplies the output tensors (the training plan's per-backward gradient arena); default torch.empty."""
     d = Y3ConvDesc(dtype_code(x.buf.dtype), k, stride, 0, 0, 0, x.c, du.c, 0)
-    dw = torch.empty(cout_real, cin_real, k, k, dtype=torch.float32, device=x.buf.device)
-    db = torch.empty(cout_real, dtype=torch.float32, device=x.buf.device) if want_bias else None
+    if alloc is None:
+        def alloc(shape):
+            return torch.empty(shape, dtype=torch.float32, device=x.buf.device)
+    dw = alloc((cout_real, cin_real, k, k))
+    db = alloc((cout_real,)) if want_bias else None
     xt, dt = x.y3(), du.y3()
     need = int(_lib.lib().y3_conv2d_wgrad_workspace_bytes(C.byref(d), C.byref(xt)))
     ws = torch.empty(need, dtype=torch.uint8, device=x.buf.device)

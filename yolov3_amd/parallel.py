@@ -17,10 +17,14 @@ def env_rank():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
-def init(backend: str | None = None):
-    """Initialise the default process group from the torch.distributed.run environment (no-op for world 1)."""
+def init(backend: str | None = None, force: bool = False):
+    """Initialise the default process group from the torch.distributed.run environment (no-op for world 1 unless `force`:
+    a one-rank RCCL communicator exercises the same device collectives, streams and event ordering as N ranks)."""
     rank, local_rank, world = env_rank()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -75,11 +79,17 @@ class GradBuckets:
     xGMI is point-to-point (7 links x ~153 GB/s): ring collectives are per-link bound, so buckets are fewer and larger
     than DDP's default (64 MiB: 4 collectives for yolov3) to amortise launch/latency; `wire_dtype=torch.bfloat16`
     halves the bytes on the wire (changes rounding: off by default).
+
+    No extra passes over the gradients: the training plan writes every gradient into one flat fp32 arena in the order the
+    backward produces them (train_engine.TrainPlan.grad_alloc), so a bucket is a contiguous range of that arena and is
+    all-reduced IN PLACE with ReduceOp.AVG (RCCL divides on the wire); the tensors autograd receives are views of the
+    arena.  Gradients that are not arena views (or a bf16 wire) take the flatten / copy-back path.
     """
 
-    def __init__(self, bucket_bytes: int = 64 << 20, wire_dtype: torch.dtype | None = None, group=None):
+    def __init__(self, bucket_bytes: int = 64 << 20, wire_dtype: torch.dtype | None = None, group=None, force: bool = False):
         self.bucket_bytes, self.wire_dtype, self.group = bucket_bytes, wire_dtype, group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.force = force   # run the bucket / side-stream / collective machinery even at world size 1 (single-GPU tests of the exchange step)
         self._pending: list = []   # (keys, tensors) of the bucket being filled
         self._bytes = 0
         self._inflight: list = []  # (work, flat, keys, shapes, dtypes, event)
@@ -95,7 +105,7 @@ class GradBuckets:
 
     def add(self, key, grad: torch.Tensor):
         """Hand over one finished gradient (called in reverse layer order by the backward plan)."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             self._out[key] = grad
             return
         ev = None
@@ -107,6 +117,31 @@ class GradBuckets:
         if self._bytes >= self.bucket_bytes:
             self._launch()
 
+    @staticmethod
+    def _arena_range(tensors):
+        """(base, lo, hi) when every tensor is a contiguous fp32 view of ONE flat base tensor (the training plan's gradient arena):
+        the bucket is then the element range [lo, hi) of the base and is reduced in place.  None otherwise."""
+        base = tensors[0]._base
+        if base is None or base.dim() != 1 or base.dtype != torch.float32:
+            return None
+        lo, hi = None, None
+        for t in tensors:
+            if t._base is not base or not t.is_contiguous() or t.dtype != torch.float32:
+                return None
+            o = t.storage_offset() - base.storage_offset()
+            lo = o if lo is None else min(lo, o)
+            hi = o + t.numel() if hi is None else max(hi, o + t.numel())
+        return base, lo, hi
+
+    def _reduce(self, flat):
+        """average `flat` over the ranks, in place; returns the async work handle"""
+        if not (dist.is_available() and dist.is_initialized()):
+            return None
+        if dist.get_backend(self.group) == "nccl":
+            return dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)   # RCCL averages on the wire: no divide pass
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return (work, flat)   # gloo has no AVG: divide after the wait
+
     def _launch(self):
         if not self._pending:
             return
@@ -116,37 +151,51 @@ class GradBuckets:
         self._pending, self._bytes = [], 0
         dev = tensors[0].device
         side = self._stream(dev)
-        wire = self.wire_dtype or torch.float32
+        rng = self._arena_range(tensors) if self.wire_dtype in (None, torch.float32) else None
+
+        def issue():
+            if rng is not None:
+                base, lo, hi = rng
+                flat = base[lo:hi]          # padding between slices rides along (<= 252 B per tensor); the slices ARE the results
+                return flat, self._reduce(flat), None
+            wire = self.wire_dtype or torch.float32
+            flat = torch.cat([t.reshape(-1).to(wire) for t in tensors])
+            return flat, self._reduce(flat), [(t.shape, t.dtype) for t in tensors]
+
         if side is not None:
             for e in events:   # every gradient of the bucket has been produced (whatever stream issued it)
                 side.wait_event(e)
             for t in tensors:
                 t.record_stream(side)
             with torch.cuda.stream(side):
-                flat = torch.cat([t.reshape(-1).to(wire) for t in tensors])
-                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                flat, work, meta = issue()
         else:
-            flat = torch.cat([t.reshape(-1).to(wire) for t in tensors])
-            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._inflight.append((work, flat, keys, [t.shape for t in tensors], [t.dtype for t in tensors], side))
+            flat, work, meta = issue()
+        self._inflight.append((work, flat, keys, tensors, meta, side))
 
     def finish(self) -> dict:
         """Flush the last bucket, wait for every collective, return {key: averaged gradient}."""
-        if self.world > 1:
-            self._launch()
-            for work, flat, keys, shapes, dtypes, side in self._inflight:
-                work.wait()
-                if side is not None:
-                    torch.cuda.current_stream(flat.device).wait_stream(side)
-                flat = flat / self.world
+        self._launch()
+        for work, flat, keys, tensors, meta, side in self._inflight:
+            if isinstance(work, tuple):      # gloo: SUM + divide
+                work[0].wait()
+                flat.div_(self.world)
+            elif work is not None:
+                work.wait()                  # nccl: makes the current stream wait for the collective's stream
+            if side is not None:
+                torch.cuda.current_stream(flat.device).wait_stream(side)
+            if meta is None:                 # reduced in place inside the arena: the views are the results
+                for k, t in zip(keys, tensors):
+                    self._out[k] = t
+            else:
                 off = 0
-                for k, shp, dt in zip(keys, shapes, dtypes):
+                for k, (shp, dt) in zip(keys, meta):
                     n = 1
                     for d in shp:
                         n *= d
                     self._out[k] = flat[off : off + n].view(shp).to(dt)
                     off += n
-            self._inflight = []
+        self._inflight = []
         out, self._out = self._out, {}
         return out
 

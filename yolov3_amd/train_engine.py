@@ -154,8 +154,8 @@ class ConvUnit(_Unit):
         dcode = ops.dtype_code(self.plan.dtype)
         gy = self.y.grad()
         du = self.plan.scratch_like(self.u)
-        dgamma = torch.empty(self.cout, dtype=torch.float32, device=self.plan.device)
-        dbeta = torch.empty(self.cout, dtype=torch.float32, device=self.plan.device)
+        dgamma = self.plan.grad_alloc((self.cout,))
+        dbeta = self.plan.grad_alloc((self.cout,))
         ut, gt, dt = self.u.y3(), gy.y3(), du.y3()
         if self.res is not None:  # out = act(bn(conv)) + res  ->  d res (+)= d out, written by the pass that reads d out anyway
             gr = self.res.grad()
@@ -399,6 +399,10 @@ class TrainPlan:
                 and dtype in (torch.float16, torch.bfloat16) and os.environ.get("Y3_STEM", "1") != "0"):
             u0.use_stem = True
         self._bn_counters = [u.m.bn.num_batches_tracked for u in self.units if isinstance(u, ConvUnit) and u.m.bn.num_batches_tracked is not None]
+        self._arena, self._arena_off = None, 0
+        self._arena_numel = sum((p.numel() + 63) // 64 * 64 for p in self.params)
+        self.generation = 0        # bumped by every forward: the saved activations belong to exactly one forward
+        self.outstanding = False   # a grad-enabled forward ran and its backward has not: the saved state must not be overwritten
 
     # -- helpers ---------------------------------------------------------------------------------
     def bn_sums(self, c):
@@ -410,13 +414,29 @@ class TrainPlan:
             t = self._bn_sums = ops.bn_scratch(self._max_c, self.device)
         return t
 
+    def grad_alloc(self, shape):
+        """fp32 gradient tensor of `shape`: a slice of this backward's flat arena, handed out in the order the backward produces
+        gradients.  Consecutive gradients are therefore adjacent in memory and parallel.GradBuckets all-reduces whole ranges of the
+        arena in place -- no flatten / copy-back passes over the 248 MB.  The arena is a fresh allocation per backward (no memset;
+        torch's caching allocator recycles it), so gradients handed to autograd never alias a later backward's."""
+        n = 1
+        for d_ in shape:
+            n *= int(d_)
+        n_al = (n + 63) // 64 * 64   # 256-byte aligned slices
+        if self._arena is None or self._arena_off + n_al > self._arena.numel():
+            self._arena = torch.empty(max(self._arena_numel, n_al), dtype=torch.float32, device=self.device)
+            self._arena_off = 0
+        t = self._arena[self._arena_off:self._arena_off + n].view(shape)
+        self._arena_off += n_al
+        return t
+
     def wgrad(self, grads, w_param, b_param, x: View, du: View, k, s, co_real, ci_real):
         """Filter (and bias) gradient of one layer.  Nothing downstream in the backward needs it, so it CAN go to a second HIP
         stream (Y3_WGRAD_STREAM=1; see __init__ for the measurement).  `du` was produced on the current stream: the side
         stream waits for an event recorded here."""
         side = self.wgrad_stream
         if side is None:
-            dw, db = ops.conv2d_wgrad(x, du, k, s, co_real, ci_real, want_bias=b_param is not None)
+            dw, db = ops.conv2d_wgrad(x, du, k, s, co_real, ci_real, want_bias=b_param is not None, alloc=self.grad_alloc)
             grads[w_param] = dw
             if b_param is not None:
                 grads[b_param] = db
@@ -469,6 +489,7 @@ class TrainPlan:
 
     # -- execution -------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor):
+        self.generation += 1
         ops.nchw_to_nhwc(x, self.x_in.view, 1.0)
         self.x_nchw = x if x.dtype in (torch.float32, torch.float16, torch.bfloat16, torch.uint8) else None
         with torch.no_grad():
@@ -481,6 +502,7 @@ class TrainPlan:
     def backward(self, graws):
         sync = getattr(self.model, "grad_sync", None)  # parallel.GradBuckets: overlapped gradient all-reduce
         grads = _GradSink(sync)
+        self._arena, self._arena_off = None, 0          # a new arena per backward (see grad_alloc)
         for a in self.acts:
             a.drop_grad()
         with torch.no_grad():
@@ -525,11 +547,20 @@ class _TrainFn(torch.autograd.Function):
     def forward(ctx, plan, x, *params):
         ctx.plan = plan
         raws = plan.forward(x)
+        ctx.generation = plan.generation
         return tuple(raws)
 
     @staticmethod
     def backward(ctx, *graws):
-        grads = ctx.plan.backward(graws)
+        plan = ctx.plan
+        if ctx.generation != plan.generation:
+            # torch autograd would have kept this forward's saved tensors alive; the static plan keeps ONE set per plan
+            raise RuntimeError(
+                "yolov3_amd: backward of a training forward whose saved activations were overwritten by a later forward of the same "
+                f"shape (forward #{ctx.generation}, plan is at #{plan.generation}). More than Y3_MAX_TRAIN_PLANS (default 2) forwards of one "
+                "shape were outstanding at once; call backward() before the next forward, or raise the limit.")
+        grads = plan.backward(graws)
+        plan.outstanding = False
         return (None, None, *grads)
 
 
@@ -543,9 +574,32 @@ def run_model_train(model, x: torch.Tensor):
     if dtype not in (torch.float16, torch.bfloat16, torch.float32):
         raise TypeError(f"unsupported training activation dtype {dtype}")
     n, c, h, w = x.shape
-    key = ("train", n, h, w, dtype, x.device.index)
-    plans = model.__dict__.setdefault("_plans", {})
-    plan = plans.get(key)
-    if plan is None:
-        plan = plans[key] = TrainPlan(model, n, h, w, dtype, x.device)
+    from .engine import plan_cache
+
+    pc = plan_cache(model)
+    grad = torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters())
+    with pc.lock:
+        plan, slot = None, 0
+        # a forward whose backward is still outstanding keeps its plan (two micro-batches whose losses are summed, a no_grad pass
+        # between forward and backward): take the first idle plan of this shape, else a new slot; when every slot is busy the least
+        # recently used one is re-used and its stale backward raises (see _TrainFn.backward)
+        while True:
+            key = ("train", n, h, w, dtype, x.device.index, slot)
+            cand = pc.get(key)
+            if cand is None or not cand.outstanding:
+                plan = cand
+                break
+            slot += 1
+            if slot >= pc.MAX_TRAIN:
+                slot = min(range(pc.MAX_TRAIN), key=lambda s_: getattr(pc.plans.get(("train", n, h, w, dtype, x.device.index, s_)), "generation", -1))
+                key = ("train", n, h, w, dtype, x.device.index, slot)
+                plan = pc.get(key)
+                break
+        if plan is None:
+            plan = TrainPlan(model, n, h, w, dtype, x.device)
+            pc.put(key, plan)
+        plan.outstanding = grad
+    if not grad:
+        with torch.no_grad():
+            return plan.forward(x)   # nothing to save for: no autograd node, the plan stays idle
     return list(_TrainFn.apply(plan, x, *plan.params))

@@ -130,6 +130,19 @@ def fuse_conv_and_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d) -> nn.Conv2d:
 class BaseModel(nn.Module):
     """reference models/yolo.py:126-187."""
 
+    @property
+    def _plans(self):
+        """compiled execution plans of this model: a view of the engine's cache, which lives OUTSIDE the module so that
+        deepcopy / pickle / torch.save of the model (reference train.py:470-488, ModelEMA) never see device plans"""
+        from .engine import plan_cache
+
+        return plan_cache(self).plans
+
+    def _drop_plans(self):
+        from .engine import drop_plans
+
+        drop_plans(self)
+
     def forward(self, x, profile=False, visualize=False):
         return self._forward_once(x, profile, visualize)
 
@@ -148,7 +161,7 @@ class BaseModel(nn.Module):
             if isinstance(m, Conv) and hasattr(m, "bn"):
                 m.conv = fuse_conv_and_bn(m.conv, m.bn)
                 delattr(m, "bn")
-        self._plans = {}
+        self._drop_plans()
         return self
 
     def info(self, verbose=False, img_size=640):
@@ -162,7 +175,7 @@ class BaseModel(nn.Module):
         m = self.model[-1]
         if isinstance(m, Detect) and m.stride is not None:
             m.stride = fn(m.stride)
-        self._plans = {}
+        self._drop_plans()
         return self
 
 
@@ -188,7 +201,6 @@ class DetectionModel(BaseModel):
         self.model, self.save = parse_model(deepcopy(self.yaml), ch=[ch])
         self.names = [str(i) for i in range(self.yaml["nc"])]
         self.inplace = self.yaml.get("inplace", True)
-        self._plans = {}
 
         m = self.model[-1]
         if isinstance(m, Detect):
