@@ -181,7 +181,8 @@ int y3_match_detections(const float* dets, int64_t img_stride, int32_t row_strid
  * y3_loss_bwd (same params / preds / targets / workspace as the preceding fwd) overwrites grads[i] (same
  * shape and dtype as preds[i]) with d(out4[0]) / d preds[i] * grad_out[0] (grad_out: DEVICE scalar or NULL = 1).
  * Duplicate matches of one cell: tobj takes the LAST match in the reference's list order (CPU index_put), box/cls
- * gradients accumulate.  gr = 1, autobalance off, sort_obj_iou off (the reference's defaults). */
+ * gradients accumulate.  A target whose image index is outside [0, bs) or whose class is outside [0, nc) (the reference raises an
+ * IndexError on the host) is skipped and turns out4 into NaN: the step fails loudly instead of reading out of bounds.  gr = 1, autobalance off, sort_obj_iou off (the reference's defaults). */
 typedef struct {
     int32_t nl, na, nc, bs;
     int32_t ny[5], nx[5];

@@ -1576,3 +1576,31 @@ parallel.finalize()
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.count("ok") == 2, out.stdout + out.stderr
+
+
+def test_loss_rejects_out_of_range_targets(dev):
+    """a target with image index >= bs (or < 0) or class >= nc used to index out of bounds in the match kernels; the
+    reference raises an IndexError.  Here the row is dropped on the device and the loss comes back NaN (no host sync to raise
+    from): loud, and nothing is read or written out of bounds (the valid rows still produce finite gradients)."""
+    hyp = dict(box=0.05, cls=0.5, cls_pw=1.0, obj=1.0, obj_pw=1.0, anchor_t=4.0, fl_gamma=0.0, label_smoothing=0.0)
+    m, crit = _loss_setup(dev, "yolov3-tiny", 5, 64, hyp)
+    p = [(torch.rand(2, 3, 64 // s, 64 // s, 10, device=dev) * 4 - 2).requires_grad_(True) for s in (16, 32)]
+    good = torch.tensor([[0, 1, 0.5, 0.5, 0.3, 0.3], [1, 4, 0.25, 0.75, 0.2, 0.4]], device=dev)
+    loss, _ = crit(p, good)
+    assert torch.isfinite(loss).all()
+    for bad_row in ([2, 1, 0.5, 0.5, 0.3, 0.3], [-1, 1, 0.5, 0.5, 0.3, 0.3], [0, 5, 0.5, 0.5, 0.3, 0.3], [0, -2, 0.5, 0.5, 0.3, 0.3], [70000, 1, 0.5, 0.5, 0.3, 0.3]):
+        tg = torch.cat([good, torch.tensor([bad_row], device=dev, dtype=torch.float32)])
+        loss, items = crit(p, tg)
+        loss.sum().backward()
+        torch.cuda.synchronize()
+        assert torch.isnan(loss).all() and torch.isnan(items).all(), bad_row
+
+
+def test_model_rejects_wrong_channel_count(dev):
+    """the stem kernel is handed the raw image pointer, so a 1-channel batch would read past the buffer; the reference
+    raises a shape error"""
+    m, _ = build_pair("yolov3-tiny", 80, 3, dev, torch.float16)
+    with pytest.raises(ValueError, match="input channels"):
+        m(torch.rand(1, 1, 64, 64, device=dev).half())
+    with pytest.raises(ValueError, match="input channels"):
+        m(torch.rand(1, 4, 64, 64, device=dev).half())

@@ -134,6 +134,11 @@ Y3_DEV Match slot_match(const LossDev& P, int lvl, int key, const float* __restr
     const int oa = key / nt;
     const int a = oa % na, o = oa / na;
     const float* tg = targets + (long long)t * 6;
+    {   // a target whose image index / class is outside the batch / class range would index out of bounds (the reference raises an
+        // IndexError on the host): the slot is dropped here and loss_final_kernel poisons the loss with NaN so the step fails loudly
+        const int tb = (int)tg[0], tc = (int)tg[1];
+        if (tb < 0 || tb >= P.bs || tc < 0 || tc >= P.nc) return m;
+    }
     const float nxf = (float)P.nx[lvl], nyf = (float)P.ny[lvl];
     const float gx = tg[2] * nxf, gy = tg[3] * nyf, gw = tg[4] * nxf, gh = tg[5] * nyf;  // t = targets * gain  (:209-212)
     const float aw = P.anchors[lvl][a][0], ah = P.anchors[lvl][a][1];
@@ -298,8 +303,19 @@ __global__ __launch_bounds__(256) void loss_reduce_level_kernel(LevelWs W) {
 }
 
 struct FinalArgs { const float* sums[MAX_NL]; long long cells[MAX_NL]; };
-__global__ void loss_final_kernel(LossDev P, FinalArgs F, float* __restrict__ out) {
+__global__ void loss_final_kernel(LossDev P, FinalArgs F, const float* __restrict__ targets, float* __restrict__ out) {
+    bool bad = false;   // one wave scans the target list for rows slot_match had to drop
+    for (int t = threadIdx.x; t < P.nt; t += 64) {
+        const int tb = (int)targets[(long long)t * 6], tc = (int)targets[(long long)t * 6 + 1];
+        bad |= tb < 0 || tb >= P.bs || tc < 0 || tc >= P.nc;
+    }
+    bad = __ballot(bad) != 0ull;
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (bad) {
+        const float qnan = __builtin_nanf("");
+        out[0] = out[1] = out[2] = out[3] = qnan;
+        return;
+    }
     float lbox = 0.0f, lobj = 0.0f, lcls = 0.0f;
     for (int i = 0; i < P.nl; ++i) {
         const float n = F.sums[i][0];
@@ -383,7 +399,7 @@ int loss_fwd(const y3_loss_params* p, const void* const* preds, const float* tar
         hipLaunchKernelGGL(loss_reduce_level_kernel, dim3(1), dim3(256), 0, st, W);
         Y3_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, D, F, out4);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, D, F, targets, out4);
     Y3_CHECK_LAUNCH();
     return 0;
 }

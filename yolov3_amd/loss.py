@@ -81,8 +81,9 @@ class ComputeLoss:
         self._anchors_host = None
 
     def _params(self, preds) -> Y3LossParams:
-        if self._anchors_host is None or self._anchors_host[0] is not self.anchors:
-            self._anchors_host = (self.anchors, self.anchors.detach().float().cpu().reshape(-1).tolist())
+        ver = (id(self.anchors), self.anchors._version)   # autoanchor rewrites m.anchors[:] in place (utils/autoanchor.py): identity alone would go stale
+        if self._anchors_host is None or self._anchors_host[0] != ver:
+            self._anchors_host = (ver, self.anchors.detach().float().cpu().reshape(-1).tolist())
         h = self.hyp
         P = Y3LossParams()
         P.nl, P.na, P.nc, P.bs = self.nl, self.na, self.nc, preds[0].shape[0]
