@@ -598,9 +598,11 @@ def _rel_errors(a, b):
 
 # Bounds for the half-precision engines against the fp32 oracle with the same weights, raw logits of every level.  Model: each of the
 # ~75 stored tensors is rounded once (relative 2^-11 fp16 / 2^-8 bf16, uniform), errors of successive layers add in quadrature and the
-# residual trunk carries them forward: relative RMS ~ sqrt(75) * eps / sqrt(3) = 0.24 % fp16 / 2.0 % bf16.  Measured on MI355X (round 2):
-# see DESIGN.md section 5; the asserted bounds sit ~2x above the measurements, not at "looks similar" levels.
-HALF_BOUNDS = {torch.float16: dict(rms=0.006, mx=0.03, corr=0.99995), torch.bfloat16: dict(rms=0.04, mx=0.12, corr=0.9985)}
+# residual trunk carries them forward: relative RMS ~ sqrt(75) * eps / sqrt(3) = 0.24 % fp16 / 2.0 % bf16 if every layer's error survived
+# to the output; BatchNorm-folded convolutions average most of it away.  Measured on MI355X (round 2, gpurun d_pytest.log): fp16 rel RMS
+# 0.00031-0.00034, max/range 0.0006-0.0008, corr 0.999999; bf16 rel RMS 0.0019-0.0027, max/range 0.0046-0.0062, corr 0.99982-0.99993 --
+# the same at 128x128, 640x640 and 1280x1280.  The asserted bounds sit ~3x above the measurements.
+HALF_BOUNDS = {torch.float16: dict(rms=0.001, mx=0.003, corr=0.99999), torch.bfloat16: dict(rms=0.008, mx=0.02, corr=0.9995)}
 
 
 @pytest.mark.parametrize("name,hw,bs,dtype", [("yolov3", 640, 12, torch.float16), ("yolov3-spp", 640, 12, torch.float16), ("yolov3", 640, 4, torch.bfloat16),
@@ -819,11 +821,11 @@ def test_train_step_autocast_fp16(dev, name, hw, adt):
     assert raws[0].dtype == adt
     (loss * 128.0).backward()
     torch.cuda.synchronize()
-    tol = 0.02 if adt == torch.float16 else 0.08
+    tol = 0.002 if adt == torch.float16 else 0.01   # measured (round 2): 1e-4..2e-4 fp16, 1.5e-3 bf16
     assert abs(loss.item() - loss_ref.item()) / loss_ref.item() < tol
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
-    # gradient direction against the oracle's fp32 autograd: cosine over the large tensors (half-precision activations through
-    # up to 75 layers: 0.98 for fp16; bf16 keeps 8 mantissa bits)
+    # gradient direction against the oracle's fp32 autograd: cosine over the large tensors (half-precision activations and
+    # gradients through up to 75 layers; bf16 keeps 8 mantissa bits)
     cos_min, worst = 1.0, None
     for k, p_ in m.named_parameters():
         ref = sdg[k].grad
@@ -834,7 +836,8 @@ def test_train_step_autocast_fp16(dev, name, hw, adt):
         if c < cos_min:
             cos_min, worst = c, k
     print(f"[autocast {name} {adt}] loss rel err {abs(loss.item() - loss_ref.item()) / loss_ref.item():.4f}, min gradient cosine {cos_min:.4f} at {worst}")
-    assert cos_min > (0.98 if adt == torch.float16 else 0.85), f"gradient direction: cosine {cos_min:.4f} at {worst}"
+    # measured (round 2): fp16 0.9919-0.9961, bf16 0.9673
+    assert cos_min > (0.985 if adt == torch.float16 else 0.94), f"gradient direction: cosine {cos_min:.4f} at {worst}"
     for p in m.parameters():
         p.grad /= 128.0
     opt.step()
@@ -1430,7 +1433,7 @@ def test_conv_beyond_2gib_output(dev):
     """VERDICT r1 'scaling traps': a conv whose output exceeds the 2^31-byte reach of a buffer descriptor (batch 128 @640x640 layer 1,
     batch 32 @1280x1280) runs as several launches over image ranges; checked on the first / boundary / last images against conv2d."""
     _lib, ops = _ops()
-    n, h, w, cin, cout = 40, 320, 320, 32, 256        # output 40 x 320 x 320 x 256 x 2 B = 2.1 GB
+    n, h, w, cin, cout = 42, 320, 320, 32, 256        # output 42 x 320 x 320 x 256 x 2 B = 2.2 GB -> two launches of 21 images
     g = torch.Generator().manual_seed(5)
     dtype = torch.float16
     wt = torch.randn(cout, cin, 1, 1, generator=g) / math.sqrt(cin)
@@ -1442,7 +1445,7 @@ def test_conv_beyond_2gib_output(dev):
     assert yv.buf.numel() * 2 > 2**31
     ops.conv2d(xv, filt, b.to(dev), yv, 1, 1, True, None, workspace=conv_ws(dev))
     torch.cuda.synchronize()
-    for img in (0, 19, 20, 39):
+    for img in (0, 20, 21, 41):
         xi = xv.as_nhwc()[img].float().cpu().permute(2, 0, 1)[None]
         ref = F.silu(F.conv2d(xi, wt.to(dtype).float(), b))
         out = yv.as_nhwc()[img].float().cpu().permute(2, 0, 1)[None]

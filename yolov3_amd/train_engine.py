@@ -275,6 +275,9 @@ class SPPPoolUnit(_Unit):
             self.x.mark_ready()
 
 
+_FORWARD_TICK = 0
+
+
 class TrainPlan:
     def __init__(self, model, n, h, w, dtype, device):
         from .yolo import Detect
@@ -401,6 +404,7 @@ class TrainPlan:
         self._bn_counters = [u.m.bn.num_batches_tracked for u in self.units if isinstance(u, ConvUnit) and u.m.bn.num_batches_tracked is not None]
         self._arena, self._arena_off = None, 0
         self._arena_numel = sum((p.numel() + 63) // 64 * 64 for p in self.params)
+        self.last_forward = 0
         self.generation = 0        # bumped by every forward: the saved activations belong to exactly one forward
         self.outstanding = False   # a grad-enabled forward ran and its backward has not: the saved state must not be overwritten
 
@@ -489,6 +493,9 @@ class TrainPlan:
 
     # -- execution -------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor):
+        global _FORWARD_TICK
+        _FORWARD_TICK += 1
+        self.last_forward = _FORWARD_TICK   # recency across plans (the slot choice in run_model_train)
         self.generation += 1
         ops.nchw_to_nhwc(x, self.x_in.view, 1.0)
         self.x_nchw = x if x.dtype in (torch.float32, torch.float16, torch.bfloat16, torch.uint8) else None
@@ -591,7 +598,7 @@ def run_model_train(model, x: torch.Tensor):
                 break
             slot += 1
             if slot >= pc.MAX_TRAIN:
-                slot = min(range(pc.MAX_TRAIN), key=lambda s_: getattr(pc.plans.get(("train", n, h, w, dtype, x.device.index, s_)), "generation", -1))
+                slot = min(range(pc.MAX_TRAIN), key=lambda s_: getattr(pc.plans.get(("train", n, h, w, dtype, x.device.index, s_)), "last_forward", -1))
                 key = ("train", n, h, w, dtype, x.device.index, slot)
                 plan = pc.get(key)
                 break
