@@ -113,12 +113,38 @@ def cpu_baseline(bs_sample=4):
     }
 
 
-def train_main(args, rank, local_rank, world, dev, parallel, yo):
+def train_flops_per_image(model, hw):
+    """conv FLOPs of one training step per image: forward + data gradient + filter gradient = 3 x the forward's
+    2*Ho*Wo*Cout*Cin*k*k per layer, minus the data gradient of the first layer (the image needs none)."""
+    from yolov3_amd.engine import graph_hw, _sources
+
+    total, first = 0.0, None
+    sizes = graph_hw(model, hw, hw)
+    for i, m in enumerate(model.model):
+        src = _sources(i, m.f)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Conv2d):
+                ho, wo = sizes[i] if not type(m).__name__ == "Detect" else (None, None)
+                if ho is None:   # Detect: one 1x1 conv per level on that level's map
+                    continue
+                f = 2.0 * ho * wo * mod.out_channels * mod.in_channels * mod.kernel_size[0] * mod.kernel_size[1]
+                total += f
+                if first is None:
+                    first = f
+    det = model.model[-1]
+    for lvl, conv in enumerate(det.m):
+        ho, wo = sizes[det.f[lvl]]
+        total += 2.0 * ho * wo * conv.out_channels * conv.in_channels
+    return 3.0 * total - (first or 0.0)
+
+
+def run_train(args, rank, world, dev, parallel, yo, batch, steps, warmup):
     """Data-parallel training step (BASELINE configs[2] shape per GPU): forward (batch-stat BN) + ComputeLoss + backward with
-    the gradient all-reduce overlapped (parallel.GradBuckets; RCCL over xGMI) + the fused optimizer step.  Weak scaling."""
+    the gradient all-reduce overlapped (parallel.GradBuckets; RCCL over xGMI) + the fused optimizer step.  Weak scaling.
+    Returns the result record (all ranks run it; rank 0 reports)."""
     from yolov3_amd import ComputeLoss, DetectionModel
 
-    bs, hw = args.batch, args.imgsz
+    bs, hw = batch, args.imgsz
     torch.manual_seed(0)
     model = DetectionModel(f"{args.model}.yaml", nc=args.nc).to(dev).train()
     model.hyp = dict(box=0.05, cls=0.5, cls_pw=1.0, obj=1.0, obj_pw=1.0, anchor_t=4.0, fl_gamma=0.0, label_smoothing=0.0)
@@ -144,23 +170,42 @@ def train_main(args, rank, local_rank, world, dev, parallel, yo):
         opt.zero_grad(set_to_none=True)
         return loss
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     parallel.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = step()
     parallel.barrier()
     dt = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    flops_img = train_flops_per_image(model, hw)
+    tflops = flops_img * bs * steps / dt / 1e12   # per GPU
+    stats = {}
+    try:   # kernel breakdown of the same step from the committed rocprofv3 --kernel-trace --stats run (bench.py cannot run the profiler)
+        stats = json.load(open(ROOT / "profiles" / "r02_train_step_kernel_groups.json"))
+    except (OSError, ValueError):
+        pass
+    rec = {
+        "metric": "images/sec (640x640) train step", "value": round(world * bs * steps / dt, 2), "unit": "images/sec", "n_gpus": world,
+        "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f16" if args.dtype == "fp16" else "bf16", "data": "synthetic (seeded uniform images, Poisson(7) targets/img; random-init weights)",
+        "config": {"workload": f"{args.model} train step {hw}x{hw} batch={bs}/GPU autocast {args.dtype}: fwd (batch-stat BN) + ComputeLoss + bwd + grad all-reduce + fused unscale/clip/SGD-nesterov/EMA [BASELINE configs[2]]",
+                   "global_batch": world * bs, "parallelism": f"dp{world} (bucketed all-reduce overlapped with backward)"},
+        "final_loss": float(loss),
+        "roofline": {"bound": "mfma", "achieved": round(tflops, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / MFMA_PEAK_TFLOPS, 4),
+                     "whole_step_frac": round(tflops / MFMA_PEAK_TFLOPS, 4), "gflop_per_image": round(flops_img / 1e9, 2),
+                     "note": "whole step (fwd + dgrad + wgrad conv FLOPs per GPU / step time); kernel shares from the committed profile",
+                     "kernel_groups": stats.get("groups"), "dominant_kernel": stats.get("dominant"), "kernel_groups_source": "profiles/r02_train_step_kernel_groups.json" if stats else None},
+    }
+    del model, opt, ema, crit
+    torch.cuda.empty_cache()
+    return rec
+
+
+def train_main(args, rank, local_rank, world, dev, parallel, yo):
+    rec = run_train(args, rank, world, dev, parallel, yo, args.batch, args.steps, args.warmup)
     if rank == 0:
-        print(json.dumps({
-            "metric": "images/sec (640x640) train step", "value": round(world * bs * args.steps / dt, 2), "unit": "images/sec", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16" if args.dtype == "fp16" else "bf16", "data": "synthetic (seeded uniform images, Poisson(7) targets/img; random-init weights)",
-            "config": {"workload": f"{args.model} train step {hw}x{hw} batch={bs}/GPU autocast {args.dtype}: fwd (batch-stat BN) + ComputeLoss + bwd + grad all-reduce + fused unscale/clip/SGD-nesterov/EMA [BASELINE configs[2]]",
-                       "global_batch": world * bs, "parallelism": f"dp{world} (bucketed all-reduce overlapped with backward)"},
-            "final_loss": float(loss),
-        }))
+        print(json.dumps(rec))
     parallel.finalize()
 
 
@@ -178,6 +223,9 @@ def main():
     ap.add_argument("--profile-layers", action="store_true", help="print the per-launch table (rank 0)")
     ap.add_argument("--no-overlap", action="store_true", help="sequential forward -> NMS per step (no second stream)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"], help="train = BASELINE configs[2] per-GPU shape (data-parallel train step)")
+    ap.add_argument("--no-train", action="store_true", help="infer mode: skip the appended train-step leg (BASELINE metric part ii, batch 64, after the timed inference region)")
+    ap.add_argument("--train-batch", type=int, default=64)
+    ap.add_argument("--train-steps", type=int, default=6)
     args = ap.parse_args()
 
     from yolov3_amd import parallel
@@ -268,9 +316,13 @@ def main():
             torch.cuda.synchronize()
             return (time.perf_counter() - t) / n
 
+        from yolov3_amd import ops as y3ops
+
         t_fwd = timed(lambda: model(x))
         t_nms = timed(lambda: non_max_suppression(pred_synth, **nms_kw))
+        cand_synth = y3ops.nms_raw.last_candidates / bs
         t_nms_own = timed(lambda: non_max_suppression(pred, **nms_kw))
+        cand_own = y3ops.nms_raw.last_candidates / bs
         plan = next(iter(model._plans.values()))
         groups = per_kernel_times(plan)
         if args.profile_layers:
@@ -279,11 +331,20 @@ def main():
         fl, by, sec, nl = groups[dom]
         total_conv_flops = sum(g[0] for g in groups.values()) / 5
         total_kernel_s = sum(g[2] for g in groups.values()) / 5
-        pmc = {}
-        try:  # HBM traffic per launch comes from the committed rocprofv3 --pmc passes (bench.py cannot run the profiler)
-            pmc = json.load(open(ROOT / "profiles" / "r01_pmc_summary.json")).get(dom.rsplit("/", 1)[0], {})  # PMC averages are per kernel symbol
-        except OSError:
-            pass
+        pmc, pmc_file = {}, None
+        for cand in ("r02_pmc_summary.json", "r01_pmc_summary.json"):   # HBM traffic per launch comes from the committed rocprofv3 --pmc passes (bench.py cannot run the profiler)
+            try:
+                pmc = json.load(open(ROOT / "profiles" / cand)).get(dom.rsplit("/", 1)[0], {})  # PMC averages are per kernel symbol
+            except OSError:
+                continue
+            if pmc:
+                pmc_file = cand
+                break
+        # the PMC average is over EVERY launch of the kernel symbol (e.g. v6 serves 3x3 stride-2 and 1x1 layers): the algorithmic bytes
+        # it is compared with are summed over the same launch set
+        sym = dom.rsplit("/", 1)[0]
+        sym_groups = [g for k, g in groups.items() if k.rsplit("/", 1)[0] == sym]
+        sym_bytes, sym_launches = sum(g[1] for g in sym_groups), sum(g[3] for g in sym_groups)
         # 3x3 launches with Cin >= 128 are MFMA-bound, the 1x1 / small-channel launches of the same template HBM-bound
         # (SURVEY Appendix B): groups are split by filter size so that the dominant group has ONE bounding roofline
         bound = "mfma" if fl / max(by, 1.0) > 312.0 else "hbm"
@@ -295,7 +356,11 @@ def main():
             "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
             "frac": round(fl / sec / 1e12 / MFMA_PEAK_TFLOPS, 4) if bound == "mfma" else round(by / sec / 1e9 / HBM_PEAK_GBS, 4),
             "traffic": round(pmc["hbm_bytes_per_launch"]) if "hbm_bytes_per_launch" in pmc else None,
-            "traffic_source": "profiles/r01_pmc_summary.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, avg per launch of this kernel symbol)" if pmc else None,
+            "traffic_source": f"profiles/{pmc_file} (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, avg per launch of this kernel symbol)" if pmc else None,
+            "traffic_launch_set": f"all {sym_launches // 5} launches per forward of kernel symbol {sym}",
+            "algorithmic_bytes_per_launch_same_set": round(sym_bytes / max(sym_launches, 1)),
+            "traffic_over_algorithmic": round(pmc["hbm_bytes_per_launch"] / (sym_bytes / max(sym_launches, 1)), 3) if "hbm_bytes_per_launch" in pmc else None,
+            "mfma_busy_frac_pmc": round(pmc["mfma_busy_frac_of_simd_cycles"], 4) if "mfma_busy_frac_of_simd_cycles" in pmc else None,
             "algorithmic_bytes_per_launch": round(by / nl),
             "launches_per_forward": nl // 5,
             "avg_launch_us": round(sec / nl * 1e6, 2),
@@ -311,6 +376,7 @@ def main():
         }
         cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()   # rank 0 at N = 1 only
         value = world * bs * args.steps / dt
+        roofline["whole_step_frac"] = round(total_conv_flops / (dt / args.steps) / 1e12 / MFMA_PEAK_TFLOPS, 4)   # conv FLOPs of one step / wall time of one step / 2.5 PF
         out = {
             "metric": "images/sec (640x640) inference+NMS",
             "value": round(value, 2),
@@ -331,10 +397,19 @@ def main():
                 "schedule": "sequential forward -> NMS per batch" if args.no_overlap else "NMS of batch i on a second HIP stream beside the forward of batch i+1 (every batch completes inside the timed region)",
             },
             "legs_ms": {"forward+decode": round(t_fwd * 1e3, 3), "nms_synthetic_pred": round(t_nms * 1e3, 3), "nms_on_model_output": round(t_nms_own * 1e3, 3)},
-            "nms_candidates_per_image": None,
+            "nms_candidates_per_image": {"synthetic_pred": round(cand_synth, 1), "model_output": round(cand_own, 1)},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
+    # BASELINE metric part (ii): the train step, measured in the same run AFTER the timed inference region (N = 1; for N > 1 the
+    # driver's line stays the inference replicas -- `--mode train --gpus N` is the data-parallel run)
+    train = None
+    if world == 1 and not args.no_train:
+        del model
+        torch.cuda.empty_cache()
+        train = run_train(args, rank, world, dev, parallel, yo, args.train_batch, args.train_steps, 2)
+    if rank == 0:
+        out["train"] = train
         print(json.dumps(out))
     parallel.finalize()
 

@@ -1,5 +1,5 @@
-"""Fold the rocprofv3 --pmc passes of tools/gpu_pmc.sh into profiles/<round>_pmc_summary.json (keys = bench.py's kernel-instance
-names, see bench.igemm_variant).  python tools/pmc_summary.py <dir with pmc_*/ sub-dirs> <out.json>
+"""Fold the rocprofv3 --pmc passes of tools/gpu_pmc.sh into profiles/<round>_pmc_summary.json (keys = bench.py's kernel-group names:
+"conv_igemm_" + y3_conv2d_fwd_variant).  python tools/pmc_summary.py <dir with pmc_*/ sub-dirs> <out.json>
 
 Per MI355X_MICROARCH.md (HBM / rocprofv3 section): one counter group per pass; FETCH_SIZE / WRITE_SIZE are reported in KiB;
 on gfx950 FETCH_SIZE counts 128-byte requests as 64 B -> read bytes = FETCH_SIZE x 1024 x 2; WRITE_SIZE x 1024 as is."""
@@ -9,12 +9,13 @@ import re
 import sqlite3
 import sys
 
-NAMES = [  # (regex on the kernel symbol, bench.py name)
-    (r"conv_igemm_v5_kernelIDF16_Li32ELi4ELi2ELi2ELi4ELi1E", "conv_igemm_v6<f16,bk32,tc256xtp256,8 waves staggered>"),
-    (r"conv_igemm_v3_kernelIDF16_Li64ELi2ELi2E", "conv_igemm_v3<f16,bk64,tc128xtp128>"),
-    (r"conv_igemm_v3_kernelIDF16_Li32ELi2ELi2E", "conv_igemm_v3<f16,bk32,tc128xtp128>"),
-    (r"conv_igemm_v3_kernelIDF16_Li32ELi1ELi4E", "conv_igemm_v3<f16,bk32,tc64xtp256>"),
-    (r"conv_igemm_v2_kernelIDF16_Li32ELi1ELi4ELi1ELi2ELb1E", "conv_igemm_v2<f16,bk32,tc32xtp256_smallc>"),
+NAMES = [  # (regex on the kernel symbol, bench.py name = "conv_igemm_" + the library's variant name)
+    (r"conv_igemm_v7_kernelIDF16_", "conv_igemm_v7"),
+    (r"conv_igemm_v5_kernelIDF16_Li32ELi4ELi2ELi2ELi4ELi1E", "conv_igemm_v6"),
+    (r"conv_igemm_v3_kernelIDF16_Li64ELi2ELi2E", "conv_igemm_v3_bk64_128x128"),
+    (r"conv_igemm_v3_kernelIDF16_Li32ELi2ELi2E", "conv_igemm_v3_bk32_128x128"),
+    (r"conv_igemm_v3_kernelIDF16_Li32ELi1ELi4E", "conv_igemm_v3_bk32_64x256"),
+    (r"conv_igemm_v2_kernelIDF16_Li32ELi1ELi4ELi1ELi2ELb1E", "conv_igemm_v2_smallc"),
     (r"stem_pair_kernel", "stem_pair"),
     (r"stem_conv_kernel", "stem_conv"),
     (r"decode_vec_kernel", "decode_vec"),
@@ -37,7 +38,12 @@ def main(root, out):
             for pat, name in NAMES:
                 if re.search(pat, k):
                     rec = res.setdefault(name, {"symbol": re.sub(r"\(anonymous namespace\)::|_ZN12_GLOBAL__N_1\d+", "", k)[:90]})
-                    rec[c] = {"dispatches": n, "avg": a}
+                    prev = rec.get(c)
+                    if prev:   # several symbols under one name (template instances): dispatch-weighted mean
+                        tot = prev["dispatches"] + n
+                        rec[c] = {"dispatches": tot, "avg": (prev["avg"] * prev["dispatches"] + a * n) / tot}
+                    else:
+                        rec[c] = {"dispatches": n, "avg": a}
                     break
     for name, rec in res.items():
         if "FETCH_SIZE" in rec and "WRITE_SIZE" in rec:

@@ -260,6 +260,7 @@ def nms_raw(pred: torch.Tensor, conf_thres: float, iou_thres: float, classes, ag
             "y3_nms",
         )
         m = meta.tolist()  # the single device->host sync of the call
+        nms_raw.last_candidates = m[bs + 1]   # candidates (rows above conf_thres, one per class under multi_label) of the whole batch: bench.py reports it
         if m[bs] == 0:
             return rows, m[:bs]
         capacity = max(m[bs + 1], 1)  # overflow: rerun with room for every candidate
