@@ -223,6 +223,11 @@ int y3_bn_finalize(const double* sums, int64_t count, int32_t channels, const fl
 int64_t y3_conv2d_fwd_stats_rows(const y3_conv_desc* desc, const y3_tensor* x, const y3_tensor* y);
 int y3_conv2d_fwd_stats(const y3_conv_desc* desc, const y3_tensor* x, const void* packed_filter, const float* bias,
                         const y3_tensor* y, float* stat_rows, int64_t capacity_rows, int64_t* n_rows, void* stream);
+/* the same with the scratch buffer of y3_conv2d_fwd_ws (the persistent kernel writes 4 rows per pixel tile: query with the same size) */
+int64_t y3_conv2d_fwd_stats_rows_ws(const y3_conv_desc* desc, const y3_tensor* x, const y3_tensor* y, size_t workspace_bytes);
+int y3_conv2d_fwd_stats_ws(const y3_conv_desc* desc, const y3_tensor* x, const void* packed_filter, const float* bias,
+                           const y3_tensor* y, float* stat_rows, int64_t capacity_rows, int64_t* n_rows, void* workspace,
+                           size_t workspace_bytes, void* stream);
 int y3_bn_finalize_rows(const float* stat_rows, int64_t n_rows, int64_t count, int32_t channels, double* sums, const float* gamma,
                         const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* scale,
                         float* shift, float* mean, float* invstd, void* stream);

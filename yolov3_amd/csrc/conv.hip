@@ -1159,6 +1159,21 @@ extern "C" int y3_conv2d_fwd_stats(const y3_conv_desc* d, const y3_tensor* x, co
     return conv_fwd_impl(d, x, filt, bias, nullptr, y, stat_rows, capacity_rows, n_rows, 0, stream);
 }
 
+// the two calls above with the stream-K workspace of y3_conv2d_fwd_ws (the persistent kernel writes 4 statistic rows per pixel tile)
+extern "C" int64_t y3_conv2d_fwd_stats_rows_ws(const y3_conv_desc* d, const y3_tensor* x, const y3_tensor* y, size_t workspace_bytes) {
+    int64_t rows = 0;
+    alignas(256) static const float dummy[64] = {0.0f};   // geometry only: never dereferenced
+    if (conv_fwd_impl(d, x, (const void*)dummy, dummy, nullptr, y, nullptr, 0, &rows, 1, nullptr, workspace_bytes ? (void*)dummy : nullptr, workspace_bytes)) return -1;
+    return rows;
+}
+
+extern "C" int y3_conv2d_fwd_stats_ws(const y3_conv_desc* d, const y3_tensor* x, const void* filt, const float* bias, const y3_tensor* y, float* stat_rows,
+                                      int64_t capacity_rows, int64_t* n_rows, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!n_rows) Y3_FAIL("y3_conv2d_fwd_stats_ws: null row count");
+    if (workspace && ((uintptr_t)workspace & 255)) Y3_FAIL("y3_conv2d_fwd_stats_ws: the workspace must be 256-byte aligned");
+    return conv_fwd_impl(d, x, filt, bias, nullptr, y, stat_rows, capacity_rows, n_rows, 0, stream, workspace, workspace_bytes);
+}
+
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Data gradient of a 3x3 stride-2 pad-1 convolution without the 4x zero-tap waste of the dilated form: the gradient

@@ -293,21 +293,29 @@ def letterbox_u8(src_hwc: torch.Tensor, dst_batch: torch.Tensor, index: int, new
                                      int(left), int(color), stream_ptr()), "y3_letterbox_u8")
 
 
-def conv2d_stats_rows(x: View, y: View, k: int, stride: int) -> int:
+def conv2d_stats_rows(x: View, y: View, k: int, stride: int, workspace: torch.Tensor | None = None) -> int:
     """rows of the statistics buffer a conv2d_stats launch of this shape writes (depends on the dispatched tile variant)."""
     d = Y3ConvDesc(dtype_code(x.buf.dtype), k, stride, _lib.Y3_ACT_NONE, 0, _lib.Y3_ALGO_AUTO, x.c, y.c, 0)
     xt, yt = x.y3(), y.y3()
-    rows = int(_lib.lib().y3_conv2d_fwd_stats_rows(C.byref(d), C.byref(xt), C.byref(yt)))
+    if workspace is not None:
+        rows = int(_lib.lib().y3_conv2d_fwd_stats_rows_ws(C.byref(d), C.byref(xt), C.byref(yt), workspace.numel()))
+    else:
+        rows = int(_lib.lib().y3_conv2d_fwd_stats_rows(C.byref(d), C.byref(xt), C.byref(yt)))
     if rows < 0:
         check(-1, "y3_conv2d_fwd_stats_rows")
     return rows
 
 
-def conv2d_stats(x: View, filt: torch.Tensor, bias: torch.Tensor, y: View, k: int, stride: int, stat_rows: torch.Tensor, capacity_rows: int) -> int:
+def conv2d_stats(x: View, filt: torch.Tensor, bias: torch.Tensor, y: View, k: int, stride: int, stat_rows: torch.Tensor, capacity_rows: int,
+                 workspace: torch.Tensor | None = None) -> int:
     """y = conv(x) (no activation) + per-(pixel tile, wave) rows of (sum, sum of squares) per filter in stat_rows (fp32)."""
     d = Y3ConvDesc(dtype_code(x.buf.dtype), k, stride, _lib.Y3_ACT_NONE, 0, _lib.Y3_ALGO_AUTO, x.c, y.c, 0)
     xt, yt = x.y3(), y.y3()
     n = C.c_int64(0)
+    if workspace is not None:
+        check(_lib.lib().y3_conv2d_fwd_stats_ws(C.byref(d), C.byref(xt), filt.data_ptr(), bias.data_ptr(), C.byref(yt), stat_rows.data_ptr(), int(capacity_rows), C.byref(n),
+                                                workspace.data_ptr(), workspace.numel(), stream_ptr()), "y3_conv2d_fwd_stats_ws")
+        return int(n.value)
     check(_lib.lib().y3_conv2d_fwd_stats(C.byref(d), C.byref(xt), filt.data_ptr(), bias.data_ptr(), C.byref(yt), stat_rows.data_ptr(), int(capacity_rows), C.byref(n), stream_ptr()),
           "y3_conv2d_fwd_stats")
     return int(n.value)

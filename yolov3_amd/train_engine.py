@@ -122,10 +122,11 @@ class ConvUnit(_Unit):
                 filt = ops.pack_filter(m.conv.weight, self.cout, self.cin, self.plan.dtype)
             if self.plan.epilogue_stats:
                 # BatchNorm statistics taken in the conv epilogue (per-tile rows of sum / sum of squares): no separate pass over u
+                ws = self.plan.conv_ws
                 if self.stat_rows is None:
-                    self.stat_rows = ops.conv2d_stats_rows(self.x.view, self.u, self.k, self.s)
+                    self.stat_rows = ops.conv2d_stats_rows(self.x.view, self.u, self.k, self.s, workspace=ws)
                 buf = self.plan.stat_buffer(self.stat_rows * 2 * self.cout)
-                n_rows = ops.conv2d_stats(self.x.view, filt, self.zero_bias, self.u, self.k, self.s, buf, self.stat_rows)
+                n_rows = ops.conv2d_stats(self.x.view, filt, self.zero_bias, self.u, self.k, self.s, buf, self.stat_rows, workspace=ws)
                 check(
                     L.y3_bn_finalize_rows(buf.data_ptr(), n_rows, self.count, self.cout, self.sums.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps),
                                           float(bn.momentum), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
@@ -134,7 +135,7 @@ class ConvUnit(_Unit):
                 )
                 stats_in_epilogue = True
             else:
-                ops.conv2d(self.x.view, filt, self.zero_bias, self.u, self.k, self.s, act=False)
+                ops.conv2d(self.x.view, filt, self.zero_bias, self.u, self.k, self.s, act=False, workspace=self.plan.conv_ws)
         if not stats_in_epilogue:
             check(
                 L.y3_bn_stats_finalize(C.byref(ut), dcode, self.sums.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps), float(bn.momentum),
@@ -184,7 +185,7 @@ class ConvUnit(_Unit):
                 if filt_d is None:
                     filt_d = ops.pack_filter_dgrad(m.conv.weight, self.cout, self.cin, self.plan.dtype)
                 zb = self.plan.zeros_f32(self.cin)
-                ops.conv2d(du, filt_d, zb, gx, self.k, 1, act=False, residual=gx if self.x.is_ready() else None, in_dilation=self.s)
+                ops.conv2d(du, filt_d, zb, gx, self.k, 1, act=False, residual=gx if self.x.is_ready() else None, in_dilation=self.s, workspace=self.plan.conv_ws)
             self.x.mark_ready()
 
 
@@ -402,6 +403,9 @@ class TrainPlan:
                 and dtype in (torch.float16, torch.bfloat16) and os.environ.get("Y3_STEM", "1") != "0"):
             u0.use_stem = True
         self._bn_counters = [u.m.bn.num_batches_tracked for u in self.units if isinstance(u, ConvUnit) and u.m.bn.num_batches_tracked is not None]
+        # scratch of the persistent conv kernel (forward + data-gradient launches of the 3x3 layers with >= 256 channels); one per plan:
+        # every conv launch of the plan runs on the compute stream
+        self.conv_ws = ops.conv_workspace(device) if dtype in (torch.float16, torch.bfloat16) else None
         self._arena, self._arena_off = None, 0
         self._arena_numel = sum((p.numel() + 63) // 64 * 64 for p in self.params)
         self.last_forward = 0
