@@ -28,6 +28,15 @@ SHAPES = [
     ("L6.cv1 256->128 @80", 80, 80, 256, 128, 1, 1, False),
     ("L8.cv1 512->256 @40", 40, 40, 512, 256, 1, 1, False),
     ("L10.cv1 1024->512 @20", 20, 20, 1024, 512, 1, 1, False),
+    ("L12 1024->512 @20 (head)", 20, 20, 1024, 512, 1, 1, False),
+    ("L16 512->256 @20", 20, 20, 512, 256, 1, 1, False),
+    ("L19.cv1 768->256 @40", 40, 40, 768, 256, 1, 1, False),
+    ("L26.cv1 384->128 @80", 80, 80, 384, 128, 1, 1, False),
+    ("L4.cv1 128->64 @160", 160, 160, 128, 64, 1, 1, False),
+    ("L2.cv1 64->32 @320", 320, 320, 64, 32, 1, 1, False),
+    ("L2.cv2 32->64 @320", 320, 320, 32, 64, 3, 1, True),
+    ("L3 64->128 s2 @320", 320, 320, 64, 128, 3, 2, False),
+    ("L5 128->256 s2 @160", 160, 160, 128, 256, 3, 2, False),
 ]
 
 
@@ -38,6 +47,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--only", default="")
     ap.add_argument("--dtype", default="fp16")
+    ap.add_argument("--sweep", action="store_true", help="also time every forced tile variant (Y3_CONV=v3a|v3b|v3c|v5a|v5b|v6a|v6b) without a workspace")
     args = ap.parse_args()
     from yolov3_amd import ops
 
@@ -66,6 +76,8 @@ def main():
         arms = [("nows", None, {}), ("ws", ws, {})]
         if ops.conv_variant(xv, yv, k, s, res, workspace_bytes=ws.numel()) == "v7":
             arms += [("ws s0", ws, {"Y3_V7_SCHED": "0"}), ("tiles s1", ws, {"Y3_V7_GRID": "-1"}), ("tiles s0", ws, {"Y3_V7_GRID": "-1", "Y3_V7_SCHED": "0"})]
+        if args.sweep:
+            arms += [(v, None, {"Y3_CONV": v}) for v in ("v3a", "v3b", "v3c", "v5a", "v5b", "v6a", "v6b")]
         times = {a[0]: [] for a in arms}
         outs = {}
         for rnd in range(args.rounds + 1):

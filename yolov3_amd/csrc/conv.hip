@@ -97,22 +97,19 @@ Y3_DEV int xcd_remap(int b, int nb) {
 }
 
 // tuning knob for A/B runs: Y3_CONV=v2|v3a|v3b|v3c (default: per-shape choice among the v3 tiles); v3 covers Cout > 64, Cin % 32 == 0
-static int conv_variant() {
-    static const int v = [] {
-        const char* e = getenv("Y3_CONV");
-        if (!e) return 3;
-        if (!strcmp(e, "v2")) return 2;
-        if (!strcmp(e, "v3b")) return 4;
-        if (!strcmp(e, "v3c")) return 5;
-        if (!strcmp(e, "v3a")) return 6;
-        if (!strcmp(e, "v5a")) return 11;
-        if (!strcmp(e, "v5b")) return 12;
-        if (!strcmp(e, "v5c")) return 13;
-        if (!strcmp(e, "v6a")) return 14;
-        if (!strcmp(e, "v6b")) return 15;
-        return 3;
-    }();
-    return v;
+static int conv_variant() {   // read per call (a getenv + a few strcmp per launch): tools/conv_lab.py sweeps variants inside one process
+    const char* e = getenv("Y3_CONV");
+    if (!e) return 3;
+    if (!strcmp(e, "v2")) return 2;
+    if (!strcmp(e, "v3b")) return 4;
+    if (!strcmp(e, "v3c")) return 5;
+    if (!strcmp(e, "v3a")) return 6;
+    if (!strcmp(e, "v5a")) return 11;
+    if (!strcmp(e, "v5b")) return 12;
+    if (!strcmp(e, "v5c")) return 13;
+    if (!strcmp(e, "v6a")) return 14;
+    if (!strcmp(e, "v6b")) return 15;
+    return 3;
 }
 
 Y3_DEV int fdiv(int n, unsigned mul, unsigned sh) { return mul ? (int)(__umulhi((unsigned)n, mul) >> (sh - 1)) : n; }

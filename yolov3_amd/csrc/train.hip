@@ -527,7 +527,11 @@ template <typename F> Y3_DEV void lds_wait6(F& a, F& b, F& c, F& d, F& e, F& f) 
 // channel i's 4 pixels; two such reads make one 8-k fragment.  Bank conflicts are avoided with an XOR on the 16-byte slot
 // index, physical = logical ^ 4 (row & 3), applied on the DMA source side (the 4 rows of a read group land on 4
 // different quarter-rows = all 64 banks once per 32-lane pass).
-template <typename T>
+// CO32 = 32-filter MFMA tiles of the block's filter tile: 4 = 128 filters (2 x 2 waves of 64 x 64), 2 = 64 filters and 1 = 32 filters
+// (4 waves side by side along the columns, 64 / 32 filters x 32 columns each).  The narrow forms serve the layers with <= 64 / <= 32
+// filters (the 640x640 and 320x320 maps of yolov3): with the 128-filter tile their launches multiplied 75 % / 50 % zero rows and were
+// MFMA-bound on padding (layer 0 at batch 64: 0.86 TFLOP executed for 0.05 useful, 1.09 ms against a 0.35 ms HBM floor).
+template <typename T, int CO32>
 __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BKP = 64, ROWB = 256, TILE = BKP * ROWB, STAGE = 2 * TILE;   // 16 KiB per operand and stage
@@ -537,7 +541,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wc = wv >> 1, wn = wv & 1;
+    constexpr int AM = CO32 >= 2 ? 2 : 1;      // filter tiles per wave
+    constexpr int WC = CO32 / AM;              // waves along the filters
+    constexpr int WN = 4 / WC;                 // waves along the columns
+    constexpr int BN = 4 / WN;                 // column tiles per wave
+    const int wc = wv / WN, wn = wv % WN;
     const int ct = blockIdx.x / p.n_nt, nt = blockIdx.x % p.n_nt;
     const long long m_begin = (long long)blockIdx.y * p.per_slice;
     long long m_end = m_begin + p.per_slice;
@@ -552,7 +560,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs p) {
     const int prow = lane >> 4, pslot = lane & 15;
     const int lslot = pslot ^ (4 * prow);
     const int a_ch = ct * 128 + lslot * 8;                 // filter group this lane copies from du
-    const bool a_ok = a_ch < p.Cout;
+    const bool a_ok = a_ch < p.Cout && lslot * 8 < CO32 * 32;
     const int ncol = nt * 128 + lslot * 8;                 // im2col column group this lane copies from x
     const int b_tap = ncol / p.Cin, b_ci = ncol - b_tap * p.Cin;
     const int b_kh = b_tap / p.ks, b_kw = b_tap - b_kh * p.ks;
@@ -579,11 +587,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs p) {
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[AM][BN];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < AM; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < BN; ++b)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.0f;
 
@@ -595,11 +603,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs p) {
     const int krow0 = (gg >> 1) * 8 + (gi >> 2);            // + 16 kk + 4 t
     const int chan0 = (gg & 1) * 16 + 4 * (gi & 3);         // + 32 (tile index) within the 128-wide operand tile
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
-    unsigned fa[2], fb[2];
+    unsigned fa[AM], fb[BN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int cha = (wc * 2 + i) * 32 + chan0, chb = (wn * 2 + i) * 32 + chan0;
+    for (int i = 0; i < AM; ++i) {
+        const int cha = (wc * AM + i) * 32 + chan0;
         fa[i] = lds0 + krow0 * ROWB + (((cha >> 3) ^ (4 * (krow0 & 3))) << 4) + (cha & 4) * 2;
+    }
+#pragma unroll
+    for (int i = 0; i < BN; ++i) {
+        const int chb = (wn * BN + i) * 32 + chan0;
         fb[i] = lds0 + TILE + krow0 * ROWB + (((chb >> 3) ^ (4 * (krow0 & 3))) << 4) + (chb & 4) * 2;
     }
     auto tr_frag = [&](unsigned base, auto stage_kk) -> frag {   // stage_kk: integral_constant<int, stage * 4 + kk>
@@ -609,11 +621,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs p) {
         const s16x8_t r = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         return __builtin_bit_cast(frag, r);
     };
-    auto mma = [&](const frag (&af)[2], const frag (&bf)[2]) {
+    auto mma = [&](const frag (&af)[AM], const frag (&bf)[BN]) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < AM; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
+            for (int b = 0; b < BN; ++b) {
                 if constexpr (std::is_same<T, f16_t>::value) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
                 else acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
             }
@@ -621,23 +633,30 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs p) {
     // the reads of k-substep kk+1 are in flight under the MFMAs of kk; the lgkmcnt(0) behind the MFMAs finds them landed
     auto compute = [&](auto stage_c) {
         constexpr int ST = decltype(stage_c)::value;
-        frag a0[2], b0[2], a1[2], b1[2];
-        auto rd = [&](auto kk_c, frag (&af)[2], frag (&bf)[2]) {
+        frag a0[AM], b0[BN], a1[AM], b1[BN];
+        auto rd = [&](auto kk_c, frag (&af)[AM], frag (&bf)[BN]) {
             constexpr int SK = ST * 4 + decltype(kk_c)::value;
-            af[0] = tr_frag(fa[0], std::integral_constant<int, SK>{}); af[1] = tr_frag(fa[1], std::integral_constant<int, SK>{});
-            bf[0] = tr_frag(fb[0], std::integral_constant<int, SK>{}); bf[1] = tr_frag(fb[1], std::integral_constant<int, SK>{});
+#pragma unroll
+            for (int i = 0; i < AM; ++i) af[i] = tr_frag(fa[i], std::integral_constant<int, SK>{});
+#pragma unroll
+            for (int i = 0; i < BN; ++i) bf[i] = tr_frag(fb[i], std::integral_constant<int, SK>{});
+        };
+        auto landed = [&](frag (&af)[AM], frag (&bf)[BN]) {   // the fragments as operands of the wait: nothing consumes them earlier
+            if constexpr (AM == 2 && BN == 2) lds_wait4(af[0], af[1], bf[0], bf[1]);
+            else if constexpr (AM == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(bf[0]) : : "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(bf[0]) : : "memory");
         };
         rd(std::integral_constant<int, 0>{}, a0, b0);
-        lds_wait4(a0[0], a0[1], b0[0], b0[1]);
+        landed(a0, b0);
         rd(std::integral_constant<int, 1>{}, a1, b1);
         mma(a0, b0);
-        lds_wait4(a1[0], a1[1], b1[0], b1[1]);
+        landed(a1, b1);
         rd(std::integral_constant<int, 2>{}, a0, b0);
         mma(a1, b1);
-        lds_wait4(a0[0], a0[1], b0[0], b0[1]);
+        landed(a0, b0);
         rd(std::integral_constant<int, 3>{}, a1, b1);
         mma(a0, b0);
-        lds_wait4(a1[0], a1[1], b1[0], b1[1]);
+        landed(a1, b1);
         mma(a1, b1);
     };
 
@@ -659,13 +678,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs p) {
     const int frow = lane & 31, fk = lane >> 5;
     float* tile = p.part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (128 * 128);
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int nl = (wn * 2 + b) * 32 + frow;
+    for (int b = 0; b < BN; ++b) {
+        const int nl = (wn * BN + b) * 32 + frow;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < AM; ++a)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int col = (wc * 2 + a) * 32 + 8 * g + 4 * fk;
+                const int col = (wc * AM + a) * 32 + 8 * g + 4 * fk;
                 f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
                 *(f32x4*)(tile + nl * 128 + col) = v;
             }
@@ -1335,8 +1354,16 @@ extern "C" int y3_conv2d_wgrad(const y3_conv_desc* d, const y3_tensor* x, const 
             if (d->dtype == Y3_F16) hipLaunchKernelGGL((wgrad_mfma_kernel<f16_t>), grid, dim3(256), 0, st, a);
             else hipLaunchKernelGGL((wgrad_mfma_kernel<bf16_t>), grid, dim3(256), 0, st, a);
         } else {
-            if (d->dtype == Y3_F16) hipLaunchKernelGGL((wgrad_dma_kernel<f16_t>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((wgrad_dma_kernel<bf16_t>), grid, dim3(256), 0, st, a);
+            const int co32 = d->cout <= 32 ? 1 : (d->cout <= 64 ? 2 : 4);   // narrow filter tiles for the <= 64-filter layers (one filter tile, n_ct == 1)
+            if (d->dtype == Y3_F16) {
+                if (co32 == 1) hipLaunchKernelGGL((wgrad_dma_kernel<f16_t, 1>), grid, dim3(256), 0, st, a);
+                else if (co32 == 2) hipLaunchKernelGGL((wgrad_dma_kernel<f16_t, 2>), grid, dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((wgrad_dma_kernel<f16_t, 4>), grid, dim3(256), 0, st, a);
+            } else {
+                if (co32 == 1) hipLaunchKernelGGL((wgrad_dma_kernel<bf16_t, 1>), grid, dim3(256), 0, st, a);
+                else if (co32 == 2) hipLaunchKernelGGL((wgrad_dma_kernel<bf16_t, 2>), grid, dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((wgrad_dma_kernel<bf16_t, 4>), grid, dim3(256), 0, st, a);
+            }
         }
         Y3_CHECK_LAUNCH();
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk(tiles << (2 * tsh))), dim3(256), 0, st, (const float*)workspace, (int)tiles, a.n_nt, (int)slices, d->cin, d->ksize, cin_real,
