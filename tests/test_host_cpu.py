@@ -332,6 +332,8 @@ def test_conv_dispatch_variant_names_and_stat_rows():
             assert rows > 0, L.y3_last_error()
             tp, per = tile_px[plain]
             m = bs * ho * ho
+            if (cin, cout, k) == (64, 128, 3):
+                assert plain == ("v3_bk32_128x256" if s == 1 else "v3_bk64_128x128")   # round-2 sweep: profiles/r02_conv_variant_sweep.txt
             assert rows == -(-m // tp) * per, f"{cin}->{cout} k{k} s{s} @{hin} bs{bs}: {rows} rows for {plain}"
             assert L.y3_conv2d_fwd_variant(C.byref(d), C.byref(x), C.byref(y), 0, ws, name, 64) == 0
             with_ws = name.value.decode()

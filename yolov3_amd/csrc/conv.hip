@@ -941,6 +941,9 @@ template <typename T> int dispatch_igemm(ConvArgs& a, hipStream_t st) {
         if (K >= 4608 && a.Cout >= 256 && a.M >= 65536) return launch_v5<T, 32, 4, 2, 2, 4, 1>(a, st);   // data gradient of the 256 -> 512 layers (one filter tile)
         if (c64 && a.ntaps == 1 && a.Cout >= 256 && a.M > 16384 && a.M <= 65536) return launch_v5<T, 32, 4, 2, 2, 4, 1>(a, st);   // 1x1 @40x40
         if (c64 && ((a.ntaps > 1 && K >= 1152) || (a.ntaps == 1 && K >= 256 && a.M <= 16384))) return launch_v3<T, 64, 2, 2>(a, st);
+        // round 2 sweep (profiles/r02_conv_variant_sweep.txt): 64 -> 128 3x3 @160x160 runs 5 % faster on the 128c x 256p tile, the stride-2
+        // 64 -> 128 layer 3 % faster with BK 64
+        if (c64 && a.ntaps > 1 && K == 576 && a.Cout == 128 && a.M >= 262144) return a.stride == 1 ? launch_v3<T, 32, 2, 4>(a, st) : launch_v3<T, 64, 2, 2>(a, st);
         return launch_v3<T, 32, 2, 2>(a, st);
     }
     // <= 64-filter layers with Cin % 32 == 0 also go to the LDS-DMA kernel (64c x 256p tile): measured 0.42 -> 0.36 ms on
