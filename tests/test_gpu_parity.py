@@ -183,6 +183,21 @@ def test_conv_v7_streamk_vs_fp32_reference(dev, dtype, name, shape, kw, monkeypa
     _conv_tol_check(name, dtype, out, ref)
 
 
+@pytest.mark.parametrize("sched", ["0", "1", "2"])
+def test_conv_v7_schedules(dev, monkeypatch, sched):
+    """the three K-loop schedules of the persistent kernel (DMA requests in the MEM phase / between the MFMAs / next step's filter
+    fragments read during the MMA phase) compute the same sums in the same order: bit-identical outputs, whole tiles and K split"""
+    outs = []
+    for grid in ("-1", "-2"):
+        monkeypatch.setenv("Y3_V7_GRID", grid)
+        monkeypatch.setenv("Y3_V7_SCHED", sched)
+        out, ref = run_conv(dev, torch.float16, 3, 40, 40, 256, 512, 3, 1, algo=1, ws=True, expect="v7", repeat=2, residual=True)
+        _conv_tol_check(f"sched{sched} grid{grid}", torch.float16, out, ref)
+        monkeypatch.setenv("Y3_V7_SCHED", "0")
+        base, _ = run_conv(dev, torch.float16, 3, 40, 40, 256, 512, 3, 1, algo=1, ws=True, expect="v7", residual=True)
+        assert torch.equal(out, base), f"schedule {sched} differs from schedule 0 (grid {grid})"
+
+
 def test_conv_v7_grid_sweep(dev, monkeypatch):
     """the same problem under different block counts (different K splits, down to whole tiles): every split sums the same
     products in fp32, so the results agree to accumulation-order noise and each one is inside the conv tolerance"""
