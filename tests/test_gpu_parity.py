@@ -183,10 +183,12 @@ def test_conv_v7_streamk_vs_fp32_reference(dev, dtype, name, shape, kw, monkeypa
     _conv_tol_check(name, dtype, out, ref)
 
 
-@pytest.mark.parametrize("sched", ["0", "1", "2"])
+@pytest.mark.parametrize("sched", ["0", "1"])
 def test_conv_v7_schedules(dev, monkeypatch, sched):
-    """the three K-loop schedules of the persistent kernel (DMA requests in the MEM phase / between the MFMAs / next step's filter
-    fragments read during the MMA phase) compute the same sums in the same order: bit-identical outputs, whole tiles and K split"""
+    """the two K-loop schedules of the persistent kernel (DMA requests in the MEM phase / between the MFMAs) compute the same sums in
+    the same order: bit-identical outputs, whole tiles and K split, launch after launch.  (A third schedule that read the next step's
+    filter fragments during the MMA phase was 1.5 % slower AND failed this test: the leading wave half read a tile whose pieces the
+    trailing half had not retired yet -- removed.)"""
     outs = []
     for grid in ("-1", "-2"):
         monkeypatch.setenv("Y3_V7_GRID", grid)

@@ -214,14 +214,6 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p)
         __builtin_amdgcn_s_barrier();              // patch + filter tile 0 visible to everyone (and the zero block)
         if (half) __builtin_amdgcn_s_barrier();    // stagger
         int s = 0;
-        frag an0[MC], an1[MC];   // SCHED 2: the filter fragments of the NEXT step, read during this step's MMA phase
-        if constexpr (SCHED == 2) {
-#pragma unroll
-            for (int a = 0; a < MC; ++a) {
-                an0[a] = *(const frag*)(smem + aoff[a]);          // step 0 reads ring stage 0 (landed: the prologue's wait + barrier)
-                an1[a] = *(const frag*)(smem + (aoff[a] ^ 32));
-            }
-        }
 #ifdef Y3_TIMELINE
         tprev = __builtin_amdgcn_s_memtime();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -236,7 +228,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p)
                 constexpr int MASK = (dh == 0 ? 1 : dh == 2 ? 2 : 0) | (dw == 0 ? 4 : dw == 2 ? 8 : 0);
                 // ---- MEM(s): [SCHED 0: request patch piece / filter tile s + 2,] read the fragments of step s, retire this wave's pieces of step s + 1 ----
                 int issued = 0;   // requests younger than filter tile s + 1: they may stay in flight
-                if constexpr (SCHED == 0 || SCHED == 2) {
+                if constexpr (SCHED == 0) {
                     if constexpr (tap >= 1 && tap <= XP) {
                         if (more_cb) { dma_x(tap - 1, cb + 1, buf ^ 1); issued += 1; }
                     }
@@ -258,13 +250,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p)
                     const unsigned char* wl = smem + (s & 3) * V7_W_STAGE;
 #pragma unroll
                     for (int a = 0; a < MC; ++a) {
-                        if constexpr (SCHED == 2) {
-                            a0[a] = an0[a];
-                            a1[a] = an1[a];
-                        } else {
-                            a0[a] = *(const frag*)(wl + aoff[a]);
-                            a1[a] = *(const frag*)(wl + (aoff[a] ^ 32));
-                        }
+                        a0[a] = *(const frag*)(wl + aoff[a]);
+                        a1[a] = *(const frag*)(wl + (aoff[a] ^ 32));
                     }
                     // (the asm statements keep these per-step: hoisted out of the channel-block loop, the 9 x 4 addresses and lane masks of
                     //  all taps would cost ~40 VGPRs + ~64 SGPRs and spill -- scratch traffic would also break the counted vmcnt)
@@ -296,26 +283,6 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p)
                 if constexpr (SCHED == 0) {
                     mma(a0, b0);
                     mma(a1, b1);
-                } else if constexpr (SCHED == 2) {
-                    // filter tile s + 1 is visible (every wave's counted vmcnt + the barrier above): its 4 fragment reads ride between this
-                    // step's MFMAs instead of lengthening the next MEM phase (the half that the MMA half waits for)
-                    const unsigned char* wn = smem + ((s + 1) & 3) * V7_W_STAGE;
-#pragma unroll
-                    for (int b = 0; b < MP; ++b) acc[0][b] = Mfma<T>::run(a0[0], b0[b], acc[0][b]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    an0[0] = *(const frag*)(wn + aoff[0]);
-                    an1[0] = *(const frag*)(wn + (aoff[0] ^ 32));
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int b = 0; b < MP; ++b) acc[1][b] = Mfma<T>::run(a0[1], b0[b], acc[1][b]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    an0[1] = *(const frag*)(wn + aoff[1]);
-                    an1[1] = *(const frag*)(wn + (aoff[1] ^ 32));
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int b = 0; b < MP; ++b) acc[0][b] = Mfma<T>::run(a1[0], b1[b], acc[0][b]);
-#pragma unroll
-                    for (int b = 0; b < MP; ++b) acc[1][b] = Mfma<T>::run(a1[1], b1[b], acc[1][b]);
                 } else {
                     // 4 groups of 4 MFMAs; the requests for step s + 3 (2 filter pieces) and, in the first XP taps, one piece of the next channel
                     // block's patch go between the groups.  Stage (s + 3) & 3 held tile s - 1, whose last fragment reads retired two barriers ago.
@@ -531,11 +498,7 @@ template <typename T> int launch_v7(ConvArgs& a, hipStream_t st) {
     const dim3 grid((unsigned)g), block(512);
     int sched = 0;   // SCHED 1 measured 2-6 % slower (profiles/r02_conv_v7.md); kept for A/B
     if (const char* e = getenv("Y3_V7_SCHED")) sched = atoi(e);
-    if (sched == 2) {
-        if (xp == 3) hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 3, 2>), grid, block, 0, st, a);
-        else if (xp == 4) hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 4, 2>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 5, 2>), grid, block, 0, st, a);
-    } else if (sched == 0) {
+    if (sched == 0) {
         if (xp == 3) hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 3, 0>), grid, block, 0, st, a);
         else if (xp == 4) hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 4, 0>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 5, 0>), grid, block, 0, st, a);
