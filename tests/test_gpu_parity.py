@@ -204,10 +204,11 @@ def test_conv_v7_grid_sweep(dev, monkeypatch):
     """the same problem under different block counts (different K splits, down to whole tiles): every split sums the same
     products in fp32, so the results agree to accumulation-order noise and each one is inside the conv tolerance"""
     outs = []
-    for grid in ("-1", "-2", "7", "24", "61"):
+    for grid, gc in (("-1", "1"), ("-2", "1"), ("7", "1"), ("24", "2"), ("61", "1"), ("-1", "2"), ("-2", "2"), ("0", "4")):   # "4" does not divide the 2 filter tiles: ignored
         monkeypatch.setenv("Y3_V7_GRID", grid)
+        monkeypatch.setenv("Y3_V7_GC", gc)   # filter-tile ranges per XCD group (the rectangle a group of blocks owns)
         out, ref = run_conv(dev, torch.float16, 4, 20, 20, 256, 512, 3, 1, algo=1, ws=True, expect="v7", repeat=2, residual=True)
-        _conv_tol_check(f"grid{grid}", torch.float16, out, ref)
+        _conv_tol_check(f"grid{grid} gc{gc}", torch.float16, out, ref)
         outs.append(out)
     for o in outs[1:]:
         assert (o - outs[0]).abs().max().item() <= 2.0**-9 * max(1.0, outs[0].abs().max().item())

@@ -59,6 +59,7 @@ struct ConvArgs {
     void* ws;      // scratch of the persistent stream-K kernel (conv_v7.h): control words, arrival flags, fp32 partial tiles; may be null
     size_t ws_bytes;
     int v7_whole;  // conv_v7.h: blocks own whole tiles (no stream-K split)
+    int v7_gc;     // conv_v7.h: filter-tile ranges per XCD group (1, 2, 4 or 8; divides n_ct)
 #ifdef Y3_TIMELINE  // debug build only (tools/timeline.py): per-block wall-clock stamps
     unsigned long long* tl;
 #endif

@@ -90,10 +90,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p)
     float* slabs = (float*)((char*)p.ws + V7_HDR_BYTES);
 
     // Work assignment.  Blocks take a ticket in START order.  Ticket t belongs to group t % NG (the XCD the dispatcher is
-    // observed to place it on: speed only) and is block t / NG of that group.  A group owns a contiguous range of whole tiles
-    // (ct fastest, so its pixel tiles' patches stay in ITS L2 across the filter tiles); inside a group the (tile, channel block)
-    // units are split evenly over its blocks.  Dependencies never cross groups and only point at EARLIER tickets (see the item
-    // loop), so progress needs no residency assumption.
+    // observed to place it on: speed only) and is block t / NG of that group.  A group owns a rectangle of whole tiles (see
+    // below); inside a group the (tile, channel block) units are split evenly over its blocks.  Dependencies never cross groups
+    // and only point at EARLIER tickets (see the item loop), so progress needs no residency assumption.
     if (tid == 0) *(unsigned*)smem = atomicAdd(&ctl->ticket, 1u);
     __syncthreads();
     const int ticket = __builtin_amdgcn_readfirstlane(*(const unsigned*)smem);
@@ -104,14 +103,20 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p)
     const int xg = ticket % NG, ig = ticket / NG;
     const int nblk = G / NG + (xg < G % NG ? 1 : 0);
     const int ncb = p.cin_blocks;
-    const int tiles = p.n_pt * p.n_ct;
-    const int t0 = (int)((long long)tiles * xg / NG), t1 = (int)((long long)tiles * (xg + 1) / NG);
-    const int Ug = (t1 - t0) * ncb;                       // units of this group
+    // A group's tiles form a rectangle (range of pixel tiles) x (range of filter tiles): gc filter-tile ranges x NG / gc pixel-tile ranges.
+    // The host picks gc to minimise what the 8 private L2s fetch together: filters x (NG / gc) + activations x gc (launch_v7).
+    const int gc = (NG == 8) ? p.v7_gc : 1, gp = NG / gc;
+    const int ctg = xg / gp, ptg = xg - ctg * gp;
+    const int nct_g = p.n_ct / gc;                       // filter tiles of this group (gc divides n_ct)
+    const int ct0 = ctg * nct_g;
+    const int pt0 = (int)((long long)p.n_pt * ptg / gp), pt1 = (int)((long long)p.n_pt * (ptg + 1) / gp);
+    const int gtiles = (pt1 - pt0) * nct_g;               // tiles of this group, filter tile fastest
+    const int Ug = gtiles * ncb;                          // units of this group
     int u_lo = (int)((long long)Ug * ig / nblk);          // this block's range, group-local
     int hi = (int)((long long)Ug * (ig + 1) / nblk);
     if (p.v7_whole) {                                     // whole tiles only: no tile is shared between blocks, no slabs
-        u_lo = (int)((long long)(t1 - t0) * ig / nblk) * ncb;
-        hi = (int)((long long)(t1 - t0) * (ig + 1) / nblk) * ncb;
+        u_lo = (int)((long long)gtiles * ig / nblk) * ncb;
+        hi = (int)((long long)gtiles * (ig + 1) / nblk) * ncb;
     }
 
     const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
@@ -126,8 +131,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p)
         const int cb0 = lo - tl * ncb;
         const int ncbs = hi - lo;
         const bool final_part = hi == (tl + 1) * ncb;     // this item ends the tile's K range: it owns the epilogue (and the bias)
-        const int tile = t0 + tl;
-        const int pt = fdiv(tile, p.dv_ct_mul, p.dv_ct_sh), ct = tile - pt * p.n_ct;
+        const int ptl = tl / nct_g;
+        const int pt = pt0 + ptl, ct = ct0 + (tl - ptl * nct_g);
         const int m0 = pt * 256;
 
         // ---- per-item lane constants (also the tile-independent ones: kept kernel-wide they are what the register allocator spills) ----
@@ -487,6 +492,18 @@ template <typename T> int launch_v7(ConvArgs& a, hipStream_t st) {
     // batches) the split is what puts every CU to work.
     const long long tiles = (long long)a.n_ct * a.n_pt;
     a.v7_whole = tiles >= 64 ? 1 : 0;
+    {   // filter-tile ranges per XCD group: minimise filters x (8 / gc) + activations x gc over the divisors of n_ct
+        const double wbytes = (double)a.Cout * a.Kpad * 2.0, xbytes = (double)a.M * a.Cin * 2.0;
+        int best = 1;
+        double best_cost = wbytes * 8 + xbytes;
+        for (int gc = 2; gc <= 8; gc *= 2) {
+            if (a.n_ct % gc) break;
+            const double cost = wbytes * (8 / gc) + xbytes * gc;
+            if (cost < best_cost) { best = gc; best_cost = cost; }
+        }
+        a.v7_gc = best;
+        if (const char* e = getenv("Y3_V7_GC")) { const int v = atoi(e); if (v >= 1 && v <= 8 && (8 % v) == 0 && (a.n_ct % v) == 0) a.v7_gc = v; }
+    }
     if (const char* e = getenv("Y3_V7_GRID")) {   // A/B knob: N > 0 caps the grid; -1 = whole tiles; -2 = even K split (stream-K) whatever the tile count
         const int g_env = atoi(e);
         if (g_env > 0 && g_env < g) g = g_env;
