@@ -510,7 +510,8 @@ template <typename T> int launch_v7(ConvArgs& a, hipStream_t st) {
         if (g_env == -1) a.v7_whole = 1;
         if (g_env == -2) a.v7_whole = 0;
     }
-    if (a.v7_whole && tiles < g) g = tiles;
+    // (whole-tile mode keeps the full grid even when tiles < CUs: the 8 groups own 24..26 tiles each, a grid cut to the tile count would
+    //  leave a 26-tile group with 25 blocks and double the makespan -- measured 193 vs 115 us)
     const int xp = v7_xp(a.W);
     const dim3 grid((unsigned)g), block(512);
     int sched = 0;   // SCHED 1 measured 2-6 % slower (profiles/r02_conv_v7.md); kept for A/B
