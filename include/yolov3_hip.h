@@ -281,6 +281,15 @@ int y3_detect_raw_bwd(const void* graw, int32_t dtype, int32_t bs, int32_t na, i
 size_t y3_sgd_tensor_record_bytes(void);
 int y3_sgd_step(const void* tensor_table, int32_t n_tensors, int32_t n_chunks, float inv_scale, float max_norm, float momentum,
                 int32_t nesterov, int32_t first_step, float ema_decay, float* scratch, int32_t* found_inf, void* stream);
+/* The same step with the loss scale read from DEVICE memory (1 float), and torch.cuda.amp.GradScaler.update() (reference
+ * train.py:345 `scaler = GradScaler(enabled=amp)`, :416-417 `scaler.step(optimizer); scaler.update()`; ATen _amp_update_scale_):
+ * found_inf -> scale *= backoff_factor, tracker = 0; otherwise ++tracker and at growth_interval: scale *= growth_factor (if finite),
+ * tracker = 0.  No host synchronisation anywhere. */
+int y3_sgd_step_dynamic(const void* tensor_table, int32_t n_tensors, int32_t n_chunks, const float* loss_scale, float max_norm,
+                        float momentum, int32_t nesterov, int32_t first_step, float ema_decay, float* scratch, int32_t* found_inf,
+                        void* stream);
+int y3_loss_scale_update(float* loss_scale, int32_t* growth_tracker, const int32_t* found_inf, float growth_factor,
+                         float backoff_factor, int32_t growth_interval, void* stream);
 
 #ifdef __cplusplus
 }

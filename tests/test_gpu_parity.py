@@ -1003,6 +1003,51 @@ def test_fused_sgd_vs_torch_reference(dev):
     assert opt.found_inf.item() == 1 and all(torch.equal(a, b.detach()) for a, b in zip(before, ps))
 
 
+def test_grad_scaler_dynamic_scale_matches_torch(dev):
+    """optim.GradScaler (device-resident scale, growth counter and found-inf flag; reference train.py:345,411-418) against
+    torch.amp.GradScaler driving torch.optim.SGD on the same gradient sequence: clean steps, an overflow step (skipped, scale
+    halves), growth after `growth_interval` clean steps -- parameters and the scale agree after every step, with no host sync in
+    our loop until the final compare."""
+    from yolov3_amd.optim import FusedSGD, GradScaler
+
+    torch.manual_seed(1)
+    shapes = [(32, 16, 3, 3), (32,), (70001,)]
+    ps = [torch.nn.Parameter(torch.randn(s, device=dev)) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt = FusedSGD(ps, lr=0.05, momentum=0.9, nesterov=True)
+    topt = torch.optim.SGD(ref, lr=0.05, momentum=0.9, nesterov=True)
+    kw = dict(init_scale=2.0**10, growth_factor=2.0, backoff_factor=0.5, growth_interval=2)
+    ours, theirs = GradScaler(**kw), torch.amp.GradScaler("cuda", **kw)
+    scales = []
+    for step in range(7):
+        overflow = step in (2, 5)
+        g = [torch.randn(s, device=dev) for s in shapes]
+        for p, r, gi in zip(ps, ref, g):
+            p.grad = gi * ours._scale if ours._scale is not None else gi * kw["init_scale"]
+            r.grad = gi * theirs.get_scale()
+            if overflow:
+                p.grad.view(-1)[3] = float("inf")
+                r.grad.view(-1)[3] = float("inf")
+        if ours._scale is None:
+            ours._lazy(dev)
+        ours.unscale_(opt)
+        ours.step(opt, max_norm=0.0)
+        ours.update()
+        theirs.step(topt)
+        theirs.update()
+        scales.append((ours._scale.clone(), theirs.get_scale()))
+    torch.cuda.synchronize()
+    for (a, b) in scales:
+        assert a.item() == b, (a.item(), b)
+    assert [b for _, b in scales] == [1024.0, 2048.0, 1024.0, 1024.0, 2048.0, 1024.0, 1024.0]
+    for p, r in zip(ps, ref):
+        torch.testing.assert_close(p.detach(), r.detach(), rtol=1e-5, atol=1e-6)
+    x = torch.ones(3, device=dev, requires_grad=True)
+    assert torch.equal(ours.scale(x.sum()), x.sum() * ours._scale)
+    sd = ours.state_dict()
+    assert sd["scale"] == 1024.0 and sd["growth_interval"] == 2
+
+
 @pytest.mark.parametrize("name,h,w,bs,dtype", [("yolov3", 96, 160, 1, torch.float32), ("yolov3-tiny", 128, 96, 3, torch.float32), ("yolov3-spp", 160, 96, 2, torch.float16)])
 def test_model_rectangular_and_odd_batches(dev, name, h, w, bs, dtype):
     """rect inference (val.py pads batches to rectangles, e.g. 640x512), batch sizes that do not fill a pixel tile,

@@ -6,6 +6,7 @@ Public surface mirrors the reference's own Python signatures:
     non_max_suppression, scale_boxes     (reference utils/general.py; + batched forms)
     process_batch                        (reference val.py:147-188; + batched form)
     ComputeLoss                          (reference utils/loss.py)
+    FusedSGD / GradScaler / ModelEMA     (reference train.py:345,411-422: scaler.scale / unscale_ / clip / step / update / ema.update)
     DetectMultiBackend (.pt branch), attempt_load, AutoShape   (reference models/common.py, models/experimental.py)
 Everything executes through libyolov3_hip.so (include/yolov3_hip.h); there is no CPU/PyTorch fallback.
 """
@@ -16,6 +17,7 @@ from .backend import DetectMultiBackend  # noqa: F401
 from .autoshape import AutoShape, Detections, letterbox_batch  # noqa: F401
 from .compat import attempt_load  # noqa: F401
 from .loss import ComputeLoss  # noqa: F401
+from .optim import FusedSGD, GradScaler, ModelEMA, smart_param_groups  # noqa: F401
 from .yolo import Detect, DetectionModel, Model, parse_model  # noqa: F401
 
 __version__ = "0.1.0"

@@ -31,8 +31,10 @@ __device__ int find_tensor(const OptTensor* __restrict__ t, int n, int chunk) {
 }
 
 // pass 1: sum of squares of the (unscaled) gradients + non-finite detection; one partial per block
-__global__ __launch_bounds__(256) void grad_norm_kernel(const OptTensor* __restrict__ t, int n, float inv_scale, float* __restrict__ partial, int* __restrict__ found_inf) {
+__global__ __launch_bounds__(256) void grad_norm_kernel(const OptTensor* __restrict__ t, int n, float inv_scale, const float* __restrict__ scale_dev,
+                                                          float* __restrict__ partial, int* __restrict__ found_inf) {
     __shared__ float red[256];
+    if (scale_dev) inv_scale *= 1.0f / scale_dev[0];   // dynamic loss scale (GradScaler): lives on the device, no host round trip
     const int ti = find_tensor(t, n, blockIdx.x);
     const OptTensor T = t[ti];
     const long long base = (long long)(blockIdx.x - T.first_chunk) * CHUNK;
@@ -76,9 +78,11 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict_
 }
 
 // pass 2: p, buf, ema update (torch.optim.SGD semantics: g += wd*p; buf = first ? g : mu*buf + g; g = nesterov ? g + mu*buf : buf)
-__global__ __launch_bounds__(256) void sgd_update_kernel(const OptTensor* __restrict__ t, int n, float inv_scale, const float* __restrict__ clip, const int* __restrict__ found_inf,
-                                                           float momentum, int nesterov, int first_step, float ema_decay) {
+__global__ __launch_bounds__(256) void sgd_update_kernel(const OptTensor* __restrict__ t, int n, float inv_scale, const float* __restrict__ scale_dev,
+                                                           const float* __restrict__ clip, const int* __restrict__ found_inf, float momentum, int nesterov, int first_step,
+                                                           float ema_decay) {
     if (*found_inf) return;  // GradScaler.step skips the update when any gradient is inf/nan
+    if (scale_dev) inv_scale *= 1.0f / scale_dev[0];
     const int ti = find_tensor(t, n, blockIdx.x);
     const OptTensor T = t[ti];
     const long long base = (long long)(blockIdx.x - T.first_chunk) * CHUNK;
@@ -98,22 +102,62 @@ __global__ __launch_bounds__(256) void sgd_update_kernel(const OptTensor* __rest
     }
 }
 
+// torch.cuda.amp.GradScaler.update() (reference train.py:345,416-417; ATen _amp_update_scale_): on a step that found inf/nan the scale
+// is multiplied by backoff_factor and the growth counter reset; otherwise the counter advances and every growth_interval clean steps
+// the scale is multiplied by growth_factor (unless that overflows fp32).  All on the device.
+__global__ void loss_scale_update_kernel(float* __restrict__ scale, int* __restrict__ growth_tracker, const int* __restrict__ found_inf, float growth_factor,
+                                         float backoff_factor, int growth_interval) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (*found_inf) {
+        *scale = *scale * backoff_factor;
+        *growth_tracker = 0;
+    } else {
+        const int successful = *growth_tracker + 1;
+        if (successful == growth_interval) {
+            const float grown = *scale * growth_factor;
+            if (fabsf(grown) <= 3.402823466e38f) *scale = grown;
+            *growth_tracker = 0;
+        } else {
+            *growth_tracker = successful;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" size_t y3_sgd_tensor_record_bytes(void) { return sizeof(OptTensor); }
 
-extern "C" int y3_sgd_step(const void* tensor_table, int32_t n_tensors, int32_t n_chunks, float inv_scale, float max_norm, float momentum, int32_t nesterov,
-                           int32_t first_step, float ema_decay, float* scratch /* n_chunks + 2 floats */, int32_t* found_inf, void* stream) {
+static int sgd_step_impl(const void* tensor_table, int32_t n_tensors, int32_t n_chunks, float inv_scale, const float* scale_dev, float max_norm, float momentum,
+                         int32_t nesterov, int32_t first_step, float ema_decay, float* scratch, int32_t* found_inf, void* stream) {
     if (!tensor_table || !scratch || !found_inf || n_tensors <= 0 || n_chunks <= 0) Y3_FAIL("y3_sgd_step: bad argument");
     hipStream_t st = (hipStream_t)stream;
     const OptTensor* t = (const OptTensor*)tensor_table;
     Y3_HIP(hipMemsetAsync(found_inf, 0, sizeof(int), st));
-    hipLaunchKernelGGL(grad_norm_kernel, dim3((unsigned)n_chunks), dim3(256), 0, st, t, n_tensors, inv_scale, scratch + 2, found_inf);
+    hipLaunchKernelGGL(grad_norm_kernel, dim3((unsigned)n_chunks), dim3(256), 0, st, t, n_tensors, inv_scale, scale_dev, scratch + 2, found_inf);
     Y3_CHECK_LAUNCH();
     hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, st, (const float*)(scratch + 2), n_chunks, max_norm, scratch);
     Y3_CHECK_LAUNCH();
-    hipLaunchKernelGGL(sgd_update_kernel, dim3((unsigned)n_chunks), dim3(256), 0, st, t, n_tensors, inv_scale, (const float*)scratch, (const int*)found_inf, momentum, nesterov,
-                       first_step, ema_decay);
+    hipLaunchKernelGGL(sgd_update_kernel, dim3((unsigned)n_chunks), dim3(256), 0, st, t, n_tensors, inv_scale, scale_dev, (const float*)scratch, (const int*)found_inf, momentum,
+                       nesterov, first_step, ema_decay);
+    Y3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int y3_sgd_step(const void* tensor_table, int32_t n_tensors, int32_t n_chunks, float inv_scale, float max_norm, float momentum, int32_t nesterov,
+                           int32_t first_step, float ema_decay, float* scratch /* n_chunks + 2 floats */, int32_t* found_inf, void* stream) {
+    return sgd_step_impl(tensor_table, n_tensors, n_chunks, inv_scale, nullptr, max_norm, momentum, nesterov, first_step, ema_decay, scratch, found_inf, stream);
+}
+
+extern "C" int y3_sgd_step_dynamic(const void* tensor_table, int32_t n_tensors, int32_t n_chunks, const float* loss_scale, float max_norm, float momentum, int32_t nesterov,
+                                   int32_t first_step, float ema_decay, float* scratch, int32_t* found_inf, void* stream) {
+    if (!loss_scale) Y3_FAIL("y3_sgd_step_dynamic: null loss scale");
+    return sgd_step_impl(tensor_table, n_tensors, n_chunks, 1.0f, loss_scale, max_norm, momentum, nesterov, first_step, ema_decay, scratch, found_inf, stream);
+}
+
+extern "C" int y3_loss_scale_update(float* loss_scale, int32_t* growth_tracker, const int32_t* found_inf, float growth_factor, float backoff_factor, int32_t growth_interval,
+                                    void* stream) {
+    if (!loss_scale || !growth_tracker || !found_inf || growth_interval < 1) Y3_FAIL("y3_loss_scale_update: bad argument");
+    hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, loss_scale, growth_tracker, found_inf, growth_factor, backoff_factor, growth_interval);
     Y3_CHECK_LAUNCH();
     return 0;
 }

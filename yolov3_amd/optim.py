@@ -85,9 +85,10 @@ class FusedSGD:
                 p.grad = None if set_to_none else (p.grad.zero_() if p.grad is not None else None)
 
     @torch.no_grad()
-    def step(self, grad_scale: float = 1.0, max_norm: float = 0.0, ema: ModelEMA | None = None):
-        """One fused update.  grad_scale: the loss scale the gradients still carry (GradScaler); max_norm: clip_grad_norm_
-        threshold (0 = off; the reference uses 10.0); ema: ModelEMA to update in the same pass."""
+    def step(self, grad_scale=1.0, max_norm: float = 0.0, ema: ModelEMA | None = None):
+        """One fused update.  grad_scale: the loss scale the gradients still carry -- a Python float, or a 1-element DEVICE fp32
+        tensor (GradScaler below: dynamic scale, read by the kernels); max_norm: clip_grad_norm_ threshold (0 = off; the
+        reference uses 10.0); ema: ModelEMA to update in the same pass."""
         recs, n_chunks = [], 0
         dev = None
         for g in self.param_groups:
@@ -117,12 +118,79 @@ class FusedSGD:
         tab, scratch, found = self._dev_bufs
         tab[: host.numel()].copy_(host, non_blocking=True)
         d = ema.next_decay() if ema is not None else 0.0
-        _lib.check(
-            L.y3_sgd_step(tab.data_ptr(), len(recs), n_chunks, 1.0 / float(grad_scale), float(max_norm), float(self.momentum), int(self.nesterov), int(self._steps == 0),
-                          float(d), scratch.data_ptr(), found.data_ptr(), ops.stream_ptr()),
-            "y3_sgd_step",
-        )
+        if isinstance(grad_scale, torch.Tensor):
+            if grad_scale.dtype != torch.float32 or grad_scale.numel() != 1 or grad_scale.device != dev:
+                raise TypeError("a dynamic loss scale must be a 1-element fp32 tensor on the parameters' device")
+            _lib.check(
+                L.y3_sgd_step_dynamic(tab.data_ptr(), len(recs), n_chunks, grad_scale.data_ptr(), float(max_norm), float(self.momentum), int(self.nesterov),
+                                      int(self._steps == 0), float(d), scratch.data_ptr(), found.data_ptr(), ops.stream_ptr()),
+                "y3_sgd_step_dynamic",
+            )
+        else:
+            _lib.check(
+                L.y3_sgd_step(tab.data_ptr(), len(recs), n_chunks, 1.0 / float(grad_scale), float(max_norm), float(self.momentum), int(self.nesterov), int(self._steps == 0),
+                              float(d), scratch.data_ptr(), found.data_ptr(), ops.stream_ptr()),
+                "y3_sgd_step",
+            )
         if ema is not None:
             ema.update_buffers(d)
         self._steps += 1
         self.last_norm, self.found_inf = scratch[0:1], found  # device tensors; reading them is the caller's (optional) sync
+
+
+class GradScaler:
+    """torch.cuda.amp.GradScaler for the fused optimizer (reference train.py:345 `scaler = torch.cuda.amp.GradScaler(enabled=amp)`,
+    :411 `scaler.scale(loss).backward()`, :414-418 `unscale_ / clip_grad_norm_ / step / update`).  The scale, the growth counter and
+    the found-inf flag live on the device: `step` hands the scale tensor to the fused kernels (unscale + inf check + clip + SGD +
+    EMA in one pass), `update` is one tiny launch -- the loop never synchronises with the host.  Defaults are torch's."""
+
+    def __init__(self, init_scale=2.0**16, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, enabled=True, device=None):
+        self.enabled = enabled
+        self.growth_factor, self.backoff_factor, self.growth_interval = float(growth_factor), float(backoff_factor), int(growth_interval)
+        self._init_scale, self._device = float(init_scale), device
+        self._scale = self._tracker = None
+        self._found = None
+
+    def _lazy(self, device):
+        if self._scale is None:
+            self._scale = torch.full((1,), self._init_scale, dtype=torch.float32, device=device)
+            self._tracker = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def scale(self, loss: torch.Tensor) -> torch.Tensor:
+        if not self.enabled:
+            return loss
+        self._lazy(loss.device)
+        return loss * self._scale.to(loss.dtype)
+
+    def unscale_(self, optimizer):
+        """no separate pass: FusedSGD.step unscales, checks for inf/nan and clips in the same kernels (kept for API parity)"""
+
+    def step(self, optimizer: FusedSGD, max_norm: float = 0.0, ema: ModelEMA | None = None):
+        if not self.enabled:
+            return optimizer.step(1.0, max_norm, ema)
+        p0 = next(p for g in optimizer.param_groups for p in g["params"])
+        self._lazy(p0.device)
+        optimizer.step(self._scale, max_norm, ema)
+        self._found = optimizer.found_inf
+
+    def update(self):
+        if not self.enabled or self._found is None:
+            return
+        _lib.check(_lib.lib().y3_loss_scale_update(self._scale.data_ptr(), self._tracker.data_ptr(), self._found.data_ptr(), self.growth_factor, self.backoff_factor,
+                                                   self.growth_interval, ops.stream_ptr()), "y3_loss_scale_update")
+        self._found = None
+
+    def get_scale(self) -> float:
+        """host read (synchronises): for logging / checkpoints only"""
+        return float(self._scale.item()) if self._scale is not None else self._init_scale
+
+    def state_dict(self):
+        return {"scale": self.get_scale(), "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor, "growth_interval": self.growth_interval,
+                "_growth_tracker": int(self._tracker.item()) if self._tracker is not None else 0}
+
+    def load_state_dict(self, sd):
+        self._init_scale = float(sd["scale"])
+        self.growth_factor, self.backoff_factor, self.growth_interval = float(sd["growth_factor"]), float(sd["backoff_factor"]), int(sd["growth_interval"])
+        if self._scale is not None:
+            self._scale.fill_(self._init_scale)
+            self._tracker.fill_(int(sd.get("_growth_tracker", 0)))
