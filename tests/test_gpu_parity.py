@@ -1021,6 +1021,7 @@ def test_grad_scaler_dynamic_scale_matches_torch(dev):
     scales = []
     for step in range(7):
         overflow = step in (2, 5)
+        theirs.scale(torch.ones(1, device=dev))   # torch initialises its scale tensor lazily in scale()
         g = [torch.randn(s, device=dev) for s in shapes]
         for p, r, gi in zip(ps, ref, g):
             p.grad = gi * ours._scale if ours._scale is not None else gi * kw["init_scale"]
