@@ -154,19 +154,21 @@ def run_train(args, rank, world, dev, parallel, yo, batch, steps, warmup):
     crit = ComputeLoss(model)
     # the reference's optimizer step (train.py:414-422): unscale_ + clip_grad_norm_(10) + SGD(nesterov, 3 param groups) + EMA (rank 0),
     # here the fused 3-launch kernel; weight decay scaled by total batch / 64 (train.py:236-237)
-    from yolov3_amd.optim import FusedSGD, ModelEMA, smart_param_groups
+    from yolov3_amd.optim import FusedSGD, GradScaler, ModelEMA, smart_param_groups
 
     opt = FusedSGD(smart_param_groups(model, 0.01, 5e-4 * bs * world / 64), momentum=0.937, nesterov=True)
     ema = ModelEMA(model) if rank == 0 else None
+    scaler = GradScaler(init_scale=1024.0)   # train.py:345; dynamic scale, growth counter and found-inf flag stay on the device
     x = torch.rand(bs, 3, hw, hw, generator=torch.Generator().manual_seed(rank)).to(dev)
     tg = yo.synth_targets(bs, args.nc, seed=1 + rank).to(dev)
-    scale = 1024.0
 
-    def step():
+    def step():   # train.py:402-422
         with torch.autocast("cuda", dtype=torch.float16 if args.dtype == "fp16" else torch.bfloat16):
             loss, _ = crit(model(x), tg)
-        (loss * scale * world).backward()  # loss *= WORLD_SIZE (train.py:406): DDP averages, the reference wants the sum
-        opt.step(grad_scale=scale, max_norm=10.0, ema=ema)
+        scaler.scale(loss * world).backward()  # loss *= WORLD_SIZE (train.py:406): DDP averages, the reference wants the sum
+        scaler.unscale_(opt)
+        scaler.step(opt, max_norm=10.0, ema=ema)   # unscale + inf check + clip_grad_norm_(10) + SGD(nesterov) + EMA, fused
+        scaler.update()
         opt.zero_grad(set_to_none=True)
         return loss
 
@@ -191,7 +193,7 @@ def run_train(args, rank, world, dev, parallel, yo, batch, steps, warmup):
         "vs_baseline": None, "dtype": "f16" if args.dtype == "fp16" else "bf16", "data": "synthetic (seeded uniform images, Poisson(7) targets/img; random-init weights)",
         "config": {"workload": f"{args.model} train step {hw}x{hw} batch={bs}/GPU autocast {args.dtype}: fwd (batch-stat BN) + ComputeLoss + bwd + grad all-reduce + fused unscale/clip/SGD-nesterov/EMA [BASELINE configs[2]]",
                    "global_batch": world * bs, "parallelism": f"dp{world} (bucketed all-reduce overlapped with backward)"},
-        "final_loss": float(loss),
+        "final_loss": float(loss.detach()), "loss_scale": scaler.get_scale(),
         "roofline": {"bound": "mfma", "achieved": round(tflops, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / MFMA_PEAK_TFLOPS, 4),
                      "whole_step_frac": round(tflops / MFMA_PEAK_TFLOPS, 4), "gflop_per_image": round(flops_img / 1e9, 2),
                      "note": "whole step (fwd + dgrad + wgrad conv FLOPs per GPU / step time); kernel shares from the committed profile",
