@@ -1448,6 +1448,8 @@ def test_reference_checkpoint_fixture_runs_on_gpu(dev, golden_dir):
     gold = torch.load(golden_dir / "ref_tiny_w025_eval.pt")
     x = torch.rand(2, 3, 96, 160, generator=torch.Generator().manual_seed(9))
     assert checksum(x) == gold["x_sum"]
+    from yolov3_amd import compat
+
     m32 = DetectMultiBackend(str(golden_dir / "ref_tiny_w025_fp16.pt"), device=dev, fp16=False)
     assert not any(".bn." in k for k in m32.model.state_dict()) and m32.stride == 32 and m32.names[3] == "c3"
     y = m32(x.to(dev))
@@ -1456,6 +1458,7 @@ def test_reference_checkpoint_fixture_runs_on_gpu(dev, golden_dir):
     m16 = DetectMultiBackend(str(golden_dir / "ref_tiny_w025_fp16.pt"), device=dev, fp16=True)
     y16 = m16(x.to(dev))   # fp32 images are cast to half like the reference's forward does (models/common.py:650-651)
     assert y16[0].dtype == torch.float16
+    compat.uninstall_aliases()
     for lvl, (a, b) in enumerate(zip(y16[1], gold["raw"])):
         rms, mx, corr = _rel_errors(a.float().cpu(), b)
         assert rms < HALF_BOUNDS[torch.float16]["rms"] and corr > 0.9999, (lvl, rms, mx, corr)

@@ -70,7 +70,10 @@ def test_reference_checkpoint_fixture_loads_without_the_reference(golden_dir):
     state dict must reproduce the reference's own eval output stored next to it."""
     from yolov3_amd import DetectionModel, compat
 
-    m = compat.attempt_load(golden_dir / "ref_tiny_w025_fp16.pt", device="cpu", fuse=False)
+    try:
+        m = compat.attempt_load(golden_dir / "ref_tiny_w025_fp16.pt", device="cpu", fuse=False)
+    finally:
+        compat.uninstall_aliases()   # the live-reference tests of this session import the real `models` package
     gold = torch.load(golden_dir / "ref_tiny_w025_eval.pt")
     assert type(m) is DetectionModel and not m.training and next(m.parameters()).dtype == torch.float32
     assert sum(p.numel() for p in m.parameters()) == gold["n_params"] and [float(s) for s in m.stride] == gold["stride"]

@@ -41,6 +41,14 @@ def install_aliases(force: bool = False) -> bool:
     return True
 
 
+def uninstall_aliases():
+    """remove the alias modules again (a process that later imports a real reference checkout must not find them: the live-reference
+    tests share a pytest session with the checkpoint-fixture tests)"""
+    for name in ("models.experimental", "models.common", "models.yolo", "models"):
+        if getattr(sys.modules.get(name), "_yolov3_amd_alias", False):
+            del sys.modules[name]
+
+
 def _adopt(model: nn.Module) -> nn.Module:
     """Normalise an unpickled reference model: swap torch's parameter-free layers for the engine's stand-ins and
     add the attributes newer code expects (mirrors the compatibility loop of models/experimental.py:115-124)."""
