@@ -1351,6 +1351,7 @@ def test_detect_batches_overlapped_equals_sequential(dev):
 
 
 PAIR_CASES = [
+    ("many_tiles_per_block", (13, 320, 352), torch.float16, 1.0),   # 13 * 40 * 6 = 3120 tiles > 512 persistent blocks: the grid-stride loop and its prefetch
     ("square", (2, 64, 64), torch.float16, 1.0),
     ("odd_rect", (1, 37, 53), torch.float16, 1.0),
     ("wide_multi_tile", (3, 96, 160), torch.float16, 1.0),
@@ -1365,7 +1366,8 @@ PAIR_CASES = [
 def test_stem_pair_vs_fp32_reference(dev, dtype, name, shape, sdt, div):
     """y3_stem_pair_fwd (layers 0 + 1 of yolov3 in one kernel, layer 0 kept in LDS) against torch fp32 convolutions on the same
     rounded operands, layer 0's output rounded to the storage dtype in between as the unfused path stores it; borders (layer 1's
-    zero padding applies to layer 0's OUTPUT), odd sizes, images smaller than a tile, uint8 / fp32 sources."""
+    zero padding applies to layer 0's OUTPUT), odd sizes, images smaller than a tile, uint8 / fp32 sources, more tiles than
+    persistent blocks."""
     _lib, ops = _ops()
     n, h, w = shape
     g = torch.Generator().manual_seed(11)

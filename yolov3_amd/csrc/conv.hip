@@ -213,29 +213,31 @@ Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MP], unsigned cha
         if (has_res) rres[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, ok ? (unsigned)(spx * p.rpitch + c) * 2u : OOB, 0, 0);
     }
 
-    auto stash = [&](auto silu) {   // activation + filter-pair swap + 16-byte chunk into the slice
+    // activation on whole accumulators (straight-line transcendentals + packed fp32, y3_common.h), pairs of consecutive filters rounded to T
+    // by one v_cvt_pk each, THEN the halves of the packed registers swapped between the lane halves: per accumulator 8 conversions and
+    // 8 swaps instead of 16 + 16 + 8 packs (the epilogue is VALU work in series with the block's K loop)
+    auto stash = [&](auto silu) {
 #pragma unroll
         for (int a = 0; a < MC; ++a)
 #pragma unroll
-            for (int gp = 0; gp < 2; ++gp)
+            for (int b = 0; b < MP; ++b)
 #pragma unroll
-                for (int b = 0; b < MP; ++b) {
-                    vec8 ov;
+                for (int gp = 0; gp < 2; ++gp) {
+                    f32x8 v;   // filters 16gp + 4fk + (0..3) and 16gp + 8 + 4fk + (0..3)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float t0 = acc[a][b][8 * gp + q];        // filter 16gp + 4fk + q
-                        float t1 = acc[a][b][8 * gp + 4 + q];    // filter 16gp + 8 + 4fk + q
-                        if (decltype(silu)::value) {
-                            t0 = t0 * __builtin_amdgcn_rcpf(1.0f + __expf(-t0));
-                            t1 = t1 * __builtin_amdgcn_rcpf(1.0f + __expf(-t1));
-                        }
-                        const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, t0), __builtin_bit_cast(unsigned, t1), false, false);
-                        ov[q] = from_f32<T>(__builtin_bit_cast(float, (unsigned)sw[0]));
-                        ov[4 + q] = from_f32<T>(__builtin_bit_cast(float, (unsigned)sw[1]));
+                    for (int q = 0; q < 8; ++q) v[q] = acc[a][b][8 * gp + q];
+                    if (decltype(silu)::value) silu_vec<f32x8, 8>(v);
+                    u32x4 ov;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(pack2<T>(v[2 * h], v[2 * h + 1]), pack2<T>(v[4 + 2 * h], v[4 + 2 * h + 1]), false, false);
+                        ov[h] = (unsigned)sw[0];
+                        ov[2 + h] = (unsigned)sw[1];
                     }
                     const int pl = b * 32 + frow;
                     const int chunk = a * 4 + gp * 2 + fk;
-                    *(vec8*)(wl + pl * RB + ((chunk ^ swz<MC * 32>(pl)) << 4)) = ov;
+                    *(u32x4*)(wl + pl * RB + ((chunk ^ swz<MC * 32>(pl)) << 4)) = ov;
+                    __builtin_amdgcn_sched_barrier(0);   // eight values at a time: the temporaries stay at 8 registers
                 }
     };
     if (p.act == Y3_ACT_SILU) stash(std::true_type{}); else stash(std::false_type{});
@@ -254,10 +256,12 @@ Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MP], unsigned cha
 #pragma unroll
             for (int q = 0; q < 8; ++q) { const float f = to_f32<T>(ov[q]); st0[q] += f; st1[q] += f * f; }
         }
-        if (has_res) {
+        if (has_res) {   // x + cv2(cv1(x)) in fp32, rounded once (what torch's half add does)
             const vec8 rr = __builtin_bit_cast(vec8, rres[i]);
+            u32x4 sum;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) ov[q] = from_f32<T>(to_f32<T>(ov[q]) + to_f32<T>(rr[q]));
+            for (int q = 0; q < 8; q += 2) sum[q >> 1] = pack2<T>(to_f32<T>(ov[q]) + to_f32<T>(rr[q]), to_f32<T>(ov[q + 1]) + to_f32<T>(rr[q + 1]));
+            ov = __builtin_bit_cast(vec8, sum);
         }
         const u32x4 raw = __builtin_bit_cast(u32x4, ov);
         if (!p.ups) {

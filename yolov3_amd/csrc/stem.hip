@@ -121,6 +121,10 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemArgs p) {
             for (int a = 0; a < MC; ++a) acc[a] = Mfma16<T>::run(af[a][kh], bf, acc[a]);
         }
         // ---- activation, filter-pair swap (8 consecutive filters per lane), transpose through the wave's slice ----
+        if (p.act == Y3_ACT_SILU) {
+#pragma unroll
+            for (int a = 0; a < MC; ++a) silu_vec<f32x16, 16>(acc[a]);
+        }
 #pragma unroll
         for (int a = 0; a < MC; ++a)
 #pragma unroll
@@ -128,11 +132,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemArgs p) {
                 frag ov;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float t0 = acc[a][8 * gp + q], t1 = acc[a][8 * gp + 4 + q];
-                    if (p.act == Y3_ACT_SILU) {
-                        t0 = t0 * __builtin_amdgcn_rcpf(1.0f + __expf(-t0));
-                        t1 = t1 * __builtin_amdgcn_rcpf(1.0f + __expf(-t1));
-                    }
+                    const float t0 = acc[a][8 * gp + q], t1 = acc[a][8 * gp + 4 + q];
                     const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, t0), __builtin_bit_cast(unsigned, t1), false, false);
                     ov[q] = from_f32<T>(__builtin_bit_cast(float, (unsigned)sw[0]));
                     ov[4 + q] = from_f32<T>(__builtin_bit_cast(float, (unsigned)sw[1]));
@@ -176,45 +176,79 @@ struct PairArgs {
     int N, Cin, H, W, Ho, Wo, ypitch, act0, act1, kpad1;
     int tiles_w, tiles_h, n_tiles;
     float divisor;
+#ifdef Y3_TIMELINE
+    unsigned long long* tl;
+#endif
 };
+#ifdef Y3_TIMELINE   // debug build (tools/stem_probe.py): per-wave tick sums of the phases of a tile
+static unsigned long long* g_pair_tl = nullptr;
+#define SP_T(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tsum[i] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define SP_T(i) do { } while (0)
+#endif
 constexpr int QR = 4, QW = 32;                    // layer-1 output rows x columns per tile
 constexpr int R0 = 2 * QR + 1, C0 = 2 * QW + 1;   // layer-0 pixels needed: 9 x 65
 constexpr int XR = R0 + 2, XW = C0 + 3;           // image patch: one halo row/column each side + the 4th pixel of the widest fragment read
-constexpr int L0P = 80;                           // bytes per layer-0 pixel row in LDS (64 + 16: stride-2 fragment reads spread over the banks)
+// layer-0 pixels in LDS: 64 bytes (32 channels) each; a region row holds its 33 even columns, then its 32 odd columns, so the
+// stride-2 fragment reads of layer 1 (columns 2 c + kw) walk CONSECUTIVE 64-byte pixels of one parity; the four 16-byte channel
+// chunks of pixel i sit at chunk ^ ((i >> 2) & 3): the 16 lanes of a ds_read_b128 pass then touch 16 different 16-byte bank slots
+constexpr int L0E = C0 / 2 + 1, L0ROW = C0 * 64;  // even pixels per row, bytes per region row
 
 template <typename T, typename S>
 __global__ __launch_bounds__(256, 2) void stem_pair_kernel(const PairArgs p) {
     typedef typename Mfma16<T>::frag frag;
     typedef T vec4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     constexpr int PATCH_BYTES = XR * XW * 8, SLICE_BYTES = 4 * 32 * 64;
     constexpr int SCR = PATCH_BYTES > SLICE_BYTES ? PATCH_BYTES : SLICE_BYTES;   // the output slices reuse the patch (dead after layer 0)
     __shared__ __attribute__((aligned(16))) unsigned char scratch[SCR];
-    __shared__ __attribute__((aligned(16))) unsigned char l0buf[R0 * C0 * L0P];
+    __shared__ __attribute__((aligned(16))) unsigned char l0buf[R0 * L0ROW];
+    __shared__ __attribute__((aligned(16))) unsigned char cw0[32 * 48 * 2];
+    __shared__ __attribute__((aligned(16))) float cb0[32], cb1[64];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 31, fk = lane >> 5;
     const int wc = wv >> 1, wp = wv & 1;   // layer 1: filter tile, row pair
 
-    // ---- per-block constants: layer-0 fragments + bias, this wave's 18 layer-1 fragments + bias ----
-    frag a0f[3];
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh) a0f[kh] = *(const frag*)((const T*)p.w0 + (frow * 3 + kh) * 16 + fk * 8);
-    f32x4 bz0[4], bz1[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        bz0[g] = *(const f32x4*)(p.b0 + 8 * g + 4 * fk);
-        bz1[g] = *(const f32x4*)(p.b1 + wc * 32 + 8 * g + 4 * fk);
-    }
+    // ---- per-block constants.  Layer-0 filters (3 KB) and both bias vectors live in LDS and are re-read where they are used (44 VGPRs
+    // if held for the block's life; the LDS pipe has room, the register file does not) ----
+    for (int i = tid; i < 32 * 48 * 2 / 16; i += 256) ((f32x4*)cw0)[i] = ((const f32x4*)p.w0)[i];
+    if (tid < 8) ((f32x4*)cb0)[tid] = ((const f32x4*)p.b0)[tid];
+    else if (tid < 24) ((f32x4*)cb1)[tid - 8] = ((const f32x4*)p.b1)[tid - 8];
     frag a1f[18];
 #pragma unroll
     for (int t = 0; t < 18; ++t) a1f[t] = *(const frag*)((const T*)p.w1 + (long long)(wc * 32 + frow) * p.kpad1 + t * 16 + fk * 8);
 
+    // The kernel is bound by VALU issue (SiLU = two quarter-rate transcendentals per value; profiles/r02_stem_pair.md), so everything a
+    // lane can know before the tile loop is computed here once: its patch pixels, and for each of its layer-0 MFMA tiles the patch
+    // read offset, the l0buf write offset and the region coordinates.
+    constexpr int NPX = (XR * XW + 255) / 256;
+    int prc[NPX];            // patch pixel (row << 8 | column) of this thread's j-th element, -1 = none
+#pragma unroll
+    for (int j = 0; j < NPX; ++j) {
+        const int e = tid + j * 256;
+        const int pr = e / XW;
+        prc[j] = e < XR * XW ? (pr << 8) | (e - pr * XW) : -1;
+    }
+    constexpr int NT0 = (R0 * C0 + 31) / 32, NJ0 = (NT0 + 3) / 4;   // layer-0 MFMA tiles per region, per wave
+    int l0rd[NJ0], l0wr[NJ0], l0rc[NJ0];   // l0wr < 0: the lane's pixel lies beyond the region (last tile)
+#pragma unroll
+    for (int j = 0; j < NJ0; ++j) {
+        int q = (wv + 4 * j) * 32 + frow;
+        const bool live = q < R0 * C0;
+        if (!live) q = R0 * C0 - 1;
+        const int r = q / C0, c = q - r * C0, ci = c >> 1;
+        l0rd[j] = (r * XW + c + 2 * fk) * 8;
+        l0wr[j] = live ? r * L0ROW + ((c & 1) ? L0E * 64 : 0) + ci * 64 + ((fk ^ ((ci >> 2) & 3)) << 4) : -1;
+        l0rc[j] = (r << 8) | c;
+    }
+    const int hw = p.H * p.W;
+
     T* __restrict__ yg = (T*)p.y;
     // image patch of a tile: every thread owns up to 3 patch pixels (x 3-4 channels).  The loads of tile i+1 are issued before
-    // layer 1 of tile i runs and land in registers behind its MFMAs (a block's phases are a serial chain and only two blocks fit a
-    // CU: without the prefetch every tile started with a full HBM round trip, 11 us per tile)
-    constexpr int NPX = (XR * XW + 255) / 256;
+    // layer 1 of tile i runs and land in registers behind its MFMAs (a block's phases are a serial chain: without the prefetch every
+    // tile started with a full HBM round trip, 11 us per tile)
     S raw[NPX][4];
     bool rin[NPX];
     auto fetch = [&](int tile) {
@@ -222,22 +256,21 @@ __global__ __launch_bounds__(256, 2) void stem_pair_kernel(const PairArgs p) {
         const int tw = b % p.tiles_w; b /= p.tiles_w;
         const int th = b % p.tiles_h;
         const int n = b / p.tiles_h;
-        const int gh0 = 2 * th * QR - 1, gw0 = 2 * tw * QW - 1;
-        const S* __restrict__ xs = (const S*)p.x + (long long)n * p.Cin * p.H * p.W;
+        const int gh0 = 2 * th * QR - 2, gw0 = 2 * tw * QW - 2;   // image coordinates of patch pixel (0, 0)
+        const S* __restrict__ xs = (const S*)p.x + (long long)n * p.Cin * hw;
 #pragma unroll
         for (int j = 0; j < NPX; ++j) {
-            const int e = tid + j * 256;
-            const int pr = e / XW, pc = e - pr * XW;
-            const int gh = gh0 + pr - 1, gw = gw0 + pc - 1;
-            rin[j] = e < XR * XW && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W;
+            const int gh = gh0 + (prc[j] >> 8), gw = gw0 + (prc[j] & 255);
+            rin[j] = prc[j] >= 0 && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W;
             if (rin[j]) {
-                const long long o = (long long)gh * p.W + gw;
+                const unsigned o = (unsigned)(gh * p.W + gw);   // channel planes of one image: < 2^31 elements (checked on the host)
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
-                    if (c < p.Cin) raw[j][c] = xs[(long long)c * p.H * p.W + o];
+                    if (c < p.Cin) raw[j][c] = xs[o + (unsigned)(c * hw)];
             }
         }
     };
+    const bool plain = std::is_same<S, T>::value && p.divisor == 1.0f;   // the source already holds T values: no convert / divide / convert
     auto stash = [&]() {   // registers -> LDS as 4-channel pixels (channel 3 = 0 unless Cin = 4), zero outside the image
 #pragma unroll
         for (int j = 0; j < NPX; ++j) {
@@ -245,15 +278,30 @@ __global__ __launch_bounds__(256, 2) void stem_pair_kernel(const PairArgs p) {
             if (e < XR * XW) {
                 vec4 v = {(T)0.0f, (T)0.0f, (T)0.0f, (T)0.0f};
                 if (rin[j]) {
+                    bool done = false;
+                    if constexpr (std::is_same<S, T>::value) {
+                        if (plain) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (c < p.Cin) v[c] = from_f32<T>(src_f32<S>(raw[j][c]) / p.divisor);
+                            for (int c = 0; c < 4; ++c)
+                                if (c < p.Cin) v[c] = raw[j][c];
+                            done = true;
+                        }
+                    }
+                    if (!done) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (c < p.Cin) v[c] = from_f32<T>(src_f32<S>(raw[j][c]) / p.divisor);
+                    }
                 }
                 *(vec4*)(scratch + e * 8) = v;
             }
         }
     };
     if ((int)blockIdx.x < p.n_tiles) fetch(blockIdx.x);
+#ifdef Y3_TIMELINE
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#endif
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         int b = tile;
         const int tw = b % p.tiles_w; b /= p.tiles_w;
@@ -261,49 +309,54 @@ __global__ __launch_bounds__(256, 2) void stem_pair_kernel(const PairArgs p) {
         const int n = b / p.tiles_h;
         const int oh0 = th * QR, ow0 = tw * QW;           // layer-1 tile origin
         const int gh0 = 2 * oh0 - 1, gw0 = 2 * ow0 - 1;   // layer-0 (= image) coordinates of region pixel (0, 0)
+        const bool border = gh0 < 0 || gw0 < 0 || gh0 + R0 > p.H || gw0 + C0 > p.W;   // some region pixels are layer 1's zero padding
 
         stash();   // this tile's patch (requested one tile ago)
+        SP_T(0);
         __syncthreads();
+        SP_T(1);
 
         // ---- layer 0 on the 9 x 65 region (flattened, 32 pixels per MFMA tile) -> l0buf[pixel][32 channels] ----
-        for (int t = wv; t < (R0 * C0 + 31) / 32; t += 4) {
-            int q = t * 32 + frow;
-            const bool live = q < R0 * C0;
-            if (!live) q = R0 * C0 - 1;
-            const int r = q / C0, c = q - r * C0;
+#pragma unroll
+        for (int j = 0; j < NJ0; ++j) {
+            if (wv + 4 * j >= NT0) break;
             f32x16 acc;
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[4 * g + e] = bz0[g][e];
+                for (int e = 0; e < 4; ++e) acc[4 * g + e] = cb0[8 * g + 4 * fk + e];
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
-                const unsigned char* src = scratch + (((r + kh) * XW + c + 2 * fk) * 8);
+                const unsigned char* src = scratch + l0rd[j] + kh * (XW * 8);
                 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-                u64x2 raw;
-                raw[0] = *(const unsigned long long*)src;
-                raw[1] = *(const unsigned long long*)(src + 8);
-                acc = Mfma16<T>::run(a0f[kh], __builtin_bit_cast(frag, raw), acc);
+                u64x2 rw;
+                rw[0] = *(const unsigned long long*)src;
+                rw[1] = *(const unsigned long long*)(src + 8);
+                acc = Mfma16<T>::run(*(const frag*)(cw0 + ((frow * 3 + kh) * 16 + fk * 8) * 2), __builtin_bit_cast(frag, rw), acc);
             }
-            const bool inside = live && (unsigned)(gh0 + r) < (unsigned)p.H && (unsigned)(gw0 + c) < (unsigned)p.W;
+            if (p.act0 == Y3_ACT_SILU) silu_vec<f32x16, 16>(acc);
+            bool keep = l0wr[j] >= 0;
+            bool inside = true;
+            if (border) inside = (unsigned)(gh0 + (l0rc[j] >> 8)) < (unsigned)p.H && (unsigned)(gw0 + (l0rc[j] & 255)) < (unsigned)p.W;
+            // round pairs of consecutive filters to T (one v_cvt_pk per pair), THEN swap the register halves between the two lane halves:
+            // a lane ends with 8 consecutive filters of its pixel per 16-byte chunk
 #pragma unroll
             for (int gp = 0; gp < 2; ++gp) {
-                frag ov;
+                u32x4 ov;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float t0 = acc[8 * gp + e], t1 = acc[8 * gp + 4 + e];
-                    if (p.act0 == Y3_ACT_SILU) {
-                        t0 = t0 * __builtin_amdgcn_rcpf(1.0f + __expf(-t0));
-                        t1 = t1 * __builtin_amdgcn_rcpf(1.0f + __expf(-t1));
-                    }
-                    const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, t0), __builtin_bit_cast(unsigned, t1), false, false);
-                    ov[e] = from_f32<T>(inside ? __builtin_bit_cast(float, (unsigned)sw[0]) : 0.0f);
-                    ov[4 + e] = from_f32<T>(inside ? __builtin_bit_cast(float, (unsigned)sw[1]) : 0.0f);
+                for (int h = 0; h < 2; ++h) {
+                    const unsigned a = pack2<T>(acc[8 * gp + 2 * h], acc[8 * gp + 2 * h + 1]);
+                    const unsigned b = pack2<T>(acc[8 * gp + 4 + 2 * h], acc[8 * gp + 4 + 2 * h + 1]);
+                    const auto sw = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+                    ov[h] = inside ? (unsigned)sw[0] : 0u;
+                    ov[2 + h] = inside ? (unsigned)sw[1] : 0u;
                 }
-                if (live) *(frag*)(l0buf + q * L0P + (gp * 2 + fk) * 16) = ov;
+                if (keep) *(u32x4*)(l0buf + (l0wr[j] ^ (gp << 5))) = ov;
             }
         }
+        SP_T(2);
         __syncthreads();
+        SP_T(3);
         if (tile + (int)gridDim.x < p.n_tiles) fetch(tile + gridDim.x);   // next tile's image loads fly under layer 1
 
         // ---- layer 1: D[32 filters of tile wc][32 columns] for rows 2 wp and 2 wp + 1, K = 9 taps x 32 channels out of l0buf ----
@@ -313,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void stem_pair_kernel(const PairArgs p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc1[b2][4 * g + e] = bz1[g][e];
+                for (int e = 0; e < 4; ++e) acc1[b2][4 * g + e] = cb1[wc * 32 + 8 * g + 4 * fk + e];
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int kh = tap / 3, kw = tap - 3 * (tap / 3);
@@ -322,31 +375,35 @@ __global__ __launch_bounds__(256, 2) void stem_pair_kernel(const PairArgs p) {
 #pragma unroll
                 for (int b2 = 0; b2 < 2; ++b2) {
                     const int lr = 2 * wp + b2;
-                    const frag bf = *(const frag*)(l0buf + ((2 * lr + kh) * C0 + 2 * frow + kw) * L0P + (ks * 2 + fk) * 16);
+                    const int ci = frow + (kw >> 1);
+                    const frag bf = *(const frag*)(l0buf + (2 * lr + kh) * L0ROW + ((kw & 1) ? L0E * 64 : 0) + ci * 64 + (((ks * 2 + fk) ^ ((ci >> 2) & 3)) << 4));
                     acc1[b2] = Mfma16<T>::run(a1f[tap * 2 + ks], bf, acc1[b2]);
                 }
         }
+        SP_T(4);
         // ---- activation, 8 consecutive filters per lane, transpose through the wave's slice, 64-byte runs per pixel ----
         unsigned char* wl = scratch + wv * (32 * 64);
         const int rp = lane >> 2, ch = lane & 3;
+        if (p.act1 == Y3_ACT_SILU) {
+            silu_vec<f32x16, 16>(acc1[0]);
+            silu_vec<f32x16, 16>(acc1[1]);
+        }
+        const long long ybase = ((long long)(n * p.Ho + oh0 + 2 * wp) * p.Wo + ow0) * p.ypitch + wc * 32 + ch * 8;
 #pragma unroll
         for (int b2 = 0; b2 < 2; ++b2) {
 #pragma unroll
             for (int gp = 0; gp < 2; ++gp) {
-                frag ov;
+                u32x4 ov;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float t0 = acc1[b2][8 * gp + e], t1 = acc1[b2][8 * gp + 4 + e];
-                    if (p.act1 == Y3_ACT_SILU) {
-                        t0 = t0 * __builtin_amdgcn_rcpf(1.0f + __expf(-t0));
-                        t1 = t1 * __builtin_amdgcn_rcpf(1.0f + __expf(-t1));
-                    }
-                    const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, t0), __builtin_bit_cast(unsigned, t1), false, false);
-                    ov[e] = from_f32<T>(__builtin_bit_cast(float, (unsigned)sw[0]));
-                    ov[4 + e] = from_f32<T>(__builtin_bit_cast(float, (unsigned)sw[1]));
+                for (int h = 0; h < 2; ++h) {
+                    const unsigned a = pack2<T>(acc1[b2][8 * gp + 2 * h], acc1[b2][8 * gp + 2 * h + 1]);
+                    const unsigned b = pack2<T>(acc1[b2][8 * gp + 4 + 2 * h], acc1[b2][8 * gp + 4 + 2 * h + 1]);
+                    const auto sw = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+                    ov[h] = (unsigned)sw[0];
+                    ov[2 + h] = (unsigned)sw[1];
                 }
                 const int chunk = gp * 2 + fk;
-                *(frag*)(wl + frow * 64 + ((chunk ^ (frow & 3)) << 4)) = ov;
+                *(u32x4*)(wl + frow * 64 + ((chunk ^ (frow & 3)) << 4)) = ov;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -355,15 +412,22 @@ __global__ __launch_bounds__(256, 2) void stem_pair_kernel(const PairArgs p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int pl = i * 16 + rp;
-                const frag ov = *(const frag*)(wl + pl * 64 + ((ch ^ (pl & 3)) << 4));
-                const int ow = ow0 + pl;
-                if (oh < p.Ho && ow < p.Wo) *(frag*)(yg + ((long long)(n * p.Ho + oh) * p.Wo + ow) * p.ypitch + wc * 32 + ch * 8) = ov;
+                const u32x4 ov = *(const u32x4*)(wl + pl * 64 + ((ch ^ (pl & 3)) << 4));
+                if (oh < p.Ho && ow0 + pl < p.Wo) *(u32x4*)(yg + ybase + (long long)(b2 * p.Wo + pl) * p.ypitch) = ov;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();   // the slice is rewritten by the next row
         }
+        SP_T(5);
         __syncthreads();   // scratch (slices) and l0buf are rewritten by the next tile
+        SP_T(6);
     }
+#ifdef Y3_TIMELINE
+    if (p.tl && blockIdx.x < 64 && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p.tl[(blockIdx.x * 4 + wv) * 8 + i] = tsum[i];
+    }
+#endif
 }
 
 template <typename T>
@@ -438,7 +502,10 @@ extern "C" int y3_stem_conv_fwd(const void* x_nchw, int32_t src_dtype, int32_t n
 }
 
 namespace {
-template <typename T> int dispatch_pair(const PairArgs& a, int sdt, int blocks, hipStream_t st) {
+template <typename T> int dispatch_pair(const PairArgs& a, int sdt, long long tiles, hipStream_t st) {
+    // persistent: 2 blocks per CU, tiles in a grid-stride loop.  (Three blocks per CU -- 168 VGPRs, the per-lane tables spilled -- and a
+    // staggered start of the blocks that share a CU were measured and dropped: the kernel is bound by VALU issue, profiles/r02_stem_pair.md)
+    const int blocks = tiles < 512 ? (int)tiles : 512;
     switch (sdt) {
         case Y3_F16: hipLaunchKernelGGL((stem_pair_kernel<T, f16_t>), dim3((unsigned)blocks), dim3(256), 0, st, a); break;
         case Y3_BF16: hipLaunchKernelGGL((stem_pair_kernel<T, bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, a); break;
@@ -450,6 +517,10 @@ template <typename T> int dispatch_pair(const PairArgs& a, int sdt, int blocks, 
     return 0;
 }
 }  // namespace
+
+#ifdef Y3_TIMELINE
+extern "C" void y3_debug_pair_timeline(void* buf) { g_pair_tl = (unsigned long long*)buf; }
+#endif
 
 extern "C" int y3_stem_pair_fwd(const void* x_nchw, int32_t src_dtype, int32_t n, int32_t cin, int32_t h, int32_t w, float divisor, const void* packed0, const float* bias0,
                                 int32_t act0, const void* packed1, const float* bias1, int32_t act1, int32_t dtype, const y3_tensor* y, void* stream) {
@@ -470,11 +541,13 @@ extern "C" int y3_stem_pair_fwd(const void* x_nchw, int32_t src_dtype, int32_t n
     if (tiles > 0x7fffffffLL) Y3_FAIL("y3_stem_pair_fwd: too many tiles");
     a.n_tiles = (int)tiles;
     a.divisor = divisor;
-    const int blocks = tiles < 512 ? (int)tiles : 512;   // persistent: 2 blocks per CU, tiles in a grid-stride loop
+#ifdef Y3_TIMELINE
+    a.tl = g_pair_tl;
+#endif
     hipStream_t st = (hipStream_t)stream;
     switch (dtype) {
-        case Y3_F16: return dispatch_pair<f16_t>(a, src_dtype, blocks, st);
-        case Y3_BF16: return dispatch_pair<bf16_t>(a, src_dtype, blocks, st);
+        case Y3_F16: return dispatch_pair<f16_t>(a, src_dtype, tiles, st);
+        case Y3_BF16: return dispatch_pair<bf16_t>(a, src_dtype, tiles, st);
     }
     Y3_FAIL("y3_stem_pair_fwd: f16/bf16 compute only");
 }

@@ -12,6 +12,7 @@
 typedef _Float16 f16_t;
 typedef __bf16 bf16_t;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -45,10 +46,39 @@ template <> Y3_DEV f16_t from_f32<f16_t>(float v) { return (f16_t)v; }   // roun
 template <> Y3_DEV bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; } // round-to-nearest-even
 template <> Y3_DEV float from_f32<float>(float v) { return v; }
 
+// two floats -> one register of two T, round-to-nearest-even: a single v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32 on gfx950 (element by
+// element the compiler emits v_cvt + v_cvt + v_pack for f16)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <typename T> Y3_DEV unsigned pack2(float a, float b);
+template <> Y3_DEV unsigned pack2<f16_t>(float a, float b) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, h2));
+}
+template <> Y3_DEV unsigned pack2<bf16_t>(float a, float b) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2));
+}
+
 // round a float through T (what torch does after every elementwise op on a half tensor)
 template <typename T> Y3_DEV float rt(float v) { return to_f32<T>(from_f32<T>(v)); }
 
 Y3_DEV float silu_f32(float v) { return v / (1.0f + __expf(-v)); }
+
+// SiLU on a whole MFMA accumulator in straight-line code: all the v_exp_f32, then all the v_rcp_f32 (quarter-rate transcendentals,
+// two per value: the floor of this op), the rest as packed fp32 (v_pk_mul_f32 / v_pk_add_f32, two values per lane and issue).
+// Written per value under a run-time `if (act == SILU)` the compiler kept one uniform branch per value PAIR: basic blocks of two
+// dependent exp -> add -> rcp -> mul chains with nothing to fill the transcendental latency.
+template <typename V, int N> Y3_DEV void silu_vec(V& a) {
+    V e = a * -1.44269504088896f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) e[i] = __builtin_amdgcn_exp2f(e[i]);
+    e = e + 1.0f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) e[i] = __builtin_amdgcn_rcpf(e[i]);
+    a = a * e;
+}
 
 // rows of per-block partial sums behind the 2*C totals of y3_bn_stats / y3_bn_act_bwd scratch buffers
 #define Y3_BN_PARTIAL_ROWS 512   // (2048 rows measured slower: the partial-row sum grows faster than the reduction gains)
