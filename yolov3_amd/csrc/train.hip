@@ -21,6 +21,31 @@ template <typename T> struct V16 {  // one 16-byte vector of T
 };
 
 Y3_DEV float silu_grad(float z, float s) { return s + z * s * (1.0f - s); }  // d silu(z)/dz with s = sigmoid(z)
+
+// The elementwise BN kernels work on PAIRS of channels: the multiplies / adds / fmas are packed fp32 (v_pk_*: two values per lane and
+// issue), the activation is a template parameter (tested per element at run time it left one uniform branch per element and nothing
+// for the scheduler to fill the transcendental latency with) and 16-bit results are rounded two at a time (v_cvt_pk).  The
+// backward reduction was bound by VALU issue, not HBM: 22 VALU + 2 transcendental instructions per element.
+template <typename T> Y3_DEV f32x2 ld2(const V16<T>& x, int q) { return f32x2{to_f32<T>(x.v[q]), to_f32<T>(x.v[q + 1])}; }
+template <typename T> Y3_DEV void st2(V16<T>& o, int q, f32x2 v) {
+    if constexpr (sizeof(T) == 2) {
+        const unsigned w = pack2<T>(v[0], v[1]);
+        __builtin_memcpy(&o.v[q], &w, 4);
+    } else {
+        o.v[q] = v[0];
+        o.v[q + 1] = v[1];
+    }
+}
+Y3_DEV f32x2 sigmoid2(f32x2 z) {
+    f32x2 e = z * -1.44269504088896f;
+    e[0] = __builtin_amdgcn_exp2f(e[0]);
+    e[1] = __builtin_amdgcn_exp2f(e[1]);
+    e = e + 1.0f;
+    e[0] = __builtin_amdgcn_rcpf(e[0]);
+    e[1] = __builtin_amdgcn_rcpf(e[1]);
+    return e;
+}
+Y3_DEV f32x2 silu_grad2(f32x2 z, f32x2 s) { return s + z * s * (1.0f - s); }
 // v_exp_f32 + v_rcp_f32 (1-2 ulp each): the elementwise BN kernels were VALU-bound on expf() + an IEEE divide per element
 Y3_DEV float sigmoid_fast(float z) { return __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }
 
@@ -34,10 +59,10 @@ bool vec_ok(const y3_tensor* t, int esz) {
 // ------------------------------------------------------------------------------------------------------------------
 // Per-channel reductions over N*H*W.  MODE 0: (sum u, sum u^2).  MODE 1: (sum dz, sum dz*xhat) for the BN+act backward.
 // Thread t owns channel vector (t % CG) on pixel lane (t / CG); CG = C / V (<= 256).
-template <typename T, int MODE>
+template <typename T, int MODE, bool SILU = false>
 __global__ __launch_bounds__(256) void channel_reduce_kernel(const T* __restrict__ u, int upitch, const T* __restrict__ dy, int dpitch, long long M, int C,
                                                                const float* __restrict__ scale, const float* __restrict__ shift,
-                                                               const float* __restrict__ mean, const float* __restrict__ invstd, int act,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                double* __restrict__ sums) {
     constexpr int V = V16<T>::N;
     __shared__ double red[256 * 2];
@@ -49,16 +74,20 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(const T* __restrict
 #pragma unroll
     for (int q = 0; q < V; ++q) a0[q] = a1[q] = 0.0;
     if (pl < PL) {
-        float sc[V], sh[V], mu[V], is[V];
+        f32x2 sc[V / 2], sh[V / 2], mu[V / 2], is[V / 2];
         if (MODE == 1) {
 #pragma unroll
-            for (int q = 0; q < V; ++q) { sc[q] = scale[cg * V + q]; sh[q] = shift[cg * V + q]; mu[q] = mean[cg * V + q]; is[q] = invstd[cg * V + q]; }
+            for (int q = 0; q < V; q += 2) {
+                const int c = cg * V + q;
+                sc[q / 2] = f32x2{scale[c], scale[c + 1]}; sh[q / 2] = f32x2{shift[c], shift[c + 1]};
+                mu[q / 2] = f32x2{mean[c], mean[c + 1]}; is[q / 2] = f32x2{invstd[c], invstd[c + 1]};
+            }
         }
         // fp32 partials over runs of 8 pixels (relative error ~1e-6 per run), flushed into the fp64 accumulators:
         // keeps the fp64 VALU work at 1/8 of the element count
-        float f0[V], f1[V];
+        f32x2 f0[V / 2], f1[V / 2];
 #pragma unroll
-        for (int q = 0; q < V; ++q) f0[q] = f1[q] = 0.0f;
+        for (int q = 0; q < V / 2; ++q) f0[q] = f1[q] = f32x2{0.0f, 0.0f};
         // 4 pixels per trip with all loads issued before the arithmetic (one 16-byte load in flight per thread left the
         // reductions at 1.5-1.8 TB/s), and the NEXT trip's loads issued before this trip's arithmetic (two register sets: with
         // 8 waves per CU the sigmoid / fp64 work of MODE 1 otherwise runs behind an idle memory pipe: 3.4 TB/s);
@@ -80,18 +109,17 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(const T* __restrict
                 if (m0 + j * stride >= M) break;
                 if (MODE == 0) {
 #pragma unroll
-                    for (int q = 0; q < V; ++q) { const float f = to_f32<T>(xs[j].v[q]); f0[q] += f; f1[q] += f * f; }
+                    for (int q = 0; q < V / 2; ++q) { const f32x2 f = ld2<T>(xs[j], 2 * q); f0[q] += f; f1[q] += f * f; }
                 } else {
 #pragma unroll
-                    for (int q = 0; q < V; ++q) {
-                        const float uf = to_f32<T>(xs[j].v[q]);
-                        float dz = to_f32<T>(gs[j].v[q]);
-                        if (act == Y3_ACT_SILU) {
-                            const float z = uf * sc[q] + sh[q];
-                            const float s = sigmoid_fast(z);
-                            dz *= silu_grad(z, s);
+                    for (int q = 0; q < V / 2; ++q) {
+                        const f32x2 uf = ld2<T>(xs[j], 2 * q);
+                        f32x2 dz = ld2<T>(gs[j], 2 * q);
+                        if (SILU) {
+                            const f32x2 z = uf * sc[q] + sh[q];
+                            dz *= silu_grad2(z, sigmoid2(z));
                         }
-                        const float xh = (uf - mu[q]) * is[q];
+                        const f32x2 xh = (uf - mu[q]) * is[q];
                         f0[q] += dz;
                         f1[q] += dz * xh;
                     }
@@ -100,7 +128,9 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(const T* __restrict
         };
         auto flush = [&]() {
 #pragma unroll
-            for (int q = 0; q < V; ++q) { a0[q] += (double)f0[q]; a1[q] += (double)f1[q]; f0[q] = f1[q] = 0.0f; }
+            for (int q = 0; q < V; ++q) { a0[q] += (double)f0[q / 2][q & 1]; a1[q] += (double)f1[q / 2][q & 1]; }
+#pragma unroll
+            for (int q = 0; q < V / 2; ++q) f0[q] = f1[q] = f32x2{0.0f, 0.0f};
         };
         V16<T> xa[4], ga[4], xb[4], gb[4];
         long long m0 = (long long)blockIdx.x * PL + pl;
@@ -116,7 +146,7 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(const T* __restrict
             flush();
         }
 #pragma unroll
-        for (int q = 0; q < V; ++q) { a0[q] += (double)f0[q]; a1[q] += (double)f1[q]; }
+        for (int q = 0; q < V; ++q) { a0[q] += (double)f0[q / 2][q & 1]; a1[q] += (double)f1[q / 2][q & 1]; }
     }
     // reduce over pixel lanes: one channel at a time through LDS (keeps LDS at 4 KiB)
     for (int q = 0; q < V; ++q) {
@@ -213,16 +243,16 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, int C, BnFin
 
 // y = act(u*scale + shift) (+ residual).  Thread (cg, pl) keeps its 8 channels' scale/shift in registers and walks
 // pixels pl, pl+PL*grid, ...: one 16-byte load and store per pixel, no per-element index arithmetic.
-template <typename T>
+template <typename T, bool SILU>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ u, int upitch, const float* __restrict__ scale, const float* __restrict__ shift,
-                                                           const T* __restrict__ res, int rpitch, T* __restrict__ y, int ypitch, long long M, int C, int act) {
+                                                           const T* __restrict__ res, int rpitch, T* __restrict__ y, int ypitch, long long M, int C) {
     constexpr int V = V16<T>::N;
     const int CG = C / V, PL = 256 / CG;
     const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
     if (pl >= PL) return;
-    float sc[V], sh[V];
+    f32x2 sc[V / 2], sh[V / 2];
 #pragma unroll
-    for (int q = 0; q < V; ++q) { sc[q] = scale[cg * V + q]; sh[q] = shift[cg * V + q]; }
+    for (int q = 0; q < V; q += 2) { sc[q / 2] = f32x2{scale[cg * V + q], scale[cg * V + q + 1]}; sh[q / 2] = f32x2{shift[cg * V + q], shift[cg * V + q + 1]}; }
     // (a 4-pixel unroll with all loads issued first measured slower here: 6.2 -> 6.9 ms per batch-64 step)
     for (long long m = (long long)blockIdx.x * PL + pl; m < M; m += (long long)gridDim.x * PL) {
         const V16<T> x = *(const V16<T>*)(u + m * upitch + cg * V);
@@ -230,50 +260,49 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ u
         if (res) r = *(const V16<T>*)(res + m * rpitch + cg * V);
         V16<T> o;
 #pragma unroll
-        for (int q = 0; q < V; ++q) {
-            float z = to_f32<T>(x.v[q]) * sc[q] + sh[q];
-            if (act == Y3_ACT_SILU) z = z * sigmoid_fast(z);
-            if (res) z += to_f32<T>(r.v[q]);
-            o.v[q] = from_f32<T>(z);
+        for (int q = 0; q < V / 2; ++q) {
+            f32x2 z = ld2<T>(x, 2 * q) * sc[q] + sh[q];
+            if (SILU) z = z * sigmoid2(z);
+            if (res) z += ld2<T>(r, 2 * q);
+            st2<T>(o, 2 * q, z);
         }
         *(V16<T>*)(y + m * ypitch + cg * V) = o;
     }
 }
 
 // du = gamma*invstd * (dz - mean(dz) - xhat*mean(dz*xhat));   dz = dy * act'(z).  Same thread mapping as the forward.
-template <typename T>
+template <typename T, bool SILU>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restrict__ u, int upitch, const T* __restrict__ dy, int dpitch,
                                                                  const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
                                                                  const float* __restrict__ invstd, const double* __restrict__ sums, double count,
-                                                                 T* __restrict__ du, int opitch, long long M, int C, int act, T* __restrict__ gres, int gpitch,
+                                                                 T* __restrict__ du, int opitch, long long M, int C, T* __restrict__ gres, int gpitch,
                                                                  int gres_acc) {
     constexpr int V = V16<T>::N;
     const int CG = C / V, PL = 256 / CG;
     const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
     if (pl >= PL) return;
-    float sc[V], sh[V], mu[V], is[V], m0[V], m1[V];
+    f32x2 sc[V / 2], sh[V / 2], mu[V / 2], is[V / 2], m0[V / 2], m1[V / 2];
 #pragma unroll
     for (int q = 0; q < V; ++q) {
         const int c = cg * V + q;
-        sc[q] = scale[c]; sh[q] = shift[c]; mu[q] = mean[c]; is[q] = invstd[c];
-        m0[q] = (float)(sums[c * 2] / count);
-        m1[q] = (float)(sums[c * 2 + 1] / count);
+        sc[q / 2][q & 1] = scale[c]; sh[q / 2][q & 1] = shift[c]; mu[q / 2][q & 1] = mean[c]; is[q / 2][q & 1] = invstd[c];
+        m0[q / 2][q & 1] = (float)(sums[c * 2] / count);
+        m1[q / 2][q & 1] = (float)(sums[c * 2 + 1] / count);
     }
     for (long long m = (long long)blockIdx.x * PL + pl; m < M; m += (long long)gridDim.x * PL) {
         const V16<T> x = *(const V16<T>*)(u + m * upitch + cg * V);
         const V16<T> g = *(const V16<T>*)(dy + m * dpitch + cg * V);
         V16<T> o;
 #pragma unroll
-        for (int q = 0; q < V; ++q) {
-            const float uf = to_f32<T>(x.v[q]);
-            float dz = to_f32<T>(g.v[q]);
-            if (act == Y3_ACT_SILU) {
-                const float z = uf * sc[q] + sh[q];
-                const float sg = sigmoid_fast(z);
-                dz *= silu_grad(z, sg);
+        for (int q = 0; q < V / 2; ++q) {
+            const f32x2 uf = ld2<T>(x, 2 * q);
+            f32x2 dz = ld2<T>(g, 2 * q);
+            if (SILU) {
+                const f32x2 z = uf * sc[q] + sh[q];
+                dz *= silu_grad2(z, sigmoid2(z));
             }
-            const float xh = (uf - mu[q]) * is[q];
-            o.v[q] = from_f32<T>(sc[q] * (dz - m0[q] - xh * m1[q]));  // scale = gamma * invstd
+            const f32x2 xh = (uf - mu[q]) * is[q];
+            st2<T>(o, 2 * q, sc[q] * (dz - m0[q] - xh * m1[q]));  // scale = gamma * invstd
         }
         *(V16<T>*)(du + m * opitch + cg * V) = o;
         if (gres) {   // out = act(bn(conv)) + residual: the residual's gradient (+)= dy, on the pass that reads dy anyway
@@ -281,7 +310,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
             if (gres_acc) {
                 const V16<T> old = *(const V16<T>*)(gres + m * gpitch + cg * V);
 #pragma unroll
-                for (int q = 0; q < V; ++q) r.v[q] = from_f32<T>(to_f32<T>(g.v[q]) + to_f32<T>(old.v[q]));
+                for (int q = 0; q < V / 2; ++q) st2<T>(r, 2 * q, ld2<T>(g, 2 * q) + ld2<T>(old, 2 * q));
             }
             *(V16<T>*)(gres + m * gpitch + cg * V) = r;
         }
@@ -1086,7 +1115,7 @@ static int bn_stats_launch(const y3_tensor* u, int32_t dtype, double* sums, hipS
     const long long M = (long long)u->n * u->h * u->w;
     if (reduce_geometry(u->c, esize(dtype), M, grid)) return -1;
     Y3_DISPATCH_T(dtype, hipLaunchKernelGGL((channel_reduce_kernel<T, 0>), dim3(grid), dim3(256), 0, st, (const T*)u->data, u->pitch, (const T*)nullptr, 0, M, u->c,
-                                            (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, sums));
+                                            (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, sums));
     Y3_CHECK_LAUNCH();
     return 0;
 }
@@ -1176,8 +1205,10 @@ extern "C" int y3_bn_act_fwd(const y3_tensor* u, const float* scale, const float
     const long long M = (long long)u->n * u->h * u->w;
     unsigned egrid;
     if (elementwise_geometry(u->c, esz, M, egrid)) return -1;
-    Y3_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_fwd_kernel<T>), dim3(egrid), dim3(256), 0, (hipStream_t)stream, (const T*)u->data, u->pitch, scale, shift,
-                                            residual ? (const T*)residual->data : (const T*)nullptr, residual ? residual->pitch : 0, (T*)y->data, y->pitch, M, u->c, act));
+#define Y3_BN_FWD(SILU) hipLaunchKernelGGL((bn_act_fwd_kernel<T, SILU>), dim3(egrid), dim3(256), 0, (hipStream_t)stream, (const T*)u->data, u->pitch, scale, shift, \
+                                          residual ? (const T*)residual->data : (const T*)nullptr, residual ? residual->pitch : 0, (T*)y->data, y->pitch, M, u->c)
+    Y3_DISPATCH_T(dtype, if (act == Y3_ACT_SILU) Y3_BN_FWD(true); else Y3_BN_FWD(false));
+#undef Y3_BN_FWD
     Y3_CHECK_LAUNCH();
     return 0;
 }
@@ -1194,17 +1225,21 @@ static int bn_act_bwd_impl(const y3_tensor* u, const y3_tensor* dy, const float*
     unsigned grid;
     if (reduce_geometry(u->c, esz, M, grid)) return -1;
     hipStream_t st = (hipStream_t)stream;
-    Y3_DISPATCH_T(dtype, hipLaunchKernelGGL((channel_reduce_kernel<T, 1>), dim3(grid), dim3(256), 0, st, (const T*)u->data, u->pitch, (const T*)dy->data, dy->pitch, M,
-                                            u->c, scale, shift, mean, invstd, act, sums));
+#define Y3_BN_RED(SILU) hipLaunchKernelGGL((channel_reduce_kernel<T, 1, SILU>), dim3(grid), dim3(256), 0, st, (const T*)u->data, u->pitch, (const T*)dy->data, dy->pitch, M, \
+                                          u->c, scale, shift, mean, invstd, sums)
+    Y3_DISPATCH_T(dtype, if (act == Y3_ACT_SILU) Y3_BN_RED(true); else Y3_BN_RED(false));
+#undef Y3_BN_RED
     Y3_CHECK_LAUNCH();
     // partial rows -> totals (the apply pass reads them) + (dbeta, dgamma) in the same launch
     hipLaunchKernelGGL(reduce_partials_kernel<2>, dim3((2 * u->c + 15) / 16), dim3(256), 0, st, sums, 2 * u->c, (int)grid, BnFinalizeArgs{}, dbeta, dgamma, 0);
     Y3_CHECK_LAUNCH();
     unsigned egrid;
     if (elementwise_geometry(u->c, esz, M, egrid)) return -1;
-    Y3_DISPATCH_T(dtype, hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T>), dim3(egrid), dim3(256), 0, st, (const T*)u->data, u->pitch, (const T*)dy->data,
-                                            dy->pitch, scale, shift, mean, invstd, (const double*)sums, (double)M, (T*)du->data, du->pitch, M, u->c, act,
-                                            gres ? (T*)gres->data : (T*)nullptr, gres ? gres->pitch : 0, gres_accumulate));
+#define Y3_BN_APPLY(SILU) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, SILU>), dim3(egrid), dim3(256), 0, st, (const T*)u->data, u->pitch, (const T*)dy->data, \
+                                            dy->pitch, scale, shift, mean, invstd, (const double*)sums, (double)M, (T*)du->data, du->pitch, M, u->c, \
+                                            gres ? (T*)gres->data : (T*)nullptr, gres ? gres->pitch : 0, gres_accumulate)
+    Y3_DISPATCH_T(dtype, if (act == Y3_ACT_SILU) Y3_BN_APPLY(true); else Y3_BN_APPLY(false));
+#undef Y3_BN_APPLY
     Y3_CHECK_LAUNCH();
     return 0;
 }
@@ -1396,7 +1431,7 @@ extern "C" int y3_conv2d_wgrad(const y3_conv_desc* d, const y3_tensor* x, const 
         if (grid) {
             double* sums = (double*)workspace;
             Y3_DISPATCH_T(d->dtype, hipLaunchKernelGGL((channel_reduce_kernel<T, 0>), dim3(grid), dim3(256), 0, st, (const T*)du->data, du->pitch, (const T*)nullptr, 0, M, d->cout,
-                                                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, sums));
+                                                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, sums));
             Y3_CHECK_LAUNCH();
             hipLaunchKernelGGL(reduce_partials_kernel<3>, dim3((2 * d->cout + 15) / 16), dim3(256), 0, st, sums, 2 * d->cout, (int)grid, BnFinalizeArgs{}, dbias, (float*)nullptr,
                                cout_real);
