@@ -211,6 +211,48 @@ def train_main(args, rank, local_rank, world, dev, parallel, yo):
     parallel.finalize()
 
 
+def clocks_under_load(fn, seconds=2.5):
+    """Shader clock and socket power while `fn` (one forward) runs back to back, sampled with rocm-smi from a thread.  Outside the timed
+    region.  MI355X is power-capped under MFMA load: the sustained clock -- not the 2.4 GHz the 2.5 PFLOP/s peak is quoted at -- is what a
+    kernel's MFMA rate can be compared with (profiles/r02_clocks.md).  Returns None when rocm-smi is not usable."""
+    import re
+    import subprocess
+    import threading
+
+    stop, rows = threading.Event(), []
+
+    def sampler():
+        while not stop.is_set():
+            try:
+                txt = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=5).stdout
+            except Exception:  # noqa: BLE001
+                return
+            c = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", txt)
+            w = re.search(r"Power \(W\): ([\d.]+)", txt)
+            if c:
+                rows.append((int(c.group(1)), float(w.group(1)) if w else None))
+
+    th = threading.Thread(target=sampler, daemon=True)
+    for _ in range(20):
+        fn()
+    torch.cuda.synchronize()
+    th.start()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+    stop.set()
+    th.join(timeout=10)
+    rows = [r for r in rows if r[0] > 500]   # a sample that caught the queue empty reads the idle clock
+    if len(rows) < 3:
+        return None
+    clk = sorted(r[0] for r in rows)
+    pw = sorted(r[1] for r in rows if r[1])
+    return {"sclk_mhz_median": clk[len(clk) // 2], "sclk_mhz_min": clk[0], "sclk_mhz_max": clk[-1], "socket_power_w_median": pw[len(pw) // 2] if pw else None,
+            "samples": len(rows), "source": "rocm-smi --showclocks --showpower sampled while the forward runs back to back (after the timed region)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -225,6 +267,7 @@ def main():
     ap.add_argument("--profile-layers", action="store_true", help="print the per-launch table (rank 0)")
     ap.add_argument("--no-overlap", action="store_true", help="sequential forward -> NMS per step (no second stream)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"], help="train = BASELINE configs[2] per-GPU shape (data-parallel train step)")
+    ap.add_argument("--no-clocks", action="store_true", help="skip the rocm-smi clock / power sampling leg (after the timed region)")
     ap.add_argument("--no-train", action="store_true", help="infer mode: skip the appended train-step leg (BASELINE metric part ii, batch 64, after the timed inference region)")
     ap.add_argument("--train-batch", type=int, default=64)
     ap.add_argument("--train-steps", type=int, default=6)
@@ -379,6 +422,12 @@ def main():
         cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()   # rank 0 at N = 1 only
         value = world * bs * args.steps / dt
         roofline["whole_step_frac"] = round(total_conv_flops / (dt / args.steps) / 1e12 / MFMA_PEAK_TFLOPS, 4)   # conv FLOPs of one step / wall time of one step / 2.5 PF
+        clk = None if args.no_clocks else clocks_under_load(lambda: model(x))
+        roofline["clocks_under_load"] = clk
+        if clk and bound == "mfma":   # the same MFMA peak at the clock the chip actually sustains under this load (power cap)
+            peak_at_clk = MFMA_PEAK_TFLOPS * clk["sclk_mhz_median"] / 2400.0
+            roofline["peak_at_sustained_clock"] = round(peak_at_clk, 1)
+            roofline["frac_of_peak_at_sustained_clock"] = round(fl / sec / 1e12 / peak_at_clk, 4)
         out = {
             "metric": "images/sec (640x640) inference+NMS",
             "value": round(value, 2),
