@@ -91,6 +91,13 @@ size_t y3_packed_filter_stem_elems(int32_t cout);
 int y3_pack_filter_stem(const float* w_oihw, int32_t cout_src, int32_t cin_src, int32_t cout, int32_t dtype, void* packed, void* stream);
 int y3_stem_conv_fwd(const void* x_nchw, int32_t src_dtype, int32_t n, int32_t cin, int32_t h, int32_t w, float divisor, const void* packed,
                      const float* bias, int32_t dtype, int32_t act, const y3_tensor* y, void* stream);
+/* Training form of the first layer (models/common.py:75 `act(bn(conv(x)))` with batch statistics): the same launch also writes one row
+ * of (sum, sum of squares) per filter of the STORED values per block into stat_rows ([rows][y->c][2] floats; rows =
+ * y3_stem_conv_stats_rows(n, h, w), reported in *n_rows) for y3_bn_finalize_rows -- no separate reduction pass over the output. */
+int64_t y3_stem_conv_stats_rows(int32_t n, int32_t h, int32_t w);
+int y3_stem_conv_fwd_stats(const void* x_nchw, int32_t src_dtype, int32_t n, int32_t cin, int32_t h, int32_t w, float divisor, const void* packed,
+                           const float* bias, int32_t dtype, int32_t act, const y3_tensor* y, float* stat_rows, int64_t capacity_rows, int64_t* n_rows,
+                           void* stream);
 /* Layers 0 + 1 of yolov3 / yolov3-spp in one kernel (models/yolov3.yaml:16-17: Conv(3,32,3,1) -> Conv(32,64,3,2)): layer 0's
  * output (the largest tensor of the network, single consumer) stays in LDS.  packed0 / bias0: 32 filters in the stem format
  * (y3_pack_filter_stem); packed1 / bias1: 64 filters over 32 channels in the generic format (y3_pack_filter); y: NHWC

@@ -315,6 +315,37 @@ def test_stem_conv_vs_fp32_reference(dev, dtype, name, shape, sdt, div, act):
     assert bad == 0, f"{name} {dtype}: {bad}/{err.numel()} outside tolerance, max abs err {err.max():.4g}"
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 3, 40, 72, 32), (1, 3, 37, 131, 32), (3, 3, 24, 200, 64), (2, 3, 32, 32, 16)], ids=["l0", "ragged", "cout64", "cout16"])
+def test_stem_conv_statistics_rows(dev, dtype, shape):
+    """y3_stem_conv_fwd_stats: the rows are (sum, sum of squares) of the STORED values of each block -- summed over the rows (fp64) they
+    equal the per-channel sums of the output tensor the same launch wrote (fp32 partials per block: 1e-5 relative), the output is
+    bit-identical to the launch without statistics, ragged tiles contribute only their valid pixels."""
+    _lib, ops = _ops()
+    n, cin, h, w, cout = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(n, cin, h, w, generator=g).to(dtype).to(dev)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    filt = ops.pack_filter_stem(wt.to(dev), cout, dtype)
+    bias = torch.zeros(cout, device=dev)
+    y0, y1 = ops.View.alloc(n, h, w, cout, dtype, dev), ops.View.alloc(n, h, w, cout, dtype, dev)
+    ops.stem_conv(x, filt, bias, y0, False)
+    rows = ops.stem_conv_stats_rows(n, h, w)
+    assert rows == n * ((h + 7) // 8) * ((w + 63) // 64)
+    buf = torch.full((rows + 1, cout, 2), float("nan"), device=dev)
+    got_rows = ops.stem_conv_stats(x, filt, bias, y1, buf, rows)
+    torch.cuda.synchronize()
+    assert got_rows == rows
+    assert torch.equal(y0.as_nhwc(), y1.as_nhwc())
+    assert torch.isnan(buf[rows]).all(), "wrote past the reported rows"
+    r = buf[:rows].double().sum(0).cpu()
+    v = y1.as_nhwc().double().reshape(-1, cout).cpu()
+    torch.testing.assert_close(r[:, 0], v.sum(0), rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(r[:, 1], (v * v).sum(0), rtol=1e-5, atol=1e-4)
+    with pytest.raises(RuntimeError, match="capacity"):
+        ops.stem_conv_stats(x, filt, bias, y1, buf, rows - 1)
+
+
 def test_stem_matches_generic_first_layer(dev, monkeypatch):
     """The same model with and without the stem kernel (Y3_STEM=0 = ingest + generic conv): identical up to fp32 summation order."""
     x = torch.rand(2, 3, 64, 96, generator=torch.Generator().manual_seed(3)).to(dev).half()

@@ -25,6 +25,8 @@ struct StemArgs {
     int act;
     int tiles_w, tiles_h;
     float divisor;
+    float* stats;       // optional: row blockIdx.x of [Cout][2] floats = (sum, sum of squares) of the block's STORED values (training: BatchNorm
+                        // batch statistics without a separate pass over the 64 B/pixel output)
 };
 
 constexpr int TR = 8, TW = 64;   // output rows x columns per block
@@ -47,6 +49,7 @@ template <typename T, typename S, int MC>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const StemArgs p) {
     typedef typename Mfma16<T>::frag frag;
     typedef T vec4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     constexpr int CH = MC * 4;         // 16-byte chunks per output pixel
     constexpr int RB = CH * 16;        // bytes per output pixel (MC * 32 filters)
     constexpr int PPI = 64 / CH;       // pixels per store instruction
@@ -99,6 +102,10 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemArgs p) {
     unsigned char* wl = slices + wv * (32 * RB);
     T* __restrict__ yg = (T*)p.y;
     const int rp = lane / CH, ch = lane % CH;
+    const bool want_stats = p.stats != nullptr;   // kernel-uniform
+    float st0[8], st1[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) st0[q] = st1[q] = 0.0f;
     for (int t = wv; t < TR * TW / 32; t += 4) {
         const int trow = t / (TW / 32), j0 = (t % (TW / 32)) * 32;
         f32x16 acc[MC];
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemArgs p) {
 #pragma unroll
             for (int a = 0; a < MC; ++a) acc[a] = Mfma16<T>::run(af[a][kh], bf, acc[a]);
         }
-        // ---- activation, filter-pair swap (8 consecutive filters per lane), transpose through the wave's slice ----
+        // ---- activation, pairs of filters rounded to T, lane-half swap (8 consecutive filters per lane), transpose through the wave's slice ----
         if (p.act == Y3_ACT_SILU) {
 #pragma unroll
             for (int a = 0; a < MC; ++a) silu_vec<f32x16, 16>(acc[a]);
@@ -129,16 +136,16 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemArgs p) {
         for (int a = 0; a < MC; ++a)
 #pragma unroll
             for (int gp = 0; gp < 2; ++gp) {
-                frag ov;
+                u32x4 ov;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float t0 = acc[a][8 * gp + q], t1 = acc[a][8 * gp + 4 + q];
-                    const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, t0), __builtin_bit_cast(unsigned, t1), false, false);
-                    ov[q] = from_f32<T>(__builtin_bit_cast(float, (unsigned)sw[0]));
-                    ov[4 + q] = from_f32<T>(__builtin_bit_cast(float, (unsigned)sw[1]));
+                for (int h = 0; h < 2; ++h) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(pack2<T>(acc[a][8 * gp + 2 * h], acc[a][8 * gp + 2 * h + 1]),
+                                                                     pack2<T>(acc[a][8 * gp + 4 + 2 * h], acc[a][8 * gp + 4 + 2 * h + 1]), false, false);
+                    ov[h] = (unsigned)sw[0];
+                    ov[2 + h] = (unsigned)sw[1];
                 }
                 const int chunk = a * 4 + gp * 2 + fk;
-                *(frag*)(wl + frow * RB + ((chunk ^ (frow & (CH - 1))) << 4)) = ov;
+                *(u32x4*)(wl + frow * RB + ((chunk ^ (frow & (CH - 1))) << 4)) = ov;
             }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -149,10 +156,34 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemArgs p) {
             const int pl = i * PPI + rp;
             const frag ov = *(const frag*)(wl + pl * RB + ((ch ^ (pl & (CH - 1))) << 4));
             const int gcol = col0 + j0 + pl;
-            if (grow < p.H && gcol < p.W && ch * 8 + 8 <= p.Cout) *(frag*)(yg + ((long long)(n * p.H + grow) * p.W + gcol) * p.ypitch + ch * 8) = ov;
+            if (grow < p.H && gcol < p.W && ch * 8 + 8 <= p.Cout) {
+                *(frag*)(yg + ((long long)(n * p.H + grow) * p.W + gcol) * p.ypitch + ch * 8) = ov;
+                if (want_stats) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { const float f = to_f32<T>(ov[q]); st0[q] += f; st1[q] += f * f; }
+                }
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();   // the slice is rewritten by the next tile
+    }
+    if (want_stats) {
+        // lanes rp * CH + ch hold partial sums of the same 8 filters: butterfly over the rp bits, then the four waves through LDS
+#pragma unroll
+        for (int off = CH; off < 64; off <<= 1)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { st0[q] += __shfl_xor(st0[q], off, 64); st1[q] += __shfl_xor(st1[q], off, 64); }
+        __syncthreads();   // every wave is done with the patch: its first 2 KiB become the reduction buffer
+        float* red = (float*)patch;
+        if (rp == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { red[(wv * CH + ch) * 16 + 2 * q] = st0[q]; red[(wv * CH + ch) * 16 + 2 * q + 1] = st1[q]; }
+        }
+        __syncthreads();
+        if (tid < CH * 16 && (tid >> 4) * 8 + 8 <= p.Cout) {   // thread = (channel group, filter of the group, sum / sum of squares)
+            const float v = red[tid] + red[CH * 16 + tid] + red[2 * CH * 16 + tid] + red[3 * CH * 16 + tid];   // fixed order: deterministic
+            p.stats[(long long)blockIdx.x * p.Cout * 2 + tid] = v;
+        }
     }
 }
 
@@ -480,25 +511,45 @@ extern "C" int y3_pack_filter_stem(const float* w, int32_t cout_src, int32_t cin
     return 0;
 }
 
-extern "C" int y3_stem_conv_fwd(const void* x_nchw, int32_t src_dtype, int32_t n, int32_t cin, int32_t h, int32_t w, float divisor, const void* packed,
-                                const float* bias, int32_t dtype, int32_t act, const y3_tensor* y, void* stream) {
-    if (!x_nchw || !packed || !y || !y->data) Y3_FAIL("y3_stem_conv_fwd: null argument");
-    if (cin < 1 || cin > 4) Y3_FAIL("y3_stem_conv_fwd: %d input channels (1..4 supported)", cin);
-    if (y->n != n || y->h != h || y->w != w) Y3_FAIL("y3_stem_conv_fwd: output must be (%d,%d,%d,*) for a stride-1 pad-1 3x3", n, h, w);
-    if ((y->c % 8) || y->c > 64 || (y->pitch % 8) || ((uintptr_t)y->data & 15) || ((uintptr_t)packed & 15)) Y3_FAIL("y3_stem_conv_fwd: 8..64 filters (multiple of 8), 16-byte aligned views");
-    if (!(divisor > 0.0f)) Y3_FAIL("y3_stem_conv_fwd: divisor must be positive");
-    if ((long long)n * h * w > 0x7fffffffLL) Y3_FAIL("y3_stem_conv_fwd: too many pixels");
+static int stem_conv_impl(const void* x_nchw, int32_t src_dtype, int32_t n, int32_t cin, int32_t h, int32_t w, float divisor, const void* packed, const float* bias,
+                          int32_t dtype, int32_t act, const y3_tensor* y, float* stat_rows, int64_t capacity_rows, int64_t* n_rows, void* stream, const char* who) {
+    if (!x_nchw || !packed || !y || !y->data) Y3_FAIL("%s: null argument", who);
+    if (cin < 1 || cin > 4) Y3_FAIL("%s: %d input channels (1..4 supported)", who, cin);
+    if (y->n != n || y->h != h || y->w != w) Y3_FAIL("%s: output must be (%d,%d,%d,*) for a stride-1 pad-1 3x3", who, n, h, w);
+    if ((y->c % 8) || y->c > 64 || (y->pitch % 8) || ((uintptr_t)y->data & 15) || ((uintptr_t)packed & 15)) Y3_FAIL("%s: 8..64 filters (multiple of 8), 16-byte aligned views", who);
+    if (!(divisor > 0.0f)) Y3_FAIL("%s: divisor must be positive", who);
+    if ((long long)n * h * w > 0x7fffffffLL) Y3_FAIL("%s: too many pixels", who);
     StemArgs a;
     a.x = x_nchw; a.w = packed; a.bias = bias; a.y = y->data;
     a.N = n; a.Cin = cin; a.H = h; a.W = w; a.ypitch = y->pitch; a.Cout = y->c; a.act = act;
     a.tiles_w = (w + TW - 1) / TW; a.tiles_h = (h + TR - 1) / TR;
     a.divisor = divisor;
+    a.stats = stat_rows;
+    const long long rows = (long long)a.tiles_w * a.tiles_h * n;
+    if (stat_rows) {
+        if (rows > capacity_rows) Y3_FAIL("%s: %lld statistics rows, capacity %lld", who, rows, (long long)capacity_rows);
+        if (n_rows) *n_rows = rows;
+    }
     hipStream_t st = (hipStream_t)stream;
     switch (dtype) {
         case Y3_F16: return dispatch_src<f16_t>(a, src_dtype, st);
         case Y3_BF16: return dispatch_src<bf16_t>(a, src_dtype, st);
     }
-    Y3_FAIL("y3_stem_conv_fwd: f16/bf16 compute only");
+    Y3_FAIL("%s: f16/bf16 compute only", who);
+}
+
+extern "C" int y3_stem_conv_fwd(const void* x_nchw, int32_t src_dtype, int32_t n, int32_t cin, int32_t h, int32_t w, float divisor, const void* packed,
+                                const float* bias, int32_t dtype, int32_t act, const y3_tensor* y, void* stream) {
+    return stem_conv_impl(x_nchw, src_dtype, n, cin, h, w, divisor, packed, bias, dtype, act, y, nullptr, 0, nullptr, stream, "y3_stem_conv_fwd");
+}
+
+extern "C" int64_t y3_stem_conv_stats_rows(int32_t n, int32_t h, int32_t w) { return (int64_t)((w + TW - 1) / TW) * ((h + TR - 1) / TR) * n; }
+
+extern "C" int y3_stem_conv_fwd_stats(const void* x_nchw, int32_t src_dtype, int32_t n, int32_t cin, int32_t h, int32_t w, float divisor, const void* packed,
+                                      const float* bias, int32_t dtype, int32_t act, const y3_tensor* y, float* stat_rows, int64_t capacity_rows, int64_t* n_rows,
+                                      void* stream) {
+    if (!stat_rows || !n_rows) Y3_FAIL("y3_stem_conv_fwd_stats: null statistics buffer");
+    return stem_conv_impl(x_nchw, src_dtype, n, cin, h, w, divisor, packed, bias, dtype, act, y, stat_rows, capacity_rows, n_rows, stream, "y3_stem_conv_fwd_stats");
 }
 
 namespace {

@@ -132,6 +132,23 @@ def stem_conv(x_nchw: torch.Tensor, filt: torch.Tensor, bias: torch.Tensor, y: V
                                       dtype_code(y.buf.dtype), _lib.Y3_ACT_SILU if act else _lib.Y3_ACT_NONE, C.byref(yt), stream_ptr()), "y3_stem_conv_fwd")
 
 
+def stem_conv_stats_rows(n: int, h: int, w: int) -> int:
+    return int(_lib.lib().y3_stem_conv_stats_rows(n, h, w))
+
+
+def stem_conv_stats(x_nchw: torch.Tensor, filt: torch.Tensor, bias: torch.Tensor, y: View, stat_rows: torch.Tensor, capacity_rows: int, divisor: float = 1.0) -> int:
+    """stem_conv without activation + one row of (sum, sum of squares) per filter and block in stat_rows (fp32): the training form of layer 0."""
+    require_gpu(x_nchw, "stem_conv_stats")
+    x = x_nchw.contiguous()
+    n, c, h, w = x.shape
+    yt = y.y3()
+    rows = C.c_int64(0)
+    check(_lib.lib().y3_stem_conv_fwd_stats(x.data_ptr(), dtype_code(x.dtype), n, c, h, w, float(divisor), filt.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                            dtype_code(y.buf.dtype), _lib.Y3_ACT_NONE, C.byref(yt), stat_rows.data_ptr(), int(capacity_rows), C.byref(rows), stream_ptr()),
+          "y3_stem_conv_fwd_stats")
+    return int(rows.value)
+
+
 def pack_filter_dgrad(w_oihw: torch.Tensor, cout: int, cin: int, dtype: torch.dtype) -> torch.Tensor:
     """OIHW fp32 weights -> filter bank of the data-gradient conv (cin filters over (kh, kw, cout), flipped taps)."""
     require_gpu(w_oihw, "pack_filter_dgrad")

@@ -114,7 +114,21 @@ class ConvUnit(_Unit):
         stats_in_epilogue = False
         if self.use_stem and self.plan.x_nchw is not None:
             # layer 0 straight from the caller's NCHW image (csrc/stem.hip); the NHWC copy is still made for the filter gradient
-            ops.stem_conv(self.plan.x_nchw, ops.pack_filter_stem(m.conv.weight, self.cout, self.plan.dtype), self.zero_bias, self.u, act=False)
+            filt = ops.pack_filter_stem(m.conv.weight, self.cout, self.plan.dtype)
+            if self.plan.epilogue_stats:   # BatchNorm statistics from the same launch: one row per block, no reduction pass over the 64 B/pixel tensor
+                xi = self.plan.x_nchw
+                rows = ops.stem_conv_stats_rows(xi.shape[0], xi.shape[2], xi.shape[3])
+                buf = self.plan.stat_buffer(rows * 2 * self.cout)
+                n_rows = ops.stem_conv_stats(xi, filt, self.zero_bias, self.u, buf, rows)
+                check(
+                    L.y3_bn_finalize_rows(buf.data_ptr(), n_rows, self.count, self.cout, self.sums.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps),
+                                          float(bn.momentum), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
+                                          self.mean.data_ptr(), self.invstd.data_ptr(), st),
+                    "y3_bn_finalize_rows",
+                )
+                stats_in_epilogue = True
+            else:
+                ops.stem_conv(self.plan.x_nchw, filt, self.zero_bias, self.u, act=False)
         else:
             if self.pair_pack:   # forward and data-gradient banks in one launch; the weights do not change before the backward
                 filt, self.filt_d = ops.pack_filter_pair(m.conv.weight, self.cout, self.cin, self.plan.dtype)
