@@ -252,6 +252,17 @@ int y3_bn_act_bwd(const y3_tensor* u, const y3_tensor* dy, const float* scale, c
 int y3_bn_act_bwd_res(const y3_tensor* u, const y3_tensor* dy, const float* scale, const float* shift, const float* mean,
                       const float* invstd, int32_t dtype, int32_t act, double* sums, const y3_tensor* du, float* dgamma,
                       float* dbeta, const y3_tensor* gres, int32_t gres_accumulate, void* stream);
+/* Backward of the first layer (Conv(3, 32, 3, 1) + BatchNorm + act; no data gradient) in two passes over (u, dy) instead of three
+ * plus a write: the reduction of y3_bn_act_bwd (totals into `sums`, dgamma, dbeta), then ONE kernel that applies the BatchNorm /
+ * activation backward, rounds du to the storage dtype as y3_bn_act_bwd would have stored it, and accumulates
+ * dw_oihw[32][cin][3][3] (fp32, the layout of nn.Conv2d.weight.grad) against the source image -- du never reaches memory.
+ * x_nchw / src_dtype / divisor: the image exactly as y3_stem_conv_fwd received it.  32 filters, cin <= 3, f16 / bf16.
+ * workspace: y3_stem_bn_bwd_wgrad_workspace_bytes() bytes (one fp32 partial tile per persistent block; summed in block order). */
+size_t y3_stem_bn_bwd_wgrad_workspace_bytes(void);
+int y3_stem_bn_bwd_wgrad(const void* x_nchw, int32_t src_dtype, int32_t n, int32_t cin, int32_t h, int32_t w, float divisor, const y3_tensor* u,
+                         const y3_tensor* dy, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t dtype,
+                         int32_t act, double* sums, float* dgamma /* may be NULL */, float* dbeta /* may be NULL */, float* dw_oihw,
+                         void* workspace, size_t workspace_bytes, void* stream);
 /* OIHW fp32 -> filter bank of the data-gradient convolution: `cin` filters over (kh, kw, cout) with flipped taps. */
 int y3_pack_filter_dgrad(const float* w_oihw, int32_t cout_src, int32_t cin_src, int32_t ksize, int32_t cout, int32_t cin,
                          int32_t dtype, void* packed, void* stream);

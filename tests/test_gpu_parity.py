@@ -1710,3 +1710,73 @@ def test_model_rejects_wrong_channel_count(dev):
         m(torch.rand(1, 1, 64, 64, device=dev).half())
     with pytest.raises(ValueError, match="input channels"):
         m(torch.rand(1, 4, 64, 64, device=dev).half())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape,sdt,div,act", [((2, 3, 40, 72), torch.float16, 1.0, True), ((1, 3, 37, 131), torch.float32, 1.0, True), ((3, 3, 24, 200), torch.uint8, 255.0, True),
+                                               ((2, 1, 19, 64), torch.float16, 1.0, False), ((5, 3, 128, 192), torch.float16, 1.0, True)],
+                         ids=["l0", "ragged_f32src", "u8_div255", "cin1_noact", "more_tiles_than_blocks"])
+def test_stem_bn_bwd_wgrad_matches_unfused_backward(dev, dtype, shape, sdt, div, act):
+    """y3_stem_bn_bwd_wgrad (layer 0 backward: BatchNorm + SiLU backward and the filter gradient in one pass, du never stored) against the
+    path it replaces -- y3_bn_act_bwd (du stored in T) + y3_conv2d_wgrad on the NHWC image: dgamma / dbeta bit-identical (same reduction),
+    dW equal up to fp32 summation order (both multiply the SAME T-rounded du and image values); and against torch autograd in fp32."""
+    import ctypes as C
+
+    _lib, ops = _ops()
+    n, cin, h, w = shape
+    cout = 32
+    g = torch.Generator().manual_seed(17)
+    if sdt == torch.uint8:
+        x = torch.randint(0, 256, (n, cin, h, w), generator=g, dtype=torch.uint8)
+    else:
+        x = torch.rand(n, cin, h, w, generator=g).to(sdt)
+    xd = x.to(dev)
+    u = (torch.randn(n, cout, h, w, generator=g) * 1.5).to(dtype)
+    dy = (torch.randn(n, cout, h, w, generator=g) * 0.1).to(dtype)
+    gamma, beta = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    uv, gv = ops.View.alloc(n, h, w, cout, dtype, dev), ops.View.alloc(n, h, w, cout, dtype, dev)
+    ops.nchw_to_nhwc(u.to(dev), uv)
+    ops.nchw_to_nhwc(dy.to(dev), gv)
+    cnt = n * h * w
+    uf = u.double()
+    mean = uf.mean((0, 2, 3))
+    var = uf.var((0, 2, 3), unbiased=False)
+    invstd = (1.0 / torch.sqrt(var + 1e-3))
+    scale = (gamma.double() * invstd).float().to(dev)
+    shift = (beta.double() - mean * gamma.double() * invstd).float().to(dev)
+    mean_d, invstd_d = mean.float().to(dev), invstd.float().to(dev)
+    a = _lib.Y3_ACT_SILU if act else _lib.Y3_ACT_NONE
+    # unfused: du stored, generic filter gradient
+    sums = ops.bn_scratch(cout, dev)
+    duv = ops.View.alloc(n, h, w, cout, dtype, dev)
+    dg0, db0 = torch.empty(cout, device=dev), torch.empty(cout, device=dev)
+    ut, gt, dt_ = uv.y3(), gv.y3(), duv.y3()
+    _lib.check(_lib.lib().y3_bn_act_bwd(C.byref(ut), C.byref(gt), scale.data_ptr(), shift.data_ptr(), mean_d.data_ptr(), invstd_d.data_ptr(), ops.dtype_code(dtype), a,
+                                        sums.data_ptr(), C.byref(dt_), dg0.data_ptr(), db0.data_ptr(), ops.stream_ptr()), "y3_bn_act_bwd")
+    xin = ops.View.alloc(n, h, w, 8, dtype, dev)
+    ops.nchw_to_nhwc(xd, xin, div)
+    dw0, _ = ops.conv2d_wgrad(xin, duv, 3, 1, cout, cin)
+    # fused
+    sums1 = ops.bn_scratch(cout, dev)
+    dg1, db1 = torch.empty(cout, device=dev), torch.empty(cout, device=dev)
+    dw1 = torch.full((cout, cin, 3, 3), float("nan"), device=dev)
+    ops.stem_bn_bwd_wgrad(xd, uv, gv, scale, shift, mean_d, invstd_d, a, sums1, dg1, db1, dw1, ops.stem_bwd_workspace(dev), div)
+    torch.cuda.synchronize()
+    assert torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    assert torch.isfinite(dw1).all()
+    ref = dw0.abs().max().item()
+    assert (dw0 - dw1).abs().max().item() <= 2e-5 * ref + 1e-6, f"fused vs unfused dW: {(dw0 - dw1).abs().max().item():.3e} of {ref:.3e}"
+    # fp32 autograd of the same function of the rounded operands
+    xq = (x.float() / div).to(dtype).float().requires_grad_(False)
+    wt = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    # d loss / d W with loss = <dy, act(bn(conv(x, W) + (u - conv(x, W)).detach()))>: the gradient wrt the conv OUTPUT at value u
+    uu = u.float().clone().requires_grad_(True)
+    z = (uu - mean.float().view(1, -1, 1, 1)) * (gamma * invstd.float()).view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)
+    # batch statistics depend on u: use torch's batch_norm for the exact backward
+    zz = F.batch_norm(uu, None, None, gamma, beta, True, 0.0, 1e-3)
+    out = F.silu(zz) if act else zz
+    (out * dy.float()).sum().backward()
+    du_ref = uu.grad
+    dw_ref = torch.nn.grad.conv2d_weight(xq, (cout, cin, 3, 3), du_ref, stride=1, padding=1)
+    err = (dw1.cpu() - dw_ref).abs().max().item() / dw_ref.abs().max().item()
+    assert err < (4e-3 if dtype == torch.float16 else 3e-2), f"dW vs fp32 autograd: {err:.3e}"

@@ -148,6 +148,9 @@ _SIGNATURES = {
     "y3_packed_filter_stem_elems": (C.c_size_t, [C.c_int32]),
     "y3_pack_filter_stem": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "y3_stem_conv_fwd": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, _P(Y3Tensor), C.c_void_p]),
+    "y3_stem_bn_bwd_wgrad_workspace_bytes": (C.c_size_t, []),
+    "y3_stem_bn_bwd_wgrad": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P(Y3Tensor), _P(Y3Tensor), C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "y3_stem_conv_stats_rows": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "y3_stem_conv_fwd_stats": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, _P(Y3Tensor),
                                          C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -1073,6 +1073,165 @@ __global__ __launch_bounds__(256) void detect_raw_bwd_kernel(const T* __restrict
     ghead[((long long)(b * ny + y) * nx + x) * pitch + ch] = v;
 }
 
+
+// ---- layer 0 backward in two passes instead of three ---------------------------------------------------------------------
+// Conv(3, 32, 3, 1) has no data gradient: its du (= BatchNorm + SiLU backward of dy, 64 B per 640x640 pixel) has ONE consumer, the
+// filter gradient -- 864 MACs per pixel.  Written by the apply pass and read back by the generic wgrad kernel it cost 3.4 GB of HBM
+// traffic and a launch that multiplied mostly zero padding (1.0 ms at batch 64).  Here the apply arithmetic (same formulas as
+// bn_act_bwd_apply_kernel) runs on a 4 x 64 pixel tile, du is rounded to T exactly as the stored tensor was and dropped into LDS
+// channel-major, the image patch is staged as three column-shifted planar copies, and dW[32 filters][27 (tap, channel)] accumulates in
+// ONE 32x32 MFMA tile per wave over the block's tiles (persistent blocks; one fp32 partial tile per block, summed in block order).
+struct StemBwdArgs {
+    const void* x;      // (N, Cin, H, W) source image
+    const void* u;      // NHWC conv output of layer 0 (32 channels)
+    const void* dy;     // NHWC gradient of the activation output
+    int upitch, dpitch;
+    const float* scale; const float* shift; const float* mean; const float* invstd;
+    const double* sums; // totals (sum dz, sum dz*xhat) per channel, interleaved
+    double count;
+    float* part;        // [gridDim.x][32 * 32]
+    int N, Cin, H, W, tiles_w, tiles_h, n_tiles;
+    float divisor;
+};
+constexpr int SB_TR = 4, SB_TW = 64;
+constexpr int SB_ROWB = SB_TR * SB_TW * 2 + 16;   // one channel's 256 pixels + 16 bytes: the 32 rows of an A-fragment read start in 16 different bank slots
+
+template <typename S> Y3_DEV float stem_src_f32(S v) { return (float)v; }
+
+template <typename T, typename S, bool SILU>
+__global__ __launch_bounds__(256, 4) void stem_bn_bwd_wgrad_kernel(const StemBwdArgs p) {
+    typedef typename std::conditional<std::is_same<T, f16_t>::value, f16x8, bf16x8>::type frag;
+    __shared__ __attribute__((aligned(16))) unsigned char duT[32 * SB_ROWB];
+    __shared__ __attribute__((aligned(16))) T patch[3 * 3 * (SB_TR + 2) * SB_TW];   // [kw][c][row][col]: column j of copy kw = image column col0 + j + kw - 1
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = tid & 3;
+    f32x2 sc[4], sh[4], mu[4], is[4], m0[4], m1[4];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int c = cg * 8 + q;
+        sc[q / 2][q & 1] = p.scale[c]; sh[q / 2][q & 1] = p.shift[c]; mu[q / 2][q & 1] = p.mean[c]; is[q / 2][q & 1] = p.invstd[c];
+        m0[q / 2][q & 1] = (float)(p.sums[c * 2] / p.count);
+        m1[q / 2][q & 1] = (float)(p.sums[c * 2 + 1] / p.count);
+    }
+    // MFMA roles: D[filter][n] += A[filter][pixel] * B[pixel][n], n = tap * Cin + channel (< 9 Cin <= 27)
+    const int fn = lane & 31, kg = lane >> 5;
+    const int b_tap = fn / p.Cin, b_c = fn - b_tap * p.Cin;
+    const bool b_ok = fn < 9 * p.Cin;
+    const int b_kh = b_tap / 3, b_kw = b_tap - 3 * b_kh;
+    const int b_off = b_ok ? (((b_kw * 3 + b_c) * (SB_TR + 2) + wv + b_kh) * SB_TW + 8 * kg) : 0;   // + 16 s; wave wv owns tile row wv
+    const int a_off = fn * SB_ROWB + (wv * SB_TW + 8 * kg) * 2;                                        // + 32 s bytes
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+    const int hw = p.H * p.W;
+    const T* __restrict__ ug = (const T*)p.u;
+    const T* __restrict__ dg = (const T*)p.dy;
+
+    for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+        int b = tile;
+        const int tw = b % p.tiles_w; b /= p.tiles_w;
+        const int th = b % p.tiles_h;
+        const int n = b / p.tiles_h;
+        const int row0 = th * SB_TR, col0 = tw * SB_TW;
+        // ---- du of the tile, two horizontally adjacent pixels x 8 channels per thread and trip, channel-major into LDS ----
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int pi = (tid >> 2) + 64 * it;          // pixel pair of the tile
+            const int r = pi >> 5, pj = pi & 31;
+            const int gh = row0 + r, gw = col0 + 2 * pj;
+            const bool v0 = gh < p.H && gw < p.W, v1 = gh < p.H && gw + 1 < p.W;
+            const long long pix = (long long)(n * p.H + gh) * p.W + gw;
+            V16<T> x0, x1, g0, g1;
+            if (v0) { x0 = *(const V16<T>*)(ug + pix * p.upitch + cg * 8); g0 = *(const V16<T>*)(dg + pix * p.dpitch + cg * 8); }
+            if (v1) { x1 = *(const V16<T>*)(ug + (pix + 1) * p.upitch + cg * 8); g1 = *(const V16<T>*)(dg + (pix + 1) * p.dpitch + cg * 8); }
+            float d0[8], d1[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x2 r0 = {0.0f, 0.0f}, r1 = {0.0f, 0.0f};
+                if (v0) {
+                    const f32x2 uf = ld2<T>(x0, 2 * q);
+                    f32x2 dz = ld2<T>(g0, 2 * q);
+                    if (SILU) { const f32x2 z = uf * sc[q] + sh[q]; dz *= silu_grad2(z, sigmoid2(z)); }
+                    r0 = sc[q] * (dz - m0[q] - ((uf - mu[q]) * is[q]) * m1[q]);
+                }
+                if (v1) {
+                    const f32x2 uf = ld2<T>(x1, 2 * q);
+                    f32x2 dz = ld2<T>(g1, 2 * q);
+                    if (SILU) { const f32x2 z = uf * sc[q] + sh[q]; dz *= silu_grad2(z, sigmoid2(z)); }
+                    r1 = sc[q] * (dz - m0[q] - ((uf - mu[q]) * is[q]) * m1[q]);
+                }
+                d0[2 * q] = r0[0]; d0[2 * q + 1] = r0[1]; d1[2 * q] = r1[0]; d1[2 * q + 1] = r1[1];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) *(unsigned*)(duT + (cg * 8 + q) * SB_ROWB + (r * SB_TW + 2 * pj) * 2) = pack2<T>(d0[q], d1[q]);
+        }
+        // ---- image patch, rounded to T as the forward rounded it: rows row0 - 1 .. row0 + 4, columns col0 - 1 .. col0 + 64; every element is
+        // loaded once and stored into the (up to three) column-shifted copies it belongs to ----
+        const S* __restrict__ xs = (const S*)p.x + (long long)n * p.Cin * hw;
+        for (int e = tid; e < p.Cin * (SB_TR + 2) * (SB_TW + 2); e += 256) {
+            const int jj = e % (SB_TW + 2);
+            int t = e / (SB_TW + 2);
+            const int r = t % (SB_TR + 2), c = t / (SB_TR + 2);
+            const int gh = row0 + r - 1, gw = col0 + jj - 1;
+            float v = 0.0f;
+            if ((unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W) v = stem_src_f32<S>(xs[c * hw + gh * p.W + gw]) / p.divisor;
+            const T tv = from_f32<T>(v);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int j = jj - kw;
+                if ((unsigned)j < (unsigned)SB_TW) patch[((kw * 3 + c) * (SB_TR + 2) + r) * SB_TW + j] = tv;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const frag a = *(const frag*)(duT + a_off + 32 * s4);
+            frag bf = *(const frag*)(patch + b_off + 16 * s4);
+            if (!b_ok) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) bf[q] = (T)0.0f;
+            }
+            if constexpr (std::is_same<T, f16_t>::value) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf, acc, 0, 0, 0);
+            else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bf, acc, 0, 0, 0);
+        }
+        __syncthreads();   // the tile's LDS is rewritten by the next trip
+    }
+    // ---- the four waves' tiles -> one partial tile per block: D[filter = 8 g + 4 kg + e][n = fn] ----
+    float* red = (float*)duT;   // 4 x 1024 floats
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[wv * 1024 + (8 * g + 4 * kg + e) * 32 + fn] = acc[4 * g + e];
+    __syncthreads();
+    float* out = p.part + (long long)blockIdx.x * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int o = tid + 256 * i;
+        out[o] = (red[o] + red[1024 + o]) + (red[2048 + o] + red[3072 + o]);
+    }
+}
+
+// dW[co][c][kh][kw] = sum over the blocks' partial tiles [co][n = (kh * 3 + kw) * Cin + c], block order (deterministic)
+__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ part, int nblocks, int cin, int cout, float* __restrict__ dw) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= cout * cin * 9) return;
+    const int kw = idx % 3, kh = (idx / 3) % 3, c = (idx / 9) % cin, co = idx / (9 * cin);
+    const int o = co * 32 + (kh * 3 + kw) * cin + c;
+    float a = 0.0f;
+    int b = 0;
+    for (; b + 7 < nblocks; b += 8) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = part[(long long)(b + q) * 1024 + o];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a += v[q];
+    }
+    for (; b < nblocks; ++b) a += part[(long long)b * 1024 + o];
+    dw[idx] = a;
+}
+
 }  // namespace
 
 #define Y3_DISPATCH_T(dtype, EXPR)                            \
@@ -1254,6 +1413,56 @@ extern "C" int y3_bn_act_bwd_res(const y3_tensor* u, const y3_tensor* dy, const 
                                  int32_t act, double* sums, const y3_tensor* du, float* dgamma, float* dbeta, const y3_tensor* gres, int32_t gres_accumulate, void* stream) {
     if (!gres) Y3_FAIL("y3_bn_act_bwd_res: null residual gradient");
     return bn_act_bwd_impl(u, dy, scale, shift, mean, invstd, dtype, act, sums, du, dgamma, dbeta, gres, gres_accumulate, stream);
+}
+
+// Layer 0 (no data gradient): BatchNorm + activation backward and the filter gradient without materialising du.
+// Pass 1 = the reduction of y3_bn_act_bwd (totals, dgamma, dbeta); pass 2 = stem_bn_bwd_wgrad_kernel + the block-order sum.
+extern "C" size_t y3_stem_bn_bwd_wgrad_workspace_bytes(void) { return (size_t)1024 * 1024 * sizeof(float); }
+
+extern "C" int y3_stem_bn_bwd_wgrad(const void* x_nchw, int32_t src_dtype, int32_t n, int32_t cin, int32_t h, int32_t w, float divisor, const y3_tensor* u,
+                                    const y3_tensor* dy, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t dtype, int32_t act,
+                                    double* sums, float* dgamma, float* dbeta, float* dw_oihw, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x_nchw || !u || !dy || !scale || !shift || !mean || !invstd || !sums || !dw_oihw || !workspace) Y3_FAIL("y3_stem_bn_bwd_wgrad: null argument");
+    if (cin < 1 || cin > 3) Y3_FAIL("y3_stem_bn_bwd_wgrad: %d input channels (1..3: the 9 * cin filter taps share one 32-wide MFMA tile)", cin);
+    if (u->c != 32 || dy->c != 32) Y3_FAIL("y3_stem_bn_bwd_wgrad: 32 filters (layer 0 of yolov3 / yolov3-spp), got %d", u->c);
+    if (u->n != n || u->h != h || u->w != w || dy->n != n || dy->h != h || dy->w != w) Y3_FAIL("y3_stem_bn_bwd_wgrad: shape mismatch");
+    if (dtype != Y3_F16 && dtype != Y3_BF16) Y3_FAIL("y3_stem_bn_bwd_wgrad: f16/bf16 only");
+    if (!vec_ok(u, 2) || !vec_ok(dy, 2)) Y3_FAIL("y3_stem_bn_bwd_wgrad: alignment");
+    if (!(divisor > 0.0f)) Y3_FAIL("y3_stem_bn_bwd_wgrad: divisor must be positive");
+    if (workspace_bytes < y3_stem_bn_bwd_wgrad_workspace_bytes() || (((uintptr_t)workspace) & 15)) Y3_FAIL("y3_stem_bn_bwd_wgrad: workspace too small / unaligned");
+    const long long M = (long long)n * h * w;
+    if (M > 0x7fffffffLL / 4) Y3_FAIL("y3_stem_bn_bwd_wgrad: too many pixels");
+    hipStream_t st = (hipStream_t)stream;
+    unsigned grid;
+    if (reduce_geometry(32, 2, M, grid)) return -1;
+#define Y3_BN_RED(SILU) hipLaunchKernelGGL((channel_reduce_kernel<T, 1, SILU>), dim3(grid), dim3(256), 0, st, (const T*)u->data, u->pitch, (const T*)dy->data, dy->pitch, M, \
+                                          32, scale, shift, mean, invstd, sums)
+    Y3_DISPATCH_T(dtype, if (act == Y3_ACT_SILU) Y3_BN_RED(true); else Y3_BN_RED(false));
+#undef Y3_BN_RED
+    Y3_CHECK_LAUNCH();
+    hipLaunchKernelGGL(reduce_partials_kernel<2>, dim3((2 * 32 + 15) / 16), dim3(256), 0, st, sums, 2 * 32, (int)grid, BnFinalizeArgs{}, dbeta, dgamma, 0);
+    Y3_CHECK_LAUNCH();
+    StemBwdArgs a;
+    a.x = x_nchw; a.u = u->data; a.dy = dy->data; a.upitch = u->pitch; a.dpitch = dy->pitch;
+    a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.sums = sums; a.count = (double)M;
+    a.part = (float*)workspace;
+    a.N = n; a.Cin = cin; a.H = h; a.W = w;
+    a.tiles_w = (w + SB_TW - 1) / SB_TW; a.tiles_h = (h + SB_TR - 1) / SB_TR;
+    const long long tiles = (long long)a.tiles_w * a.tiles_h * n;
+    a.n_tiles = (int)tiles;
+    a.divisor = divisor;
+    const int blocks = tiles < 1024 ? (int)tiles : 1024;   // persistent: 4 blocks per CU
+#define Y3_SB(TT, SS) do { if (act == Y3_ACT_SILU) hipLaunchKernelGGL((stem_bn_bwd_wgrad_kernel<TT, SS, true>), dim3(blocks), dim3(256), 0, st, a); \
+                           else hipLaunchKernelGGL((stem_bn_bwd_wgrad_kernel<TT, SS, false>), dim3(blocks), dim3(256), 0, st, a); } while (0)
+#define Y3_SB_SRC(TT) switch (src_dtype) { case Y3_F16: Y3_SB(TT, f16_t); break; case Y3_BF16: Y3_SB(TT, bf16_t); break; case Y3_F32: Y3_SB(TT, float); break; \
+                                            case Y3_U8: Y3_SB(TT, unsigned char); break; default: Y3_FAIL("y3_stem_bn_bwd_wgrad: bad source dtype %d", src_dtype); }
+    if (dtype == Y3_F16) { Y3_SB_SRC(f16_t) } else { Y3_SB_SRC(bf16_t) }
+#undef Y3_SB_SRC
+#undef Y3_SB
+    Y3_CHECK_LAUNCH();
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((32 * cin * 9 + 255) / 256), dim3(256), 0, st, (const float*)workspace, blocks, cin, 32, dw_oihw);
+    Y3_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int y3_pack_filter_dgrad(const float* w, int32_t cout_src, int32_t cin_src, int32_t ks, int32_t cout, int32_t cin, int32_t dtype, void* packed,

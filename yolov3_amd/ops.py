@@ -149,6 +149,26 @@ def stem_conv_stats(x_nchw: torch.Tensor, filt: torch.Tensor, bias: torch.Tensor
     return int(rows.value)
 
 
+def stem_bwd_workspace(device) -> torch.Tensor:
+    return torch.empty(int(_lib.lib().y3_stem_bn_bwd_wgrad_workspace_bytes()), dtype=torch.uint8, device=device)
+
+
+def stem_bn_bwd_wgrad(x_nchw: torch.Tensor, u: View, dy: View, scale, shift, mean, invstd, act: int, sums: torch.Tensor, dgamma, dbeta, dw: torch.Tensor,
+                      workspace: torch.Tensor, divisor: float = 1.0):
+    """Layer 0 backward (no data gradient): BatchNorm + activation backward of dy and the filter gradient dw (fp32 OIHW) in one pass over
+    (u, dy) after the reduction pass -- du is never written.  32 filters, <= 3 image channels."""
+    require_gpu(x_nchw, "stem_bn_bwd_wgrad")
+    x = x_nchw.contiguous()
+    n, c, h, w = x.shape
+    if dw.dtype != torch.float32 or not dw.is_contiguous() or tuple(dw.shape) != (32, c, 3, 3):
+        raise TypeError("stem_bn_bwd_wgrad: dw must be a contiguous fp32 (32, cin, 3, 3) tensor")
+    ut, gt = u.y3(), dy.y3()
+    check(_lib.lib().y3_stem_bn_bwd_wgrad(x.data_ptr(), dtype_code(x.dtype), n, c, h, w, float(divisor), C.byref(ut), C.byref(gt), scale.data_ptr(), shift.data_ptr(),
+                                          mean.data_ptr(), invstd.data_ptr(), dtype_code(u.buf.dtype), int(act), sums.data_ptr(),
+                                          dgamma.data_ptr() if dgamma is not None else None, dbeta.data_ptr() if dbeta is not None else None, dw.data_ptr(),
+                                          workspace.data_ptr(), workspace.numel(), stream_ptr()), "y3_stem_bn_bwd_wgrad")
+
+
 def pack_filter_dgrad(w_oihw: torch.Tensor, cout: int, cin: int, dtype: torch.dtype) -> torch.Tensor:
     """OIHW fp32 weights -> filter bank of the data-gradient conv (cin filters over (kh, kw, cout), flipped taps)."""
     require_gpu(w_oihw, "pack_filter_dgrad")

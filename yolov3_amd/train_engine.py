@@ -15,6 +15,7 @@ two consumers, residual connections) needs no special casing.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 from torch import nn
@@ -103,6 +104,11 @@ class ConvUnit(_Unit):
         # the data gradient of this unit runs through the generic dgrad bank (not the stride-2 parity-class banks, not layer 0)
         self.pair_pack = need_dx and plan.dtype in (torch.float16, torch.bfloat16) and not (self.s == 2 and self.k == 3)
 
+    def fused_stem_bwd(self) -> bool:
+        """layer 0 through y3_stem_bn_bwd_wgrad (Y3_STEM_BWD=0: BatchNorm backward + generic filter gradient, for A/B runs)"""
+        return (self.use_stem and self.plan.x_nchw is not None and not self.need_dx and self.res is None and self.cout == 32 and self.ci_real <= 3
+                and os.environ.get("Y3_STEM_BWD", "1") != "0")
+
     def fwd(self):
         m, bn = self.m, self.m.bn
         L = _lib.lib()
@@ -168,9 +174,20 @@ class ConvUnit(_Unit):
         st = ops.stream_ptr()
         dcode = ops.dtype_code(self.plan.dtype)
         gy = self.y.grad()
-        du = self.plan.scratch_like(self.u)
         dgamma = self.plan.grad_alloc((self.cout,))
         dbeta = self.plan.grad_alloc((self.cout,))
+        if self.fused_stem_bwd():
+            # layer 0: no data gradient, so du has one consumer -- the filter gradient; both in one pass over (u, dy), du never stored
+            xi = self.plan.x_nchw
+            if xi._version != self.plan.x_version:
+                raise RuntimeError("the input batch was modified in place between the forward and the backward of this training step")
+            dw = self.plan.grad_alloc(tuple(m.conv.weight.shape))
+            ops.stem_bn_bwd_wgrad(xi, self.u, gy, self.scale, self.shift, self.mean, self.invstd, self.act, self.sums, dgamma, dbeta, dw, self.plan.stem_bwd_ws())
+            grads[m.conv.weight] = dw
+            grads[m.bn.weight] = dgamma
+            grads[m.bn.bias] = dbeta
+            return
+        du = self.plan.scratch_like(self.u)
         ut, gt, dt = self.u.y3(), gy.y3(), du.y3()
         if self.res is not None:  # out = act(bn(conv)) + res  ->  d res (+)= d out, written by the pass that reads d out anyway
             gr = self.res.grad()
@@ -403,7 +420,7 @@ class TrainPlan:
                 raise NotImplementedError(type(k).__name__)
         self.params = list(model.parameters())
         self.x_nchw = None
-        import os
+        self.x_version = 0
 
         # Y3_WGRAD_STREAM=1: filter gradients on a second HIP stream.  Measured at batch 64: backward 48.7 -> 48.0 ms, optimizer wait
         # +0.35 ms -- both kernel families fill the chip on their own, the hardware runs the two queues mostly back to back --
@@ -476,6 +493,12 @@ class TrainPlan:
                 db.record_stream(cur)
                 grads[b_param] = db
 
+    def stem_bwd_ws(self):
+        t = getattr(self, "_stem_bwd_ws", None)
+        if t is None:
+            t = self._stem_bwd_ws = ops.stem_bwd_workspace(self.device)
+        return t
+
     def stat_buffer(self, n_floats):
         """fp32 scratch for the conv epilogue's statistics rows, shared by all units (stream-ordered reuse)."""
         t = getattr(self, "_stat_buf", None)
@@ -515,8 +538,11 @@ class TrainPlan:
         _FORWARD_TICK += 1
         self.last_forward = _FORWARD_TICK   # recency across plans (the slot choice in run_model_train)
         self.generation += 1
-        ops.nchw_to_nhwc(x, self.x_in.view, 1.0)
         self.x_nchw = x if x.dtype in (torch.float32, torch.float16, torch.bfloat16, torch.uint8) else None
+        self.x_version = x._version
+        u0 = self.units[0] if self.units else None
+        if not (isinstance(u0, ConvUnit) and u0.fused_stem_bwd() and self.epilogue_stats):
+            ops.nchw_to_nhwc(x, self.x_in.view, 1.0)   # layer 0 through the generic kernels (or its generic filter gradient) reads the NHWC copy
         with torch.no_grad():
             for u in self.units:
                 u.fwd()
