@@ -82,6 +82,9 @@ int y3_conv2d_fwd_ws(const y3_conv_desc* desc, const y3_tensor* x, const void* p
  * The parity tests assert it so that a tolerance is always attached to the kernel that actually ran. */
 int y3_conv2d_fwd_variant(const y3_conv_desc* desc, const y3_tensor* x, const y3_tensor* y, int32_t has_residual,
                           size_t workspace_bytes, char* name, size_t name_capacity);
+/* Name of the variant the last convolution / data-gradient call of the calling thread launched ("v3_quad": the four output-parity
+ * classes of y3_conv2d_dgrad_s2 in one launch). */
+int y3_conv_last_variant(char* name, size_t name_cap);
 
 /* Stem convolution: the first layer `Conv(ch<=4, 32|64, 3, 1)` (reference models/yolov3.yaml:16, models/common.py:57-81) computed
  * straight from the caller's NCHW image, fused with the ingest (`im.half(); im /= 255`, val.py:354-360): no NHWC copy of the

@@ -906,8 +906,10 @@ WGRAD_CASES = [
     ("head_255", (2, 20, 20, 256, 256, 1, 1), {"cout_real": 255}),
     ("cin32_3x3", (1, 33, 17, 32, 64, 3, 1), {}),
     ("many_pixels", (4, 80, 80, 64, 64, 3, 1), {}),
-    ("3x3s2_even_cin32", (2, 32, 48, 32, 64, 3, 2), {}),
+    ("3x3s2_even_cin32", (2, 32, 48, 32, 64, 3, 2), {"dgrad_variant": "v3_quad"}),
     ("3x3s2_deep", (2, 10, 10, 512, 1024, 3, 2), {}),
+    ("3x3s2_even_5tiles", (3, 36, 44, 64, 128, 3, 2), {"dgrad_variant": "v3_quad"}),     # 5 pixel tiles per class: the last group of 8 block ids is partial
+    ("3x3s2_even_cin128", (2, 64, 64, 128, 256, 3, 2), {"dgrad_variant": "v3_quad"}),
 ]
 
 
@@ -941,6 +943,8 @@ def test_conv_wgrad_and_dgrad_vs_autograd(dev, dtype, name, shape, kw):
         g2 = ops.View.alloc(n, h, w, cin, dtype, dev)
         g2.buf.fill_(float("nan"))
         ops.conv2d_dgrad_s2(wt.detach().to(dev), gv, g2, accumulate=False)
+        if "dgrad_variant" in kw:   # even sizes + a v3 tile: the four parity classes go out as one launch
+            assert ops.last_conv_variant() == kw["dgrad_variant"]
         d2 = g2.as_nhwc().float().cpu().permute(0, 3, 1, 2)[:, :cin_real]
         assert (d2 - x.grad).abs().max().item() / x.grad.abs().max().item() < tol, "dgrad_s2 (write)"
         ops.conv2d_dgrad_s2(wt.detach().to(dev), gv, g2, accumulate=True)

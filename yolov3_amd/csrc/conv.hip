@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_v2_kernel(const ConvArgs p)
 // double-buffered in registers so the ds_read of k-substep s+1 is in flight under the MFMAs of s.
 // WAVES 2x2; per-wave tile (MC*32 couts) x (MP*32 pixels).
 template <typename T, int BK, int MC, int MP>
-__global__ __launch_bounds__(256, (BK == 32 && MC * MP <= 4 ? 4 : 2)) void conv_igemm_v3_kernel(const ConvArgs p) {
+Y3_DEV void conv_igemm_v3_body(const ConvArgs& p, const int block_id, const int n_blocks) {
 #if defined(__HIP_DEVICE_COMPILE__)  // device-only builtins (LDS address space, buffer->LDS DMA): the host pass only needs the stub
     constexpr int WAVES_C = 2, WAVES_P = 2;
     constexpr int TC = WAVES_C * MC * 32;
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256, (BK == 32 && MC * MP <= 4 ? 4 : 2)) void conv_
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wc = wv / WAVES_P, wp = wv % WAVES_P;
 
-    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int L = xcd_remap(block_id, n_blocks);
     const int pt = fdiv(L, p.dv_ct_mul, p.dv_ct_sh), ct = L - pt * p.n_ct;
 
     const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
@@ -603,6 +603,26 @@ __global__ __launch_bounds__(256, (BK == 32 && MC * MP <= 4 ? 4 : 2)) void conv_
     epilogue_wave<T, MC, MP>(p, acc, smem + wv * (MP * 32 * MC * 64), ct * TC + wc * MC * 32, pt * TP + wp * MP * 32, lane, pt * WAVES_P + wp);
     Y3_STAMP(4);
 #endif
+}
+
+template <typename T, int BK, int MC, int MP>
+__global__ __launch_bounds__(256, (BK == 32 && MC * MP <= 4 ? 4 : 2)) void conv_igemm_v3_kernel(const ConvArgs p) {
+    conv_igemm_v3_body<T, BK, MC, MP>(p, blockIdx.x, gridDim.x);
+}
+
+// Four convolutions of the SAME input in one launch: the output-parity classes of a stride-2 data gradient (y3_conv2d_dgrad_s2).  As
+// four launches every class streamed du from HBM again (4 x the 64-channel 320x320 map of layer 1 at batch 64 = 3.4 GB for 1.7 GB of
+// output).  Block ids are laid out so that the four classes of one pixel tile are dispatched back to back on the SAME XCD
+// (id = 32 * (t / 8) + 8 * class + t % 8: the XCD is id % 8 = t % 8), so three of the four reads of a du tile hit that XCD's L2.
+struct ConvArgs4 {
+    ConvArgs a[4];
+};
+template <typename T, int BK, int MC, int MP>
+__global__ __launch_bounds__(256, (BK == 32 && MC * MP <= 4 ? 4 : 2)) void conv_igemm_v3_quad_kernel(const ConvArgs4 q, const int n_blocks) {
+    const int cls = (blockIdx.x >> 3) & 3;
+    const int bid = (int)((blockIdx.x >> 5) << 3) | (int)(blockIdx.x & 7);
+    if (bid >= n_blocks) return;
+    conv_igemm_v3_body<T, BK, MC, MP>(q.a[cls], bid, n_blocks);
 }
 
 // ---- v5: the v3 structure generalised to WAVES_C x WAVES_P waves (8 waves = 512 threads, 256 couts x 256 pixels).
@@ -820,18 +840,37 @@ template <typename T, int BK, int WAVES_C, int WAVES_P, int MC, int MP, int SCHE
     return 0;
 }
 
-template <typename T, int BK, int MC, int MP> int launch_v3(ConvArgs& a, hipStream_t st) {
+// set by y3_conv2d_dgrad_s2 around the dispatch of its last class: the four classes' arguments (same Cout, M and channel counts;
+// only the filter bank, the tap table and the output parity differ) go out as ONE launch of the variant picked for that class
+static thread_local ConvArgs* g_quad = nullptr;
+static thread_local bool g_quad_done = false;
+
+template <typename T, int BK, int MC, int MP> void geometry_v3(ConvArgs& a) {
     constexpr int TC = 2 * MC * 32, TP = 2 * MP * 32;
     a.n_ct = y3_ceil_div(a.Cout, TC);
     a.n_pt = y3_ceil_div(a.M, TP);
     set_divisors(a);
     a.cin_blocks = a.Cin / BK;
     a.nk = a.ntaps * a.cin_blocks;
+    a.stat_wp = 2;
+}
+template <typename T, int BK, int MC, int MP> int launch_v3(ConvArgs& a, hipStream_t st) {
+    geometry_v3<T, BK, MC, MP>(a);
     const long long nb = (long long)a.n_ct * a.n_pt;
     if (nb > 0x7fffffffLL) Y3_FAIL("conv grid too large");
-    a.stat_wp = 2;
     g_last_variant = BK == 64 ? "v3_bk64_128x128" : (MC == 1 ? "v3_bk32_64x256" : (MP == 4 ? "v3_bk32_128x256" : "v3_bk32_128x128"));
     if (a.dry) return 0;
+    if (g_quad && (nb + 7) / 8 * 32 <= 0x7fffffffLL) {
+        ConvArgs4 q;
+        for (int i = 0; i < 4; ++i) {
+            q.a[i] = g_quad[i];
+            geometry_v3<T, BK, MC, MP>(q.a[i]);
+        }
+        hipLaunchKernelGGL((conv_igemm_v3_quad_kernel<T, BK, MC, MP>), dim3((unsigned)((nb + 7) / 8 * 32)), dim3(256), 0, st, q, (int)nb);
+        Y3_CHECK_LAUNCH();
+        g_quad_done = true;
+        return 0;
+    }
     hipLaunchKernelGGL((conv_igemm_v3_kernel<T, BK, MC, MP>), dim3((unsigned)nb), dim3(256), 0, st, a);
     Y3_CHECK_LAUNCH();
     return 0;
@@ -1150,6 +1189,15 @@ extern "C" int y3_conv2d_fwd_variant(const y3_conv_desc* d, const y3_tensor* x, 
     return 0;
 }
 
+// name of the kernel variant the LAST conv / data-gradient call of this thread launched ("v3_quad" = the four parity classes of a
+// stride-2 data gradient in one launch): tests assert the path they mean to exercise
+extern "C" int y3_conv_last_variant(char* name, size_t name_cap) {
+    if (!name || name_cap < 2) Y3_FAIL("y3_conv_last_variant: no room for the name");
+    strncpy(name, g_last_variant, name_cap - 1);
+    name[name_cap - 1] = 0;
+    return 0;
+}
+
 // rows of the statistics buffer the launch described by (desc, x, y) would write (depends on the tile variant dispatched)
 extern "C" int64_t y3_conv2d_fwd_stats_rows(const y3_conv_desc* d, const y3_tensor* x, const y3_tensor* y) {
     int64_t rows = 0;
@@ -1259,6 +1307,8 @@ extern "C" int y3_conv2d_dgrad_s2(int32_t dtype, const y3_tensor* du, const void
     hipStream_t st = (hipStream_t)stream;
     const int cout = du->c, cin = gx->c;
     size_t off = 0;
+    ConvArgs cls[4];
+    bool live[4];
     for (int ph = 0; ph < 2; ++ph)
         for (int pw = 0; pw < 2; ++pw) {
             const S2Class c = s2_class(ph, pw);
@@ -1266,9 +1316,10 @@ extern "C" int y3_conv2d_dgrad_s2(int32_t dtype, const y3_tensor* du, const void
             const int kpad = (int)y3_round_up((size_t)ntaps * cout, 64);
             const int Hc = (H - ph + 1) / 2, Wc = (W - pw + 1) / 2;
             const size_t bank = (size_t)y3_filter_rows(cin) * kpad;
+            ConvArgs& a = cls[ph * 2 + pw];
+            live[ph * 2 + pw] = Hc > 0 && Wc > 0;
+            memset(&a, 0, sizeof(a));
             if (Hc > 0 && Wc > 0) {
-                ConvArgs a;
-                memset(&a, 0, sizeof(a));
                 a.x = du->data; a.w = (const char*)packed4 + off * 2; a.bias = nullptr; a.res = residual ? residual->data : nullptr; a.y = gx->data;
                 a.N = du->n; a.H = du->h; a.W = du->w; a.Cin = cout; a.xpitch = du->pitch;
                 a.Ho = Hc; a.Wo = Wc; a.Cout = cin; a.ypitch = gx->pitch; a.rpitch = residual ? residual->pitch : 0;
@@ -1286,10 +1337,39 @@ extern "C" int y3_conv2d_dgrad_s2(int32_t dtype, const y3_tensor* du, const void
                 a.y_bytes = yb < 0x7fffffffLL ? (unsigned)yb : 0u;
                 a.r_bytes = rb < 0x7fffffffLL ? (unsigned)rb : 0u;
                 if (!a.x_bytes || !a.w_bytes || !a.y_bytes || (residual && !a.r_bytes)) Y3_FAIL("y3_conv2d_dgrad_s2: tensor too large");
-                const int rc = dtype == Y3_F16 ? dispatch_igemm<f16_t>(a, st) : dispatch_igemm<bf16_t>(a, st);
-                if (rc) return rc;
             }
             off += bank;
+        }
+    // all four classes in ONE launch when they share the geometry (even H and W) and the dispatcher picks a v3 tile for the class with
+    // the longest K loop (the 4-tap class: its variant suits the shorter ones); Y3_DGRAD_QUAD=0 keeps the four launches (A/B)
+    static const bool quad_on = [] { const char* e = getenv("Y3_DGRAD_QUAD"); return !(e && atoi(e) == 0); }();
+    bool quad = quad_on && live[0] && live[1] && live[2] && live[3] && cls[0].M == cls[3].M && cls[1].M == cls[3].M && cls[2].M == cls[3].M;
+    if (quad) {
+        int big = 0;
+        for (int i = 1; i < 4; ++i)
+            if (cls[i].ntaps > cls[big].ntaps) big = i;
+        ConvArgs probe = cls[big];
+        probe.dry = 1;
+        const int rc0 = dtype == Y3_F16 ? dispatch_igemm<f16_t>(probe, st) : dispatch_igemm<bf16_t>(probe, st);
+        if (rc0) return rc0;
+        if (strncmp(g_last_variant, "v3_", 3) == 0) {
+            g_quad = cls;
+            g_quad_done = false;
+            ConvArgs lead = cls[big];
+            const int rc = dtype == Y3_F16 ? dispatch_igemm<f16_t>(lead, st) : dispatch_igemm<bf16_t>(lead, st);
+            g_quad = nullptr;
+            if (rc) return rc;
+            if (g_quad_done) {
+                g_last_variant = "v3_quad";
+                return 0;
+            }
+            Y3_FAIL("y3_conv2d_dgrad_s2: the fused launch was not taken");
+        }
+    }
+    for (int i = 0; i < 4; ++i)
+        if (live[i]) {
+            const int rc = dtype == Y3_F16 ? dispatch_igemm<f16_t>(cls[i], st) : dispatch_igemm<bf16_t>(cls[i], st);
+            if (rc) return rc;
         }
     return 0;
 }

@@ -179,6 +179,13 @@ def pack_filter_dgrad(w_oihw: torch.Tensor, cout: int, cin: int, dtype: torch.dt
     return out
 
 
+def last_conv_variant() -> str:
+    """variant name of the last conv / data-gradient launch of this thread (tests)"""
+    buf = C.create_string_buffer(64)
+    check(_lib.lib().y3_conv_last_variant(buf, 64), "y3_conv_last_variant")
+    return buf.value.decode()
+
+
 def conv2d_dgrad_s2(w_oihw: torch.Tensor, du: View, gx: View, accumulate: bool):
     """Data gradient of a 3x3 stride-2 conv through the four output-parity class convolutions (f16/bf16)."""
     dt = du.buf.dtype
