@@ -123,3 +123,22 @@ def test_stem_pair_eligibility(monkeypatch):
     assert eligible("yolov3") and eligible("yolov3-spp") and not eligible("yolov3-tiny")
     monkeypatch.setenv("Y3_STEM_PAIR", "0")
     assert not eligible("yolov3")
+
+
+def test_bneck_pair_eligibility(monkeypatch):
+    """Only Bottleneck(64, 64) (cv1 64 -> 32 1x1, cv2 32 -> 64 3x3: layer 2 of yolov3 / yolov3-spp) on a 64-channel half-precision view
+    takes the one-kernel form; the wider bottlenecks, fp32 plans and Y3_BNECK_PAIR=0 keep the two generic launches."""
+    from types import SimpleNamespace
+
+    from yolov3_amd import DetectionModel
+    from yolov3_amd import engine as e
+
+    m = DetectionModel("yolov3.yaml").eval()
+    b2, b4 = m.model[2], m.model[4][0]
+    v64, v128 = SimpleNamespace(c=64), SimpleNamespace(c=128)
+    monkeypatch.delenv("Y3_BNECK_PAIR", raising=False)
+    assert e._bneck_pair_eligible(b2, v64, torch.float16) and e._bneck_pair_eligible(b2, v64, torch.bfloat16)
+    assert not e._bneck_pair_eligible(b2, v64, torch.float32)
+    assert not e._bneck_pair_eligible(b4, v128, torch.float16)
+    monkeypatch.setenv("Y3_BNECK_PAIR", "0")
+    assert not e._bneck_pair_eligible(b2, v64, torch.float16)

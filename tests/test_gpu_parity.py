@@ -1450,6 +1450,22 @@ def test_stem_pair_matches_unfused_model(dev, monkeypatch):
         assert (a - b).abs().max().item() <= 2.0**-9 * b.abs().max().item()
 
 
+def test_bneck_pair_matches_unfused_model(dev, monkeypatch):
+    """yolov3 forward with layer 2 (Bottleneck(64, 64)) as one kernel against the same model with Y3_BNECK_PAIR=0 (two generic
+    launches): the plan uses the kernel, and the raw head tensors agree up to fp32 summation order."""
+    x = torch.rand(2, 3, 96, 128, generator=torch.Generator().manual_seed(4))
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("Y3_BNECK_PAIR", flag)
+        m, _ = build_pair("yolov3", 80, 21, dev, torch.float16)
+        pred, raw = m(x.to(dev).half())
+        kinds = [ln.kernel for ln in next(iter(m._plans.values())).launches]
+        assert ("bneck_pair" in kinds) == (flag == "1")
+        outs.append([r.float().cpu() for r in raw])
+    for a, b in zip(*outs):
+        assert (a - b).abs().max().item() <= 2.0**-9 * b.abs().max().item()
+
+
 # ------------------------------------------------------------------------------------------------ round 2: plans, scaling traps, exchange step, checkpoints
 def test_plans_survive_deepcopy_and_checkpoint_roundtrip(dev, tmp_path):
     """After a real forward (plans + packed filters exist) the reference's checkpoint path must work: deepcopy(model) (ModelEMA),
@@ -1784,3 +1800,54 @@ def test_stem_bn_bwd_wgrad_matches_unfused_backward(dev, dtype, shape, sdt, div,
     dw_ref = torch.nn.grad.conv2d_weight(xq, (cout, cin, 3, 3), du_ref, stride=1, padding=1)
     err = (dw1.cpu() - dw_ref).abs().max().item() / dw_ref.abs().max().item()
     assert err < (4e-3 if dtype == torch.float16 else 3e-2), f"dW vs fp32 autograd: {err:.3e}"
+
+
+BNECK_CASES = [
+    ("square", (2, 64, 64), True),
+    ("odd_rect", (1, 37, 53), True),
+    ("many_tiles_per_block", (9, 96, 224), True),      # 9 * 12 * 7 = 756 tiles > 512 persistent blocks: the grid-stride loop and its DMA prefetch
+    ("smaller_than_a_tile", (1, 5, 7), True),
+    ("no_shortcut", (2, 40, 72), False),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name,shape,add", BNECK_CASES, ids=[c[0] for c in BNECK_CASES])
+def test_bneck_pair_vs_fp32_reference(dev, dtype, name, shape, add):
+    """y3_bneck_pair_fwd (Bottleneck(64, 64) in one kernel, the 32-channel intermediate kept in LDS) against torch fp32 convolutions on
+    the same rounded operands, the intermediate rounded to the storage dtype as the two-launch form stores it and the residual added
+    to the ROUNDED cv2 output (what `x + cv2(cv1(x))` does on half tensors); borders (cv2's zero padding applies to cv1's OUTPUT), odd
+    sizes, images smaller than a tile; and bit-compared with the two generic launches it replaces where those exist."""
+    _lib, ops = _ops()
+    n, h, w = shape
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(n, 64, h, w, generator=g).to(dtype)
+    w1 = (torch.randn(32, 64, 1, 1, generator=g) / 8.0).to(dtype).float()
+    b1 = torch.randn(32, generator=g) * 0.1
+    w2 = (torch.randn(64, 32, 3, 3, generator=g) / math.sqrt(288)).to(dtype).float()
+    b2 = torch.randn(64, generator=g) * 0.1
+    t = F.silu(F.conv2d(x.float(), w1, b1)).to(dtype).float()
+    ref = F.silu(F.conv2d(t, w2, b2, padding=1)).to(dtype).float()
+    if add:
+        ref = ref + x.float()
+    xv = ops.View.alloc(n, h, w, 64, dtype, dev)
+    ops.nchw_to_nhwc(x.to(dev), xv)
+    f1 = ops.pack_filter(w1.to(dev), 32, 64, dtype)
+    f2 = ops.pack_filter(w2.to(dev), 64, 32, dtype)
+    b1d, b2d = b1.to(dev), b2.to(dev)
+    yv = ops.View.alloc(n, h, w, 64, dtype, dev)
+    yv.buf.fill_(float("nan"))
+    ops.bneck_pair(xv, f1, b1d, True, f2, b2d, True, add, yv)
+    torch.cuda.synchronize()
+    got = yv.as_nhwc().float().cpu().permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all(), "an output pixel was not written"
+    tol = 2.0**-8 if dtype == torch.float16 else 2.0**-5
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err < tol, f"{name} {dtype}: {err:.2e}"
+    # the two launches it replaces: same arithmetic up to fp32 summation order inside each conv
+    tv, y2 = ops.View.alloc(n, h, w, 32, dtype, dev), ops.View.alloc(n, h, w, 64, dtype, dev)
+    ops.conv2d(xv, f1, b1d, tv, 1, 1, True)
+    ops.conv2d(tv, f2, b2d, y2, 3, 1, True, residual=xv if add else None)
+    torch.cuda.synchronize()
+    two = y2.as_nhwc().float().cpu().permute(0, 3, 1, 2)
+    assert (got - two).abs().max().item() <= 2 * tol * ref.abs().max().item()

@@ -17,6 +17,7 @@ NAMES = [  # (regex on the kernel symbol, bench.py name = "conv_igemm_" + the li
     (r"conv_igemm_v3_kernelIDF16_Li32ELi1ELi4E", "conv_igemm_v3_bk32_64x256"),
     (r"conv_igemm_v2_kernelIDF16_Li32ELi1ELi4ELi1ELi2ELb1E", "conv_igemm_v2_smallc"),
     (r"stem_pair_kernel", "stem_pair"),
+    (r"bneck_pair_kernel", "bneck_pair"),
     (r"stem_conv_kernel", "stem_conv"),
     (r"decode_vec_kernel", "decode_vec"),
     (r"nms_candidates_kernel", "nms_candidates"),

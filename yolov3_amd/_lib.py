@@ -91,6 +91,7 @@ _SIGNATURES = {
         C.c_int,
         [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P(Y3NmsParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p],
     ),
+    "y3_bneck_pair_fwd": (C.c_int, [_P(Y3Tensor), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _P(Y3Tensor), C.c_void_p]),
     "y3_stem_pair_fwd": (
         C.c_int,
         [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, _P(Y3Tensor),

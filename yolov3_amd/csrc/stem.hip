@@ -461,6 +461,257 @@ __global__ __launch_bounds__(256, 2) void stem_pair_kernel(const PairArgs p) {
 #endif
 }
 
+// ---- Bottleneck(64, 64) in one kernel -----------------------------------------------------------------------------------------
+// models/yolov3.yaml:18 (layer 2): x + cv2(cv1(x)), cv1 = Conv(64, 32, 1, 1), cv2 = Conv(32, 64, 3, 1), on the 320x320 map.  As two
+// launches the 32-channel intermediate (210 MB at batch 32) is written and read back and x is read twice (cv1's input, cv2's
+// residual): 1.68 GB of HBM traffic for 0.84 GB of input + output, both launches HBM-bound (0.13 + 0.28 ms of a 7 ms forward).
+// Here a block owns an 8 x 32 tile of output pixels: the 10 x 34 pixel patch of x goes to LDS once (prefetched into registers under
+// the previous tile's MFMAs), cv1 (+ bias + SiLU, rounded to T as the stored tensor would be, zero outside the image = cv2's
+// padding) runs on the 340 patch pixels into LDS, cv2 reads its nine taps out of LDS with the wave's 18 filter fragments resident in
+// registers (the layer-1 half of stem_pair with stride 1), and the residual comes from the x patch already in LDS.
+struct BneckArgs {
+    const void* x;      // NHWC (N, H, W, 64)
+    const void* w1;     // generic packed bank of cv1 [>= 32 rows][kpad1 = 64], k = ci
+    const float* b1;    // 32 floats
+    const void* w2;     // generic packed bank of cv2 [>= 64 rows][kpad2], k = (kh * 3 + kw) * 32 + ci
+    const float* b2;    // 64 floats
+    void* y;            // NHWC (N, H, W, 64)
+    int N, H, W, xpitch, ypitch, act1, act2, add, kpad1, kpad2;
+    int tiles_w, tiles_h, n_tiles;
+    unsigned x_bytes;   // extent of x for the buffer descriptor of the LDS-DMA loads
+};
+constexpr int BR = 8, BC = 32;                    // output rows x columns per tile
+constexpr int RR = BR + 2, RC = BC + 2;           // cv1 region: 10 x 34 pixels
+constexpr int RPX = RR * RC;                      // 340
+constexpr int NT1 = (RPX + 31) / 32;              // cv1 MFMA pixel tiles per region: 11
+constexpr int L1PITCH = 40;                       // cv1-output pixels per region row in LDS (64 B each).  40 = 2 mod 4 x ... : the chunk swizzle key
+                                                  // ((row * 40 + col) >> 2) & 3 = ((col >> 2) & 3) ^ 2 (row & 1): the row term only swaps the two k-halves
+constexpr int XPIECES = (RPX * 8 + 63) / 64;      // 1 KiB LDS-DMA pieces of the x patch: 43 (the last one half empty)
+constexpr int XJ = (XPIECES + 3) / 4;             // pieces per wave: 11
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void bneck_pair_kernel(const BneckArgs p) {
+    typedef typename Mfma16<T>::frag frag;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    __shared__ __attribute__((aligned(16))) unsigned char xbuf[XPIECES * 1024];         // x patch, pixel q (flattened region index): chunk c at c ^ ((q >> 1) & 7)
+    __shared__ __attribute__((aligned(16))) unsigned char l1buf[RR * L1PITCH * 64];     // cv1 output, pixel (r, c): chunk c at c ^ key(r, c)
+    __shared__ __attribute__((aligned(16))) unsigned char slices[4 * 32 * 64];
+    __shared__ __attribute__((aligned(16))) float cb1[32], cb2[64];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 31, fk = lane >> 5;
+    const int wc = wv >> 1, wp = wv & 1;   // cv2: filter tile, group of four output rows
+
+    if (tid < 8) ((f32x4*)cb1)[tid] = ((const f32x4*)p.b1)[tid];
+    else if (tid < 24) ((f32x4*)cb2)[tid - 8] = ((const f32x4*)p.b2)[tid - 8];
+    frag a2f[18];
+#pragma unroll
+    for (int t = 0; t < 18; ++t) a2f[t] = *(const frag*)((const T*)p.w2 + (long long)(wc * 32 + frow) * p.kpad2 + t * 16 + fk * 8);
+
+    // ---- per-lane constants (tile independent; everything that advances with the piece / pixel-tile index is recomputed incrementally
+    // per tile: kept in registers for the block's life the tables were spilled) ----
+    // x patch by LDS-DMA (`buffer_load ... lds`: the wave's 64 lanes fill 64 consecutive 16-byte slots): piece wv + 4 j = 8 pixels x 8 chunks,
+    // lane -> pixel q = 8 wv + (lane >> 3) + 32 j, physical chunk lane & 7 = logical chunk ^ ((q >> 1) & 7) -- the key does not depend on j
+    // (32 j >> 1 = 0 mod 8) -- and the swizzle is applied on the SOURCE address
+    const int xq0 = 8 * wv + (lane >> 3);                                  // < 32 < RC: region row 0, column xq0
+    const unsigned xsrc = (unsigned)(((lane & 7) ^ ((xq0 >> 1) & 7)) * 16);   // byte offset of the chunk within the pixel
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    // cv1: MFMA pixel tile wv + 4 j, pixel q = 32 wv + frow + 128 j: the xbuf key (q >> 1) & 7 does not depend on j either
+    constexpr int NJ1 = (NT1 + 3) / 4;
+    const int c1q0 = 32 * wv + frow;
+    const int c1r0 = c1q0 / RC, c1c0 = c1q0 - c1r0 * RC;
+    const int c1rd0 = c1q0 * 128 + ((fk ^ ((c1q0 >> 1) & 7)) << 4);       // + 128 * 128 j; k-step ks: ^ (32 ks)
+    // cv2: lane's column frow + kw, k-chunk 2 ks + fk of an EVEN region row (odd rows: ks ^ 1)
+    int c2rd[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) c2rd[kw] = (frow + kw) * 64 + ((fk ^ (((frow + kw) >> 2) & 3)) << 4);
+
+    T* __restrict__ yg = (T*)p.y;
+    auto fetch = [&](int tile) {   // the tile's 10 x 34 pixel patch of x -> xbuf, zeros outside the image (out-of-range offsets read 0)
+        int b = tile;
+        const int tw = b % p.tiles_w; b /= p.tiles_w;
+        const int th = b % p.tiles_h;
+        const int n = b / p.tiles_h;
+        const int gh0 = th * BR - 1, gw0 = tw * BC - 1;
+        int r = 0, c = xq0;
+#pragma unroll
+        for (int j = 0; j < XJ; ++j) {
+            if (wv + 4 * j >= XPIECES) break;
+            const int gh = gh0 + r, gw = gw0 + c;
+            const bool ok = xq0 + 32 * j < RPX && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W;
+            const unsigned off = ok ? (unsigned)(((n * p.H + gh) * p.W + gw) * p.xpitch) * 2u + xsrc : 0xffffffffu;
+            // by inline asm: issued through the builtin, the compiler waits for the pieces (vmcnt(0)) in front of the first LDS access that
+            // follows -- it cannot tell that they land in xbuf while cv2 reads l1buf -- and the patch no longer streams in under the MFMAs.
+            // The counted wait is the explicit vmcnt(0) at the top of the next tile.
+            const unsigned ldsa = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_ptr_t)xbuf + (unsigned)((wv + 4 * j) * 1024));
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(ldsa), "v"(off), "s"(rs_x) : "memory");
+            c += 32;
+            if (c >= RC) { c -= RC; r += 1; }
+        }
+    };
+    if ((int)blockIdx.x < p.n_tiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+        int b = tile;
+        const int tw = b % p.tiles_w; b /= p.tiles_w;
+        const int th = b % p.tiles_h;
+        const int n = b / p.tiles_h;
+        const int oh0 = th * BR, ow0 = tw * BC;
+        const int gh0 = oh0 - 1, gw0 = ow0 - 1;   // image coordinates of region pixel (0, 0)
+        const bool border = gh0 < 0 || gw0 < 0 || gh0 + RR > p.H || gw0 + RC > p.W;
+
+        frag a1f[4];   // cv1's filters: 4 KB in L1 / L2, re-read per tile (16 registers the K loop of cv2 needs more)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a1f[t] = *(const frag*)((const T*)p.w1 + (long long)frow * p.kpad1 + t * 16 + fk * 8);
+        // this wave's pieces of the patch (requested one tile ago) have landed.  The filter fragments are operands of the wait: the compiler
+        // then knows its own loads are complete too and does not put a vmcnt(0) of its own in front of cv2 (where it would wait for the
+        // NEXT tile's pieces, issued just before)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(a1f[0]), "+v"(a1f[1]), "+v"(a1f[2]), "+v"(a1f[3]) : : "memory");
+        __syncthreads();
+
+        // ---- cv1 (1 x 1, K = 64) on the region -> l1buf ----
+        int r1 = c1r0, c1 = c1c0;
+#pragma unroll
+        for (int j = 0; j < NJ1; ++j) {
+            if (wv + 4 * j >= NT1) break;
+            f32x16 acc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[4 * g + e] = cb1[8 * g + 4 * fk + e];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) acc = Mfma16<T>::run(a1f[ks], *(const frag*)(xbuf + ((c1rd0 + j * (128 * 128)) ^ (ks << 5))), acc);
+            if (p.act1 == Y3_ACT_SILU) silu_vec<f32x16, 16>(acc);
+            const bool live = c1q0 + 128 * j < RPX;   // the last pixel tile is partly beyond the region (its reads stay inside xbuf's padding)
+            bool inside = true;
+            if (border) inside = (unsigned)(gh0 + r1) < (unsigned)p.H && (unsigned)(gw0 + c1) < (unsigned)p.W;
+            const int wr = (r1 * L1PITCH + c1) * 64 + ((fk ^ ((c1 >> 2) & 3) ^ ((r1 & 1) << 1)) << 4);   // chunk 2 gp + fk -> ^ (32 gp)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                u32x4 ov;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(pack2<T>(acc[8 * gp + 2 * h], acc[8 * gp + 2 * h + 1]),
+                                                                     pack2<T>(acc[8 * gp + 4 + 2 * h], acc[8 * gp + 4 + 2 * h + 1]), false, false);
+                    ov[h] = inside ? (unsigned)sw[0] : 0u;
+                    ov[2 + h] = inside ? (unsigned)sw[1] : 0u;
+                }
+                if (live) *(u32x4*)(l1buf + (wr ^ (gp << 5))) = ov;
+            }
+            c1 += 128 - 3 * RC;   // pixel + 128 = 3 region rows + 26 columns
+            r1 += 3;
+            if (c1 >= RC) { c1 -= RC; r1 += 1; }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        // xbuf is dead (the residual is re-read from global memory below: those lines sit in L2): the next tile's patch streams into it
+        // under this tile's MFMAs
+        {
+            int nt = tile + (int)gridDim.x;
+            asm volatile("" : "+s"(nt));   // the piece addresses are computed HERE: scheduled to the top of the tile they lived in scratch until now,
+                                           // and every reload's vmcnt(0) waited for the previous piece -- eleven serial round trips per tile
+            if (nt < p.n_tiles) fetch(nt);
+        }
+        // ---- cv2: D[32 filters of tile wc][32 columns] for output rows 4 wp .. 4 wp + 3, K = 9 taps x 32 channels out of l1buf ----
+        f32x16 acc2[4];
+#pragma unroll
+        for (int b2 = 0; b2 < 4; ++b2)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc2[b2][4 * g + e] = cb2[wc * 32 + 8 * g + 4 * fk + e];
+        const unsigned char* l1w = l1buf + (4 * wp) * (L1PITCH * 64);
+        // the four fragments of k-step s + 1 are read while the four MFMAs of step s run; scheduling fences keep it at that (left alone the
+        // compiler hoisted dozens of reads and spilled the resident filter fragments to make room)
+        auto rd = [&](auto step_c, frag (&bf)[4]) {   // step = 2 tap + ks
+            constexpr int tap = decltype(step_c)::value >> 1, ks = decltype(step_c)::value & 1, kh = tap / 3, kw = tap - 3 * (tap / 3);
+#pragma unroll
+            for (int b2 = 0; b2 < 4; ++b2) {
+                const int rr = b2 + kh;   // region row minus 4 wp (even): its parity decides which k-half sits where
+                bf[b2] = *(const frag*)(l1w + rr * (L1PITCH * 64) + (c2rd[kw] ^ ((ks ^ (rr & 1)) << 5)));
+            }
+        };
+        auto mm = [&](auto step_c, const frag (&bf)[4]) {
+#pragma unroll
+            for (int b2 = 0; b2 < 4; ++b2) acc2[b2] = Mfma16<T>::run(a2f[decltype(step_c)::value], bf[b2], acc2[b2]);
+        };
+        frag bA[4], bB[4];
+        rd(std::integral_constant<int, 0>{}, bA);
+        __builtin_amdgcn_sched_barrier(0);
+#define Y3_BN_STEP(S0, CUR, NXT) rd(std::integral_constant<int, S0 + 1>{}, NXT); mm(std::integral_constant<int, S0>{}, CUR); __builtin_amdgcn_sched_barrier(0);
+        Y3_BN_STEP(0, bA, bB) Y3_BN_STEP(1, bB, bA) Y3_BN_STEP(2, bA, bB) Y3_BN_STEP(3, bB, bA) Y3_BN_STEP(4, bA, bB) Y3_BN_STEP(5, bB, bA)
+        Y3_BN_STEP(6, bA, bB) Y3_BN_STEP(7, bB, bA) Y3_BN_STEP(8, bA, bB) Y3_BN_STEP(9, bB, bA) Y3_BN_STEP(10, bA, bB) Y3_BN_STEP(11, bB, bA)
+        Y3_BN_STEP(12, bA, bB) Y3_BN_STEP(13, bB, bA) Y3_BN_STEP(14, bA, bB) Y3_BN_STEP(15, bB, bA) Y3_BN_STEP(16, bA, bB)
+#undef Y3_BN_STEP
+        mm(std::integral_constant<int, 17>{}, bB);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- activation, 8 consecutive filters per lane, transpose through the wave's slice, residual from the x patch, 64-byte runs ----
+        u32x4 xres[8];   // residual x[pixel][this wave's 32 channels], in the store layout of the epilogue
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));   // (same reason: the epilogue's addresses are computed after the K loop, not carried through it)
+        const int rp = lane_o >> 2, ch = lane_o & 3;
+        if (p.add) {   // bounds-checked descriptor loads (out-of-range lanes carry offset 0xffffffff and read 0): straight-line, all eight in flight
+                       // under the SiLU pass below -- behind `if (inside)` branches each was issued at its use and waited for alone
+            const int pix0 = ((n * p.H + oh0 + 4 * wp) * p.W + ow0) * p.xpitch + wc * 32 + ch * 8;   // elements: < 2^30 (x_bytes < 2^31)
+#pragma unroll
+            for (int b2 = 0; b2 < 4; ++b2)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int pl = i * 16 + rp;
+                    const bool ok = oh0 + 4 * wp + b2 < p.H && ow0 + pl < p.W;
+                    xres[b2 * 2 + i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? (unsigned)(pix0 + (b2 * p.W + pl) * p.xpitch) * 2u : 0xffffffffu, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        unsigned char* wl = slices + wv * (32 * 64);
+        if (p.act2 == Y3_ACT_SILU) {
+#pragma unroll
+            for (int b2 = 0; b2 < 4; ++b2) {
+                silu_vec<f32x16, 16>(acc2[b2]);
+                __builtin_amdgcn_sched_barrier(0);   // one accumulator at a time: 16 temporaries, not 64
+            }
+        }
+        const long long ybase = ((long long)(n * p.H + oh0 + 4 * wp) * p.W + ow0) * p.ypitch + wc * 32 + ch * 8;
+#pragma unroll
+        for (int b2 = 0; b2 < 4; ++b2) {
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                u32x4 ov;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(pack2<T>(acc2[b2][8 * gp + 2 * h], acc2[b2][8 * gp + 2 * h + 1]),
+                                                                     pack2<T>(acc2[b2][8 * gp + 4 + 2 * h], acc2[b2][8 * gp + 4 + 2 * h + 1]), false, false);
+                    ov[h] = (unsigned)sw[0];
+                    ov[2 + h] = (unsigned)sw[1];
+                }
+                const int chunk = gp * 2 + fk;
+                *(u32x4*)(wl + frow * 64 + ((chunk ^ (frow & 3)) << 4)) = ov;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int orow = 4 * wp + b2;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int pl = i * 16 + rp;
+                frag ov = *(const frag*)(wl + pl * 64 + ((ch ^ (pl & 3)) << 4));
+                if (p.add) {   // x + cv2(cv1(x)): fp32 sum of the two stored values, rounded once
+                    const frag xr = __builtin_bit_cast(frag, xres[b2 * 2 + i]);
+                    u32x4 sum;
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) sum[e >> 1] = pack2<T>(to_f32<T>(ov[e]) + to_f32<T>(xr[e]), to_f32<T>(ov[e + 1]) + to_f32<T>(xr[e + 1]));
+                    ov = __builtin_bit_cast(frag, sum);
+                }
+                if (oh0 + orow < p.H && ow0 + pl < p.W) *(frag*)(yg + ybase + (long long)(b2 * p.W + pl) * p.ypitch) = ov;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();   // the slice is rewritten by the next row
+        }
+        __syncthreads();   // xbuf, l1buf and the slices are rewritten by the next tile
+    }
+}
+
 template <typename T>
 __global__ void pack_stem_kernel(const float* __restrict__ src, int cout_src, int cin_src, int rows, T* __restrict__ dst) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -601,4 +852,35 @@ extern "C" int y3_stem_pair_fwd(const void* x_nchw, int32_t src_dtype, int32_t n
         case Y3_BF16: return dispatch_pair<bf16_t>(a, src_dtype, tiles, st);
     }
     Y3_FAIL("y3_stem_pair_fwd: f16/bf16 compute only");
+}
+
+extern "C" int y3_bneck_pair_fwd(const y3_tensor* x, const void* packed1, const float* bias1, int32_t act1, const void* packed2, const float* bias2, int32_t act2,
+                                 int32_t add_residual, int32_t dtype, const y3_tensor* y, void* stream) {
+    if (!x || !x->data || !packed1 || !bias1 || !packed2 || !bias2 || !y || !y->data) Y3_FAIL("y3_bneck_pair_fwd: null argument");
+    if (x->c != 64 || y->c != 64) Y3_FAIL("y3_bneck_pair_fwd: Bottleneck(64, 64) only (cv1 64 -> 32, cv2 32 -> 64), got %d -> %d channels", x->c, y->c);
+    if (y->n != x->n || y->h != x->h || y->w != x->w) Y3_FAIL("y3_bneck_pair_fwd: output shape");
+    if ((x->pitch % 8) || (y->pitch % 8) || ((uintptr_t)x->data & 15) || ((uintptr_t)y->data & 15) || ((uintptr_t)packed1 & 15) || ((uintptr_t)packed2 & 15) ||
+        ((uintptr_t)bias1 & 15) || ((uintptr_t)bias2 & 15))
+        Y3_FAIL("y3_bneck_pair_fwd: 16-byte aligned views");
+    if (x->data == y->data) Y3_FAIL("y3_bneck_pair_fwd: in-place operation is not supported (tiles read their neighbours' input)");
+    BneckArgs a;
+    a.x = x->data; a.w1 = packed1; a.b1 = bias1; a.w2 = packed2; a.b2 = bias2; a.y = y->data;
+    a.N = x->n; a.H = x->h; a.W = x->w; a.xpitch = x->pitch; a.ypitch = y->pitch; a.act1 = act1; a.act2 = act2; a.add = add_residual ? 1 : 0;
+    a.kpad1 = y3_filter_kpad(64, 1); a.kpad2 = y3_filter_kpad(32, 3);
+    a.tiles_w = (x->w + BC - 1) / BC; a.tiles_h = (x->h + BR - 1) / BR;
+    const long long tiles = (long long)a.tiles_w * a.tiles_h * x->n;
+    if (tiles > 0x7fffffffLL || (long long)x->n * x->h * x->w > 0x7fffffffLL) Y3_FAIL("y3_bneck_pair_fwd: too many pixels");
+    a.n_tiles = (int)tiles;
+    const long long xb = (((long long)x->n * x->h * x->w - 1) * x->pitch + x->c) * 2;
+    if (xb >= 0x7fffffffLL) Y3_FAIL("y3_bneck_pair_fwd: input beyond the 2 GiB reach of a buffer descriptor (split the batch)");
+    a.x_bytes = (unsigned)xb;
+    const int blocks = tiles < 512 ? (int)tiles : 512;   // persistent: 2 blocks per CU
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case Y3_F16: hipLaunchKernelGGL((bneck_pair_kernel<f16_t>), dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+        case Y3_BF16: hipLaunchKernelGGL((bneck_pair_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+        default: Y3_FAIL("y3_bneck_pair_fwd: f16/bf16 only");
+    }
+    Y3_CHECK_LAUNCH();
+    return 0;
 }
