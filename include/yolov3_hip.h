@@ -108,10 +108,10 @@ int y3_stem_conv_fwd_stats(const void* x_nchw, int32_t src_dtype, int32_t n, int
 int y3_stem_pair_fwd(const void* x_nchw, int32_t src_dtype, int32_t n, int32_t cin, int32_t h, int32_t w, float divisor,
                      const void* packed0, const float* bias0, int32_t act0, const void* packed1, const float* bias1, int32_t act1,
                      int32_t dtype, const y3_tensor* y, void* stream);
-/* Bottleneck(64, 64) of models/yolov3.yaml:18 (layer 2) in one kernel: y = [x +] cv2(cv1(x)) with cv1 = 1x1 conv 64 -> 32 (+ bias1, act1)
- * and cv2 = 3x3 stride-1 conv 32 -> 64 (+ bias2, act2); the 32-channel intermediate (rounded to the storage dtype as the two-launch
- * form stores it) stays in LDS and x is read once.  packed1 / packed2: generic banks (y3_pack_filter) of 32 x (1x1x64) and 64 x (3x3x32).
- * x, y: NHWC (n, h, w, 64) views, not aliased. */
+/* Bottleneck(C, C), C = 64 or 128 (models/yolov3.yaml:18,20: layers 2 and 4) in one kernel: y = [x +] cv2(cv1(x)) with cv1 = 1x1 conv
+ * C -> C/2 (+ bias1, act1) and cv2 = 3x3 stride-1 conv C/2 -> C (+ bias2, act2); the C/2-channel intermediate (rounded to the storage
+ * dtype as the two-launch form stores it) stays in LDS and x is read once.  packed1 / packed2: generic banks (y3_pack_filter) of
+ * C/2 x (1x1xC) and C x (3x3xC/2).  x, y: NHWC (n, h, w, C) views, not aliased. */
 int y3_bneck_pair_fwd(const y3_tensor* x, const void* packed1, const float* bias1, int32_t act1, const void* packed2, const float* bias2,
                       int32_t act2, int32_t add_residual, int32_t dtype, const y3_tensor* y, void* stream);
 

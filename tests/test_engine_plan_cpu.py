@@ -126,19 +126,23 @@ def test_stem_pair_eligibility(monkeypatch):
 
 
 def test_bneck_pair_eligibility(monkeypatch):
-    """Only Bottleneck(64, 64) (cv1 64 -> 32 1x1, cv2 32 -> 64 3x3: layer 2 of yolov3 / yolov3-spp) on a 64-channel half-precision view
-    takes the one-kernel form; the wider bottlenecks, fp32 plans and Y3_BNECK_PAIR=0 keep the two generic launches."""
+    """Bottleneck(64, 64) and Bottleneck(128, 128) (layers 2 and 4 of yolov3 / yolov3-spp) on half-precision views take the one-kernel form;
+    the wider bottlenecks, fp32 plans and Y3_BNECK_PAIR=0 keep the two generic launches (Y3_BNECK_PAIR=64: only C = 64)."""
     from types import SimpleNamespace
 
     from yolov3_amd import DetectionModel
     from yolov3_amd import engine as e
 
     m = DetectionModel("yolov3.yaml").eval()
-    b2, b4 = m.model[2], m.model[4][0]
-    v64, v128 = SimpleNamespace(c=64), SimpleNamespace(c=128)
+    b2, b4, b6 = m.model[2], m.model[4][0], m.model[6][0]
+    v64, v128, v256 = SimpleNamespace(c=64), SimpleNamespace(c=128), SimpleNamespace(c=256)
     monkeypatch.delenv("Y3_BNECK_PAIR", raising=False)
     assert e._bneck_pair_eligible(b2, v64, torch.float16) and e._bneck_pair_eligible(b2, v64, torch.bfloat16)
+    assert e._bneck_pair_eligible(b4, v128, torch.float16)
     assert not e._bneck_pair_eligible(b2, v64, torch.float32)
-    assert not e._bneck_pair_eligible(b4, v128, torch.float16)
+    assert not e._bneck_pair_eligible(b6, v256, torch.float16)
+    assert not e._bneck_pair_eligible(b4, v64, torch.float16)      # channel count of the view and of the module disagree
+    monkeypatch.setenv("Y3_BNECK_PAIR", "64")
+    assert e._bneck_pair_eligible(b2, v64, torch.float16) and not e._bneck_pair_eligible(b4, v128, torch.float16)
     monkeypatch.setenv("Y3_BNECK_PAIR", "0")
     assert not e._bneck_pair_eligible(b2, v64, torch.float16)

@@ -1811,31 +1811,33 @@ BNECK_CASES = [
 ]
 
 
+@pytest.mark.parametrize("c", [64, 128])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("name,shape,add", BNECK_CASES, ids=[c[0] for c in BNECK_CASES])
-def test_bneck_pair_vs_fp32_reference(dev, dtype, name, shape, add):
-    """y3_bneck_pair_fwd (Bottleneck(64, 64) in one kernel, the 32-channel intermediate kept in LDS) against torch fp32 convolutions on
+def test_bneck_pair_vs_fp32_reference(dev, dtype, name, shape, add, c):
+    """y3_bneck_pair_fwd (Bottleneck(64, 64) / Bottleneck(128, 128) in one kernel, the C/2-channel intermediate kept in LDS) against torch fp32 convolutions on
     the same rounded operands, the intermediate rounded to the storage dtype as the two-launch form stores it and the residual added
     to the ROUNDED cv2 output (what `x + cv2(cv1(x))` does on half tensors); borders (cv2's zero padding applies to cv1's OUTPUT), odd
     sizes, images smaller than a tile; and bit-compared with the two generic launches it replaces where those exist."""
     _lib, ops = _ops()
     n, h, w = shape
     g = torch.Generator().manual_seed(23)
-    x = torch.randn(n, 64, h, w, generator=g).to(dtype)
-    w1 = (torch.randn(32, 64, 1, 1, generator=g) / 8.0).to(dtype).float()
-    b1 = torch.randn(32, generator=g) * 0.1
-    w2 = (torch.randn(64, 32, 3, 3, generator=g) / math.sqrt(288)).to(dtype).float()
-    b2 = torch.randn(64, generator=g) * 0.1
+    cm = c // 2
+    x = torch.randn(n, c, h, w, generator=g).to(dtype)
+    w1 = (torch.randn(cm, c, 1, 1, generator=g) / math.sqrt(c)).to(dtype).float()
+    b1 = torch.randn(cm, generator=g) * 0.1
+    w2 = (torch.randn(c, cm, 3, 3, generator=g) / math.sqrt(9 * cm)).to(dtype).float()
+    b2 = torch.randn(c, generator=g) * 0.1
     t = F.silu(F.conv2d(x.float(), w1, b1)).to(dtype).float()
     ref = F.silu(F.conv2d(t, w2, b2, padding=1)).to(dtype).float()
     if add:
         ref = ref + x.float()
-    xv = ops.View.alloc(n, h, w, 64, dtype, dev)
+    xv = ops.View.alloc(n, h, w, c, dtype, dev)
     ops.nchw_to_nhwc(x.to(dev), xv)
-    f1 = ops.pack_filter(w1.to(dev), 32, 64, dtype)
-    f2 = ops.pack_filter(w2.to(dev), 64, 32, dtype)
+    f1 = ops.pack_filter(w1.to(dev), cm, c, dtype)
+    f2 = ops.pack_filter(w2.to(dev), c, cm, dtype)
     b1d, b2d = b1.to(dev), b2.to(dev)
-    yv = ops.View.alloc(n, h, w, 64, dtype, dev)
+    yv = ops.View.alloc(n, h, w, c, dtype, dev)
     yv.buf.fill_(float("nan"))
     ops.bneck_pair(xv, f1, b1d, True, f2, b2d, True, add, yv)
     torch.cuda.synchronize()
@@ -1845,7 +1847,7 @@ def test_bneck_pair_vs_fp32_reference(dev, dtype, name, shape, add):
     err = (got - ref).abs().max().item() / ref.abs().max().item()
     assert err < tol, f"{name} {dtype}: {err:.2e}"
     # the two launches it replaces: same arithmetic up to fp32 summation order inside each conv
-    tv, y2 = ops.View.alloc(n, h, w, 32, dtype, dev), ops.View.alloc(n, h, w, 64, dtype, dev)
+    tv, y2 = ops.View.alloc(n, h, w, cm, dtype, dev), ops.View.alloc(n, h, w, c, dtype, dev)
     ops.conv2d(xv, f1, b1d, tv, 1, 1, True)
     ops.conv2d(tv, f2, b2d, y2, 3, 1, True, residual=xv if add else None)
     torch.cuda.synchronize()

@@ -9,16 +9,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from yolov3_amd import ops  # noqa: E402
 
 
-def main():
+def run(c, h, w):
     dev, dt = torch.device("cuda:0"), torch.float16
-    n, h, w = 32, 320, 320
+    n, cm = 32, c // 2
     g = torch.Generator().manual_seed(1)
-    xv = ops.View.alloc(n, h, w, 64, dt, dev)
+    xv = ops.View.alloc(n, h, w, c, dt, dev)
     xv.buf.copy_(torch.randn(xv.buf.shape, generator=g).to(dt))
-    f1 = ops.pack_filter((torch.randn(32, 64, 1, 1, generator=g) / 8).to(dev), 32, 64, dt)
-    f2 = ops.pack_filter((torch.randn(64, 32, 3, 3, generator=g) / math.sqrt(288)).to(dev), 64, 32, dt)
-    b1, b2 = torch.zeros(32, device=dev), torch.zeros(64, device=dev)
-    tv, yv, y2 = ops.View.alloc(n, h, w, 32, dt, dev), ops.View.alloc(n, h, w, 64, dt, dev), ops.View.alloc(n, h, w, 64, dt, dev)
+    f1 = ops.pack_filter((torch.randn(cm, c, 1, 1, generator=g) / math.sqrt(c)).to(dev), cm, c, dt)
+    f2 = ops.pack_filter((torch.randn(c, cm, 3, 3, generator=g) / math.sqrt(9 * cm)).to(dev), c, cm, dt)
+    b1, b2 = torch.zeros(cm, device=dev), torch.zeros(c, device=dev)
+    tv, yv, y2 = ops.View.alloc(n, h, w, cm, dt, dev), ops.View.alloc(n, h, w, c, dt, dev), ops.View.alloc(n, h, w, c, dt, dev)
 
     def fused():
         ops.bneck_pair(xv, f1, b1, True, f2, b2, True, True, yv)
@@ -37,9 +37,10 @@ def main():
             fn()
         e1.record()
         torch.cuda.synchronize()
-        print(f"{name}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us", flush=True)
+        print(f"Bottleneck({c}) {h}x{w} batch 32, {name}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us", flush=True)
     print("max |fused - two| =", (yv.as_nhwc().float() - y2.as_nhwc().float()).abs().max().item())
 
 
 if __name__ == "__main__":
-    main()
+    run(64, 320, 320)
+    run(128, 160, 160)

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -461,72 +462,98 @@ __global__ __launch_bounds__(256, 2) void stem_pair_kernel(const PairArgs p) {
 #endif
 }
 
-// ---- Bottleneck(64, 64) in one kernel -----------------------------------------------------------------------------------------
-// models/yolov3.yaml:18 (layer 2): x + cv2(cv1(x)), cv1 = Conv(64, 32, 1, 1), cv2 = Conv(32, 64, 3, 1), on the 320x320 map.  As two
-// launches the 32-channel intermediate (210 MB at batch 32) is written and read back and x is read twice (cv1's input, cv2's
-// residual): 1.68 GB of HBM traffic for 0.84 GB of input + output, both launches HBM-bound (0.13 + 0.28 ms of a 7 ms forward).
-// Here a block owns an 8 x 32 tile of output pixels: the 10 x 34 pixel patch of x goes to LDS once (prefetched into registers under
-// the previous tile's MFMAs), cv1 (+ bias + SiLU, rounded to T as the stored tensor would be, zero outside the image = cv2's
-// padding) runs on the 340 patch pixels into LDS, cv2 reads its nine taps out of LDS with the wave's 18 filter fragments resident in
-// registers (the layer-1 half of stem_pair with stride 1), and the residual comes from the x patch already in LDS.
+// ---- Bottleneck(C, C), C = 64 or 128, in one kernel --------------------------------------------------------------------------------
+// models/yolov3.yaml:18,20 (layers 2 and 4): x + cv2(cv1(x)), cv1 = Conv(C, C/2, 1, 1), cv2 = Conv(C/2, C, 3, 1), on the 320x320 / 160x160
+// maps.  As two launches the C/2-channel intermediate is written and read back and x is read twice (cv1's input, cv2's residual):
+// layer 2 moved 1.68 GB of HBM traffic for 0.84 GB of input + output (0.13 + 0.28 ms of a 7 ms forward at batch 32).
+// Here a block owns an 8 x 32 tile of output pixels: the 10 x 34 pixel patch of x goes to LDS once by LDS-DMA (the next tile's patch
+// streams in under this tile's cv2), cv1 (+ bias + SiLU, rounded to T as the stored tensor would be, zero outside the image = cv2's
+// padding) runs on the 340 patch pixels into LDS, cv2 reads its nine taps out of LDS with the wave's 9 * C/32 filter fragments
+// resident in registers (the layer-1 half of stem_pair with stride 1), and the residual is re-read from global memory (L2 hits).
+// Waves: (C/32 filter tiles of cv2) x (two groups of four output rows) = 4 (C = 64, two blocks per CU) or 8 (C = 128, one block per CU).
 struct BneckArgs {
-    const void* x;      // NHWC (N, H, W, 64)
-    const void* w1;     // generic packed bank of cv1 [>= 32 rows][kpad1 = 64], k = ci
-    const float* b1;    // 32 floats
-    const void* w2;     // generic packed bank of cv2 [>= 64 rows][kpad2], k = (kh * 3 + kw) * 32 + ci
-    const float* b2;    // 64 floats
-    void* y;            // NHWC (N, H, W, 64)
+    const void* x;      // NHWC (N, H, W, C)
+    const void* w1;     // generic packed bank of cv1 [>= C/2 rows][kpad1], k = ci
+    const float* b1;    // C/2 floats
+    const void* w2;     // generic packed bank of cv2 [>= C rows][kpad2], k = (kh * 3 + kw) * C/2 + ci
+    const float* b2;    // C floats
+    void* y;            // NHWC (N, H, W, C)
     int N, H, W, xpitch, ypitch, act1, act2, add, kpad1, kpad2;
     int tiles_w, tiles_h, n_tiles;
     unsigned x_bytes;   // extent of x for the buffer descriptor of the LDS-DMA loads
 };
-constexpr int BR = 8, BC = 32;                    // output rows x columns per tile
-constexpr int RR = BR + 2, RC = BC + 2;           // cv1 region: 10 x 34 pixels
-constexpr int RPX = RR * RC;                      // 340
-constexpr int NT1 = (RPX + 31) / 32;              // cv1 MFMA pixel tiles per region: 11
-constexpr int L1PITCH = 40;                       // cv1-output pixels per region row in LDS (64 B each).  40 = 2 mod 4 x ... : the chunk swizzle key
-                                                  // ((row * 40 + col) >> 2) & 3 = ((col >> 2) & 3) ^ 2 (row & 1): the row term only swaps the two k-halves
-constexpr int XPIECES = (RPX * 8 + 63) / 64;      // 1 KiB LDS-DMA pieces of the x patch: 43 (the last one half empty)
-constexpr int XJ = (XPIECES + 3) / 4;             // pieces per wave: 11
+constexpr int BC = 32, RC = BC + 2;               // output columns per tile, columns of the cv1 region
+constexpr int bneck_rows(int c) { return c == 64 ? 8 : 4; }   // output rows per tile: 8 x 32 at C = 64; 4 x 32 at C = 128, where a wave's 36 resident
+                                                              // filter fragments (144 VGPRs) leave room for two output rows of accumulators, not four
+constexpr int L1PITCH = 40;                       // cv1-output pixels per region row in LDS: 40 keeps the row term of the chunk swizzle key a pure
+                                                  // XOR on the k-step index (see c2key below)
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void bneck_pair_kernel(const BneckArgs p) {
+template <typename F, int... Is> Y3_DEV void sfor_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, typename F> Y3_DEV void sfor(F&& f) { sfor_impl(f, std::make_integer_sequence<int, N>{}); }
+
+template <typename T, int C>
+__global__ __launch_bounds__(C * 4, C == 64 ? 2 : 1) void bneck_pair_kernel(const BneckArgs p) {
     typedef typename Mfma16<T>::frag frag;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    __shared__ __attribute__((aligned(16))) unsigned char xbuf[XPIECES * 1024];         // x patch, pixel q (flattened region index): chunk c at c ^ ((q >> 1) & 7)
-    __shared__ __attribute__((aligned(16))) unsigned char l1buf[RR * L1PITCH * 64];     // cv1 output, pixel (r, c): chunk c at c ^ key(r, c)
-    __shared__ __attribute__((aligned(16))) unsigned char slices[4 * 32 * 64];
-    __shared__ __attribute__((aligned(16))) float cb1[32], cb2[64];
+    constexpr int BR = bneck_rows(C), RW = BR / 2;   // output rows per tile / per wave
+    constexpr int RR = BR + 2, RPX = RR * RC;        // cv1 region: 10 x 34 = 340 or 6 x 34 = 204 pixels
+    constexpr int NT1 = (RPX + 31) / 32;             // cv1 MFMA pixel tiles per region: 11 or 7
+    constexpr int CM = C / 2;                     // channels of the intermediate
+    constexpr int FT = C / 32;                    // filter tiles of cv2 = waves along the filters
+    constexpr int NWV = 2 * FT;
+    constexpr int XB = C * 2, XCHK = XB / 16;     // bytes / 16-byte chunks per x pixel: 128 / 8 or 256 / 16
+    constexpr int LB = CM * 2, LCHK = LB / 16;    // the same for the intermediate: 64 / 4 or 128 / 8
+    constexpr int K1S = C / 16, M1 = CM / 32;     // cv1: k-steps, filter tiles
+    constexpr int KT = CM / 16;                   // cv2: k-steps per tap
+    constexpr int K2S = 9 * KT;                   // cv2: k-steps = resident filter fragments per wave
+    constexpr int XPIECES = (RPX * XCHK + 63) / 64;   // 1 KiB LDS-DMA pieces of the x patch (the last one partly empty)
+    constexpr int XJ = (XPIECES + NWV - 1) / NWV;
+    constexpr int NJ1 = (NT1 + NWV - 1) / NWV;    // cv1 pixel tiles per wave
+    constexpr int QSTEP = 32 * NWV;               // pixel distance between a wave's consecutive cv1 tiles: 128 = 3 rows + 26, 256 = 7 rows + 18
+    // swizzles (16 slots of 16 B per 256-B bank row): x pixel q: chunk ^ xkey(q); intermediate pixel (r, c): chunk ^ lkey(c) ^ (row parity term)
+    constexpr int XKS = XCHK == 8 ? 1 : 0;        // xkey(q) = (q >> XKS) & (XCHK - 1)
+    constexpr int LKS = LCHK == 4 ? 2 : 1;        // lkey(c) = (c >> LKS) & (LCHK - 1);  ((r * 40 + c) >> LKS) & (LCHK - 1) = lkey(c) ^ ((r & 1) * LCHK / 2)
+    __shared__ __attribute__((aligned(16))) unsigned char xbuf[XPIECES * 1024];
+    __shared__ __attribute__((aligned(16))) unsigned char l1buf[RR * L1PITCH * LB];
+    __shared__ __attribute__((aligned(16))) unsigned char slices[NWV * 32 * 64];
+    __shared__ __attribute__((aligned(16))) float cb1[CM], cb2[C];
+    // cv1's filters: at C = 128 (one block per CU: LDS to spare, no VGPR to spare beside cv2's 36 resident fragments) a swizzled copy in LDS,
+    // row r's 16-byte chunk c at c ^ (r & 15); at C = 64 (two blocks per CU fill the LDS) re-read from L1 / L2 per tile
+    constexpr bool W1_LDS = C == 128;
+    __shared__ __attribute__((aligned(16))) unsigned char cw1[W1_LDS ? CM * C * 2 : 16];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 31, fk = lane >> 5;
-    const int wc = wv >> 1, wp = wv & 1;   // cv2: filter tile, group of four output rows
+    const int wc = wv >> 1, wp = wv & 1;   // cv2: filter tile, group of RW output rows
 
-    if (tid < 8) ((f32x4*)cb1)[tid] = ((const f32x4*)p.b1)[tid];
-    else if (tid < 24) ((f32x4*)cb2)[tid - 8] = ((const f32x4*)p.b2)[tid - 8];
-    frag a2f[18];
+    if (tid < CM / 4) ((f32x4*)cb1)[tid] = ((const f32x4*)p.b1)[tid];
+    else if (tid < CM / 4 + C / 4) ((f32x4*)cb2)[tid - CM / 4] = ((const f32x4*)p.b2)[tid - CM / 4];
+    if constexpr (W1_LDS) {
+        for (int i = tid; i < CM * XCHK; i += 64 * NWV) {
+            const int r = i / XCHK, c = i % XCHK;
+            *(u32x4*)(cw1 + r * XB + ((c ^ (r & 15)) << 4)) = *(const u32x4*)((const T*)p.w1 + (long long)r * p.kpad1 + c * 8);
+        }
+    }
+    frag a2f[K2S];
 #pragma unroll
-    for (int t = 0; t < 18; ++t) a2f[t] = *(const frag*)((const T*)p.w2 + (long long)(wc * 32 + frow) * p.kpad2 + t * 16 + fk * 8);
+    for (int t = 0; t < K2S; ++t) a2f[t] = *(const frag*)((const T*)p.w2 + (long long)(wc * 32 + frow) * p.kpad2 + t * 16 + fk * 8);
 
     // ---- per-lane constants (tile independent; everything that advances with the piece / pixel-tile index is recomputed incrementally
-    // per tile: kept in registers for the block's life the tables were spilled) ----
-    // x patch by LDS-DMA (`buffer_load ... lds`: the wave's 64 lanes fill 64 consecutive 16-byte slots): piece wv + 4 j = 8 pixels x 8 chunks,
-    // lane -> pixel q = 8 wv + (lane >> 3) + 32 j, physical chunk lane & 7 = logical chunk ^ ((q >> 1) & 7) -- the key does not depend on j
-    // (32 j >> 1 = 0 mod 8) -- and the swizzle is applied on the SOURCE address
-    const int xq0 = 8 * wv + (lane >> 3);                                  // < 32 < RC: region row 0, column xq0
-    const unsigned xsrc = (unsigned)(((lane & 7) ^ ((xq0 >> 1) & 7)) * 16);   // byte offset of the chunk within the pixel
+    // per tile: kept in registers for the block's life such tables were spilled) ----
+    // x patch by LDS-DMA (`buffer_load ... lds`: the wave's 64 lanes fill 64 consecutive 16-byte slots): piece wv + NWV j = 64 / XCHK pixels,
+    // lane -> pixel q = (64 / XCHK) wv + lane / XCHK + 32 j, physical chunk lane % XCHK = logical chunk ^ xkey(q) -- the key does not depend on
+    // j -- and the swizzle is applied on the SOURCE address
     const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
-    // cv1: MFMA pixel tile wv + 4 j, pixel q = 32 wv + frow + 128 j: the xbuf key (q >> 1) & 7 does not depend on j either
-    constexpr int NJ1 = (NT1 + 3) / 4;
+    // cv1: MFMA pixel tile wv + NWV j, pixel q = 32 wv + frow + QSTEP j: xkey(q) does not depend on j either
     const int c1q0 = 32 * wv + frow;
     const int c1r0 = c1q0 / RC, c1c0 = c1q0 - c1r0 * RC;
-    const int c1rd0 = c1q0 * 128 + ((fk ^ ((c1q0 >> 1) & 7)) << 4);       // + 128 * 128 j; k-step ks: ^ (32 ks)
-    // cv2: lane's column frow + kw, k-chunk 2 ks + fk of an EVEN region row (odd rows: ks ^ 1)
+    const int c1rd0 = c1q0 * XB + ((fk ^ ((c1q0 >> XKS) & (XCHK - 1))) << 4);              // + QSTEP * XB * j; k-step ks: ^ (32 ks)
+    // cv2: lane's column frow + kw, k-chunk fk of an EVEN region row: k-step ks of the tap is ^ (32 ks), odd rows ^ (16 * LCHK / 2) more
     int c2rd[3];
 #pragma unroll
-    for (int kw = 0; kw < 3; ++kw) c2rd[kw] = (frow + kw) * 64 + ((fk ^ (((frow + kw) >> 2) & 3)) << 4);
+    for (int kw = 0; kw < 3; ++kw) c2rd[kw] = (frow + kw) * LB + ((fk ^ (((frow + kw) >> LKS) & (LCHK - 1))) << 4);
 
     T* __restrict__ yg = (T*)p.y;
     auto fetch = [&](int tile) {   // the tile's 10 x 34 pixel patch of x -> xbuf, zeros outside the image (out-of-range offsets read 0)
@@ -535,17 +562,20 @@ __global__ __launch_bounds__(256, 2) void bneck_pair_kernel(const BneckArgs p) {
         const int th = b % p.tiles_h;
         const int n = b / p.tiles_h;
         const int gh0 = th * BR - 1, gw0 = tw * BC - 1;
+        int lane_f = lane;
+        asm volatile("" : "+v"(lane_f));   // the lane constants below are recomputed per call (a handful of VALU instructions), not carried
+        const int xq0 = (64 / XCHK) * wv + lane_f / XCHK;                                        // < 32 < RC: region row 0, column xq0
+        const unsigned xsrc = (unsigned)(((lane_f % XCHK) ^ ((xq0 >> XKS) & (XCHK - 1))) * 16);   // byte offset of the chunk within the pixel
         int r = 0, c = xq0;
 #pragma unroll
         for (int j = 0; j < XJ; ++j) {
-            if (wv + 4 * j >= XPIECES) break;
+            if (wv + NWV * j >= XPIECES) break;
             const int gh = gh0 + r, gw = gw0 + c;
             const bool ok = xq0 + 32 * j < RPX && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W;
             const unsigned off = ok ? (unsigned)(((n * p.H + gh) * p.W + gw) * p.xpitch) * 2u + xsrc : 0xffffffffu;
-            // by inline asm: issued through the builtin, the compiler waits for the pieces (vmcnt(0)) in front of the first LDS access that
-            // follows -- it cannot tell that they land in xbuf while cv2 reads l1buf -- and the patch no longer streams in under the MFMAs.
+            // by inline asm: issued through the builtin, the compiler waits for the pieces (vmcnt(0)) in front of LDS accesses that follow.
             // The counted wait is the explicit vmcnt(0) at the top of the next tile.
-            const unsigned ldsa = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_ptr_t)xbuf + (unsigned)((wv + 4 * j) * 1024));
+            const unsigned ldsa = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_ptr_t)xbuf + (unsigned)((wv + NWV * j) * 1024));
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(ldsa), "v"(off), "s"(rs_x) : "memory");
             c += 32;
             if (c >= RC) { c -= RC; r += 1; }
@@ -561,48 +591,76 @@ __global__ __launch_bounds__(256, 2) void bneck_pair_kernel(const BneckArgs p) {
         const int gh0 = oh0 - 1, gw0 = ow0 - 1;   // image coordinates of region pixel (0, 0)
         const bool border = gh0 < 0 || gw0 < 0 || gh0 + RR > p.H || gw0 + RC > p.W;
 
-        frag a1f[4];   // cv1's filters: 4 KB in L1 / L2, re-read per tile (16 registers the K loop of cv2 needs more)
+        frag a1g[W1_LDS ? 1 : K1S * M1];   // C = 64: cv1's filter fragments, requested here so that they arrive with the patch
+        if constexpr (!W1_LDS) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) a1f[t] = *(const frag*)((const T*)p.w1 + (long long)frow * p.kpad1 + t * 16 + fk * 8);
-        // this wave's pieces of the patch (requested one tile ago) have landed.  The filter fragments are operands of the wait: the compiler
-        // then knows its own loads are complete too and does not put a vmcnt(0) of its own in front of cv2 (where it would wait for the
-        // NEXT tile's pieces, issued just before)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(a1f[0]), "+v"(a1f[1]), "+v"(a1f[2]), "+v"(a1f[3]) : : "memory");
+            for (int ks = 0; ks < K1S; ++ks)
+#pragma unroll
+                for (int m = 0; m < M1; ++m) a1g[ks * M1 + m] = *(const frag*)((const T*)p.w1 + (long long)(m * 32 + frow) * p.kpad1 + ks * 16 + fk * 8);
+        }
+        // this wave's pieces of the patch (requested one tile ago) have landed.  Through the builtin, not inline asm: the compiler then also
+        // knows that ITS loads (the resident filter fragments) are complete and puts no counted waits for them into the K loop of cv2,
+        // where they would wait for the next tile's pieces, issued just before
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
         __syncthreads();
 
-        // ---- cv1 (1 x 1, K = 64) on the region -> l1buf ----
-        int r1 = c1r0, c1 = c1c0;
+        // ---- cv1 (1 x 1, K = C) on the region -> l1buf.  The wave's pixel tiles share the filter fragments of a k-step (re-read from L1 / L2 per
+        // tile: 16 KB at C = 128 -- in registers for the block's life they would not leave room for cv2's) ----
+        {
+            f32x16 acc[NJ1][M1];
 #pragma unroll
-        for (int j = 0; j < NJ1; ++j) {
-            if (wv + 4 * j >= NT1) break;
-            f32x16 acc;
+            for (int j = 0; j < NJ1; ++j)
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
+                for (int m = 0; m < M1; ++m)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[4 * g + e] = cb1[8 * g + 4 * fk + e];
+                    for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) acc = Mfma16<T>::run(a1f[ks], *(const frag*)(xbuf + ((c1rd0 + j * (128 * 128)) ^ (ks << 5))), acc);
-            if (p.act1 == Y3_ACT_SILU) silu_vec<f32x16, 16>(acc);
-            const bool live = c1q0 + 128 * j < RPX;   // the last pixel tile is partly beyond the region (its reads stay inside xbuf's padding)
-            bool inside = true;
-            if (border) inside = (unsigned)(gh0 + r1) < (unsigned)p.H && (unsigned)(gw0 + c1) < (unsigned)p.W;
-            const int wr = (r1 * L1PITCH + c1) * 64 + ((fk ^ ((c1 >> 2) & 3) ^ ((r1 & 1) << 1)) << 4);   // chunk 2 gp + fk -> ^ (32 gp)
+                        for (int e = 0; e < 4; ++e) acc[j][m][4 * g + e] = cb1[m * 32 + 8 * g + 4 * fk + e];
 #pragma unroll
-            for (int gp = 0; gp < 2; ++gp) {
-                u32x4 ov;
+            for (int ks = 0; ks < K1S; ++ks) {
+                frag af[M1];
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const auto sw = __builtin_amdgcn_permlane32_swap(pack2<T>(acc[8 * gp + 2 * h], acc[8 * gp + 2 * h + 1]),
-                                                                     pack2<T>(acc[8 * gp + 4 + 2 * h], acc[8 * gp + 4 + 2 * h + 1]), false, false);
-                    ov[h] = inside ? (unsigned)sw[0] : 0u;
-                    ov[2 + h] = inside ? (unsigned)sw[1] : 0u;
+                for (int m = 0; m < M1; ++m) {
+                    if constexpr (W1_LDS) af[m] = *(const frag*)(cw1 + (m * 32 + frow) * XB + (((2 * ks + fk) ^ (frow & 15)) << 4));
+                    else af[m] = a1g[ks * M1 + m];
                 }
-                if (live) *(u32x4*)(l1buf + (wr ^ (gp << 5))) = ov;
+#pragma unroll
+                for (int j = 0; j < NJ1; ++j) {
+                    if (wv + NWV * j >= NT1) break;
+                    const frag bf = *(const frag*)(xbuf + ((c1rd0 + j * (QSTEP * XB)) ^ (ks << 5)));
+#pragma unroll
+                    for (int m = 0; m < M1; ++m) acc[j][m] = Mfma16<T>::run(af[m], bf, acc[j][m]);
+                }
             }
-            c1 += 128 - 3 * RC;   // pixel + 128 = 3 region rows + 26 columns
-            r1 += 3;
-            if (c1 >= RC) { c1 -= RC; r1 += 1; }
-            __builtin_amdgcn_sched_barrier(0);
+            int r1 = c1r0, c1 = c1c0;
+#pragma unroll
+            for (int j = 0; j < NJ1; ++j) {
+                if (wv + NWV * j >= NT1) break;
+                const bool live = c1q0 + QSTEP * j < RPX;   // the last pixel tile is partly beyond the region (its reads stay inside xbuf's padding)
+                bool inside = true;
+                if (border) inside = (unsigned)(gh0 + r1) < (unsigned)p.H && (unsigned)(gw0 + c1) < (unsigned)p.W;
+                const int wr = (r1 * L1PITCH + c1) * LB + ((fk ^ ((c1 >> LKS) & (LCHK - 1)) ^ ((r1 & 1) * (LCHK / 2))) << 4);   // chunk 4 m + 2 gp + fk -> ^ (64 m + 32 gp)
+#pragma unroll
+                for (int m = 0; m < M1; ++m) {
+                    if (p.act1 == Y3_ACT_SILU) silu_vec<f32x16, 16>(acc[j][m]);
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        u32x4 ov;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const auto sw = __builtin_amdgcn_permlane32_swap(pack2<T>(acc[j][m][8 * gp + 2 * h], acc[j][m][8 * gp + 2 * h + 1]),
+                                                                             pack2<T>(acc[j][m][8 * gp + 4 + 2 * h], acc[j][m][8 * gp + 4 + 2 * h + 1]), false, false);
+                            ov[h] = inside ? (unsigned)sw[0] : 0u;
+                            ov[2 + h] = inside ? (unsigned)sw[1] : 0u;
+                        }
+                        if (live) *(u32x4*)(l1buf + (wr ^ ((m * 4 + gp * 2) << 4))) = ov;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                c1 += QSTEP % RC;
+                r1 += QSTEP / RC;
+                if (c1 >= RC) { c1 -= RC; r1 += 1; }
+            }
         }
         __syncthreads();
         // xbuf is dead (the residual is re-read from global memory below: those lines sit in L2): the next tile's patch streams into it
@@ -613,53 +671,60 @@ __global__ __launch_bounds__(256, 2) void bneck_pair_kernel(const BneckArgs p) {
                                            // and every reload's vmcnt(0) waited for the previous piece -- eleven serial round trips per tile
             if (nt < p.n_tiles) fetch(nt);
         }
-        // ---- cv2: D[32 filters of tile wc][32 columns] for output rows 4 wp .. 4 wp + 3, K = 9 taps x 32 channels out of l1buf ----
-        f32x16 acc2[4];
+        // ---- cv2: D[32 filters of tile wc][32 columns] for output rows RW wp .. RW wp + RW - 1, K = 9 taps x C/2 channels out of l1buf ----
+        f32x16 acc2[RW];
 #pragma unroll
-        for (int b2 = 0; b2 < 4; ++b2)
+        for (int b2 = 0; b2 < RW; ++b2)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc2[b2][4 * g + e] = cb2[wc * 32 + 8 * g + 4 * fk + e];
-        const unsigned char* l1w = l1buf + (4 * wp) * (L1PITCH * 64);
-        // the four fragments of k-step s + 1 are read while the four MFMAs of step s run; scheduling fences keep it at that (left alone the
+        const unsigned char* l1w = l1buf + (RW * wp) * (L1PITCH * LB);
+        // the RW fragments of k-step s + 1 are read while the RW MFMAs of step s run; scheduling fences keep it at that (left alone the
         // compiler hoisted dozens of reads and spilled the resident filter fragments to make room)
-        auto rd = [&](auto step_c, frag (&bf)[4]) {   // step = 2 tap + ks
-            constexpr int tap = decltype(step_c)::value >> 1, ks = decltype(step_c)::value & 1, kh = tap / 3, kw = tap - 3 * (tap / 3);
+        auto rd = [&](auto step_c, frag (&bf)[RW]) {   // step = KT tap + ks
+            constexpr int tap = decltype(step_c)::value / KT, ks = decltype(step_c)::value % KT, kh = tap / 3, kw = tap - 3 * (tap / 3);
 #pragma unroll
-            for (int b2 = 0; b2 < 4; ++b2) {
-                const int rr = b2 + kh;   // region row minus 4 wp (even): its parity decides which k-half sits where
-                bf[b2] = *(const frag*)(l1w + rr * (L1PITCH * 64) + (c2rd[kw] ^ ((ks ^ (rr & 1)) << 5)));
+            for (int b2 = 0; b2 < RW; ++b2) {
+                const int rr = b2 + kh;   // region row minus RW wp (even): odd rows hold k-chunk c where even rows hold c ^ (LCHK / 2)
+                bf[b2] = *(const frag*)(l1w + rr * (L1PITCH * LB) + (c2rd[kw] ^ (((2 * ks) ^ ((rr & 1) * (LCHK / 2))) << 4)));
             }
         };
-        auto mm = [&](auto step_c, const frag (&bf)[4]) {
+        auto mm = [&](auto step_c, const frag (&bf)[RW]) {
 #pragma unroll
-            for (int b2 = 0; b2 < 4; ++b2) acc2[b2] = Mfma16<T>::run(a2f[decltype(step_c)::value], bf[b2], acc2[b2]);
+            for (int b2 = 0; b2 < RW; ++b2) acc2[b2] = Mfma16<T>::run(a2f[decltype(step_c)::value], bf[b2], acc2[b2]);
         };
-        frag bA[4], bB[4];
+        frag bA[RW], bB[RW];
         rd(std::integral_constant<int, 0>{}, bA);
         __builtin_amdgcn_sched_barrier(0);
-#define Y3_BN_STEP(S0, CUR, NXT) rd(std::integral_constant<int, S0 + 1>{}, NXT); mm(std::integral_constant<int, S0>{}, CUR); __builtin_amdgcn_sched_barrier(0);
-        Y3_BN_STEP(0, bA, bB) Y3_BN_STEP(1, bB, bA) Y3_BN_STEP(2, bA, bB) Y3_BN_STEP(3, bB, bA) Y3_BN_STEP(4, bA, bB) Y3_BN_STEP(5, bB, bA)
-        Y3_BN_STEP(6, bA, bB) Y3_BN_STEP(7, bB, bA) Y3_BN_STEP(8, bA, bB) Y3_BN_STEP(9, bB, bA) Y3_BN_STEP(10, bA, bB) Y3_BN_STEP(11, bB, bA)
-        Y3_BN_STEP(12, bA, bB) Y3_BN_STEP(13, bB, bA) Y3_BN_STEP(14, bA, bB) Y3_BN_STEP(15, bB, bA) Y3_BN_STEP(16, bA, bB)
-#undef Y3_BN_STEP
-        mm(std::integral_constant<int, 17>{}, bB);
+        sfor<K2S / 2 - 1>([&](auto i_c) {   // two k-steps per trip: the fragment buffers swap roles
+            constexpr int s0 = 2 * decltype(i_c)::value;
+            rd(std::integral_constant<int, s0 + 1>{}, bB);
+            mm(std::integral_constant<int, s0>{}, bA);
+            __builtin_amdgcn_sched_barrier(0);
+            rd(std::integral_constant<int, s0 + 2>{}, bA);
+            mm(std::integral_constant<int, s0 + 1>{}, bB);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        rd(std::integral_constant<int, K2S - 1>{}, bB);
+        mm(std::integral_constant<int, K2S - 2>{}, bA);
         __builtin_amdgcn_sched_barrier(0);
-        // ---- activation, 8 consecutive filters per lane, transpose through the wave's slice, residual from the x patch, 64-byte runs ----
-        u32x4 xres[8];   // residual x[pixel][this wave's 32 channels], in the store layout of the epilogue
+        mm(std::integral_constant<int, K2S - 1>{}, bB);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- activation, 8 consecutive filters per lane, transpose through the wave's slice, residual, 64-byte runs per pixel ----
+        u32x4 xres[2 * RW];   // residual x[pixel][this wave's 32 channels], in the store layout of the epilogue
         int lane_o = lane;
         asm volatile("" : "+v"(lane_o));   // (same reason: the epilogue's addresses are computed after the K loop, not carried through it)
         const int rp = lane_o >> 2, ch = lane_o & 3;
         if (p.add) {   // bounds-checked descriptor loads (out-of-range lanes carry offset 0xffffffff and read 0): straight-line, all eight in flight
                        // under the SiLU pass below -- behind `if (inside)` branches each was issued at its use and waited for alone
-            const int pix0 = ((n * p.H + oh0 + 4 * wp) * p.W + ow0) * p.xpitch + wc * 32 + ch * 8;   // elements: < 2^30 (x_bytes < 2^31)
+            const int pix0 = ((n * p.H + oh0 + RW * wp) * p.W + ow0) * p.xpitch + wc * 32 + ch * 8;   // elements: < 2^30 (x_bytes < 2^31)
 #pragma unroll
-            for (int b2 = 0; b2 < 4; ++b2)
+            for (int b2 = 0; b2 < RW; ++b2)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int pl = i * 16 + rp;
-                    const bool ok = oh0 + 4 * wp + b2 < p.H && ow0 + pl < p.W;
+                    const bool ok = oh0 + RW * wp + b2 < p.H && ow0 + pl < p.W;
                     xres[b2 * 2 + i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? (unsigned)(pix0 + (b2 * p.W + pl) * p.xpitch) * 2u : 0xffffffffu, 0, 0);
                 }
             __builtin_amdgcn_sched_barrier(0);
@@ -667,14 +732,14 @@ __global__ __launch_bounds__(256, 2) void bneck_pair_kernel(const BneckArgs p) {
         unsigned char* wl = slices + wv * (32 * 64);
         if (p.act2 == Y3_ACT_SILU) {
 #pragma unroll
-            for (int b2 = 0; b2 < 4; ++b2) {
+            for (int b2 = 0; b2 < RW; ++b2) {
                 silu_vec<f32x16, 16>(acc2[b2]);
                 __builtin_amdgcn_sched_barrier(0);   // one accumulator at a time: 16 temporaries, not 64
             }
         }
-        const long long ybase = ((long long)(n * p.H + oh0 + 4 * wp) * p.W + ow0) * p.ypitch + wc * 32 + ch * 8;
+        const long long ybase = ((long long)(n * p.H + oh0 + RW * wp) * p.W + ow0) * p.ypitch + wc * 32 + ch * 8;
 #pragma unroll
-        for (int b2 = 0; b2 < 4; ++b2) {
+        for (int b2 = 0; b2 < RW; ++b2) {
 #pragma unroll
             for (int gp = 0; gp < 2; ++gp) {
                 u32x4 ov;
@@ -691,7 +756,7 @@ __global__ __launch_bounds__(256, 2) void bneck_pair_kernel(const BneckArgs p) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int orow = 4 * wp + b2;
+            const int orow = RW * wp + b2;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int pl = i * 16 + rp;
@@ -708,7 +773,7 @@ __global__ __launch_bounds__(256, 2) void bneck_pair_kernel(const BneckArgs p) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();   // the slice is rewritten by the next row
         }
-        __syncthreads();   // xbuf, l1buf and the slices are rewritten by the next tile
+        __syncthreads();   // l1buf and the slices are rewritten by the next tile
     }
 }
 
@@ -857,7 +922,8 @@ extern "C" int y3_stem_pair_fwd(const void* x_nchw, int32_t src_dtype, int32_t n
 extern "C" int y3_bneck_pair_fwd(const y3_tensor* x, const void* packed1, const float* bias1, int32_t act1, const void* packed2, const float* bias2, int32_t act2,
                                  int32_t add_residual, int32_t dtype, const y3_tensor* y, void* stream) {
     if (!x || !x->data || !packed1 || !bias1 || !packed2 || !bias2 || !y || !y->data) Y3_FAIL("y3_bneck_pair_fwd: null argument");
-    if (x->c != 64 || y->c != 64) Y3_FAIL("y3_bneck_pair_fwd: Bottleneck(64, 64) only (cv1 64 -> 32, cv2 32 -> 64), got %d -> %d channels", x->c, y->c);
+    const int c = x->c;
+    if ((c != 64 && c != 128) || y->c != c) Y3_FAIL("y3_bneck_pair_fwd: Bottleneck(64, 64) or Bottleneck(128, 128) (cv1 C -> C/2 1x1, cv2 C/2 -> C 3x3), got %d -> %d channels", x->c, y->c);
     if (y->n != x->n || y->h != x->h || y->w != x->w) Y3_FAIL("y3_bneck_pair_fwd: output shape");
     if ((x->pitch % 8) || (y->pitch % 8) || ((uintptr_t)x->data & 15) || ((uintptr_t)y->data & 15) || ((uintptr_t)packed1 & 15) || ((uintptr_t)packed2 & 15) ||
         ((uintptr_t)bias1 & 15) || ((uintptr_t)bias2 & 15))
@@ -866,20 +932,24 @@ extern "C" int y3_bneck_pair_fwd(const y3_tensor* x, const void* packed1, const 
     BneckArgs a;
     a.x = x->data; a.w1 = packed1; a.b1 = bias1; a.w2 = packed2; a.b2 = bias2; a.y = y->data;
     a.N = x->n; a.H = x->h; a.W = x->w; a.xpitch = x->pitch; a.ypitch = y->pitch; a.act1 = act1; a.act2 = act2; a.add = add_residual ? 1 : 0;
-    a.kpad1 = y3_filter_kpad(64, 1); a.kpad2 = y3_filter_kpad(32, 3);
-    a.tiles_w = (x->w + BC - 1) / BC; a.tiles_h = (x->h + BR - 1) / BR;
+    a.kpad1 = y3_filter_kpad(c, 1); a.kpad2 = y3_filter_kpad(c / 2, 3);
+    a.tiles_w = (x->w + BC - 1) / BC; a.tiles_h = (x->h + bneck_rows(c) - 1) / bneck_rows(c);
     const long long tiles = (long long)a.tiles_w * a.tiles_h * x->n;
     if (tiles > 0x7fffffffLL || (long long)x->n * x->h * x->w > 0x7fffffffLL) Y3_FAIL("y3_bneck_pair_fwd: too many pixels");
     a.n_tiles = (int)tiles;
     const long long xb = (((long long)x->n * x->h * x->w - 1) * x->pitch + x->c) * 2;
     if (xb >= 0x7fffffffLL) Y3_FAIL("y3_bneck_pair_fwd: input beyond the 2 GiB reach of a buffer descriptor (split the batch)");
     a.x_bytes = (unsigned)xb;
-    const int blocks = tiles < 512 ? (int)tiles : 512;   // persistent: 2 blocks per CU
+    const int cap = c == 64 ? 512 : 256;   // persistent: 2 blocks of 4 waves / 1 block of 8 waves per CU
+    const int blocks = tiles < cap ? (int)tiles : cap;
     hipStream_t st = (hipStream_t)stream;
-    switch (dtype) {
-        case Y3_F16: hipLaunchKernelGGL((bneck_pair_kernel<f16_t>), dim3((unsigned)blocks), dim3(256), 0, st, a); break;
-        case Y3_BF16: hipLaunchKernelGGL((bneck_pair_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, a); break;
-        default: Y3_FAIL("y3_bneck_pair_fwd: f16/bf16 only");
+    if (dtype != Y3_F16 && dtype != Y3_BF16) Y3_FAIL("y3_bneck_pair_fwd: f16/bf16 only");
+    if (c == 64) {
+        if (dtype == Y3_F16) hipLaunchKernelGGL((bneck_pair_kernel<f16_t, 64>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((bneck_pair_kernel<bf16_t, 64>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    } else {
+        if (dtype == Y3_F16) hipLaunchKernelGGL((bneck_pair_kernel<f16_t, 128>), dim3((unsigned)blocks), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((bneck_pair_kernel<bf16_t, 128>), dim3((unsigned)blocks), dim3(512), 0, st, a);
     }
     Y3_CHECK_LAUNCH();
     return 0;

@@ -305,6 +305,7 @@ class Plan:
                 xv, yv, w1, w2 = kw["x"].real(), kw["y"].real(), kw["w1"], kw["w2"]
                 xt, yt = xv.y3(), yv.y3()
                 m = xv.n * xv.h * xv.w
+                cc, cm = xv.c, xv.c // 2
                 self.launches.append(
                     _Launch(
                         L.y3_bneck_pair_fwd,
@@ -312,8 +313,8 @@ class Plan:
                          _lib.Y3_ACT_SILU if w2.act else _lib.Y3_ACT_NONE, int(kw["add"]), dcode, C.byref(yt)),
                         keep=(xt, yt, w1, w2),
                         label=kw["label"],
-                        flops=2.0 * m * (32 * 64 + 64 * 32 * 9),                                  # counted like the two generic launches
-                        bytes=esz * (m * 64 + m * 64 + 32 * 64 + 64 * 32 * 9),                   # x once, y once: the intermediate never leaves the CU
+                        flops=2.0 * m * (cm * cc + cc * cm * 9),                                  # counted like the two generic launches
+                        bytes=esz * (m * cc + m * cc + cm * cc + cc * cm * 9),                   # x once, y once: the intermediate never leaves the CU
                         kernel="bneck_pair",
                     )
                 )
@@ -390,12 +391,13 @@ class _Compiler:
 
     def bottleneck(self, m: Bottleneck, x: SView, y: SView = None, label=""):
         if _bneck_pair_eligible(m, x, self.dtype):
-            # Bottleneck(64, 64) (yolov3 layer 2, the 320x320 map): one kernel, the 32-channel intermediate stays in LDS and x is read once
+            # Bottleneck(64, 64) / Bottleneck(128, 128) (yolov3 layers 2 and 4, the 320x320 / 160x160 maps): one kernel, the C/2-channel
+            # intermediate stays in LDS and x is read once
             p = self.plan
-            w1 = make_conv_weights(m.cv1.conv, getattr(m.cv1, "bn", None), isinstance(m.cv1.act, nn.SiLU), self.dtype, cin_pad=64, cache=self.wcache)
-            w2 = make_conv_weights(m.cv2.conv, getattr(m.cv2, "bn", None), isinstance(m.cv2.act, nn.SiLU), self.dtype, cin_pad=32, cache=self.wcache)
+            w1 = make_conv_weights(m.cv1.conv, getattr(m.cv1, "bn", None), isinstance(m.cv1.act, nn.SiLU), self.dtype, cin_pad=x.c, cache=self.wcache)
+            w2 = make_conv_weights(m.cv2.conv, getattr(m.cv2, "bn", None), isinstance(m.cv2.act, nn.SiLU), self.dtype, cin_pad=x.c // 2, cache=self.wcache)
             if y is None:
-                y = p.new_view(x.n, x.h, x.w, 64, label)
+                y = p.new_view(x.n, x.h, x.w, x.c, label)
             p.add("bneck_pair", [x], [y], x=x, y=y, w1=w1, w2=w2, add=bool(m.add), label=label)
             return y
         t = self.conv_unit(m.cv1, x, label=label + ".cv1")
@@ -411,18 +413,21 @@ class _Compiler:
 
 
 def _bneck_pair_eligible(m, x, dtype) -> bool:
-    """Bottleneck(64, 64): cv1 = Conv(64, 32, 1, 1), cv2 = Conv(32, 64, 3, 1) on a 64-channel view: csrc/stem.hip (y3_bneck_pair_fwd) computes
-    both with the intermediate kept in LDS.  Y3_BNECK_PAIR=0 restores the two generic launches (A/B runs)."""
+    """Bottleneck(C, C), C = 64 or 128: cv1 = Conv(C, C/2, 1, 1), cv2 = Conv(C/2, C, 3, 1) on a C-channel view: csrc/stem.hip
+    (y3_bneck_pair_fwd) computes both with the intermediate kept in LDS.  Y3_BNECK_PAIR=0 restores the two generic launches, =64 keeps the
+    kernel for C = 64 only (A/B runs)."""
     import os
 
-    if os.environ.get("Y3_BNECK_PAIR", "1") == "0" or dtype not in (torch.float16, torch.bfloat16) or x.c != 64:
+    flag = os.environ.get("Y3_BNECK_PAIR", "1")
+    if flag == "0" or dtype not in (torch.float16, torch.bfloat16) or x.c not in (64, 128) or (flag == "64" and x.c != 64):
         return False
     c1, c2 = m.cv1.conv, m.cv2.conv
+    c = x.c
 
     def plain(c, k):
         return c.kernel_size == (k, k) and c.stride == (1, 1) and c.padding == (k // 2, k // 2) and c.dilation == (1, 1) and c.groups == 1
 
-    return (c1.in_channels == 64 and c1.out_channels == 32 and plain(c1, 1) and c2.in_channels == 32 and c2.out_channels == 64 and plain(c2, 3)
+    return (c1.in_channels == c and c1.out_channels == c // 2 and plain(c1, 1) and c2.in_channels == c // 2 and c2.out_channels == c and plain(c2, 3)
             and isinstance(m.cv1.act, (nn.SiLU, nn.Identity)) and isinstance(m.cv2.act, (nn.SiLU, nn.Identity)))
 
 

@@ -180,7 +180,7 @@ def pack_filter_dgrad(w_oihw: torch.Tensor, cout: int, cin: int, dtype: torch.dt
 
 
 def bneck_pair(x: View, filt1: torch.Tensor, bias1: torch.Tensor, act1: bool, filt2: torch.Tensor, bias2: torch.Tensor, act2: bool, add: bool, y: View):
-    """Bottleneck(64, 64): y = [x +] cv2(cv1(x)), cv1 1x1 64 -> 32, cv2 3x3 32 -> 64, the intermediate kept in LDS (csrc/stem.hip)."""
+    """Bottleneck(C, C), C = 64 or 128: y = [x +] cv2(cv1(x)), cv1 1x1 C -> C/2, cv2 3x3 C/2 -> C, the intermediate kept in LDS (csrc/stem.hip)."""
     xt, yt = x.y3(), y.y3()
     check(_lib.lib().y3_bneck_pair_fwd(C.byref(xt), filt1.data_ptr(), bias1.data_ptr(), _lib.Y3_ACT_SILU if act1 else _lib.Y3_ACT_NONE, filt2.data_ptr(), bias2.data_ptr(),
                                        _lib.Y3_ACT_SILU if act2 else _lib.Y3_ACT_NONE, int(bool(add)), dtype_code(x.buf.dtype), C.byref(yt), stream_ptr()), "y3_bneck_pair_fwd")
