@@ -636,7 +636,7 @@ __global__ __launch_bounds__(C * 4, C == 64 ? 2 : 1) void bneck_pair_kernel(cons
 #pragma unroll
             for (int j = 0; j < NJ1; ++j) {
                 if (wv + NWV * j >= NT1) break;
-                const bool live = c1q0 + QSTEP * j < RPX;   // the last pixel tile is partly beyond the region (its reads stay inside xbuf's padding)
+                const bool live = c1q0 + QSTEP * j < RPX;   // the last pixel tile is partly beyond the region: those lanes multiplied whatever follows the patch in LDS and store nothing
                 bool inside = true;
                 if (border) inside = (unsigned)(gh0 + r1) < (unsigned)p.H && (unsigned)(gw0 + c1) < (unsigned)p.W;
                 const int wr = (r1 * L1PITCH + c1) * LB + ((fk ^ ((c1 >> LKS) & (LCHK - 1)) ^ ((r1 & 1) * (LCHK / 2))) << 4);   // chunk 4 m + 2 gp + fk -> ^ (64 m + 32 gp)
