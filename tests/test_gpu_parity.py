@@ -1853,3 +1853,157 @@ def test_bneck_pair_vs_fp32_reference(dev, dtype, name, shape, add, c):
     torch.cuda.synchronize()
     two = y2.as_nhwc().float().cpu().permute(0, 3, 1, 2)
     assert (got - two).abs().max().item() <= 2 * tol * ref.abs().max().item()
+
+
+# ------------------------------------------------------------------------------------------------ BatchNorm-backward statistics in the data-gradient epilogue
+BNB_CASES = [
+    # name, (n, h, w, c_du, c_gx, k), residual, sliced output, activation, workspace (v7 where eligible), expected variant
+    ("v3_bk64_3x3", (2, 40, 40, 128, 256, 3), False, False, True, False, "v3_bk64_128x128"),
+    ("v6_3x3_res", (4, 20, 20, 512, 512, 3), True, False, True, False, "v6"),
+    ("v7_3x3_res", (4, 20, 20, 512, 512, 3), True, False, True, True, "v7"),
+    ("v7_stream_k_ragged", (2, 21, 19, 256, 256, 3), False, False, True, True, "v7"),
+    ("1x1_res_sliced", (2, 40, 40, 128, 256, 1), True, True, True, False, None),
+    ("1x1_deep_noact", (2, 20, 20, 512, 1024, 1), True, False, False, False, None),
+    ("cout64_odd_pixels", (2, 33, 17, 32, 64, 1), False, False, True, False, "v3_bk32_64x256"),
+    ("cout_not_tile_multiple", (2, 24, 24, 64, 200, 3), True, False, True, False, None),
+    ("many_rows_two_level_sum", (8, 96, 96, 32, 64, 1), True, False, True, False, None),
+    ("head_255", (2, 20, 20, 256, 1024, 1), False, False, True, False, None),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name,shape,residual,sliced,act,ws,expect", BNB_CASES, ids=[c[0] for c in BNB_CASES])
+def test_dgrad_epilogue_bn_backward_statistics(dev, dtype, name, shape, residual, sliced, act, ws, expect):
+    """y3_conv2d_fwd_bnb_ws (the data-gradient launch that completes dy also writes the BatchNorm backward's reduction rows):
+    same dy as y3_conv2d_fwd(_ws) bit for bit; the fp64 sum of its rows equals (sum g, sum g*u), g = dy*act'(scale*u+shift) of the STORED
+    dy, to 2e-5 of sum|g| (fp32 partial sums over <= 128 pixels, v_exp/v_rcp sigmoid); y3_bn_bwd_finalize_rows turns them into the
+    totals / dgamma / dbeta that y3_bn_act_bwd computes with its own pass over (dy, u); y3_bn_act_bwd_apply from those totals gives
+    y3_bn_act_bwd's du (and residual gradient) up to one rounding of T."""
+    import ctypes as C
+
+    _lib, ops = _ops()
+    n, h, w, cd, cg, k = shape
+    g = torch.Generator().manual_seed(23)
+    du_in = (torch.randn(n, cd, h, w, generator=g) * 0.5).to(dtype)
+    wt = torch.randn(cg, cd, k, k, generator=g) / math.sqrt(cd * k * k)
+    u = (torch.randn(n, cg, h, w, generator=g) * 1.5 + torch.randn(1, cg, 1, 1, generator=g)).to(dtype)
+    gamma, beta = torch.rand(cg, generator=g) + 0.5, torch.randn(cg, generator=g) * 0.3
+    uf = u.double()
+    mean, var = uf.mean((0, 2, 3)), uf.var((0, 2, 3), unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-3)
+    scale = (gamma.double() * invstd).float().to(dev)
+    shift = (beta.double() - mean * gamma.double() * invstd).float().to(dev)
+    mean_d, invstd_d = mean.float().to(dev), invstd.float().to(dev)
+    a = _lib.Y3_ACT_SILU if act else _lib.Y3_ACT_NONE
+    xv = ops.View.alloc(n, h, w, cd, dtype, dev)
+    ops.nchw_to_nhwc(du_in.to(dev), xv)
+    uv = ops.View.alloc(n, h, w, cg, dtype, dev)
+    ops.nchw_to_nhwc(u.to(dev), uv)
+    filt = ops.pack_filter(wt.to(dev), cg, cd, dtype)
+    zb = torch.zeros(cg, device=dev)
+    wsb = conv_ws(dev) if ws else None
+
+    def out_view():
+        if sliced:
+            big = ops.View.alloc(n, h, w, cg + 24, dtype, dev)
+            big.buf.fill_(3.0)
+            return big, big.slice(16, cg)
+        v = ops.View.alloc(n, h, w, cg, dtype, dev)
+        return v, v
+
+    prev = (torch.randn(n, cg, h, w, generator=g) * 0.2).to(dtype) if residual else None
+    big0, y0 = out_view()
+    big1, y1 = out_view()
+    if residual:   # the gradient accumulated so far lives in the output buffer itself (residual port = output)
+        ops.nchw_to_nhwc(prev.to(dev), y0)
+        ops.nchw_to_nhwc(prev.to(dev), y1)
+    ops.conv2d(xv, filt, zb, y0, k, 1, act=False, residual=y0 if residual else None, in_dilation=1, workspace=wsb)
+    rows = ops.conv2d_bnb(xv, None, None, y1, k, None, 1, uv, scale, shift, a, None, 0, workspace=wsb)
+    assert rows > 0
+    if expect is not None:
+        assert ops.last_conv_variant() == expect, ops.last_conv_variant()
+    buf = torch.full((rows * 2 * cg,), float("nan"), device=dev)
+    got = ops.conv2d_bnb(xv, filt, zb, y1, k, y1 if residual else None, 1, uv, scale, shift, a, buf, rows, workspace=wsb)
+    torch.cuda.synchronize()
+    assert got == rows
+    assert torch.equal(big0.buf, big1.buf), "the gradient itself must not change"
+    dy = ops.nhwc_to_nchw(y1).double().cpu()
+    z = uf * scale.double().cpu().view(1, -1, 1, 1) + shift.double().cpu().view(1, -1, 1, 1)
+    sg = torch.sigmoid(z)
+    gg = dy * (sg + z * sg * (1 - sg)) if act else dy
+    ref0, ref1 = gg.sum((0, 2, 3)), (gg * uf).sum((0, 2, 3))
+    tot = buf.view(rows, cg, 2).double().sum(0).cpu()
+    assert torch.isfinite(tot).all(), "a statistics row was not written"
+    mag0, mag1 = gg.abs().sum((0, 2, 3)).max().item(), (gg * uf).abs().sum((0, 2, 3)).max().item()
+    assert (tot[:, 0] - ref0).abs().max().item() <= 2e-5 * mag0, f"sum g: {(tot[:, 0] - ref0).abs().max().item():.3e} of {mag0:.3e}"
+    assert (tot[:, 1] - ref1).abs().max().item() <= 2e-5 * mag1, f"sum g*u: {(tot[:, 1] - ref1).abs().max().item():.3e} of {mag1:.3e}"
+    # rows -> totals / dgamma / dbeta, against the separate reduction pass
+    sums = ops.bn_scratch(cg, dev)
+    totals = torch.full((4 * cg,), float("nan"), dtype=torch.float64, device=dev)
+    dg1, db1 = torch.empty(cg, device=dev), torch.empty(cg, device=dev)
+    _lib.check(_lib.lib().y3_bn_bwd_finalize_rows(buf.data_ptr(), rows, n * h * w, cg, sums.data_ptr(), mean_d.data_ptr(), invstd_d.data_ptr(), totals.data_ptr(), dg1.data_ptr(),
+                                                  db1.data_ptr(), ops.stream_ptr()), "y3_bn_bwd_finalize_rows")
+    sums0 = ops.bn_scratch(cg, dev)
+    dg0, db0 = torch.empty(cg, device=dev), torch.empty(cg, device=dev)
+    du0, du1 = ops.View.alloc(n, h, w, cg, dtype, dev), ops.View.alloc(n, h, w, cg, dtype, dev)
+    gr0, gr1 = ops.View.alloc(n, h, w, cg, dtype, dev), ops.View.alloc(n, h, w, cg, dtype, dev)
+    gr0.buf.fill_(0.25)
+    gr1.buf.fill_(0.25)
+    # y1 may be a channel slice of a wider buffer: both passes take (pointer, pitch) views
+    ut, gt, d0, d1, g0t, g1t = uv.y3(), y1.y3(), du0.y3(), du1.y3(), gr0.y3(), gr1.y3()
+    dc = ops.dtype_code(dtype)
+    _lib.check(_lib.lib().y3_bn_act_bwd_res(C.byref(ut), C.byref(gt), scale.data_ptr(), shift.data_ptr(), mean_d.data_ptr(), invstd_d.data_ptr(), dc, a, sums0.data_ptr(),
+                                            C.byref(d0), dg0.data_ptr(), db0.data_ptr(), C.byref(g0t), 1, ops.stream_ptr()), "y3_bn_act_bwd_res")
+    _lib.check(_lib.lib().y3_bn_act_bwd_apply(C.byref(ut), C.byref(gt), scale.data_ptr(), shift.data_ptr(), mean_d.data_ptr(), invstd_d.data_ptr(), dc, a, totals.data_ptr(),
+                                              C.byref(d1), C.byref(g1t), 1, ops.stream_ptr()), "y3_bn_act_bwd_apply")
+    torch.cuda.synchronize()
+    xh_mag = ((uf - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1) * gg).abs().sum((0, 2, 3)).max().item()
+    assert (db1.double().cpu() - db0.double().cpu()).abs().max().item() <= 4e-5 * mag0
+    assert (dg1.double().cpu() - dg0.double().cpu()).abs().max().item() <= 4e-5 * max(xh_mag, mag1 * invstd.max().item() * 1e-1), "dgamma"
+    assert torch.equal(gr0.buf, gr1.buf), "residual gradient accumulation"
+    a0, a1 = du0.buf.float(), du1.buf.float()
+    ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    assert (a0 - a1).abs().max().item() <= ulp * a0.abs().max().item() + 1e-6, "du from the epilogue totals vs du from the reduction pass"
+
+
+@pytest.mark.parametrize("name,hw,adt", [("yolov3", 128, torch.float16), ("yolov3-spp", 96, torch.bfloat16), ("yolov3-tiny", 160, torch.float16)])
+def test_train_step_bn_backward_in_dgrad_epilogue_matches_separate_reduction(dev, monkeypatch, name, hw, adt):
+    """The training plan with the BatchNorm-backward reductions taken in the data-gradient epilogues (default) against the same plan with the
+    separate reduction pass (Y3_BNB_EPILOGUE=0): identical forward, every parameter gradient equal up to the summation order of the two
+    reductions (they feed du, so the difference propagates through the layers below as half-precision rounding flips)."""
+    from yolov3_amd import ComputeLoss
+    from yolov3_amd.engine import plan_cache
+
+    nc, bs = 80, 4
+    hyp = dict(box=0.05, cls=0.5, cls_pw=1.0, obj=1.0, obj_pw=1.0, anchor_t=4.0, fl_gamma=0.0, label_smoothing=0.0)
+    x = torch.rand(bs, 3, hw, hw, generator=torch.Generator().manual_seed(2)).to(dev)
+    tg = yo.synth_targets(bs, nc, seed=6).to(dev)
+    grads, fused_units = {}, {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("Y3_BNB_EPILOGUE", mode)
+        m, _ = build_pair(name, nc, 19, dev, torch.float32)
+        m.train()
+        m.hyp = hyp
+        crit = ComputeLoss(m)
+        with torch.autocast("cuda", dtype=adt):
+            loss, _ = crit(m(x), tg)
+        (loss * 128.0).backward()
+        torch.cuda.synchronize()
+        plan = next(p for k, p in plan_cache(m).plans.items() if k[0] == "train")
+        fused_units[mode] = plan.bnb_units
+        grads[mode] = {k: p.grad.float().cpu() for k, p in m.named_parameters()}
+        grads[mode]["__loss__"] = loss.detach().float().cpu()
+    assert fused_units["0"] == 0
+    assert fused_units["1"] >= {"yolov3": 65, "yolov3-spp": 65, "yolov3-tiny": 4}[name], fused_units
+    assert torch.equal(grads["0"]["__loss__"], grads["1"]["__loss__"])
+    worst = (1.0, None)
+    for k, g0 in grads["0"].items():
+        g1 = grads["1"][k]
+        assert torch.isfinite(g1).all(), k
+        if g0.numel() < 64:
+            continue
+        c = torch.nn.functional.cosine_similarity(g0.flatten(), g1.flatten(), dim=0).item()
+        if c < worst[0]:
+            worst = (c, k)
+    print(f"[bnb epilogue {name} {adt}] min gradient cosine fused vs separate {worst[0]:.6f} at {worst[1]}")
+    assert worst[0] > (0.999 if adt == torch.float16 else 0.98), worst

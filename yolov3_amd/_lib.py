@@ -137,6 +137,16 @@ _SIGNATURES = {
         [_P(Y3Tensor), _P(Y3Tensor), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, _P(Y3Tensor), C.c_void_p, C.c_void_p, _P(Y3Tensor), C.c_int32,
          C.c_void_p],
     ),
+    "y3_conv2d_fwd_bnb_ws": (
+        C.c_int,
+        [_P(Y3ConvDesc), _P(Y3Tensor), C.c_void_p, C.c_void_p, _P(Y3Tensor), _P(Y3Tensor), _P(Y3Tensor), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
+         C.c_void_p, C.c_size_t, C.c_void_p],
+    ),
+    "y3_bn_bwd_finalize_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "y3_bn_act_bwd_apply": (
+        C.c_int,
+        [_P(Y3Tensor), _P(Y3Tensor), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, _P(Y3Tensor), _P(Y3Tensor), C.c_int32, C.c_void_p],
+    ),
     "y3_pack_filter_dgrad": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "y3_pack_filter_pair": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "y3_packed_filter_dgrad_s2_elems": (C.c_size_t, [C.c_int32, C.c_int32]),

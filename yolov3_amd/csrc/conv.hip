@@ -56,6 +56,15 @@ struct ConvArgs {
     float* stats;
     int stat_wp;   // waves along the pixel axis of the launched variant
     int dry;       // geometry only (y3_conv2d_fwd_stats_rows): fill n_pt / stat_wp, launch nothing
+    // BatchNorm-BACKWARD statistics in the epilogue of a data gradient (y3_conv2d_fwd_bnb_ws): this launch writes the FINAL gradient
+    // dy of a tensor y = act(bn(u)); with u (same n, h, w, c as the output) and the unit's (scale, shift) the rows of `stats` carry
+    // (sum g, sum g * u), g = dy * act'(scale * u + shift) of the value as STORED, instead of (sum, sum of squares): the reduction
+    // pass of the BatchNorm backward over (dy, u) disappears (train.hip turns sum g*u into sum g*xhat in the fp64 row sum)
+    const void* bnb_u;
+    const float* bnb_scale;
+    const float* bnb_shift;
+    int bnb_upitch, bnb_act;
+    unsigned bnb_ubytes;
     void* ws;      // scratch of the persistent stream-K kernel (conv_v7.h): control words, arrival flags, fp32 partial tiles; may be null
     size_t ws_bytes;
     int v7_whole;  // conv_v7.h: blocks own whole tiles (no stream-K split)
@@ -174,7 +183,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // the same coalesced pattern before the arithmetic starts and added in fp32.  One block barrier (the stage buffers must be
 // idle), no idle waves.  (The block-wide fp32 transpose this replaces cost 8-17 us per block with half of the waves parked
 // during the exp/rcp pass; a register-only variant with 32-byte runs lost on the residual layers: profiles/r01_conv_timeline.md.)
-template <typename T, int MC, int MP>
+template <typename T, int MC, int MP, bool BNB = false>
 Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MP], unsigned char* wl, int c_base, int m_base, int lane, int stat_row = -1) {
     typedef typename Mfma<T>::frag vec8;   // 8 x T = one 16-byte chunk
     constexpr int CH = MC * 4;          // 16-byte chunks per pixel row of this wave's slice
@@ -245,14 +254,49 @@ Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MP], unsigned cha
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const bool want_stats = p.stats != nullptr;   // kernel-uniform
+    // BNB: rows of (sum g, sum g*u) for the BatchNorm backward (see ConvArgs); its own instantiation -- the extra registers must not
+    // touch the forward kernels
     float st0[8], st1[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) st0[q] = st1[q] = 0.0f;
+    // the pre-BatchNorm tensor u at the pixels / channels this lane stores: requested here, after the accumulators died (NI more
+    // 16-byte registers next to the residual rows would not fit beside them), consumed in the store loop below
+    u32x4 ru[BNB ? NI : 1];
+    f32x2 bsc[4], bsh[4];
+    if constexpr (BNB) {
+        const auto rsrc_u = __builtin_amdgcn_make_buffer_rsrc((void*)p.bnb_u, 0, (int)p.bnb_ubytes, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int pl = i * PPI + rp;
+            const int spx = __builtin_amdgcn_ds_bpermute((pl & 31) << 2, opx[(i * PPI) / 32]);
+            ru[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, yoff[i] != OOB ? (unsigned)(spx * p.bnb_upitch + c) * 2u : OOB, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bsc[q] = cv ? f32x2{p.bnb_scale[c + 2 * q], p.bnb_scale[c + 2 * q + 1]} : f32x2{0.0f, 0.0f};
+            bsh[q] = cv ? f32x2{p.bnb_shift[c + 2 * q], p.bnb_shift[c + 2 * q + 1]} : f32x2{0.0f, 0.0f};
+        }
+    }
+    auto bnb_rows = [&](auto silu, const vec8& gv, const u32x4& uraw) {
+        const vec8 uu = __builtin_bit_cast(vec8, uraw);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x2 uf = {to_f32<T>(uu[2 * q]), to_f32<T>(uu[2 * q + 1])};
+            f32x2 g = {to_f32<T>(gv[2 * q]), to_f32<T>(gv[2 * q + 1])};
+            if (decltype(silu)::value) {
+                const f32x2 z = uf * bsc[q] + bsh[q];
+                g *= silu_grad2(z, sigmoid2(z));
+            }
+            const f32x2 gu = g * uf;
+            st0[2 * q] += g[0]; st0[2 * q + 1] += g[1];
+            st1[2 * q] += gu[0]; st1[2 * q + 1] += gu[1];
+        }
+    };
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int pl = i * PPI + rp;
         vec8 ov = *(const vec8*)(wl + pl * RB + ((ch ^ swz<MC * 32>(pl)) << 4));
-        if (want_stats && yoff[i] != OOB) {
+        if (!BNB && want_stats && yoff[i] != OOB) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) { const float f = to_f32<T>(ov[q]); st0[q] += f; st1[q] += f * f; }
         }
@@ -262,6 +306,11 @@ Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MP], unsigned cha
 #pragma unroll
             for (int q = 0; q < 8; q += 2) sum[q >> 1] = pack2<T>(to_f32<T>(ov[q]) + to_f32<T>(rr[q]), to_f32<T>(ov[q + 1]) + to_f32<T>(rr[q + 1]));
             ov = __builtin_bit_cast(vec8, sum);
+        }
+        if constexpr (BNB) {   // on the value as stored (after the accumulation through the residual port)
+            if (yoff[i] != OOB) {
+                if (p.bnb_act == Y3_ACT_SILU) bnb_rows(std::true_type{}, ov, ru[i]); else bnb_rows(std::false_type{}, ov, ru[i]);
+            }
         }
         const u32x4 raw = __builtin_bit_cast(u32x4, ov);
         if (!p.ups) {
@@ -461,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_v2_kernel(const ConvArgs p)
 // vmcnt(0) precedes it) and retires the reads of the stage tile t+1 is about to overwrite.  Fragments are
 // double-buffered in registers so the ds_read of k-substep s+1 is in flight under the MFMAs of s.
 // WAVES 2x2; per-wave tile (MC*32 couts) x (MP*32 pixels).
-template <typename T, int BK, int MC, int MP>
+template <typename T, int BK, int MC, int MP, bool BNB = false>
 Y3_DEV void conv_igemm_v3_body(const ConvArgs& p, const int block_id, const int n_blocks) {
 #if defined(__HIP_DEVICE_COMPILE__)  // device-only builtins (LDS address space, buffer->LDS DMA): the host pass only needs the stub
     constexpr int WAVES_C = 2, WAVES_P = 2;
@@ -600,14 +649,14 @@ Y3_DEV void conv_igemm_v3_body(const ConvArgs& p, const int block_id, const int 
     Y3_STAMP(3);
 
     __syncthreads();  // every wave is done with the stage buffers: they become the per-wave transpose slices
-    epilogue_wave<T, MC, MP>(p, acc, smem + wv * (MP * 32 * MC * 64), ct * TC + wc * MC * 32, pt * TP + wp * MP * 32, lane, pt * WAVES_P + wp);
+    epilogue_wave<T, MC, MP, BNB>(p, acc, smem + wv * (MP * 32 * MC * 64), ct * TC + wc * MC * 32, pt * TP + wp * MP * 32, lane, pt * WAVES_P + wp);
     Y3_STAMP(4);
 #endif
 }
 
-template <typename T, int BK, int MC, int MP>
+template <typename T, int BK, int MC, int MP, bool BNB = false>
 __global__ __launch_bounds__(256, (BK == 32 && MC * MP <= 4 ? 4 : 2)) void conv_igemm_v3_kernel(const ConvArgs p) {
-    conv_igemm_v3_body<T, BK, MC, MP>(p, blockIdx.x, gridDim.x);
+    conv_igemm_v3_body<T, BK, MC, MP, BNB>(p, blockIdx.x, gridDim.x);
 }
 
 // Four convolutions of the SAME input in one launch: the output-parity classes of a stride-2 data gradient (y3_conv2d_dgrad_s2).  As
@@ -617,12 +666,12 @@ __global__ __launch_bounds__(256, (BK == 32 && MC * MP <= 4 ? 4 : 2)) void conv_
 struct ConvArgs4 {
     ConvArgs a[4];
 };
-template <typename T, int BK, int MC, int MP>
+template <typename T, int BK, int MC, int MP, bool BNB = false>
 __global__ __launch_bounds__(256, (BK == 32 && MC * MP <= 4 ? 4 : 2)) void conv_igemm_v3_quad_kernel(const ConvArgs4 q, const int n_blocks) {
     const int cls = (blockIdx.x >> 3) & 3;
     const int bid = (int)((blockIdx.x >> 5) << 3) | (int)(blockIdx.x & 7);
     if (bid >= n_blocks) return;
-    conv_igemm_v3_body<T, BK, MC, MP>(q.a[cls], bid, n_blocks);
+    conv_igemm_v3_body<T, BK, MC, MP, BNB>(q.a[cls], bid, n_blocks);
 }
 
 // ---- v5: the v3 structure generalised to WAVES_C x WAVES_P waves (8 waves = 512 threads, 256 couts x 256 pixels).
@@ -646,7 +695,7 @@ __global__ __launch_bounds__(256, (BK == 32 && MC * MP <= 4 ? 4 : 2)) void conv_
 // tile t+2 lands in the stage of tile t-2, whose last reads retired two intervals ago.  A tile is first read (by the
 // leading half) in the interval after every wave's counted vmcnt retired its pieces of that tile and passed a barrier:
 // the wait sits at the end of MEM(t-1), the reads in MEM(t).  Waits never drain to 0 in the steady state.
-template <typename T, int BK, int WAVES_C, int WAVES_P, int MC, int MP, int SCHED = 0>
+template <typename T, int BK, int WAVES_C, int WAVES_P, int MC, int MP, int SCHED = 0, bool BNB = false>
 __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, 2) void conv_igemm_v5_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // device-only builtins (LDS address space, buffer->LDS DMA): the host pass only needs the stub
     constexpr int NT = 64 * WAVES_C * WAVES_P;
@@ -818,12 +867,12 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, 2) void conv_igemm_v5_kerne
         Y3_STAMP(3);
         __syncthreads();  // every wave is done with the stage buffers: they become the per-wave transpose slices
     }
-    epilogue_wave<T, MC, MP>(p, acc, smem + wv * (MP * 32 * MC * 64), ct * TC + wc * MC * 32, pt * TP + wp * MP * 32, lane, pt * WAVES_P + wp);
+    epilogue_wave<T, MC, MP, BNB>(p, acc, smem + wv * (MP * 32 * MC * 64), ct * TC + wc * MC * 32, pt * TP + wp * MP * 32, lane, pt * WAVES_P + wp);
     Y3_STAMP(4);
 #endif
 }
 
-template <typename T, int BK, int WAVES_C, int WAVES_P, int MC, int MP, int SCHED = 0> int launch_v5(ConvArgs& a, hipStream_t st) {
+template <typename T, int BK, int WAVES_C, int WAVES_P, int MC, int MP, int SCHED = 0, bool BNB = false> int launch_v5(ConvArgs& a, hipStream_t st) {
     constexpr int TC = WAVES_C * MC * 32, TP = WAVES_P * MP * 32;
     a.n_ct = y3_ceil_div(a.Cout, TC);
     a.n_pt = y3_ceil_div(a.M, TP);
@@ -835,7 +884,7 @@ template <typename T, int BK, int WAVES_C, int WAVES_P, int MC, int MP, int SCHE
     a.stat_wp = WAVES_P;
     g_last_variant = SCHED == 1 ? "v6" : (BK == 64 ? "v5_bk64" : "v5_bk32");
     if (a.dry) return 0;
-    hipLaunchKernelGGL((conv_igemm_v5_kernel<T, BK, WAVES_C, WAVES_P, MC, MP, SCHED>), dim3((unsigned)nb), dim3(64 * WAVES_C * WAVES_P), 0, st, a);
+    hipLaunchKernelGGL((conv_igemm_v5_kernel<T, BK, WAVES_C, WAVES_P, MC, MP, SCHED, BNB>), dim3((unsigned)nb), dim3(64 * WAVES_C * WAVES_P), 0, st, a);
     Y3_CHECK_LAUNCH();
     return 0;
 }
@@ -854,7 +903,7 @@ template <typename T, int BK, int MC, int MP> void geometry_v3(ConvArgs& a) {
     a.nk = a.ntaps * a.cin_blocks;
     a.stat_wp = 2;
 }
-template <typename T, int BK, int MC, int MP> int launch_v3(ConvArgs& a, hipStream_t st) {
+template <typename T, int BK, int MC, int MP, bool BNB = false> int launch_v3(ConvArgs& a, hipStream_t st) {
     geometry_v3<T, BK, MC, MP>(a);
     const long long nb = (long long)a.n_ct * a.n_pt;
     if (nb > 0x7fffffffLL) Y3_FAIL("conv grid too large");
@@ -866,12 +915,12 @@ template <typename T, int BK, int MC, int MP> int launch_v3(ConvArgs& a, hipStre
             q.a[i] = g_quad[i];
             geometry_v3<T, BK, MC, MP>(q.a[i]);
         }
-        hipLaunchKernelGGL((conv_igemm_v3_quad_kernel<T, BK, MC, MP>), dim3((unsigned)((nb + 7) / 8 * 32)), dim3(256), 0, st, q, (int)nb);
+        hipLaunchKernelGGL((conv_igemm_v3_quad_kernel<T, BK, MC, MP, BNB>), dim3((unsigned)((nb + 7) / 8 * 32)), dim3(256), 0, st, q, (int)nb);
         Y3_CHECK_LAUNCH();
         g_quad_done = true;
         return 0;
     }
-    hipLaunchKernelGGL((conv_igemm_v3_kernel<T, BK, MC, MP>), dim3((unsigned)nb), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_igemm_v3_kernel<T, BK, MC, MP, BNB>), dim3((unsigned)nb), dim3(256), 0, st, a);
     Y3_CHECK_LAUNCH();
     return 0;
 }
@@ -958,54 +1007,62 @@ int launch_igemm(ConvArgs& a, hipStream_t st) {
 
 #include "conv_v7.h"
 
-template <typename T> int dispatch_igemm(ConvArgs& a, hipStream_t st) {
+// BNB = the data-gradient launch also writes the BatchNorm-backward statistic rows (ConvArgs::bnb_*): separate instantiations of the
+// LDS-DMA kernels (the register-staged v2 fallback has none: the caller asks y3_conv2d_fwd_variant first)
+template <typename T, bool BNB = false> int dispatch_igemm(ConvArgs& a, hipStream_t st) {
     const bool c64 = (a.Cin % 64) == 0, c32 = (a.Cin % 32) == 0;
-    const int var = conv_variant();
+    const int var = BNB ? 3 : conv_variant();
     if (!(a.x_bytes && a.w_bytes && a.y_bytes && (!a.res || a.r_bytes)))
         Y3_FAIL("conv: a tensor exceeds the 2 GiB reach of a buffer descriptor (split the batch)");
     const bool dma_ok = true;
-    if (var == 3 && v7_eligible(a)) return launch_v7<T>(a, st);
+    if (var == 3 && v7_eligible(a)) return launch_v7<T, BNB>(a, st);
     if (var >= 3 && a.Cout > 64 && c32 && dma_ok) {
-        if (var == 4) return launch_v3<T, 32, 2, 4>(a, st);   // 128c x 256p, BK 32
-        if (var == 5) return launch_v3<T, 32, 2, 2>(a, st);   // 128c x 128p, BK 32 (4 blocks / CU)
-        if (var == 6) return c64 ? launch_v3<T, 64, 2, 2>(a, st) : launch_v3<T, 32, 2, 2>(a, st);
-        if (var == 14 && a.Cout >= 256) return launch_v5<T, 32, 2, 4, 4, 2, 1>(a, st);   // staggered halves, wave 128c x 64p
-        if (var == 15 && a.Cout >= 256) return launch_v5<T, 32, 4, 2, 2, 4, 1>(a, st);   // staggered halves, wave 64c x 128p
-        if (var >= 11 && var <= 13 && c64 && a.Cout >= 256) {
-            if (var == 11) return launch_v5<T, 64, 2, 4, 4, 2>(a, st);   // 256c x 256p, wave 128c x 64p, BK 64
-            if (var == 12) return launch_v5<T, 64, 4, 2, 2, 4>(a, st);   // 256c x 256p, wave 64c x 128p, BK 64
-            return launch_v5<T, 32, 2, 4, 4, 2>(a, st);                  // 256c x 256p, wave 128c x 64p, BK 32 (2 blocks/CU by LDS)
+        if constexpr (!BNB) {   // forced variants (A/B runs)
+            if (var == 4) return launch_v3<T, 32, 2, 4>(a, st);   // 128c x 256p, BK 32
+            if (var == 5) return launch_v3<T, 32, 2, 2>(a, st);   // 128c x 128p, BK 32 (4 blocks / CU)
+            if (var == 6) return c64 ? launch_v3<T, 64, 2, 2>(a, st) : launch_v3<T, 32, 2, 2>(a, st);
+            if (var == 14 && a.Cout >= 256) return launch_v5<T, 32, 2, 4, 4, 2, 1>(a, st);   // staggered halves, wave 128c x 64p
+            if (var == 15 && a.Cout >= 256) return launch_v5<T, 32, 4, 2, 2, 4, 1>(a, st);   // staggered halves, wave 64c x 128p
+            if (var >= 11 && var <= 13 && c64 && a.Cout >= 256) {
+                if (var == 11) return launch_v5<T, 64, 2, 4, 4, 2>(a, st);   // 256c x 256p, wave 128c x 64p, BK 64
+                if (var == 12) return launch_v5<T, 64, 4, 2, 2, 4>(a, st);   // 256c x 256p, wave 64c x 128p, BK 64
+                return launch_v5<T, 32, 2, 4, 4, 2>(a, st);                  // 256c x 256p, wave 128c x 64p, BK 32 (2 blocks/CU by LDS)
+            }
         }
         // auto (measured on MI355X, profiles/r01_conv_variants.md): long-K layers with >= 512 filters want the 8-wave
         // 256x256 tile (v5), short K loops want 4 resident blocks per CU (BK 32), small pixel counts with long K the
         // 128x256 tile, the rest the BK 64 128x128 tile.
         // (re-measured after the epilogue rewrite, gpurun_out/variants2.log -> profiles/r01_conv_variants.md)
         const int K = a.ntaps * a.Cin;
-        if (K >= 2304 && a.Cout >= 512) return launch_v5<T, 32, 4, 2, 2, 4, 1>(a, st);   // 256c x 256p, 8 waves (64c x 128p each), staggered halves
-        if (K >= 4608 && a.Cout >= 256 && a.M >= 65536) return launch_v5<T, 32, 4, 2, 2, 4, 1>(a, st);   // data gradient of the 256 -> 512 layers (one filter tile)
-        if (c64 && a.ntaps == 1 && a.Cout >= 256 && a.M > 16384 && a.M <= 65536) return launch_v5<T, 32, 4, 2, 2, 4, 1>(a, st);   // 1x1 @40x40
-        if (c64 && ((a.ntaps > 1 && K >= 1152) || (a.ntaps == 1 && K >= 256 && a.M <= 16384))) return launch_v3<T, 64, 2, 2>(a, st);
+        if (K >= 2304 && a.Cout >= 512) return launch_v5<T, 32, 4, 2, 2, 4, 1, BNB>(a, st);   // 256c x 256p, 8 waves (64c x 128p each), staggered halves
+        if (K >= 4608 && a.Cout >= 256 && a.M >= 65536) return launch_v5<T, 32, 4, 2, 2, 4, 1, BNB>(a, st);   // data gradient of the 256 -> 512 layers (one filter tile)
+        if (c64 && a.ntaps == 1 && a.Cout >= 256 && a.M > 16384 && a.M <= 65536) return launch_v5<T, 32, 4, 2, 2, 4, 1, BNB>(a, st);   // 1x1 @40x40
+        if (c64 && ((a.ntaps > 1 && K >= 1152) || (a.ntaps == 1 && K >= 256 && a.M <= 16384))) return launch_v3<T, 64, 2, 2, BNB>(a, st);
         // round 2 sweep (profiles/r02_conv_variant_sweep.txt): 64 -> 128 3x3 @160x160 runs 5 % faster on the 128c x 256p tile, the stride-2
         // 64 -> 128 layer 3 % faster with BK 64
-        if (c64 && a.ntaps > 1 && K == 576 && a.Cout == 128 && a.M >= 262144) return a.stride == 1 ? launch_v3<T, 32, 2, 4>(a, st) : launch_v3<T, 64, 2, 2>(a, st);
-        return launch_v3<T, 32, 2, 2>(a, st);
+        if (c64 && a.ntaps > 1 && K == 576 && a.Cout == 128 && a.M >= 262144) return a.stride == 1 ? launch_v3<T, 32, 2, 4, BNB>(a, st) : launch_v3<T, 64, 2, 2, BNB>(a, st);
+        return launch_v3<T, 32, 2, 2, BNB>(a, st);
     }
     // <= 64-filter layers with Cin % 32 == 0 also go to the LDS-DMA kernel (64c x 256p tile): measured 0.42 -> 0.36 ms on
     // 32->64 s2 @640x640 and 0.44 -> 0.38 ms on 32->64 @320x320 (bs 32); Y3_CONV_SMALL=v2 restores the register-staged kernel
     static const bool small_v3 = !(getenv("Y3_CONV_SMALL") && !strcmp(getenv("Y3_CONV_SMALL"), "v2"));
-    if (small_v3 && var != 2 && a.Cout <= 64 && c32 && dma_ok) return launch_v3<T, 32, 1, 4>(a, st);   // 64c x 256p, wave 32c x 128p
-    if (a.Cout > 64) {
-        if (c64) return launch_igemm<T, 64, 2, 2, 2, 2, false>(a, st);
-        if (c32) return launch_igemm<T, 32, 2, 2, 2, 2, false>(a, st);
-        return launch_igemm<T, 32, 2, 2, 2, 2, true>(a, st);
-    } else if (a.Cout > 32) {
-        if (c64) return launch_igemm<T, 64, 1, 4, 2, 1, false>(a, st);
-        if (c32) return launch_igemm<T, 32, 1, 4, 2, 1, false>(a, st);
-        return launch_igemm<T, 32, 1, 4, 2, 1, true>(a, st);
+    if ((small_v3 || BNB) && var != 2 && a.Cout <= 64 && c32 && dma_ok) return launch_v3<T, 32, 1, 4, BNB>(a, st);   // 64c x 256p, wave 32c x 128p
+    if constexpr (BNB) {
+        Y3_FAIL("conv: the BatchNorm-backward statistics need an LDS-DMA kernel variant (Cin %% 32 == 0)");
     } else {
-        if (c64) return launch_igemm<T, 64, 1, 4, 1, 2, false>(a, st);
-        if (c32) return launch_igemm<T, 32, 1, 4, 1, 2, false>(a, st);
-        return launch_igemm<T, 32, 1, 4, 1, 2, true>(a, st);
+        if (a.Cout > 64) {
+            if (c64) return launch_igemm<T, 64, 2, 2, 2, 2, false>(a, st);
+            if (c32) return launch_igemm<T, 32, 2, 2, 2, 2, false>(a, st);
+            return launch_igemm<T, 32, 2, 2, 2, 2, true>(a, st);
+        } else if (a.Cout > 32) {
+            if (c64) return launch_igemm<T, 64, 1, 4, 2, 1, false>(a, st);
+            if (c32) return launch_igemm<T, 32, 1, 4, 2, 1, false>(a, st);
+            return launch_igemm<T, 32, 1, 4, 2, 1, true>(a, st);
+        } else {
+            if (c64) return launch_igemm<T, 64, 1, 4, 1, 2, false>(a, st);
+            if (c32) return launch_igemm<T, 32, 1, 4, 1, 2, false>(a, st);
+            return launch_igemm<T, 32, 1, 4, 1, 2, true>(a, st);
+        }
     }
 }
 
@@ -1040,8 +1097,17 @@ extern "C" int y3_pack_filter(const float* w, int32_t cout_src, int32_t cin_src,
     return 0;
 }
 
+// BatchNorm-backward statistics of a data-gradient launch (ConvArgs::bnb_*): the pre-BatchNorm tensor of the unit whose output gradient
+// this launch completes, and that unit's normalisation
+struct BnbHost {
+    const y3_tensor* u;
+    const float* scale;
+    const float* shift;
+    int act;
+};
+
 static int conv_fwd_impl(const y3_conv_desc* d, const y3_tensor* x, const void* filt, const float* bias, const y3_tensor* res, const y3_tensor* y, float* stats,
-                         int64_t stat_capacity_rows, int64_t* stat_rows, int dry, void* stream, void* ws = nullptr, size_t ws_bytes = 0) {
+                         int64_t stat_capacity_rows, int64_t* stat_rows, int dry, void* stream, void* ws = nullptr, size_t ws_bytes = 0, const BnbHost* bnb = nullptr) {
     if (!d || !x || !filt || !bias || !y) Y3_FAIL("y3_conv2d_fwd: null argument");
     if (d->ksize != 1 && d->ksize != 3) Y3_FAIL("y3_conv2d_fwd: ksize %d unsupported", d->ksize);
     if (d->stride != 1 && d->stride != 2) Y3_FAIL("y3_conv2d_fwd: stride %d unsupported", d->stride);
@@ -1098,6 +1164,14 @@ static int conv_fwd_impl(const y3_conv_desc* d, const y3_tensor* x, const void* 
         if (algo != Y3_ALGO_MFMA || d->dtype == Y3_F32) Y3_FAIL("y3_conv2d_fwd_stats: the epilogue statistics need the f16/bf16 MFMA path");
         if (d->upsample2x) Y3_FAIL("y3_conv2d_fwd_stats: upsample2x unsupported");
     }
+    if (bnb) {
+        if (!stat_rows) Y3_FAIL("y3_conv2d_fwd_bnb: null row count");
+        const y3_tensor* u = bnb->u;
+        if (!u || !bnb->scale || !bnb->shift) Y3_FAIL("y3_conv2d_fwd_bnb: null argument");
+        if (u->n != y->n || u->h != y->h || u->w != y->w || u->c != y->c) Y3_FAIL("y3_conv2d_fwd_bnb: u is (%d,%d,%d,%d), the gradient (%d,%d,%d,%d)", u->n, u->h, u->w, u->c, y->n, y->h, y->w, y->c);
+        if ((u->pitch % vec) || ((uintptr_t)u->data & 15)) Y3_FAIL("y3_conv2d_fwd_bnb: u must be 16-byte aligned with pitch %% %d == 0", vec);
+        if (bnb->act != Y3_ACT_NONE && bnb->act != Y3_ACT_SILU) Y3_FAIL("y3_conv2d_fwd_bnb: bad activation %d", bnb->act);
+    }
 
     // The MFMA kernels address every tensor through a buffer descriptor (bounds-checked loads are what makes halo / tail lanes free),
     // and a descriptor reaches 2^31 bytes.  Images are independent, so a batch whose input, output or residual exceeds that is run
@@ -1105,13 +1179,15 @@ static int conv_fwd_impl(const y3_conv_desc* d, const y3_tensor* x, const void* 
     // reference has no such limit (ATen indexes with 64 bits).
     const long long opx_img = (long long)Ho * Wo * (d->upsample2x ? 4 : 1);
     const long long img_x = (long long)x->h * x->w * x->pitch * esz, img_y = opx_img * y->pitch * esz, img_r = res ? opx_img * res->pitch * esz : 0;
+    const long long img_u = bnb ? opx_img * bnb->u->pitch * esz : 0;
     const long long LIM = 0x7fffffffLL - 65536;
     const long long wb = (long long)y3_filter_rows(d->cout) * a.Kpad * esz;
     if (wb >= LIM) Y3_FAIL("y3_conv2d_fwd: filter bank beyond 2 GiB");
     int chunk = x->n;
     if (algo == Y3_ALGO_MFMA) {
-        if (img_x >= LIM || img_y >= LIM || img_r >= LIM) Y3_FAIL("y3_conv2d_fwd: one image exceeds the 2 GiB reach of a buffer descriptor");
-        while (chunk > 1 && ((long long)chunk * img_x >= LIM || (long long)chunk * img_y >= LIM || (long long)chunk * img_r >= LIM)) chunk = (chunk + 1) / 2;
+        if (img_x >= LIM || img_y >= LIM || img_r >= LIM || img_u >= LIM) Y3_FAIL("y3_conv2d_fwd: one image exceeds the 2 GiB reach of a buffer descriptor");
+        while (chunk > 1 && ((long long)chunk * img_x >= LIM || (long long)chunk * img_y >= LIM || (long long)chunk * img_r >= LIM || (long long)chunk * img_u >= LIM))
+            chunk = (chunk + 1) / 2;
     }
     if (stat_rows) *stat_rows = 0;
     int64_t rows_done = 0;
@@ -1128,10 +1204,20 @@ static int conv_fwd_impl(const y3_conv_desc* d, const y3_tensor* x, const void* 
         c.w_bytes = (unsigned)wb;
         c.y_bytes = yb < 0x7fffffffLL ? (unsigned)yb : 0u;
         c.r_bytes = rb < 0x7fffffffLL ? (unsigned)rb : 0u;
+        if (bnb) {
+            const long long ub = (((long long)c.N * opx_img - 1) * bnb->u->pitch + bnb->u->c) * esz;
+            c.bnb_u = (const char*)bnb->u->data + (long long)n0 * img_u;
+            c.bnb_upitch = bnb->u->pitch;
+            c.bnb_ubytes = (unsigned)ub;
+            c.bnb_scale = bnb->scale;
+            c.bnb_shift = bnb->shift;
+            c.bnb_act = bnb->act;
+        }
         if (stat_rows) {   // BatchNorm statistics in the epilogue: a dry pass of the dispatcher decides the rows of this launch
             ConvArgs g = c;
             g.dry = 1;
-            const int rc = d->dtype == Y3_F16 ? dispatch_igemm<f16_t>(g, st) : dispatch_igemm<bf16_t>(g, st);
+            const int rc = bnb ? (d->dtype == Y3_F16 ? dispatch_igemm<f16_t, true>(g, st) : dispatch_igemm<bf16_t, true>(g, st))
+                               : (d->dtype == Y3_F16 ? dispatch_igemm<f16_t>(g, st) : dispatch_igemm<bf16_t>(g, st));
             if (rc) return rc;
             const int64_t rows = (int64_t)g.n_pt * g.stat_wp;
             *stat_rows += rows;
@@ -1143,7 +1229,8 @@ static int conv_fwd_impl(const y3_conv_desc* d, const y3_tensor* x, const void* 
         }
         int rc;
         if (algo == Y3_ALGO_MFMA) {
-            if (d->dtype == Y3_F16) rc = dispatch_igemm<f16_t>(c, st);
+            if (bnb) rc = d->dtype == Y3_F16 ? dispatch_igemm<f16_t, true>(c, st) : dispatch_igemm<bf16_t, true>(c, st);
+            else if (d->dtype == Y3_F16) rc = dispatch_igemm<f16_t>(c, st);
             else if (d->dtype == Y3_BF16) rc = dispatch_igemm<bf16_t>(c, st);
             else Y3_FAIL("y3_conv2d_fwd: MFMA path needs f16/bf16");
         } else {
@@ -1225,6 +1312,26 @@ extern "C" int y3_conv2d_fwd_stats_ws(const y3_conv_desc* d, const y3_tensor* x,
     if (!n_rows) Y3_FAIL("y3_conv2d_fwd_stats_ws: null row count");
     if (workspace && ((uintptr_t)workspace & 255)) Y3_FAIL("y3_conv2d_fwd_stats_ws: the workspace must be 256-byte aligned");
     return conv_fwd_impl(d, x, filt, bias, nullptr, y, stat_rows, capacity_rows, n_rows, 0, stream, workspace, workspace_bytes);
+}
+
+// A data-gradient convolution (y3_conv2d_fwd_ws on a y3_pack_filter_dgrad bank, residual = the gradient accumulated so far) that
+// COMPLETES the gradient dy of a tensor y = act(bn(u)): besides storing dy it writes, per (pixel tile, pixel wave), one row [cout][2]
+// fp32 of (sum g, sum g * u) with g = dy * act'(scale * u + shift) of the stored value -- the two reductions of the BatchNorm backward
+// without the pass over (dy, u) (y3_bn_bwd_finalize_rows sums the rows).  stat_rows == NULL: only *n_rows is filled (geometry query).
+extern "C" int y3_conv2d_fwd_bnb_ws(const y3_conv_desc* d, const y3_tensor* x, const void* filt, const float* bias, const y3_tensor* res, const y3_tensor* y,
+                                    const y3_tensor* u, const float* scale, const float* shift, int32_t act, float* stat_rows, int64_t capacity_rows, int64_t* n_rows,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    if (!n_rows) Y3_FAIL("y3_conv2d_fwd_bnb_ws: null row count");
+    if (workspace && ((uintptr_t)workspace & 255)) Y3_FAIL("y3_conv2d_fwd_bnb_ws: the workspace must be 256-byte aligned");
+    alignas(256) static const float dummy[64] = {0.0f};   // geometry query: never dereferenced
+    const BnbHost b{u, stat_rows ? scale : dummy, stat_rows ? shift : dummy, act};
+    if (!stat_rows) {
+        y3_tensor uu;
+        if (!u && y) { uu = *y; uu.data = (void*)dummy; }
+        const BnbHost q{u ? u : &uu, dummy, dummy, act};
+        return conv_fwd_impl(d, x, (const void*)dummy, dummy, nullptr, y, nullptr, 0, n_rows, 1, nullptr, workspace_bytes ? (void*)dummy : nullptr, workspace_bytes, &q);
+    }
+    return conv_fwd_impl(d, x, filt, bias, res, y, stat_rows, capacity_rows, n_rows, 0, stream, workspace, workspace_bytes, &b);
 }
 
 

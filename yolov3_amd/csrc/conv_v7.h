@@ -62,7 +62,7 @@ Y3_DEV void wait_vm(int n) {   // n is wave-uniform; the immediate must be a lit
 #define V7_T(i) do { } while (0)
 #endif
 
-template <typename T, int XP, int SCHED>
+template <typename T, int XP, int SCHED, bool BNB = false>
 __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #ifdef Y3_TIMELINE
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p)
                 f32x16 part[MC][2];
 #pragma unroll
                 for (int a = 0; a < MC; ++a) { part[a][0] = r[a][2 * hb]; part[a][1] = r[a][2 * hb + 1]; }
-                epilogue_wave<T, MC, 2>(p, part, smem + wv * (2 * 32 * MC * 64), ct * 256 + wc * MC * 32, m0 + wp * 128 + hb * 64, lane, (pt * 2 + wp) * 2 + hb);
+                epilogue_wave<T, MC, 2, BNB>(p, part, smem + wv * (2 * 32 * MC * 64), ct * 256 + wc * MC * 32, m0 + wp * 128 + hb * 64, lane, (pt * 2 + wp) * 2 + hb);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();   // the slice is private to the wave: its reads of pass 0 precede the writes of pass 1
             }
@@ -473,7 +473,7 @@ static bool v7_eligible(const ConvArgs& a) {
     return units >= 32 && units < 0x7fffffffLL;   // tiny problems stay on the one-tile-per-block kernels
 }
 
-template <typename T> int launch_v7(ConvArgs& a, hipStream_t st) {
+template <typename T, bool BNB = false> int launch_v7(ConvArgs& a, hipStream_t st) {
     a.n_ct = a.Cout / 256;
     a.n_pt = y3_ceil_div(a.M, 256);
     set_divisors(a);
@@ -516,7 +516,11 @@ template <typename T> int launch_v7(ConvArgs& a, hipStream_t st) {
     const dim3 grid((unsigned)g), block(512);
     int sched = 0;   // SCHED 1 measured 2-6 % slower (profiles/r02_conv_v7.md); kept for A/B
     if (const char* e = getenv("Y3_V7_SCHED")) sched = atoi(e);
-    if (sched == 0) {
+    if (BNB) {
+        if (xp == 3) hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 3, 0, BNB>), grid, block, 0, st, a);
+        else if (xp == 4) hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 4, 0, BNB>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 5, 0, BNB>), grid, block, 0, st, a);
+    } else if (sched == 0) {
         if (xp == 3) hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 3, 0>), grid, block, 0, st, a);
         else if (xp == 4) hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 4, 0>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 5, 0>), grid, block, 0, st, a);

@@ -20,6 +20,31 @@ template <typename T> struct V16 {  // one 16-byte vector of T
     T v[N];
 };
 
+// 16-byte vector access with the cache policy as a template flag: NT = `nt` loads / stores.  Measured on MI355X (tools/lab/bn_lab.hip,
+// profiles/r02_bn_lab_sweep*.txt): on tensors that no cache level can hold (>= 128 MB here) the elementwise BatchNorm passes gain
+// 10-30 % from non-temporal STORES (fwd 5.5 -> 7.1 TB/s on 210 MB) and the two-read passes another 5-10 % from non-temporal LOADS;
+// on tensors that fit the 256 MB Infinity Cache `nt` loads lose 10-15 %, so the host picks per launch by the tensor's bytes.
+typedef unsigned int y3_u32x4 __attribute__((ext_vector_type(4)));
+template <bool NT, typename T> Y3_DEV V16<T> ldv(const T* p) {
+    const y3_u32x4 r = NT ? __builtin_nontemporal_load((const y3_u32x4*)p) : *(const y3_u32x4*)p;
+    return __builtin_bit_cast(V16<T>, r);
+}
+template <bool NT, typename T> Y3_DEV void stv(T* p, const V16<T>& v) {
+    const y3_u32x4 r = __builtin_bit_cast(y3_u32x4, v);
+    if (NT) __builtin_nontemporal_store(r, (y3_u32x4*)p); else *(y3_u32x4*)p = r;
+}
+constexpr long long Y3_NT_BYTES_DEFAULT = 128ll << 20;   // tensors at least this large take the non-temporal forms
+// Y3_BN_STREAM=0 restores the round-1 form of the elementwise passes (plain loads / stores, grid capped at 8192 blocks) for A/B runs
+static bool bn_stream_tuned() {
+    static const bool on = [] { const char* e = getenv("Y3_BN_STREAM"); return !(e && atoi(e) == 0); }();
+    return on;
+}
+static long long bn_nt_bytes() {   // Y3_BN_NT_MB=<n>: threshold in MiB (A/B runs)
+    static const long long v = [] { const char* e = getenv("Y3_BN_NT_MB"); return e ? (long long)atoll(e) << 20 : Y3_NT_BYTES_DEFAULT; }();
+    return v;
+}
+#define Y3_NT_BYTES (bn_stream_tuned() ? bn_nt_bytes() : (1ll << 62))
+
 Y3_DEV float silu_grad(float z, float s) { return s + z * s * (1.0f - s); }  // d silu(z)/dz with s = sigmoid(z)
 
 // The elementwise BN kernels work on PAIRS of channels: the multiplies / adds / fmas are packed fp32 (v_pk_*: two values per lane and
@@ -36,16 +61,7 @@ template <typename T> Y3_DEV void st2(V16<T>& o, int q, f32x2 v) {
         o.v[q + 1] = v[1];
     }
 }
-Y3_DEV f32x2 sigmoid2(f32x2 z) {
-    f32x2 e = z * -1.44269504088896f;
-    e[0] = __builtin_amdgcn_exp2f(e[0]);
-    e[1] = __builtin_amdgcn_exp2f(e[1]);
-    e = e + 1.0f;
-    e[0] = __builtin_amdgcn_rcpf(e[0]);
-    e[1] = __builtin_amdgcn_rcpf(e[1]);
-    return e;
-}
-Y3_DEV f32x2 silu_grad2(f32x2 z, f32x2 s) { return s + z * s * (1.0f - s); }
+// sigmoid2 / silu_grad2: y3_common.h (shared with the data-gradient epilogue of conv.hip)
 // v_exp_f32 + v_rcp_f32 (1-2 ulp each): the elementwise BN kernels were VALU-bound on expf() + an IEEE divide per element
 Y3_DEV float sigmoid_fast(float z) { return __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }
 
@@ -59,7 +75,7 @@ bool vec_ok(const y3_tensor* t, int esz) {
 // ------------------------------------------------------------------------------------------------------------------
 // Per-channel reductions over N*H*W.  MODE 0: (sum u, sum u^2).  MODE 1: (sum dz, sum dz*xhat) for the BN+act backward.
 // Thread t owns channel vector (t % CG) on pixel lane (t / CG); CG = C / V (<= 256).
-template <typename T, int MODE, bool SILU = false>
+template <typename T, int MODE, bool SILU = false, bool NTL = false>
 __global__ __launch_bounds__(256) void channel_reduce_kernel(const T* __restrict__ u, int upitch, const T* __restrict__ dy, int dpitch, long long M, int C,
                                                                const float* __restrict__ scale, const float* __restrict__ shift,
                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -98,8 +114,8 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(const T* __restrict
             for (int j = 0; j < 4; ++j) {
                 const long long m = m0 + j * stride;
                 if (m < M) {
-                    xs[j] = *(const V16<T>*)(u + m * upitch + cg * V);
-                    if (MODE == 1) gs[j] = *(const V16<T>*)(dy + m * dpitch + cg * V);
+                    xs[j] = ldv<NTL, T>(u + m * upitch + cg * V);
+                    if (MODE == 1) gs[j] = ldv<NTL, T>(dy + m * dpitch + cg * V);
                 }
             }
         };
@@ -168,6 +184,8 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(const T* __restrict
 // The consumers of the totals ride along (one launch instead of two or three ~5 us launches per conv unit and pass):
 //   MODE 1: + BatchNorm finalize (mean / biased var -> scale, shift, running statistics) for the block's 8 channels
 //   MODE 2: + (dbeta, dgamma) of the BN backward        MODE 3: + fp32 copy of the even entries (bias gradient)
+//   MODE 4: the rows are (sum g, sum g*u) from a data-gradient epilogue (conv.hip, BNB): totals = (sum g, invstd * (sum g*u - mean * sum g))
+//           = (sum g, sum g*xhat) go to `totals` (what bn_act_bwd_apply_kernel reads) + (dbeta, dgamma); f.mean / f.invstd are inputs
 struct BnFinalizeArgs {
     double count;
     const float* gamma;
@@ -196,7 +214,7 @@ Y3_DEV void bn_finalize_channel(int c, double s0, double s1, const BnFinalizeArg
 // TIN = double: rows 1.. of `sums` (the reduction kernels' partial rows); TIN = float: the rows the conv epilogue wrote (`part`)
 template <int MODE, typename TIN = double>
 __global__ __launch_bounds__(256) void reduce_partials_kernel(double* __restrict__ sums, int n2c, int nblocks, BnFinalizeArgs f, float* __restrict__ o0, float* __restrict__ o1,
-                                                                int c_out, const TIN* __restrict__ part = nullptr) {
+                                                                int c_out, const TIN* __restrict__ part = nullptr, double* __restrict__ totals = nullptr) {
     __shared__ double red[256];
     const int j = blockIdx.x * 16 + (threadIdx.x & 15);
     const int rl = threadIdx.x >> 4;
@@ -223,13 +241,28 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(double* __restrict
         __syncthreads();
     }
     if (rl == 0 && j < n2c) {
-        sums[j] = red[threadIdx.x];
+        if (MODE != 4) sums[j] = red[threadIdx.x];
         if (MODE != 0 && (j & 1) == 0) {   // entries (2c, 2c+1) of channel c sit in neighbouring lanes of row-lane 0
             const int c = j >> 1;
             const double s0 = red[threadIdx.x], s1 = red[threadIdx.x + 1];
             if (MODE == 1) bn_finalize_channel(c, s0, s1, f);
-            if (MODE == 2) { if (o0) o0[c] = (float)s0; if (o1) o1[c] = (float)s1; }
+            if (MODE == 2) {
+                if (o0) o0[c] = (float)s0;
+                if (o1) o1[c] = (float)s1;
+                // means for the apply pass in partial row 0 (this block is the only reader of its 16 columns and is done with them): the
+                // apply kernel then needs no fp64 division per thread
+                if (f.count > 0.0) { sums[n2c + j] = s0 / f.count; sums[n2c + j + 1] = s1 / f.count; }
+            }
             if (MODE == 3) { if (c < c_out) o0[c] = (float)s0; }
+            if (MODE == 4) {
+                const double sx = (double)f.invstd[c] * (s1 - (double)f.mean[c] * s0);
+                totals[j] = s0;
+                totals[j + 1] = sx;
+                totals[n2c + j] = s0 / f.count;       // means, as the apply pass reads them
+                totals[n2c + j + 1] = sx / f.count;
+                if (o0) o0[c] = (float)s0;
+                if (o1) o1[c] = (float)sx;
+            }
         }
     }
 }
@@ -243,7 +276,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, int C, BnFin
 
 // y = act(u*scale + shift) (+ residual).  Thread (cg, pl) keeps its 8 channels' scale/shift in registers and walks
 // pixels pl, pl+PL*grid, ...: one 16-byte load and store per pixel, no per-element index arithmetic.
-template <typename T, bool SILU>
+template <typename T, bool SILU, bool NTS = false>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ u, int upitch, const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const T* __restrict__ res, int rpitch, T* __restrict__ y, int ypitch, long long M, int C) {
     constexpr int V = V16<T>::N;
@@ -266,15 +299,16 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ u
             if (res) z += ld2<T>(r, 2 * q);
             st2<T>(o, 2 * q, z);
         }
-        *(V16<T>*)(y + m * ypitch + cg * V) = o;
+        stv<NTS, T>(y + m * ypitch + cg * V, o);
     }
 }
 
 // du = gamma*invstd * (dz - mean(dz) - xhat*mean(dz*xhat));   dz = dy * act'(z).  Same thread mapping as the forward.
-template <typename T, bool SILU>
+// `means` = (mean dz, mean dz*xhat) per channel as fp64 (row 1 of the reduction scratch / second half of the epilogue totals)
+template <typename T, bool SILU, bool NT = false>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restrict__ u, int upitch, const T* __restrict__ dy, int dpitch,
                                                                  const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
-                                                                 const float* __restrict__ invstd, const double* __restrict__ sums, double count,
+                                                                 const float* __restrict__ invstd, const double* __restrict__ means,
                                                                  T* __restrict__ du, int opitch, long long M, int C, T* __restrict__ gres, int gpitch,
                                                                  int gres_acc) {
     constexpr int V = V16<T>::N;
@@ -286,12 +320,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
     for (int q = 0; q < V; ++q) {
         const int c = cg * V + q;
         sc[q / 2][q & 1] = scale[c]; sh[q / 2][q & 1] = shift[c]; mu[q / 2][q & 1] = mean[c]; is[q / 2][q & 1] = invstd[c];
-        m0[q / 2][q & 1] = (float)(sums[c * 2] / count);
-        m1[q / 2][q & 1] = (float)(sums[c * 2 + 1] / count);
+        m0[q / 2][q & 1] = (float)means[c * 2];
+        m1[q / 2][q & 1] = (float)means[c * 2 + 1];
     }
     for (long long m = (long long)blockIdx.x * PL + pl; m < M; m += (long long)gridDim.x * PL) {
-        const V16<T> x = *(const V16<T>*)(u + m * upitch + cg * V);
-        const V16<T> g = *(const V16<T>*)(dy + m * dpitch + cg * V);
+        const V16<T> x = ldv<NT, T>(u + m * upitch + cg * V);
+        const V16<T> g = ldv<NT, T>(dy + m * dpitch + cg * V);
         V16<T> o;
 #pragma unroll
         for (int q = 0; q < V / 2; ++q) {
@@ -304,7 +338,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
             const f32x2 xh = (uf - mu[q]) * is[q];
             st2<T>(o, 2 * q, sc[q] * (dz - m0[q] - xh * m1[q]));  // scale = gamma * invstd
         }
-        *(V16<T>*)(du + m * opitch + cg * V) = o;
+        stv<NT, T>(du + m * opitch + cg * V, o);
         if (gres) {   // out = act(bn(conv)) + residual: the residual's gradient (+)= dy, on the pass that reads dy anyway
             V16<T> r = g;
             if (gres_acc) {
@@ -1255,7 +1289,8 @@ static int reduce_geometry(int C, int esz, long long M, unsigned& grid) {
     return 0;
 }
 
-// streaming kernels: 4 pixels per thread per pass, capped so the grid stays a few waves deep on 256 CUs
+// streaming kernels: 4 pixels per thread.  (Round 1 capped the grid at 8192 blocks; measured with tools/lab/bn_lab.hip the uncapped
+// grid -- every thread makes its 4 trips and leaves -- streams 839 MB tensors at 6.0-6.3 TB/s instead of 4.9-5.5.)
 static int elementwise_geometry(int C, int esz, long long M, unsigned& grid) {
     const int V = 16 / esz;
     if (C % V) Y3_FAIL("channel count %d must be a multiple of %d", C, V);
@@ -1263,7 +1298,8 @@ static int elementwise_geometry(int C, int esz, long long M, unsigned& grid) {
     if (CG > 256) Y3_FAIL("channel count %d too large (max %d)", C, 256 * V);
     const int PL = 256 / CG;
     long long g = (M + (long long)PL * 4 - 1) / ((long long)PL * 4);
-    if (g > 8192) g = 8192;
+    const long long cap = bn_stream_tuned() ? (1ll << 20) : 8192;
+    if (g > cap) g = cap;
     if (g < 1) g = 1;
     grid = (unsigned)g;
     return 0;
@@ -1364,9 +1400,10 @@ extern "C" int y3_bn_act_fwd(const y3_tensor* u, const float* scale, const float
     const long long M = (long long)u->n * u->h * u->w;
     unsigned egrid;
     if (elementwise_geometry(u->c, esz, M, egrid)) return -1;
-#define Y3_BN_FWD(SILU) hipLaunchKernelGGL((bn_act_fwd_kernel<T, SILU>), dim3(egrid), dim3(256), 0, (hipStream_t)stream, (const T*)u->data, u->pitch, scale, shift, \
+    const bool nt = M * u->c * esz >= Y3_NT_BYTES;
+#define Y3_BN_FWD(SILU, NTS) hipLaunchKernelGGL((bn_act_fwd_kernel<T, SILU, NTS>), dim3(egrid), dim3(256), 0, (hipStream_t)stream, (const T*)u->data, u->pitch, scale, shift, \
                                           residual ? (const T*)residual->data : (const T*)nullptr, residual ? residual->pitch : 0, (T*)y->data, y->pitch, M, u->c)
-    Y3_DISPATCH_T(dtype, if (act == Y3_ACT_SILU) Y3_BN_FWD(true); else Y3_BN_FWD(false));
+    Y3_DISPATCH_T(dtype, if (act == Y3_ACT_SILU) { if (nt) Y3_BN_FWD(true, true); else Y3_BN_FWD(true, false); } else { if (nt) Y3_BN_FWD(false, true); else Y3_BN_FWD(false, false); });
 #undef Y3_BN_FWD
     Y3_CHECK_LAUNCH();
     return 0;
@@ -1384,20 +1421,24 @@ static int bn_act_bwd_impl(const y3_tensor* u, const y3_tensor* dy, const float*
     unsigned grid;
     if (reduce_geometry(u->c, esz, M, grid)) return -1;
     hipStream_t st = (hipStream_t)stream;
-#define Y3_BN_RED(SILU) hipLaunchKernelGGL((channel_reduce_kernel<T, 1, SILU>), dim3(grid), dim3(256), 0, st, (const T*)u->data, u->pitch, (const T*)dy->data, dy->pitch, M, \
+    const bool nt = M * u->c * esz >= Y3_NT_BYTES;
+#define Y3_BN_RED(SILU, NTL) hipLaunchKernelGGL((channel_reduce_kernel<T, 1, SILU, NTL>), dim3(grid), dim3(256), 0, st, (const T*)u->data, u->pitch, (const T*)dy->data, dy->pitch, M, \
                                           u->c, scale, shift, mean, invstd, sums)
-    Y3_DISPATCH_T(dtype, if (act == Y3_ACT_SILU) Y3_BN_RED(true); else Y3_BN_RED(false));
+    // (the reduction's operands are read again by the apply pass: plain loads keep what fits in the Infinity Cache)
+    Y3_DISPATCH_T(dtype, if (act == Y3_ACT_SILU) { if (nt) Y3_BN_RED(true, true); else Y3_BN_RED(true, false); } else { if (nt) Y3_BN_RED(false, true); else Y3_BN_RED(false, false); });
 #undef Y3_BN_RED
     Y3_CHECK_LAUNCH();
-    // partial rows -> totals (the apply pass reads them) + (dbeta, dgamma) in the same launch
-    hipLaunchKernelGGL(reduce_partials_kernel<2>, dim3((2 * u->c + 15) / 16), dim3(256), 0, st, sums, 2 * u->c, (int)grid, BnFinalizeArgs{}, dbeta, dgamma, 0);
+    // partial rows -> totals + (dbeta, dgamma) + the means the apply pass reads (partial row 0) in the same launch
+    BnFinalizeArgs fm{};
+    fm.count = (double)M;
+    hipLaunchKernelGGL(reduce_partials_kernel<2>, dim3((2 * u->c + 15) / 16), dim3(256), 0, st, sums, 2 * u->c, (int)grid, fm, dbeta, dgamma, 0);
     Y3_CHECK_LAUNCH();
     unsigned egrid;
     if (elementwise_geometry(u->c, esz, M, egrid)) return -1;
-#define Y3_BN_APPLY(SILU) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, SILU>), dim3(egrid), dim3(256), 0, st, (const T*)u->data, u->pitch, (const T*)dy->data, \
-                                            dy->pitch, scale, shift, mean, invstd, (const double*)sums, (double)M, (T*)du->data, du->pitch, M, u->c, \
+#define Y3_BN_APPLY(SILU, NT) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, SILU, NT>), dim3(egrid), dim3(256), 0, st, (const T*)u->data, u->pitch, (const T*)dy->data, \
+                                            dy->pitch, scale, shift, mean, invstd, (const double*)sums + 2 * u->c, (T*)du->data, du->pitch, M, u->c, \
                                             gres ? (T*)gres->data : (T*)nullptr, gres ? gres->pitch : 0, gres_accumulate)
-    Y3_DISPATCH_T(dtype, if (act == Y3_ACT_SILU) Y3_BN_APPLY(true); else Y3_BN_APPLY(false));
+    Y3_DISPATCH_T(dtype, if (act == Y3_ACT_SILU) { if (nt) Y3_BN_APPLY(true, true); else Y3_BN_APPLY(true, false); } else { if (nt) Y3_BN_APPLY(false, true); else Y3_BN_APPLY(false, false); });
 #undef Y3_BN_APPLY
     Y3_CHECK_LAUNCH();
     return 0;
@@ -1413,6 +1454,52 @@ extern "C" int y3_bn_act_bwd_res(const y3_tensor* u, const y3_tensor* dy, const 
                                  int32_t act, double* sums, const y3_tensor* du, float* dgamma, float* dbeta, const y3_tensor* gres, int32_t gres_accumulate, void* stream) {
     if (!gres) Y3_FAIL("y3_bn_act_bwd_res: null residual gradient");
     return bn_act_bwd_impl(u, dy, scale, shift, mean, invstd, dtype, act, sums, du, dgamma, dbeta, gres, gres_accumulate, stream);
+}
+
+// BatchNorm backward whose two reductions came out of the data-gradient launch that completed dy (y3_conv2d_fwd_bnb_ws, conv.hip):
+// (1) fixed-order fp64 sum of the (sum g, sum g*u) rows -> `totals` [C][2] = (sum g, sum g*xhat), dbeta, dgamma;
+// (2) the apply pass alone.  Replaces the reduction pass of y3_bn_act_bwd over (dy, u).
+extern "C" int y3_bn_bwd_finalize_rows(const float* stat_rows, int64_t n_rows, int64_t count, int32_t C, double* sums, const float* mean, const float* invstd,
+                                       double* totals, float* dgamma, float* dbeta, void* stream) {
+    if (!stat_rows || !sums || !mean || !invstd || !totals || n_rows <= 0 || n_rows > 0x7fffffffLL || C <= 0 || count <= 0) Y3_FAIL("y3_bn_bwd_finalize_rows: bad argument");
+    BnFinalizeArgs f{};
+    f.count = (double)count;
+    f.mean = const_cast<float*>(mean);      // MODE 4 only reads them
+    f.invstd = const_cast<float*>(invstd);
+    hipStream_t st = (hipStream_t)stream;
+    if (n_rows > Y3_BN_PARTIAL_ROWS) {   // `sums` is a Y3_BN_SCRATCH_DOUBLES(C) buffer: two levels through its partial rows
+        const int per = (int)((n_rows + Y3_BN_PARTIAL_ROWS - 1) / Y3_BN_PARTIAL_ROWS);
+        const int blocks = (int)((n_rows + per - 1) / per);
+        hipLaunchKernelGGL(stat_rows_to_partials_kernel, dim3((unsigned)blocks), dim3(256), 0, st, stat_rows, (long long)n_rows, 2 * C, per, sums);
+        Y3_CHECK_LAUNCH();
+        hipLaunchKernelGGL((reduce_partials_kernel<4, double>), dim3((2 * C + 15) / 16), dim3(256), 0, st, sums, 2 * C, blocks, f, dbeta, dgamma, 0, (const double*)nullptr, totals);
+    } else {
+        hipLaunchKernelGGL((reduce_partials_kernel<4, float>), dim3((2 * C + 15) / 16), dim3(256), 0, st, sums, 2 * C, (int)n_rows, f, dbeta, dgamma, 0, stat_rows, totals);
+    }
+    Y3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int y3_bn_act_bwd_apply(const y3_tensor* u, const y3_tensor* dy, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t dtype,
+                                   int32_t act, const double* totals, const y3_tensor* du, const y3_tensor* gres, int32_t gres_accumulate, void* stream) {
+    if (!u || !dy || !scale || !shift || !mean || !invstd || !totals || !du) Y3_FAIL("y3_bn_act_bwd_apply: null argument");
+    if (dy->n != u->n || dy->h != u->h || dy->w != u->w || dy->c != u->c || du->c != u->c || du->h != u->h) Y3_FAIL("y3_bn_act_bwd_apply: shape mismatch");
+    const int esz = esize(dtype);
+    if (!vec_ok(u, esz) || !vec_ok(dy, esz) || !vec_ok(du, esz)) Y3_FAIL("y3_bn_act_bwd_apply: alignment");
+    if (gres && (gres->n != u->n || gres->h != u->h || gres->w != u->w || gres->c != u->c || !vec_ok(gres, esz))) Y3_FAIL("y3_bn_act_bwd_apply: residual gradient shape / alignment");
+    if (gres && gres->data == dy->data) Y3_FAIL("y3_bn_act_bwd_apply: the residual gradient must not alias dy");
+    const long long M = (long long)u->n * u->h * u->w;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned egrid;
+    if (elementwise_geometry(u->c, esz, M, egrid)) return -1;
+    const bool nt = M * u->c * esz >= Y3_NT_BYTES;
+#define Y3_BN_APPLY(SILU, NT) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, SILU, NT>), dim3(egrid), dim3(256), 0, st, (const T*)u->data, u->pitch, (const T*)dy->data, \
+                                            dy->pitch, scale, shift, mean, invstd, totals + 2 * u->c, (T*)du->data, du->pitch, M, u->c, \
+                                            gres ? (T*)gres->data : (T*)nullptr, gres ? gres->pitch : 0, gres_accumulate)
+    Y3_DISPATCH_T(dtype, if (act == Y3_ACT_SILU) { if (nt) Y3_BN_APPLY(true, true); else Y3_BN_APPLY(true, false); } else { if (nt) Y3_BN_APPLY(false, true); else Y3_BN_APPLY(false, false); });
+#undef Y3_BN_APPLY
+    Y3_CHECK_LAUNCH();
+    return 0;
 }
 
 // Layer 0 (no data gradient): BatchNorm + activation backward and the filter gradient without materialising du.
@@ -1435,9 +1522,10 @@ extern "C" int y3_stem_bn_bwd_wgrad(const void* x_nchw, int32_t src_dtype, int32
     hipStream_t st = (hipStream_t)stream;
     unsigned grid;
     if (reduce_geometry(32, 2, M, grid)) return -1;
-#define Y3_BN_RED(SILU) hipLaunchKernelGGL((channel_reduce_kernel<T, 1, SILU>), dim3(grid), dim3(256), 0, st, (const T*)u->data, u->pitch, (const T*)dy->data, dy->pitch, M, \
+    const bool nt = M * 32 * 2 >= Y3_NT_BYTES;
+#define Y3_BN_RED(SILU, NTL) hipLaunchKernelGGL((channel_reduce_kernel<T, 1, SILU, NTL>), dim3(grid), dim3(256), 0, st, (const T*)u->data, u->pitch, (const T*)dy->data, dy->pitch, M, \
                                           32, scale, shift, mean, invstd, sums)
-    Y3_DISPATCH_T(dtype, if (act == Y3_ACT_SILU) Y3_BN_RED(true); else Y3_BN_RED(false));
+    Y3_DISPATCH_T(dtype, if (act == Y3_ACT_SILU) { if (nt) Y3_BN_RED(true, true); else Y3_BN_RED(true, false); } else { if (nt) Y3_BN_RED(false, true); else Y3_BN_RED(false, false); });
 #undef Y3_BN_RED
     Y3_CHECK_LAUNCH();
     hipLaunchKernelGGL(reduce_partials_kernel<2>, dim3((2 * 32 + 15) / 16), dim3(256), 0, st, sums, 2 * 32, (int)grid, BnFinalizeArgs{}, dbeta, dgamma, 0);

@@ -80,6 +80,19 @@ template <typename V, int N> Y3_DEV void silu_vec(V& a) {
     a = a * e;
 }
 
+// packed-pair sigmoid / SiLU derivative (the elementwise BatchNorm kernels of train.hip and the BatchNorm-backward statistics of the
+// data-gradient epilogue in conv.hip): v_exp_f32 + v_rcp_f32 per value, the rest packed fp32
+Y3_DEV f32x2 sigmoid2(f32x2 z) {
+    f32x2 e = z * -1.44269504088896f;
+    e[0] = __builtin_amdgcn_exp2f(e[0]);
+    e[1] = __builtin_amdgcn_exp2f(e[1]);
+    e = e + 1.0f;
+    e[0] = __builtin_amdgcn_rcpf(e[0]);
+    e[1] = __builtin_amdgcn_rcpf(e[1]);
+    return e;
+}
+Y3_DEV f32x2 silu_grad2(f32x2 z, f32x2 s) { return s + z * s * (1.0f - s); }   // d silu(z)/dz with s = sigmoid(z)
+
 // rows of per-block partial sums behind the 2*C totals of y3_bn_stats / y3_bn_act_bwd scratch buffers
 #define Y3_BN_PARTIAL_ROWS 512   // (2048 rows measured slower: the partial-row sum grows faster than the reduction gains)
 

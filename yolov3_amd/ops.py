@@ -372,6 +372,24 @@ def conv2d_stats(x: View, filt: torch.Tensor, bias: torch.Tensor, y: View, k: in
     return int(n.value)
 
 
+def conv2d_bnb(x: View, filt: torch.Tensor, bias: torch.Tensor, y: View, k: int, residual: View | None, in_dilation: int, u: View, scale: torch.Tensor,
+               shift: torch.Tensor, act: int, stat_rows: torch.Tensor | None, capacity_rows: int, workspace: torch.Tensor | None = None) -> int:
+    """The data-gradient conv2d(x, filt) -> y (+ residual) that completes the gradient of a tensor act(bn(u)), with the BatchNorm
+    backward's (sum g, sum g*u) rows written by its epilogue (y3_conv2d_fwd_bnb_ws).  stat_rows None: rows the launch would write."""
+    d = Y3ConvDesc(dtype_code(x.buf.dtype), k, 1, _lib.Y3_ACT_NONE, 0, _lib.Y3_ALGO_AUTO, x.c, y.c, in_dilation)
+    xt, yt, ut = x.y3(), y.y3(), u.y3()
+    rt = residual.y3() if residual is not None else None
+    n = C.c_int64(0)
+    check(
+        _lib.lib().y3_conv2d_fwd_bnb_ws(C.byref(d), C.byref(xt), filt.data_ptr() if filt is not None else None, bias.data_ptr() if bias is not None else None,
+                                        C.byref(rt) if rt is not None else None, C.byref(yt), C.byref(ut), scale.data_ptr(), shift.data_ptr(), int(act),
+                                        stat_rows.data_ptr() if stat_rows is not None else None, int(capacity_rows), C.byref(n),
+                                        workspace.data_ptr() if workspace is not None else None, workspace.numel() if workspace is not None else 0, stream_ptr()),
+        "y3_conv2d_fwd_bnb_ws",
+    )
+    return int(n.value)
+
+
 def stem_pair(x_nchw: torch.Tensor, filt0: torch.Tensor, bias0: torch.Tensor, act0: bool, filt1: torch.Tensor, bias1: torch.Tensor, act1: bool, y: View, divisor: float = 1.0):
     """Conv(3->32, 3, 1) -> Conv(32->64, 3, 2) straight from the NCHW image into the NHWC view y (layer 0's output stays in LDS)."""
     require_gpu(x_nchw, "stem_pair")
