@@ -271,6 +271,7 @@ def main():
     ap.add_argument("--no-train", action="store_true", help="infer mode: skip the appended train-step leg (BASELINE metric part ii, batch 64, after the timed inference region)")
     ap.add_argument("--train-batch", type=int, default=64)
     ap.add_argument("--train-steps", type=int, default=6)
+    ap.add_argument("--train-timeout", type=float, default=240.0, help="N > 1: seconds the appended train leg may take before the inference line is printed without it")
     args = ap.parse_args()
 
     from yolov3_amd import parallel
@@ -452,17 +453,43 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
-    # BASELINE metric part (ii): the train step, measured in the same run AFTER the timed inference region (N = 1; for N > 1 the
-    # driver's line stays the inference replicas -- `--mode train --gpus N` is the data-parallel run)
-    train = None
-    if world == 1 and not args.no_train:
-        del model
-        torch.cuda.empty_cache()
-        train = run_train(args, rank, world, dev, parallel, yo, args.train_batch, args.train_steps, 2)
-    if rank == 0:
-        out["train"] = train
-        print(json.dumps(out))
+    # BASELINE metric part (ii): the train step, measured in the same run AFTER the timed inference region.  At N > 1 it is the
+    # data-parallel step of BASELINE configs[2] (batch 64 per GPU, RCCL gradient all-reduce overlapped with the backward; `value` = images/s
+    # of the whole job), so the driver's N = 1, 2, 4, 8 runs carry the training scaling curve next to the inference replicas.  The
+    # inference line must survive whatever happens in that leg: an exception is recorded in `train`, and a watchdog prints the line
+    # and ends the process if a collective hangs.
+    import threading
+
+    state = {"printed": False}
+
+    def emit(train):
+        if rank == 0 and not state["printed"]:
+            state["printed"] = True
+            out["train"] = train
+            print(json.dumps(out), flush=True)
+
+    def on_timeout():
+        emit({"error": f"train leg did not finish within {args.train_timeout:.0f} s (world {world})"})
+        os._exit(0)
+
+    train, wd = None, None
+    if not args.no_train:
+        if world > 1:
+            wd = threading.Timer(args.train_timeout, on_timeout)
+            wd.daemon = True
+            wd.start()
+        try:
+            del model
+            torch.cuda.empty_cache()
+            train = run_train(args, rank, world, dev, parallel, yo, args.train_batch, args.train_steps, 2)
+        except Exception as e:  # noqa: BLE001
+            if world == 1:
+                raise
+            train = {"error": f"{type(e).__name__}: {e}"[:400]}
+    emit(train)
     parallel.finalize()
+    if wd is not None:
+        wd.cancel()
 
 
 if __name__ == "__main__":
