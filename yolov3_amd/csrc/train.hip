@@ -405,7 +405,27 @@ struct WgradArgs {
     unsigned x_bytes, du_bytes;
     y3_divisor dv_hw, dv_w;   // Ho*Wo, Wo
     int step_n, step_q, step_r;   // a K-step of the 256-tile kernel (32 pixels) as (images, rows, columns): 32 = (step_n*Ho + step_q)*Wo + step_r
+    int xcd_group;                // wgrad_block: the tiles of a pixel slice back to back on one XCD
 };
+
+// (tile, slice) of a block of the split-K filter-gradient grids (grid = tiles x slices).  The hardware hands consecutive workgroups to
+// consecutive XCDs, so with tile = blockIdx.x the column tiles of ONE pixel slice -- which read the same du rows and overlapping x
+// rows -- land on different XCDs and each L2 fetches the slice again.  xcd_group: workgroups are taken in runs of 8 x tiles; inside a
+// run the 8 XCDs get one slice each and walk its tiles back to back, so a slice's operands are fetched into one L2 once.
+Y3_DEV void wgrad_block(int xcd_group, int& tile, int& slice) {
+    tile = blockIdx.x;
+    slice = blockIdx.y;
+    if (!xcd_group) return;
+    const int tiles = gridDim.x, slices = gridDim.y;
+    const long long L = (long long)blockIdx.y * tiles + blockIdx.x;
+    const long long run = 8ll * tiles;
+    const int g = (int)(L / run), r = (int)(L - (long long)g * run);
+    const int left = slices - g * 8;          // slices of this run (8, fewer in the last one)
+    const int w = left < 8 ? left : 8;
+    slice = g * 8 + r % w;
+    tile = r / w;
+}
+
 
 Y3_DEV unsigned pack_lo(unsigned a, unsigned b) { return (a & 0xffffu) | (b << 16); }
 Y3_DEV unsigned pack_hi(unsigned a, unsigned b) { return (a >> 16) | (b & 0xffff0000u); }
@@ -422,8 +442,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wc = wv >> 1, wn = wv & 1;
-    const int ct = blockIdx.x / p.n_nt, nt = blockIdx.x % p.n_nt;
-    const long long m_begin = (long long)blockIdx.y * p.per_slice;
+    int tile_id, slice_id;
+    wgrad_block(p.xcd_group, tile_id, slice_id);
+    const int ct = tile_id / p.n_nt, nt = tile_id % p.n_nt;
+    const long long m_begin = (long long)slice_id * p.per_slice;
     long long m_end = m_begin + p.per_slice;
     if (m_end > p.M) m_end = p.M;
     if (m_begin >= m_end) return;
@@ -547,7 +569,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs p) {
     }
 
     // D[row = co][col = n] -> partial tile [n][co] (each lane owns 4 consecutive co: one 16-byte store)
-    float* tile = p.part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (128 * 128);
+    float* tile = p.part + ((size_t)slice_id * gridDim.x + tile_id) * (128 * 128);
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int nl = (wn * 2 + b) * 32 + frow;
@@ -609,8 +631,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs p) {
     constexpr int WN = 4 / WC;                 // waves along the columns
     constexpr int BN = 4 / WN;                 // column tiles per wave
     const int wc = wv / WN, wn = wv % WN;
-    const int ct = blockIdx.x / p.n_nt, nt = blockIdx.x % p.n_nt;
-    const long long m_begin = (long long)blockIdx.y * p.per_slice;
+    int tile_id, slice_id;
+    wgrad_block(p.xcd_group, tile_id, slice_id);
+    const int ct = tile_id / p.n_nt, nt = tile_id % p.n_nt;
+    const long long m_begin = (long long)slice_id * p.per_slice;
     long long m_end = m_begin + p.per_slice;
     if (m_end > p.M) m_end = p.M;
     if (m_begin >= m_end) return;
@@ -739,7 +763,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs p) {
 
     // D[row = co][col = n] -> partial tile [n][co] (each lane owns 4 consecutive co: one 16-byte store)
     const int frow = lane & 31, fk = lane >> 5;
-    float* tile = p.part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (128 * 128);
+    float* tile = p.part + ((size_t)slice_id * gridDim.x + tile_id) * (128 * 128);
 #pragma unroll
     for (int b = 0; b < BN; ++b) {
         const int nl = (wn * BN + b) * 32 + frow;
@@ -775,8 +799,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_big_kernel(const WgradArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wc = wv >> 1, wn = wv & 1;      // 4 x 2 waves: 64 filters x 128 columns each
-    const int ct = blockIdx.x / p.n_nt, nt = blockIdx.x % p.n_nt;
-    const long long m_begin = (long long)blockIdx.y * p.per_slice;
+    int tile_id, slice_id;
+    wgrad_block(p.xcd_group, tile_id, slice_id);
+    const int ct = tile_id / p.n_nt, nt = tile_id % p.n_nt;
+    const long long m_begin = (long long)slice_id * p.per_slice;
     long long m_end = m_begin + p.per_slice;
     if (m_end > p.M) m_end = p.M;
     if (m_begin >= m_end) return;
@@ -915,7 +941,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_big_kernel(const WgradArgs p) {
 
     // D[row = co][col = n] -> partial tile [n][co] (each lane owns 4 consecutive co: one 16-byte store)
     const int frow = lane & 31, fk = lane >> 5;
-    float* tile = p.part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (256 * 256);
+    float* tile = p.part + ((size_t)slice_id * gridDim.x + tile_id) * (256 * 256);
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         const int nl = (wn * 4 + b) * 32 + frow;
@@ -1734,6 +1760,12 @@ extern "C" int y3_conv2d_wgrad(const y3_conv_desc* d, const y3_tensor* x, const 
         if (!workspace || workspace_bytes < (((size_t)slices * tiles * sizeof(float)) << (2 * tsh))) Y3_FAIL("y3_conv2d_wgrad: workspace too small");
         a.per_slice = (int)per;
         const dim3 grid((unsigned)tiles, (unsigned)slices);
+        // wgrad_block: a slice's tiles back to back on one XCD.  Measured at batch 64 (profiles/r02_wgrad_xcd.txt): 64 -> 128 layers 0.60 -> 0.48 and
+        // 0.52 -> 0.45 ms, the 256-tile kernel slightly better, but the narrow (<= 64-filter, 3 column tiles) launches of the 320x320 maps lose
+        // 10-15 %, so those keep the dispatch order.  Y3_WGRAD_XCD=0: never; 1: 128-tile kernels only; 2 (default): + the 256-tile kernel; 3: all
+        static const int xcd_mode = [] { const char* e = getenv("Y3_WGRAD_XCD"); return e ? atoi(e) : 2; }();
+        const bool narrow = tsh == 7 && d->cout <= 64;
+        a.xcd_group = (tiles > 1 && slices > 1 && (narrow ? xcd_mode >= 3 : (tsh == 8 ? xcd_mode >= 2 : xcd_mode >= 1))) ? 1 : 0;
         if (tsh == 8) {
             if (d->dtype == Y3_F16) hipLaunchKernelGGL((wgrad_big_kernel<f16_t>), grid, dim3(512), 0, st, a);
             else hipLaunchKernelGGL((wgrad_big_kernel<bf16_t>), grid, dim3(512), 0, st, a);
