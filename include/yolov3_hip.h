@@ -296,6 +296,18 @@ int y3_pack_filter_dgrad(const float* w_oihw, int32_t cout_src, int32_t cin_src,
 /* y3_pack_filter (forward bank) and y3_pack_filter_dgrad (data-gradient bank) of one layer in one launch (f16/bf16). */
 int y3_pack_filter_pair(const float* w_oihw, int32_t cout_src, int32_t cin_src, int32_t ksize, int32_t cout, int32_t cin,
                         int32_t dtype, void* packed_fwd, void* packed_dgrad, void* stream);
+/* y3_pack_filter_pair for MANY layers in one launch (the training step re-packs every layer's banks each step).  `jobs` is a DEVICE
+ * array; job i occupies blocks [first_block, first_block + y3_pack_job_blocks(...)) of a grid of total_blocks 256-thread blocks, the
+ * jobs laid out back to back in array order.  packed_fwd / packed_dgrad may be NULL (that bank is not wanted).  f16 / bf16. */
+typedef struct y3_pack_job {
+    const float* w;          /* OIHW fp32 weights (nn.Conv2d.weight) */
+    void* packed_fwd;        /* y3_packed_filter_elems(cout, cin, ksize) elements, or NULL */
+    void* packed_dgrad;      /* y3_packed_filter_elems(cin, cout, ksize) elements, or NULL */
+    int32_t cout_src, cin_src, ksize, cout, cin;
+    int32_t first_block;
+} y3_pack_job;
+int64_t y3_pack_job_blocks(int32_t ksize, int32_t cout, int32_t cin, int32_t want_fwd, int32_t want_dgrad);
+int y3_pack_filter_jobs(const y3_pack_job* jobs_device, int32_t n_jobs, int64_t total_blocks, int32_t dtype, void* stream);
 /* Data gradient of a 3x3 stride-2 pad-1 conv without multiplying the zero taps of the dilated form: four output-parity
  * classes, each a small stride-1 conv of du (1, 2, 2 and 4 taps) with its own filter bank, written to every second
  * pixel of gx (+= residual when given; residual may alias gx).  f16/bf16 only. */

@@ -2007,3 +2007,38 @@ def test_train_step_bn_backward_in_dgrad_epilogue_matches_separate_reduction(dev
             worst = (c, k)
     print(f"[bnb epilogue {name} {adt}] min gradient cosine fused vs separate {worst[0]:.6f} at {worst[1]}")
     assert worst[0] > (0.999 if adt == torch.float16 else 0.98), worst
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_pack_filter_jobs_matches_per_layer_packing(dev, dtype):
+    """y3_pack_filter_jobs (every layer's forward + data-gradient bank in ONE launch, the training step's packing) against y3_pack_filter_pair /
+    y3_pack_filter layer by layer: bit-identical banks, including channel-padded heads, a forward-only job and a job whose weights moved
+    (the device table is rebuilt from the new pointer)."""
+    _lib, ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    shapes = [(64, 32, 3), (32, 64, 1), (255, 1024, 1), (128, 64, 3), (1024, 512, 3), (21, 256, 1)]
+    ws = [torch.randn(co, ci, k, k, generator=g).to(dev) for co, ci, k in shapes]
+    jobs = ops.PackJobs(dtype, dev)
+    banks = []
+    for i, (w, (co, ci, k)) in enumerate(zip(ws, shapes)):
+        banks.append(jobs.add(w, (co + 7) // 8 * 8, ci, True, i != 3))
+    for b in banks:
+        for t in b:
+            if t is not None:
+                t.fill_(float("nan"))
+    jobs.run()
+    torch.cuda.synchronize()
+    for i, (w, (co, ci, k)) in enumerate(zip(ws, shapes)):
+        cop = (co + 7) // 8 * 8
+        f_ref, d_ref = ops.pack_filter_pair(w, cop, ci, dtype)
+        assert torch.equal(banks[i][0].view(torch.int16), f_ref.view(torch.int16)), f"forward bank {i}"
+        if i != 3:
+            assert torch.equal(banks[i][1].view(torch.int16), d_ref.view(torch.int16)), f"data-gradient bank {i}"
+            assert torch.equal(d_ref.view(torch.int16), ops.pack_filter_dgrad(w, cop, ci, dtype).view(torch.int16))
+        else:
+            assert banks[i][1] is None
+    # a weight tensor that moved: the job table follows
+    jobs.jobs[1] = (ws[1].clone() * 2.0,) + jobs.jobs[1][1:]
+    jobs.run()
+    torch.cuda.synchronize()
+    assert torch.equal(banks[1][0].view(torch.int16), ops.pack_filter(ws[1] * 2.0, 32, 64, dtype).view(torch.int16))

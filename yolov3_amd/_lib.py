@@ -149,6 +149,8 @@ _SIGNATURES = {
     ),
     "y3_pack_filter_dgrad": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "y3_pack_filter_pair": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "y3_pack_job_blocks": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "y3_pack_filter_jobs": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
     "y3_packed_filter_dgrad_s2_elems": (C.c_size_t, [C.c_int32, C.c_int32]),
     "y3_pack_filter_dgrad_s2": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "y3_conv2d_dgrad_s2": (C.c_int, [C.c_int32, _P(Y3Tensor), C.c_void_p, _P(Y3Tensor), _P(Y3Tensor), C.c_void_p]),

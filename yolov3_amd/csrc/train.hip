@@ -1075,6 +1075,44 @@ __global__ void pack_filter_pair_kernel(const float* __restrict__ src, int cout_
     }
 }
 
+// Every layer's banks in ONE launch: the training step re-packs all filters each step (the fp32 master weights moved); 75 pack
+// launches of 4-40 us (0.8 ms per batch-64 step, most of it launch-to-launch latency) become one.  A block finds its job by a binary
+// search over the jobs' first block (wave-uniform scalar loads), then does pack_filter_pair_kernel's work.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_filter_jobs_kernel(const y3_pack_job* __restrict__ jobs, int n_jobs) {
+    int lo = 0, hi = n_jobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const y3_pack_job j = jobs[lo];
+    const float* __restrict__ src = j.w;
+    const int ks = j.ksize, cin = j.cin, cout = j.cout;
+    const int rows_f = (cout + 127) / 128 * 128, kpad_f = (ks * ks * cin + 63) / 64 * 64;
+    const int rows_d = (cin + 127) / 128 * 128, kpad_d = (ks * ks * cout + 63) / 64 * 64;
+    const long long idx = (long long)((int)blockIdx.x - j.first_block) * 256 + threadIdx.x;
+    if (j.packed_fwd && idx < (long long)rows_f * kpad_f) {
+        const int k = (int)(idx % kpad_f), co = (int)(idx / kpad_f);
+        float v = 0.0f;
+        if (co < j.cout_src && k < ks * ks * cin) {
+            const int tap = k / cin, ci = k - tap * cin;
+            const int kh = tap / ks, kw = tap - kh * ks;
+            if (ci < j.cin_src) v = src[(((long long)co * j.cin_src + ci) * ks + kh) * ks + kw];
+        }
+        ((T*)j.packed_fwd)[idx] = from_f32<T>(v);
+    }
+    if (j.packed_dgrad && idx < (long long)rows_d * kpad_d) {
+        const int k = (int)(idx % kpad_d), ci = (int)(idx / kpad_d);
+        float v = 0.0f;
+        if (ci < j.cin_src && k < ks * ks * cout) {
+            const int tap = k / cout, co = k - tap * cout;
+            const int kh = ks - 1 - tap / ks, kw = ks - 1 - tap % ks;
+            if (co < j.cout_src) v = src[(((long long)co * j.cin_src + ci) * ks + kh) * ks + kw];
+        }
+        ((T*)j.packed_dgrad)[idx] = from_f32<T>(v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // backward of nearest x2 upsampling: dx[h,w] (+)= sum of the 2x2 block of dy
 template <typename T>
@@ -1658,6 +1696,24 @@ extern "C" int y3_pack_filter_pair(const float* w, int32_t cout_src, int32_t cin
     hipStream_t st = (hipStream_t)stream;
     if (dtype == Y3_F16) hipLaunchKernelGGL((pack_filter_pair_kernel<f16_t>), dim3(nblk(total)), dim3(256), 0, st, w, cout_src, cin_src, ks, cout, cin, rows_f, kpad_f, rows_d, kpad_d, (f16_t*)packed_fwd, (f16_t*)packed_dgrad);
     else hipLaunchKernelGGL((pack_filter_pair_kernel<bf16_t>), dim3(nblk(total)), dim3(256), 0, st, w, cout_src, cin_src, ks, cout, cin, rows_f, kpad_f, rows_d, kpad_d, (bf16_t*)packed_fwd, (bf16_t*)packed_dgrad);
+    Y3_CHECK_LAUNCH();
+    return 0;
+}
+
+// blocks a job of y3_pack_filter_jobs occupies (the caller lays the jobs out back to back: first_block = running sum)
+extern "C" int64_t y3_pack_job_blocks(int32_t ksize, int32_t cout, int32_t cin, int32_t want_fwd, int32_t want_dgrad) {
+    const long long tf = want_fwd ? (long long)y3_filter_rows(cout) * y3_filter_kpad(cin, ksize) : 0;
+    const long long td = want_dgrad ? (long long)y3_filter_rows(cin) * y3_filter_kpad(cout, ksize) : 0;
+    const long long total = tf > td ? tf : td;
+    return (total + 255) / 256;
+}
+
+extern "C" int y3_pack_filter_jobs(const y3_pack_job* jobs_device, int32_t n_jobs, int64_t total_blocks, int32_t dtype, void* stream) {
+    if (!jobs_device || n_jobs <= 0 || total_blocks <= 0 || total_blocks > 0x7fffffffLL) Y3_FAIL("y3_pack_filter_jobs: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == Y3_F16) hipLaunchKernelGGL((pack_filter_jobs_kernel<f16_t>), dim3((unsigned)total_blocks), dim3(256), 0, st, jobs_device, n_jobs);
+    else if (dtype == Y3_BF16) hipLaunchKernelGGL((pack_filter_jobs_kernel<bf16_t>), dim3((unsigned)total_blocks), dim3(256), 0, st, jobs_device, n_jobs);
+    else Y3_FAIL("y3_pack_filter_jobs: f16/bf16 only");
     Y3_CHECK_LAUNCH();
     return 0;
 }

@@ -390,6 +390,45 @@ def conv2d_bnb(x: View, filt: torch.Tensor, bias: torch.Tensor, y: View, k: int,
     return int(n.value)
 
 
+class PackJobs:
+    """Every layer's filter banks in one launch (y3_pack_filter_jobs): `add` registers a layer and returns its persistent (forward bank,
+    data-gradient bank) tensors, `run` re-packs all of them from the current fp32 weights.  The job table lives on the device and is
+    rebuilt only when a weight tensor moved (data_ptr changed)."""
+
+    def __init__(self, dtype: torch.dtype, device):
+        self.dtype, self.device = dtype, device
+        self.jobs = []          # (weight param, fwd bank | None, dgrad bank | None, cout, cin)
+        self._table, self._ptrs, self._blocks = None, None, 0
+
+    def add(self, w: torch.Tensor, cout: int, cin: int, want_fwd: bool = True, want_dgrad: bool = True):
+        co, ci, k, _ = w.shape
+        fwd = torch.empty(packed_filter_elems(cout, cin, k), dtype=self.dtype, device=self.device) if want_fwd else None
+        dg = torch.empty(packed_filter_elems(cin, cout, k), dtype=self.dtype, device=self.device) if want_dgrad else None
+        self.jobs.append((w, fwd, dg, cout, cin))
+        self._table = None
+        return fwd, dg
+
+    def run(self):
+        if not self.jobs:
+            return
+        ptrs = [w.data_ptr() for w, *_ in self.jobs]
+        if self._table is None or ptrs != self._ptrs:
+            import struct
+
+            L = _lib.lib()
+            rows, first = [], 0
+            for (w, fwd, dg, cout, cin), ptr in zip(self.jobs, ptrs):
+                if w.dtype != torch.float32 or not w.is_contiguous():
+                    raise TypeError("PackJobs expects contiguous fp32 master weights")
+                co, ci, k, _ = w.shape
+                rows.append(struct.pack("<QQQ6i", ptr, fwd.data_ptr() if fwd is not None else 0, dg.data_ptr() if dg is not None else 0, co, ci, k, cout, cin, first))
+                first += int(L.y3_pack_job_blocks(k, cout, cin, int(fwd is not None), int(dg is not None)))
+            host = torch.frombuffer(bytearray(b"".join(rows)), dtype=torch.uint8)
+            self._table = host.to(self.device)
+            self._ptrs, self._blocks = ptrs, first
+        check(_lib.lib().y3_pack_filter_jobs(self._table.data_ptr(), len(self.jobs), self._blocks, dtype_code(self.dtype), stream_ptr()), "y3_pack_filter_jobs")
+
+
 def stem_pair(x_nchw: torch.Tensor, filt0: torch.Tensor, bias0: torch.Tensor, act0: bool, filt1: torch.Tensor, bias1: torch.Tensor, act1: bool, y: View, divisor: float = 1.0):
     """Conv(3->32, 3, 1) -> Conv(32->64, 3, 2) straight from the NCHW image into the NHWC view y (layer 0's output stays in LDS)."""
     require_gpu(x_nchw, "stem_pair")

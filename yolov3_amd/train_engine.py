@@ -104,6 +104,7 @@ class ConvUnit(_Unit):
         # the data gradient of this unit runs through the generic dgrad bank (not the stride-2 parity-class banks, not layer 0)
         self.pair_pack = need_dx and plan.dtype in (torch.float16, torch.bfloat16) and not (self.s == 2 and self.k == 3)
         # BatchNorm-backward reductions taken in the epilogue of the data gradient that completes y's gradient (TrainPlan._plan_bnb):
+        self.bank_fwd = self.bank_dgrad = None   # persistent filter banks filled by the plan's one-launch packing (TrainPlan.pack_jobs)
         self.bnb_target = None   # the ConvUnit whose output gradient THIS unit's data gradient completes (its y is our x)
         self.bnb_totals = None   # our own (sum g, sum g*xhat) totals, filled by whoever completes our y's gradient
         self.bnb_done = False
@@ -155,7 +156,9 @@ class ConvUnit(_Unit):
             else:
                 ops.stem_conv(self.plan.x_nchw, filt, self.zero_bias, self.u, act=False)
         else:
-            if self.pair_pack:   # forward and data-gradient banks in one launch; the weights do not change before the backward
+            if self.plan.banks_fresh and self.bank_fwd is not None:   # packed with every other layer at the top of this forward
+                filt, self.filt_d = self.bank_fwd, self.bank_dgrad
+            elif self.pair_pack:   # forward and data-gradient banks in one launch; the weights do not change before the backward
                 filt, self.filt_d = ops.pack_filter_pair(m.conv.weight, self.cout, self.cin, self.plan.dtype)
             else:
                 filt = ops.pack_filter(m.conv.weight, self.cout, self.cin, self.plan.dtype)
@@ -278,10 +281,15 @@ class HeadUnit(_Unit):
         self.raw = None
         self.bnb_target = None   # see ConvUnit
         self.bnb_rows = None
+        self.bank_fwd = self.bank_dgrad = None
+        self.filt_d = None
 
     def fwd(self):
         w = self.conv.weight
-        filt = ops.pack_filter(w, self.cout, self.x.view.c, self.plan.dtype)
+        if self.plan.banks_fresh and self.bank_fwd is not None:
+            filt, self.filt_d = self.bank_fwd, self.bank_dgrad
+        else:
+            filt, self.filt_d = ops.pack_filter(w, self.cout, self.x.view.c, self.plan.dtype), None
         bias = torch.zeros(self.cout, dtype=torch.float32, device=self.plan.device)
         bias[: self.conv.out_channels] = _f32(self.conv.bias)
         ops.conv2d(self.x.view, filt, bias, self.head, 1, 1, act=False)
@@ -301,7 +309,9 @@ class HeadUnit(_Unit):
         check(L.y3_detect_raw_bwd(graw.data_ptr(), ops.dtype_code(self.plan.dtype), v.n, det.na, v.h, v.w, det.no, C.byref(gt), ops.stream_ptr()), "y3_detect_raw_bwd")
         self.plan.wgrad(grads, self.conv.weight, self.conv.bias, self.x.view, ghead, 1, 1, self.conv.out_channels, self.conv.in_channels)
         gx = self.x.grad()
-        filt_d = ops.pack_filter_dgrad(self.conv.weight, self.cout, self.x.view.c, self.plan.dtype)
+        filt_d, self.filt_d = self.filt_d, None
+        if filt_d is None:
+            filt_d = ops.pack_filter_dgrad(self.conv.weight, self.cout, self.x.view.c, self.plan.dtype)
         res = gx if self.x.is_ready() else None
         if self.bnb_target is not None:
             self.plan.dgrad_bnb(self, self.bnb_target, ghead, filt_d, self.plan.zeros_f32(self.x.view.c), gx, res, 1, 1, None, grads)
@@ -493,6 +503,15 @@ class TrainPlan:
         self._arena, self._arena_off = None, 0
         self._arena_numel = sum((p.numel() + 63) // 64 * 64 for p in self.params)
         self._plan_bnb()
+        # all filter banks of a step in one launch (Y3_PACK_JOBS=0: one launch per layer, as before)
+        self.pack_jobs, self.banks_fresh = None, False
+        if dtype in (torch.float16, torch.bfloat16) and os.environ.get("Y3_PACK_JOBS", "1") != "0":
+            self.pack_jobs = ops.PackJobs(dtype, device)
+            for u in self.units:
+                if isinstance(u, ConvUnit) and not u.use_stem:
+                    u.bank_fwd, u.bank_dgrad = self.pack_jobs.add(u.m.conv.weight, u.cout, u.cin, True, u.pair_pack)
+            for hd in self.heads:
+                hd.bank_fwd, hd.bank_dgrad = self.pack_jobs.add(hd.conv.weight, hd.cout, hd.x.view.c, True, True)
         self.last_forward = 0
         self.generation = 0        # bumped by every forward: the saved activations belong to exactly one forward
         self.outstanding = False   # a grad-enabled forward ran and its backward has not: the saved state must not be overwritten
@@ -665,11 +684,17 @@ class TrainPlan:
         if not (isinstance(u0, ConvUnit) and u0.fused_stem_bwd() and self.epilogue_stats):
             ops.nchw_to_nhwc(x, self.x_in.view, 1.0)   # layer 0 through the generic kernels (or its generic filter gradient) reads the NHWC copy
         with torch.no_grad():
-            for u in self.units:
-                u.fwd()
-            if self._bn_counters:   # nn.BatchNorm2d.num_batches_tracked += 1, one launch for all 72 counters
-                torch._foreach_add_(self._bn_counters, 1)
-            return [hd.fwd() for hd in self.heads]
+            try:
+                if self.pack_jobs is not None:
+                    self.pack_jobs.run()
+                    self.banks_fresh = True
+                for u in self.units:
+                    u.fwd()
+                if self._bn_counters:   # nn.BatchNorm2d.num_batches_tracked += 1, one launch for all 72 counters
+                    torch._foreach_add_(self._bn_counters, 1)
+                return [hd.fwd() for hd in self.heads]
+            finally:
+                self.banks_fresh = False   # a unit driven outside TrainPlan.forward (tools) packs for itself
 
     def backward(self, graws):
         sync = getattr(self.model, "grad_sync", None)  # parallel.GradBuckets: overlapped gradient all-reduce
