@@ -185,6 +185,9 @@ def install() -> None:
         bbox_iou=upstream.bbox_iou,
         box_iou=upstream.box_iou,
         smooth_bce=upstream.smooth_bce,
+        smooth=upstream.smooth,
+        plot_mc_curve=lambda *a, **k: None,
+        plot_pr_curve=lambda *a, **k: None,
     )
     _mod("ultralytics.utils.plotting")
     _mod("ultralytics.data")

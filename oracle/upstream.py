@@ -124,6 +124,15 @@ def smooth_bce(eps=0.1):
 
 
 # --------------------------------------------------------------------------- model helpers
+def smooth(y, f=0.05):
+    """ultralytics.utils.metrics.smooth (box filter of fraction f), used by the reference's ap_per_class (utils/metrics.py:82) to pick
+    the max-F1 operating point.  Restated from the published function: parity unpinned like the rest of this file."""
+    nf = round(len(y) * f * 2) // 2 + 1
+    p = np.ones(nf // 2)
+    yp = np.concatenate((p * y[0], y, p * y[-1]), 0)
+    return np.convolve(yp, np.ones(nf) / nf, mode="valid")
+
+
 def fuse_conv_and_bn(conv, bn):
     """Fold an eval-mode BatchNorm2d into the preceding Conv2d.  Anchor: reference
     models/yolo.py:168 (``m.conv = fuse_conv_and_bn(m.conv, m.bn)``)."""

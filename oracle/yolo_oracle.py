@@ -579,6 +579,20 @@ def synth_val_case(seed, n_lab=12, n_det=60, nc=5, img=(480, 640), dup=0.5):
     return det.contiguous(), labels.contiguous()
 
 
+def synth_ap_stats(seed, n_det=600, n_lab=200, nc=6, n_iou=10, absent=1):
+    """Seeded (tp, conf, pred_cls, target_cls) NumPy statistics as val.py:416 hands them to ap_per_class: tp is monotone over the IoU
+    thresholds (a detection correct at 0.75 is correct at 0.5), the last `absent` classes have labels but no predictions and class 0
+    has predictions only -- the edge cases of the per-class loop (utils/metrics.py:53-58)."""
+    g = torch.Generator().manual_seed(seed)
+    conf = torch.rand(n_det, generator=g)
+    q = torch.rand(n_det, generator=g) * (0.3 + 0.7 * conf)          # better-scored detections hit more often
+    thr = torch.linspace(0.25, 0.9, n_iou)
+    tp = q[:, None] > thr[None, :]
+    pred_cls = torch.randint(0, max(1, nc - absent), (n_det,), generator=g).float()
+    target_cls = torch.randint(1, nc, (n_lab,), generator=g).float()
+    return tp.numpy(), conf.numpy(), pred_cls.numpy(), target_cls.numpy()
+
+
 def synth_scale_case(img1_shape, seed=12, n=400):
     """(n, 6) rows [x1,y1,x2,y2,conf,cls] in letterboxed img1 space (boxes partly outside the image so that the clip
     matters), from synth_predictions: the scale_boxes test input."""

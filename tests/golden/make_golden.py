@@ -248,6 +248,25 @@ def gen_val_edge_goldens(ns):
     torch.save(out, OUT / "val_edge.pt")
 
 
+def gen_metrics_goldens(ns):
+    """utils/metrics.py ap_per_class / compute_ap of the unmodified reference on seeded statistics (oracle.yolo_oracle.synth_ap_stats)."""
+    import importlib
+
+    rm = importlib.import_module("utils.metrics")
+    out = {}
+    for key, kw in [("mixed", dict(seed=3)), ("single_iou", dict(seed=4, n_iou=1)), ("few", dict(seed=5, n_det=7, n_lab=5, nc=3, absent=0)),
+                    ("one_class", dict(seed=6, n_det=120, n_lab=40, nc=2, absent=0)), ("big", dict(seed=7, n_det=20000, n_lab=3000, nc=80, absent=5))]:
+        tp, conf, pc, tc = yo.synth_ap_stats(**kw)
+        res = rm.ap_per_class(tp, conf, pc, tc, plot=False, names={})   # (the reference default names=() has no .items(): val.py always passes a dict)
+        out[key] = {"kw": kw, "in_sum": float(tp.sum() + conf.sum() + pc.sum() + tc.sum()), "out": [torch.as_tensor(r.copy()) for r in res]}
+    r = torch.linspace(0, 0.83, 57).numpy() ** 1.5
+    p = (1.0 - 0.6 * torch.linspace(0, 1, 57).numpy() ** 2) * (1 + 0.05 * torch.sin(torch.arange(57.0)).numpy())
+    ap, mpre, mrec = rm.compute_ap(r, p)
+    out["compute_ap"] = {"ap": float(ap), "mpre": torch.as_tensor(mpre.copy()), "mrec": torch.as_tensor(mrec.copy())}
+    torch.save(out, OUT / "metrics.pt")
+    print("metrics.pt", {k: (float(v["out"][5].mean()) if "out" in v else v["ap"]) for k, v in out.items()})
+
+
 def gen_big_goldens(ns):
     """The benchmarked resolutions (416x416 tiny = BASELINE configs[0], 640x640 yolov3 = configs[1]/[3]): eval output of the
     unmodified reference.  Fixtures stay small: every STEP-th prediction row + whole-tensor statistics (sum |.|, max |.|)."""
@@ -300,7 +319,7 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ns = ref_shim.load()
-    which = set(sys.argv[1:]) or {"model", "decode", "nms", "loss", "val_edge", "big", "ckpt"}  # python make_golden.py [model decode nms loss val_edge big ckpt]
+    which = set(sys.argv[1:]) or {"model", "decode", "nms", "loss", "val_edge", "big", "ckpt", "metrics"}  # python make_golden.py [model decode nms loss val_edge big ckpt metrics]
     if "model" in which:
         gen_model_goldens(ns)
     if "decode" in which:
@@ -311,6 +330,8 @@ if __name__ == "__main__":
         gen_loss_goldens(ns)
     if "val_edge" in which:
         gen_val_edge_goldens(ns)
+    if "metrics" in which:
+        gen_metrics_goldens(ns)
     if "big" in which:
         gen_big_goldens(ns)
     if "ckpt" in which:

@@ -208,3 +208,37 @@ def test_scale_boxes_matches_reference(golden_dir):
         assert checksum(boxes) == rec["in_sum"], name
         got = yo.scale_boxes(rec["img1"], boxes.clone()[:, :4], rec["img0"], rec["ratio_pad"])
         assert torch.equal(got, rec["out"]), name
+
+
+# ------------------------------------------------------------------------------------------------ validation metrics (host, NumPy)
+def test_ap_per_class_matches_reference_golden(golden_dir):
+    """yolov3_amd.metrics.ap_per_class / compute_ap (the host half of val.py:416-421) against the UNMODIFIED reference's utils/metrics.py on
+    seeded statistics: every returned array equal to 1e-12 (same NumPy operations in the same order), incl. classes with labels but no
+    predictions, predictions without labels, a single IoU threshold and 20 000 detections over 80 classes."""
+    import numpy as np
+
+    from yolov3_amd import metrics
+
+    gold = torch.load(golden_dir / "metrics.pt")
+    for key, rec in gold.items():
+        if key == "compute_ap":
+            continue
+        tp, conf, pc, tc = yo.synth_ap_stats(**rec["kw"])
+        assert float(tp.sum() + conf.sum() + pc.sum() + tc.sum()) == rec["in_sum"], "seeded statistics drifted"
+        res = metrics.ap_per_class(tp, conf, pc, tc, names={})
+        assert len(res) == len(rec["out"]) == 7
+        for got, ref in zip(res, rec["out"]):
+            np.testing.assert_allclose(np.asarray(got, dtype=np.float64), ref.double().numpy(), rtol=0, atol=1e-12, err_msg=key)
+    r = torch.linspace(0, 0.83, 57).numpy() ** 1.5
+    p = (1.0 - 0.6 * torch.linspace(0, 1, 57).numpy() ** 2) * (1 + 0.05 * torch.sin(torch.arange(57.0)).numpy())
+    ap, mpre, mrec = metrics.compute_ap(r, p)
+    c = gold["compute_ap"]
+    assert abs(ap - c["ap"]) < 1e-12
+    np.testing.assert_allclose(mpre, c["mpre"].numpy(), atol=1e-12)
+    np.testing.assert_allclose(mrec, c["mrec"].numpy(), atol=1e-12)
+    # val.py:416-421 glue
+    tp, conf, pc, tc = yo.synth_ap_stats(seed=3)
+    mp, mr, m50, m5095 = metrics.mean_results([(tp[:300], conf[:300], pc[:300], tc[:90]), (tp[300:], conf[300:], pc[300:], tc[90:])])
+    ref = gold["mixed"]["out"]
+    assert abs(m50 - float(ref[5][:, 0].mean())) < 1e-12 and abs(m5095 - float(ref[5].mean(1).mean())) < 1e-12
+    assert abs(mp - float(ref[2].mean())) < 1e-12 and abs(mr - float(ref[3].mean())) < 1e-12

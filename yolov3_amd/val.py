@@ -1,7 +1,7 @@
 """Host-side mirror of the metric-matching step of reference val.py: ``process_batch`` (:147-188) with the reference
 signature, and a batched form that consumes the batched NMS output without a per-image Python loop or device->host
 copies.  The matching runs in csrc/val_edge.hip; AP accumulation (``ap_per_class``) stays NumPy in the
-reference and is out of scope."""
+reference: yolov3_amd/metrics.py is its host mirror."""
 from __future__ import annotations
 
 import torch
