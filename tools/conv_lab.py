@@ -77,7 +77,7 @@ def main():
         if ops.conv_variant(xv, yv, k, s, res, workspace_bytes=ws.numel()) == "v7":
             arms += [("v7 s0", ws, {"Y3_V7_SCHED": "0"}), ("v7 s1", ws, {"Y3_V7_SCHED": "1"}), ("v7 streamK", ws, {"Y3_V7_GRID": "-2"})]
         if args.sweep:
-            arms += [(v, None, {"Y3_CONV": v}) for v in ("v3a", "v3b", "v3c", "v5a", "v5b", "v6a", "v6b")]
+            arms += [(v, None, {"Y3_CONV": v}) for v in ("v3a", "v5b", "v6b", "v8")]
         times = {a[0]: [] for a in arms}
         outs = {}
         for rnd in range(args.rounds + 1):

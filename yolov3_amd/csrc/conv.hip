@@ -119,6 +119,7 @@ static int conv_variant() {   // read per call (a getenv + a few strcmp per laun
     if (!strcmp(e, "v5c")) return 13;
     if (!strcmp(e, "v6a")) return 14;
     if (!strcmp(e, "v6b")) return 15;
+    if (!strcmp(e, "v8")) return 16;
     return 3;
 }
 
@@ -696,7 +697,7 @@ __global__ __launch_bounds__(256, (BK == 32 && MC * MP <= 4 ? 4 : 2)) void conv_
 // leading half) in the interval after every wave's counted vmcnt retired its pieces of that tile and passed a barrier:
 // the wait sits at the end of MEM(t-1), the reads in MEM(t).  Waits never drain to 0 in the steady state.
 template <typename T, int BK, int WAVES_C, int WAVES_P, int MC, int MP, int SCHED = 0, bool BNB = false>
-__global__ __launch_bounds__(64 * WAVES_C * WAVES_P, 2) void conv_igemm_v5_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (MC * MP >= 16 ? 1 : 2)) void conv_igemm_v5_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // device-only builtins (LDS address space, buffer->LDS DMA): the host pass only needs the stub
     constexpr int NT = 64 * WAVES_C * WAVES_P;
     constexpr int TC = WAVES_C * MC * 32;
@@ -707,8 +708,8 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, 2) void conv_igemm_v5_kerne
     static_assert((TC * S) % NT == 0 && (TP * S) % NT == 0, "whole chunks only");
     constexpr int W_BYTES = TC * BK * 2;
     constexpr int STAGE_BYTES = (TC + TP) * BK * 2;
-    constexpr int NST = SCHED == 1 ? 4 : 2;
-    static_assert(SCHED == 0 || (NT == 512 && BK == 32 && WJ + XJ == 4), "the staggered schedule is written for 8 waves, BK 32, 4 DMA pieces per wave and tile");
+    constexpr int NST = (SCHED == 1 || SCHED == 2) ? 4 : 2;
+    static_assert(SCHED != 1 || (NT == 512 && BK == 32 && WJ + XJ == 4), "the staggered schedule is written for 8 waves, BK 32, 4 DMA pieces per wave and tile");
     constexpr int LDS_BYTES = NST * STAGE_BYTES > TC * TP * 2 ? NST * STAGE_BYTES : TC * TP * 2;  // K-loop stages, re-used as the epilogue's T-typed output tile
     constexpr int ROWSTEP = NT / S;
     constexpr int KSUB = BK / 16;
@@ -758,18 +759,25 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, 2) void conv_igemm_v5_kerne
 
     int nx_tap = 0, nx_cb = 0, nx_kh, nx_kw;   // (tap, channel block) of the next tile to be requested: K-steps are issued strictly in order
     tap_offsets(p, 0, nx_kh, nx_kw);
-    auto dma = [&](int it, int stage) {
+    auto dma = [&](int it, int stage, bool live = true) {   // live = false: a request past the last K-step (all lanes out of bounds: zeros into a free stage)
         const int cb = nx_cb, kh = nx_kh, kw = nx_kw;
-        if (++nx_cb == p.cin_blocks) { nx_cb = 0; ++nx_tap; tap_offsets(p, nx_tap, nx_kh, nx_kw); }
+        if constexpr (SCHED == 2) {   // branch-free cursor: the loop body of the one-wave-per-SIMD schedule must stay one basic block
+            const int wrap = (nx_cb + 1 == p.cin_blocks) ? 1 : 0;
+            nx_cb = wrap ? 0 : nx_cb + 1;
+            nx_tap += wrap;
+            tap_offsets(p, nx_tap < 15 ? nx_tap : 15, nx_kh, nx_kw);
+        } else {
+            if (++nx_cb == p.cin_blocks) { nx_cb = 0; ++nx_tap; tap_offsets(p, nx_tap, nx_kh, nx_kw); }
+        }
         unsigned char* wl = smem + stage * STAGE_BYTES;
         unsigned char* xl = wl + W_BYTES;
 #pragma unroll
         for (int j = 0; j < WJ; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(wl + (j * NT + wv * 64) * 16), 16, woff[j] + (unsigned)(it * BK * 2), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(wl + (j * NT + wv * 64) * 16), 16, live ? woff[j] + (unsigned)(it * BK * 2) : OOB, 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < XJ; ++j) {
             const int hi = hi0[j] + kh, wi = wi0[j] + kw;
-            const bool ok = (int)mvalid[j] & (int)in_image(hi, wi, p);
+            const bool ok = (int)live & (int)mvalid[j] & (int)in_image(hi, wi, p);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(xl + (j * NT + wv * 64) * 16), 16,
                                                      ok ? (unsigned)(xoff[j] + tap_bytes(hi0[j], wi0[j], kh, kw, cb * BK, p) + xc0[j]) : OOB, 0, 0, 0);
         }
@@ -846,6 +854,63 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, 2) void conv_igemm_v5_kerne
         }
         if (!half) __builtin_amdgcn_s_barrier();  // re-align: every wave has now passed 2 nk + 2 barriers and retired all its fragment reads
         Y3_STAMP(3);
+    } else if constexpr (SCHED == 2) {
+        // "v8": ONE wave per SIMD (4 waves of 128 filters x 128 pixels: 0.5 fragment reads per MFMA instead of the 0.75 of the 8-wave tile,
+        // accumulators in AGPRs).  No second wave hides a wave's memory phase, so (a) tiles are requested THREE K-steps ahead into a 4-stage
+        // ring and retired with counted waits, (b) the fragment reads and DMA requests of a K-step are spread between the MFMAs of the
+        // previous half K-step (sched_group_barrier pipelines), (c) the waits are the builtin (the compiler's scoreboard sees them: an asm
+        // wait left it inserting its own vmcnt waits in front of the address arithmetic of the next requests).
+        constexpr int PIECES = WJ + XJ;
+        static_assert(PIECES == 8 && KSUB == 2, "vmcnt immediates / two half K-steps below");
+        constexpr int VM0 = 0x0F70, VM8 = 0x0F78, VM16 = 0x4F70;   // s_waitcnt vmcnt(n) with expcnt / lgkmcnt left open (gfx9 encoding: vmcnt = [3:0] + [15:14])
+        __builtin_amdgcn_s_waitcnt(VM0);   // whatever the set-up loaded has landed: from here on vmcnt counts DMA pieces only
+        // always three tiles in flight (requests past the last K-step are dead: every lane out of bounds), so the loop body is ONE basic
+        // block -- the scheduler can spread the requests between the MFMAs -- and every wait is vmcnt(16)
+        dma(0, 0);
+        dma(1, 1, p.nk > 1);
+        dma(2, 2, p.nk > 2);
+        Y3_STAMP(1);
+        __builtin_amdgcn_s_waitcnt(VM16);
+        __builtin_amdgcn_s_barrier();   // tile 0 is visible to every wave
+        Y3_STAMP(2);
+        frag a0[MC], b0[MP], a1[MC], b1[MP];
+        load_frags(0, 0, a0, b0);
+        for (int it = 0; it < p.nk; ++it) {
+            const int st = it & 3;
+            // ---- half K-step 0: MFMAs on (a0, b0); in their shadow the fragments of half 1 and the requests of tile it+3 ----
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(st, 1, a1, b1);
+            dma(it + 3, (it + 3) & 3, it + 3 < p.nk);   // the stage of tile it-1: every wave passed the barrier of iteration it-1 after its last read
+            mma(a0, b0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);   // address arithmetic of the requests
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 DMA request
+                __builtin_amdgcn_sched_group_barrier(0x006, 8, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- tile it+1 must be complete (this wave's pieces, then everyone's) before anyone reads it ----
+            __builtin_amdgcn_s_waitcnt(VM16);
+            __builtin_amdgcn_s_barrier();
+            // ---- half K-step 1: MFMAs on (a1, b1); in their shadow the first fragments of tile it+1 (a dead tile after the last K-step) ----
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags((it + 1) & 3, 0, a0, b0);
+            mma(a1, b1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        Y3_STAMP(3);
+        __syncthreads();
     } else {
         dma(0, 0);
         Y3_STAMP(1);
@@ -882,7 +947,7 @@ template <typename T, int BK, int WAVES_C, int WAVES_P, int MC, int MP, int SCHE
     const long long nb = (long long)a.n_ct * a.n_pt;
     if (nb > 0x7fffffffLL) Y3_FAIL("conv grid too large");
     a.stat_wp = WAVES_P;
-    g_last_variant = SCHED == 1 ? "v6" : (BK == 64 ? "v5_bk64" : "v5_bk32");
+    g_last_variant = SCHED == 2 ? "v8" : (SCHED == 1 ? "v6" : (BK == 64 ? "v5_bk64" : "v5_bk32"));
     if (a.dry) return 0;
     hipLaunchKernelGGL((conv_igemm_v5_kernel<T, BK, WAVES_C, WAVES_P, MC, MP, SCHED, BNB>), dim3((unsigned)nb), dim3(64 * WAVES_C * WAVES_P), 0, st, a);
     Y3_CHECK_LAUNCH();
@@ -1023,6 +1088,7 @@ template <typename T, bool BNB = false> int dispatch_igemm(ConvArgs& a, hipStrea
             if (var == 6) return c64 ? launch_v3<T, 64, 2, 2>(a, st) : launch_v3<T, 32, 2, 2>(a, st);
             if (var == 14 && a.Cout >= 256) return launch_v5<T, 32, 2, 4, 4, 2, 1>(a, st);   // staggered halves, wave 128c x 64p
             if (var == 15 && a.Cout >= 256) return launch_v5<T, 32, 4, 2, 2, 4, 1>(a, st);   // staggered halves, wave 64c x 128p
+            if (var == 16 && a.Cout >= 256) return launch_v5<T, 32, 2, 2, 4, 4, 2>(a, st);   // "v8": 4 waves of 128c x 128p, 3-stage ring
             if (var >= 11 && var <= 13 && c64 && a.Cout >= 256) {
                 if (var == 11) return launch_v5<T, 64, 2, 4, 4, 2>(a, st);   // 256c x 256p, wave 128c x 64p, BK 64
                 if (var == 12) return launch_v5<T, 64, 4, 2, 2, 4>(a, st);   // 256c x 256p, wave 64c x 128p, BK 64
