@@ -863,44 +863,56 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (MC * MP >= 16 ? 1 : 2)) vo
         constexpr int PIECES = WJ + XJ;
         static_assert(PIECES == 8 && KSUB == 2, "vmcnt immediates / two half K-steps below");
         constexpr int VM0 = 0x0F70, VM8 = 0x0F78, VM16 = 0x4F70;   // s_waitcnt vmcnt(n) with expcnt / lgkmcnt left open (gfx9 encoding: vmcnt = [3:0] + [15:14])
-        __builtin_amdgcn_s_waitcnt(VM0);   // whatever the set-up loaded has landed: from here on vmcnt counts DMA pieces only
-        // always three tiles in flight (requests past the last K-step are dead: every lane out of bounds), so the loop body is ONE basic
-        // block -- the scheduler can spread the requests between the MFMAs -- and every wait is vmcnt(16)
-        dma(0, 0);
-        dma(1, 1, p.nk > 1);
-        dma(2, 2, p.nk > 2);
-        Y3_STAMP(1);
-        __builtin_amdgcn_s_waitcnt(VM16);
-        __builtin_amdgcn_s_barrier();   // tile 0 is visible to every wave
-        Y3_STAMP(2);
+        // Requests: a piece's byte offset is (per-lane part, constant over the channel blocks of a tap) + (channel block, the same for
+        // every lane), so the per-lane part lives in registers -- xb[j], recomputed once per TAP, the out-of-image / tail lanes parked at
+        // 2^31 (beyond every descriptor, and far enough from 2^32 that adding the scalar part cannot wrap) -- and the channel block rides in
+        // the instruction's scalar offset: a K-step issues 8 requests and a handful of scalar instructions instead of ~130 vector ones.
+        constexpr unsigned PARK = 0x80000000u;
+        unsigned xb[XJ];
+        auto tap_setup = [&](int tap) {
+            int kh, kw;
+            tap_offsets(p, tap, kh, kw);
+#pragma unroll
+            for (int j = 0; j < XJ; ++j) {
+                const int hi = hi0[j] + kh, wi = wi0[j] + kw;
+                const bool ok = (int)mvalid[j] & (int)in_image(hi, wi, p);
+                xb[j] = ok ? (unsigned)(xoff[j] + tap_bytes(hi0[j], wi0[j], kh, kw, 0, p) + xc0[j]) : PARK;
+            }
+        };
+        auto request = [&](int stage, unsigned w_soff, unsigned x_soff, bool live) {
+            unsigned char* wl = smem + stage * STAGE_BYTES;
+            unsigned char* xl = wl + W_BYTES;
+#pragma unroll
+            for (int j = 0; j < WJ; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(wl + (j * NT + wv * 64) * 16), 16, live ? woff[j] : PARK, w_soff, 0, 0);
+#pragma unroll
+            for (int j = 0; j < XJ; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(xl + (j * NT + wv * 64) * 16), 16, live ? xb[j] : PARK, x_soff, 0, 0);
+        };
         frag a0[MC], b0[MP], a1[MC], b1[MP];
-        load_frags(0, 0, a0, b0);
-        for (int it = 0; it < p.nk; ++it) {
-            const int st = it & 3;
-            // ---- half K-step 0: MFMAs on (a0, b0); in their shadow the fragments of half 1 and the requests of tile it+3 ----
+        int c = 0;   // K-step being multiplied; the request cursor runs three K-steps ahead
+        // one K-step of compute + (optionally live) one request; ONE basic block
+        auto kstep = [&](unsigned w_soff, unsigned x_soff, bool live) {
+            const int st = c & 3;
             __builtin_amdgcn_sched_barrier(0);
             load_frags(st, 1, a1, b1);
-            dma(it + 3, (it + 3) & 3, it + 3 < p.nk);   // the stage of tile it-1: every wave passed the barrier of iteration it-1 after its last read
+            request((c + 3) & 3, w_soff, x_soff, live);   // the stage of K-step c-1: every wave passed the barrier of step c-1 after its last read
             mma(a0, b0);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
-                __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);   // address arithmetic of the requests
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 DMA request
-                __builtin_amdgcn_sched_group_barrier(0x006, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // 1 request
             }
             __builtin_amdgcn_sched_barrier(0);
-            // ---- tile it+1 must be complete (this wave's pieces, then everyone's) before anyone reads it ----
-            __builtin_amdgcn_s_waitcnt(VM16);
-            __builtin_amdgcn_s_barrier();
-            // ---- half K-step 1: MFMAs on (a1, b1); in their shadow the first fragments of tile it+1 (a dead tile after the last K-step) ----
+            __builtin_amdgcn_s_waitcnt(VM16);   // this wave's pieces of K-step c+1 have landed (c+2, c+3 stay in flight) ...
+            __builtin_amdgcn_s_barrier();       // ... and everyone's
             __builtin_amdgcn_sched_barrier(0);
-            load_frags((it + 1) & 3, 0, a0, b0);
+            load_frags((c + 1) & 3, 0, a0, b0);
             mma(a1, b1);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -908,7 +920,29 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (MC * MP >= 16 ? 1 : 2)) vo
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
+            ++c;
+        };
+        __builtin_amdgcn_s_waitcnt(VM0);   // whatever the set-up loaded has landed: from here on vmcnt counts DMA pieces only
+        // always three K-steps in flight (requests past the last one are dead: every lane parked), so every wait is vmcnt(16)
+        const int cbs = p.cin_blocks;      // >= 3: v8 serves Cin >= 96
+        tap_setup(0);
+        request(0, 0u, 0u, true);
+        request(1, (unsigned)(BK * 2), (unsigned)(BK * 2), p.nk > 1);
+        request(2, (unsigned)(2 * BK * 2), (unsigned)(2 * BK * 2), p.nk > 2);
+        Y3_STAMP(1);
+        __builtin_amdgcn_s_waitcnt(VM16);
+        __builtin_amdgcn_s_barrier();   // K-step 0 is visible to every wave
+        Y3_STAMP(2);
+        load_frags(0, 0, a0, b0);
+        unsigned w_soff = (unsigned)(3 * BK * 2);
+        for (int rt = 0; rt < p.ntaps; ++rt) {
+            if (rt) tap_setup(rt);   // the per-lane offsets of this tap (once per cin_blocks K-steps)
+            for (int rcb = rt ? 0 : 3; rcb < cbs; ++rcb) {
+                kstep(w_soff, (unsigned)(rcb * BK * 2), true);
+                w_soff += (unsigned)(BK * 2);
+            }
         }
+        for (int k = 0; k < 3; ++k) kstep(0u, 0u, false);   // drain: the last three K-steps, dead requests
         Y3_STAMP(3);
         __syncthreads();
     } else {
