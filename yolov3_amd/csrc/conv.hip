@@ -966,7 +966,21 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (MC * MP >= 16 ? 1 : 2)) vo
         Y3_STAMP(3);
         __syncthreads();  // every wave is done with the stage buffers: they become the per-wave transpose slices
     }
-    epilogue_wave<T, MC, MP, BNB>(p, acc, smem + wv * (MP * 32 * MC * 64), ct * TC + wc * MC * 32, pt * TP + wp * MP * 32, lane, pt * WAVES_P + wp);
+    if constexpr (SCHED == 2 && MP == 4) {
+        // two passes of 64 pixels per wave (v7's form): half the residual / offset registers of one 128-pixel pass -- with one wave per SIMD
+        // nothing hides a spill's round trip
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            f32x16 part[MC][2];
+#pragma unroll
+            for (int a = 0; a < MC; ++a) { part[a][0] = acc[a][2 * hb]; part[a][1] = acc[a][2 * hb + 1]; }
+            epilogue_wave<T, MC, 2, BNB>(p, part, smem + wv * (2 * 32 * MC * 64), ct * TC + wc * MC * 32, pt * TP + wp * MP * 32 + hb * 64, lane, (pt * WAVES_P + wp) * 2 + hb);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();   // the slice is private to the wave: its reads of pass 0 precede the writes of pass 1
+        }
+    } else {
+        epilogue_wave<T, MC, MP, BNB>(p, acc, smem + wv * (MP * 32 * MC * 64), ct * TC + wc * MC * 32, pt * TP + wp * MP * 32, lane, pt * WAVES_P + wp);
+    }
     Y3_STAMP(4);
 #endif
 }
@@ -980,7 +994,7 @@ template <typename T, int BK, int WAVES_C, int WAVES_P, int MC, int MP, int SCHE
     a.nk = a.ntaps * a.cin_blocks;
     const long long nb = (long long)a.n_ct * a.n_pt;
     if (nb > 0x7fffffffLL) Y3_FAIL("conv grid too large");
-    a.stat_wp = WAVES_P;
+    a.stat_wp = (SCHED == 2 && MP == 4) ? WAVES_P * 2 : WAVES_P;   // the one-wave-per-SIMD schedule writes its statistics rows in two 64-pixel passes
     g_last_variant = SCHED == 2 ? "v8" : (SCHED == 1 ? "v6" : (BK == 64 ? "v5_bk64" : "v5_bk32"));
     if (a.dry) return 0;
     hipLaunchKernelGGL((conv_igemm_v5_kernel<T, BK, WAVES_C, WAVES_P, MC, MP, SCHED, BNB>), dim3((unsigned)nb), dim3(64 * WAVES_C * WAVES_P), 0, st, a);
