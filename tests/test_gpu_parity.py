@@ -2057,3 +2057,53 @@ def test_map_parity_on_synthetic_scenes(dev):
     assert res["reference_cpu_fp32"]["mAP50"] > 0.25, res
     assert res["abs_diff_fp32"]["mAP50"] <= 1e-3 and res["abs_diff_fp32"]["mAP50-95"] <= 1e-3, res
     assert res["abs_diff_fp16"]["mAP50"] <= 1e-2 and res["abs_diff_fp16"]["mAP50-95"] <= 1e-2, res
+
+
+V8_CASES = [
+    ("3x3_res_20x20", (8, 20, 20, 512, 1024, 3, 1), dict(residual=True)),
+    ("3x3_ragged_pixels_sliced", (3, 21, 19, 256, 512, 3, 1), dict(sliced=True)),
+    ("3x3_s2", (4, 40, 40, 256, 512, 3, 2), {}),
+    ("1x1_noact", (4, 40, 40, 512, 256, 1, 1), dict(act=False)),
+    ("3x3_cin96_min_blocks", (2, 24, 24, 96, 256, 3, 1), {}),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name,shape,kw", V8_CASES, ids=[c[0] for c in V8_CASES])
+def test_conv_v8_experimental_variant(dev, monkeypatch, dtype, name, shape, kw):
+    """Y3_CONV=v8 (one wave per SIMD, 128 x 128 wave tiles, 4-stage request ring, tap-major loop nest, dead requests past the last
+    K-step, two-pass epilogue; not dispatched by default): inside the conv tolerance against fp32 conv2d on the same rounded operands,
+    BIT-IDENTICAL to the v6 kernel it shares its tile and K order with, repeated launches identical, and the BatchNorm statistics rows
+    of its two-pass epilogue sum to the statistics of the stored tensor."""
+    _lib, ops = _ops()
+    n, h, w, cin, cout, k, s = shape
+    tol_r, tol_a = (2.0 ** -10, 2e-3) if dtype == torch.float16 else (2.0 ** -7, 1.5e-2)
+    monkeypatch.setenv("Y3_CONV", "v8")
+    out8, ref = run_conv(dev, dtype, n, h, w, cin, cout, k, s, seed=7, expect="v8", repeat=2, **kw)
+    monkeypatch.setenv("Y3_CONV", "v6b")
+    out6, _ = run_conv(dev, dtype, n, h, w, cin, cout, k, s, seed=7, expect="v6", **kw)
+    assert torch.equal(out8, out6), f"v8 differs from v6: {(out8 - out6).abs().max().item():.3e}"
+    bad = ((out8 - ref).abs() > tol_r * ref.abs() + tol_a).sum().item()
+    assert bad == 0, f"{bad} elements outside the conv tolerance"
+    if k == 3 and s == 1 and not kw:
+        return
+    # statistics rows through the two-pass epilogue
+    monkeypatch.setenv("Y3_CONV", "v8")
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(n, cin, h, w, generator=g).to(dtype)
+    wt = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    xv = ops.View.alloc(n, h, w, cin, dtype, dev)
+    ops.nchw_to_nhwc(x.to(dev), xv)
+    ho, wo = (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
+    filt = ops.pack_filter(wt.to(dev), cout, cin, dtype)
+    zb = torch.zeros(cout, device=dev)
+    y1 = ops.View.alloc(n, ho, wo, cout, dtype, dev)
+    rows = ops.conv2d_stats_rows(xv, y1, k, s)
+    buf = torch.full((rows * 2 * cout,), float("nan"), device=dev)
+    assert ops.conv2d_stats(xv, filt, zb, y1, k, s, buf, rows) == rows and ops.last_conv_variant() == "v8"
+    torch.cuda.synchronize()
+    u = y1.as_nhwc().double().cpu().reshape(-1, cout)
+    tot = buf.view(rows, cout, 2).double().sum(0).cpu()
+    assert torch.isfinite(tot).all(), "a statistics row was not written"
+    assert (tot[:, 0] - u.sum(0)).abs().max().item() <= 1e-5 * u.abs().sum(0).max().item()
+    assert (tot[:, 1] - (u * u).sum(0)).abs().max().item() <= 1e-5 * (u * u).sum(0).max().item()

@@ -1136,7 +1136,7 @@ template <typename T, bool BNB = false> int dispatch_igemm(ConvArgs& a, hipStrea
             if (var == 6) return c64 ? launch_v3<T, 64, 2, 2>(a, st) : launch_v3<T, 32, 2, 2>(a, st);
             if (var == 14 && a.Cout >= 256) return launch_v5<T, 32, 2, 4, 4, 2, 1>(a, st);   // staggered halves, wave 128c x 64p
             if (var == 15 && a.Cout >= 256) return launch_v5<T, 32, 4, 2, 2, 4, 1>(a, st);   // staggered halves, wave 64c x 128p
-            if (var == 16 && a.Cout >= 256) return launch_v5<T, 32, 2, 2, 4, 4, 2>(a, st);   // "v8": 4 waves of 128c x 128p, 3-stage ring
+            if (var == 16 && a.Cout >= 256 && a.Cin >= 96) return launch_v5<T, 32, 2, 2, 4, 4, 2>(a, st);   // "v8": 4 waves of 128c x 128p, 4-stage ring (>= 3 channel blocks per tap: its first three requests share tap 0)
             if (var >= 11 && var <= 13 && c64 && a.Cout >= 256) {
                 if (var == 11) return launch_v5<T, 64, 2, 4, 4, 2>(a, st);   // 256c x 256p, wave 128c x 64p, BK 64
                 if (var == 12) return launch_v5<T, 64, 4, 2, 2, 4>(a, st);   // 256c x 256p, wave 64c x 128p, BK 64
