@@ -789,6 +789,7 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (MC * MP >= 16 ? 1 : 2)) vo
     // the accumulators start at the bias of their filter (lane holds filters 8g + 4fk + q of each 32-filter tile): the
     // loads overlap the first tile's flight and the epilogue has no bias pass
     f32x16 acc[MC][MP];
+    f32x4 bzs[SCHED == 2 ? MC : 1][4];   // SCHED 2 requests its first tiles BEFORE the accumulators are initialised (the bias loads fly with them)
 #pragma unroll
     for (int a = 0; a < MC; ++a)
 #pragma unroll
@@ -796,11 +797,25 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (MC * MP >= 16 ? 1 : 2)) vo
             const int cb = ct * TC + (wc * MC + a) * 32 + 8 * g + 4 * fk;
             f32x4 bz = {0.f, 0.f, 0.f, 0.f};
             if (p.bias && cb + 4 <= p.Cout) bz = *(const f32x4*)(p.bias + cb);
+            if constexpr (SCHED == 2) {
+                bzs[a][g] = bz;
+            } else {
 #pragma unroll
-            for (int b = 0; b < MP; ++b)
+                for (int b = 0; b < MP; ++b)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[a][b][4 * g + q] = bz[q];
+                    for (int q = 0; q < 4; ++q) acc[a][b][4 * g + q] = bz[q];
+            }
         }
+    auto init_acc = [&]() {   // SCHED 2 only
+#pragma unroll
+        for (int a = 0; a < (SCHED == 2 ? MC : 0); ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int b = 0; b < MP; ++b)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[a][b][4 * g + q] = bzs[a][g][q];
+    };
 
     auto load_frags = [&](int stage, int kk, frag (&af)[MC], frag (&bf)[MP]) {
         const unsigned char* wl = smem + stage * STAGE_BYTES;
@@ -922,21 +937,26 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (MC * MP >= 16 ? 1 : 2)) vo
             __builtin_amdgcn_sched_barrier(0);
             ++c;
         };
-        __builtin_amdgcn_s_waitcnt(VM0);   // whatever the set-up loaded has landed: from here on vmcnt counts DMA pieces only
-        // always three K-steps in flight (requests past the last one are dead: every lane parked), so every wait is vmcnt(16)
+        // always three K-steps in flight (requests past the last one are dead: every lane parked), so every wait is vmcnt(16).
+        // The bias loads were issued above and are OLDER than every request: the counted wait for K-step 0 covers them, and the
+        // accumulators are initialised while the first tiles fly.
         const int cbs = p.cin_blocks;      // >= 3: v8 serves Cin >= 96
         tap_setup(0);
         request(0, 0u, 0u, true);
         request(1, (unsigned)(BK * 2), (unsigned)(BK * 2), p.nk > 1);
         request(2, (unsigned)(2 * BK * 2), (unsigned)(2 * BK * 2), p.nk > 2);
         Y3_STAMP(1);
+        __builtin_amdgcn_sched_barrier(0);
+        init_acc();
         __builtin_amdgcn_s_waitcnt(VM16);
         __builtin_amdgcn_s_barrier();   // K-step 0 is visible to every wave
         Y3_STAMP(2);
         load_frags(0, 0, a0, b0);
         unsigned w_soff = (unsigned)(3 * BK * 2);
         for (int rt = 0; rt < p.ntaps; ++rt) {
-            if (rt) tap_setup(rt);   // the per-lane offsets of this tap (once per cin_blocks K-steps)
+            // the per-lane offsets of this tap, once per cin_blocks K-steps (tried in the shadow of the previous tap's last MFMAs: its
+            // exec-masked 64-bit multiplies split the scheduling region and the pipeline directives did not take)
+            if (rt) tap_setup(rt);
             for (int rcb = rt ? 0 : 3; rcb < cbs; ++rcb) {
                 kstep(w_soff, (unsigned)(rcb * BK * 2), true);
                 w_soff += (unsigned)(BK * 2);
