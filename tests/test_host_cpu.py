@@ -368,3 +368,38 @@ def test_wgrad_geometry_fills_whole_rounds():
         nbytes = L.y3_conv2d_wgrad_workspace_bytes(C.byref(_desc(_lib.Y3_F16, k, 1, cin, cout)), C.byref(x))
         tiles = -(-cout // 128) * -(-(k * k * cin) // 128)
         assert nbytes % (128 * 128 * 4 * tiles) == 0, (cin, cout, k, hw)
+
+
+def test_map_parity_helpers_on_cpu():
+    """tests/map_parity.py (the mAP-parity experiment of the GPU suite): the scene generator is seeded and emits the reference's label
+    format with boxes that match the painted rectangles; the oracle evaluation runs end to end (random weights: no assertion on the value)
+    and the metrics glue returns the four numbers."""
+    import sys
+
+    sys.path.insert(0, str(ROOT / "tests"))
+    import map_parity as mp
+
+    x1, l1 = mp.make_scenes(6, 96, 3, seed=9)
+    x2, l2 = mp.make_scenes(6, 96, 3, seed=9)
+    assert torch.equal(x1, x2) and torch.equal(l1, l2)
+    assert x1.shape == (6, 3, 96, 96) and float(x1.min()) >= 0.0 and float(x1.max()) <= 1.0
+    assert l1.shape[1] == 6 and set(l1[:, 0].long().tolist()) == set(range(6)) and int(l1[:, 1].max()) < 3
+    assert float(l1[:, 2:].min()) > 0.0 and float((l1[:, 2] + l1[:, 4] / 2).max()) <= 1.0 + 1e-6 and float((l1[:, 3] + l1[:, 5] / 2).max()) <= 1.0 + 1e-6
+    # the LAST rectangle painted into an image is fully visible: its interior carries its class colour
+    i, c, xc, yc, w, h = l1[l1[:, 0] == 0][-1].tolist()
+    px = x1[0, :, int(yc * 96), int(xc * 96)]
+    base = torch.tensor(mp.COLOURS[int(c)])
+    assert int(px.argmax()) == int(base.argmax()) or float((px / px.max() - base / base.max()).abs().max()) < 0.35
+    tg = mp.batch_targets(l1, torch.tensor([4, 1]))
+    assert set(tg[:, 0].long().tolist()) == {0, 1} and tg.shape[0] == int((l1[:, 0] == 4).sum() + (l1[:, 0] == 1).sum())
+    lab = mp.labels_native(l1, 2, 96)
+    assert lab.shape[1] == 5 and bool((lab[:, 3] > lab[:, 1]).all()) and bool((lab[:, 4] > lab[:, 2]).all())
+    import yaml
+
+    from oracle import yolo_oracle as yo
+
+    d = yaml.safe_load(open(ROOT / "yolov3_amd" / "cfg" / "yolov3-tiny.yaml"))
+    layers, _, anchors, nc = yo.parse_cfg(d, 3, 3)
+    sd = yo.seeded_state_dict(layers, nc, anchors, yo.model_strides(layers), seed=1)
+    (p, r, m50, m), n_det = mp.evaluate_oracle("yolov3-tiny", 3, sd, x1[:4], l1, 96, bs=4)
+    assert all(0.0 <= v <= 1.0 for v in (p, r, m50, m)) and n_det >= 0
