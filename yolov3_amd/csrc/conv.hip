@@ -1148,6 +1148,13 @@ template <typename T, bool BNB = false> int dispatch_igemm(ConvArgs& a, hipStrea
     if (!(a.x_bytes && a.w_bytes && a.y_bytes && (!a.res || a.r_bytes)))
         Y3_FAIL("conv: a tensor exceeds the 2 GiB reach of a buffer descriptor (split the batch)");
     const bool dma_ok = true;
+    if constexpr (!BNB) {
+        // Y3_CONV_V8=1: the one-wave-per-SIMD tile (v8) where it measured ahead of v6 / v7 -- 3x3, K >= 4608, >= 1024 filters (the 20x20
+        // layers: 117 vs 120-121 us, profiles/r02_v8_fifth_try.txt).  Off by default: measured after the round's last full-suite run.
+        static const bool v8_auto = [] { const char* e = getenv("Y3_CONV_V8"); return e && atoi(e) == 1; }();
+        if (v8_auto && var == 3 && c32 && a.ntaps == 9 && a.ntaps * a.Cin >= 4608 && a.Cout >= 1024 && a.Cin >= 96 && !a.ups)
+            return launch_v5<T, 32, 2, 2, 4, 4, 2>(a, st);
+    }
     if (var == 3 && v7_eligible(a)) return launch_v7<T, BNB>(a, st);
     if (var >= 3 && a.Cout > 64 && c32 && dma_ok) {
         if constexpr (!BNB) {   // forced variants (A/B runs)
