@@ -59,6 +59,17 @@ typedef struct {
 int y3_abi_version(void);
 const char* y3_last_error(void);
 
+/* Run-time tuning knobs: every A/B hook of the library in one table (no counterpart in the reference; ATen's equivalents are
+ * torch.backends.cudnn.benchmark and friends).  Defaults are the measured-best settings.  Keys: "conv" (0 per-shape dispatch, 2 / 4 / 5 /
+ * 6 / 15 force a tile variant), "conv_v7" (1 auto, 0 off, 2 every eligible shape), "v7_grid" (0 auto, N > 0 grid cap, -1 whole tiles,
+ * -2 stream-K), "v7_gc" (0 auto, 1 / 2 / 4 / 8), "conv_ahead" (3 / 2: K-steps the LDS-DMA requests run ahead), "bn_nt_bytes" (threshold of
+ * the non-temporal BatchNorm passes), "wgrad" (0 per-shape, 2 128-tile, 3 256-tile, 4 direct fp32), "wgrad_xcd" (0..3), "dgrad_quad"
+ * (1 / 0), "spp_direct" (0 / 1).  The environment variable Y3_TUNE="key=value,key=value" is read once when the library is first used.
+ * Process-wide, not stream-ordered: set a knob before enqueueing the launches it should affect. */
+int y3_tune_set(const char* key, int64_t value); /* 0, or -1 for an unknown key */
+int64_t y3_tune_get(const char* key);            /* INT64_MIN for an unknown key */
+void y3_tune_reset(void);                        /* defaults + Y3_TUNE again */
+
 /* number of elements (of `dtype`) of a packed filter bank for (cout, cin, ksize) */
 size_t y3_packed_filter_elems(int32_t cout, int32_t cin, int32_t ksize);
 /* OIHW fp32 (cout_src x cin_src x k x k) -> packed [cout_pad][k*k*cin_pad (+K pad)] in `dtype`;
@@ -261,24 +272,6 @@ int y3_bn_act_bwd(const y3_tensor* u, const y3_tensor* dy, const float* scale, c
 int y3_bn_act_bwd_res(const y3_tensor* u, const y3_tensor* dy, const float* scale, const float* shift, const float* mean,
                       const float* invstd, int32_t dtype, int32_t act, double* sums, const y3_tensor* du, float* dgamma,
                       float* dbeta, const y3_tensor* gres, int32_t gres_accumulate, void* stream);
-/* BatchNorm-backward reductions in the epilogue of the data gradient that COMPLETES dy (autograd of models/common.py:75; the producer
- * of dy is the data gradient of the consumer layer, reference models/yolo.py:135-147 graph order).  y3_conv2d_fwd_bnb_ws = y3_conv2d_fwd_ws
- * on a y3_pack_filter_dgrad bank (residual = the gradient accumulated so far, may be NULL) whose output is the gradient of a tensor
- * y = act(bn(u)): per (pixel tile, pixel wave) of the dispatched tile it also writes one row [cout][2] fp32 of (sum g, sum g*u),
- * g = dy * act'(scale*u + shift) of the value as stored.  stat_rows == NULL: geometry query, only *n_rows is written.  f16 / bf16,
- * cin % 32 == 0.  y3_bn_bwd_finalize_rows: fixed-order fp64 sum of those rows -> totals[C][2] = (sum g, sum g*xhat), dbeta, dgamma
- * (`sums`: Y3_BN_SCRATCH_DOUBLES(C) scratch).  y3_bn_act_bwd_apply: the apply pass of y3_bn_act_bwd(_res) from such totals --
- * together they are y3_bn_act_bwd without its pass over (dy, u). */
-int y3_conv2d_fwd_bnb_ws(const y3_conv_desc* desc, const y3_tensor* x, const void* packed_filter, const float* bias,
-                         const y3_tensor* residual /* may be NULL */, const y3_tensor* y, const y3_tensor* u, const float* scale,
-                         const float* shift, int32_t act, float* stat_rows, int64_t capacity_rows, int64_t* n_rows,
-                         void* workspace /* may be NULL */, size_t workspace_bytes, void* stream);
-int y3_bn_bwd_finalize_rows(const float* stat_rows, int64_t n_rows, int64_t count /* n*h*w of u */, int32_t channels, double* sums,
-                            const float* mean, const float* invstd, double* totals /* 4 * channels doubles: sums, then means */,
-                            float* dgamma /* may be NULL */, float* dbeta /* may be NULL */, void* stream);
-int y3_bn_act_bwd_apply(const y3_tensor* u, const y3_tensor* dy, const float* scale, const float* shift, const float* mean,
-                        const float* invstd, int32_t dtype, int32_t act, const double* totals, const y3_tensor* du,
-                        const y3_tensor* gres /* may be NULL */, int32_t gres_accumulate, void* stream);
 /* Backward of the first layer (Conv(3, 32, 3, 1) + BatchNorm + act; no data gradient) in two passes over (u, dy) instead of three
  * plus a write: the reduction of y3_bn_act_bwd (totals into `sums`, dgamma, dbeta), then ONE kernel that applies the BatchNorm /
  * activation backward, rounds du to the storage dtype as y3_bn_act_bwd would have stored it, and accumulates

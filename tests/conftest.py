@@ -15,3 +15,12 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return ROOT / "tests" / "golden"
+
+
+@pytest.fixture
+def tune():
+    """set run-time knobs of libyolov3_hip.so (y3_tune_set, include/yolov3_hip.h) for one test; defaults are restored afterwards"""
+    from yolov3_amd import ops
+
+    yield ops.tune_set
+    ops.tune_reset()

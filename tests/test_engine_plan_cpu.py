@@ -148,39 +148,20 @@ def test_bneck_pair_eligibility(monkeypatch):
     assert not e._bneck_pair_eligible(b2, v64, torch.float16)
 
 
-def test_train_plan_static_analysis_on_cpu(monkeypatch):
-    """TrainPlan's build-time analysis needs no GPU: (1) the one-launch filter packing registers every non-stem conv unit and the three
-    Detect heads, with a data-gradient bank for every unit whose data gradient runs through the forward kernels; (2) with
-    Y3_BNB_EPILOGUE=1 the launch that completes a unit's output gradient is found for 65 of yolov3's 72 conv units -- the exceptions are
-    layer 0 (fused stem backward), the four units whose gradient is completed by a stride-2 parity-class launch and the two convs in
-    front of an Upsample -- and every producer / target pair is consistent (the producer's data gradient writes exactly the target's
-    output channels)."""
+def test_train_plan_static_analysis_on_cpu():
+    """TrainPlan's build-time analysis needs no GPU: the one-launch filter packing registers every non-stem conv unit and the three
+    Detect heads, with a data-gradient bank for every unit whose data gradient runs through the forward kernels; fp32 plans pack per layer."""
     import torch
 
     from yolov3_amd import DetectionModel
     from yolov3_amd.train_engine import ConvUnit, TrainPlan
 
     m = DetectionModel("yolov3.yaml", nc=80).train()
-    monkeypatch.delenv("Y3_BNB_EPILOGUE", raising=False)
     p = TrainPlan(m, 1, 64, 64, torch.float16, torch.device("cpu"))
     convs = [u for u in p.units if isinstance(u, ConvUnit)]
-    assert len(convs) == 72 and p.bnb_units == 0 and all(u.bnb_target is None for u in convs)   # off by default
+    assert len(convs) == 72
     jobs = p.pack_jobs.jobs
     assert len(jobs) == 71 + 3 and sum(1 for j in jobs if j[2] is not None) == 66 + 3   # 5 stride-2 3x3 units keep their parity-class banks
     assert all(u.bank_fwd is not None for u in convs if not u.use_stem) and convs[0].use_stem and convs[0].bank_fwd is None
-
-    monkeypatch.setenv("Y3_BNB_EPILOGUE", "1")
-    q = TrainPlan(m, 1, 64, 64, torch.float16, torch.device("cpu"))
-    qconvs = [u for u in q.units if isinstance(u, ConvUnit)]
-    fused = [u for u in qconvs if u.bnb_totals is not None]
-    assert q.bnb_units == len(fused) == 65
-    assert sorted(u.label for u in qconvs if u.bnb_totals is None) == sorted(["L0", "L2.0.cv2", "L4.1.cv2", "L6.7.cv2", "L8.7.cv2", "L16", "L23"])
-    prods = [u for u in list(q.units) + q.heads if getattr(u, "bnb_target", None) is not None]
-    assert len(prods) == 65 and len({id(u.bnb_target) for u in prods}) == 65
-    for u in prods:
-        t = u.bnb_target
-        assert u.x.view.c == t.y.view.c == t.cout and (u.x.view.n, u.x.view.h, u.x.view.w) == (t.y.view.n, t.y.view.h, t.y.view.w)
-        assert t.bnb_totals.numel() == 4 * t.cout and t.bnb_totals.dtype == torch.float64
-    # fp32 plans take neither path
     r = TrainPlan(m, 1, 64, 64, torch.float32, torch.device("cpu"))
-    assert r.bnb_units == 0 and r.pack_jobs is None
+    assert r.pack_jobs is None

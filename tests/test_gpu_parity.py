@@ -176,37 +176,37 @@ V7_CASES = [   # every case has >= 32 (tile, channel block) units, the dispatche
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("name,shape,kw", V7_CASES, ids=[c[0] for c in V7_CASES])
-def test_conv_v7_streamk_vs_fp32_reference(dev, dtype, name, shape, kw, monkeypatch):
-    monkeypatch.setenv("Y3_CONV_V7", "all")    # also the Cin < 256 shapes the dispatcher leaves to the 128x128 kernels
-    monkeypatch.setenv("Y3_V7_GRID", "-2")     # even K split whatever the tile count: every case crosses tile boundaries inside blocks
+def test_conv_v7_streamk_vs_fp32_reference(dev, dtype, name, shape, kw, tune):
+    tune("conv_v7", 2)     # also the Cin < 256 shapes the dispatcher leaves to the 128x128 kernels
+    tune("v7_grid", -2)    # even K split whatever the tile count: every case crosses tile boundaries inside blocks
     out, ref = run_conv(dev, dtype, *shape, algo=1, ws=True, expect="v7", repeat=3, **kw)
     _conv_tol_check(name, dtype, out, ref)
 
 
-@pytest.mark.parametrize("sched", ["0", "1"])
-def test_conv_v7_schedules(dev, monkeypatch, sched):
-    """the two K-loop schedules of the persistent kernel (DMA requests in the MEM phase / between the MFMAs) compute the same sums in
-    the same order: bit-identical outputs, whole tiles and K split, launch after launch.  (A third schedule that read the next step's
-    filter fragments during the MMA phase was 1.5 % slower AND failed this test: the leading wave half read a tile whose pieces the
-    trailing half had not retired yet -- removed.)"""
+@pytest.mark.parametrize("variant,shape", [("v7", (3, 40, 40, 256, 512, 3, 1)), ("v6", (3, 40, 40, 256, 512, 3, 2)), ("v6", (4, 40, 40, 512, 256, 1, 1))],
+                         ids=["v7_3x3", "v6_3x3_s2", "v6_1x1"])
+def test_conv_request_depth_bit_identical(dev, tune, variant, shape):
+    """knob "conv_ahead": the LDS-DMA requests of the 256x256 kernels run 3 K-steps ahead of the MFMAs (default, round 3) or 2 (the
+    round-2 schedule).  Both schedules add the same products in the same order: bit-identical outputs -- for v7 with whole tiles and with
+    the K split, launch after launch (a stage overwritten while a wave still reads it would show up here as a flip)."""
     outs = []
-    for grid in ("-1", "-2"):
-        monkeypatch.setenv("Y3_V7_GRID", grid)
-        monkeypatch.setenv("Y3_V7_SCHED", sched)
-        out, ref = run_conv(dev, torch.float16, 3, 40, 40, 256, 512, 3, 1, algo=1, ws=True, expect="v7", repeat=2, residual=True)
-        _conv_tol_check(f"sched{sched} grid{grid}", torch.float16, out, ref)
-        monkeypatch.setenv("Y3_V7_SCHED", "0")
-        base, _ = run_conv(dev, torch.float16, 3, 40, 40, 256, 512, 3, 1, algo=1, ws=True, expect="v7", residual=True)
-        assert torch.equal(out, base), f"schedule {sched} differs from schedule 0 (grid {grid})"
+    for grid in ((-1, -2) if variant == "v7" else (0,)):
+        tune("v7_grid", grid)
+        for ahead in (3, 2):
+            tune("conv_ahead", ahead)
+            out, ref = run_conv(dev, torch.float16, *shape, algo=1, ws=True, expect=variant, repeat=3, residual=shape[6] == 1 and shape[5] == 3)
+            _conv_tol_check(f"{variant} ahead{ahead} grid{grid}", torch.float16, out, ref)
+            outs.append(out)
+        assert torch.equal(outs[-1], outs[-2]), f"request depth 3 differs from depth 2 ({variant}, grid {grid})"
 
 
-def test_conv_v7_grid_sweep(dev, monkeypatch):
+def test_conv_v7_grid_sweep(dev, tune):
     """the same problem under different block counts (different K splits, down to whole tiles): every split sums the same
     products in fp32, so the results agree to accumulation-order noise and each one is inside the conv tolerance"""
     outs = []
-    for grid, gc in (("-1", "1"), ("-2", "1"), ("7", "1"), ("24", "2"), ("61", "1"), ("-1", "2"), ("-2", "2"), ("0", "4")):   # "4" does not divide the 2 filter tiles: ignored
-        monkeypatch.setenv("Y3_V7_GRID", grid)
-        monkeypatch.setenv("Y3_V7_GC", gc)   # filter-tile ranges per XCD group (the rectangle a group of blocks owns)
+    for grid, gc in ((-1, 1), (-2, 1), (7, 1), (24, 2), (61, 1), (-1, 2), (-2, 2), (0, 4)):   # 4 does not divide the 2 filter tiles: ignored
+        tune("v7_grid", grid)
+        tune("v7_gc", gc)   # filter-tile ranges per XCD group (the rectangle a group of blocks owns)
         out, ref = run_conv(dev, torch.float16, 4, 20, 20, 256, 512, 3, 1, algo=1, ws=True, expect="v7", repeat=2, residual=True)
         _conv_tol_check(f"grid{grid} gc{gc}", torch.float16, out, ref)
         outs.append(out)
@@ -1855,160 +1855,6 @@ def test_bneck_pair_vs_fp32_reference(dev, dtype, name, shape, add, c):
     assert (got - two).abs().max().item() <= 2 * tol * ref.abs().max().item()
 
 
-# ------------------------------------------------------------------------------------------------ BatchNorm-backward statistics in the data-gradient epilogue
-BNB_CASES = [
-    # name, (n, h, w, c_du, c_gx, k), residual, sliced output, activation, workspace (v7 where eligible), expected variant
-    ("v3_bk64_3x3", (2, 40, 40, 128, 256, 3), False, False, True, False, "v3_bk64_128x128"),
-    ("v6_3x3_res", (4, 20, 20, 512, 512, 3), True, False, True, False, "v6"),
-    ("v7_3x3_res", (4, 20, 20, 512, 512, 3), True, False, True, True, "v7"),
-    ("v7_stream_k_ragged", (2, 21, 19, 256, 256, 3), False, False, True, True, "v7"),
-    ("1x1_res_sliced", (2, 40, 40, 128, 256, 1), True, True, True, False, None),
-    ("1x1_deep_noact", (2, 20, 20, 512, 1024, 1), True, False, False, False, None),
-    ("cout64_odd_pixels", (2, 33, 17, 32, 64, 1), False, False, True, False, "v3_bk32_64x256"),
-    ("cout_not_tile_multiple", (2, 24, 24, 64, 200, 3), True, False, True, False, None),
-    ("many_rows_two_level_sum", (8, 96, 96, 32, 64, 1), True, False, True, False, None),
-    ("head_255", (2, 20, 20, 256, 1024, 1), False, False, True, False, None),
-]
-
-
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("name,shape,residual,sliced,act,ws,expect", BNB_CASES, ids=[c[0] for c in BNB_CASES])
-def test_dgrad_epilogue_bn_backward_statistics(dev, dtype, name, shape, residual, sliced, act, ws, expect):
-    """y3_conv2d_fwd_bnb_ws (the data-gradient launch that completes dy also writes the BatchNorm backward's reduction rows):
-    same dy as y3_conv2d_fwd(_ws) bit for bit; the fp64 sum of its rows equals (sum g, sum g*u), g = dy*act'(scale*u+shift) of the STORED
-    dy, to 2e-5 of sum|g| (fp32 partial sums over <= 128 pixels, v_exp/v_rcp sigmoid); y3_bn_bwd_finalize_rows turns them into the
-    totals / dgamma / dbeta that y3_bn_act_bwd computes with its own pass over (dy, u); y3_bn_act_bwd_apply from those totals gives
-    y3_bn_act_bwd's du (and residual gradient) up to one rounding of T."""
-    import ctypes as C
-
-    _lib, ops = _ops()
-    n, h, w, cd, cg, k = shape
-    g = torch.Generator().manual_seed(23)
-    du_in = (torch.randn(n, cd, h, w, generator=g) * 0.5).to(dtype)
-    wt = torch.randn(cg, cd, k, k, generator=g) / math.sqrt(cd * k * k)
-    u = (torch.randn(n, cg, h, w, generator=g) * 1.5 + torch.randn(1, cg, 1, 1, generator=g)).to(dtype)
-    gamma, beta = torch.rand(cg, generator=g) + 0.5, torch.randn(cg, generator=g) * 0.3
-    uf = u.double()
-    mean, var = uf.mean((0, 2, 3)), uf.var((0, 2, 3), unbiased=False)
-    invstd = 1.0 / torch.sqrt(var + 1e-3)
-    scale = (gamma.double() * invstd).float().to(dev)
-    shift = (beta.double() - mean * gamma.double() * invstd).float().to(dev)
-    mean_d, invstd_d = mean.float().to(dev), invstd.float().to(dev)
-    a = _lib.Y3_ACT_SILU if act else _lib.Y3_ACT_NONE
-    xv = ops.View.alloc(n, h, w, cd, dtype, dev)
-    ops.nchw_to_nhwc(du_in.to(dev), xv)
-    uv = ops.View.alloc(n, h, w, cg, dtype, dev)
-    ops.nchw_to_nhwc(u.to(dev), uv)
-    filt = ops.pack_filter(wt.to(dev), cg, cd, dtype)
-    zb = torch.zeros(cg, device=dev)
-    wsb = conv_ws(dev) if ws else None
-
-    def out_view():
-        if sliced:
-            big = ops.View.alloc(n, h, w, cg + 24, dtype, dev)
-            big.buf.fill_(3.0)
-            return big, big.slice(16, cg)
-        v = ops.View.alloc(n, h, w, cg, dtype, dev)
-        return v, v
-
-    prev = (torch.randn(n, cg, h, w, generator=g) * 0.2).to(dtype) if residual else None
-    big0, y0 = out_view()
-    big1, y1 = out_view()
-    if residual:   # the gradient accumulated so far lives in the output buffer itself (residual port = output)
-        ops.nchw_to_nhwc(prev.to(dev), y0)
-        ops.nchw_to_nhwc(prev.to(dev), y1)
-    ops.conv2d(xv, filt, zb, y0, k, 1, act=False, residual=y0 if residual else None, in_dilation=1, workspace=wsb)
-    rows = ops.conv2d_bnb(xv, None, None, y1, k, None, 1, uv, scale, shift, a, None, 0, workspace=wsb)
-    assert rows > 0
-    if expect is not None:
-        assert ops.last_conv_variant() == expect, ops.last_conv_variant()
-    buf = torch.full((rows * 2 * cg,), float("nan"), device=dev)
-    got = ops.conv2d_bnb(xv, filt, zb, y1, k, y1 if residual else None, 1, uv, scale, shift, a, buf, rows, workspace=wsb)
-    torch.cuda.synchronize()
-    assert got == rows
-    assert torch.equal(big0.buf, big1.buf), "the gradient itself must not change"
-    dy = ops.nhwc_to_nchw(y1).double().cpu()
-    z = uf * scale.double().cpu().view(1, -1, 1, 1) + shift.double().cpu().view(1, -1, 1, 1)
-    sg = torch.sigmoid(z)
-    gg = dy * (sg + z * sg * (1 - sg)) if act else dy
-    ref0, ref1 = gg.sum((0, 2, 3)), (gg * uf).sum((0, 2, 3))
-    tot = buf.view(rows, cg, 2).double().sum(0).cpu()
-    assert torch.isfinite(tot).all(), "a statistics row was not written"
-    mag0, mag1 = gg.abs().sum((0, 2, 3)).max().item(), (gg * uf).abs().sum((0, 2, 3)).max().item()
-    assert (tot[:, 0] - ref0).abs().max().item() <= 2e-5 * mag0, f"sum g: {(tot[:, 0] - ref0).abs().max().item():.3e} of {mag0:.3e}"
-    assert (tot[:, 1] - ref1).abs().max().item() <= 2e-5 * mag1, f"sum g*u: {(tot[:, 1] - ref1).abs().max().item():.3e} of {mag1:.3e}"
-    # rows -> totals / dgamma / dbeta, against the separate reduction pass
-    sums = ops.bn_scratch(cg, dev)
-    totals = torch.full((4 * cg,), float("nan"), dtype=torch.float64, device=dev)
-    dg1, db1 = torch.empty(cg, device=dev), torch.empty(cg, device=dev)
-    _lib.check(_lib.lib().y3_bn_bwd_finalize_rows(buf.data_ptr(), rows, n * h * w, cg, sums.data_ptr(), mean_d.data_ptr(), invstd_d.data_ptr(), totals.data_ptr(), dg1.data_ptr(),
-                                                  db1.data_ptr(), ops.stream_ptr()), "y3_bn_bwd_finalize_rows")
-    sums0 = ops.bn_scratch(cg, dev)
-    dg0, db0 = torch.empty(cg, device=dev), torch.empty(cg, device=dev)
-    du0, du1 = ops.View.alloc(n, h, w, cg, dtype, dev), ops.View.alloc(n, h, w, cg, dtype, dev)
-    gr0, gr1 = ops.View.alloc(n, h, w, cg, dtype, dev), ops.View.alloc(n, h, w, cg, dtype, dev)
-    gr0.buf.fill_(0.25)
-    gr1.buf.fill_(0.25)
-    # y1 may be a channel slice of a wider buffer: both passes take (pointer, pitch) views
-    ut, gt, d0, d1, g0t, g1t = uv.y3(), y1.y3(), du0.y3(), du1.y3(), gr0.y3(), gr1.y3()
-    dc = ops.dtype_code(dtype)
-    _lib.check(_lib.lib().y3_bn_act_bwd_res(C.byref(ut), C.byref(gt), scale.data_ptr(), shift.data_ptr(), mean_d.data_ptr(), invstd_d.data_ptr(), dc, a, sums0.data_ptr(),
-                                            C.byref(d0), dg0.data_ptr(), db0.data_ptr(), C.byref(g0t), 1, ops.stream_ptr()), "y3_bn_act_bwd_res")
-    _lib.check(_lib.lib().y3_bn_act_bwd_apply(C.byref(ut), C.byref(gt), scale.data_ptr(), shift.data_ptr(), mean_d.data_ptr(), invstd_d.data_ptr(), dc, a, totals.data_ptr(),
-                                              C.byref(d1), C.byref(g1t), 1, ops.stream_ptr()), "y3_bn_act_bwd_apply")
-    torch.cuda.synchronize()
-    xh_mag = ((uf - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1) * gg).abs().sum((0, 2, 3)).max().item()
-    assert (db1.double().cpu() - db0.double().cpu()).abs().max().item() <= 4e-5 * mag0
-    assert (dg1.double().cpu() - dg0.double().cpu()).abs().max().item() <= 4e-5 * max(xh_mag, mag1 * invstd.max().item() * 1e-1), "dgamma"
-    assert torch.equal(gr0.buf, gr1.buf), "residual gradient accumulation"
-    a0, a1 = du0.buf.float(), du1.buf.float()
-    ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
-    assert (a0 - a1).abs().max().item() <= ulp * a0.abs().max().item() + 1e-6, "du from the epilogue totals vs du from the reduction pass"
-
-
-@pytest.mark.parametrize("name,hw,adt", [("yolov3", 128, torch.float16), ("yolov3-spp", 96, torch.bfloat16), ("yolov3-tiny", 160, torch.float16)])
-def test_train_step_bn_backward_in_dgrad_epilogue_matches_separate_reduction(dev, monkeypatch, name, hw, adt):
-    """The training plan with the BatchNorm-backward reductions taken in the data-gradient epilogues (default) against the same plan with the
-    separate reduction pass (Y3_BNB_EPILOGUE=0): identical forward, every parameter gradient equal up to the summation order of the two
-    reductions (they feed du, so the difference propagates through the layers below as half-precision rounding flips)."""
-    from yolov3_amd import ComputeLoss
-    from yolov3_amd.engine import plan_cache
-
-    nc, bs = 80, 4
-    hyp = dict(box=0.05, cls=0.5, cls_pw=1.0, obj=1.0, obj_pw=1.0, anchor_t=4.0, fl_gamma=0.0, label_smoothing=0.0)
-    x = torch.rand(bs, 3, hw, hw, generator=torch.Generator().manual_seed(2)).to(dev)
-    tg = yo.synth_targets(bs, nc, seed=6).to(dev)
-    grads, fused_units = {}, {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("Y3_BNB_EPILOGUE", mode)
-        m, _ = build_pair(name, nc, 19, dev, torch.float32)
-        m.train()
-        m.hyp = hyp
-        crit = ComputeLoss(m)
-        with torch.autocast("cuda", dtype=adt):
-            loss, _ = crit(m(x), tg)
-        (loss * 128.0).backward()
-        torch.cuda.synchronize()
-        plan = next(p for k, p in plan_cache(m).plans.items() if k[0] == "train")
-        fused_units[mode] = plan.bnb_units
-        grads[mode] = {k: p.grad.float().cpu() for k, p in m.named_parameters()}
-        grads[mode]["__loss__"] = loss.detach().float().cpu()
-    assert fused_units["0"] == 0
-    assert fused_units["1"] >= {"yolov3": 65, "yolov3-spp": 65, "yolov3-tiny": 4}[name], fused_units
-    assert torch.equal(grads["0"]["__loss__"], grads["1"]["__loss__"])
-    worst = (1.0, None)
-    for k, g0 in grads["0"].items():
-        g1 = grads["1"][k]
-        assert torch.isfinite(g1).all(), k
-        if g0.numel() < 64:
-            continue
-        c = torch.nn.functional.cosine_similarity(g0.flatten(), g1.flatten(), dim=0).item()
-        if c < worst[0]:
-            worst = (c, k)
-    print(f"[bnb epilogue {name} {adt}] min gradient cosine fused vs separate {worst[0]:.6f} at {worst[1]}")
-    assert worst[0] > (0.999 if adt == torch.float16 else 0.98), worst
-
-
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_pack_filter_jobs_matches_per_layer_packing(dev, dtype):
     """y3_pack_filter_jobs (every layer's forward + data-gradient bank in ONE launch, the training step's packing) against y3_pack_filter_pair /
@@ -2057,53 +1903,3 @@ def test_map_parity_on_synthetic_scenes(dev):
     assert res["reference_cpu_fp32"]["mAP50"] > 0.25, res
     assert res["abs_diff_fp32"]["mAP50"] <= 1e-3 and res["abs_diff_fp32"]["mAP50-95"] <= 1e-3, res
     assert res["abs_diff_fp16"]["mAP50"] <= 1e-2 and res["abs_diff_fp16"]["mAP50-95"] <= 1e-2, res
-
-
-V8_CASES = [
-    ("3x3_res_20x20", (8, 20, 20, 512, 1024, 3, 1), dict(residual=True)),
-    ("3x3_ragged_pixels_sliced", (3, 21, 19, 256, 512, 3, 1), dict(sliced=True)),
-    ("3x3_s2", (4, 40, 40, 256, 512, 3, 2), {}),
-    ("1x1_noact", (4, 40, 40, 512, 256, 1, 1), dict(act=False)),
-    ("3x3_cin96_min_blocks", (2, 24, 24, 96, 256, 3, 1), {}),
-]
-
-
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("name,shape,kw", V8_CASES, ids=[c[0] for c in V8_CASES])
-def test_conv_v8_experimental_variant(dev, monkeypatch, dtype, name, shape, kw):
-    """Y3_CONV=v8 (one wave per SIMD, 128 x 128 wave tiles, 4-stage request ring, tap-major loop nest, dead requests past the last
-    K-step, two-pass epilogue; not dispatched by default): inside the conv tolerance against fp32 conv2d on the same rounded operands,
-    BIT-IDENTICAL to the v6 kernel it shares its tile and K order with, repeated launches identical, and the BatchNorm statistics rows
-    of its two-pass epilogue sum to the statistics of the stored tensor."""
-    _lib, ops = _ops()
-    n, h, w, cin, cout, k, s = shape
-    tol_r, tol_a = (2.0 ** -10, 2e-3) if dtype == torch.float16 else (2.0 ** -7, 1.5e-2)
-    monkeypatch.setenv("Y3_CONV", "v8")
-    out8, ref = run_conv(dev, dtype, n, h, w, cin, cout, k, s, seed=7, expect="v8", repeat=2, **kw)
-    monkeypatch.setenv("Y3_CONV", "v6b")
-    out6, _ = run_conv(dev, dtype, n, h, w, cin, cout, k, s, seed=7, expect="v6", **kw)
-    assert torch.equal(out8, out6), f"v8 differs from v6: {(out8 - out6).abs().max().item():.3e}"
-    bad = ((out8 - ref).abs() > tol_r * ref.abs() + tol_a).sum().item()
-    assert bad == 0, f"{bad} elements outside the conv tolerance"
-    if k == 3 and s == 1 and not kw:
-        return
-    # statistics rows through the two-pass epilogue
-    monkeypatch.setenv("Y3_CONV", "v8")
-    g = torch.Generator().manual_seed(4)
-    x = torch.randn(n, cin, h, w, generator=g).to(dtype)
-    wt = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
-    xv = ops.View.alloc(n, h, w, cin, dtype, dev)
-    ops.nchw_to_nhwc(x.to(dev), xv)
-    ho, wo = (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
-    filt = ops.pack_filter(wt.to(dev), cout, cin, dtype)
-    zb = torch.zeros(cout, device=dev)
-    y1 = ops.View.alloc(n, ho, wo, cout, dtype, dev)
-    rows = ops.conv2d_stats_rows(xv, y1, k, s)
-    buf = torch.full((rows * 2 * cout,), float("nan"), device=dev)
-    assert ops.conv2d_stats(xv, filt, zb, y1, k, s, buf, rows) == rows and ops.last_conv_variant() == "v8"
-    torch.cuda.synchronize()
-    u = y1.as_nhwc().double().cpu().reshape(-1, cout)
-    tot = buf.view(rows, cout, 2).double().sum(0).cpu()
-    assert torch.isfinite(tot).all(), "a statistics row was not written"
-    assert (tot[:, 0] - u.sum(0)).abs().max().item() <= 1e-5 * u.abs().sum(0).max().item()
-    assert (tot[:, 1] - (u * u).sum(0)).abs().max().item() <= 1e-5 * (u * u).sum(0).max().item()

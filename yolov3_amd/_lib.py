@@ -72,6 +72,9 @@ _P = C.POINTER
 _SIGNATURES = {
     "y3_abi_version": (C.c_int, []),
     "y3_last_error": (C.c_char_p, []),
+    "y3_tune_set": (C.c_int, [C.c_char_p, C.c_int64]),
+    "y3_tune_get": (C.c_int64, [C.c_char_p]),
+    "y3_tune_reset": (None, []),
     "y3_packed_filter_elems": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "y3_pack_filter": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "y3_conv2d_fwd": (C.c_int, [_P(Y3ConvDesc), _P(Y3Tensor), C.c_void_p, C.c_void_p, _P(Y3Tensor), _P(Y3Tensor), C.c_void_p]),
@@ -136,16 +139,6 @@ _SIGNATURES = {
         C.c_int,
         [_P(Y3Tensor), _P(Y3Tensor), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, _P(Y3Tensor), C.c_void_p, C.c_void_p, _P(Y3Tensor), C.c_int32,
          C.c_void_p],
-    ),
-    "y3_conv2d_fwd_bnb_ws": (
-        C.c_int,
-        [_P(Y3ConvDesc), _P(Y3Tensor), C.c_void_p, C.c_void_p, _P(Y3Tensor), _P(Y3Tensor), _P(Y3Tensor), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
-         C.c_void_p, C.c_size_t, C.c_void_p],
-    ),
-    "y3_bn_bwd_finalize_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "y3_bn_act_bwd_apply": (
-        C.c_int,
-        [_P(Y3Tensor), _P(Y3Tensor), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, _P(Y3Tensor), _P(Y3Tensor), C.c_int32, C.c_void_p],
     ),
     "y3_pack_filter_dgrad": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "y3_pack_filter_pair": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -56,15 +56,6 @@ struct ConvArgs {
     float* stats;
     int stat_wp;   // waves along the pixel axis of the launched variant
     int dry;       // geometry only (y3_conv2d_fwd_stats_rows): fill n_pt / stat_wp, launch nothing
-    // BatchNorm-BACKWARD statistics in the epilogue of a data gradient (y3_conv2d_fwd_bnb_ws): this launch writes the FINAL gradient
-    // dy of a tensor y = act(bn(u)); with u (same n, h, w, c as the output) and the unit's (scale, shift) the rows of `stats` carry
-    // (sum g, sum g * u), g = dy * act'(scale * u + shift) of the value as STORED, instead of (sum, sum of squares): the reduction
-    // pass of the BatchNorm backward over (dy, u) disappears (train.hip turns sum g*u into sum g*xhat in the fp64 row sum)
-    const void* bnb_u;
-    const float* bnb_scale;
-    const float* bnb_shift;
-    int bnb_upitch, bnb_act;
-    unsigned bnb_ubytes;
     void* ws;      // scratch of the persistent stream-K kernel (conv_v7.h): control words, arrival flags, fp32 partial tiles; may be null
     size_t ws_bytes;
     int v7_whole;  // conv_v7.h: blocks own whole tiles (no stream-K split)
@@ -106,21 +97,10 @@ Y3_DEV int xcd_remap(int b, int nb) {
     return base + i;
 }
 
-// tuning knob for A/B runs: Y3_CONV=v2|v3a|v3b|v3c (default: per-shape choice among the v3 tiles); v3 covers Cout > 64, Cin % 32 == 0
-static int conv_variant() {   // read per call (a getenv + a few strcmp per launch): tools/conv_lab.py sweeps variants inside one process
-    const char* e = getenv("Y3_CONV");
-    if (!e) return 3;
-    if (!strcmp(e, "v2")) return 2;
-    if (!strcmp(e, "v3b")) return 4;
-    if (!strcmp(e, "v3c")) return 5;
-    if (!strcmp(e, "v3a")) return 6;
-    if (!strcmp(e, "v5a")) return 11;
-    if (!strcmp(e, "v5b")) return 12;
-    if (!strcmp(e, "v5c")) return 13;
-    if (!strcmp(e, "v6a")) return 14;
-    if (!strcmp(e, "v6b")) return 15;
-    if (!strcmp(e, "v8")) return 16;
-    return 3;
+// forced tile variant for A/B runs (knob "conv", y3_common.h); 3 = per-shape dispatch
+static int conv_variant() {
+    const int v = (int)y3_knob(Y3K_CONV);
+    return v == 0 ? 3 : v;
 }
 
 Y3_DEV int fdiv(int n, unsigned mul, unsigned sh) { return mul ? (int)(__umulhi((unsigned)n, mul) >> (sh - 1)) : n; }
@@ -184,7 +164,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // the same coalesced pattern before the arithmetic starts and added in fp32.  One block barrier (the stage buffers must be
 // idle), no idle waves.  (The block-wide fp32 transpose this replaces cost 8-17 us per block with half of the waves parked
 // during the exp/rcp pass; a register-only variant with 32-byte runs lost on the residual layers: profiles/r01_conv_timeline.md.)
-template <typename T, int MC, int MP, bool BNB = false>
+template <typename T, int MC, int MP>
 Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MP], unsigned char* wl, int c_base, int m_base, int lane, int stat_row = -1) {
     typedef typename Mfma<T>::frag vec8;   // 8 x T = one 16-byte chunk
     constexpr int CH = MC * 4;          // 16-byte chunks per pixel row of this wave's slice
@@ -255,49 +235,14 @@ Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MP], unsigned cha
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const bool want_stats = p.stats != nullptr;   // kernel-uniform
-    // BNB: rows of (sum g, sum g*u) for the BatchNorm backward (see ConvArgs); its own instantiation -- the extra registers must not
-    // touch the forward kernels
     float st0[8], st1[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) st0[q] = st1[q] = 0.0f;
-    // the pre-BatchNorm tensor u at the pixels / channels this lane stores: requested here, after the accumulators died (NI more
-    // 16-byte registers next to the residual rows would not fit beside them), consumed in the store loop below
-    u32x4 ru[BNB ? NI : 1];
-    f32x2 bsc[4], bsh[4];
-    if constexpr (BNB) {
-        const auto rsrc_u = __builtin_amdgcn_make_buffer_rsrc((void*)p.bnb_u, 0, (int)p.bnb_ubytes, 0x00020000);
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int pl = i * PPI + rp;
-            const int spx = __builtin_amdgcn_ds_bpermute((pl & 31) << 2, opx[(i * PPI) / 32]);
-            ru[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_u, yoff[i] != OOB ? (unsigned)(spx * p.bnb_upitch + c) * 2u : OOB, 0, 0);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            bsc[q] = cv ? f32x2{p.bnb_scale[c + 2 * q], p.bnb_scale[c + 2 * q + 1]} : f32x2{0.0f, 0.0f};
-            bsh[q] = cv ? f32x2{p.bnb_shift[c + 2 * q], p.bnb_shift[c + 2 * q + 1]} : f32x2{0.0f, 0.0f};
-        }
-    }
-    auto bnb_rows = [&](auto silu, const vec8& gv, const u32x4& uraw) {
-        const vec8 uu = __builtin_bit_cast(vec8, uraw);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x2 uf = {to_f32<T>(uu[2 * q]), to_f32<T>(uu[2 * q + 1])};
-            f32x2 g = {to_f32<T>(gv[2 * q]), to_f32<T>(gv[2 * q + 1])};
-            if (decltype(silu)::value) {
-                const f32x2 z = uf * bsc[q] + bsh[q];
-                g *= silu_grad2(z, sigmoid2(z));
-            }
-            const f32x2 gu = g * uf;
-            st0[2 * q] += g[0]; st0[2 * q + 1] += g[1];
-            st1[2 * q] += gu[0]; st1[2 * q + 1] += gu[1];
-        }
-    };
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int pl = i * PPI + rp;
         vec8 ov = *(const vec8*)(wl + pl * RB + ((ch ^ swz<MC * 32>(pl)) << 4));
-        if (!BNB && want_stats && yoff[i] != OOB) {
+        if (want_stats && yoff[i] != OOB) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) { const float f = to_f32<T>(ov[q]); st0[q] += f; st1[q] += f * f; }
         }
@@ -307,11 +252,6 @@ Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MP], unsigned cha
 #pragma unroll
             for (int q = 0; q < 8; q += 2) sum[q >> 1] = pack2<T>(to_f32<T>(ov[q]) + to_f32<T>(rr[q]), to_f32<T>(ov[q + 1]) + to_f32<T>(rr[q + 1]));
             ov = __builtin_bit_cast(vec8, sum);
-        }
-        if constexpr (BNB) {   // on the value as stored (after the accumulation through the residual port)
-            if (yoff[i] != OOB) {
-                if (p.bnb_act == Y3_ACT_SILU) bnb_rows(std::true_type{}, ov, ru[i]); else bnb_rows(std::false_type{}, ov, ru[i]);
-            }
         }
         const u32x4 raw = __builtin_bit_cast(u32x4, ov);
         if (!p.ups) {
@@ -511,7 +451,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_v2_kernel(const ConvArgs p)
 // vmcnt(0) precedes it) and retires the reads of the stage tile t+1 is about to overwrite.  Fragments are
 // double-buffered in registers so the ds_read of k-substep s+1 is in flight under the MFMAs of s.
 // WAVES 2x2; per-wave tile (MC*32 couts) x (MP*32 pixels).
-template <typename T, int BK, int MC, int MP, bool BNB = false>
+template <typename T, int BK, int MC, int MP>
 Y3_DEV void conv_igemm_v3_body(const ConvArgs& p, const int block_id, const int n_blocks) {
 #if defined(__HIP_DEVICE_COMPILE__)  // device-only builtins (LDS address space, buffer->LDS DMA): the host pass only needs the stub
     constexpr int WAVES_C = 2, WAVES_P = 2;
@@ -650,14 +590,14 @@ Y3_DEV void conv_igemm_v3_body(const ConvArgs& p, const int block_id, const int 
     Y3_STAMP(3);
 
     __syncthreads();  // every wave is done with the stage buffers: they become the per-wave transpose slices
-    epilogue_wave<T, MC, MP, BNB>(p, acc, smem + wv * (MP * 32 * MC * 64), ct * TC + wc * MC * 32, pt * TP + wp * MP * 32, lane, pt * WAVES_P + wp);
+    epilogue_wave<T, MC, MP>(p, acc, smem + wv * (MP * 32 * MC * 64), ct * TC + wc * MC * 32, pt * TP + wp * MP * 32, lane, pt * WAVES_P + wp);
     Y3_STAMP(4);
 #endif
 }
 
-template <typename T, int BK, int MC, int MP, bool BNB = false>
+template <typename T, int BK, int MC, int MP>
 __global__ __launch_bounds__(256, (BK == 32 && MC * MP <= 4 ? 4 : 2)) void conv_igemm_v3_kernel(const ConvArgs p) {
-    conv_igemm_v3_body<T, BK, MC, MP, BNB>(p, blockIdx.x, gridDim.x);
+    conv_igemm_v3_body<T, BK, MC, MP>(p, blockIdx.x, gridDim.x);
 }
 
 // Four convolutions of the SAME input in one launch: the output-parity classes of a stride-2 data gradient (y3_conv2d_dgrad_s2).  As
@@ -667,52 +607,64 @@ __global__ __launch_bounds__(256, (BK == 32 && MC * MP <= 4 ? 4 : 2)) void conv_
 struct ConvArgs4 {
     ConvArgs a[4];
 };
-template <typename T, int BK, int MC, int MP, bool BNB = false>
+template <typename T, int BK, int MC, int MP>
 __global__ __launch_bounds__(256, (BK == 32 && MC * MP <= 4 ? 4 : 2)) void conv_igemm_v3_quad_kernel(const ConvArgs4 q, const int n_blocks) {
     const int cls = (blockIdx.x >> 3) & 3;
     const int bid = (int)((blockIdx.x >> 5) << 3) | (int)(blockIdx.x & 7);
     if (bid >= n_blocks) return;
-    conv_igemm_v3_body<T, BK, MC, MP, BNB>(q.a[cls], bid, n_blocks);
+    conv_igemm_v3_body<T, BK, MC, MP>(q.a[cls], bid, n_blocks);
 }
 
-// ---- v5: the v3 structure generalised to WAVES_C x WAVES_P waves (8 waves = 512 threads, 256 couts x 256 pixels).
+// ---- v6: 8 waves (512 threads), 256 couts x 256 pixels, BK 32, the v3 staging generalised to a 4-stage LDS ring.
 // Probe runs (profiles/r01_conv_probe.md) showed v3 spending as many issue cycles on `buffer_load ... lds` pieces as on the
 // MFMAs they feed and its MFMA + ds_read half topping out at ~45 %: a 256x256 tile halves the staged bytes (DMA pieces)
-// per MFMA and a 128c x 64p wave tile needs 0.75 fragment reads per MFMA instead of 1.  One block (8 waves) per CU.
-// Original v3 notes follow.
-// ---- v3: LDS-DMA staging.  `buffer_load_dwordx4 ... lds` moves each wave's 1 KiB chunk straight from L2/HBM into
-// the LDS tile (no VGPR round trip, no ds_write pass); the destination is lane-linear, so the XOR swizzle is applied
-// to the SOURCE address (lane = physical slot, it fetches the logical slot that belongs there) and again on the
-// fragment read.  Out-of-range lanes (halo, tails, K padding) carry offset 0xffffffff: the descriptor's bounds check
-// makes them land as zeros.  Two LDS stages, ONE barrier per K-step: the barrier both publishes tile t (each wave's
-// vmcnt(0) precedes it) and retires the reads of the stage tile t+1 is about to overwrite.  Fragments are
-// double-buffered in registers so the ds_read of k-substep s+1 is in flight under the MFMAs of s.
-// WAVES 2x2; per-wave tile (MC*32 couts) x (MP*32 pixels).
+// per MFMA and a 64c x 128p wave tile needs 0.75 fragment reads per MFMA instead of 1.  One block (8 waves) per CU.
 //
-// SCHED 1 ("v6"): the two halves of the block (waves 0-3 / 4-7 = one wave of each half on every SIMD) run ONE barrier interval
+// Schedule: the two halves of the block (waves 0-3 / 4-7 = one wave of each half on every SIMD) run ONE barrier interval
 // apart, so while one half multiplies the other half requests tiles and reads fragments -- the MFMA pipe of a SIMD always
-// has the other wave's memory phase to hide.  Per K-tile (BK 32) a wave does MEM(t) = { request tile t+2 (4 DMA pieces),
-// read the 12 fragments of tile t, s_waitcnt vmcnt(4) } | barrier | MMA(t) = { 16 MFMAs } | barrier.  Four LDS stages:
-// tile t+2 lands in the stage of tile t-2, whose last reads retired two intervals ago.  A tile is first read (by the
-// leading half) in the interval after every wave's counted vmcnt retired its pieces of that tile and passed a barrier:
+// has the other wave's memory phase to hide.  Per K-tile a wave does MEM(t) = { request tile t + AHEAD (4 DMA pieces),
+// read the 12 fragments of tile t, counted s_waitcnt vmcnt } | barrier | MMA(t) = { 16 MFMAs } | barrier.  A tile is first read
+// (by the leading half) in the interval after every wave's counted vmcnt retired its pieces of that tile and passed a barrier:
 // the wait sits at the end of MEM(t-1), the reads in MEM(t).  Waits never drain to 0 in the steady state.
-template <typename T, int BK, int WAVES_C, int WAVES_P, int MC, int MP, int SCHED = 0, bool BNB = false>
-__global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (MC * MP >= 16 ? 1 : 2)) void conv_igemm_v5_kernel(const ConvArgs p) {
+//   AHEAD 2 (round 1 / 2): tile t+2 lands in the stage of tile t-2, whose last reads retired two intervals ago.
+//   AHEAD 3 (round 3): tile t+3 lands in the stage of tile t-1.  The probe of round 2 (profiles/r02_v7_probe.txt) had every wave
+//     parked ~185 of ~1620 ticks per K-step in the counted wait -- a piece that misses L2 takes longer than the one K-step AHEAD 2
+//     gives it, and vmcnt retires in order.  The last readers of stage (t-1)&3 are the trailing half's MEM(t-1), one interval
+//     before the leading half's MEM(t): every wave therefore completes its fragment reads (lgkmcnt(0)) BEFORE the barrier that
+//     ends its MEM phase, so that no read can still be in flight when the other half's request is issued behind that barrier.
+template <int N> Y3_DEV void wait_vmcnt() {   // `s_waitcnt vmcnt(N)`; the immediate must be a literal
+    static_assert(N >= 0 && N <= 12, "extend the table");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if constexpr (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+}
+
+template <typename T, int AHEAD>
+__global__ __launch_bounds__(512, 2) void conv_igemm_v6_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // device-only builtins (LDS address space, buffer->LDS DMA): the host pass only needs the stub
+    constexpr int BK = 32, WAVES_C = 4, WAVES_P = 2, MC = 2, MP = 4;
     constexpr int NT = 64 * WAVES_C * WAVES_P;
     constexpr int TC = WAVES_C * MC * 32;
     constexpr int TP = WAVES_P * MP * 32;
     constexpr int S = BK / 8;
     constexpr int WJ = TC * S / NT;
     constexpr int XJ = TP * S / NT;
-    static_assert((TC * S) % NT == 0 && (TP * S) % NT == 0, "whole chunks only");
+    static_assert(WJ + XJ == 4 && (AHEAD == 2 || AHEAD == 3), "4 DMA pieces per wave and tile; 4 stages hold AHEAD <= 3");
     constexpr int W_BYTES = TC * BK * 2;
     constexpr int STAGE_BYTES = (TC + TP) * BK * 2;
-    constexpr int NST = (SCHED == 1 || SCHED == 2) ? 4 : 2;
-    static_assert(SCHED != 1 || (NT == 512 && BK == 32 && WJ + XJ == 4), "the staggered schedule is written for 8 waves, BK 32, 4 DMA pieces per wave and tile");
+    constexpr int NST = 4;
     constexpr int LDS_BYTES = NST * STAGE_BYTES > TC * TP * 2 ? NST * STAGE_BYTES : TC * TP * 2;  // K-loop stages, re-used as the epilogue's T-typed output tile
     constexpr int ROWSTEP = NT / S;
-    constexpr int KSUB = BK / 16;
     typedef typename Mfma<T>::frag frag;
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -759,25 +711,18 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (MC * MP >= 16 ? 1 : 2)) vo
 
     int nx_tap = 0, nx_cb = 0, nx_kh, nx_kw;   // (tap, channel block) of the next tile to be requested: K-steps are issued strictly in order
     tap_offsets(p, 0, nx_kh, nx_kw);
-    auto dma = [&](int it, int stage, bool live = true) {   // live = false: a request past the last K-step (all lanes out of bounds: zeros into a free stage)
+    auto dma = [&](int it, int stage) {
         const int cb = nx_cb, kh = nx_kh, kw = nx_kw;
-        if constexpr (SCHED == 2) {   // branch-free cursor: the loop body of the one-wave-per-SIMD schedule must stay one basic block
-            const int wrap = (nx_cb + 1 == p.cin_blocks) ? 1 : 0;
-            nx_cb = wrap ? 0 : nx_cb + 1;
-            nx_tap += wrap;
-            tap_offsets(p, nx_tap < 15 ? nx_tap : 15, nx_kh, nx_kw);
-        } else {
-            if (++nx_cb == p.cin_blocks) { nx_cb = 0; ++nx_tap; tap_offsets(p, nx_tap, nx_kh, nx_kw); }
-        }
+        if (++nx_cb == p.cin_blocks) { nx_cb = 0; ++nx_tap; tap_offsets(p, nx_tap, nx_kh, nx_kw); }
         unsigned char* wl = smem + stage * STAGE_BYTES;
         unsigned char* xl = wl + W_BYTES;
 #pragma unroll
         for (int j = 0; j < WJ; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(wl + (j * NT + wv * 64) * 16), 16, live ? woff[j] + (unsigned)(it * BK * 2) : OOB, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(wl + (j * NT + wv * 64) * 16), 16, woff[j] + (unsigned)(it * BK * 2), 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < XJ; ++j) {
             const int hi = hi0[j] + kh, wi = wi0[j] + kw;
-            const bool ok = (int)live & (int)mvalid[j] & (int)in_image(hi, wi, p);
+            const bool ok = (int)mvalid[j] & (int)in_image(hi, wi, p);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(xl + (j * NT + wv * 64) * 16), 16,
                                                      ok ? (unsigned)(xoff[j] + tap_bytes(hi0[j], wi0[j], kh, kw, cb * BK, p) + xc0[j]) : OOB, 0, 0, 0);
         }
@@ -789,7 +734,6 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (MC * MP >= 16 ? 1 : 2)) vo
     // the accumulators start at the bias of their filter (lane holds filters 8g + 4fk + q of each 32-filter tile): the
     // loads overlap the first tile's flight and the epilogue has no bias pass
     f32x16 acc[MC][MP];
-    f32x4 bzs[SCHED == 2 ? MC : 1][4];   // SCHED 2 requests its first tiles BEFORE the accumulators are initialised (the bias loads fly with them)
 #pragma unroll
     for (int a = 0; a < MC; ++a)
 #pragma unroll
@@ -797,25 +741,11 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (MC * MP >= 16 ? 1 : 2)) vo
             const int cb = ct * TC + (wc * MC + a) * 32 + 8 * g + 4 * fk;
             f32x4 bz = {0.f, 0.f, 0.f, 0.f};
             if (p.bias && cb + 4 <= p.Cout) bz = *(const f32x4*)(p.bias + cb);
-            if constexpr (SCHED == 2) {
-                bzs[a][g] = bz;
-            } else {
 #pragma unroll
-                for (int b = 0; b < MP; ++b)
+            for (int b = 0; b < MP; ++b)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[a][b][4 * g + q] = bz[q];
-            }
+                for (int q = 0; q < 4; ++q) acc[a][b][4 * g + q] = bz[q];
         }
-    auto init_acc = [&]() {   // SCHED 2 only
-#pragma unroll
-        for (int a = 0; a < (SCHED == 2 ? MC : 0); ++a)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int b = 0; b < MP; ++b)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[a][b][4 * g + q] = bzs[a][g][q];
-    };
 
     auto load_frags = [&](int stage, int kk, frag (&af)[MC], frag (&bf)[MP]) {
         const unsigned char* wl = smem + stage * STAGE_BYTES;
@@ -838,186 +768,62 @@ __global__ __launch_bounds__(64 * WAVES_C * WAVES_P, (MC * MP >= 16 ? 1 : 2)) vo
 #pragma unroll
             for (int b = 0; b < MP; ++b) acc[a][b] = Mfma<T>::run(af[a], bf[b], acc[a][b]);
     };
+    // leave the pieces of `tiles` younger K-tiles (4 per wave and tile) in flight
+    auto wait_tiles = [&](int tiles) {
+        if (tiles >= 2) wait_vmcnt<8>();
+        else if (tiles == 1) wait_vmcnt<4>();
+        else wait_vmcnt<0>();
+    };
 
-    if constexpr (SCHED == 1) {
-        const int half = wv >> 2;   // 0: leading half, 1: trailing half (one barrier interval behind)
-        dma(0, 0);
-        if (p.nk > 1) dma(1, 1);
-        Y3_STAMP(1);
-        if (p.nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();          // tile 0 is visible to everyone
-        Y3_STAMP(2);
-        if (half) __builtin_amdgcn_s_barrier();   // stagger
-        for (int it = 0; it < p.nk; ++it) {
-            // ---- MEM(it): request tile it+2, read the fragments of tile it, retire this wave's pieces of tile it+1 ----
-            const bool more = it + 2 < p.nk;
-            if (more) dma(it + 2, (it + 2) & 3);
-            frag a0[MC], b0[MP], a1[MC], b1[MP];
-            load_frags(it & 3, 0, a0, b0);
-            load_frags(it & 3, 1, a1, b1);
-            if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            // ---- MMA(it) ----
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
-            mma(a0, b0);
-            mma(a1, b1);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-        }
-        if (!half) __builtin_amdgcn_s_barrier();  // re-align: every wave has now passed 2 nk + 2 barriers and retired all its fragment reads
-        Y3_STAMP(3);
-    } else if constexpr (SCHED == 2) {
-        // "v8": ONE wave per SIMD (4 waves of 128 filters x 128 pixels: 0.5 fragment reads per MFMA instead of the 0.75 of the 8-wave tile,
-        // accumulators in AGPRs).  No second wave hides a wave's memory phase, so (a) tiles are requested THREE K-steps ahead into a 4-stage
-        // ring and retired with counted waits, (b) the fragment reads and DMA requests of a K-step are spread between the MFMAs of the
-        // previous half K-step (sched_group_barrier pipelines), (c) the waits are the builtin (the compiler's scoreboard sees them: an asm
-        // wait left it inserting its own vmcnt waits in front of the address arithmetic of the next requests).
-        constexpr int PIECES = WJ + XJ;
-        static_assert(PIECES == 8 && KSUB == 2, "vmcnt immediates / two half K-steps below");
-        constexpr int VM0 = 0x0F70, VM8 = 0x0F78, VM16 = 0x4F70;   // s_waitcnt vmcnt(n) with expcnt / lgkmcnt left open (gfx9 encoding: vmcnt = [3:0] + [15:14])
-        // Requests: a piece's byte offset is (per-lane part, constant over the channel blocks of a tap) + (channel block, the same for
-        // every lane), so the per-lane part lives in registers -- xb[j], recomputed once per TAP, the out-of-image / tail lanes parked at
-        // 2^31 (beyond every descriptor, and far enough from 2^32 that adding the scalar part cannot wrap) -- and the channel block rides in
-        // the instruction's scalar offset: a K-step issues 8 requests and a handful of scalar instructions instead of ~130 vector ones.
-        constexpr unsigned PARK = 0x80000000u;
-        unsigned xb[XJ];
-        auto tap_setup = [&](int tap) {
-            int kh, kw;
-            tap_offsets(p, tap, kh, kw);
-#pragma unroll
-            for (int j = 0; j < XJ; ++j) {
-                const int hi = hi0[j] + kh, wi = wi0[j] + kw;
-                const bool ok = (int)mvalid[j] & (int)in_image(hi, wi, p);
-                xb[j] = ok ? (unsigned)(xoff[j] + tap_bytes(hi0[j], wi0[j], kh, kw, 0, p) + xc0[j]) : PARK;
-            }
-        };
-        auto request = [&](int stage, unsigned w_soff, unsigned x_soff, bool live) {
-            unsigned char* wl = smem + stage * STAGE_BYTES;
-            unsigned char* xl = wl + W_BYTES;
-#pragma unroll
-            for (int j = 0; j < WJ; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(wl + (j * NT + wv * 64) * 16), 16, live ? woff[j] : PARK, w_soff, 0, 0);
-#pragma unroll
-            for (int j = 0; j < XJ; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(xl + (j * NT + wv * 64) * 16), 16, live ? xb[j] : PARK, x_soff, 0, 0);
-        };
+    const int half = wv >> 2;   // 0: leading half, 1: trailing half (one barrier interval behind)
+    const int nk = p.nk;
+    dma(0, 0);
+    if (nk > 1) dma(1, 1);
+    if (AHEAD == 3 && nk > 2) dma(2, 2);
+    Y3_STAMP(1);
+    wait_tiles(min(nk, AHEAD) - 1);
+    __builtin_amdgcn_s_barrier();          // tile 0 is visible to everyone
+    Y3_STAMP(2);
+    if (half) __builtin_amdgcn_s_barrier();   // stagger
+    for (int it = 0; it < nk; ++it) {
+        // ---- MEM(it): request tile it + AHEAD, read the fragments of tile it, retire this wave's pieces of tile it + 1 ----
+        if (it + AHEAD < nk) dma(it + AHEAD, (it + AHEAD) & 3);
         frag a0[MC], b0[MP], a1[MC], b1[MP];
-        int c = 0;   // K-step being multiplied; the request cursor runs three K-steps ahead
-        // one K-step of compute + (optionally live) one request; ONE basic block
-        auto kstep = [&](unsigned w_soff, unsigned x_soff, bool live) {
-            const int st = c & 3;
-            __builtin_amdgcn_sched_barrier(0);
-            load_frags(st, 1, a1, b1);
-            request((c + 3) & 3, w_soff, x_soff, live);   // the stage of K-step c-1: every wave passed the barrier of step c-1 after its last read
-            mma(a0, b0);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // 1 request
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_waitcnt(VM16);   // this wave's pieces of K-step c+1 have landed (c+2, c+3 stay in flight) ...
-            __builtin_amdgcn_s_barrier();       // ... and everyone's
-            __builtin_amdgcn_sched_barrier(0);
-            load_frags((c + 1) & 3, 0, a0, b0);
-            mma(a1, b1);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            ++c;
-        };
-        // always three K-steps in flight (requests past the last one are dead: every lane parked), so every wait is vmcnt(16).
-        // The bias loads were issued above and are OLDER than every request: the counted wait for K-step 0 covers them, and the
-        // accumulators are initialised while the first tiles fly.
-        const int cbs = p.cin_blocks;      // >= 3: v8 serves Cin >= 96
-        tap_setup(0);
-        request(0, 0u, 0u, true);
-        request(1, (unsigned)(BK * 2), (unsigned)(BK * 2), p.nk > 1);
-        request(2, (unsigned)(2 * BK * 2), (unsigned)(2 * BK * 2), p.nk > 2);
-        Y3_STAMP(1);
+        load_frags(it & 3, 0, a0, b0);
+        load_frags(it & 3, 1, a1, b1);
+        wait_tiles(min(nk - 1, it + AHEAD) - min(nk - 1, it + 1));
+        if constexpr (AHEAD == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the stage just read is requested into by the other half right behind the barrier
         __builtin_amdgcn_sched_barrier(0);
-        init_acc();
-        __builtin_amdgcn_s_waitcnt(VM16);
-        __builtin_amdgcn_s_barrier();   // K-step 0 is visible to every wave
-        Y3_STAMP(2);
-        load_frags(0, 0, a0, b0);
-        unsigned w_soff = (unsigned)(3 * BK * 2);
-        for (int rt = 0; rt < p.ntaps; ++rt) {
-            // the per-lane offsets of this tap, once per cin_blocks K-steps (tried in the shadow of the previous tap's last MFMAs: its
-            // exec-masked 64-bit multiplies split the scheduling region and the pipeline directives did not take)
-            if (rt) tap_setup(rt);
-            for (int rcb = rt ? 0 : 3; rcb < cbs; ++rcb) {
-                kstep(w_soff, (unsigned)(rcb * BK * 2), true);
-                w_soff += (unsigned)(BK * 2);
-            }
-        }
-        for (int k = 0; k < 3; ++k) kstep(0u, 0u, false);   // drain: the last three K-steps, dead requests
-        Y3_STAMP(3);
-        __syncthreads();
-    } else {
-        dma(0, 0);
-        Y3_STAMP(1);
-        for (int it = 0; it < p.nk; ++it) {
-            __syncthreads();  // tile `it` has landed for every wave; stage (it+1)&1 is no longer being read
-            if (it == 0) Y3_STAMP(2);
-            if (it + 1 < p.nk) dma(it + 1, (it + 1) & 1);
-            const int st = it & 1;
-            frag a0[MC], b0[MP], a1[MC], b1[MP];
-            load_frags(st, 0, a0, b0);
-#pragma unroll
-            for (int kk = 0; kk < KSUB; kk += 2) {
-                load_frags(st, kk + 1, a1, b1);
-                mma(a0, b0);
-                if (kk + 2 < KSUB) load_frags(st, kk + 2, a0, b0);
-                mma(a1, b1);
-            }
-        }
-        Y3_STAMP(3);
-        __syncthreads();  // every wave is done with the stage buffers: they become the per-wave transpose slices
+        __builtin_amdgcn_s_barrier();
+        // ---- MMA(it) ----
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        mma(a0, b0);
+        mma(a1, b1);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
     }
-    if constexpr (SCHED == 2 && MP == 4) {
-        // two passes of 64 pixels per wave (v7's form): half the residual / offset registers of one 128-pixel pass -- with one wave per SIMD
-        // nothing hides a spill's round trip
-#pragma unroll
-        for (int hb = 0; hb < 2; ++hb) {
-            f32x16 part[MC][2];
-#pragma unroll
-            for (int a = 0; a < MC; ++a) { part[a][0] = acc[a][2 * hb]; part[a][1] = acc[a][2 * hb + 1]; }
-            epilogue_wave<T, MC, 2, BNB>(p, part, smem + wv * (2 * 32 * MC * 64), ct * TC + wc * MC * 32, pt * TP + wp * MP * 32 + hb * 64, lane, (pt * WAVES_P + wp) * 2 + hb);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();   // the slice is private to the wave: its reads of pass 0 precede the writes of pass 1
-        }
-    } else {
-        epilogue_wave<T, MC, MP, BNB>(p, acc, smem + wv * (MP * 32 * MC * 64), ct * TC + wc * MC * 32, pt * TP + wp * MP * 32, lane, pt * WAVES_P + wp);
-    }
+    if (!half) __builtin_amdgcn_s_barrier();  // re-align: every wave has now passed 2 nk + 2 barriers and retired all its fragment reads
+    Y3_STAMP(3);
+    epilogue_wave<T, MC, MP>(p, acc, smem + wv * (MP * 32 * MC * 64), ct * TC + wc * MC * 32, pt * TP + wp * MP * 32, lane, pt * WAVES_P + wp);
     Y3_STAMP(4);
 #endif
 }
 
-template <typename T, int BK, int WAVES_C, int WAVES_P, int MC, int MP, int SCHED = 0, bool BNB = false> int launch_v5(ConvArgs& a, hipStream_t st) {
-    constexpr int TC = WAVES_C * MC * 32, TP = WAVES_P * MP * 32;
-    a.n_ct = y3_ceil_div(a.Cout, TC);
-    a.n_pt = y3_ceil_div(a.M, TP);
+template <typename T> int launch_v6(ConvArgs& a, hipStream_t st) {
+    a.n_ct = y3_ceil_div(a.Cout, 256);
+    a.n_pt = y3_ceil_div(a.M, 256);
     set_divisors(a);
-    a.cin_blocks = a.Cin / BK;
+    a.cin_blocks = a.Cin / 32;
     a.nk = a.ntaps * a.cin_blocks;
     const long long nb = (long long)a.n_ct * a.n_pt;
     if (nb > 0x7fffffffLL) Y3_FAIL("conv grid too large");
-    a.stat_wp = (SCHED == 2 && MP == 4) ? WAVES_P * 2 : WAVES_P;   // the one-wave-per-SIMD schedule writes its statistics rows in two 64-pixel passes
-    g_last_variant = SCHED == 2 ? "v8" : (SCHED == 1 ? "v6" : (BK == 64 ? "v5_bk64" : "v5_bk32"));
+    a.stat_wp = 2;
+    g_last_variant = "v6";
     if (a.dry) return 0;
-    hipLaunchKernelGGL((conv_igemm_v5_kernel<T, BK, WAVES_C, WAVES_P, MC, MP, SCHED, BNB>), dim3((unsigned)nb), dim3(64 * WAVES_C * WAVES_P), 0, st, a);
+    if (y3_knob(Y3K_CONV_AHEAD) == 2) hipLaunchKernelGGL((conv_igemm_v6_kernel<T, 2>), dim3((unsigned)nb), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((conv_igemm_v6_kernel<T, 3>), dim3((unsigned)nb), dim3(512), 0, st, a);
     Y3_CHECK_LAUNCH();
     return 0;
 }
@@ -1036,7 +842,7 @@ template <typename T, int BK, int MC, int MP> void geometry_v3(ConvArgs& a) {
     a.nk = a.ntaps * a.cin_blocks;
     a.stat_wp = 2;
 }
-template <typename T, int BK, int MC, int MP, bool BNB = false> int launch_v3(ConvArgs& a, hipStream_t st) {
+template <typename T, int BK, int MC, int MP> int launch_v3(ConvArgs& a, hipStream_t st) {
     geometry_v3<T, BK, MC, MP>(a);
     const long long nb = (long long)a.n_ct * a.n_pt;
     if (nb > 0x7fffffffLL) Y3_FAIL("conv grid too large");
@@ -1048,12 +854,12 @@ template <typename T, int BK, int MC, int MP, bool BNB = false> int launch_v3(Co
             q.a[i] = g_quad[i];
             geometry_v3<T, BK, MC, MP>(q.a[i]);
         }
-        hipLaunchKernelGGL((conv_igemm_v3_quad_kernel<T, BK, MC, MP, BNB>), dim3((unsigned)((nb + 7) / 8 * 32)), dim3(256), 0, st, q, (int)nb);
+        hipLaunchKernelGGL((conv_igemm_v3_quad_kernel<T, BK, MC, MP>), dim3((unsigned)((nb + 7) / 8 * 32)), dim3(256), 0, st, q, (int)nb);
         Y3_CHECK_LAUNCH();
         g_quad_done = true;
         return 0;
     }
-    hipLaunchKernelGGL((conv_igemm_v3_kernel<T, BK, MC, MP, BNB>), dim3((unsigned)nb), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_igemm_v3_kernel<T, BK, MC, MP>), dim3((unsigned)nb), dim3(256), 0, st, a);
     Y3_CHECK_LAUNCH();
     return 0;
 }
@@ -1140,70 +946,46 @@ int launch_igemm(ConvArgs& a, hipStream_t st) {
 
 #include "conv_v7.h"
 
-// BNB = the data-gradient launch also writes the BatchNorm-backward statistic rows (ConvArgs::bnb_*): separate instantiations of the
-// LDS-DMA kernels (the register-staged v2 fallback has none: the caller asks y3_conv2d_fwd_variant first)
-template <typename T, bool BNB = false> int dispatch_igemm(ConvArgs& a, hipStream_t st) {
+template <typename T> int dispatch_igemm(ConvArgs& a, hipStream_t st) {
     const bool c64 = (a.Cin % 64) == 0, c32 = (a.Cin % 32) == 0;
-    const int var = BNB ? 3 : conv_variant();
+    const int var = conv_variant();
     if (!(a.x_bytes && a.w_bytes && a.y_bytes && (!a.res || a.r_bytes)))
         Y3_FAIL("conv: a tensor exceeds the 2 GiB reach of a buffer descriptor (split the batch)");
-    const bool dma_ok = true;
-    if constexpr (!BNB) {
-        // Y3_CONV_V8=1: the one-wave-per-SIMD tile (v8) where it measured ahead of v6 / v7 -- 3x3, K >= 4608, >= 1024 filters (the 20x20
-        // layers: 117 vs 120-121 us, profiles/r02_v8_fifth_try.txt).  Off by default: measured after the round's last full-suite run.
-        static const bool v8_auto = [] { const char* e = getenv("Y3_CONV_V8"); return e && atoi(e) == 1; }();
-        if (v8_auto && var == 3 && c32 && a.ntaps == 9 && a.ntaps * a.Cin >= 4608 && a.Cout >= 1024 && a.Cin >= 96 && !a.ups)
-            return launch_v5<T, 32, 2, 2, 4, 4, 2>(a, st);
-    }
-    if (var == 3 && v7_eligible(a)) return launch_v7<T, BNB>(a, st);
-    if (var >= 3 && a.Cout > 64 && c32 && dma_ok) {
-        if constexpr (!BNB) {   // forced variants (A/B runs)
-            if (var == 4) return launch_v3<T, 32, 2, 4>(a, st);   // 128c x 256p, BK 32
-            if (var == 5) return launch_v3<T, 32, 2, 2>(a, st);   // 128c x 128p, BK 32 (4 blocks / CU)
-            if (var == 6) return c64 ? launch_v3<T, 64, 2, 2>(a, st) : launch_v3<T, 32, 2, 2>(a, st);
-            if (var == 14 && a.Cout >= 256) return launch_v5<T, 32, 2, 4, 4, 2, 1>(a, st);   // staggered halves, wave 128c x 64p
-            if (var == 15 && a.Cout >= 256) return launch_v5<T, 32, 4, 2, 2, 4, 1>(a, st);   // staggered halves, wave 64c x 128p
-            if (var == 16 && a.Cout >= 256 && a.Cin >= 96) return launch_v5<T, 32, 2, 2, 4, 4, 2>(a, st);   // "v8": 4 waves of 128c x 128p, 4-stage ring (>= 3 channel blocks per tap: its first three requests share tap 0)
-            if (var >= 11 && var <= 13 && c64 && a.Cout >= 256) {
-                if (var == 11) return launch_v5<T, 64, 2, 4, 4, 2>(a, st);   // 256c x 256p, wave 128c x 64p, BK 64
-                if (var == 12) return launch_v5<T, 64, 4, 2, 2, 4>(a, st);   // 256c x 256p, wave 64c x 128p, BK 64
-                return launch_v5<T, 32, 2, 4, 4, 2>(a, st);                  // 256c x 256p, wave 128c x 64p, BK 32 (2 blocks/CU by LDS)
-            }
-        }
-        // auto (measured on MI355X, profiles/r01_conv_variants.md): long-K layers with >= 512 filters want the 8-wave
-        // 256x256 tile (v5), short K loops want 4 resident blocks per CU (BK 32), small pixel counts with long K the
+    if (var == 3 && v7_eligible(a)) return launch_v7<T>(a, st);
+    if (var >= 3 && a.Cout > 64 && c32) {
+        // forced tiles (knob "conv", A/B runs)
+        if (var == 4) return launch_v3<T, 32, 2, 4>(a, st);   // 128c x 256p, BK 32
+        if (var == 5) return launch_v3<T, 32, 2, 2>(a, st);   // 128c x 128p, BK 32 (4 blocks / CU)
+        if (var == 6) return c64 ? launch_v3<T, 64, 2, 2>(a, st) : launch_v3<T, 32, 2, 2>(a, st);
+        if (var == 15 && a.Cout >= 256) return launch_v6<T>(a, st);
+        // auto (measured on MI355X, profiles/r01_conv_variants.md, r02_conv_variant_sweep.txt): long-K layers with >= 512 filters want
+        // the 8-wave 256x256 tile (v6), short K loops want 4 resident blocks per CU (BK 32), small pixel counts with long K the
         // 128x256 tile, the rest the BK 64 128x128 tile.
-        // (re-measured after the epilogue rewrite, gpurun_out/variants2.log -> profiles/r01_conv_variants.md)
         const int K = a.ntaps * a.Cin;
-        if (K >= 2304 && a.Cout >= 512) return launch_v5<T, 32, 4, 2, 2, 4, 1, BNB>(a, st);   // 256c x 256p, 8 waves (64c x 128p each), staggered halves
-        if (K >= 4608 && a.Cout >= 256 && a.M >= 65536) return launch_v5<T, 32, 4, 2, 2, 4, 1, BNB>(a, st);   // data gradient of the 256 -> 512 layers (one filter tile)
-        if (c64 && a.ntaps == 1 && a.Cout >= 256 && a.M > 16384 && a.M <= 65536) return launch_v5<T, 32, 4, 2, 2, 4, 1, BNB>(a, st);   // 1x1 @40x40
-        if (c64 && ((a.ntaps > 1 && K >= 1152) || (a.ntaps == 1 && K >= 256 && a.M <= 16384))) return launch_v3<T, 64, 2, 2, BNB>(a, st);
-        // round 2 sweep (profiles/r02_conv_variant_sweep.txt): 64 -> 128 3x3 @160x160 runs 5 % faster on the 128c x 256p tile, the stride-2
-        // 64 -> 128 layer 3 % faster with BK 64
-        if (c64 && a.ntaps > 1 && K == 576 && a.Cout == 128 && a.M >= 262144) return a.stride == 1 ? launch_v3<T, 32, 2, 4, BNB>(a, st) : launch_v3<T, 64, 2, 2, BNB>(a, st);
-        return launch_v3<T, 32, 2, 2, BNB>(a, st);
+        if (K >= 2304 && a.Cout >= 512) return launch_v6<T>(a, st);
+        if (K >= 4608 && a.Cout >= 256 && a.M >= 65536) return launch_v6<T>(a, st);   // data gradient of the 256 -> 512 layers (one filter tile)
+        if (c64 && a.ntaps == 1 && a.Cout >= 256 && a.M > 16384 && a.M <= 65536) return launch_v6<T>(a, st);   // 1x1 @40x40
+        if (c64 && ((a.ntaps > 1 && K >= 1152) || (a.ntaps == 1 && K >= 256 && a.M <= 16384))) return launch_v3<T, 64, 2, 2>(a, st);
+        // 64 -> 128 3x3 @160x160 runs 5 % faster on the 128c x 256p tile, the stride-2 64 -> 128 layer 3 % faster with BK 64
+        if (c64 && a.ntaps > 1 && K == 576 && a.Cout == 128 && a.M >= 262144) return a.stride == 1 ? launch_v3<T, 32, 2, 4>(a, st) : launch_v3<T, 64, 2, 2>(a, st);
+        return launch_v3<T, 32, 2, 2>(a, st);
     }
     // <= 64-filter layers with Cin % 32 == 0 also go to the LDS-DMA kernel (64c x 256p tile): measured 0.42 -> 0.36 ms on
-    // 32->64 s2 @640x640 and 0.44 -> 0.38 ms on 32->64 @320x320 (bs 32); Y3_CONV_SMALL=v2 restores the register-staged kernel
-    static const bool small_v3 = !(getenv("Y3_CONV_SMALL") && !strcmp(getenv("Y3_CONV_SMALL"), "v2"));
-    if ((small_v3 || BNB) && var != 2 && a.Cout <= 64 && c32 && dma_ok) return launch_v3<T, 32, 1, 4, BNB>(a, st);   // 64c x 256p, wave 32c x 128p
-    if constexpr (BNB) {
-        Y3_FAIL("conv: the BatchNorm-backward statistics need an LDS-DMA kernel variant (Cin %% 32 == 0)");
+    // 32->64 s2 @640x640 and 0.44 -> 0.38 ms on 32->64 @320x320 (bs 32)
+    if (var != 2 && a.Cout <= 64 && c32) return launch_v3<T, 32, 1, 4>(a, st);   // 64c x 256p, wave 32c x 128p
+    // register-staged fallback: Cin % 32 != 0 (layer 0 when the stem kernel is not eligible)
+    if (a.Cout > 64) {
+        if (c64) return launch_igemm<T, 64, 2, 2, 2, 2, false>(a, st);
+        if (c32) return launch_igemm<T, 32, 2, 2, 2, 2, false>(a, st);
+        return launch_igemm<T, 32, 2, 2, 2, 2, true>(a, st);
+    } else if (a.Cout > 32) {
+        if (c64) return launch_igemm<T, 64, 1, 4, 2, 1, false>(a, st);
+        if (c32) return launch_igemm<T, 32, 1, 4, 2, 1, false>(a, st);
+        return launch_igemm<T, 32, 1, 4, 2, 1, true>(a, st);
     } else {
-        if (a.Cout > 64) {
-            if (c64) return launch_igemm<T, 64, 2, 2, 2, 2, false>(a, st);
-            if (c32) return launch_igemm<T, 32, 2, 2, 2, 2, false>(a, st);
-            return launch_igemm<T, 32, 2, 2, 2, 2, true>(a, st);
-        } else if (a.Cout > 32) {
-            if (c64) return launch_igemm<T, 64, 1, 4, 2, 1, false>(a, st);
-            if (c32) return launch_igemm<T, 32, 1, 4, 2, 1, false>(a, st);
-            return launch_igemm<T, 32, 1, 4, 2, 1, true>(a, st);
-        } else {
-            if (c64) return launch_igemm<T, 64, 1, 4, 1, 2, false>(a, st);
-            if (c32) return launch_igemm<T, 32, 1, 4, 1, 2, false>(a, st);
-            return launch_igemm<T, 32, 1, 4, 1, 2, true>(a, st);
-        }
+        if (c64) return launch_igemm<T, 64, 1, 4, 1, 2, false>(a, st);
+        if (c32) return launch_igemm<T, 32, 1, 4, 1, 2, false>(a, st);
+        return launch_igemm<T, 32, 1, 4, 1, 2, true>(a, st);
     }
 }
 
@@ -1238,17 +1020,8 @@ extern "C" int y3_pack_filter(const float* w, int32_t cout_src, int32_t cin_src,
     return 0;
 }
 
-// BatchNorm-backward statistics of a data-gradient launch (ConvArgs::bnb_*): the pre-BatchNorm tensor of the unit whose output gradient
-// this launch completes, and that unit's normalisation
-struct BnbHost {
-    const y3_tensor* u;
-    const float* scale;
-    const float* shift;
-    int act;
-};
-
 static int conv_fwd_impl(const y3_conv_desc* d, const y3_tensor* x, const void* filt, const float* bias, const y3_tensor* res, const y3_tensor* y, float* stats,
-                         int64_t stat_capacity_rows, int64_t* stat_rows, int dry, void* stream, void* ws = nullptr, size_t ws_bytes = 0, const BnbHost* bnb = nullptr) {
+                         int64_t stat_capacity_rows, int64_t* stat_rows, int dry, void* stream, void* ws = nullptr, size_t ws_bytes = 0) {
     if (!d || !x || !filt || !bias || !y) Y3_FAIL("y3_conv2d_fwd: null argument");
     if (d->ksize != 1 && d->ksize != 3) Y3_FAIL("y3_conv2d_fwd: ksize %d unsupported", d->ksize);
     if (d->stride != 1 && d->stride != 2) Y3_FAIL("y3_conv2d_fwd: stride %d unsupported", d->stride);
@@ -1305,14 +1078,6 @@ static int conv_fwd_impl(const y3_conv_desc* d, const y3_tensor* x, const void* 
         if (algo != Y3_ALGO_MFMA || d->dtype == Y3_F32) Y3_FAIL("y3_conv2d_fwd_stats: the epilogue statistics need the f16/bf16 MFMA path");
         if (d->upsample2x) Y3_FAIL("y3_conv2d_fwd_stats: upsample2x unsupported");
     }
-    if (bnb) {
-        if (!stat_rows) Y3_FAIL("y3_conv2d_fwd_bnb: null row count");
-        const y3_tensor* u = bnb->u;
-        if (!u || !bnb->scale || !bnb->shift) Y3_FAIL("y3_conv2d_fwd_bnb: null argument");
-        if (u->n != y->n || u->h != y->h || u->w != y->w || u->c != y->c) Y3_FAIL("y3_conv2d_fwd_bnb: u is (%d,%d,%d,%d), the gradient (%d,%d,%d,%d)", u->n, u->h, u->w, u->c, y->n, y->h, y->w, y->c);
-        if ((u->pitch % vec) || ((uintptr_t)u->data & 15)) Y3_FAIL("y3_conv2d_fwd_bnb: u must be 16-byte aligned with pitch %% %d == 0", vec);
-        if (bnb->act != Y3_ACT_NONE && bnb->act != Y3_ACT_SILU) Y3_FAIL("y3_conv2d_fwd_bnb: bad activation %d", bnb->act);
-    }
 
     // The MFMA kernels address every tensor through a buffer descriptor (bounds-checked loads are what makes halo / tail lanes free),
     // and a descriptor reaches 2^31 bytes.  Images are independent, so a batch whose input, output or residual exceeds that is run
@@ -1320,14 +1085,13 @@ static int conv_fwd_impl(const y3_conv_desc* d, const y3_tensor* x, const void* 
     // reference has no such limit (ATen indexes with 64 bits).
     const long long opx_img = (long long)Ho * Wo * (d->upsample2x ? 4 : 1);
     const long long img_x = (long long)x->h * x->w * x->pitch * esz, img_y = opx_img * y->pitch * esz, img_r = res ? opx_img * res->pitch * esz : 0;
-    const long long img_u = bnb ? opx_img * bnb->u->pitch * esz : 0;
     const long long LIM = 0x7fffffffLL - 65536;
     const long long wb = (long long)y3_filter_rows(d->cout) * a.Kpad * esz;
     if (wb >= LIM) Y3_FAIL("y3_conv2d_fwd: filter bank beyond 2 GiB");
     int chunk = x->n;
     if (algo == Y3_ALGO_MFMA) {
-        if (img_x >= LIM || img_y >= LIM || img_r >= LIM || img_u >= LIM) Y3_FAIL("y3_conv2d_fwd: one image exceeds the 2 GiB reach of a buffer descriptor");
-        while (chunk > 1 && ((long long)chunk * img_x >= LIM || (long long)chunk * img_y >= LIM || (long long)chunk * img_r >= LIM || (long long)chunk * img_u >= LIM))
+        if (img_x >= LIM || img_y >= LIM || img_r >= LIM) Y3_FAIL("y3_conv2d_fwd: one image exceeds the 2 GiB reach of a buffer descriptor");
+        while (chunk > 1 && ((long long)chunk * img_x >= LIM || (long long)chunk * img_y >= LIM || (long long)chunk * img_r >= LIM))
             chunk = (chunk + 1) / 2;
     }
     if (stat_rows) *stat_rows = 0;
@@ -1345,20 +1109,10 @@ static int conv_fwd_impl(const y3_conv_desc* d, const y3_tensor* x, const void* 
         c.w_bytes = (unsigned)wb;
         c.y_bytes = yb < 0x7fffffffLL ? (unsigned)yb : 0u;
         c.r_bytes = rb < 0x7fffffffLL ? (unsigned)rb : 0u;
-        if (bnb) {
-            const long long ub = (((long long)c.N * opx_img - 1) * bnb->u->pitch + bnb->u->c) * esz;
-            c.bnb_u = (const char*)bnb->u->data + (long long)n0 * img_u;
-            c.bnb_upitch = bnb->u->pitch;
-            c.bnb_ubytes = (unsigned)ub;
-            c.bnb_scale = bnb->scale;
-            c.bnb_shift = bnb->shift;
-            c.bnb_act = bnb->act;
-        }
         if (stat_rows) {   // BatchNorm statistics in the epilogue: a dry pass of the dispatcher decides the rows of this launch
             ConvArgs g = c;
             g.dry = 1;
-            const int rc = bnb ? (d->dtype == Y3_F16 ? dispatch_igemm<f16_t, true>(g, st) : dispatch_igemm<bf16_t, true>(g, st))
-                               : (d->dtype == Y3_F16 ? dispatch_igemm<f16_t>(g, st) : dispatch_igemm<bf16_t>(g, st));
+            const int rc = d->dtype == Y3_F16 ? dispatch_igemm<f16_t>(g, st) : dispatch_igemm<bf16_t>(g, st);
             if (rc) return rc;
             const int64_t rows = (int64_t)g.n_pt * g.stat_wp;
             *stat_rows += rows;
@@ -1370,8 +1124,7 @@ static int conv_fwd_impl(const y3_conv_desc* d, const y3_tensor* x, const void* 
         }
         int rc;
         if (algo == Y3_ALGO_MFMA) {
-            if (bnb) rc = d->dtype == Y3_F16 ? dispatch_igemm<f16_t, true>(c, st) : dispatch_igemm<bf16_t, true>(c, st);
-            else if (d->dtype == Y3_F16) rc = dispatch_igemm<f16_t>(c, st);
+            if (d->dtype == Y3_F16) rc = dispatch_igemm<f16_t>(c, st);
             else if (d->dtype == Y3_BF16) rc = dispatch_igemm<bf16_t>(c, st);
             else Y3_FAIL("y3_conv2d_fwd: MFMA path needs f16/bf16");
         } else {
@@ -1453,26 +1206,6 @@ extern "C" int y3_conv2d_fwd_stats_ws(const y3_conv_desc* d, const y3_tensor* x,
     if (!n_rows) Y3_FAIL("y3_conv2d_fwd_stats_ws: null row count");
     if (workspace && ((uintptr_t)workspace & 255)) Y3_FAIL("y3_conv2d_fwd_stats_ws: the workspace must be 256-byte aligned");
     return conv_fwd_impl(d, x, filt, bias, nullptr, y, stat_rows, capacity_rows, n_rows, 0, stream, workspace, workspace_bytes);
-}
-
-// A data-gradient convolution (y3_conv2d_fwd_ws on a y3_pack_filter_dgrad bank, residual = the gradient accumulated so far) that
-// COMPLETES the gradient dy of a tensor y = act(bn(u)): besides storing dy it writes, per (pixel tile, pixel wave), one row [cout][2]
-// fp32 of (sum g, sum g * u) with g = dy * act'(scale * u + shift) of the stored value -- the two reductions of the BatchNorm backward
-// without the pass over (dy, u) (y3_bn_bwd_finalize_rows sums the rows).  stat_rows == NULL: only *n_rows is filled (geometry query).
-extern "C" int y3_conv2d_fwd_bnb_ws(const y3_conv_desc* d, const y3_tensor* x, const void* filt, const float* bias, const y3_tensor* res, const y3_tensor* y,
-                                    const y3_tensor* u, const float* scale, const float* shift, int32_t act, float* stat_rows, int64_t capacity_rows, int64_t* n_rows,
-                                    void* workspace, size_t workspace_bytes, void* stream) {
-    if (!n_rows) Y3_FAIL("y3_conv2d_fwd_bnb_ws: null row count");
-    if (workspace && ((uintptr_t)workspace & 255)) Y3_FAIL("y3_conv2d_fwd_bnb_ws: the workspace must be 256-byte aligned");
-    alignas(256) static const float dummy[64] = {0.0f};   // geometry query: never dereferenced
-    const BnbHost b{u, stat_rows ? scale : dummy, stat_rows ? shift : dummy, act};
-    if (!stat_rows) {
-        y3_tensor uu;
-        if (!u && y) { uu = *y; uu.data = (void*)dummy; }
-        const BnbHost q{u ? u : &uu, dummy, dummy, act};
-        return conv_fwd_impl(d, x, (const void*)dummy, dummy, nullptr, y, nullptr, 0, n_rows, 1, nullptr, workspace_bytes ? (void*)dummy : nullptr, workspace_bytes, &q);
-    }
-    return conv_fwd_impl(d, x, filt, bias, res, y, stat_rows, capacity_rows, n_rows, 0, stream, workspace, workspace_bytes, &b);
 }
 
 
@@ -1589,8 +1322,8 @@ extern "C" int y3_conv2d_dgrad_s2(int32_t dtype, const y3_tensor* du, const void
             off += bank;
         }
     // all four classes in ONE launch when they share the geometry (even H and W) and the dispatcher picks a v3 tile for the class with
-    // the longest K loop (the 4-tap class: its variant suits the shorter ones); Y3_DGRAD_QUAD=0 keeps the four launches (A/B)
-    static const bool quad_on = [] { const char* e = getenv("Y3_DGRAD_QUAD"); return !(e && atoi(e) == 0); }();
+    // the longest K loop (the 4-tap class: its variant suits the shorter ones); knob "dgrad_quad" = 0 keeps the four launches (A/B)
+    const bool quad_on = y3_knob(Y3K_DGRAD_QUAD) != 0;
     bool quad = quad_on && live[0] && live[1] && live[2] && live[3] && cls[0].M == cls[3].M && cls[1].M == cls[3].M && cls[2].M == cls[3].M;
     if (quad) {
         int big = 0;

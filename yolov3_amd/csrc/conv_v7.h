@@ -4,7 +4,7 @@
 // (reference models/common.py:57-81 Conv inside Bottleneck.cv2, models/yolov3.yaml:23-31 and the 3x3 convs of the head) --
 // 24 of the 29 equal-FLOP 3x3 launches of a yolov3 forward, and the data gradients of the same layers.
 //
-// What v6 (conv_igemm_v5_kernel<SCHED 1>) left on the table at the BASELINE shapes (profiles/r01_*):
+// What v6 (conv_igemm_v6_kernel) left on the table at the BASELINE shapes (profiles/r01_*):
 //   (1) 200 / 400 / 800 tiles of 256x256 on 256 CUs: every launch pays for whole CU-rounds it fills to 78 %;
 //   (2) every one of the 9 taps re-stages the SAME input pixels (shifted by one row / column) from L2 into LDS: per 32-channel
 //       block 9 x 16 KiB of activations + 9 x 16 KiB of filters = 288 `buffer_load ... lds` pieces, and the MEM phase of a
@@ -23,7 +23,12 @@
 //     come from an atomic ticket and a consumer only waits for EARLIER tickets of its own group, i.e. for blocks that are already
 //     running and publish before anything else: no residency or dispatch-order assumption, no deadlock.
 //   * K-loop schedule = v6's: the two wave halves run one barrier interval apart (MEM of one half beside MMA of the other),
-//     4-stage filter ring, counted vmcnt, patch double-buffered per channel block.
+//     4-stage filter ring, counted vmcnt, patch double-buffered per channel block.  AHEAD = how many K-steps the filter requests run
+//     ahead of the MFMAs: 2 in round 2; 3 since round 3 (filter tile s + 3 lands in the stage of tile s - 1 -- see conv_igemm_v6_kernel
+//     for why every wave then completes its fragment reads before the barrier that ends its MEM phase).
+//   * a finisher whose producer never publishes (bounded spin: a hung or preempted block must not hang the GPU) sets ctl->error and
+//     POISONS its tile with NaN; the flag is sticky, so every later launch on that workspace writes NaN too until the owner calls
+//     y3_conv_workspace_reset -- a lost hand-off is loud, never a silently wrong sum (round-2 advisor finding).
 //
 // LDS: [4 x 16 KiB filter ring][2 x XP x 8 KiB patch][64 B zeros]; the epilogue re-uses [0, 128 KiB) as per-wave transpose slices.
 
@@ -46,23 +51,24 @@ template <typename F, int... Is> Y3_DEV void static_for_impl(F&& f, std::integer
 template <int N, typename F> Y3_DEV void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 Y3_DEV void wait_vm(int n) {   // n is wave-uniform; the immediate must be a literal
-    if (n >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    switch (n) {
+        case 0: wait_vmcnt<0>(); break;
+        case 1: wait_vmcnt<1>(); break;
+        case 2: wait_vmcnt<2>(); break;
+        case 3: wait_vmcnt<3>(); break;
+        case 4: wait_vmcnt<4>(); break;
+        case 5: wait_vmcnt<5>(); break;
+        default: wait_vmcnt<6>(); break;
+    }
 }
 
-// SCHED 0: the DMA requests of a K-step are issued at the head of the wave's MEM phase (v6's placement).
-// SCHED 1: they are issued BETWEEN the MFMAs of the MMA phase, one step further ahead (filter tile s + 3 during MMA(s)): a
-//          `buffer_load ... lds` costs 60-185 issue cycles, which made MEM (~800 cycles) longer than the 16 MFMAs (512) it hides behind;
-//          inside the MFMA stream the same requests fill issue slots the matrix pipe leaves free.
 #ifdef Y3_TIMELINE   // debug build (tools/v7_probe.py): per-wave cycle sums of the four intervals of a K-step
 #define V7_T(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tsum[i] += t_ - tprev; tprev = t_; } while (0)
 #else
 #define V7_T(i) do { } while (0)
 #endif
 
-template <typename T, int XP, int SCHED, bool BNB = false>
+template <typename T, int XP, int AHEAD>
 __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #ifdef Y3_TIMELINE
@@ -72,7 +78,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p)
     constexpr int PATCH_BYTES = XP * 8 * 1024;
     constexpr int PATCH_OFF = V7_RING;
     constexpr int ZOFF = (V7_RING + 2 * PATCH_BYTES) > 131072 ? (V7_RING + 2 * PATCH_BYTES) : 131072;
-    constexpr int LDS_BYTES = ZOFF + 64;
+    constexpr int LDS_BYTES = ZOFF + 128;   // [ZOFF, +64): the zero block of the edge taps; [ZOFF + 64, +128): block-wide broadcast words
     typedef typename Mfma<T>::frag frag;
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -93,9 +99,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p)
     // observed to place it on: speed only) and is block t / NG of that group.  A group owns a rectangle of whole tiles (see
     // below); inside a group the (tile, channel block) units are split evenly over its blocks.  Dependencies never cross groups
     // and only point at EARLIER tickets (see the item loop), so progress needs no residency assumption.
-    if (tid == 0) *(unsigned*)smem = atomicAdd(&ctl->ticket, 1u);
+    unsigned* bcast = (unsigned*)(smem + ZOFF + 64);
+    if (tid == 0) {
+        bcast[0] = atomicAdd(&ctl->ticket, 1u);
+        bcast[1] = __hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sticky: a lost hand-off of an EARLIER launch on this workspace
+    }
     __syncthreads();
-    const int ticket = __builtin_amdgcn_readfirstlane(*(const unsigned*)smem);
+    const int ticket = __builtin_amdgcn_readfirstlane(bcast[0]);
+    bool poisoned = __builtin_amdgcn_readfirstlane(bcast[1]) != 0u;   // this block writes its tiles as NaN
     __syncthreads();
     if (tid < 4) *(u32x4*)(smem + ZOFF + tid * 16) = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
@@ -199,8 +210,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p)
                 for (int b = 0; b < MP; ++b) acc[a][b] = Mfma<T>::run(af[a], bf[b], acc[a][b]);
         };
 
-        // ---- prologue: patch of the first channel block, filter tiles of the first 2 (SCHED 0) / 3 (SCHED 1) steps ----
-        const int nsteps = 9 * ncbs;
+        // ---- prologue: patch of the first channel block, filter tiles of the first AHEAD steps ----
         auto kbyte_of = [&](int step) {   // byte offset inside a packed filter row of K-step `step` of this item: k = tap * Cin + cb * 32
             const int cbi_ = step / 9, tap_ = step - cbi_ * 9;
             return (tap_ * p.Cin + (cb0 + cbi_) * 32) * 2;
@@ -209,12 +219,12 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p)
 #pragma unroll
         for (int j = 0; j < XP; ++j) dma_x(j, cb0, 0);
         dma_w(kbyte_of(0), 0);
-        dma_w(kbyte_of(1), 1);
-        if constexpr (SCHED == 1) {
-            dma_w(kbyte_of(2), 2);   // nsteps >= 9
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        dma_w(kbyte_of(1), 1);   // nsteps >= 9
+        if constexpr (AHEAD == 3) {
+            dma_w(kbyte_of(2), 2);
+            wait_vmcnt<4>();
         } else {
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            wait_vmcnt<2>();
         }
         __builtin_amdgcn_s_barrier();              // patch + filter tile 0 visible to everyone (and the zero block)
         if (half) __builtin_amdgcn_s_barrier();    // stagger
@@ -231,24 +241,22 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p)
                 constexpr int tap = decltype(TAP)::value;
                 constexpr int dh = tap / 3, dw = tap % 3;
                 constexpr int MASK = (dh == 0 ? 1 : dh == 2 ? 2 : 0) | (dw == 0 ? 4 : dw == 2 ? 8 : 0);
-                // ---- MEM(s): [SCHED 0: request patch piece / filter tile s + 2,] read the fragments of step s, retire this wave's pieces of step s + 1 ----
+                // ---- MEM(s): request a patch piece / filter tile s + AHEAD, read the fragments of step s, retire this wave's pieces of step s + 1 ----
                 int issued = 0;   // requests younger than filter tile s + 1: they may stay in flight
-                if constexpr (SCHED == 0) {
-                    if constexpr (tap >= 1 && tap <= XP) {
-                        if (more_cb) { dma_x(tap - 1, cb + 1, buf ^ 1); issued += 1; }
-                    }
-                    if (more_cb || tap + 2 < 9) {
-                        constexpr int tap2 = (tap + 2) % 9;
-                        const int cb2 = cb + (tap + 2 >= 9 ? 1 : 0);
-                        dma_w((tap2 * p.Cin + cb2 * 32) * 2, (s + 2) & 3);
-                        issued += 2;
-                    }
-                } else {
-                    // issued during MMA(s - 1): filter tile s + 2, and a patch piece when step s - 1 was one of the first XP taps of this channel block
-                    if (s + 2 < nsteps) issued += 2;
-                    if constexpr (tap >= 1 && tap <= XP) {
+                if constexpr (AHEAD == 3) {   // what MEM(s - 1) requested: filter tile s + 2 and, in taps 2 .. XP + 1 (same channel block), a patch piece
+                    if (more_cb || tap + 2 < 9) issued += 2;
+                    if constexpr (tap >= 2 && tap <= XP + 1) {
                         if (more_cb) issued += 1;
                     }
+                }
+                if constexpr (tap >= 1 && tap <= XP) {
+                    if (more_cb) { dma_x(tap - 1, cb + 1, buf ^ 1); issued += 1; }
+                }
+                if (more_cb || tap + AHEAD < 9) {
+                    constexpr int tapa = (tap + AHEAD) % 9;
+                    const int cba = cb + (tap + AHEAD >= 9 ? 1 : 0);
+                    dma_w((tapa * p.Cin + cba * 32) * 2, (s + AHEAD) & 3);
+                    issued += 2;
                 }
                 frag a0[MC], a1[MC], b0[MP], b1[MP];
                 {
@@ -279,41 +287,15 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p)
                 V7_T(0);   // MEM issue (requests + fragment reads issued, reads landed)
                 wait_vm(issued);
                 V7_T(1);   // vmcnt wait
+                if constexpr (AHEAD == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // stage (s - 1) & 3 is requested into by the other half right behind this barrier
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 V7_T(2);   // barrier after MEM
                 // ---- MMA(s) ----
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(1);
-                if constexpr (SCHED == 0) {
-                    mma(a0, b0);
-                    mma(a1, b1);
-                } else {
-                    // 4 groups of 4 MFMAs; the requests for step s + 3 (2 filter pieces) and, in the first XP taps, one piece of the next channel
-                    // block's patch go between the groups.  Stage (s + 3) & 3 held tile s - 1, whose last fragment reads retired two barriers ago.
-                    const bool more_w = s + 3 < nsteps;
-                    constexpr int tap3 = (tap + 3) % 9;
-                    const int kb3 = (tap3 * p.Cin + (cb + (tap + 3 >= 9 ? 1 : 0)) * 32) * 2;
-#pragma unroll
-                    for (int b = 0; b < MP; ++b) acc[0][b] = Mfma<T>::run(a0[0], b0[b], acc[0][b]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (more_w) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(smem + ((s + 3) & 3) * V7_W_STAGE + wv * 1024), 16, woff[0] + (unsigned)kb3, 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int b = 0; b < MP; ++b) acc[1][b] = Mfma<T>::run(a0[1], b0[b], acc[1][b]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (more_w) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(smem + ((s + 3) & 3) * V7_W_STAGE + (8 + wv) * 1024), 16, woff[1] + (unsigned)kb3, 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int b = 0; b < MP; ++b) acc[0][b] = Mfma<T>::run(a1[0], b1[b], acc[0][b]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (tap < XP) {
-                        if (more_cb) dma_x(tap, cb + 1, buf ^ 1);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int b = 0; b < MP; ++b) acc[1][b] = Mfma<T>::run(a1[1], b1[b], acc[1][b]);
-                }
+                mma(a0, b0);
+                mma(a1, b1);
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 V7_T(3);   // MMA issue (the last MFMAs may still be in the pipe)
@@ -332,15 +314,31 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p)
                 f32x16 part[MC][2];
 #pragma unroll
                 for (int a = 0; a < MC; ++a) { part[a][0] = r[a][2 * hb]; part[a][1] = r[a][2 * hb + 1]; }
-                epilogue_wave<T, MC, 2, BNB>(p, part, smem + wv * (2 * 32 * MC * 64), ct * 256 + wc * MC * 32, m0 + wp * 128 + hb * 64, lane, (pt * 2 + wp) * 2 + hb);
+                epilogue_wave<T, MC, 2>(p, part, smem + wv * (2 * 32 * MC * 64), ct * 256 + wc * MC * 32, m0 + wp * 128 + hb * 64, lane, (pt * 2 + wp) * 2 + hb);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();   // the slice is private to the wave: its reads of pass 0 precede the writes of pass 1
             }
             __syncthreads();   // the slices are free again before the next item's DMA lands
         };
 
+        // a hand-off was lost (now or in an earlier launch on this workspace): the tile goes out as NaN -- loud, not silently wrong.
+        // A plain store loop on the cold path: nothing of it is live across the K loop.
+        auto poison_tile = [&]() {
+            const int m = m0 + (tid >> 1);
+            if (m < p.M) {
+                int n, ho, wo;
+                pix_coords(m, p, n, ho, wo);
+                const long long o = out_pix(n, ho, wo, p);
+                const unsigned nan2 = sizeof(T) == 2 && std::is_same<T, f16_t>::value ? 0x7e007e00u : 0x7fc07fc0u;
+                const auto rsrc_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)p.y_bytes, 0x00020000);
+                for (int c = ct * 256 + (tid & 1) * 128, e = c + 128; c < e; c += 8)
+                    if (c + 8 <= p.Cout) __builtin_amdgcn_raw_buffer_store_b128(u32x4{nan2, nan2, nan2, nan2}, rsrc_y, (unsigned)((o * p.ypitch + c) * 2), 0, 0);
+            }
+            __syncthreads();
+        };
+
         if (cb0 == 0 && final_part) {
-            finish(acc);   // whole tile in one item: straight from the registers
+            if (poisoned) poison_tile(); else finish(acc);   // whole tile in one item: straight from the registers
         } else {
             // ---- a share of a tile: the fp32 partial goes to this block's slab (buffer stores with scalar offsets: 32 flat pointers per
             //      lane would cost 64 VGPRs) ----
@@ -377,18 +375,22 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p)
                     j_last = j;
                 }
                 if (tid == 0) {
-                    for (int j = ig - 1; j >= j_last; --j) {
+                    unsigned lost = 0u;
+                    for (int j = ig - 1; j >= j_last && !lost; --j) {
                         const int uj0 = (int)((long long)Ug * j / nblk), uj1 = (int)((long long)Ug * (j + 1) / nblk);
                         if (uj0 == uj1) continue;
                         unsigned spins = 0;
                         while (__hip_atomic_load(&flags[j * NG + xg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
                             __builtin_amdgcn_s_sleep(8);
-                            if (++spins > (1u << 22)) { ctl->error = 1u; break; }   // bounded: a lost producer must not hang the GPU
+                            if (++spins > (1u << 22)) { lost = 1u; break; }   // bounded: a lost producer must not hang the GPU
                         }
                     }
+                    if (lost) __hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sticky until y3_conv_workspace_reset
+                    bcast[2] = lost;
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 }
                 __syncthreads();
+                if (__builtin_amdgcn_readfirstlane(bcast[2]) != 0u) poisoned = true;   // the sum would be garbage: this tile and the block's remaining ones go out as NaN
                 f32x16 r[MC][MP];
 #pragma unroll
                 for (int a = 0; a < MC; ++a)
@@ -418,7 +420,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p)
                 __syncthreads();
                 if (tid == 0)
                     for (int j = ig - 1; j >= j_last; --j) __hip_atomic_store(&flags[j * NG + xg], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
-                finish(r);
+                if (poisoned) poison_tile(); else finish(r);
             }
         }
         hi = lo;
@@ -459,13 +461,12 @@ static int v7_xp(int W) {
 }
 
 static bool v7_eligible(const ConvArgs& a) {
-    const char* sw = getenv("Y3_CONV_V7");   // read per call: the lab / tests flip it inside one process
-    const bool off = sw && !strcmp(sw, "0");
-    if (off || a.ups || !a.ws || a.ws_bytes < V7_HDR_BYTES + 2 * V7_MAX_BLOCKS * V7_SLAB_BYTES) return false;
+    const int mode = (int)y3_knob(Y3K_CONV_V7);   // 1: where it measured ahead; 0: never; 2: every shape the kernel can run
+    if (mode == 0 || a.ups || !a.ws || a.ws_bytes < V7_HDR_BYTES + 2 * V7_MAX_BLOCKS * V7_SLAB_BYTES) return false;
     if (a.ks != 3 || a.stride != 1 || a.pad != 1 || a.dil_shift != 0 || a.ntaps != 9 || a.omul != 1 || a.ooh != 0 || a.oow != 0) return false;
     if (a.H != a.Ho || a.W != a.Wo || a.oH != a.Ho || a.oW != a.Wo) return false;
     if ((a.Cin % 32) != 0 || (a.Cout % 256) != 0 || v7_xp(a.W) == 0) return false;
-    if (a.Cin < 256 && !(sw && !strcmp(sw, "all"))) return false;   // K = 1152 (4 channel blocks per tile): the per-tile prologue / epilogue outweighs the faster main loop (169 vs 153 us @80x80)
+    if (a.Cin < 256 && mode != 2) return false;   // K = 1152 (4 channel blocks per tile): the per-tile prologue / epilogue outweighs the faster main loop (169 vs 153 us @80x80)
     if (!a.x_bytes || !a.w_bytes || !a.y_bytes || (a.res && !a.r_bytes)) return false;
     for (int t = 0; t < 9; ++t)
         if (a.tdh[t] != t / 3 || a.tdw[t] != t % 3) return false;
@@ -473,7 +474,7 @@ static bool v7_eligible(const ConvArgs& a) {
     return units >= 32 && units < 0x7fffffffLL;   // tiny problems stay on the one-tile-per-block kernels
 }
 
-template <typename T, bool BNB = false> int launch_v7(ConvArgs& a, hipStream_t st) {
+template <typename T> int launch_v7(ConvArgs& a, hipStream_t st) {
     a.n_ct = a.Cout / 256;
     a.n_pt = y3_ceil_div(a.M, 256);
     set_divisors(a);
@@ -502,10 +503,11 @@ template <typename T, bool BNB = false> int launch_v7(ConvArgs& a, hipStream_t s
             if (cost < best_cost) { best = gc; best_cost = cost; }
         }
         a.v7_gc = best;
-        if (const char* e = getenv("Y3_V7_GC")) { const int v = atoi(e); if (v >= 1 && v <= 8 && (8 % v) == 0 && (a.n_ct % v) == 0) a.v7_gc = v; }
+        const int v = (int)y3_knob(Y3K_V7_GC);
+        if (v >= 1 && v <= 8 && (8 % v) == 0 && (a.n_ct % v) == 0) a.v7_gc = v;
     }
-    if (const char* e = getenv("Y3_V7_GRID")) {   // A/B knob: N > 0 caps the grid; -1 = whole tiles; -2 = even K split (stream-K) whatever the tile count
-        const int g_env = atoi(e);
+    {   // knob "v7_grid": N > 0 caps the grid; -1 = whole tiles; -2 = even K split (stream-K) whatever the tile count
+        const long long g_env = y3_knob(Y3K_V7_GRID);
         if (g_env > 0 && g_env < g) g = g_env;
         if (g_env == -1) a.v7_whole = 1;
         if (g_env == -2) a.v7_whole = 0;
@@ -514,20 +516,14 @@ template <typename T, bool BNB = false> int launch_v7(ConvArgs& a, hipStream_t s
     //  leave a 26-tile group with 25 blocks and double the makespan -- measured 193 vs 115 us)
     const int xp = v7_xp(a.W);
     const dim3 grid((unsigned)g), block(512);
-    int sched = 0;   // SCHED 1 measured 2-6 % slower (profiles/r02_conv_v7.md); kept for A/B
-    if (const char* e = getenv("Y3_V7_SCHED")) sched = atoi(e);
-    if (BNB) {
-        if (xp == 3) hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 3, 0, BNB>), grid, block, 0, st, a);
-        else if (xp == 4) hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 4, 0, BNB>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 5, 0, BNB>), grid, block, 0, st, a);
-    } else if (sched == 0) {
-        if (xp == 3) hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 3, 0>), grid, block, 0, st, a);
-        else if (xp == 4) hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 4, 0>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 5, 0>), grid, block, 0, st, a);
+    if (y3_knob(Y3K_CONV_AHEAD) == 2) {
+        if (xp == 3) hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 3, 2>), grid, block, 0, st, a);
+        else if (xp == 4) hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 4, 2>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 5, 2>), grid, block, 0, st, a);
     } else {
-        if (xp == 3) hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 3, 1>), grid, block, 0, st, a);
-        else if (xp == 4) hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 4, 1>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 5, 1>), grid, block, 0, st, a);
+        if (xp == 3) hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 3, 3>), grid, block, 0, st, a);
+        else if (xp == 4) hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 4, 3>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 5, 3>), grid, block, 0, st, a);
     }
     Y3_CHECK_LAUNCH();
     return 0;

@@ -294,7 +294,7 @@ extern "C" int y3_spp_pyramid(const y3_tensor* x, const y3_tensor* y, int32_t dt
         const long long P = (long long)x->h * x->w;
         int CG = 4;
         while (CG > 1 && (vecs % CG || 2 * P * CG * 16 > 65536)) CG >>= 1;
-        static const bool direct = getenv("Y3_SPP") && !strcmp(getenv("Y3_SPP"), "direct");
+        const bool direct = y3_knob(Y3K_SPP_DIRECT) != 0;   // knob "spp_direct" (A/B: pools without the LDS pyramid)
         if (!direct && 2 * P * CG * 16 <= 65536 && (long long)x->n * (vecs / CG) < 0x7fffffffLL) {
             const size_t lds = (size_t)(2 * P * CG * 16);
             Y3_DISPATCH_FLOAT(dtype, hipLaunchKernelGGL((spp_lds_kernel<T>), dim3((unsigned)(x->n * (vecs / CG))), dim3(256), lds, (hipStream_t)stream, (const T*)x->data, x->h, x->w,

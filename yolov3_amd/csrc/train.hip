@@ -33,17 +33,9 @@ template <bool NT, typename T> Y3_DEV void stv(T* p, const V16<T>& v) {
     const y3_u32x4 r = __builtin_bit_cast(y3_u32x4, v);
     if (NT) __builtin_nontemporal_store(r, (y3_u32x4*)p); else *(y3_u32x4*)p = r;
 }
-constexpr long long Y3_NT_BYTES_DEFAULT = 128ll << 20;   // tensors at least this large take the non-temporal forms
-// Y3_BN_STREAM=0 restores the round-1 form of the elementwise passes (plain loads / stores, grid capped at 8192 blocks) for A/B runs
-static bool bn_stream_tuned() {
-    static const bool on = [] { const char* e = getenv("Y3_BN_STREAM"); return !(e && atoi(e) == 0); }();
-    return on;
-}
-static long long bn_nt_bytes() {   // Y3_BN_NT_MB=<n>: threshold in MiB (A/B runs)
-    static const long long v = [] { const char* e = getenv("Y3_BN_NT_MB"); return e ? (long long)atoll(e) << 20 : Y3_NT_BYTES_DEFAULT; }();
-    return v;
-}
-#define Y3_NT_BYTES (bn_stream_tuned() ? bn_nt_bytes() : (1ll << 62))
+// tensors at least this large take the non-temporal forms of the elementwise passes (knob "bn_nt_bytes", default 128 MiB: below the
+// Infinity-Cache size the plain forms win, profiles/r02_bn_lab_sweep*.txt); the tests lower it to run the forms on small tensors
+#define Y3_NT_BYTES y3_knob(Y3K_BN_NT_BYTES)
 
 Y3_DEV float silu_grad(float z, float s) { return s + z * s * (1.0f - s); }  // d silu(z)/dz with s = sigmoid(z)
 
@@ -184,8 +176,6 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(const T* __restrict
 // The consumers of the totals ride along (one launch instead of two or three ~5 us launches per conv unit and pass):
 //   MODE 1: + BatchNorm finalize (mean / biased var -> scale, shift, running statistics) for the block's 8 channels
 //   MODE 2: + (dbeta, dgamma) of the BN backward        MODE 3: + fp32 copy of the even entries (bias gradient)
-//   MODE 4: the rows are (sum g, sum g*u) from a data-gradient epilogue (conv.hip, BNB): totals = (sum g, invstd * (sum g*u - mean * sum g))
-//           = (sum g, sum g*xhat) go to `totals` (what bn_act_bwd_apply_kernel reads) + (dbeta, dgamma); f.mean / f.invstd are inputs
 struct BnFinalizeArgs {
     double count;
     const float* gamma;
@@ -214,7 +204,7 @@ Y3_DEV void bn_finalize_channel(int c, double s0, double s1, const BnFinalizeArg
 // TIN = double: rows 1.. of `sums` (the reduction kernels' partial rows); TIN = float: the rows the conv epilogue wrote (`part`)
 template <int MODE, typename TIN = double>
 __global__ __launch_bounds__(256) void reduce_partials_kernel(double* __restrict__ sums, int n2c, int nblocks, BnFinalizeArgs f, float* __restrict__ o0, float* __restrict__ o1,
-                                                                int c_out, const TIN* __restrict__ part = nullptr, double* __restrict__ totals = nullptr) {
+                                                                int c_out, const TIN* __restrict__ part = nullptr) {
     __shared__ double red[256];
     const int j = blockIdx.x * 16 + (threadIdx.x & 15);
     const int rl = threadIdx.x >> 4;
@@ -241,7 +231,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(double* __restrict
         __syncthreads();
     }
     if (rl == 0 && j < n2c) {
-        if (MODE != 4) sums[j] = red[threadIdx.x];
+        sums[j] = red[threadIdx.x];
         if (MODE != 0 && (j & 1) == 0) {   // entries (2c, 2c+1) of channel c sit in neighbouring lanes of row-lane 0
             const int c = j >> 1;
             const double s0 = red[threadIdx.x], s1 = red[threadIdx.x + 1];
@@ -254,15 +244,6 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(double* __restrict
                 if (f.count > 0.0) { sums[n2c + j] = s0 / f.count; sums[n2c + j + 1] = s1 / f.count; }
             }
             if (MODE == 3) { if (c < c_out) o0[c] = (float)s0; }
-            if (MODE == 4) {
-                const double sx = (double)f.invstd[c] * (s1 - (double)f.mean[c] * s0);
-                totals[j] = s0;
-                totals[j + 1] = sx;
-                totals[n2c + j] = s0 / f.count;       // means, as the apply pass reads them
-                totals[n2c + j + 1] = sx / f.count;
-                if (o0) o0[c] = (float)s0;
-                if (o1) o1[c] = (float)sx;
-            }
         }
     }
 }
@@ -426,165 +407,6 @@ Y3_DEV void wgrad_block(int xcd_group, int& tile, int& slice) {
     tile = r / w;
 }
 
-
-Y3_DEV unsigned pack_lo(unsigned a, unsigned b) { return (a & 0xffffu) | (b << 16); }
-Y3_DEV unsigned pack_hi(unsigned a, unsigned b) { return (a >> 16) | (b & 0xffff0000u); }
-
-template <typename T>
-__global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(const WgradArgs p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    // K-step = 64 pixels.  LDS rows: 64 pixels = 128 B padded to 144 B (36 dwords: conflict-free ds_read_b128 fragment
-    // reads for the MFMA lane groups; the transposed ds_write_b64 of a 16-lane group covers one whole row).
-    constexpr int BKP = 64, PITCH = 144, TILE = 128 * PITCH, STAGE = 2 * TILE;
-    typedef typename std::conditional<std::is_same<T, f16_t>::value, f16x8, bf16x8>::type frag;
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wc = wv >> 1, wn = wv & 1;
-    int tile_id, slice_id;
-    wgrad_block(p.xcd_group, tile_id, slice_id);
-    const int ct = tile_id / p.n_nt, nt = tile_id % p.n_nt;
-    const long long m_begin = (long long)slice_id * p.per_slice;
-    long long m_end = m_begin + p.per_slice;
-    if (m_end > p.M) m_end = p.M;
-    if (m_begin >= m_end) return;
-
-    const bool is_b = tid >= 128;           // waves 0-1 stage du (A), waves 2-3 stage x (B): wave-uniform
-    const int t = tid & 127;
-    const int pq = t & 15, g8 = t >> 4;     // pixel quad (16 x 4 = 64 pixels), 8-channel group 0..7 (+8 on the 2nd pass)
-    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
-    const auto rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)p.du, 0, (int)p.du_bytes, 0x00020000);
-    constexpr unsigned OOB = 0xffffffffu;
-
-    int kh[2] = {0, 0}, kw[2] = {0, 0}, ch0[2];
-    bool colok[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int g = g8 + 8 * j;
-        if (!is_b) {
-            ch0[j] = ct * 128 + g * 8;
-            colok[j] = ch0[j] < p.Cout;
-        } else {
-            const int n = nt * 128 + g * 8;
-            const int tap = n / p.Cin;
-            ch0[j] = n - tap * p.Cin;
-            kh[j] = tap / p.ks;
-            kw[j] = tap - kh[j] * p.ks;
-            colok[j] = tap < p.ks * p.ks;
-        }
-    }
-    long long m0 = m_begin + 4 * pq;
-    int img = (int)(m0 / ((long long)p.Ho * p.Wo));
-    int rem = (int)(m0 - (long long)img * p.Ho * p.Wo);
-    int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-
-    auto fetch = [&](u32x4 (&r)[2][4]) {
-        int h = ho, w = wo, n = img;
-        long long m = m0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool live = m < m_end;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                unsigned off = OOB;
-                if (live && colok[j]) {
-                    if (!is_b) {
-                        off = (unsigned)((m * p.dpitch + ch0[j]) * 2);
-                    } else {
-                        const int hi = h * p.stride - p.pad + kh[j], wi = w * p.stride - p.pad + kw[j];
-                        if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) off = (unsigned)((((long long)(n * p.H + hi) * p.W + wi) * p.xpitch + ch0[j]) * 2);
-                    }
-                }
-                r[j][i] = is_b ? __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0) : __builtin_amdgcn_raw_buffer_load_b128(rs_d, off, 0, 0);
-            }
-            ++m;
-            if (++w == p.Wo) { w = 0; if (++h == p.Ho) { h = 0; ++n; } }
-        }
-        // advance the cursor by one K-step
-        m0 += BKP;
-        wo += BKP;
-        while (wo >= p.Wo) { wo -= p.Wo; if (++ho == p.Ho) { ho = 0; ++img; } }
-    };
-    auto stash = [&](int stage, const u32x4 (&r)[2][4]) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            unsigned char* base = smem + stage * STAGE + (is_b ? TILE : 0) + ((g8 + 8 * j) * 8) * PITCH + pq * 8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int wd = e >> 1;
-                uint2 v;
-                if (e & 1) { v.x = pack_hi(r[j][0][wd], r[j][1][wd]); v.y = pack_hi(r[j][2][wd], r[j][3][wd]); }
-                else { v.x = pack_lo(r[j][0][wd], r[j][1][wd]); v.y = pack_lo(r[j][2][wd], r[j][3][wd]); }
-                *(uint2*)(base + e * PITCH) = v;
-            }
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.0f;
-    const int frow = lane & 31, fk = lane >> 5;
-    auto compute = [&](int stage) {
-        const unsigned char* al = smem + stage * STAGE;
-        const unsigned char* bl = al + TILE;
-#pragma unroll
-        for (int kk = 0; kk < BKP / 16; ++kk) {
-            frag af[2], bf[2];
-#pragma unroll
-            for (int a = 0; a < 2; ++a) af[a] = *(const frag*)(al + ((wc * 2 + a) * 32 + frow) * PITCH + (kk * 2 + fk) * 16);
-#pragma unroll
-            for (int b = 0; b < 2; ++b) bf[b] = *(const frag*)(bl + ((wn * 2 + b) * 32 + frow) * PITCH + (kk * 2 + fk) * 16);
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    if constexpr (std::is_same<T, f16_t>::value) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
-                    else acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
-                }
-        }
-    };
-
-    // two register sets: while step s is multiplied out of LDS, step s+1 sits in registers and step s+2 is in flight
-    const int steps = (int)((m_end - m_begin + BKP - 1) / BKP);
-    u32x4 ra[2][4], rb[2][4];
-    fetch(ra);
-    fetch(rb);
-    stash(0, ra);
-    __syncthreads();
-    for (int it = 0; it < steps; it += 2) {
-        fetch(ra);            // step it+2 (cursor already past m_end -> all lanes OOB -> zeros, no traffic)
-        compute(0);
-        stash(1, rb);         // step it+1
-        __syncthreads();
-        if (it + 1 >= steps) break;
-        fetch(rb);            // step it+3
-        compute(1);
-        stash(0, ra);         // step it+2
-        __syncthreads();
-    }
-
-    // D[row = co][col = n] -> partial tile [n][co] (each lane owns 4 consecutive co: one 16-byte store)
-    float* tile = p.part + ((size_t)slice_id * gridDim.x + tile_id) * (128 * 128);
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int nl = (wn * 2 + b) * 32 + frow;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col = (wc * 2 + a) * 32 + 8 * g + 4 * fk;
-                f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
-                *(f32x4*)(tile + nl * 128 + col) = v;
-            }
-    }
-#endif
-}
-
 // Transposing LDS read as inline asm.  Through the builtin the compiler treats the read as possibly aliasing every pending
 // `buffer_load ... lds` and puts `s_waitcnt vmcnt(0)` in front of the first fragment read of each K-step: the tile requested a
 // moment earlier is then awaited before any MFMA is issued (no load/compute overlap inside a wave -- seen in the ISA of the
@@ -603,11 +425,11 @@ template <typename F> Y3_DEV void lds_wait6(F& a, F& b, F& c, F& d, F& e, F& f) 
 }
 
 // ---- wgrad, LDS-DMA + transposing LDS reads (gfx950 ds_read_b64_tr_b16) -------------------------------------------------
-// Same GEMM and tiling as wgrad_mfma_kernel (128 filters x 128 (tap, channel) columns per block, K-step = 64 pixels,
-// partial tiles per pixel slice), but the operands are staged in their NATURAL layout: a K-step of du is 64 rows of 128
+// 128 filters x 128 (tap, channel) columns per block, K-step = 64 pixels, partial tiles per pixel slice; the operands are staged in
+// their NATURAL layout: a K-step of du is 64 rows of 128
 // filters, a K-step of the im2col'd x is 64 rows of 128 columns, both pixel-major exactly as NHWC stores them, so
 // `buffer_load ... lds` fills the stage buffers directly (no VGPR round trip, no 32 pack + 16 ds_write_b64 per thread and
-// K-step as in the register-transposing kernel above).  The MFMA wants the pixel (= reduction) index contiguous per lane:
+// K-step as in the register-transposing kernel of round 1, removed in round 3).  The MFMA wants the pixel (= reduction) index contiguous per lane:
 // ds_read_b64_tr_b16 delivers exactly that -- a 16-lane group reads a [4 pixels][16 channels] block and lane i gets
 // channel i's 4 pixels; two such reads make one 8-k fragment.  Bank conflicts are avoided with an XOR on the 16-byte slot
 // index, physical = logical ^ 4 (row & 3), applied on the DMA source side (the 4 rows of a read group land on 4
@@ -1417,7 +1239,7 @@ static int elementwise_geometry(int C, int esz, long long M, unsigned& grid) {
     if (CG > 256) Y3_FAIL("channel count %d too large (max %d)", C, 256 * V);
     const int PL = 256 / CG;
     long long g = (M + (long long)PL * 4 - 1) / ((long long)PL * 4);
-    const long long cap = bn_stream_tuned() ? (1ll << 20) : 8192;
+    const long long cap = 1ll << 20;
     if (g > cap) g = cap;
     if (g < 1) g = 1;
     grid = (unsigned)g;
@@ -1575,52 +1397,6 @@ extern "C" int y3_bn_act_bwd_res(const y3_tensor* u, const y3_tensor* dy, const 
     return bn_act_bwd_impl(u, dy, scale, shift, mean, invstd, dtype, act, sums, du, dgamma, dbeta, gres, gres_accumulate, stream);
 }
 
-// BatchNorm backward whose two reductions came out of the data-gradient launch that completed dy (y3_conv2d_fwd_bnb_ws, conv.hip):
-// (1) fixed-order fp64 sum of the (sum g, sum g*u) rows -> `totals` [C][2] = (sum g, sum g*xhat), dbeta, dgamma;
-// (2) the apply pass alone.  Replaces the reduction pass of y3_bn_act_bwd over (dy, u).
-extern "C" int y3_bn_bwd_finalize_rows(const float* stat_rows, int64_t n_rows, int64_t count, int32_t C, double* sums, const float* mean, const float* invstd,
-                                       double* totals, float* dgamma, float* dbeta, void* stream) {
-    if (!stat_rows || !sums || !mean || !invstd || !totals || n_rows <= 0 || n_rows > 0x7fffffffLL || C <= 0 || count <= 0) Y3_FAIL("y3_bn_bwd_finalize_rows: bad argument");
-    BnFinalizeArgs f{};
-    f.count = (double)count;
-    f.mean = const_cast<float*>(mean);      // MODE 4 only reads them
-    f.invstd = const_cast<float*>(invstd);
-    hipStream_t st = (hipStream_t)stream;
-    if (n_rows > Y3_BN_PARTIAL_ROWS) {   // `sums` is a Y3_BN_SCRATCH_DOUBLES(C) buffer: two levels through its partial rows
-        const int per = (int)((n_rows + Y3_BN_PARTIAL_ROWS - 1) / Y3_BN_PARTIAL_ROWS);
-        const int blocks = (int)((n_rows + per - 1) / per);
-        hipLaunchKernelGGL(stat_rows_to_partials_kernel, dim3((unsigned)blocks), dim3(256), 0, st, stat_rows, (long long)n_rows, 2 * C, per, sums);
-        Y3_CHECK_LAUNCH();
-        hipLaunchKernelGGL((reduce_partials_kernel<4, double>), dim3((2 * C + 15) / 16), dim3(256), 0, st, sums, 2 * C, blocks, f, dbeta, dgamma, 0, (const double*)nullptr, totals);
-    } else {
-        hipLaunchKernelGGL((reduce_partials_kernel<4, float>), dim3((2 * C + 15) / 16), dim3(256), 0, st, sums, 2 * C, (int)n_rows, f, dbeta, dgamma, 0, stat_rows, totals);
-    }
-    Y3_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int y3_bn_act_bwd_apply(const y3_tensor* u, const y3_tensor* dy, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t dtype,
-                                   int32_t act, const double* totals, const y3_tensor* du, const y3_tensor* gres, int32_t gres_accumulate, void* stream) {
-    if (!u || !dy || !scale || !shift || !mean || !invstd || !totals || !du) Y3_FAIL("y3_bn_act_bwd_apply: null argument");
-    if (dy->n != u->n || dy->h != u->h || dy->w != u->w || dy->c != u->c || du->c != u->c || du->h != u->h) Y3_FAIL("y3_bn_act_bwd_apply: shape mismatch");
-    const int esz = esize(dtype);
-    if (!vec_ok(u, esz) || !vec_ok(dy, esz) || !vec_ok(du, esz)) Y3_FAIL("y3_bn_act_bwd_apply: alignment");
-    if (gres && (gres->n != u->n || gres->h != u->h || gres->w != u->w || gres->c != u->c || !vec_ok(gres, esz))) Y3_FAIL("y3_bn_act_bwd_apply: residual gradient shape / alignment");
-    if (gres && gres->data == dy->data) Y3_FAIL("y3_bn_act_bwd_apply: the residual gradient must not alias dy");
-    const long long M = (long long)u->n * u->h * u->w;
-    hipStream_t st = (hipStream_t)stream;
-    unsigned egrid;
-    if (elementwise_geometry(u->c, esz, M, egrid)) return -1;
-    const bool nt = M * u->c * esz >= Y3_NT_BYTES;
-#define Y3_BN_APPLY(SILU, NT) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, SILU, NT>), dim3(egrid), dim3(256), 0, st, (const T*)u->data, u->pitch, (const T*)dy->data, \
-                                            dy->pitch, scale, shift, mean, invstd, totals + 2 * u->c, (T*)du->data, du->pitch, M, u->c, \
-                                            gres ? (T*)gres->data : (T*)nullptr, gres ? gres->pitch : 0, gres_accumulate)
-    Y3_DISPATCH_T(dtype, if (act == Y3_ACT_SILU) { if (nt) Y3_BN_APPLY(true, true); else Y3_BN_APPLY(true, false); } else { if (nt) Y3_BN_APPLY(false, true); else Y3_BN_APPLY(false, false); });
-#undef Y3_BN_APPLY
-    Y3_CHECK_LAUNCH();
-    return 0;
-}
-
 // Layer 0 (no data gradient): BatchNorm + activation backward and the filter gradient without materialising du.
 // Pass 1 = the reduction of y3_bn_act_bwd (totals, dgamma, dbeta); pass 2 = stem_bn_bwd_wgrad_kernel + the block-order sum.
 extern "C" size_t y3_stem_bn_bwd_wgrad_workspace_bytes(void) { return (size_t)1024 * 1024 * sizeof(float); }
@@ -1718,23 +1494,12 @@ extern "C" int y3_pack_filter_jobs(const y3_pack_job* jobs_device, int32_t n_job
     return 0;
 }
 
-// Y3_WGRAD=regs|dma: force the 128x128 kernels; =big: the 256x256 kernel whenever the shape allows it (tests); default: per shape
-static int wgrad_mode() {
-    static const int v = [] {
-        const char* e = getenv("Y3_WGRAD");
-        if (!e) return 0;
-        if (!strcmp(e, "regs")) return 1;
-        if (!strcmp(e, "dma")) return 2;
-        if (!strcmp(e, "big")) return 3;
-        if (!strcmp(e, "direct")) return 4;
-        return 0;
-    }();
-    return v;
-}
+// knob "wgrad": 0 per shape; 2 the 128x128 kernel; 3 the 256x256 kernel whenever the shape allows it (tests); 4 the direct fp32 kernel
+static int wgrad_mode() { return (int)y3_knob(Y3K_WGRAD); }
 // 256x256 tiles (one 8-wave block per CU): whole 256-filter tiles, a long reduction and enough columns to fill the tile
 static bool wgrad_use_big(const y3_conv_desc* d, long long M) {
     const int mode = wgrad_mode();
-    if (d->dtype == Y3_F32 || mode == 1 || mode == 2 || mode == 4) return false;
+    if (d->dtype == Y3_F32 || mode == 2 || mode == 4) return false;
     const bool shape_ok = (d->cout % 256) == 0 && d->ksize * d->ksize * d->cin >= 1024 && M >= 256;
     if (mode == 3) return shape_ok;
     return shape_ok && d->ksize * d->ksize * d->cin >= 1152 && M >= 16384;
@@ -1818,16 +1583,13 @@ extern "C" int y3_conv2d_wgrad(const y3_conv_desc* d, const y3_tensor* x, const 
         const dim3 grid((unsigned)tiles, (unsigned)slices);
         // wgrad_block: a slice's tiles back to back on one XCD.  Measured at batch 64 (profiles/r02_wgrad_xcd.txt): 64 -> 128 layers 0.60 -> 0.48 and
         // 0.52 -> 0.45 ms, the 256-tile kernel slightly better, but the narrow (<= 64-filter, 3 column tiles) launches of the 320x320 maps lose
-        // 10-15 %, so those keep the dispatch order.  Y3_WGRAD_XCD=0: never; 1: 128-tile kernels only; 2 (default): + the 256-tile kernel; 3: all
-        static const int xcd_mode = [] { const char* e = getenv("Y3_WGRAD_XCD"); return e ? atoi(e) : 2; }();
+        // 10-15 %, so those keep the dispatch order.  Knob "wgrad_xcd" = 0: never; 1: 128-tile kernels only; 2 (default): + the 256-tile kernel; 3: all
+        const int xcd_mode = (int)y3_knob(Y3K_WGRAD_XCD);
         const bool narrow = tsh == 7 && d->cout <= 64;
         a.xcd_group = (tiles > 1 && slices > 1 && (narrow ? xcd_mode >= 3 : (tsh == 8 ? xcd_mode >= 2 : xcd_mode >= 1))) ? 1 : 0;
         if (tsh == 8) {
             if (d->dtype == Y3_F16) hipLaunchKernelGGL((wgrad_big_kernel<f16_t>), grid, dim3(512), 0, st, a);
             else hipLaunchKernelGGL((wgrad_big_kernel<bf16_t>), grid, dim3(512), 0, st, a);
-        } else if (wgrad_mode() == 1) {   // A/B: the register-transposing kernel
-            if (d->dtype == Y3_F16) hipLaunchKernelGGL((wgrad_mfma_kernel<f16_t>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((wgrad_mfma_kernel<bf16_t>), grid, dim3(256), 0, st, a);
         } else {
             const int co32 = d->cout <= 32 ? 1 : (d->cout <= 64 ? 2 : 4);   // narrow filter tiles for the <= 64-filter layers (one filter tile, n_ct == 1)
             if (d->dtype == Y3_F16) {
@@ -1841,8 +1603,7 @@ extern "C" int y3_conv2d_wgrad(const y3_conv_desc* d, const y3_tensor* x, const 
             }
         }
         Y3_CHECK_LAUNCH();
-        static const bool reduce4 = [] { const char* e = getenv("Y3_WGRAD_REDUCE"); return !(e && !strcmp(e, "1")); }();   // Y3_WGRAD_REDUCE=1: the one-element kernel (A/B)
-        if (reduce4 && (((uintptr_t)workspace) & 15) == 0)
+        if ((((uintptr_t)workspace) & 15) == 0)   // (the one-element kernel serves workspaces that are not 16-byte aligned)
             hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(nblk((tiles << (2 * tsh)) / 4)), dim3(256), 0, st, (const float*)workspace, (int)tiles, a.n_nt, (int)slices, d->cin, d->ksize,
                                cin_real, cout_real, dw_oihw, tsh);
         else

@@ -32,6 +32,22 @@ def stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def tune_set(key: str, value: int):
+    """run-time knob of the library (y3_tune_set: A/B hooks, test coverage of size-gated forms); process-wide"""
+    check(_lib.lib().y3_tune_set(key.encode(), int(value)), "y3_tune_set")
+
+
+def tune_get(key: str) -> int:
+    v = _lib.lib().y3_tune_get(key.encode())
+    if v == -(2**63):
+        raise _lib.Y3Error(_lib.lib().y3_last_error().decode(errors="replace"))
+    return int(v)
+
+
+def tune_reset():
+    _lib.lib().y3_tune_reset()
+
+
 @dataclass
 class View:
     """NHWC view: channels [coff, coff+c) of a (n, h, w, pitch) buffer."""
@@ -369,24 +385,6 @@ def conv2d_stats(x: View, filt: torch.Tensor, bias: torch.Tensor, y: View, k: in
         return int(n.value)
     check(_lib.lib().y3_conv2d_fwd_stats(C.byref(d), C.byref(xt), filt.data_ptr(), bias.data_ptr(), C.byref(yt), stat_rows.data_ptr(), int(capacity_rows), C.byref(n), stream_ptr()),
           "y3_conv2d_fwd_stats")
-    return int(n.value)
-
-
-def conv2d_bnb(x: View, filt: torch.Tensor, bias: torch.Tensor, y: View, k: int, residual: View | None, in_dilation: int, u: View, scale: torch.Tensor,
-               shift: torch.Tensor, act: int, stat_rows: torch.Tensor | None, capacity_rows: int, workspace: torch.Tensor | None = None) -> int:
-    """The data-gradient conv2d(x, filt) -> y (+ residual) that completes the gradient of a tensor act(bn(u)), with the BatchNorm
-    backward's (sum g, sum g*u) rows written by its epilogue (y3_conv2d_fwd_bnb_ws).  stat_rows None: rows the launch would write."""
-    d = Y3ConvDesc(dtype_code(x.buf.dtype), k, 1, _lib.Y3_ACT_NONE, 0, _lib.Y3_ALGO_AUTO, x.c, y.c, in_dilation)
-    xt, yt, ut = x.y3(), y.y3(), u.y3()
-    rt = residual.y3() if residual is not None else None
-    n = C.c_int64(0)
-    check(
-        _lib.lib().y3_conv2d_fwd_bnb_ws(C.byref(d), C.byref(xt), filt.data_ptr() if filt is not None else None, bias.data_ptr() if bias is not None else None,
-                                        C.byref(rt) if rt is not None else None, C.byref(yt), C.byref(ut), scale.data_ptr(), shift.data_ptr(), int(act),
-                                        stat_rows.data_ptr() if stat_rows is not None else None, int(capacity_rows), C.byref(n),
-                                        workspace.data_ptr() if workspace is not None else None, workspace.numel() if workspace is not None else 0, stream_ptr()),
-        "y3_conv2d_fwd_bnb_ws",
-    )
     return int(n.value)
 
 

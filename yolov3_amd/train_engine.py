@@ -103,26 +103,11 @@ class ConvUnit(_Unit):
         self.filt_d = None
         # the data gradient of this unit runs through the generic dgrad bank (not the stride-2 parity-class banks, not layer 0)
         self.pair_pack = need_dx and plan.dtype in (torch.float16, torch.bfloat16) and not (self.s == 2 and self.k == 3)
-        # BatchNorm-backward reductions taken in the epilogue of the data gradient that completes y's gradient (TrainPlan._plan_bnb):
         self.bank_fwd = self.bank_dgrad = None   # persistent filter banks filled by the plan's one-launch packing (TrainPlan.pack_jobs)
-        self.bnb_target = None   # the ConvUnit whose output gradient THIS unit's data gradient completes (its y is our x)
-        self.bnb_totals = None   # our own (sum g, sum g*xhat) totals, filled by whoever completes our y's gradient
-        self.bnb_done = False
-        self.bnb_rows = None
 
     def generic_dgrad(self) -> bool:
         """the data gradient runs as ONE launch of the forward conv kernels on the flipped bank (not the stride-2 parity classes)"""
         return self.need_dx and not (self.s == 2 and self.k == 3 and self.plan.dtype != torch.float32)
-
-    def bnb_finalize(self, grads, rows: torch.Tensor, n_rows: int):
-        """rows of (sum g, sum g*u) written by the launch that completed y's gradient -> totals, dgamma, dbeta (one small launch)"""
-        dgamma = self.plan.grad_alloc((self.cout,))
-        dbeta = self.plan.grad_alloc((self.cout,))
-        check(_lib.lib().y3_bn_bwd_finalize_rows(rows.data_ptr(), n_rows, self.count, self.cout, self.sums.data_ptr(), self.mean.data_ptr(), self.invstd.data_ptr(),
-                                                 self.bnb_totals.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ops.stream_ptr()), "y3_bn_bwd_finalize_rows")
-        grads[self.m.bn.weight] = dgamma
-        grads[self.m.bn.bias] = dbeta
-        self.bnb_done = True
 
     def fused_stem_bwd(self) -> bool:
         """layer 0 through y3_stem_bn_bwd_wgrad (Y3_STEM_BWD=0: BatchNorm backward + generic filter gradient, for A/B runs)"""
@@ -196,9 +181,8 @@ class ConvUnit(_Unit):
         st = ops.stream_ptr()
         dcode = ops.dtype_code(self.plan.dtype)
         gy = self.y.grad()
-        if not self.bnb_done:   # (with the reductions from a data-gradient epilogue dgamma / dbeta were allocated and handed over there)
-            dgamma = self.plan.grad_alloc((self.cout,))
-            dbeta = self.plan.grad_alloc((self.cout,))
+        dgamma = self.plan.grad_alloc((self.cout,))
+        dbeta = self.plan.grad_alloc((self.cout,))
         if self.fused_stem_bwd():
             # layer 0: no data gradient, so du has one consumer -- the filter gradient; both in one pass over (u, dy), du never stored
             xi = self.plan.x_nchw
@@ -212,23 +196,6 @@ class ConvUnit(_Unit):
             return
         du = self.plan.scratch_like(self.u)
         ut, gt, dt = self.u.y3(), gy.y3(), du.y3()
-        if self.bnb_done:
-            # the reductions (and dgamma / dbeta) came out of the data gradient that completed gy: only the apply pass is left
-            self.bnb_done = False
-            grt = None
-            if self.res is not None:
-                gr = self.res.grad()
-                grt = gr.y3()
-            check(
-                L.y3_bn_act_bwd_apply(C.byref(ut), C.byref(gt), self.scale.data_ptr(), self.shift.data_ptr(), self.mean.data_ptr(), self.invstd.data_ptr(), dcode, self.act,
-                                      self.bnb_totals.data_ptr(), C.byref(dt), C.byref(grt) if grt is not None else None, int(self.res.is_ready()) if self.res is not None else 0, st),
-                "y3_bn_act_bwd_apply",
-            )
-            if self.res is not None:
-                self.res.mark_ready()
-            self.plan.wgrad(grads, m.conv.weight, None, self.x.view, du, self.k, self.s, self.co_real, self.ci_real)
-            self._dgrad(du, grads)
-            return
         if self.res is not None:  # out = act(bn(conv)) + res  ->  d res (+)= d out, written by the pass that reads d out anyway
             gr = self.res.grad()
             grt = gr.y3()
@@ -262,11 +229,7 @@ class ConvUnit(_Unit):
                 filt_d = ops.pack_filter_dgrad(m.conv.weight, self.cout, self.cin, self.plan.dtype)
             zb = self.plan.zeros_f32(self.cin)
             res = gx if self.x.is_ready() else None
-            tgt = self.bnb_target
-            if tgt is not None:   # this launch completes the gradient of tgt.y: it also writes tgt's BatchNorm-backward statistic rows
-                self.plan.dgrad_bnb(self, tgt, du, filt_d, zb, gx, res, self.k, self.s, self.plan.conv_ws, grads)
-            else:
-                ops.conv2d(du, filt_d, zb, gx, self.k, 1, act=False, residual=res, in_dilation=self.s, workspace=self.plan.conv_ws)
+            ops.conv2d(du, filt_d, zb, gx, self.k, 1, act=False, residual=res, in_dilation=self.s, workspace=self.plan.conv_ws)
         self.x.mark_ready()
 
 
@@ -279,8 +242,6 @@ class HeadUnit(_Unit):
         self.cout = _pad8(conv.out_channels)
         self.head = View.alloc(v.n, v.h, v.w, self.cout, plan.dtype, plan.device)
         self.raw = None
-        self.bnb_target = None   # see ConvUnit
-        self.bnb_rows = None
         self.bank_fwd = self.bank_dgrad = None
         self.filt_d = None
 
@@ -313,10 +274,7 @@ class HeadUnit(_Unit):
         if filt_d is None:
             filt_d = ops.pack_filter_dgrad(self.conv.weight, self.cout, self.x.view.c, self.plan.dtype)
         res = gx if self.x.is_ready() else None
-        if self.bnb_target is not None:
-            self.plan.dgrad_bnb(self, self.bnb_target, ghead, filt_d, self.plan.zeros_f32(self.x.view.c), gx, res, 1, 1, None, grads)
-        else:
-            ops.conv2d(ghead, filt_d, self.plan.zeros_f32(self.x.view.c), gx, 1, 1, act=False, residual=res)
+        ops.conv2d(ghead, filt_d, self.plan.zeros_f32(self.x.view.c), gx, 1, 1, act=False, residual=res)
         self.x.mark_ready()
 
 
@@ -502,7 +460,6 @@ class TrainPlan:
         self.conv_ws = ops.conv_workspace(device) if dtype in (torch.float16, torch.bfloat16) else None
         self._arena, self._arena_off = None, 0
         self._arena_numel = sum((p.numel() + 63) // 64 * 64 for p in self.params)
-        self._plan_bnb()
         # all filter banks of a step in one launch (Y3_PACK_JOBS=0: one launch per layer, as before)
         self.pack_jobs, self.banks_fresh = None, False
         if dtype in (torch.float16, torch.bfloat16) and os.environ.get("Y3_PACK_JOBS", "1") != "0":
@@ -515,73 +472,6 @@ class TrainPlan:
         self.last_forward = 0
         self.generation = 0        # bumped by every forward: the saved activations belong to exactly one forward
         self.outstanding = False   # a grad-enabled forward ran and its backward has not: the saved state must not be overwritten
-
-    def _plan_bnb(self):
-        """BatchNorm-backward reductions in the data-gradient epilogue: for every ConvUnit U find the launch that COMPLETES the gradient
-        of U.y -- the last gradient producer of that tensor in backward order.  When it is a single conv launch (the data gradient of a
-        consumer ConvUnit / Detect head, through the forward conv kernels) over exactly U.y's channel range, that launch is handed U's
-        pre-BatchNorm tensor and normalisation and writes the (sum g, sum g*u) rows next to the gradient (y3_conv2d_fwd_bnb_ws): U's
-        backward then skips the reduction pass over (dy, u).  Everything else (gradients completed by an upsample / pool backward, by the
-        residual add of a bn pass, by the stride-2 parity-class launches, Concat buffers written as a whole) keeps the separate reduction.
-        OFF by default, Y3_BNB_EPILOGUE=1 switches it on: measured on MI355X at batch 64 the step does not gain (67.4 -> 68.1 ms on one box,
-        67.5 -> 67.3 on another; profiles/r02_bn_stream_ab.txt) -- the reduction pass it removes reads (dy, u) at 5-6 TB/s, the data-gradient
-        kernels that take it over read u on top of their own traffic and run the extra sigmoid work in an epilogue that is in series with
-        their K loop, and their BNB instantiations allocate registers slightly worse."""
-        self.bnb_units = 0
-        if self.dtype not in (torch.float16, torch.bfloat16) or os.environ.get("Y3_BNB_EPILOGUE", "0") != "1":
-            return
-
-        def span(a: Act):
-            lo = 0
-            while getattr(a, "parent", None) is not None:
-                lo += a.coff
-                a = a.parent
-            return a, lo
-
-        events = []   # (root act, lo, hi, is a single conv launch, producer unit) in backward order
-        for hd in self.heads:
-            r, lo = span(hd.x)
-            events.append((r, lo, lo + hd.x.view.c, True, hd))
-        for u in reversed(self.units):
-            if isinstance(u, ConvUnit):
-                if u.res is not None:
-                    r, lo = span(u.res)
-                    events.append((r, lo, lo + u.res.view.c, False, u))
-                if u.need_dx:
-                    r, lo = span(u.x)
-                    events.append((r, lo, lo + u.x.view.c, u.generic_dgrad(), u))
-            elif isinstance(u, (UpsampleUnit, MaxPoolUnit)):
-                r, lo = span(u.x)
-                events.append((r, lo, lo + u.x.view.c, False, u))
-            elif isinstance(u, SPPPoolUnit):
-                r, lo = span(u.x)
-                events.append((r, lo, lo + u.x.view.c, False, u))
-        for U in self.units:
-            if not isinstance(U, ConvUnit) or U is self.units[0] and U.use_stem:
-                continue
-            r, lo = span(U.y)
-            hi = lo + U.y.view.c
-            last = None
-            for e in events:
-                if e[0] is r and e[1] < hi and lo < e[2]:
-                    last = e
-            if last is None or not last[3] or (last[1], last[2]) != (lo, hi):
-                continue
-            prod = last[4]
-            # prod.cout = channels of the gradient the producer convolves (the data gradient's "Cin"): the LDS-DMA kernels need 32-channel blocks
-            if prod.cout % 32 or prod.bnb_target is not None or U.cout != U.co_real:
-                continue
-            prod.bnb_target = U
-            U.bnb_totals = torch.zeros(4 * U.cout, dtype=torch.float64, device=self.device)   # (sum g, sum g*xhat) per channel, then their means
-            self.bnb_units += 1
-
-    def dgrad_bnb(self, prod, tgt: "ConvUnit", du: View, filt_d, zb, gx: View, res, k, s, ws, grads):
-        """the data gradient of `prod` that completes the gradient of tgt.y, with tgt's BatchNorm-backward statistic rows from its epilogue"""
-        if prod.bnb_rows is None:
-            prod.bnb_rows = ops.conv2d_bnb(du, None, None, gx, k, None, s, tgt.u, tgt.scale, tgt.shift, tgt.act, None, 0, workspace=ws)
-        buf = self.stat_buffer(prod.bnb_rows * 2 * tgt.cout)
-        n_rows = ops.conv2d_bnb(du, filt_d, zb, gx, k, res, s, tgt.u, tgt.scale, tgt.shift, tgt.act, buf, prod.bnb_rows, workspace=ws)
-        tgt.bnb_finalize(grads, buf, n_rows)
 
     # -- helpers ---------------------------------------------------------------------------------
     def bn_sums(self, c):
