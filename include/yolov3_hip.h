@@ -86,6 +86,11 @@ int y3_conv2d_fwd(const y3_conv_desc* desc, const y3_tensor* x, const void* pack
  * cut by a block's share of the K loop are completed through fp32 partial tiles in the workspace.  Results are deterministic
  * (fixed split, fixed summation order).  Layers the kernel does not cover run exactly as y3_conv2d_fwd. */
 size_t y3_conv_workspace_bytes(void);
+/* A K-split hand-off that never arrived (bounded spin in the finisher: a preempted or hung producer block) is LOUD: the tile is
+ * written as NaN and a sticky flag in the workspace makes every later launch on it write NaN too.  y3_conv_workspace_error reads the
+ * flag (synchronises `stream`; *error = 0 / 1), y3_conv_workspace_reset re-arms the workspace header (stream-ordered). */
+int y3_conv_workspace_error(const void* workspace, size_t workspace_bytes, int32_t* error, void* stream);
+int y3_conv_workspace_reset(void* workspace, size_t workspace_bytes, void* stream);
 int y3_conv2d_fwd_ws(const y3_conv_desc* desc, const y3_tensor* x, const void* packed_filter, const float* bias,
                      const y3_tensor* residual /* may be NULL */, const y3_tensor* y, void* workspace, size_t workspace_bytes,
                      void* stream);
@@ -312,6 +317,9 @@ int y3_conv2d_dgrad_s2(int32_t dtype, const y3_tensor* du, const void* packed4, 
 /* filter gradient (and optional bias gradient = per-channel sum of du) of the conv described by `desc`
  * (dtype, ksize, stride, cin, cout = padded sizes of x / du); dw is (cout_real, cin_real, k, k) fp32, overwritten. */
 size_t y3_conv2d_wgrad_workspace_bytes(const y3_conv_desc* desc, const y3_tensor* x);
+/* dry run: the geometry y3_conv2d_wgrad launches for (desc, x) -- tile edge (128 / 256; 0 = direct fp32 kernel), number of pixel
+ * slices (split-K over n*ho*wo) and whether a slice's tiles are grouped per XCD (knob "wgrad_xcd") */
+int y3_conv2d_wgrad_plan(const y3_conv_desc* desc, const y3_tensor* x, int32_t* tile, int64_t* slices, int32_t* xcd_grouped);
 int y3_conv2d_wgrad(const y3_conv_desc* desc, const y3_tensor* x, const y3_tensor* du, int32_t cout_real, int32_t cin_real,
                     float* dw_oihw, float* dbias /* may be NULL */, void* workspace, size_t workspace_bytes, void* stream);
 /* backward of nn.Upsample(x2, nearest) / nn.MaxPool2d (+ZeroPad2d) / Detect's view+permute (models/yolo.py:98) */

@@ -135,13 +135,19 @@ def test_bneck_pair_eligibility(monkeypatch):
 
     m = DetectionModel("yolov3.yaml").eval()
     b2, b4, b6 = m.model[2], m.model[4][0], m.model[6][0]
-    v64, v128, v256 = SimpleNamespace(c=64), SimpleNamespace(c=128), SimpleNamespace(c=256)
+    def view(c, n=32, h=320, w=320):
+        return SimpleNamespace(c=c, pitch=c, n=n, h=h, w=w)
+
+    v64, v128, v256 = view(64), view(128, h=160, w=160), view(256, h=80, w=80)
     monkeypatch.delenv("Y3_BNECK_PAIR", raising=False)
     assert e._bneck_pair_eligible(b2, v64, torch.float16) and e._bneck_pair_eligible(b2, v64, torch.bfloat16)
     assert e._bneck_pair_eligible(b4, v128, torch.float16)
     assert not e._bneck_pair_eligible(b2, v64, torch.float32)
     assert not e._bneck_pair_eligible(b6, v256, torch.float16)
     assert not e._bneck_pair_eligible(b4, v64, torch.float16)      # channel count of the view and of the module disagree
+    # a tensor beyond the 2 GiB reach of one buffer descriptor stays on the generic (batch-chunking) launches (round-2 advisor finding)
+    assert e._bneck_pair_eligible(b2, view(64, n=163), torch.float16) and not e._bneck_pair_eligible(b2, view(64, n=164), torch.float16)
+    assert not e._bneck_pair_eligible(b4, view(128, n=82, h=320, w=320), torch.float16)
     monkeypatch.setenv("Y3_BNECK_PAIR", "64")
     assert e._bneck_pair_eligible(b2, v64, torch.float16) and not e._bneck_pair_eligible(b4, v128, torch.float16)
     monkeypatch.setenv("Y3_BNECK_PAIR", "0")

@@ -52,7 +52,7 @@ def conv_ws(dev):
 
 
 def run_conv(dev, dtype, n, h, w, cin, cout, k, s, act=True, residual=False, ups=False, sliced=False, algo=0, seed=0, cin_real=None, cout_real=None, ws=False, expect=None,
-             repeat=1):
+             repeat=1, check_ws=True):
     """Returns (hip output NCHW fp32 cpu, reference NCHW fp32 cpu computed from the SAME rounded operands).  ws: call through
     y3_conv2d_fwd_ws; expect: assert the kernel variant the dispatcher picks (so a tolerance is tied to the kernel that ran)."""
     _lib, ops = _ops()
@@ -105,7 +105,7 @@ def run_conv(dev, dtype, n, h, w, cin, cout, k, s, act=True, residual=False, ups
             first = cur
         else:
             assert torch.equal(first, cur), f"launch {r} differs from launch 0 (non-deterministic or stale workspace state)"
-    if ws:
+    if ws and check_ws:
         hdr = wsp[:64].view(torch.int32)
         assert hdr[2].item() == 0, "stream-K kernel reported a lost producer (spin bound hit)"
         assert hdr[0].item() == 0 and hdr[1].item() == 0 and int(wsp[64:64 + 4096].view(torch.int32).abs().sum()) == 0, "workspace control words not re-armed"
@@ -1905,3 +1905,268 @@ def test_map_parity_on_synthetic_scenes(dev):
     assert res["reference_cpu_fp32"]["mAP50"] > 0.25, res
     assert res["abs_diff_fp32"]["mAP50"] <= 1e-3 and res["abs_diff_fp32"]["mAP50-95"] <= 1e-3, res
     assert res["abs_diff_fp16"]["mAP50"] <= 1e-2 and res["abs_diff_fp16"]["mAP50-95"] <= 1e-2, res
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configs[2] shapes: the training kernels at the sizes the bench runs
+# (round-2 review: split-K slice counts, XCD-grouped grids, 16-byte non-temporal partial sums and the >= 128 MB BatchNorm forms ran in bench.py only)
+BENCH_WGRAD_CASES = [
+    # name, (n, h, w, cin, cout, k, s), (tile edge, xcd-grouped) the dispatcher must pick
+    ("L6cv2_128_256_80", (64, 80, 80, 128, 256, 3, 1), (256, 1)),
+    ("L8cv2_256_512_40", (64, 40, 40, 256, 512, 3, 1), (256, 1)),
+    ("L10cv2_512_1024_20", (64, 20, 20, 512, 1024, 3, 1), (256, 1)),
+    ("L5_128_256_s2_160", (64, 160, 160, 128, 256, 3, 2), (256, 1)),
+    ("L4cv2_64_128_160", (64, 160, 160, 64, 128, 3, 1), (128, 1)),
+    ("L3_64_128_s2_320", (64, 320, 320, 64, 128, 3, 2), (128, 1)),
+    ("L2cv1_64_32_1x1_320", (64, 320, 320, 64, 32, 1, 1), (128, 0)),
+]
+
+
+@pytest.mark.parametrize("name,shape,plan", BENCH_WGRAD_CASES, ids=[c[0] for c in BENCH_WGRAD_CASES])
+def test_conv_wgrad_benchmark_shapes_fp16(dev, name, shape, plan):
+    """y3_conv2d_wgrad at the batch-64 shapes of the benchmarked train step (409 600 / 102 400 / 25 600 / 1.6 M / 6.5 M pixels): the
+    dispatcher's tile / slice / XCD decision is asserted through the dry-run query, the result is run-to-run deterministic, and 8 filter
+    rows spread over the MFMA blocks and waves of the filter tile (every (tap, channel) column, i.e. every column tile and every pixel
+    slice contributes to each) equal torch's fp32 autograd on the same rounded operands."""
+    _lib, ops = _ops()
+    n, h, w, cin, cout, k, s = shape
+    dtype = torch.float16
+    ho, wo = (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
+    g = torch.Generator(device=dev).manual_seed(11)
+    xv = ops.View.alloc(n, h, w, cin, dtype, dev)
+    xv.buf.normal_(generator=g)
+    gv = ops.View.alloc(n, ho, wo, cout, dtype, dev)
+    gv.buf.normal_(generator=g)
+    tile, slices, xg = ops.conv2d_wgrad_plan(xv, cout, k, s)
+    assert (tile, xg) == plan, f"{name}: dispatcher picked tile {tile}, xcd-grouped {xg}"
+    assert slices >= 2, f"{name}: one pixel slice -- the split-K sum is not exercised"
+    dw, _ = ops.conv2d_wgrad(xv, gv, k, s, cout, cin)
+    dw2, _ = ops.conv2d_wgrad(xv, gv, k, s, cout, cin)
+    torch.cuda.synchronize()
+    assert torch.equal(dw, dw2), "filter gradient is not run-to-run deterministic"
+    rows = sorted({0, 37 % cout, 70 % cout, 101 % cout, (cout // 2 + 2) % cout, (cout - 89) % cout, cout - 56 if cout > 56 else 5, cout - 1})
+    # reference: conv2d restricted to those filters (cost ~ rows / cout of the full layer), image chunks to bound host memory
+    wt = torch.zeros(len(rows), cin, k, k, requires_grad=True)
+    xn, gn = xv.as_nhwc(), gv.as_nhwc()
+    for i0 in range(0, n, 8):
+        xc = xn[i0 : i0 + 8].permute(0, 3, 1, 2).float().cpu()
+        gc = gn[i0 : i0 + 8][..., rows].permute(0, 3, 1, 2).float().cpu()
+        F.conv2d(xc, wt, None, stride=s, padding=k // 2).backward(gc)
+    ref = wt.grad
+    got = dw.cpu()[rows]
+    e_w = (got - ref).abs().max().item() / ref.abs().max().item()
+    print(f"[wgrad {name}] tile {tile} slices {slices} xcd {xg}: max rel err {e_w:.2e}")
+    assert e_w < 2e-3, f"{name}: wgrad {e_w:.2e}"
+
+
+def _bn_reference(u, dy, gamma, beta, eps, act, res):
+    """fp64 torch reference of train-mode act(bn(u)) (+ res) and its backward (du, dgamma, dbeta), NHWC (M, C) operands"""
+    u = u.double().requires_grad_(True)
+    gm, bt = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    mean, var = u.mean(0), u.var(0, unbiased=False)
+    z = (u - mean) / torch.sqrt(var + eps) * gm + bt
+    y = z * torch.sigmoid(z) if act else z
+    if res is not None:
+        y = y + res.double()
+    y.backward(dy.double())
+    return y.detach(), u.grad, gm.grad, bt.grad, mean.detach(), var.detach()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("nt", [0, 1], ids=["plain", "nontemporal"])
+@pytest.mark.parametrize("shape,act,residual", [((2, 40, 40, 128), True, True), ((3, 23, 19, 64), True, False), ((1, 64, 64, 256), False, False), ((2, 16, 16, 1024), True, True)],
+                         ids=["c128_res", "c64_ragged", "c256_linear", "c1024_res"])
+def test_bn_passes_plain_and_nontemporal_forms(dev, tune, dtype, nt, shape, act, residual):
+    """The elementwise / reduction passes of train-mode BatchNorm + SiLU (y3_bn_stats_finalize, y3_bn_act_fwd, y3_bn_act_bwd(_res)) against
+    an fp64 torch reference, in their plain form and -- knob bn_nt_bytes = 0 -- in the non-temporal form the library takes for tensors of
+    >= 128 MB (the batch-64 activations of the 640 / 320 / 160-pixel layers); both forms must agree bit for bit."""
+    import ctypes as C
+
+    _lib, ops = _ops()
+    L = _lib.lib()
+    n, h, w, c = shape
+    M = n * h * w
+    g = torch.Generator(device=dev).manual_seed(3)
+    outs = {}
+    for form in ([0, 1] if nt else [0]):
+        tune("bn_nt_bytes", 0 if form else 1 << 62)
+        g.manual_seed(3)
+        uv, yv, dyv, duv = (ops.View.alloc(n, h, w, c, dtype, dev) for _ in range(4))
+        uv.buf.normal_(generator=g).mul_(1.5).add_(0.25)
+        dyv.buf.normal_(generator=g)
+        rv = gr = None
+        if residual:
+            rv, gr = ops.View.alloc(n, h, w, c, dtype, dev), ops.View.alloc(n, h, w, c, dtype, dev)
+            rv.buf.normal_(generator=g)
+            gr.buf.fill_(0.5)
+        gamma = torch.rand(c, device=dev, generator=g) + 0.5
+        beta = torch.randn(c, device=dev, generator=g) * 0.3
+        sums = ops.bn_scratch(c, dev)
+        scale, shift, mean, invstd, dgamma, dbeta = (torch.empty(c, device=dev) for _ in range(6))
+        rmean, rvar = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+        ut, yt, dyt, dut = uv.y3(), yv.y3(), dyv.y3(), duv.y3()
+        dc, a, st = ops.dtype_code(dtype), (_lib.Y3_ACT_SILU if act else _lib.Y3_ACT_NONE), ops.stream_ptr()
+        _lib.check(L.y3_bn_stats_finalize(C.byref(ut), dc, sums.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-3, 0.03, rmean.data_ptr(), rvar.data_ptr(), scale.data_ptr(),
+                                          shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), st), "y3_bn_stats_finalize")
+        rt = rv.y3() if rv is not None else None
+        _lib.check(L.y3_bn_act_fwd(C.byref(ut), scale.data_ptr(), shift.data_ptr(), C.byref(rt) if rt is not None else None, C.byref(yt), dc, a, st), "y3_bn_act_fwd")
+        if residual:
+            grt = gr.y3()
+            _lib.check(L.y3_bn_act_bwd_res(C.byref(ut), C.byref(dyt), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), dc, a, sums.data_ptr(), C.byref(dut),
+                                           dgamma.data_ptr(), dbeta.data_ptr(), C.byref(grt), 1, st), "y3_bn_act_bwd_res")
+        else:
+            _lib.check(L.y3_bn_act_bwd(C.byref(ut), C.byref(dyt), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), dc, a, sums.data_ptr(), C.byref(dut),
+                                       dgamma.data_ptr(), dbeta.data_ptr(), st), "y3_bn_act_bwd")
+        torch.cuda.synchronize()
+        outs[form] = dict(y=yv.buf.clone(), du=duv.buf.clone(), dgamma=dgamma.clone(), dbeta=dbeta.clone(), mean=mean.clone(), invstd=invstd.clone(), rmean=rmean.clone(),
+                          rvar=rvar.clone(), gres=gr.buf.clone() if gr is not None else None)
+        if form == 0:
+            yr, dur, dgr, dbr, mr, vr = _bn_reference(uv.buf.view(M, c), dyv.buf.view(M, c), gamma, beta, 1e-3, act, rv.buf.view(M, c) if rv is not None else None)
+            ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+            o = outs[0]
+            assert (o["mean"].double() - mr).abs().max().item() <= 1e-5 * max(1.0, mr.abs().max().item())
+            assert (o["invstd"].double() - 1 / torch.sqrt(vr + 1e-3)).abs().max().item() <= 1e-5 * o["invstd"].max().item()
+            assert (o["rmean"].double() - 0.03 * mr).abs().max().item() <= 1e-6 + 1e-5 * mr.abs().max().item()
+            assert (o["rvar"].double() - (0.97 + 0.03 * vr * M / (M - 1))).abs().max().item() <= 1e-5
+            assert (o["y"].view(M, c).double() - yr).abs().max().item() <= 1.01 * ulp * yr.abs().max().item()
+            assert (o["du"].view(M, c).double() - dur).abs().max().item() <= 1.5 * ulp * dur.abs().max().item() + 1e-6
+            assert (o["dgamma"].double() - dgr).abs().max().item() <= 2e-5 * dyv.buf.float().abs().sum().item() / c
+            assert (o["dbeta"].double() - dbr).abs().max().item() <= 2e-5 * dyv.buf.float().abs().sum().item() / c
+            if gr is not None:
+                assert torch.equal(o["gres"].float(), (0.5 + dyv.buf.float()).to(dtype).float()), "residual gradient accumulation"
+    if nt:
+        for kname in outs[0]:
+            if outs[0][kname] is not None:
+                assert torch.equal(outs[0][kname], outs[1][kname]), f"non-temporal form differs from the plain form in {kname}"
+
+
+def test_bn_passes_on_a_tensor_beyond_the_nontemporal_threshold(dev):
+    """default knobs on the batch-64 activation of the 160-pixel layers (64 x 160 x 160 x 128 fp16 = 419 MB >= bn_nt_bytes): statistics,
+    normalisation + SiLU and the backward reduce / apply run in the forms the benchmarked train step runs them in (non-temporal loads and
+    stores, uncapped grids, two-level partial sums) and match a chunked fp32 torch evaluation."""
+    import ctypes as C
+
+    _lib, ops = _ops()
+    L = _lib.lib()
+    assert ops.tune_get("bn_nt_bytes") == 128 << 20
+    n, h, w, c = 64, 160, 160, 128
+    dtype = torch.float16
+    M = n * h * w
+    g = torch.Generator(device=dev).manual_seed(9)
+    uv, yv, dyv, duv = (ops.View.alloc(n, h, w, c, dtype, dev) for _ in range(4))
+    assert uv.buf.numel() * 2 >= 128 << 20
+    uv.buf.normal_(generator=g).add_(0.1)
+    dyv.buf.normal_(generator=g)
+    gamma = torch.rand(c, device=dev, generator=g) + 0.5
+    beta = torch.randn(c, device=dev, generator=g) * 0.3
+    sums = ops.bn_scratch(c, dev)
+    scale, shift, mean, invstd, dgamma, dbeta = (torch.empty(c, device=dev) for _ in range(6))
+    ut, yt, dyt, dut = uv.y3(), yv.y3(), dyv.y3(), duv.y3()
+    dc, st = ops.dtype_code(dtype), ops.stream_ptr()
+    _lib.check(L.y3_bn_stats_finalize(C.byref(ut), dc, sums.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-3, 0.03, None, None, scale.data_ptr(), shift.data_ptr(),
+                                      mean.data_ptr(), invstd.data_ptr(), st), "y3_bn_stats_finalize")
+    _lib.check(L.y3_bn_act_fwd(C.byref(ut), scale.data_ptr(), shift.data_ptr(), None, C.byref(yt), dc, _lib.Y3_ACT_SILU, st), "y3_bn_act_fwd")
+    _lib.check(L.y3_bn_act_bwd(C.byref(ut), C.byref(dyt), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), dc, _lib.Y3_ACT_SILU, sums.data_ptr(), C.byref(dut),
+                               dgamma.data_ptr(), dbeta.data_ptr(), st), "y3_bn_act_bwd")
+    torch.cuda.synchronize()
+    U, DY = uv.buf.view(M, c), dyv.buf.view(M, c)
+    s0 = torch.zeros(c, dtype=torch.float64, device=dev)
+    s1 = torch.zeros(c, dtype=torch.float64, device=dev)
+    CH = 1 << 18
+    for i in range(0, M, CH):
+        b = U[i : i + CH].double()
+        s0 += b.sum(0)
+        s1 += (b * b).sum(0)
+    mr = s0 / M
+    vr = s1 / M - mr * mr
+    isr = 1 / torch.sqrt(vr + 1e-3)
+    assert (mean.double() - mr).abs().max().item() <= 1e-6 and (invstd.double() - isr).abs().max().item() <= 1e-5 * isr.max().item()
+    sg = torch.zeros(c, dtype=torch.float64, device=dev)
+    sgx = torch.zeros(c, dtype=torch.float64, device=dev)
+    ymax = 0.0
+    for i in range(0, M, CH):
+        xh = (U[i : i + CH].float() - mr.float()) * isr.float()
+        z = xh * gamma + beta
+        sgm = torch.sigmoid(z)
+        yref = z * sgm
+        ymax = max(ymax, (yv.buf.view(M, c)[i : i + CH].float() - yref).abs().max().item() / max(1.0, yref.abs().max().item()))
+        gz = DY[i : i + CH].float() * (sgm + z * sgm * (1 - sgm))
+        sg += gz.double().sum(0)
+        sgx += (gz * xh).double().sum(0)
+    assert ymax <= 2.0 ** -10, f"bn_act_fwd: {ymax:.3e}"
+    assert (dbeta.double() - sg).abs().max().item() <= 1e-4 * sg.abs().max().item() + 1e-2
+    assert (dgamma.double() - sgx).abs().max().item() <= 1e-4 * sgx.abs().max().item() + 1e-2
+    dmax = 0.0
+    for i in range(0, M, CH):
+        xh = (U[i : i + CH].float() - mr.float()) * isr.float()
+        z = xh * gamma + beta
+        sgm = torch.sigmoid(z)
+        gz = DY[i : i + CH].float() * (sgm + z * sgm * (1 - sgm))
+        dref = (gamma * isr.float()) * (gz - (sg / M).float() - xh * (sgx / M).float())
+        dmax = max(dmax, (duv.buf.view(M, c)[i : i + CH].float() - dref).abs().max().item() / dref.abs().max().item())
+    assert dmax <= 1.5 * 2.0 ** -10, f"bn_act_bwd: {dmax:.3e}"
+
+
+@pytest.mark.parametrize("adt", [torch.float16, torch.bfloat16])
+def test_train_step_640_autocast_vs_oracle_autograd(dev, adt):
+    """BASELINE configs[2] resolution: one autocast training step of yolov3 at 640 x 640, batch 4 -- 1.6 M / 409 600 / ... / 1 600 pixel maps,
+    i.e. the fused stem backward, the 256-tile filter gradients with many pixel slices, v7 with statistics rows, the one-launch stride-2 data
+    gradients and the two-level statistics sums at real map sizes -- against torch autograd over the fp32 CPU oracle: loss, and the
+    direction and norm of every large parameter gradient."""
+    from yolov3_amd import ComputeLoss
+
+    nc, bs, hw = 80, 4, 640
+    hyp = dict(box=0.05, cls=0.5, cls_pw=1.0, obj=1.0, obj_pw=1.0, anchor_t=4.0, fl_gamma=0.0, label_smoothing=0.0)
+    m, (layers, save, sd, strides) = build_pair("yolov3", nc, 23, dev, torch.float32)
+    m.train()
+    m.hyp = hyp
+    x = torch.rand(bs, 3, hw, hw, generator=torch.Generator().manual_seed(12))
+    tg = yo.synth_targets(bs, nc, seed=13)
+    sdg = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
+    raws_ref = yo.forward(layers, save, sdg, x, strides, training=True)
+    loss_ref, _, _ = yo.compute_loss(raws_ref, tg, sd[[k for k in sd if k.endswith("anchors")][0]], hyp, nc)
+    loss_ref.backward()
+    crit = ComputeLoss(m)
+    with torch.autocast("cuda", dtype=adt):
+        raws = m(x.to(dev))
+        loss, _ = crit(raws, tg.to(dev))
+    (loss * 128.0).backward()
+    torch.cuda.synchronize()
+    rel = abs(loss.item() - loss_ref.item()) / loss_ref.item()
+    cos_min, worst, norm_worst = 1.0, None, (0.0, None)
+    for k, p_ in m.named_parameters():
+        ref = sdg[k].grad
+        assert p_.grad is not None and torch.isfinite(p_.grad).all(), k
+        if ref is None or ref.numel() < 4096:
+            continue
+        gq = p_.grad.float().cpu() / 128.0
+        cq = torch.nn.functional.cosine_similarity(gq.flatten(), ref.flatten(), dim=0).item()
+        nr = abs(gq.norm().item() / ref.norm().item() - 1.0)
+        if cq < cos_min:
+            cos_min, worst = cq, k
+        if nr > norm_worst[0]:
+            norm_worst = (nr, k)
+    print(f"[train 640 {adt}] loss rel err {rel:.2e}, min gradient cosine {cos_min:.4f} at {worst}, worst norm ratio error {norm_worst[0]:.3f} at {norm_worst[1]}")
+    assert rel < (0.002 if adt == torch.float16 else 0.01)
+    assert cos_min > (0.985 if adt == torch.float16 else 0.90), f"gradient direction: cosine {cos_min:.4f} at {worst}"
+    assert norm_worst[0] < (0.05 if adt == torch.float16 else 0.25), norm_worst
+
+
+def test_conv_workspace_lost_handoff_is_loud_and_resettable(dev, tune):
+    """The sticky error flag of the K-split workspace (conv_v7.h): once set -- here by hand, in production by a finisher whose producer
+    never published within the bounded spin -- every launch on that workspace writes NaN instead of a silently wrong sum, the host can
+    read the flag (y3_conv_workspace_error) and re-arm the workspace (y3_conv_workspace_reset); afterwards the results are exact again."""
+    _lib, ops = _ops()
+    tune("v7_grid", -2)
+    shape = (2, 20, 20, 256, 512, 3, 1)
+    good, ref = run_conv(dev, torch.float16, *shape, algo=1, ws=True, expect="v7")
+    ws = conv_ws(dev)
+    assert not ops.conv_workspace_error(ws)
+    hdr = ws[:64].view(torch.int32)
+    hdr[2] = 1   # V7Ctl::error
+    bad, _ = run_conv(dev, torch.float16, *shape, algo=1, ws=True, expect="v7", check_ws=False)
+    assert torch.isnan(bad).all(), "a poisoned workspace must not produce finite tiles"
+    assert ops.conv_workspace_error(ws)
+    ops.conv_workspace_reset(ws)
+    assert not ops.conv_workspace_error(ws)
+    again, _ = run_conv(dev, torch.float16, *shape, algo=1, ws=True, expect="v7")
+    assert torch.equal(again, good)

@@ -79,6 +79,8 @@ _SIGNATURES = {
     "y3_pack_filter": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "y3_conv2d_fwd": (C.c_int, [_P(Y3ConvDesc), _P(Y3Tensor), C.c_void_p, C.c_void_p, _P(Y3Tensor), _P(Y3Tensor), C.c_void_p]),
     "y3_conv_workspace_bytes": (C.c_size_t, []),
+    "y3_conv_workspace_error": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "y3_conv_workspace_reset": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "y3_conv2d_fwd_ws": (C.c_int, [_P(Y3ConvDesc), _P(Y3Tensor), C.c_void_p, C.c_void_p, _P(Y3Tensor), _P(Y3Tensor), C.c_void_p, C.c_size_t, C.c_void_p]),
     "y3_conv_last_variant": (C.c_int, [C.c_char_p, C.c_size_t]),
     "y3_conv2d_fwd_variant": (C.c_int, [_P(Y3ConvDesc), _P(Y3Tensor), _P(Y3Tensor), C.c_int32, C.c_size_t, C.c_char_p, C.c_size_t]),
@@ -148,6 +150,7 @@ _SIGNATURES = {
     "y3_pack_filter_dgrad_s2": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "y3_conv2d_dgrad_s2": (C.c_int, [C.c_int32, _P(Y3Tensor), C.c_void_p, _P(Y3Tensor), _P(Y3Tensor), C.c_void_p]),
     "y3_conv2d_wgrad_workspace_bytes": (C.c_size_t, [_P(Y3ConvDesc), _P(Y3Tensor)]),
+    "y3_conv2d_wgrad_plan": (C.c_int, [_P(Y3ConvDesc), _P(Y3Tensor), C.c_void_p, C.c_void_p, C.c_void_p]),
     "y3_conv2d_wgrad": (C.c_int, [_P(Y3ConvDesc), _P(Y3Tensor), _P(Y3Tensor), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "y3_upsample2x_bwd": (C.c_int, [_P(Y3Tensor), _P(Y3Tensor), C.c_int32, C.c_int32, C.c_void_p]),
     "y3_maxpool2d_bwd": (C.c_int, [_P(Y3Tensor), _P(Y3Tensor), _P(Y3Tensor), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

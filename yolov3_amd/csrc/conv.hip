@@ -1150,6 +1150,22 @@ extern "C" int y3_conv2d_fwd(const y3_conv_desc* d, const y3_tensor* x, const vo
 // ---- the same convolution with a scratch buffer: unlocks the persistent stream-K kernel (conv_v7.h) where it applies ----
 extern "C" size_t y3_conv_workspace_bytes(void) { return V7_HDR_BYTES + 2 * (size_t)V7_MAX_BLOCKS * V7_SLAB_BYTES; }   // a published + a private slab per block
 
+// the sticky hand-off flag of the stream-K path (conv_v7.h: a finisher whose producer never published poisons its tile and every later
+// launch on the workspace): y3_conv_workspace_error reads it (synchronises `stream`), y3_conv_workspace_reset re-arms the header
+extern "C" int y3_conv_workspace_error(const void* workspace, size_t workspace_bytes, int32_t* error, void* stream) {
+    if (!workspace || !error || workspace_bytes < V7_HDR_BYTES) Y3_FAIL("y3_conv_workspace_error: bad argument");
+    V7Ctl h;
+    Y3_HIP(hipMemcpyAsync(&h, workspace, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    Y3_HIP(hipStreamSynchronize((hipStream_t)stream));
+    *error = (int32_t)h.error;
+    return 0;
+}
+extern "C" int y3_conv_workspace_reset(void* workspace, size_t workspace_bytes, void* stream) {
+    if (!workspace || workspace_bytes < V7_HDR_BYTES) Y3_FAIL("y3_conv_workspace_reset: bad argument");
+    Y3_HIP(hipMemsetAsync(workspace, 0, V7_HDR_BYTES, (hipStream_t)stream));
+    return 0;
+}
+
 extern "C" int y3_conv2d_fwd_ws(const y3_conv_desc* d, const y3_tensor* x, const void* filt, const float* bias, const y3_tensor* res, const y3_tensor* y, void* workspace,
                                 size_t workspace_bytes, void* stream) {
     if (workspace && ((uintptr_t)workspace & 255)) Y3_FAIL("y3_conv2d_fwd_ws: the workspace must be 256-byte aligned");

@@ -68,7 +68,10 @@ Y3_DEV void wait_vm(int n) {   // n is wave-uniform; the immediate must be a lit
 #define V7_T(i) do { } while (0)
 #endif
 
-template <typename T, int XP, int AHEAD>
+// ABL (tools/v7_ablate.py, -DY3_ABLATE builds only; 0 in the shipped library): what a K-step costs without one of its parts -- results are
+// garbage, only the launch time means something.  1: half the MFMAs; 2: no filter requests in the loop; 3: no patch requests; 4: no pixel
+// fragment reads; 5: no fragment reads at all; 6: no MFMAs; 7: no requests and no reads (MMA + barriers only)
+template <typename T, int XP, int AHEAD, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #ifdef Y3_TIMELINE
@@ -244,22 +247,28 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p)
                 // ---- MEM(s): request a patch piece / filter tile s + AHEAD, read the fragments of step s, retire this wave's pieces of step s + 1 ----
                 int issued = 0;   // requests younger than filter tile s + 1: they may stay in flight
                 if constexpr (AHEAD == 3) {   // what MEM(s - 1) requested: filter tile s + 2 and, in taps 2 .. XP + 1 (same channel block), a patch piece
-                    if (more_cb || tap + 2 < 9) issued += 2;
-                    if constexpr (tap >= 2 && tap <= XP + 1) {
+                    if ((more_cb || tap + 2 < 9) && ABL != 2 && ABL != 7) issued += 2;
+                    if constexpr (tap >= 2 && tap <= XP + 1 && ABL != 3 && ABL != 7) {
                         if (more_cb) issued += 1;
                     }
                 }
-                if constexpr (tap >= 1 && tap <= XP) {
+                if constexpr (tap >= 1 && tap <= XP && ABL != 3 && ABL != 7) {
                     if (more_cb) { dma_x(tap - 1, cb + 1, buf ^ 1); issued += 1; }
                 }
-                if (more_cb || tap + AHEAD < 9) {
+                if ((more_cb || tap + AHEAD < 9) && ABL != 2 && ABL != 7) {
                     constexpr int tapa = (tap + AHEAD) % 9;
                     const int cba = cb + (tap + AHEAD >= 9 ? 1 : 0);
                     dma_w((tapa * p.Cin + cba * 32) * 2, (s + AHEAD) & 3);
                     issued += 2;
                 }
                 frag a0[MC], a1[MC], b0[MP], b1[MP];
-                {
+                if constexpr (ABL == 4 || ABL == 5 || ABL == 7) {   // fragments from nowhere (uninitialised registers kept opaque)
+#pragma unroll
+                    for (int a = 0; a < MC; ++a) asm volatile("" : "=v"(a0[a]), "=v"(a1[a]));
+#pragma unroll
+                    for (int b = 0; b < MP; ++b) asm volatile("" : "=v"(b0[b]), "=v"(b1[b]));
+                }
+                if constexpr (ABL != 5 && ABL != 7) {
                     const unsigned char* wl = smem + (s & 3) * V7_W_STAGE;
 #pragma unroll
                     for (int a = 0; a < MC; ++a) {
@@ -273,7 +282,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p)
                     const int row = rowv + dh * p.W + dw;
                     const int pa = PATCH_OFF + buf * PATCH_BYTES + row * 64 + ((fk ^ ((row >> 2) & 3)) << 4);
 #pragma unroll
-                    for (int b = 0; b < MP; ++b) {
+                    for (int b = 0; b < (ABL == 4 ? 0 : MP); ++b) {
                         int ab = pa + b * 2048;
                         if constexpr (MASK != 0) {
                             int e = ef[b];
@@ -293,10 +302,20 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p)
                 V7_T(2);   // barrier after MEM
                 // ---- MMA(s) ----
                 __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(1);
-                mma(a0, b0);
-                mma(a1, b1);
-                __builtin_amdgcn_s_setprio(0);
+                if constexpr (ABL != 8 && ABL != 9 && ABL != 10) __builtin_amdgcn_s_setprio(1);
+                if constexpr (ABL == 9) __builtin_amdgcn_s_setprio(0);
+                if constexpr (ABL == 10) __builtin_amdgcn_s_setprio(1);
+                if constexpr (ABL != 6) mma(a0, b0);
+                if constexpr (ABL != 6 && ABL != 1) mma(a1, b1);
+                if constexpr (ABL == 1 || ABL == 6) {   // the unused fragments stay live up to here
+#pragma unroll
+                    for (int a = 0; a < MC; ++a) asm volatile("" :: "v"(a0[a]), "v"(a1[a]));
+#pragma unroll
+                    for (int b = 0; b < MP; ++b) asm volatile("" :: "v"(b0[b]), "v"(b1[b]));
+                }
+                if constexpr (ABL != 8 && ABL != 9 && ABL != 10) __builtin_amdgcn_s_setprio(0);
+                if constexpr (ABL == 9) __builtin_amdgcn_s_setprio(1);   // priority to the MEM phase that follows
+                if constexpr (ABL == 10) __builtin_amdgcn_s_setprio(2);
                 __builtin_amdgcn_sched_barrier(0);
                 V7_T(3);   // MMA issue (the last MFMAs may still be in the pipe)
                 __builtin_amdgcn_s_barrier();
@@ -516,6 +535,27 @@ template <typename T> int launch_v7(ConvArgs& a, hipStream_t st) {
     //  leave a 26-tile group with 25 blocks and double the makespan -- measured 193 vs 115 us)
     const int xp = v7_xp(a.W);
     const dim3 grid((unsigned)g), block(512);
+#ifdef Y3_ABLATE
+    if (const char* e = getenv("Y3_V7_ABL")) {   // lab build only: the environment is read per launch on purpose
+        const int abl = atoi(e);
+        if (xp == 3 && abl >= 1 && abl <= 10) {
+            switch (abl) {
+                case 1: hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 3, 2, 1>), grid, block, 0, st, a); break;
+                case 2: hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 3, 2, 2>), grid, block, 0, st, a); break;
+                case 3: hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 3, 2, 3>), grid, block, 0, st, a); break;
+                case 4: hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 3, 2, 4>), grid, block, 0, st, a); break;
+                case 5: hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 3, 2, 5>), grid, block, 0, st, a); break;
+                case 6: hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 3, 2, 6>), grid, block, 0, st, a); break;
+                case 8: hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 3, 2, 8>), grid, block, 0, st, a); break;
+                case 9: hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 3, 2, 9>), grid, block, 0, st, a); break;
+                case 10: hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 3, 2, 10>), grid, block, 0, st, a); break;
+                default: hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 3, 2, 7>), grid, block, 0, st, a); break;
+            }
+            Y3_CHECK_LAUNCH();
+            return 0;
+        }
+    }
+#endif
     if (y3_knob(Y3K_CONV_AHEAD) == 2) {
         if (xp == 3) hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 3, 2>), grid, block, 0, st, a);
         else if (xp == 4) hipLaunchKernelGGL((conv_igemm_v7_kernel<T, 4, 2>), grid, block, 0, st, a);

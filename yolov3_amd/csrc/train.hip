@@ -1541,6 +1541,33 @@ static void wgrad_geometry(const y3_conv_desc* d, long long M, int& n_ct, int& n
     slices = (M + per - 1) / per;
 }
 
+static int wgrad_xcd_grouped(const y3_conv_desc* d, long long tiles, long long slices, int tsh) {
+    const int xcd_mode = (int)y3_knob(Y3K_WGRAD_XCD);
+    const bool narrow = tsh == 7 && d->cout <= 64;
+    return (tiles > 1 && slices > 1 && (narrow ? xcd_mode >= 3 : (tsh == 8 ? xcd_mode >= 2 : xcd_mode >= 1))) ? 1 : 0;
+}
+
+// geometry y3_conv2d_wgrad would launch for (desc, x): tile edge (128 / 256; 0 = the direct fp32 kernel), pixel slices, and whether a
+// slice's tiles are placed back to back on one XCD -- so that tests can assert WHICH form a shape exercises
+extern "C" int y3_conv2d_wgrad_plan(const y3_conv_desc* d, const y3_tensor* x, int32_t* tile, int64_t* slices_out, int32_t* xcd_grouped) {
+    if (!d || !x || !tile || !slices_out || !xcd_grouped) Y3_FAIL("y3_conv2d_wgrad_plan: null argument");
+    const int pad = d->ksize / 2;
+    const int Ho = (x->h + 2 * pad - d->ksize) / d->stride + 1, Wo = (x->w + 2 * pad - d->ksize) / d->stride + 1;
+    const long long M = (long long)x->n * Ho * Wo;
+    const long long xb = (((long long)x->n * x->h * x->w - 1) * x->pitch + x->c) * 2, db_ = ((M - 1) * d->cout + d->cout) * 2;
+    if (d->dtype == Y3_F32 || wgrad_mode() == 4 || xb >= 0x7fffffffLL || db_ >= 0x7fffffffLL) {
+        *tile = 0; *slices_out = 0; *xcd_grouped = 0;
+        return 0;
+    }
+    int n_ct, n_nt, tsh;
+    long long slices, per;
+    wgrad_geometry(d, M, n_ct, n_nt, slices, per, tsh);
+    *tile = 1 << tsh;
+    *slices_out = slices;
+    *xcd_grouped = wgrad_xcd_grouped(d, (long long)n_ct * n_nt, slices, tsh);
+    return 0;
+}
+
 extern "C" size_t y3_conv2d_wgrad_workspace_bytes(const y3_conv_desc* d, const y3_tensor* x) {
     if (!d || !x || d->dtype == Y3_F32) return 256;
     const int pad = d->ksize / 2;
@@ -1584,9 +1611,7 @@ extern "C" int y3_conv2d_wgrad(const y3_conv_desc* d, const y3_tensor* x, const 
         // wgrad_block: a slice's tiles back to back on one XCD.  Measured at batch 64 (profiles/r02_wgrad_xcd.txt): 64 -> 128 layers 0.60 -> 0.48 and
         // 0.52 -> 0.45 ms, the 256-tile kernel slightly better, but the narrow (<= 64-filter, 3 column tiles) launches of the 320x320 maps lose
         // 10-15 %, so those keep the dispatch order.  Knob "wgrad_xcd" = 0: never; 1: 128-tile kernels only; 2 (default): + the 256-tile kernel; 3: all
-        const int xcd_mode = (int)y3_knob(Y3K_WGRAD_XCD);
-        const bool narrow = tsh == 7 && d->cout <= 64;
-        a.xcd_group = (tiles > 1 && slices > 1 && (narrow ? xcd_mode >= 3 : (tsh == 8 ? xcd_mode >= 2 : xcd_mode >= 1))) ? 1 : 0;
+        a.xcd_group = wgrad_xcd_grouped(d, tiles, slices, tsh);
         if (tsh == 8) {
             if (d->dtype == Y3_F16) hipLaunchKernelGGL((wgrad_big_kernel<f16_t>), grid, dim3(512), 0, st, a);
             else hipLaunchKernelGGL((wgrad_big_kernel<bf16_t>), grid, dim3(512), 0, st, a);

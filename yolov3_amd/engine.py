@@ -421,6 +421,8 @@ def _bneck_pair_eligible(m, x, dtype) -> bool:
     flag = os.environ.get("Y3_BNECK_PAIR", "1")
     if flag == "0" or dtype not in (torch.float16, torch.bfloat16) or x.c not in (64, 128) or (flag == "64" and x.c != 64):
         return False
+    if x.n * x.h * x.w * x.pitch * 2 >= 2**31:   # one buffer descriptor per tensor in y3_bneck_pair_fwd (the generic path chunks the batch instead)
+        return False
     c1, c2 = m.cv1.conv, m.cv2.conv
     c = x.c
 

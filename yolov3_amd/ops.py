@@ -99,6 +99,17 @@ def conv_workspace(device) -> torch.Tensor:
     return torch.zeros(int(_lib.lib().y3_conv_workspace_bytes()), dtype=torch.uint8, device=device)
 
 
+def conv_workspace_error(ws: torch.Tensor) -> bool:
+    """True when a K-split hand-off on this workspace was lost (its tiles were written as NaN); synchronises the current stream"""
+    e = C.c_int32(0)
+    check(_lib.lib().y3_conv_workspace_error(ws.data_ptr(), ws.numel(), C.byref(e), stream_ptr()), "y3_conv_workspace_error")
+    return bool(e.value)
+
+
+def conv_workspace_reset(ws: torch.Tensor):
+    check(_lib.lib().y3_conv_workspace_reset(ws.data_ptr(), ws.numel(), stream_ptr()), "y3_conv_workspace_reset")
+
+
 def conv2d(x: View, filt: torch.Tensor, bias: torch.Tensor, y: View, k: int, stride: int, act: bool, residual: View | None = None, upsample2x: bool = False,
            algo: int = _lib.Y3_ALGO_AUTO, in_dilation: int = 0, workspace: torch.Tensor | None = None):
     d = Y3ConvDesc(dtype_code(x.buf.dtype), k, stride, _lib.Y3_ACT_SILU if act else _lib.Y3_ACT_NONE, int(upsample2x), algo, x.c, y.c, in_dilation)
@@ -238,6 +249,15 @@ def conv2d_wgrad(x: View, du: View, k: int, stride: int, cout_real: int, cin_rea
                                      ws.data_ptr(), need, stream_ptr()),
           "y3_conv2d_wgrad")
     return dw, db
+
+
+def conv2d_wgrad_plan(x: View, cout: int, k: int, stride: int):
+    """(tile edge, pixel slices, xcd-grouped) of the filter-gradient launch for this shape (y3_conv2d_wgrad_plan: dry run)"""
+    d = Y3ConvDesc(dtype_code(x.buf.dtype), k, stride, 0, 0, 0, x.c, cout, 0)
+    xt = x.y3()
+    tile, slices, xg = C.c_int32(0), C.c_int64(0), C.c_int32(0)
+    check(_lib.lib().y3_conv2d_wgrad_plan(C.byref(d), C.byref(xt), C.byref(tile), C.byref(slices), C.byref(xg)), "y3_conv2d_wgrad_plan")
+    return int(tile.value), int(slices.value), int(xg.value)
 
 
 BN_PARTIAL_ROWS = 512
