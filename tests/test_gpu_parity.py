@@ -177,6 +177,7 @@ V7_CASES = [   # every case has >= 32 (tile, channel block) units, the dispatche
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("name,shape,kw", V7_CASES, ids=[c[0] for c in V7_CASES])
 def test_conv_v7_streamk_vs_fp32_reference(dev, dtype, name, shape, kw, tune):
+    tune("conv_v9", 0)
     tune("conv_v7", 2)     # also the Cin < 256 shapes the dispatcher leaves to the 128x128 kernels
     tune("v7_grid", -2)    # even K split whatever the tile count: every case crosses tile boundaries inside blocks
     out, ref = run_conv(dev, dtype, *shape, algo=1, ws=True, expect="v7", repeat=3, **kw)
@@ -190,6 +191,7 @@ def test_conv_request_depth_bit_identical(dev, tune, variant, shape):
     round-2 schedule).  Both schedules add the same products in the same order: bit-identical outputs -- for v7 with whole tiles and with
     the K split, launch after launch (a stage overwritten while a wave still reads it would show up here as a flip)."""
     outs = []
+    tune("conv_v9", 0)
     if variant == "v6":
         tune("conv", 15)   # force the 256x256 v6 tile whatever the per-shape dispatch would pick at this small batch
     for grid in ((-1, -2) if variant == "v7" else (0,)):
@@ -206,6 +208,7 @@ def test_conv_v7_grid_sweep(dev, tune):
     """the same problem under different block counts (different K splits, down to whole tiles): every split sums the same
     products in fp32, so the results agree to accumulation-order noise and each one is inside the conv tolerance"""
     outs = []
+    tune("conv_v9", 0)
     for grid, gc in ((-1, 1), (-2, 1), (7, 1), (24, 2), (61, 1), (-1, 2), (-2, 2), (0, 4)):   # 4 does not divide the 2 filter tiles: ignored
         tune("v7_grid", grid)
         tune("v7_gc", gc)   # filter-tile ranges per XCD group (the rectangle a group of blocks owns)
@@ -2156,6 +2159,7 @@ def test_conv_workspace_lost_handoff_is_loud_and_resettable(dev, tune):
     never published within the bounded spin -- every launch on that workspace writes NaN instead of a silently wrong sum, the host can
     read the flag (y3_conv_workspace_error) and re-arm the workspace (y3_conv_workspace_reset); afterwards the results are exact again."""
     _lib, ops = _ops()
+    tune("conv_v9", 0)
     tune("v7_grid", -2)
     shape = (2, 20, 20, 256, 512, 3, 1)
     good, ref = run_conv(dev, torch.float16, *shape, algo=1, ws=True, expect="v7")
@@ -2170,3 +2174,64 @@ def test_conv_workspace_lost_handoff_is_loud_and_resettable(dev, tune):
     assert not ops.conv_workspace_error(ws)
     again, _ = run_conv(dev, torch.float16, *shape, algo=1, ws=True, expect="v7")
     assert torch.equal(again, good)
+
+
+# ------------------------------------------------------------------------------------------------ conv v9 (one wave per SIMD, padded-image halo patch)
+V9_CASES = [
+    # name, (n,h,w,cin,cout,k,s), kwargs, knobs (v9_mp, v9_vp; 0 = the host's plan)
+    ("plan_20x20_res", (8, 20, 20, 256, 512, 3, 1), {"residual": True}, (0, 0)),
+    ("mp8_vp256_rows_and_images", (6, 20, 20, 64, 256, 3, 1), {}, (8, 256)),             # tiles cross 12 rows and an image boundary
+    ("mp7_vp200_tiny_images", (40, 7, 5, 32, 256, 3, 1), {"residual": True}, (7, 200)),   # 35-pixel images: 5 image boundaries per tile, ncb = 1
+    ("mp6_vp192_odd_map", (3, 21, 19, 96, 256, 3, 1), {"sliced": True}, (6, 192)),        # 3 channel blocks, ragged last tile
+    ("mp7_vp201_w80_two_requests", (2, 80, 80, 64, 256, 3, 1), {}, (7, 201)),             # 36 patch pieces: two request slots per tap, vp not a multiple of anything
+    ("mp8_vp33_w40", (1, 40, 40, 128, 512, 3, 1), {"act": False}, (8, 33)),               # mostly-empty column blocks
+    ("mp7_vp224_1x1_image_rows", (2, 13, 26, 160, 256, 3, 1), {}, (7, 224)),
+    ("mp6_w160", (1, 160, 160, 32, 256, 3, 1), {"residual": True}, (6, 160)),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name,shape,kw,knobs", V9_CASES, ids=[c[0] for c in V9_CASES])
+def test_conv_v9_vs_fp32_reference(dev, tune, dtype, name, shape, kw, knobs):
+    """conv_v9.h (one wave per SIMD, private filter stages, padded-image halo patch with an 80-byte pitch, 192 / 224 / 256-pixel tiles with an
+    arbitrary number of valid pixels) against fp32 conv2d on the same rounded operands: tiles that cross rows and image boundaries, edge
+    taps (zeros through out-of-range request lanes), 1 .. 8 channel blocks, one and two patch request slots per tap, ragged last tiles,
+    residual / sliced outputs; repeated launches bit-identical."""
+    mp, vp = knobs
+    tune("conv_v9", 2)
+    tune("v9_mp", mp)
+    tune("v9_vp", vp)
+    want = f"v9_mp{mp}" if mp else None
+    out, ref = run_conv(dev, dtype, *shape, algo=1, ws=True, expect=want, repeat=2, **kw)
+    _lib, ops = _ops()
+    assert ops.last_conv_variant().startswith("v9"), ops.last_conv_variant()
+    _conv_tol_check(name, dtype, out, ref)
+
+
+def test_conv_v9_statistics_rows(dev, tune):
+    """BatchNorm statistics rows from the v9 epilogue (one row per 64-pixel pass and pixel tile, only the tile's valid pixels counted):
+    their fp64 sum equals the statistics of the stored tensor."""
+    _lib, ops = _ops()
+    tune("conv_v9", 2)
+    tune("v9_mp", 7)
+    tune("v9_vp", 200)
+    n, h, w, cin, cout, k, s = 5, 20, 20, 64, 256, 3, 1
+    dtype = torch.float16
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(n, cin, h, w, generator=g).to(dtype)
+    wt = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    xv = ops.View.alloc(n, h, w, cin, dtype, dev)
+    ops.nchw_to_nhwc(x.to(dev), xv)
+    filt = ops.pack_filter(wt.to(dev), cout, cin, dtype)
+    zb = torch.zeros(cout, device=dev)
+    y1 = ops.View.alloc(n, h, w, cout, dtype, dev)
+    rows = ops.conv2d_stats_rows(xv, y1, k, s)
+    assert rows == 10 * 4, rows   # 2000 pixels / 200 per tile, 4 passes of 64 pixels
+    buf = torch.full((rows * 2 * cout,), float("nan"), device=dev)
+    assert ops.conv2d_stats(xv, filt, zb, y1, k, s, buf, rows) == rows and ops.last_conv_variant() == "v9_mp7"
+    torch.cuda.synchronize()
+    u = y1.as_nhwc().double().cpu().reshape(-1, cout)
+    tot = buf.view(rows, cout, 2).double().sum(0).cpu()
+    assert torch.isfinite(tot).all(), "a statistics row was not written"
+    assert (tot[:, 0] - u.sum(0)).abs().max().item() <= 1e-5 * u.abs().sum(0).max().item()
+    assert (tot[:, 1] - (u * u).sum(0)).abs().max().item() <= 1e-5 * (u * u).sum(0).max().item()

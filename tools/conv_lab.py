@@ -2,8 +2,8 @@
 
     python tools/conv_lab.py [--rounds 7] [--reps 20] [--batch 32] [--only 3x3]
 
-Arms per shape: "ws" = y3_conv2d_fwd_ws (the dispatcher may pick the persistent stream-K kernel v7), "nows" = y3_conv2d_fwd
-(round-1 kernels), plus v7 under Y3_V7_GRID=-1 (whole tiles per block: isolates the halo-patch main loop from the stream-K split).
+Arms per shape (run-time knobs, y3_tune_set): "auto" = the dispatcher's choice with a workspace (v9 where eligible), "no v9" = knob
+conv_v9 = 0 (v7 / v6 / v3 as in round 2), "nows" = y3_conv2d_fwd without a workspace and without v9 (round-1 kernels).
 Prints median / min microseconds per launch and TFLOP/s.  Inputs are random (DVFS: never time on zeros)."""
 import argparse
 import math
@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--only", default="")
     ap.add_argument("--dtype", default="fp16")
-    ap.add_argument("--sweep", action="store_true", help="also time every forced tile variant (Y3_CONV=v3a|v3b|v3c|v5a|v5b|v6a|v6b) without a workspace")
+    ap.add_argument("--sweep", action="store_true", help="also time the forced tile variants (knob conv = 4 / 5 / 6 / 15) and the forced v9 wave-tile widths")
     args = ap.parse_args()
     from yolov3_amd import ops
 
@@ -73,35 +73,33 @@ def main():
             rv = ops.View.alloc(n, ho, wo, cout, dtype, dev)
             rv.buf.copy_(torch.randn(rv.buf.numel(), generator=g).to(dev).to(dtype))
         flops = 2.0 * n * ho * wo * cout * cin * k * k
-        arms = [("nows", None, {}), ("ws", ws, {})]
-        if ops.conv_variant(xv, yv, k, s, res, workspace_bytes=ws.numel()) == "v7":
-            arms += [("v7 s0", ws, {"Y3_V7_SCHED": "0"}), ("v7 s1", ws, {"Y3_V7_SCHED": "1"}), ("v7 streamK", ws, {"Y3_V7_GRID": "-2"})]
+        arms = [("nows", None, {"conv_v9": 0}), ("no v9", ws, {"conv_v9": 0}), ("auto", ws, {})]
         if args.sweep:
-            arms += [(v, None, {"Y3_CONV": v}) for v in ("v3a", "v5b", "v6b", "v8")]
+            arms += [(f"conv={v}", None, {"conv": v, "conv_v9": 0}) for v in (4, 6, 15)]
+            if k == 3 and s == 1 and cout % 256 == 0:
+                arms += [(f"v9 mp{m}", ws, {"conv_v9": 2, "v9_mp": m}) for m in (6, 7, 8)]
         times = {a[0]: [] for a in arms}
         outs = {}
         for rnd in range(args.rounds + 1):
             for arm, wsp, env in arms:
                 for kk, vv in env.items():
-                    os.environ[kk] = vv
+                    ops.tune_set(kk, vv)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(args.reps):
                     ops.conv2d(xv, filt, bias, yv, k, s, True, rv, workspace=wsp)
                 e1.record()
                 torch.cuda.synchronize()
-                for kk in env:
-                    os.environ.pop(kk)
+                ops.tune_reset()
                 if rnd:   # round 0 = warm-up
                     times[arm].append(e0.elapsed_time(e1) * 1e3 / args.reps)
                 else:
                     outs[arm] = yv.as_nhwc().float().clone()
         for arm, wsp, env in arms:
             for kk, vv in env.items():
-                os.environ[kk] = vv
+                ops.tune_set(kk, vv)
             var = ops.conv_variant(xv, yv, k, s, res, workspace_bytes=wsp.numel() if wsp is not None else 0)
-            for kk in env:
-                os.environ.pop(kk)
+            ops.tune_reset()
             med, mn = statistics.median(times[arm]), min(times[arm])
             diff = (outs[arm] - outs["nows"]).abs().max().item()
             print(f"{name:28s} {arm:10s} {var:18s} {med:9.1f} {mn:9.1f} {flops / med / 1e6:10.1f} {flops / mn / 1e6:10.1f}   max|d vs nows| {diff:.3g}")

@@ -60,6 +60,8 @@ struct ConvArgs {
     size_t ws_bytes;
     int v7_whole;  // conv_v7.h: blocks own whole tiles (no stream-K split)
     int v7_gc;     // conv_v7.h: filter-tile ranges per XCD group (1, 2, 4 or 8; divides n_ct)
+    int v9_vp, v9_npiece;   // conv_v9.h: valid pixels per tile, 1 KiB pieces of its halo patch
+    unsigned dv_pw_mul, dv_pw_sh, dv_h1_mul, dv_h1_sh;   // conv_v9.h: reciprocals of W + 2 and H + 1
 #ifdef Y3_TIMELINE  // debug build only (tools/timeline.py): per-block wall-clock stamps
     unsigned long long* tl;
 #endif
@@ -165,7 +167,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // idle), no idle waves.  (The block-wide fp32 transpose this replaces cost 8-17 us per block with half of the waves parked
 // during the exp/rcp pass; a register-only variant with 32-byte runs lost on the residual layers: profiles/r01_conv_timeline.md.)
 template <typename T, int MC, int MP>
-Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MP], unsigned char* wl, int c_base, int m_base, int lane, int stat_row = -1) {
+Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MP], unsigned char* wl, int c_base, int m_base, int lane, int stat_row = -1, int m_end = 0x7fffffff) {
     typedef typename Mfma<T>::frag vec8;   // 8 x T = one 16-byte chunk
     constexpr int CH = MC * 4;          // 16-byte chunks per pixel row of this wave's slice
     constexpr int RB = CH * 16;         // row bytes
@@ -179,16 +181,17 @@ Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MP], unsigned cha
     const auto rsrc_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)p.y_bytes, 0x00020000);
     const auto rsrc_r = __builtin_amdgcn_make_buffer_rsrc((void*)(has_res ? p.res : p.y), 0, has_res ? (int)p.r_bytes : 0, 0x00020000);
 
-    // output pixel index of the MFMA pixels this lane owns (-1: beyond M), then re-distributed to the store layout
+    // output pixel index of the MFMA pixels this lane owns (-1: beyond M or beyond the tile's valid pixels), then re-distributed to the store layout
+    const int mlim = m_end < p.M ? m_end : p.M;
     int opx[MP];
 #pragma unroll
     for (int b = 0; b < MP; ++b) {
         const int m = m_base + b * 32 + frow;
-        const int mm = m < p.M ? m : 0;
+        const int mm = m < mlim ? m : 0;
         int n, ho, wo;
         pix_coords(mm, p, n, ho, wo);
         const int o = p.ups ? ((n * p.Ho * 2 + 2 * ho) * (p.Wo * 2) + 2 * wo) : (int)out_pix(n, ho, wo, p);
-        opx[b] = m < p.M ? o : -1;
+        opx[b] = m < mlim ? o : -1;
     }
     const int c = c_base + ch * 8;
     const bool cv = c + 8 <= p.Cout;
@@ -945,12 +948,14 @@ int launch_igemm(ConvArgs& a, hipStream_t st) {
 }
 
 #include "conv_v7.h"
+#include "conv_v9.h"
 
 template <typename T> int dispatch_igemm(ConvArgs& a, hipStream_t st) {
     const bool c64 = (a.Cin % 64) == 0, c32 = (a.Cin % 32) == 0;
     const int var = conv_variant();
     if (!(a.x_bytes && a.w_bytes && a.y_bytes && (!a.res || a.r_bytes)))
         Y3_FAIL("conv: a tensor exceeds the 2 GiB reach of a buffer descriptor (split the batch)");
+    if (var == 3 && v9_eligible(a)) return launch_v9<T>(a, st);
     if (var == 3 && v7_eligible(a)) return launch_v7<T>(a, st);
     if (var >= 3 && a.Cout > 64 && c32) {
         // forced tiles (knob "conv", A/B runs)

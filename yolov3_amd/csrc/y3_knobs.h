@@ -1,0 +1,19 @@
+// Run-time tuning knobs of libyolov3_hip.so: ids (this enum) and names / defaults (api.cpp::kKnobs) in the same order.
+#pragma once
+enum y3_knob_id {
+    Y3K_CONV = 0,       // "conv":        0 per-shape dispatch; 2 register-staged v2; 4 / 5 / 6 the v3 tiles 128x256 / 128x128 BK32 / 128x128 BK64; 15 v6
+    Y3K_CONV_V7,        // "conv_v7":     1 where it measured ahead; 0 never; 2 every eligible shape (also Cin < 256)
+    Y3K_V7_GRID,        // "v7_grid":     0 auto; N > 0 caps the persistent grid; -1 whole tiles; -2 even K split (stream-K)
+    Y3K_V7_GC,          // "v7_gc":       0 auto; 1 / 2 / 4 / 8 filter-tile ranges per XCD group
+    Y3K_CONV_AHEAD,     // "conv_ahead":  K-steps the LDS-DMA requests of v6 / v7 / wgrad_big run ahead of the MFMAs (3; 2 = the round-2 schedule)
+    Y3K_BN_NT_BYTES,    // "bn_nt_bytes": tensors at least this large take the non-temporal forms of the elementwise BatchNorm passes
+    Y3K_WGRAD,          // "wgrad":       0 per-shape; 2 the 128x128 kernel; 3 the 256x256 kernel wherever the shape allows; 4 the direct fp32 kernel
+    Y3K_WGRAD_XCD,      // "wgrad_xcd":   0 dispatch order; 1 a slice's tiles on one XCD for the 128-tile kernel; 2 + the 256-tile kernel; 3 all
+    Y3K_DGRAD_QUAD,     // "dgrad_quad":  1 the four parity classes of a stride-2 data gradient in one launch; 0 four launches
+    Y3K_SPP_DIRECT,     // "spp_direct":  1 SPP pools without the LDS pyramid
+    Y3K_CONV_V9,        // "conv_v9":     1 the one-wave-per-SIMD 3x3 kernel where a launch has at least a quarter round of tiles; 0 never; 2 every eligible shape
+    Y3K_V9_MP,          // "v9_mp":       0 the host's tile plan; 6 / 7 / 8 force the wave-tile width (32-pixel column blocks) of conv_v9.h (tests)
+    Y3K_V9_VP,          // "v9_vp":       0 the host's tile plan; > 0 force the valid pixels per tile (tests: tiles that cross rows and images)
+    Y3K_COUNT
+};
+long long y3_knob(int id);
