@@ -182,6 +182,28 @@ def run_train(args, rank, world, dev, parallel, yo, batch, steps, warmup):
     dt = parallel.max_over_ranks(time.perf_counter() - t0, dev)
     flops_img = train_flops_per_image(model, hw)
     tflops = flops_img * bs * steps / dt / 1e12   # per GPU
+    # N = 1: what the gradient exchange costs the step when it runs beside the backward -- the same bucket / side-stream / event machinery as
+    # N ranks on a ONE-rank RCCL communicator (the collective itself moves no bytes over xGMI at one rank: this prices the plumbing and shows
+    # the side stream does not stall the compute stream; the wire time of N = 8 is modelled in DESIGN.md section 7)
+    exchange = None
+    if world == 1 and not os.environ.get("Y3_NO_EXCHANGE_LEG"):
+        try:
+            parallel.init(force=True)
+            model.grad_sync = parallel.GradBuckets(force=True)
+            step()
+            parallel.barrier()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            parallel.barrier()
+            dt1 = time.perf_counter() - t1
+            exchange = {"ms_per_step_with_exchange": round(dt1 / steps * 1e3, 3), "ms_per_step_without": round(dt / steps * 1e3, 3),
+                        "gradient_bytes": int(sum(p.numel() for p in model.parameters()) * 4), "bucket_bytes": model.grad_sync.bucket_bytes,
+                        "communicator": "RCCL, 1 rank (in-place ReduceOp.AVG on arena ranges, side stream, event-ordered against the producing kernels)"}
+        except Exception as e:  # noqa: BLE001
+            exchange = {"error": f"{type(e).__name__}: {e}"[:300]}
+        finally:
+            model.grad_sync = None
     stats = {}
     try:   # kernel breakdown of the same step from the committed rocprofv3 --kernel-trace --stats run (bench.py cannot run the profiler)
         stats = json.load(open(ROOT / "profiles" / "r02_train_step_kernel_groups.json"))
@@ -193,7 +215,7 @@ def run_train(args, rank, world, dev, parallel, yo, batch, steps, warmup):
         "vs_baseline": None, "dtype": "f16" if args.dtype == "fp16" else "bf16", "data": "synthetic (seeded uniform images, Poisson(7) targets/img; random-init weights)",
         "config": {"workload": f"{args.model} train step {hw}x{hw} batch={bs}/GPU autocast {args.dtype}: fwd (batch-stat BN) + ComputeLoss + bwd + grad all-reduce + fused unscale/clip/SGD-nesterov/EMA [BASELINE configs[2]]",
                    "global_batch": world * bs, "parallelism": f"dp{world} (bucketed all-reduce overlapped with backward)"},
-        "final_loss": float(loss.detach()), "loss_scale": scaler.get_scale(),
+        "final_loss": float(loss.detach()), "loss_scale": scaler.get_scale(), "gradient_exchange_1rank": exchange,
         "roofline": {"bound": "mfma", "achieved": round(tflops, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / MFMA_PEAK_TFLOPS, 4),
                      "whole_step_frac": round(tflops / MFMA_PEAK_TFLOPS, 4), "gflop_per_image": round(flops_img / 1e9, 2),
                      "note": "whole step (fwd + dgrad + wgrad conv FLOPs per GPU / step time); kernel shares from the committed profile",
@@ -272,15 +294,17 @@ def main():
     ap.add_argument("--train-batch", type=int, default=64)
     ap.add_argument("--train-steps", type=int, default=6)
     ap.add_argument("--train-timeout", type=float, default=240.0, help="N > 1: seconds the appended train leg may take before the inference line is printed without it")
+    ap.add_argument("--dist-backend", default=None, choices=["nccl", "gloo"],
+                    help="process-group backend (default nccl = RCCL; gloo: plumbing smoke with several ranks on fewer GPUs, tools/gpu_dist_smoke.sh)")
     args = ap.parse_args()
 
     from yolov3_amd import parallel
 
-    rank, local_rank, world = parallel.init()
+    rank, local_rank, world = parallel.init(args.dist_backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    dev = torch.device("cuda", local_rank)
+    dev = parallel.local_device(local_rank)
     torch.cuda.set_device(dev)
 
     from oracle import yolo_oracle as yo  # only for the seeded synthetic inputs + cpu_baseline leg

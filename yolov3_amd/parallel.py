@@ -27,13 +27,20 @@ def init(backend: str | None = None, force: bool = False):
         os.environ.setdefault("WORLD_SIZE", str(world))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        backend = backend or os.environ.get("Y3_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             kw["device_id"] = torch.device("cuda", local_rank)
         dist.init_process_group(backend, **kw)
     return rank, local_rank, world
+
+
+def local_device(local_rank: int) -> torch.device:
+    """cuda:<local_rank>; on a box with fewer GPUs than local ranks (the 2-rank gloo smoke of the multi-process plumbing on a 1-GPU box) the
+    ranks share the devices round-robin -- RCCL itself refuses two ranks on one device"""
+    n = torch.cuda.device_count()
+    return torch.device("cuda", local_rank % n if n else 0)
 
 
 def barrier():
@@ -95,6 +102,7 @@ class GradBuckets:
         self._inflight: list = []  # (work, flat, keys, shapes, dtypes, event)
         self._out: dict = {}
         self._side = None
+        self._ranges: list = []    # (arena, lo, hi) of the in-place buckets in flight
 
     def _stream(self, device):
         if device.type != "cuda":
@@ -152,6 +160,14 @@ class GradBuckets:
         dev = tensors[0].device
         side = self._stream(dev)
         rng = self._arena_range(tensors) if self.wire_dtype in (None, torch.float32) else None
+        if rng is not None:
+            # in-place ranges of one arena must be disjoint: a range that reaches into one that is already being reduced would be averaged twice
+            # (harmless with AVG over identical values, a race on the SUM + divide path) -- such a bucket takes the flatten / copy-back path
+            base, lo, hi = rng
+            if any(b is base and lo < h and l < hi for b, l, h in self._ranges):
+                rng = None
+            else:
+                self._ranges.append((base, lo, hi))
 
         def issue():
             if rng is not None:
@@ -196,6 +212,7 @@ class GradBuckets:
                     self._out[k] = flat[off : off + n].view(shp).to(dt)
                     off += n
         self._inflight = []
+        self._ranges = []
         out, self._out = self._out, {}
         return out
 

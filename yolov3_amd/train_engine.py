@@ -190,9 +190,9 @@ class ConvUnit(_Unit):
                 raise RuntimeError("the input batch was modified in place between the forward and the backward of this training step")
             dw = self.plan.grad_alloc(tuple(m.conv.weight.shape))
             ops.stem_bn_bwd_wgrad(xi, self.u, gy, self.scale, self.shift, self.mean, self.invstd, self.act, self.sums, dgamma, dbeta, dw, self.plan.stem_bwd_ws())
-            grads[m.conv.weight] = dw
-            grads[m.bn.weight] = dgamma
+            grads[m.bn.weight] = dgamma   # handed over in the order the arena slices were taken: a bucket is then one contiguous range (parallel.GradBuckets)
             grads[m.bn.bias] = dbeta
+            grads[m.conv.weight] = dw
             return
         du = self.plan.scratch_like(self.u)
         ut, gt, dt = self.u.y3(), gy.y3(), du.y3()
@@ -211,9 +211,9 @@ class ConvUnit(_Unit):
                                 self.sums.data_ptr(), C.byref(dt), dgamma.data_ptr(), dbeta.data_ptr(), st),
                 "y3_bn_act_bwd",
             )
+        grads[m.bn.weight] = dgamma   # cout == co_real (checked in fwd): whole tensors, so autograd takes them without a copy; handed over in
+        grads[m.bn.bias] = dbeta      # arena order (dgamma, dbeta, then the filter gradient below): buckets stay contiguous, disjoint ranges
         self.plan.wgrad(grads, m.conv.weight, None, self.x.view, du, self.k, self.s, self.co_real, self.ci_real)
-        grads[m.bn.weight] = dgamma   # cout == co_real (checked in fwd): whole tensors, so autograd takes them without a copy
-        grads[m.bn.bias] = dbeta
         self._dgrad(du, grads)
 
     def _dgrad(self, du: View, grads=None):
