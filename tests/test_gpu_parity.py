@@ -1667,12 +1667,17 @@ def test_gradient_exchange_over_rccl_one_rank(dev):
             dist.destroy_process_group()
 
 
-@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (the round-end 8-GPU node; the 1-GPU test box skips it)")
-def test_gradient_exchange_over_rccl_two_ranks(tmp_path):
-    """two ranks, one GPU each, through torch.distributed.run: both ranks end with the same averaged gradients = mean of the two
-    single-rank gradients (the same check the gloo test makes on CPU tensors, on device buffers over RCCL)"""
+@pytest.mark.parametrize("backend", ["nccl", "gloo"])
+def test_gradient_exchange_two_ranks(tmp_path, backend):
+    """two ranks through torch.distributed.run: both ranks end with the same averaged gradients = mean of the two single-rank gradients, on
+    device buffers.  nccl (RCCL, one GPU per rank) needs two GPUs; gloo runs on the 1-GPU box too -- the two ranks share the device
+    (parallel.local_device), the collective goes through the host: the same rendezvous, rank / device mapping, bucket, side-stream and
+    SUM + divide code as a multi-GPU job, which is what has to work the first time the driver launches N > 1."""
     import subprocess
     import sys
+
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (the round-end 8-GPU node; the 1-GPU test box runs the gloo form)")
 
     script = tmp_path / "two_rank.py"
     script.write_text(f"""
@@ -1680,8 +1685,9 @@ import sys, torch, yaml
 sys.path.insert(0, {str(ROOT)!r})
 from yolov3_amd import ComputeLoss, DetectionModel, parallel
 from oracle import yolo_oracle as yo
-rank, local_rank, world = parallel.init("nccl")
-dev = torch.device("cuda", local_rank)
+rank, local_rank, world = parallel.init({backend!r})
+dev = parallel.local_device(local_rank)
+torch.cuda.set_device(dev)
 torch.manual_seed(0)
 m = DetectionModel("yolov3-tiny.yaml", nc=80).to(dev).train()
 m.hyp = dict(box=0.05, cls=0.5, cls_pw=1.0, obj=1.0, obj_pw=1.0, anchor_t=4.0, fl_gamma=0.0, label_smoothing=0.0)
@@ -1697,9 +1703,9 @@ def grads(sync):
     return torch.cat([p.grad.flatten() for p in m.parameters()])
 own = grads(False)
 avg = grads(True)
-both = [torch.empty_like(own) for _ in range(world)]
-torch.distributed.all_gather(both, own)
-ref = sum(both) / world
+ref = own.clone()
+torch.distributed.all_reduce(ref)
+ref /= world
 assert torch.allclose(avg, ref, rtol=1e-5, atol=1e-7), float((avg - ref).abs().max())
 print("rank", rank, "ok")
 parallel.finalize()
@@ -1958,7 +1964,8 @@ def test_conv_wgrad_benchmark_shapes_fp16(dev, name, shape, plan):
     got = dw.cpu()[rows]
     e_w = (got - ref).abs().max().item() / ref.abs().max().item()
     print(f"[wgrad {name}] tile {tile} slices {slices} xcd {xg}: max rel err {e_w:.2e}")
-    assert e_w < 2e-3, f"{name}: wgrad {e_w:.2e}"
+    # same rounded operands on both sides, fp32 accumulation over up to 6.5 M pixels in 51..1024 partial sums: measured 5e-7 .. 3e-6 (round 3)
+    assert e_w < 2e-5, f"{name}: wgrad {e_w:.2e}"
 
 
 def _bn_reference(u, dy, gamma, beta, eps, act, res):
@@ -2149,9 +2156,12 @@ def test_train_step_640_autocast_vs_oracle_autograd(dev, adt):
         if nr > norm_worst[0]:
             norm_worst = (nr, k)
     print(f"[train 640 {adt}] loss rel err {rel:.2e}, min gradient cosine {cos_min:.4f} at {worst}, worst norm ratio error {norm_worst[0]:.3f} at {norm_worst[1]}")
-    assert rel < (0.002 if adt == torch.float16 else 0.01)
-    assert cos_min > (0.985 if adt == torch.float16 else 0.90), f"gradient direction: cosine {cos_min:.4f} at {worst}"
-    assert norm_worst[0] < (0.05 if adt == torch.float16 else 0.25), norm_worst
+    # measured (round 3, MI355X): fp16 loss 1e-7, min cosine 0.9947, worst norm error 0.5 %; bf16 loss 1e-5, min cosine 0.938, norm 2.1 %.
+    # (bf16 keeps 8 mantissa bits: the MIN over ~60 tensors is set by the BatchNorm backward's mean subtraction, which amplifies the relative
+    #  rounding noise of du; two builds that differ only in fp32 instruction selection move it by ~0.01 -- hence the margin)
+    assert rel < (1e-4 if adt == torch.float16 else 1e-3)
+    assert cos_min > (0.99 if adt == torch.float16 else 0.92), f"gradient direction: cosine {cos_min:.4f} at {worst}"
+    assert norm_worst[0] < (0.02 if adt == torch.float16 else 0.06), norm_worst
 
 
 def test_conv_workspace_lost_handoff_is_loud_and_resettable(dev, tune):
