@@ -444,6 +444,24 @@ def main():
                               for k, g in sorted(groups.items(), key=lambda kv: -kv[1][2])},
             },
         }
+        # context for `frac`: what the vendor GEMM (torch.matmul -> hipBLASLt) reaches on the plain GEMM the dominant layer group is equivalent
+        # to -- same FLOPs, no halo gather, no bias / SiLU / residual epilogue -- measured here, after the timed region, rank 0 at N = 1 only
+        if world == 1 and bound == "mfma" and dom.endswith("/3x3"):
+            try:
+                ln = max((l for l in plan.launches if l.flops and not getattr(l, "kernel", "") and f"conv_igemm_{plan.conv_variant(l)}/3x3" == dom), key=lambda l: l.flops)
+                d_, xt_, yt_ = ln.keep[0], ln.keep[1], ln.keep[2]
+                Mg, Ng, Kg = yt_.n * yt_.h * yt_.w, d_.cout, 9 * d_.cin
+                ga = torch.randn(Mg, Kg, device=dev, dtype=dtype)
+                gb = torch.randn(Ng, Kg, device=dev, dtype=dtype)
+                for _ in range(3):
+                    torch.matmul(ga, gb.t())
+                t_g = timed(lambda: torch.matmul(ga, gb.t()), n=10)
+                roofline["vendor_gemm_same_shape"] = {"M": Mg, "N": Ng, "K": Kg, "us": round(t_g * 1e6, 1), "tflops": round(2.0 * Mg * Ng * Kg / t_g / 1e12, 1),
+                                                      "frac": round(2.0 * Mg * Ng * Kg / t_g / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                                                      "note": "torch.matmul(A, B^T) fp16/bf16 random operands: hipBLASLt on the GEMM the largest launch of the dominant group is equivalent to (no im2col / halo, no fused epilogue)"}
+                del ga, gb
+            except Exception as e:  # noqa: BLE001
+                roofline["vendor_gemm_same_shape"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()   # rank 0 at N = 1 only
         value = world * bs * args.steps / dt
         roofline["whole_step_frac"] = round(total_conv_flops / (dt / args.steps) / 1e12 / MFMA_PEAK_TFLOPS, 4)   # conv FLOPs of one step / wall time of one step / 2.5 PF
