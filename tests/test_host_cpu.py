@@ -413,3 +413,36 @@ def test_map_parity_helpers_on_cpu():
     sd = yo.seeded_state_dict(layers, nc, anchors, yo.model_strides(layers), seed=1)
     (p, r, m50, m), n_det = mp.evaluate_oracle("yolov3-tiny", 3, sd, x1[:4], l1, 96, bs=4)
     assert all(0.0 <= v <= 1.0 for v in (p, r, m50, m)) and n_det >= 0
+
+
+def test_grad_sink_flushes_the_bucket_before_the_tail_of_the_backward():
+    """The last collective of a backward is the exposed one: once only `_GradSink.TAIL_BYTES` of parameters are still to come the sink asks
+    the bucket object to send what it holds (otherwise ~47 MB of yolov3's gradients would wait for `finish()` behind a bucket boundary)."""
+    import torch
+
+    from yolov3_amd.train_engine import _GradSink
+
+    class FakeSync:
+        def __init__(self):
+            self.events = []
+
+        def add(self, k, g):
+            self.events.append(("add", k))
+
+        def flush(self):
+            self.events.append(("flush",))
+
+        def finish(self):
+            return {}
+
+    tail = _GradSink.TAIL_BYTES
+    sizes = [tail // 4, tail // 4, tail // 4, tail // 8, tail // 8, tail // 8]          # elements of fp32: 1, 1, 1, .5, .5, .5 tails -> 4.5 tails in all
+    fs = FakeSync()
+    sink = _GradSink(fs, sum(sizes) * 4)
+    for i, n in enumerate(sizes):
+        sink[i] = torch.empty(n)
+    kinds = [e[0] for e in fs.events]
+    assert kinds.count("flush") == 1
+    # 3.5 tails seen after the 4th gradient = total - 1 tail: flushed right there, the remaining two gradients fill the last (small) bucket
+    assert kinds == ["add", "add", "add", "add", "flush", "add", "add"], kinds
+    assert _GradSink(None).result() == {}

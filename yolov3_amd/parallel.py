@@ -125,6 +125,11 @@ class GradBuckets:
         if self._bytes >= self.bucket_bytes:
             self._launch()
 
+    def flush(self):
+        """launch the bucket that is being filled now (the training plan calls this when only a few MB of gradients are still to come, so
+        that the collective left for finish() is small)"""
+        self._launch()
+
     @staticmethod
     def _arena_range(tensors):
         """(base, lo, hi) when every tensor is a contiguous fp32 view of ONE flat base tensor (the training plan's gradient arena):

@@ -588,7 +588,7 @@ class TrainPlan:
 
     def backward(self, graws):
         sync = getattr(self.model, "grad_sync", None)  # parallel.GradBuckets: overlapped gradient all-reduce
-        grads = _GradSink(sync)
+        grads = _GradSink(sync, sum(p.numel() * 4 for p in self.params))
         self._arena, self._arena_off = None, 0          # a new arena per backward (see grad_alloc)
         for a in self.acts:
             a.drop_grad()
@@ -615,13 +615,23 @@ class _GradSink(dict):
     """dict of finished parameter gradients; with a GradBuckets object every gradient is handed to the overlapped
     all-reduce the moment its kernels have been issued (reverse layer order = the order backward produces them)."""
 
-    def __init__(self, sync=None):
+    TAIL_BYTES = 16 << 20   # what may still be pending when the backward ends (the last bucket's collective is the exposed one)
+
+    def __init__(self, sync=None, total_bytes=0):
         super().__init__()
         self.sync = sync
+        self.total_bytes, self.seen_bytes, self.tail_flushed = total_bytes, 0, False
 
     def __setitem__(self, key, value):
         if self.sync is not None:
             self.sync.add(key, value)
+            # the gradients of the last layers of the backward (= the first layers of the net: a few MB of parameters behind the longest,
+            # HBM-bound kernels of the step) would otherwise wait in a half-filled bucket with ~47 MB of earlier ones until finish():
+            # send what has accumulated once only TAIL_BYTES of parameters are still to come
+            self.seen_bytes += value.numel() * value.element_size()
+            if not self.tail_flushed and self.total_bytes and self.seen_bytes >= self.total_bytes - self.TAIL_BYTES:
+                self.tail_flushed = True
+                self.sync.flush()
         else:
             super().__setitem__(key, value)
 
