@@ -206,7 +206,7 @@ def run_train(args, rank, world, dev, parallel, yo, batch, steps, warmup):
             model.grad_sync = None
     stats = {}
     try:   # kernel breakdown of the same step from the committed rocprofv3 --kernel-trace --stats run (bench.py cannot run the profiler)
-        stats = json.load(open(ROOT / "profiles" / "r02_train_step_kernel_groups.json"))
+        stats = json.load(open(ROOT / "profiles" / "r03_train_step_kernel_groups.json"))
     except (OSError, ValueError):
         pass
     rec = {
@@ -219,7 +219,7 @@ def run_train(args, rank, world, dev, parallel, yo, batch, steps, warmup):
         "roofline": {"bound": "mfma", "achieved": round(tflops, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / MFMA_PEAK_TFLOPS, 4),
                      "whole_step_frac": round(tflops / MFMA_PEAK_TFLOPS, 4), "gflop_per_image": round(flops_img / 1e9, 2),
                      "note": "whole step (fwd + dgrad + wgrad conv FLOPs per GPU / step time); kernel shares from the committed profile",
-                     "kernel_groups": stats.get("groups"), "dominant_kernel": stats.get("dominant"), "kernel_groups_source": "profiles/r02_train_step_kernel_groups.json" if stats else None},
+                     "kernel_groups": stats.get("groups"), "dominant_kernel": stats.get("dominant"), "kernel_groups_source": "profiles/r03_train_step_kernel_groups.json" if stats else None},
     }
     del model, opt, ema, crit
     torch.cuda.empty_cache()
@@ -388,6 +388,18 @@ def main():
 
         from yolov3_amd import ops as y3ops
 
+        # the same steps strictly sequentially (forward -> NMS on one stream), outside the timed region: `value` depends on the two-stream
+        # schedule, this is the figure without it (same process, same box)
+        seq = None
+        if not args.no_overlap:
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for _ in range(max(5, args.steps // 2)):
+                step()
+            torch.cuda.synchronize()
+            seq = round(bs * max(5, args.steps // 2) / (time.perf_counter() - ts), 2)
         t_fwd = timed(lambda: model(x))
         t_nms = timed(lambda: non_max_suppression(pred_synth, **nms_kw))
         cand_synth = y3ops.nms_raw.last_candidates / bs
@@ -490,6 +502,7 @@ def main():
                 "parallelism": f"replicas x{world} (no data-path collective)",
                 "schedule": "sequential forward -> NMS per batch" if args.no_overlap else "NMS of batch i on a second HIP stream beside the forward of batch i+1 (every batch completes inside the timed region)",
             },
+            "sequential_images_per_sec_per_gpu": seq,
             "legs_ms": {"forward+decode": round(t_fwd * 1e3, 3), "nms_synthetic_pred": round(t_nms * 1e3, 3), "nms_on_model_output": round(t_nms_own * 1e3, 3)},
             "nms_candidates_per_image": {"synthetic_pred": round(cand_synth, 1), "model_output": round(cand_own, 1)},
             "roofline": roofline,
