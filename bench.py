@@ -226,10 +226,10 @@ def run_train(args, rank, world, dev, parallel, yo, batch, steps, warmup):
     return rec
 
 
-def train_main(args, rank, local_rank, world, dev, parallel, yo):
+def train_main(args, rank, local_rank, world, dev, parallel, yo, print_record):
     rec = run_train(args, rank, world, dev, parallel, yo, args.batch, args.steps, args.warmup)
     if rank == 0:
-        print(json.dumps(rec))
+        print_record(rec)
     parallel.finalize()
 
 
@@ -298,6 +298,15 @@ def main():
                     help="process-group backend (default nccl = RCCL; gloo: plumbing smoke with several ranks on fewer GPUs, tools/gpu_dist_smoke.sh)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON record: libraries that chat on fd 1 (RCCL prints a version banner when a communicator is
+    # created) go to stderr for the rest of the process, the record is written to the saved descriptor
+    sys.stdout.flush()
+    _json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def print_record(obj):
+        os.write(_json_fd, (json.dumps(obj) + "\n").encode())
+
     from yolov3_amd import parallel
 
     rank, local_rank, world = parallel.init(args.dist_backend)
@@ -311,7 +320,7 @@ def main():
     from yolov3_amd import DetectionModel, non_max_suppression
 
     if args.mode == "train":
-        return train_main(args, rank, local_rank, world, dev, parallel, yo)
+        return train_main(args, rank, local_rank, world, dev, parallel, yo, print_record)
 
     dtype = torch.float16 if args.dtype == "fp16" else torch.bfloat16
     bs, hw = args.batch, args.imgsz
@@ -508,6 +517,12 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
+        try:   # the UNMODIFIED reference timed where it can run (the build container; /root/reference does not exist on the GPU box): committed record
+            ref = json.load(open(ROOT / "profiles" / "r03_cpu_reference.json"))
+            out["cpu_reference_recorded"] = {"kind": ref["kind"], "host": ref["host"], "inference": ref["inference"], "train_step": ref["train_step"],
+                                             "source": "profiles/r03_cpu_reference.json (tools/cpu_reference.py, not measured in this run)"}
+        except (OSError, ValueError, KeyError):
+            pass
     # BASELINE metric part (ii): the train step, measured in the same run AFTER the timed inference region.  At N > 1 it is the
     # data-parallel step of BASELINE configs[2] (batch 64 per GPU, RCCL gradient all-reduce overlapped with the backward; `value` = images/s
     # of the whole job), so the driver's N = 1, 2, 4, 8 runs carry the training scaling curve next to the inference replicas.  The
@@ -521,7 +536,7 @@ def main():
         if rank == 0 and not state["printed"]:
             state["printed"] = True
             out["train"] = train
-            print(json.dumps(out), flush=True)
+            print_record(out)
 
     def on_timeout():
         emit({"error": f"train leg did not finish within {args.train_timeout:.0f} s (world {world})"})

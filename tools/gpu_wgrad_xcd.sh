@@ -3,9 +3,9 @@ timeout 600 python -m pytest tests/test_gpu_parity.py -q -x --tb=short -p no:cac
 tail -4 gpurun_out/wx_pytest.log
 run() { timeout 300 python bench.py --mode train --batch 64 --steps 6 --warmup 2 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['value'], d['ms_per_step'], d['final_loss'])"; }
 for i in 1 2; do
-  Y3_WGRAD_XCD=0 run "dispatch order          "
-  Y3_WGRAD_XCD=1 run "xcd groups (128 tiles)  "
-  Y3_WGRAD_XCD=2 run "xcd groups (all)        "
+  Y3_TUNE=wgrad_xcd=0 run "dispatch order          "
+  Y3_TUNE=wgrad_xcd=1 run "xcd groups (128 tiles)  "
+  Y3_TUNE=wgrad_xcd=2 run "xcd groups (all)        "
 done
-Y3_WGRAD_XCD=0 timeout 300 python tools/train_layers.py > gpurun_out/wx_layers_0.txt 2>&1
-Y3_WGRAD_XCD=1 timeout 300 python tools/train_layers.py > gpurun_out/wx_layers_1.txt 2>&1
+Y3_TUNE=wgrad_xcd=0 timeout 300 python tools/train_layers.py > gpurun_out/wx_layers_0.txt 2>&1
+Y3_TUNE=wgrad_xcd=1 timeout 300 python tools/train_layers.py > gpurun_out/wx_layers_1.txt 2>&1

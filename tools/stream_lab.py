@@ -48,7 +48,7 @@ def main():
         flops = 2.0 * n * h * w * cout * cin * k * k / (s * s)
         for arm in ("nows", "v7whole"):
             if arm == "v7whole":
-                os.environ["Y3_V7_GRID"] = "-1"
+                ops.tune_set("v7_grid", -1); ops.tune_set("conv_v9", 0)
             for S in (1, 2, 4, 8):
                 nb = n // S
                 xs, ys = [], []
@@ -82,7 +82,7 @@ def main():
                 med = statistics.median(ts)
                 print(f"{name:26s} {arm:8s} {S:7d} {med:24.1f} {flops / med / 1e6:8.1f}")
                 sys.stdout.flush()
-            os.environ.pop("Y3_V7_GRID", None)
+            ops.tune_reset()
 
 
 if __name__ == "__main__":

@@ -41,9 +41,8 @@ def main():
         filt = ops.pack_filter((torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)).to(dev), cout, cin, torch.float16)
         bias = torch.randn(cout, generator=g).to(dev)
         yv = ops.View.alloc(n, h, w, cout, torch.float16, dev)
-        for sched in ("0", "1"):
-            os.environ["Y3_V7_GRID"] = "-1"
-            os.environ["Y3_V7_SCHED"] = sched
+        for sched in ("0",):
+            ops.tune_set("v7_grid", -1); ops.tune_set("conv_v9", 0)
             tl = torch.zeros(64 * 8 * 8, dtype=torch.int64, device=dev)
             for _ in range(3):
                 ops.conv2d(xv, filt, bias, yv, 3, 1, True, None, workspace=ws)
@@ -62,7 +61,7 @@ def main():
             for half, wvs in (("leading waves 0-3", [0, 1, 2, 3]), ("trailing waves 4-7", [4, 5, 6, 7])):
                 m = t[:32, wvs, :5].mean(dim=(0, 1)) / per_block_steps
                 print(f"    {half}: MEM issue {m[0]:.0f}  vmcnt wait {m[1]:.0f}  barrier(MEM) {m[2]:.0f}  MMA issue {m[3]:.0f}  barrier(MMA) {m[4]:.0f}  sum {m.sum():.0f}")
-        os.environ.pop("Y3_V7_GRID"); os.environ.pop("Y3_V7_SCHED")
+        ops.tune_reset()
 
 
 if __name__ == "__main__":
