@@ -143,18 +143,23 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_v9_kernel(const ConvArgs p)
     };
     // ABL 9 (lab): the filter operand straight into registers in MFMA-fragment order (1 KiB contiguous per instruction, what a fragment-packed
     // bank would allow) instead of LDS-DMA + ds_read: inline asm so that the waitcnt pass does not see an ordinary load beside the DMA
-    frag Aring[ABL == 9 ? 3 : 1][4];
+    frag Aring[(ABL == 9 || ABL == 12) ? 3 : 1][4];
     u32x4 wdesc = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)p.w)), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)p.w >> 32)),
                    p.w_bytes, 0x00020000u};
     const unsigned wlin = (unsigned)(((long long)(ct * 256 + wv * 64) * p.Kpad) * 2) + (unsigned)lane * 16u;
+    // ABL 12: the same register loads in FRAGMENT shape from the row-major bank as it is (lane -> row frow of 32-row block a, 16 bytes of k-group fk + 2 kk)
+    unsigned wfrag[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wfrag[j] = (unsigned)(((long long)(ct * 256 + wv * 64 + (j & 1) * 32 + frow) * p.Kpad) * 2) + (unsigned)((j >> 1) * 32 + fk * 16);
     auto ld_w = [&](int kbyte, auto ST) {
-        constexpr int st = decltype(ST)::value < (ABL == 9 ? 3 : 1) ? decltype(ST)::value : 0;   // (only called in the ABL 9 instantiation)
+        constexpr int st = decltype(ST)::value < ((ABL == 9 || ABL == 12) ? 3 : 1) ? decltype(ST)::value : 0;   // (only called in the ABL 9 / 12 instantiations)
         auto& ring = Aring;   // (operands of an asm statement alone do not make a generic lambda capture a variable)
         const unsigned wl = wlin;
         const u32x4 wd = wdesc;
+        unsigned wf[4] = {wfrag[0], wfrag[1], wfrag[2], wfrag[3]};
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(ring[st][j]) : "v"(wl + (unsigned)(j * 1024)), "s"(wd), "s"(kbyte) : "memory");
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(ring[st][j]) : "v"(ABL == 12 ? wf[j] : wl + (unsigned)(j * 1024)), "s"(wd), "s"(kbyte) : "memory");
     };
     auto mma = [&](const frag (&af)[MC], const frag (&bf)[MP]) {
 #pragma unroll
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_v9_kernel(const ConvArgs p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the bias loads share the counter
 #pragma unroll
     for (int i = 0; i < NXP; ++i) dma_x(i, 0, 0, true);
-    if constexpr (ABL == 9) {
+    if constexpr (ABL == 9 || ABL == 12) {
         ld_w(0, IC<0>{});
         ld_w(p.Cin * 2, IC<1>{});
     } else {
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_v9_kernel(const ConvArgs p)
             constexpr int ntap = (tap + 1) % 9, ndh = ntap / 3, ndw = ntap % 3;
             constexpr int tap2 = (tap + 2) % 9;
             // ---- phase 1: MFMAs of substep 0 | fragment reads of substep 1, filter tile of K-step s + 2 (stage (s + 2) % 3 = (tap + 2) % 3: 9 % 3 == 0)
-            if constexpr (ABL == 9) {
+            if constexpr (ABL == 9 || ABL == 12) {
                 A0[0] = Aring[tap % 3][0]; A0[1] = Aring[tap % 3][1]; A1[0] = Aring[tap % 3][2]; A1[1] = Aring[tap % 3][3];
             } else if constexpr (ABL == 4 || ABL == 5 || ABL == 7) {
 #pragma unroll
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_v9_kernel(const ConvArgs p)
 #pragma unroll
                 for (int b = 0; b < MP; ++b) B1[b] = *(const frag*)(smem + bb[dh][b] + dw * V9_PITCH + 32);
             }
-            if constexpr (ABL == 9) ld_w((tap2 * p.Cin + (cb + (tap + 2 >= 9 ? 1 : 0)) * 32) * 2, IC<tap2 % 3>{});
+            if constexpr (ABL == 9 || ABL == 12) ld_w((tap2 * p.Cin + (cb + (tap + 2 >= 9 ? 1 : 0)) * 32) * 2, IC<tap2 % 3>{});
             else if constexpr (ABL != 1 && ABL != 7) dma_w((tap2 * p.Cin + (cb + (tap + 2 >= 9 ? 1 : 0)) * 32) * 2, tap2 % 3);
             if constexpr (ABL != 6) mma(A0, B0);
             else {
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_v9_kernel(const ConvArgs p)
                     for (int b = 0; b < MP; ++b) bb[d][b] += bufd;
                 bufd = -bufd;
             }
-            if constexpr (ABL == 9) {
+            if constexpr (ABL == 9 || ABL == 12) {
             } else if constexpr (ABL == 4 || ABL == 5 || ABL == 7) {
 #pragma unroll
                 for (int a = 0; a < MC; ++a) asm volatile("" : "=v"(A0[a]));
@@ -434,7 +439,7 @@ template <typename T> int launch_v9(ConvArgs& a, hipStream_t st) {
 #ifdef Y3_ABLATE
     if (const char* e = getenv("Y3_V9_ABL")) {   // lab build only
         const int abl = atoi(e);
-        if (pl.mp == 7 && !two && abl >= 1 && abl <= 11) {
+        if (pl.mp == 7 && !two && abl >= 1 && abl <= 12) {
             switch (abl) {
                 case 1: hipLaunchKernelGGL((conv_igemm_v9_kernel<T, 7, 1, 1>), grid, block, 0, st, a); break;
                 case 2: hipLaunchKernelGGL((conv_igemm_v9_kernel<T, 7, 1, 2>), grid, block, 0, st, a); break;
@@ -446,6 +451,7 @@ template <typename T> int launch_v9(ConvArgs& a, hipStream_t st) {
                 case 9: hipLaunchKernelGGL((conv_igemm_v9_kernel<T, 7, 1, 9>), grid, block, 0, st, a); break;
                 case 10: hipLaunchKernelGGL((conv_igemm_v9_kernel<T, 7, 1, 10>), grid, block, 0, st, a); break;
                 case 11: hipLaunchKernelGGL((conv_igemm_v9_kernel<T, 7, 1, 11>), grid, block, 0, st, a); break;
+                case 12: hipLaunchKernelGGL((conv_igemm_v9_kernel<T, 7, 1, 12>), grid, block, 0, st, a); break;
                 default: hipLaunchKernelGGL((conv_igemm_v9_kernel<T, 7, 1, 8>), grid, block, 0, st, a); break;
             }
             Y3_CHECK_LAUNCH();

@@ -637,7 +637,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_big_kernel(const WgradArgs p) {
     const int prow = lane >> 5, pslot = lane & 31;
     int a_ch[2], b_ci[2], b_kh[2], b_kw[2];
     bool a_ok[2], b_ok[2];
-    int cm[2], cn[2], cho[2], cwo[2];    // pixel cursor of the lane's row in piece j: flat index, image, output row, output column
+    // pixel cursor of the lane's row in piece j: flat output index, output row / column (for the wraps), and -- advanced INCREMENTALLY, no
+    // multiplication per K-step (round 3: the per-step `v_mul_lo_u32` / `v_mad_u64_u32` of the offset arithmetic cost more issue time than the
+    // requests they fed) -- the input row / column of the lane's tap and the byte offsets of its 16 bytes in du and x
+    int cm[2], cho[2], cwo[2], chi[2], cwi[2];
+    unsigned aoffv[2], xlin[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int row = 2 * j + prow;                    // row & 3 (4w is a multiple of 4)
@@ -653,12 +657,24 @@ __global__ __launch_bounds__(512, 2) void wgrad_big_kernel(const WgradArgs p) {
         const long long m = m_begin + wv * 4 + row;
         const int mm = (int)(m < p.M ? m : p.M - 1);
         cm[j] = (int)m;
-        cn[j] = y3_fdiv(mm, p.dv_hw);
-        const int rem = mm - cn[j] * (p.Ho * p.Wo);
+        const int n0 = y3_fdiv(mm, p.dv_hw);
+        const int rem = mm - n0 * (p.Ho * p.Wo);
         cho[j] = y3_fdiv(rem, p.dv_w);
         cwo[j] = rem - cho[j] * p.Wo;
+        chi[j] = cho[j] * p.stride - p.pad + b_kh[j];
+        cwi[j] = cwo[j] * p.stride - p.pad + b_kw[j];
+        aoffv[j] = ((unsigned)cm[j] * (unsigned)p.dpitch + (unsigned)a_ch[j]) * 2u;
+        xlin[j] = (unsigned)(((n0 * p.H + chi[j]) * p.W + cwi[j]) * p.xpitch + b_ci[j]) * 2u;   // meaningful only while (chi, cwi) is inside the image
     }
     const int m_end_i = (int)m_end;
+    // what a K-step of 32 pixels = (step_n images, step_q rows, step_r columns) adds, and what a column / row wrap of the cursor adds on top
+    const int xp2 = p.xpitch * 2;
+    const unsigned a_step = (unsigned)(BKP * p.dpitch * 2);
+    const int wi_step = p.step_r * p.stride, wi_wrap = p.Wo * p.stride;
+    const int hi_step = p.step_q * p.stride, hi_wrap = p.Ho * p.stride;
+    const unsigned x_step = (unsigned)(((p.step_n * p.H + p.step_q * p.stride) * p.W + p.step_r * p.stride) * xp2);
+    const unsigned x_wrapw = (unsigned)((p.stride * p.W - p.Wo * p.stride) * xp2);            // column cursor back by Wo, row cursor forward by one
+    const unsigned x_wraph = (unsigned)((p.H - p.Ho * p.stride) * p.W * xp2);                 // row cursor back by Ho, image forward by one
 
     auto dma = [&](int stage) {   // K-steps are requested strictly in order: the cursors advance by 32 pixels per call
         unsigned char* al = smem + stage * STAGE;
@@ -666,18 +682,23 @@ __global__ __launch_bounds__(512, 2) void wgrad_big_kernel(const WgradArgs p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const bool live = cm[j] < m_end_i;
-            const unsigned aoff = (live && a_ok[j]) ? ((unsigned)cm[j] * (unsigned)p.dpitch + (unsigned)a_ch[j]) * 2u : OOB;
-            const int hi = cho[j] * p.stride - p.pad + b_kh[j], wi = cwo[j] * p.stride - p.pad + b_kw[j];
-            const bool inb = live && b_ok[j] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            const unsigned boff = inb ? (unsigned)(((cn[j] * p.H + hi) * p.W + wi) * p.xpitch + b_ci[j]) * 2u : OOB;
+            const unsigned aoff = (live && a_ok[j]) ? aoffv[j] : OOB;
+            const bool inb = live && b_ok[j] && (unsigned)chi[j] < (unsigned)p.H && (unsigned)cwi[j] < (unsigned)p.W;
+            const unsigned boff = inb ? xlin[j] : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (lds_ptr_t)(al + (wv * 4 + j * 2) * ROWB), 16, aoff, 0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(bl + (wv * 4 + j * 2) * ROWB), 16, boff, 0, 0, 0);
             cm[j] += BKP;
-            cn[j] += p.step_n;
+            aoffv[j] += a_step;
             cwo[j] += p.step_r;
             cho[j] += p.step_q;
-            if (cwo[j] >= p.Wo) { cwo[j] -= p.Wo; ++cho[j]; }
-            if (cho[j] >= p.Ho) { cho[j] -= p.Ho; ++cn[j]; }   // step_q <= Ho - 1: one wrap is enough
+            const bool ww = cwo[j] >= p.Wo;
+            cwo[j] -= ww ? p.Wo : 0;
+            cho[j] += ww ? 1 : 0;
+            const bool wh = cho[j] >= p.Ho;   // step_q <= Ho - 1: one wrap is enough
+            cho[j] -= wh ? p.Ho : 0;
+            cwi[j] += wi_step - (ww ? wi_wrap : 0);
+            chi[j] += hi_step + (ww ? p.stride : 0) - (wh ? hi_wrap : 0);
+            xlin[j] += x_step + (ww ? x_wrapw : 0u) + (wh ? x_wraph : 0u);
         }
     };
 
