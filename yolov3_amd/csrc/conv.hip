@@ -490,7 +490,7 @@ Y3_DEV void conv_igemm_v3_body(const ConvArgs& p, const int block_id, const int 
     const int pslot = tid % S;   // physical 16-byte slot this lane fills in every row it touches
     const int row0 = tid / S;
 
-    int xoff[XJ], hi0[XJ], wi0[XJ], xc0[XJ];
+    int xoff[XJ], hi0[XJ], wi0[XJ], xc0[XJ], xlin0[XJ];
     bool mvalid[XJ];
 #pragma unroll
     for (int j = 0; j < XJ; ++j) {
@@ -505,7 +505,10 @@ Y3_DEV void conv_igemm_v3_body(const ConvArgs& p, const int block_id, const int 
         xoff[j] = (int)(((long long)n * p.H * p.W * p.xpitch) * 2);  // byte offset of image n
         xc0[j] = ((pslot ^ swz<BK>(row)) * 8) * 2;          // byte offset of the logical slot inside the K-step
         mvalid[j] = v;
+        // plain (non-dilated) input: the lane's offset is a per-lane constant + a per-K-step SCALAR ((kh W + kw) xpitch + channel block), see dma
+        xlin0[j] = xoff[j] + ((hi0[j] * p.W + wi0[j]) * p.xpitch) * 2 + xc0[j];
     }
+    const bool plain_x = p.dil_shift == 0;   // kernel-uniform
     unsigned woff[WJ];
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
@@ -523,12 +526,23 @@ Y3_DEV void conv_igemm_v3_body(const ConvArgs& p, const int block_id, const int 
 #pragma unroll
         for (int j = 0; j < WJ; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(wl + (j * 256 + wv * 64) * 16), 16, woff[j] + (unsigned)(it * BK * 2), 0, 0, 0);
+        if (plain_x) {
+            // (round 3) no multiplication per piece: the per-K-step part of the offset is scalar
+            const int s_tap = ((kh * p.W + kw) * p.xpitch + cb * BK) * 2;
 #pragma unroll
-        for (int j = 0; j < XJ; ++j) {
-            const int hi = hi0[j] + kh, wi = wi0[j] + kw;
-            const bool ok = (int)mvalid[j] & (int)in_image(hi, wi, p);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(xl + (j * 256 + wv * 64) * 16), 16,
-                                                     ok ? (unsigned)(xoff[j] + tap_bytes(hi0[j], wi0[j], kh, kw, cb * BK, p) + xc0[j]) : OOB, 0, 0, 0);
+            for (int j = 0; j < XJ; ++j) {
+                const int hi = hi0[j] + kh, wi = wi0[j] + kw;
+                const bool ok = (int)mvalid[j] & (int)((unsigned)hi < (unsigned)p.H) & (int)((unsigned)wi < (unsigned)p.W);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(xl + (j * 256 + wv * 64) * 16), 16, ok ? (unsigned)(xlin0[j] + s_tap) : OOB, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < XJ; ++j) {
+                const int hi = hi0[j] + kh, wi = wi0[j] + kw;
+                const bool ok = (int)mvalid[j] & (int)in_image(hi, wi, p);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(xl + (j * 256 + wv * 64) * 16), 16,
+                                                         ok ? (unsigned)(xoff[j] + tap_bytes(hi0[j], wi0[j], kh, kw, cb * BK, p) + xc0[j]) : OOB, 0, 0, 0);
+            }
         }
     };
 
@@ -689,7 +703,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v6_kernel(const ConvArgs p)
     const int pslot = tid % S;   // physical 16-byte slot this lane fills in every row it touches
     const int row0 = tid / S;
 
-    int xoff[XJ], hi0[XJ], wi0[XJ], xc0[XJ];
+    int xoff[XJ], hi0[XJ], wi0[XJ], xc0[XJ], xlin0[XJ];
     bool mvalid[XJ];
 #pragma unroll
     for (int j = 0; j < XJ; ++j) {
@@ -704,7 +718,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v6_kernel(const ConvArgs p)
         xoff[j] = (int)(((long long)n * p.H * p.W * p.xpitch) * 2);  // byte offset of image n
         xc0[j] = ((pslot ^ swz<BK>(row)) * 8) * 2;          // byte offset of the logical slot inside the K-step
         mvalid[j] = v;
+        // plain (non-dilated) input: the lane's offset is a per-lane constant + a per-K-step SCALAR ((kh W + kw) xpitch + channel block), see dma
+        xlin0[j] = xoff[j] + ((hi0[j] * p.W + wi0[j]) * p.xpitch) * 2 + xc0[j];
     }
+    const bool plain_x = p.dil_shift == 0;   // kernel-uniform
     unsigned woff[WJ];
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
@@ -722,12 +739,22 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v6_kernel(const ConvArgs p)
 #pragma unroll
         for (int j = 0; j < WJ; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(wl + (j * NT + wv * 64) * 16), 16, woff[j] + (unsigned)(it * BK * 2), 0, 0, 0);
+        if (plain_x) {
+            const int s_tap = ((kh * p.W + kw) * p.xpitch + cb * BK) * 2;   // (round 3) the per-K-step part of the offset is scalar: no multiplication per piece
 #pragma unroll
-        for (int j = 0; j < XJ; ++j) {
-            const int hi = hi0[j] + kh, wi = wi0[j] + kw;
-            const bool ok = (int)mvalid[j] & (int)in_image(hi, wi, p);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(xl + (j * NT + wv * 64) * 16), 16,
-                                                     ok ? (unsigned)(xoff[j] + tap_bytes(hi0[j], wi0[j], kh, kw, cb * BK, p) + xc0[j]) : OOB, 0, 0, 0);
+            for (int j = 0; j < XJ; ++j) {
+                const int hi = hi0[j] + kh, wi = wi0[j] + kw;
+                const bool ok = (int)mvalid[j] & (int)((unsigned)hi < (unsigned)p.H) & (int)((unsigned)wi < (unsigned)p.W);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(xl + (j * NT + wv * 64) * 16), 16, ok ? (unsigned)(xlin0[j] + s_tap) : OOB, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < XJ; ++j) {
+                const int hi = hi0[j] + kh, wi = wi0[j] + kw;
+                const bool ok = (int)mvalid[j] & (int)in_image(hi, wi, p);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(xl + (j * NT + wv * 64) * 16), 16,
+                                                         ok ? (unsigned)(xoff[j] + tap_bytes(hi0[j], wi0[j], kh, kw, cb * BK, p) + xc0[j]) : OOB, 0, 0, 0);
+            }
         }
     };
 

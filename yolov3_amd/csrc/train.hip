@@ -475,24 +475,60 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(const WgradArgs p) {
     const int b_kh = b_tap / p.ks, b_kw = b_tap - b_kh * p.ks;
     const bool b_ok = b_tap < p.ks * p.ks;
 
-    auto dma = [&](int it, int stage) {
+    // pixel cursors of the lane's four rows (rows 16 w + 4 j + prow of a K-step), advanced incrementally by one K-step of 64 pixels: output
+    // row / column (for the wraps), input row / column of the lane's tap, byte offsets of its 16 bytes in du and x -- no division and no
+    // multiplication per K-step (round 3; the stateless form recomputed two multiply-shift divisions and five multiplies per row and K-step)
+    int cm[4], cho[4], cwo[4], chi[4], cwi[4];
+    unsigned aoffv[4], xlin[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long long m = m_begin + wv * 16 + j * 4 + prow;
+        const int mm = (int)(m < p.M ? m : p.M - 1);
+        cm[j] = (int)m;
+        const int n0 = y3_fdiv(mm, p.dv_hw);
+        const int rem = mm - n0 * (p.Ho * p.Wo);
+        cho[j] = y3_fdiv(rem, p.dv_w);
+        cwo[j] = rem - cho[j] * p.Wo;
+        chi[j] = cho[j] * p.stride - p.pad + b_kh;
+        cwi[j] = cwo[j] * p.stride - p.pad + b_kw;
+        aoffv[j] = ((unsigned)cm[j] * (unsigned)p.dpitch + (unsigned)a_ch) * 2u;
+        xlin[j] = (unsigned)(((n0 * p.H + chi[j]) * p.W + cwi[j]) * p.xpitch + b_ci) * 2u;   // meaningful only while (chi, cwi) is inside the image
+    }
+    const int m_end_i = (int)m_end;
+    const int st_n = y3_fdiv(BKP, p.dv_hw), st_rem = BKP - st_n * (p.Ho * p.Wo);          // 64 pixels = (st_n images, st_q rows, st_r columns)
+    const int st_q = y3_fdiv(st_rem, p.dv_w), st_r = st_rem - st_q * p.Wo;
+    const int xp2 = p.xpitch * 2;
+    const unsigned a_step = (unsigned)(BKP * p.dpitch * 2);
+    const int wi_step = st_r * p.stride, wi_wrap = p.Wo * p.stride;
+    const int hi_step = st_q * p.stride, hi_wrap = p.Ho * p.stride;
+    const unsigned x_step = (unsigned)(((st_n * p.H + st_q * p.stride) * p.W + st_r * p.stride) * xp2);
+    const unsigned x_wrapw = (unsigned)((p.stride * p.W - p.Wo * p.stride) * xp2);
+    const unsigned x_wraph = (unsigned)((p.H - p.Ho * p.stride) * p.W * xp2);
+
+    auto dma = [&](int it, int stage) {   // K-steps are requested strictly in order (it = 0, 1, 2, ...): the cursors advance by one K-step per call
+        (void)it;
         unsigned char* al = smem + stage * STAGE;
         unsigned char* bl = al + TILE;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int row = wv * 16 + j * 4 + prow;
-            const long long m = m_begin + (long long)it * BKP + row;
-            const bool live = m < m_end;
-            const int mm = live ? (int)m : 0;
-            const int n = y3_fdiv(mm, p.dv_hw);
-            const int rem = mm - n * (p.Ho * p.Wo);
-            const int ho = y3_fdiv(rem, p.dv_w), wo = rem - ho * p.Wo;
-            const unsigned aoff = (live && a_ok) ? (unsigned)(((long long)mm * p.dpitch + a_ch) * 2) : OOB;
-            const int hi = ho * p.stride - p.pad + b_kh, wi = wo * p.stride - p.pad + b_kw;
-            const bool inb = live && b_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            const unsigned boff = inb ? (unsigned)((((long long)(n * p.H + hi) * p.W + wi) * p.xpitch + b_ci) * 2) : OOB;
+            const bool live = cm[j] < m_end_i;
+            const unsigned aoff = (live && a_ok) ? aoffv[j] : OOB;
+            const bool inb = live && b_ok && (unsigned)chi[j] < (unsigned)p.H && (unsigned)cwi[j] < (unsigned)p.W;
+            const unsigned boff = inb ? xlin[j] : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (lds_ptr_t)(al + (wv * 16 + j * 4) * ROWB), 16, aoff, 0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(bl + (wv * 16 + j * 4) * ROWB), 16, boff, 0, 0, 0);
+            cm[j] += BKP;
+            aoffv[j] += a_step;
+            cwo[j] += st_r;
+            cho[j] += st_q;
+            const bool ww = cwo[j] >= p.Wo;
+            cwo[j] -= ww ? p.Wo : 0;
+            cho[j] += ww ? 1 : 0;
+            const bool wh = cho[j] >= p.Ho;   // st_q <= Ho - 1: one wrap is enough
+            cho[j] -= wh ? p.Ho : 0;
+            cwi[j] += wi_step - (ww ? wi_wrap : 0);
+            chi[j] += hi_step + (ww ? p.stride : 0) - (wh ? hi_wrap : 0);
+            xlin[j] += x_step + (ww ? x_wrapw : 0u) + (wh ? x_wraph : 0u);
         }
     };
 
