@@ -1616,6 +1616,23 @@ def test_train_two_outstanding_forwards_keep_their_activations(dev):
     with pytest.raises(RuntimeError, match="overwritten by a later forward"):
         held[0].backward()
     held[2].backward()
+    # a forward whose graph is dropped without a backward frees its slot (round-2 advisor finding): afterwards a fresh forward / backward
+    # pair runs in slot 0 again and no plan is left marked busy
+    from yolov3_amd.engine import plan_cache
+
+    del held
+    m.zero_grad(set_to_none=True)
+    dropped = crit(m(xs[0]), tgs[0])[0]
+    del dropped
+    import gc
+
+    gc.collect()
+    tplans = [p_ for k, p_ in plan_cache(m).plans.items() if k[0] == "train"]
+    assert tplans and not any(p_.outstanding for p_ in tplans), [p_.outstanding for p_ in tplans]
+    crit(m(xs[0]), tgs[0])[0].backward()
+    torch.cuda.synchronize()
+    for p, a in zip(m.parameters(), sep[0]):
+        torch.testing.assert_close(p.grad, a, rtol=1e-4, atol=1e-6)
 
 
 def test_gradient_exchange_over_rccl_one_rank(dev):
@@ -1720,7 +1737,7 @@ parallel.finalize()
 def test_loss_rejects_out_of_range_targets(dev):
     """a target with image index >= bs (or < 0) or class >= nc used to index out of bounds in the match kernels; the
     reference raises an IndexError.  Here the row is dropped on the device and the loss comes back NaN (no host sync to raise
-    from): loud, and nothing is read or written out of bounds (the valid rows still produce finite gradients)."""
+    from), and so does every gradient of the backward: loud, and nothing is read or written out of bounds."""
     hyp = dict(box=0.05, cls=0.5, cls_pw=1.0, obj=1.0, obj_pw=1.0, anchor_t=4.0, fl_gamma=0.0, label_smoothing=0.0)
     m, crit = _loss_setup(dev, "yolov3-tiny", 5, 64, hyp)
     p = [(torch.rand(2, 3, 64 // s, 64 // s, 10, device=dev) * 4 - 2).requires_grad_(True) for s in (16, 32)]
@@ -1729,10 +1746,15 @@ def test_loss_rejects_out_of_range_targets(dev):
     assert torch.isfinite(loss).all()
     for bad_row in ([2, 1, 0.5, 0.5, 0.3, 0.3], [-1, 1, 0.5, 0.5, 0.3, 0.3], [0, 5, 0.5, 0.5, 0.3, 0.3], [0, -2, 0.5, 0.5, 0.3, 0.3], [70000, 1, 0.5, 0.5, 0.3, 0.3]):
         tg = torch.cat([good, torch.tensor([bad_row], device=dev, dtype=torch.float32)])
+        for q in p:
+            q.grad = None
         loss, items = crit(p, tg)
         loss.sum().backward()
         torch.cuda.synchronize()
         assert torch.isnan(loss).all() and torch.isnan(items).all(), bad_row
+        # the backward is poisoned too (round 3): the objectness gradient reaches every cell, so every level's gradient is NaN and a
+        # GradScaler-driven loop skips the step instead of applying the valid rows' gradients
+        assert all(torch.isnan(q.grad[..., 4]).all() for q in p), bad_row
 
 
 def test_model_rejects_wrong_channel_count(dev):

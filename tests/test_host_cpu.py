@@ -288,6 +288,12 @@ def test_plans_live_outside_the_module_and_are_bounded():
         pc.put(("train", 1, 64, 64, torch.float16, 0, s_), object())
     kinds = [k[0] for k in pc.plans]
     assert kinds.count("eval") == PlanCache.MAX_EVAL and kinds.count("train") == PlanCache.MAX_TRAIN
+    # training plans are capped per SHAPE (slots of outstanding forwards) and by the number of shapes, least recently used shape first
+    for hw in (96, 128, 160, 192):
+        pc.put(("train", 1, hw, hw, torch.float16, 0, 0), object())
+    tshapes = [k[1:6] for k in pc.plans if k[0] == "train"]
+    assert len(set(tshapes)) == PlanCache.MAX_TRAIN_SHAPES and (1, 64, 64, torch.float16, 0) not in tshapes and (1, 192, 192, torch.float16, 0) in tshapes
+    assert [k[0] for k in pc.plans].count("eval") == PlanCache.MAX_EVAL
     assert ("eval", 1, 32, 32, torch.float16, 0, 0) not in pc.plans            # the oldest went first
     assert len(m._plans) == len(pc.plans) and "_plans" not in m.__dict__
     m2 = copy.deepcopy(m)                                                       # used to raise: cannot pickle 'CArgObject'

@@ -429,14 +429,23 @@ int loss_fwd(const y3_loss_params* p, const void* const* preds, const float* tar
 
 // scale factors need the per-level match count, which lives on the device: a tiny kernel turns it into the
 // three per-level multipliers so the backward needs no host round trip.
-__global__ void loss_scales_kernel(LossDev P, FinalArgs F, const float* __restrict__ grad_out, float* __restrict__ scales /* nl*3 */) {
+__global__ void loss_scales_kernel(LossDev P, FinalArgs F, const float* __restrict__ targets, const float* __restrict__ grad_out, float* __restrict__ scales /* nl*3 */) {
+    // a target row outside the batch / class range made the forward return NaN (loss_final_kernel; the reference raises IndexError on the
+    // host); the BACKWARD of such a call is poisoned the same way -- every gradient NaN, so GradScaler's found-inf skips the step
+    // (round-2 advisor finding: finite gradients of the valid rows used to let the optimizer step on a batch the reference would have rejected)
+    bool bad = false;
+    for (int t = threadIdx.x; t < P.nt; t += 64) {
+        const int tb = (int)targets[(long long)t * 6], tc = (int)targets[(long long)t * 6 + 1];
+        bad |= tb < 0 || tb >= P.bs || tc < 0 || tc >= P.nc;
+    }
+    bad = __ballot(bad) != 0ull;
     const int i = threadIdx.x;
     if (i >= P.nl) return;
-    const float go = grad_out ? grad_out[0] : 1.0f;
+    const float go = bad ? __builtin_nanf("") : (grad_out ? grad_out[0] : 1.0f);
     const float n = F.sums[i][0];
     const float bsf = (float)P.bs;
-    scales[i * 3 + 0] = n > 0.0f ? go * bsf * P.box_gain / n : 0.0f;
-    scales[i * 3 + 1] = (n > 0.0f && P.nc > 1) ? go * bsf * P.cls_gain / (n * (float)P.nc) : 0.0f;
+    scales[i * 3 + 0] = (n > 0.0f || bad) ? go * bsf * P.box_gain / (n > 0.0f ? n : 1.0f) : 0.0f;
+    scales[i * 3 + 1] = ((n > 0.0f && P.nc > 1) || bad) ? go * bsf * P.cls_gain / ((n > 0.0f ? n : 1.0f) * (float)P.nc) : 0.0f;
     scales[i * 3 + 2] = go * bsf * P.obj_gain * P.balance[i] / (float)F.cells[i];
 }
 
@@ -454,7 +463,7 @@ int loss_bwd(const y3_loss_params* p, const void* const* preds, const float* tar
         F.cells[i] = Ws[i].cells;
     }
     float* scales = (float*)(ws + off);
-    hipLaunchKernelGGL(loss_scales_kernel, dim3(1), dim3(64), 0, st, D, F, grad_out, scales);
+    hipLaunchKernelGGL(loss_scales_kernel, dim3(1), dim3(64), 0, st, D, F, targets, grad_out, scales);
     Y3_CHECK_LAUNCH();
     const int no = p->nc + 5;
     for (int i = 0; i < p->nl; ++i) {

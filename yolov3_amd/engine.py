@@ -675,7 +675,8 @@ class PlanCache:
     shared by all eval plans and live as long as the parameters are not modified."""
 
     MAX_EVAL = int(os.environ.get("Y3_MAX_PLANS", "6"))
-    MAX_TRAIN = int(os.environ.get("Y3_MAX_TRAIN_PLANS", "2"))
+    MAX_TRAIN = int(os.environ.get("Y3_MAX_TRAIN_PLANS", "2"))          # outstanding forwards per shape
+    MAX_TRAIN_SHAPES = int(os.environ.get("Y3_MAX_TRAIN_SHAPES", "3"))   # distinct (batch, h, w, dtype) training shapes kept compiled
 
     def __init__(self):
         self.plans: "OrderedDict" = OrderedDict()
@@ -697,11 +698,24 @@ class PlanCache:
 
     def put(self, key, plan):
         self.plans[key] = plan
-        train = key[0] == "train"
-        same = [k for k in self.plans if (k[0] == "train") == train]
-        cap = self.MAX_TRAIN if train else self.MAX_EVAL
-        for k in same[: max(0, len(same) - cap)]:
-            del self.plans[k]   # the activation pool / workspace go back to torch's allocator once the last launch that uses them has run
+        if key[0] != "train":
+            same = [k for k in self.plans if k[0] != "train"]
+            for k in same[: max(0, len(same) - self.MAX_EVAL)]:
+                del self.plans[k]   # the activation pool / workspace go back to torch's allocator once the last launch that uses them has run
+            return
+        # training plans: MAX_TRAIN slots per SHAPE (a slot = one outstanding forward, train_engine.run_model_train) and at most
+        # MAX_TRAIN_SHAPES shapes (multi-scale training, a short last batch), least recently used shape first -- a global cap of two plans
+        # rebuilt a plan (and its zeroed conv workspace) on every change of shape (round-2 advisor finding)
+        shapes = []
+        for k in self.plans:
+            if k[0] == "train" and k[1:6] not in shapes:
+                shapes.append(k[1:6])
+        for shp in shapes[: max(0, len(shapes) - self.MAX_TRAIN_SHAPES)]:
+            for k in [k for k in self.plans if k[0] == "train" and k[1:6] == shp]:
+                del self.plans[k]
+        mine = [k for k in self.plans if k[0] == "train" and k[1:6] == key[1:6]]
+        for k in mine[: max(0, len(mine) - self.MAX_TRAIN)]:
+            del self.plans[k]
 
 
 _PLAN_CACHES: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
@@ -744,7 +758,8 @@ def run_model(model, x: torch.Tensor, profile=False):
         refs = list(model.parameters()) + list(model.buffers())
         version = (_param_version(refs), len(refs))
         if pc.weights_version != version:   # parameters were modified in place (or replaced) since the filters were packed
-            pc.plans.clear()
+            for k in [k for k in pc.plans if k[0] != "train"]:   # training plans re-pack their banks from the fp32 masters every forward: they stay
+                del pc.plans[k]
             pc.weights.clear()
             pc.weights_version = version
         plan = pc.get(key)

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 
 import torch
 from torch import nn
@@ -639,12 +640,29 @@ class _GradSink(dict):
         return self.sync.finish() if self.sync is not None else self
 
 
+class _SlotToken:
+    """lives in the autograd context of one training forward; its destruction (backward done and graph freed, or graph dropped without a
+    backward) releases the plan slot that forward occupied, unless a later forward has taken the plan over since"""
+
+    def __init__(self, plan, generation):
+        self.plan, self.generation = weakref.ref(plan), generation
+
+    def __del__(self):
+        pl = self.plan()
+        if pl is not None and pl.generation == self.generation:
+            pl.outstanding = False
+
+
 class _TrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plan, x, *params):
         ctx.plan = plan
         raws = plan.forward(x)
         ctx.generation = plan.generation
+        # a forward whose graph is dropped without a backward (an exception in the loss, a dry run under grad mode) must not pin the plan's
+        # slot forever: the token dies with the autograd node and marks the plan idle again (round-2 advisor finding)
+        ctx._slot_token = _SlotToken(plan, plan.generation)
+        raws = [r.detach() for r in raws]   # fresh tensor objects: the plan keeps its own (HeadUnit.raw) and must not hold the autograd node through them
         return tuple(raws)
 
     @staticmethod
