@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256, 2) void stem_pair_kernel(const PairArgs p) {
 // Here a block owns an 8 x 32 tile of output pixels: the 10 x 34 pixel patch of x goes to LDS once by LDS-DMA (the next tile's patch
 // streams in under this tile's cv2), cv1 (+ bias + SiLU, rounded to T as the stored tensor would be, zero outside the image = cv2's
 // padding) runs on the 340 patch pixels into LDS, cv2 reads its nine taps out of LDS with the wave's 9 * C/32 filter fragments
-// resident in registers (the layer-1 half of stem_pair with stride 1), and the residual is re-read from global memory (L2 hits).
+// resident in registers (the layer-1 half of stem_pair with stride 1), and the residual is the centre of the patch, read out of LDS (round 3).
 // Waves: (C/32 filter tiles of cv2) x (two groups of four output rows) = 4 (C = 64, two blocks per CU) or 8 (C = 128, one block per CU).
 struct BneckArgs {
     const void* x;      // NHWC (N, H, W, C)
@@ -662,9 +662,24 @@ __global__ __launch_bounds__(C * 4, C == 64 ? 2 : 1) void bneck_pair_kernel(cons
                 if (c1 >= RC) { c1 -= RC; r1 += 1; }
             }
         }
+        // (round 3) the residual x[pixel][this wave's 32 channels] is the centre of the patch that is still in xbuf: taken from there, in the store
+        // layout of the epilogue, BEFORE the barrier behind which the next tile's patch overwrites it -- the second read of x from HBM / L2
+        // (PMC: 2.3 x the algorithmic input per launch in round 2) is gone; 2 RW registers live across cv2
+        u32x4 xres[2 * RW];
+        if (p.add) {
+            int lane_r = lane;
+            asm volatile("" : "+v"(lane_r));
+            const int rp_r = lane_r >> 2, lc = wc * 4 + (lane_r & 3);   // pixel within a group of 16, logical 16-byte chunk of the pixel
+#pragma unroll
+            for (int b2 = 0; b2 < RW; ++b2)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int q = (RW * wp + b2 + 1) * RC + (i * 16 + rp_r + 1);   // region pixel of output (row RW wp + b2, column 16 i + rp)
+                    xres[b2 * 2 + i] = *(const u32x4*)(xbuf + q * XB + ((lc ^ ((q >> XKS) & (XCHK - 1))) << 4));
+                }
+        }
         __syncthreads();
-        // xbuf is dead (the residual is re-read from global memory below: those lines sit in L2): the next tile's patch streams into it
-        // under this tile's MFMAs
+        // xbuf is dead: the next tile's patch streams into it under this tile's MFMAs
         {
             int nt = tile + (int)gridDim.x;
             asm volatile("" : "+s"(nt));   // the piece addresses are computed HERE: scheduled to the top of the tile they lived in scratch until now,
@@ -712,23 +727,9 @@ __global__ __launch_bounds__(C * 4, C == 64 ? 2 : 1) void bneck_pair_kernel(cons
         mm(std::integral_constant<int, K2S - 1>{}, bB);
         __builtin_amdgcn_sched_barrier(0);
         // ---- activation, 8 consecutive filters per lane, transpose through the wave's slice, residual, 64-byte runs per pixel ----
-        u32x4 xres[2 * RW];   // residual x[pixel][this wave's 32 channels], in the store layout of the epilogue
         int lane_o = lane;
-        asm volatile("" : "+v"(lane_o));   // (same reason: the epilogue's addresses are computed after the K loop, not carried through it)
+        asm volatile("" : "+v"(lane_o));   // (the epilogue's addresses are computed after the K loop, not carried through it)
         const int rp = lane_o >> 2, ch = lane_o & 3;
-        if (p.add) {   // bounds-checked descriptor loads (out-of-range lanes carry offset 0xffffffff and read 0): straight-line, all eight in flight
-                       // under the SiLU pass below -- behind `if (inside)` branches each was issued at its use and waited for alone
-            const int pix0 = ((n * p.H + oh0 + RW * wp) * p.W + ow0) * p.xpitch + wc * 32 + ch * 8;   // elements: < 2^30 (x_bytes < 2^31)
-#pragma unroll
-            for (int b2 = 0; b2 < RW; ++b2)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int pl = i * 16 + rp;
-                    const bool ok = oh0 + RW * wp + b2 < p.H && ow0 + pl < p.W;
-                    xres[b2 * 2 + i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? (unsigned)(pix0 + (b2 * p.W + pl) * p.xpitch) * 2u : 0xffffffffu, 0, 0);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-        }
         unsigned char* wl = slices + wv * (32 * 64);
         if (p.act2 == Y3_ACT_SILU) {
 #pragma unroll
