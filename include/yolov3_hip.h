@@ -231,6 +231,10 @@ int y3_loss_fwd(const y3_loss_params* p, int32_t dtype, const void* const* preds
                 float* out4, void* workspace, size_t workspace_bytes, void* stream);
 int y3_loss_bwd(const y3_loss_params* p, int32_t dtype, const void* const* preds, const float* targets, int32_t nt,
                 const float* grad_out, void* const* grads, void* workspace, size_t workspace_bytes, void* stream);
+/* ComputeLoss(autobalance=True), reference utils/loss.py:171-175: the per-level objectness losses `obji` of the forward that filled
+ * `workspace` (same params / dtype / nt), nl device floats; the caller reads them back and moves its balance weights */
+int y3_loss_level_obj(const y3_loss_params* p, int32_t dtype, int32_t nt, void* workspace, size_t workspace_bytes, float* obj_levels,
+                      void* stream);
 
 /* ---------------------------------------------------------------------------------------------- training
  * Train-mode `Conv` = act(bn(conv(x))) with BATCH statistics (reference models/common.py:75; BN eps 1e-3 / momentum

@@ -324,13 +324,16 @@ def build_targets(shapes, targets, anchors_grid, anchor_t=4.0):
     return out
 
 
-def compute_loss(p, targets, anchors_grid, hyp, nc):
+def compute_loss(p, targets, anchors_grid, hyp, nc, balance=None, autobalance_ssi=None):
     """reference utils/loss.py:131-181 with criteria from :104-129 (BCEWithLogits with pos_weight,
-    label smoothing, balance [4,1,0.4] for 3 levels else first nl of [4,1,.25,.06,.02]; gr=1;
-    autobalance off).  FocalLoss (:31-63) applied when hyp['fl_gamma']>0.
+    label smoothing, balance [4,1,0.4] for 3 levels else first nl of [4,1,.25,.06,.02]; gr=1).
+    FocalLoss (:31-63) applied when hyp['fl_gamma']>0.  `balance`: the per-level objectness weights to use (a list that is UPDATED IN PLACE
+    when `autobalance_ssi` is given: utils/loss.py:171-175, each level's weight moves by 1e-4 towards 1 / its objectness loss after that
+    level's term was added, then all are divided by the weight of the stride-16 level `autobalance_ssi`).
     Returns (loss(1,), items(3,), aux) where loss=(lbox+lobj+lcls)*bs (:181)."""
     nl = len(p)
-    balance = {3: [4.0, 1.0, 0.4]}.get(nl, [4.0, 1.0, 0.25, 0.06, 0.02])
+    if balance is None:
+        balance = {3: [4.0, 1.0, 0.4]}.get(nl, [4.0, 1.0, 0.25, 0.06, 0.02])
     cp, cn = upstream.smooth_bce(eps=hyp.get("label_smoothing", 0.0))
     cls_pw = torch.tensor([hyp["cls_pw"]])
     obj_pw = torch.tensor([hyp["obj_pw"]])
@@ -363,8 +366,15 @@ def compute_loss(p, targets, anchors_grid, hyp, nc):
                 t = torch.full_like(pcls, cn)
                 t[range(n), tcls] = cp
                 lcls = lcls + bce(pcls, t, cls_pw)
-        lobj = lobj + bce(pi[..., 4], tobj, obj_pw) * balance[i]
+        obji = bce(pi[..., 4], tobj, obj_pw)
+        lobj = lobj + obji * balance[i]
+        if autobalance_ssi is not None:
+            balance[i] = balance[i] * 0.9999 + 0.0001 / obji.detach().item()
         aux.append(tobj)
+    if autobalance_ssi is not None:
+        ssv = balance[autobalance_ssi]
+        for i in range(len(balance)):   # the whole list, including the unused tail of the 5-entry default when nl != 3 (utils/loss.py:175)
+            balance[i] = balance[i] / ssv
     lbox = lbox * hyp["box"]
     lobj = lobj * hyp["obj"]
     lcls = lcls * hyp["cls"]

@@ -2269,3 +2269,34 @@ def test_conv_v9_statistics_rows(dev, tune):
     assert torch.isfinite(tot).all(), "a statistics row was not written"
     assert (tot[:, 0] - u.sum(0)).abs().max().item() <= 1e-5 * u.abs().sum(0).max().item()
     assert (tot[:, 1] - (u * u).sum(0)).abs().max().item() <= 1e-5 * (u * u).sum(0).max().item()
+
+
+@pytest.mark.parametrize("name,dtype", [("yolov3", torch.float32), ("yolov3-tiny", torch.float16)])
+def test_loss_autobalance_vs_oracle(dev, name, dtype):
+    """ComputeLoss(autobalance=True) (reference utils/loss.py:121, :171-175; the oracle's restatement is pinned to the unmodified reference by
+    tests/test_oracle_vs_reference_live.py): three consecutive calls -- every loss formed with the weights the previous calls left, the weights
+    after each call equal to the oracle's (one read-back of nl floats per call: y3_loss_level_obj)."""
+    hyp = dict(box=0.05, cls=0.5, cls_pw=1.0, obj=1.0, obj_pw=1.0, anchor_t=4.0, fl_gamma=0.0, label_smoothing=0.0)
+    from yolov3_amd import ComputeLoss
+
+    nc, hw, bs = 20, 128, 3
+    m, (layers, save, sd, strides) = build_pair(name, nc, 5, dev, torch.float32)
+    m.hyp = hyp
+    crit = ComputeLoss(m, autobalance=True)
+    ssi = [int(s) for s in strides].index(16)
+    assert crit.ssi == ssi
+    balance = {3: [4.0, 1.0, 0.4]}.get(len(strides), [4.0, 1.0, 0.25, 0.06, 0.02])[: len(strides)]
+    balance = list(balance)
+    anchors = sd[[k for k in sd if k.endswith("anchors")][0]]
+    shapes = [(bs, 3, hw // int(s), hw // int(s), nc + 5) for s in strides]
+    tol = 1e-4 if dtype == torch.float32 else 3e-3
+    for step in range(3):
+        tg = yo.synth_targets(bs, nc, seed=90 + step)
+        p = yo.synth_raw_predictions(shapes, seed=60 + step)
+        pq = [t.to(dtype) for t in p]
+        loss_ref, _, _ = yo.compute_loss([t.float() for t in pq], tg, anchors, hyp, nc, balance=balance, autobalance_ssi=ssi)
+        loss, _ = crit([t.to(dev) for t in pq], tg.to(dev))
+        assert abs(loss.item() - loss_ref.item()) <= tol * abs(loss_ref.item()), (step, loss.item(), loss_ref.item())
+        for a, b in zip(crit.balance, balance):
+            assert abs(a - b) <= tol * abs(b), (step, crit.balance, balance)
+    assert abs(crit.balance[ssi] - 1.0) < 1e-6

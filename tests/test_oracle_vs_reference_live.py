@@ -105,3 +105,34 @@ def test_compute_loss_oracle_equals_reference_on_fresh_targets(ref):
         torch.testing.assert_close(items, items_ref, rtol=1e-6, atol=1e-6)
         for a, b in zip(p, p_ref):
             torch.testing.assert_close(a.grad, b.grad, rtol=1e-5, atol=1e-8)
+
+
+def test_autobalance_oracle_equals_reference_over_consecutive_calls(ref):
+    """ComputeLoss(autobalance=True) (reference utils/loss.py:121, :171-175): the per-level objectness weights after three consecutive calls,
+    and every call's loss, from the unmodified reference and from oracle.compute_loss(balance=..., autobalance_ssi=...)."""
+    import yaml
+    from pathlib import Path
+
+    cfg = Path(__file__).resolve().parents[1] / "yolov3_amd" / "cfg"
+    for name, nc, hw, bs in [("yolov3", 80, 96, 2), ("yolov3-tiny", 20, 128, 3)]:
+        d = yaml.safe_load(open(cfg / f"{name}.yaml"))
+        layers, save, anchors, nc_v = yo.parse_cfg(d, 3, nc)
+        strides = yo.model_strides(layers)
+        sd = yo.seeded_state_dict(layers, nc_v, anchors, strides, seed=7)
+        m = ref.DetectionModel(str(cfg / f"{name}.yaml"), ch=3, nc=nc)
+        m.load_state_dict(sd, strict=True)
+        hyp = dict(box=0.05, cls=0.5, cls_pw=1.0, obj=1.0, obj_pw=1.0, anchor_t=4.0, fl_gamma=0.0, label_smoothing=0.0)
+        m.hyp = hyp
+        crit = ref.ComputeLoss(m, autobalance=True)
+        ssi = [int(s) for s in strides].index(16)
+        assert crit.ssi == ssi
+        balance = list(crit.balance)
+        shapes = [(bs, 3, hw // int(s), hw // int(s), nc + 5) for s in strides]
+        for step in range(3):
+            tg = yo.synth_targets(bs, nc, seed=90 + step)
+            p = yo.synth_raw_predictions(shapes, seed=60 + step)
+            loss_ref, _ = crit([t.clone() for t in p], tg)
+            loss, _, _ = yo.compute_loss(p, tg, m.model[-1].anchors.clone(), hyp, nc, balance=balance, autobalance_ssi=ssi)
+            torch.testing.assert_close(loss, loss_ref.detach(), rtol=1e-6, atol=1e-6)
+            torch.testing.assert_close(torch.tensor(balance), torch.tensor([float(b) for b in crit.balance]), rtol=1e-6, atol=1e-7)
+        assert abs(balance[ssi] - 1.0) < 1e-9 and balance != [4.0, 1.0, 0.4][: len(balance)]

@@ -119,6 +119,7 @@ _SIGNATURES = {
         C.c_int,
         [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     ),
+    "y3_loss_level_obj": (C.c_int, [_P(Y3LossParams), C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "y3_conv2d_fwd_stats_rows": (C.c_int64, [_P(Y3ConvDesc), _P(Y3Tensor), _P(Y3Tensor)]),
     "y3_conv2d_fwd_stats": (C.c_int, [_P(Y3ConvDesc), _P(Y3Tensor), C.c_void_p, C.c_void_p, _P(Y3Tensor), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "y3_conv2d_fwd_stats_rows_ws": (C.c_int64, [_P(Y3ConvDesc), _P(Y3Tensor), _P(Y3Tensor), C.c_size_t]),

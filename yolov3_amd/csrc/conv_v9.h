@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_v9_kernel(const ConvArgs p)
             } else if constexpr (ABL == 4 || ABL == 5 || ABL == 7) {
 #pragma unroll
                 for (int a = 0; a < MC; ++a) asm volatile("" : "=v"(A1[a]));
-            } else {
+            } else if constexpr (ABL != 13) {
 #pragma unroll
                 for (int a = 0; a < MC; ++a) A1[a] = *(const frag*)(smem + a_k1 + a * 2048 + (tap % 3) * V9_STAGE);
             }
@@ -212,6 +212,10 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_v9_kernel(const ConvArgs p)
             } else {
 #pragma unroll
                 for (int b = 0; b < MP; ++b) B1[b] = *(const frag*)(smem + bb[dh][b] + dw * V9_PITCH + 32);
+            }
+            if constexpr (ABL == 13) {   // lab: the filter fragments read AFTER the pixel fragments
+#pragma unroll
+                for (int a = 0; a < MC; ++a) A1[a] = *(const frag*)(smem + a_k1 + a * 2048 + (tap % 3) * V9_STAGE);
             }
             if constexpr (ABL == 9 || ABL == 12) ld_w((tap2 * p.Cin + (cb + (tap + 2 >= 9 ? 1 : 0)) * 32) * 2, IC<tap2 % 3>{});
             else if constexpr (ABL != 1 && ABL != 7) dma_w((tap2 * p.Cin + (cb + (tap + 2 >= 9 ? 1 : 0)) * 32) * 2, tap2 % 3);
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_v9_kernel(const ConvArgs p)
             } else if constexpr (ABL == 4 || ABL == 5 || ABL == 7) {
 #pragma unroll
                 for (int a = 0; a < MC; ++a) asm volatile("" : "=v"(A0[a]));
-            } else {
+            } else if constexpr (ABL != 13) {
 #pragma unroll
                 for (int a = 0; a < MC; ++a) A0[a] = *(const frag*)(smem + a_k0 + a * 2048 + (ntap % 3) * V9_STAGE);
             }
@@ -280,6 +284,10 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_v9_kernel(const ConvArgs p)
             } else {
 #pragma unroll
                 for (int b = 0; b < MP; ++b) B0[b] = *(const frag*)(smem + bb[ndh][b] + ndw * V9_PITCH);
+            }
+            if constexpr (ABL == 13) {
+#pragma unroll
+                for (int a = 0; a < MC; ++a) A0[a] = *(const frag*)(smem + a_k0 + a * 2048 + (ntap % 3) * V9_STAGE);
             }
             if constexpr (tap < 7 && ABL != 2 && ABL != 7) {
 #pragma unroll
@@ -439,7 +447,7 @@ template <typename T> int launch_v9(ConvArgs& a, hipStream_t st) {
 #ifdef Y3_ABLATE
     if (const char* e = getenv("Y3_V9_ABL")) {   // lab build only
         const int abl = atoi(e);
-        if (pl.mp == 7 && !two && abl >= 1 && abl <= 12) {
+        if (pl.mp == 7 && !two && abl >= 1 && abl <= 13) {
             switch (abl) {
                 case 1: hipLaunchKernelGGL((conv_igemm_v9_kernel<T, 7, 1, 1>), grid, block, 0, st, a); break;
                 case 2: hipLaunchKernelGGL((conv_igemm_v9_kernel<T, 7, 1, 2>), grid, block, 0, st, a); break;
@@ -452,6 +460,7 @@ template <typename T> int launch_v9(ConvArgs& a, hipStream_t st) {
                 case 10: hipLaunchKernelGGL((conv_igemm_v9_kernel<T, 7, 1, 10>), grid, block, 0, st, a); break;
                 case 11: hipLaunchKernelGGL((conv_igemm_v9_kernel<T, 7, 1, 11>), grid, block, 0, st, a); break;
                 case 12: hipLaunchKernelGGL((conv_igemm_v9_kernel<T, 7, 1, 12>), grid, block, 0, st, a); break;
+                case 13: hipLaunchKernelGGL((conv_igemm_v9_kernel<T, 7, 1, 13>), grid, block, 0, st, a); break;
                 default: hipLaunchKernelGGL((conv_igemm_v9_kernel<T, 7, 1, 8>), grid, block, 0, st, a); break;
             }
             Y3_CHECK_LAUNCH();

@@ -497,6 +497,31 @@ extern "C" size_t y3_loss_workspace_bytes(const y3_loss_params* p, int32_t nt) {
     return total_ws(p, nt, 4);
 }
 
+// per-level objectness loss (the mean BCE the forward summed per level) out of the workspace a y3_loss_fwd call filled: what
+// ComputeLoss(autobalance=True) reads back per step (reference utils/loss.py:171-175, `obji.detach().item()`)
+__global__ void loss_level_obj_kernel(FinalArgs F, int nl, float* __restrict__ out) {
+    const int i = threadIdx.x;
+    if (i < nl) out[i] = F.sums[i][3] / (float)F.cells[i];
+}
+extern "C" int y3_loss_level_obj(const y3_loss_params* p, int32_t dtype, int32_t nt, void* workspace, size_t workspace_bytes, float* obj_levels, void* stream) {
+    if (check_params(p, nt) != 0) return -1;
+    if (!workspace || !obj_levels) Y3_FAIL("y3_loss_level_obj: null argument");
+    if (dtype != Y3_F16 && dtype != Y3_BF16 && dtype != Y3_F32) Y3_FAIL("y3_loss_level_obj: bad dtype %d", dtype);
+    const int esz = dtype == Y3_F32 ? 4 : 2;   // the workspace is carved with the element size of the predictions (the tobj planes)
+    if (workspace_bytes < total_ws(p, nt, 4)) Y3_FAIL("y3_loss_level_obj: workspace too small");
+    FinalArgs F;
+    size_t off = 0;
+    for (int i = 0; i < p->nl; ++i) {
+        LevelWs W;
+        off = carve_level(W, (unsigned char*)workspace, off, p, i, nt, esz);
+        F.sums[i] = W.sums;
+        F.cells[i] = W.cells;
+    }
+    hipLaunchKernelGGL(loss_level_obj_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, F, p->nl, obj_levels);
+    Y3_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int y3_loss_fwd(const y3_loss_params* p, int32_t dtype, const void* const* preds, const float* targets, int32_t nt, float* out4, void* workspace,
                            size_t workspace_bytes, void* stream) {
     if (check_params(p, nt) != 0) return -1;

@@ -40,6 +40,7 @@ class _LossFn(torch.autograd.Function):
         ptrs = (C.c_void_p * len(preds))(*[t.data_ptr() for t in preds])
         check(L.y3_loss_fwd(C.byref(P), ops.dtype_code(dtype), ptrs, tg.data_ptr() if nt else None, nt, out4.data_ptr(), ws.data_ptr(), need, ops.stream_ptr()), "y3_loss_fwd")
         ctx.crit, ctx.P, ctx.ws, ctx.tg, ctx.need = crit, P, ws, tg, need
+        crit._last_fwd = (P, ops.dtype_code(dtype), nt, ws, need)   # ComputeLoss(autobalance=True) reads the per-level objectness losses out of it
         ctx.save_for_backward(*preds)
         ctx.mark_non_differentiable(out4)
         return out4[0:1].clone(), out4
@@ -67,15 +68,14 @@ class ComputeLoss:
     sort_obj_iou = False
 
     def __init__(self, model, autobalance=False):
-        if autobalance:
-            raise NotImplementedError("autobalance needs a host read-back of every level's objectness loss per step (utils/loss.py:172); not on the MI355X path")
         self.device = next(model.parameters()).device
         h = model.hyp
         self.cp, self.cn = smooth_bce(eps=h.get("label_smoothing", 0.0))
         m = de_parallel(model).model[-1]
         self.balance = {3: [4.0, 1.0, 0.4]}.get(m.nl, [4.0, 1.0, 0.25, 0.06, 0.02])
-        self.ssi = 0
+        self.ssi = [int(v) for v in m.stride.tolist()].index(16) if autobalance else 0   # stride-16 level (utils/loss.py:121)
         self.gr, self.hyp, self.autobalance = 1.0, h, autobalance
+        self._last_fwd = None
         self.na, self.nc, self.nl = m.na, m.nc, m.nl
         self.anchors = m.anchors
         self._anchors_host = None
@@ -108,4 +108,14 @@ class ComputeLoss:
         for t in p:
             ops.require_gpu(t, "ComputeLoss")
         loss, out4 = _LossFn.apply(self, targets, *p)
+        if self.autobalance:
+            # utils/loss.py:171-175: every level's weight moves towards 1 / its objectness loss (after this call's loss was formed with the old
+            # weights), then all are normalised by the stride-16 level's.  The reference pays one host sync per level (`obji.item()`); here one
+            # read-back of nl floats per call
+            P, dcode, nt, ws, need = self._last_fwd
+            obj = torch.empty(self.nl, dtype=torch.float32, device=ws.device)
+            check(_lib.lib().y3_loss_level_obj(C.byref(P), dcode, nt, ws.data_ptr(), need, obj.data_ptr(), ops.stream_ptr()), "y3_loss_level_obj")
+            for i, oi in enumerate(obj.tolist()):
+                self.balance[i] = self.balance[i] * 0.9999 + 0.0001 / oi
+            self.balance = [x / self.balance[self.ssi] for x in self.balance]
         return loss, out4[1:4].detach()
