@@ -199,6 +199,18 @@ int y3_nms(const void* pred, int32_t dtype, int32_t bs, int32_t n_rows, int32_t 
  * image `index` is written.  new_h/new_w/top/left are computed by the caller exactly as the reference does (Python round()). */
 int y3_letterbox_u8(const uint8_t* src, int32_t h0, int32_t w0, int32_t cs, uint8_t* dst_batch, int32_t index, int32_t H1,
                     int32_t W1, int32_t new_h, int32_t new_w, int32_t top, int32_t left, int32_t color, void* stream);
+/* Test-time augmentation edges: reference models/yolo.py:239-276 (_forward_augment, _descale_pred, _clip_augmented).
+ * y3_scale_img: upstream ultralytics.utils.torch_utils.scale_img (un-vendored) fused with the `x.flip(3)` of models/yolo.py:246 -- NCHW (n, c, h, w)
+ * -> NCHW (n, c, oh, ow): the (optionally left-right mirrored) batch resized like F.interpolate(size=(ih, iw), mode="bilinear",
+ * align_corners=False), pad_value (the reference's 0.447) right / below up to (oh, ow).  The caller computes ih = int(h ratio), iw = int(w ratio),
+ * oh = ceil(h ratio / gs) gs, ow likewise, as the reference does.  src != dst.
+ * y3_descale_pred: rows [row0, row0 + nrows) of every image of a decoded prediction (bs, src_rows, no) -> rows [dst_row0, ...) of the concatenated
+ * (bs, dst_rows, no) result, xywh / scale, flip 3: x = img_w - x, flip 2: y = img_h - y (0: none); every step rounded to dtype like the reference's
+ * in-place tensor ops.  The row windows are _clip_augmented's. */
+int y3_scale_img(const void* src, int32_t dtype, int32_t n, int32_t c, int32_t h, int32_t w, int32_t ih, int32_t iw, int32_t oh, int32_t ow,
+                 int32_t flip_lr, float pad_value, void* dst, void* stream);
+int y3_descale_pred(const void* src, int32_t dtype, int32_t bs, int32_t src_rows, int32_t no, int32_t row0, int32_t nrows, float scale,
+                    int32_t flip, float img_h, float img_w, void* dst, int32_t dst_rows, int32_t dst_row0, void* stream);
 int y3_scale_boxes(float* rows, int64_t img_stride, int32_t row_stride, const int32_t* counts, int32_t bs, int32_t max_rows,
                    const float* params, void* stream);
 int y3_match_detections(const float* dets, int64_t img_stride, int32_t row_stride, const int32_t* counts, int32_t bs,
@@ -281,6 +293,24 @@ int y3_bn_act_bwd(const y3_tensor* u, const y3_tensor* dy, const float* scale, c
 int y3_bn_act_bwd_res(const y3_tensor* u, const y3_tensor* dy, const float* scale, const float* shift, const float* mean,
                       const float* invstd, int32_t dtype, int32_t act, double* sums, const y3_tensor* du, float* dgamma,
                       float* dbeta, const y3_tensor* gres, int32_t gres_accumulate, void* stream);
+/* SyncBatchNorm (reference train.py:270-272 `--sync-bn`: torch.nn.SyncBatchNorm.convert_sync_batchnorm before DDP).  The host side all-reduces a few
+ * fp64 words per layer between these calls (yolov3_amd/train_engine.py); everything stays on the device:
+ *   forward : y3_bn_sum_rows (rows of a y3_conv2d_fwd_stats launch -> sums[0 .. 2C) = per-channel (sum, sum of squares); y3_bn_stats is the form that
+ *             reads u) -> all-reduce(sums[0 .. 2C), element count) -> y3_bn_finalize_devcount (y3_bn_finalize with the count read from the device).
+ *   backward: y3_bn_act_bwd_reduce (this rank's totals of (dz, dz xhat) in sums[0 .. 2C), dgamma / dbeta from them -- local, the gradient exchange
+ *             averages them like every other parameter gradient -- and the local means in sums[2C .. 4C)) -> the host overwrites sums[2C .. 4C)
+ *             with all-reduced totals / all-reduced count -> y3_bn_act_bwd_apply (du, and the residual's gradient as y3_bn_act_bwd_res).
+ * y3_bn_act_bwd == reduce + apply back to back. */
+int y3_bn_sum_rows(const float* stat_rows, int64_t n_rows, int32_t C, double* sums, void* stream);
+int y3_bn_finalize_devcount(const double* sums, const double* count_dev, int32_t C, const float* gamma, const float* beta, float eps,
+                            float momentum, float* running_mean, float* running_var, float* scale, float* shift, float* mean,
+                            float* invstd, void* stream);
+int y3_bn_act_bwd_reduce(const y3_tensor* u, const y3_tensor* dy, const float* scale, const float* shift, const float* mean,
+                         const float* invstd, int32_t dtype, int32_t act, double* sums, float* dgamma /* may be NULL */,
+                         float* dbeta /* may be NULL */, void* stream);
+int y3_bn_act_bwd_apply(const y3_tensor* u, const y3_tensor* dy, const float* scale, const float* shift, const float* mean,
+                        const float* invstd, int32_t dtype, int32_t act, const double* sums, const y3_tensor* du,
+                        const y3_tensor* gres /* may be NULL */, int32_t gres_accumulate, void* stream);
 /* Backward of the first layer (Conv(3, 32, 3, 1) + BatchNorm + act; no data gradient) in two passes over (u, dy) instead of three
  * plus a write: the reduction of y3_bn_act_bwd (totals into `sums`, dgamma, dbeta), then ONE kernel that applies the BatchNorm /
  * activation backward, rounds du to the storage dtype as y3_bn_act_bwd would have stored it, and accumulates

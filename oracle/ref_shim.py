@@ -173,6 +173,7 @@ def install() -> None:
         initialize_weights=upstream.initialize_weights,
         intersect_dicts=upstream.intersect_dicts,
         one_cycle=upstream.one_cycle,
+        scale_img=upstream.scale_img,
         model_info=lambda *a, **k: None,
         time_sync=lambda: __import__("time").perf_counter(),
         autocast=lambda *a, **k: contextlib.nullcontext(),

@@ -8,7 +8,7 @@ are not installable here (no network):
 * ``ultralytics`` (PyPI, floor pin ``>=8.4.110`` -- reference requirements.txt:18,
   pyproject.toml:78): ``utils.metrics.{bbox_iou,box_iou,smooth_bce}``,
   ``utils.ops.{xywh2xyxy,xyxy2xywh,clip_boxes,make_divisible}``,
-  ``utils.torch_utils.{fuse_conv_and_bn,initialize_weights}``.
+  ``utils.torch_utils.{fuse_conv_and_bn,initialize_weights,scale_img}``.
 * ``torchvision`` (floor pin ``>=0.9.0`` -- reference requirements.txt:17): ``ops.nms``.
 
 Each function below restates the published algorithm and names the reference call site
@@ -168,6 +168,19 @@ def initialize_weights(model):
             m.momentum = 0.03
         elif t in (nn.Hardswish, nn.LeakyReLU, nn.ReLU, nn.ReLU6, nn.SiLU):
             m.inplace = True
+
+
+def scale_img(img, ratio=1.0, same_shape=False, gs=32):
+    """Published upstream ``ultralytics.utils.torch_utils.scale_img`` (call site: reference models/yolo.py:246, test-time augmentation): bilinear resize of
+    an NCHW batch to (int(h ratio), int(w ratio)), then right / bottom padding with 0.447 (the ImageNet mean) up to the next multiple of ``gs``."""
+    if ratio == 1.0:
+        return img
+    h, w = img.shape[2:]
+    s = (int(h * ratio), int(w * ratio))
+    img = torch.nn.functional.interpolate(img, size=s, mode="bilinear", align_corners=False)
+    if not same_shape:
+        h, w = (math.ceil(x * ratio / gs) * gs for x in (h, w))
+    return torch.nn.functional.pad(img, [0, w - s[1], 0, h - s[0]], value=0.447)
 
 
 def one_cycle(y1=0.0, y2=1.0, steps=100):

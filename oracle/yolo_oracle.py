@@ -219,6 +219,28 @@ def forward(layers, save, sd, x, strides=None, training=False, stats=None):
     return x
 
 
+def forward_augment(layers, save, sd, x, strides):
+    """Test-time augmentation: reference models/yolo.py:239-276 (_forward_augment: scales 1 / 0.83 / 0.67, the middle pass mirrored left-right;
+    _descale_pred with inplace=True; _clip_augmented).  Returns the concatenated prediction (bs, rows, no)."""
+    img_size = x.shape[-2:]
+    gs = int(max(float(v) for v in strides))
+    nl = len(strides)
+    y = []
+    for si, fi in zip([1, 0.83, 0.67], [None, 3, None]):
+        xi = upstream.scale_img(x.flip(fi) if fi else x, si, gs=gs)
+        yi = forward(layers, save, sd, xi, strides)[0].clone()
+        yi[..., :4] /= si                                   # :255
+        if fi == 2:
+            yi[..., 1] = img_size[0] - yi[..., 1]
+        elif fi == 3:
+            yi[..., 0] = img_size[1] - yi[..., 0]           # :259
+        y.append(yi)
+    g = sum(4**k for k in range(nl))                         # :271-276
+    y[0] = y[0][:, : y[0].shape[1] - (y[0].shape[1] // g) * 1]
+    y[-1] = y[-1][:, (y[-1].shape[1] // g) * 4 ** (nl - 1) :]
+    return torch.cat(y, 1)
+
+
 # =========================================================================== NMS
 def non_max_suppression(
     prediction,

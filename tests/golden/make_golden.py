@@ -20,7 +20,7 @@ import yaml
 ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
 
-from oracle import ref_shim, yolo_oracle as yo  # noqa: E402
+from oracle import ref_shim, upstream, yolo_oracle as yo  # noqa: E402
 
 OUT = Path(__file__).resolve().parent
 CFG = ROOT / "yolov3_amd" / "cfg"
@@ -315,11 +315,33 @@ def gen_ckpt_fixture(ns):
     print("ckpt", (OUT / "ref_tiny_w025_fp16.pt").stat().st_size, tuple(pred.shape))
 
 
+def gen_tta_goldens(ns):
+    """model(x, augment=True) of the UNMODIFIED reference (models/yolo.py:239-276) on top of the restated upstream scale_img (oracle/upstream.py;
+    ultralytics is not vendored), plus the scaled / mirrored inputs themselves (F.interpolate on this host)."""
+    out = {}
+    for name, nc, h, w, bs in [("yolov3-tiny", 20, 96, 160, 2), ("yolov3", 7, 128, 96, 1)]:
+        m, sd, layers, save, strides = build_ref_model(ns, name, nc, seed=13)
+        m.eval()
+        x = torch.rand(bs, 3, h, w, generator=torch.Generator().manual_seed(8))
+        with torch.no_grad():
+            pred, none = m(x, augment=True)
+        assert none is None
+        gs = int(m.stride.max())
+        out[f"{name}-nc{nc}-{h}x{w}-bs{bs}"] = {
+            "x_sum": checksum(x),
+            "pred": pred.clone(),
+            "x_083_flip": upstream.scale_img(x.flip(3), 0.83, gs=gs).clone(),
+            "x_067": upstream.scale_img(x, 0.67, gs=gs).clone(),
+        }
+        print("tta", name, tuple(pred.shape))
+    torch.save(out, OUT / "tta.pt")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ns = ref_shim.load()
-    which = set(sys.argv[1:]) or {"model", "decode", "nms", "loss", "val_edge", "big", "ckpt", "metrics"}  # python make_golden.py [model decode nms loss val_edge big ckpt metrics]
+    which = set(sys.argv[1:]) or {"model", "decode", "nms", "loss", "val_edge", "big", "ckpt", "metrics", "tta"}  # python make_golden.py [model decode nms loss val_edge big ckpt metrics tta]
     if "model" in which:
         gen_model_goldens(ns)
     if "decode" in which:
@@ -336,4 +358,6 @@ if __name__ == "__main__":
         gen_big_goldens(ns)
     if "ckpt" in which:
         gen_ckpt_fixture(ns)
+    if "tta" in which:
+        gen_tta_goldens(ns)
     print("golden files:", [(p.name, p.stat().st_size) for p in OUT.glob("*.pt")])

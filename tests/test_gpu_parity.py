@@ -2300,3 +2300,157 @@ def test_loss_autobalance_vs_oracle(dev, name, dtype):
         for a, b in zip(crit.balance, balance):
             assert abs(a - b) <= tol * abs(b), (step, crit.balance, balance)
     assert abs(crit.balance[ssi] - 1.0) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------- test-time augmentation (models/yolo.py:239-276)
+TTA_KEYS = ["yolov3-tiny-nc20-96x160-bs2", "yolov3-nc7-128x96-bs1"]
+
+
+def _tta_case(key):
+    name, nc, hw, bs = key.rsplit("-", 3)
+    h, w = (int(v) for v in hw.split("x"))
+    return name, int(nc[2:]), h, w, int(bs[2:])
+
+
+@pytest.mark.parametrize("key", TTA_KEYS)
+def test_scale_img_vs_reference_golden(dev, golden_dir, key):
+    """y3_scale_img (mirror + bilinear resize + 0.447 padding in one kernel) against the tensors the reference's scale_img call produced on the CPU
+    (F.interpolate align_corners=False; fp32 weights summed in a different order there: 1e-6), then in fp16 / bf16 against the rounded fp32 result."""
+    from yolov3_amd import ops
+    from oracle import upstream
+
+    gold = torch.load(golden_dir / "tta.pt")[key]
+    name, nc, h, w, bs = _tta_case(key)
+    x = torch.rand(bs, 3, h, w, generator=torch.Generator().manual_seed(8))
+    assert checksum(x) == gold["x_sum"]
+    a = ops.scale_img(x.to(dev), 0.83, gs=32, flip_lr=True)
+    b = ops.scale_img(x.to(dev), 0.67, gs=32)
+    assert a.shape == gold["x_083_flip"].shape and b.shape == gold["x_067"].shape
+    torch.testing.assert_close(a.cpu(), gold["x_083_flip"], rtol=0, atol=1e-6)
+    torch.testing.assert_close(b.cpu(), gold["x_067"], rtol=0, atol=1e-6)
+    xd = x.to(dev)
+    assert ops.scale_img(xd, 1.0) is xd
+    torch.testing.assert_close(ops.scale_img(xd, 1.0, flip_lr=True).cpu(), x.flip(3), rtol=0, atol=0)   # mirror only: exact
+    for dt, ulp in ((torch.float16, 2.0**-10), (torch.bfloat16, 2.0**-7)):
+        xh = x.to(dt)
+        ref = upstream.scale_img(xh.float().flip(3), 0.83, gs=32)
+        got = ops.scale_img(xh.to(dev), 0.83, gs=32, flip_lr=True)
+        assert got.dtype == dt
+        err = (got.float().cpu() - ref).abs().max().item()
+        assert err <= ulp, (dt, err)   # values in [0, 1): at most one unit in the last place of T
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_descale_pred_bit_exact(dev, dtype):
+    """y3_descale_pred against the reference's in-place tensor ops (models/yolo.py:253-261: `p[..., :4] /= scale`, `p[..., 0] = w - p[..., 0]`) run by
+    torch on the CPU in the same dtype, row windows included: bit-exact"""
+    from yolov3_amd import ops
+
+    g = torch.Generator().manual_seed(77)
+    bs, rows, no = 3, 1000, 25
+    p = (torch.rand(bs, rows, no, generator=g) * 640).to(dtype)
+    for scale, flip, lo, n, off in [(0.83, 3, 0, rows, 5), (0.67, None, 160, rows - 160, 0), (1, None, 0, rows - 40, 0), (0.83, 2, 7, 100, 3)]:
+        ref = p.clone()
+        ref[..., :4] /= scale
+        if flip == 2:
+            ref[..., 1] = 480 - ref[..., 1]
+        elif flip == 3:
+            ref[..., 0] = 640 - ref[..., 0]
+        out = torch.full((bs, off + n + 2, no), -1.0, dtype=dtype, device=dev)
+        ops.descale_pred_into(p.to(dev), lo, n, scale, flip, (480, 640), out, off)
+        got = out.cpu()
+        assert torch.equal(got[:, off : off + n].view(torch.int16 if dtype != torch.float32 else torch.int32), ref[:, lo : lo + n].contiguous().view(torch.int16 if dtype != torch.float32 else torch.int32))
+        assert (got[:, :off] == -1).all() and (got[:, off + n :] == -1).all()   # nothing outside the window
+
+
+@pytest.mark.parametrize("key", TTA_KEYS)
+def test_augmented_forward_vs_reference_golden(dev, golden_dir, key):
+    """model(x, augment=True) (fp32 engine) against the UNMODIFIED reference's augmented prediction (tests/golden/tta.pt): shape (the clipped row
+    windows) and values at the whole-model tolerance; the call returns (pred, None) like the reference"""
+    gold = torch.load(golden_dir / "tta.pt")[key]
+    name, nc, h, w, bs = _tta_case(key)
+    m, _ = build_pair(name, nc, 13, dev, torch.float32)
+    x = torch.rand(bs, 3, h, w, generator=torch.Generator().manual_seed(8))
+    assert checksum(x) == gold["x_sum"]
+    pred, none = m(x.to(dev), augment=True)
+    assert none is None and pred.shape == gold["pred"].shape
+    torch.testing.assert_close(pred.cpu(), gold["pred"], rtol=1e-4, atol=2e-4)
+    m.train()
+    with pytest.raises(RuntimeError):
+        m(x.to(dev), augment=True)
+
+
+def test_augmented_forward_half_vs_oracle(dev):
+    """fp16 engine, yolov3 at 256 x 320, batch 2: the augmented prediction against the fp32 oracle's (same weights) -- confidences and classes
+    absolutely, boxes relative to the image size (half-precision storage through 75 layers, as test_model_half_vs_fp32_oracle)"""
+    m, (layers, save, sd, strides) = build_pair("yolov3", 80, 21, dev, torch.float16)
+    x = torch.rand(2, 3, 256, 320, generator=torch.Generator().manual_seed(9)).half()
+    pred, _ = m(x.to(dev), augment=True)
+    with torch.no_grad():
+        ref = yo.forward_augment(layers, save, sd, x.float(), strides)
+    assert pred.shape == ref.shape and pred.dtype == torch.float16
+    d = (pred.float().cpu() - ref).abs()
+    assert d[..., 4:].max().item() < 2e-2
+    assert (d[..., :4] / (ref[..., :4].abs() + 32.0)).max().item() < 3e-2
+
+
+@pytest.mark.parametrize("backend", ["nccl", "gloo"])
+def test_sync_batchnorm_two_ranks(tmp_path, backend):
+    """--sync-bn (reference train.py:270-272: torch.nn.SyncBatchNorm.convert_sync_batchnorm(model) before DDP).  Two ranks, half of a batch each, against
+    ONE process running the whole batch through plain BatchNorm with the same weights: with statistics taken over both ranks the activations of a
+    rank's half, the running statistics and -- for a loss that is a sum over images -- world x the averaged parameter gradients are those of the
+    whole-batch run.  (Per-rank statistics would differ in the second digit: the check at the end.)"""
+    import subprocess
+    import sys
+
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (the round-end 8-GPU node; the 1-GPU test box runs the gloo form)")
+    script = tmp_path / "sync_bn.py"
+    script.write_text(f"""
+import copy, sys, torch
+sys.path.insert(0, {str(ROOT)!r})
+from yolov3_amd import DetectionModel, parallel
+rank, local_rank, world = parallel.init({backend!r})
+dev = parallel.local_device(local_rank)
+torch.cuda.set_device(dev)
+torch.manual_seed(0)
+full = DetectionModel("yolov3-tiny.yaml", nc=20).to(dev).train()
+parallel.broadcast_parameters(full)
+sync = torch.nn.SyncBatchNorm.convert_sync_batchnorm(copy.deepcopy(full)).to(dev).train()
+assert sum(isinstance(q, torch.nn.SyncBatchNorm) for q in sync.modules()) == 11
+g = torch.Generator().manual_seed(3)
+x = torch.rand(8, 3, 96, 128, generator=g).to(dev)
+wts = [torch.randn(8, 3, 96 // s, 128 // s, 25, generator=g).to(dev) for s in (16, 32)]
+lo, hi = rank * 4, rank * 4 + 4
+def run(model, xs, ws, exchange):
+    model.grad_sync = parallel.GradBuckets(bucket_bytes=4 << 20) if exchange else None
+    model.zero_grad(set_to_none=True)
+    out = model(xs)
+    sum((o * w).sum() for o, w in zip(out, ws)).backward()
+    torch.cuda.synchronize()
+    return [o.detach() for o in out], torch.cat([q.grad.flatten() for q in model.parameters()])
+out_f, g_f = run(full, x, wts, False)
+out_s, g_s = run(sync, x[lo:hi], [w[lo:hi] for w in wts], True)
+def close(a, b, tol, what):
+    err, ref = float((a - b).abs().max()), float(b.abs().max())
+    assert err <= tol * ref, (what, err, ref)
+for a, b in zip(out_s, out_f):
+    close(a, b[lo:hi], 2e-5, "activations")
+close(g_s * world, g_f, 2e-4, "gradients")
+bufs_f, bufs_s = dict(full.named_buffers()), dict(sync.named_buffers())
+for k, v in bufs_f.items():
+    if k.endswith("running_mean") or k.endswith("running_var"):
+        close(bufs_s[k], v, 1e-5, k)
+    if k.endswith("num_batches_tracked"):
+        assert int(bufs_s[k]) == int(v) == 1
+# and the statistics really were global: the same half batch through per-rank BatchNorm gives something else
+own = copy.deepcopy(full)
+own.load_state_dict(sync.state_dict(), strict=False)
+out_o, _ = run(own, x[lo:hi], [w[lo:hi] for w in wts], False)
+assert float((out_o[0] - out_f[0][lo:hi]).abs().max()) > 1e-3 * float(out_f[0].abs().max())
+print("rank", rank, "ok")
+parallel.finalize()
+""")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29537", str(script)],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.count("ok") == 2, out.stdout + out.stderr

@@ -242,3 +242,26 @@ def test_ap_per_class_matches_reference_golden(golden_dir):
     ref = gold["mixed"]["out"]
     assert abs(m50 - float(ref[5][:, 0].mean())) < 1e-12 and abs(m5095 - float(ref[5].mean(1).mean())) < 1e-12
     assert abs(mp - float(ref[2].mean())) < 1e-12 and abs(mr - float(ref[3].mean())) < 1e-12
+
+
+TTA_KEYS = ["yolov3-tiny-nc20-96x160-bs2", "yolov3-nc7-128x96-bs1"]
+
+
+def tta_case(key):
+    name, nc, hw, bs = key.rsplit("-", 3)
+    h, w = (int(v) for v in hw.split("x"))
+    return name, int(nc[2:]), h, w, int(bs[2:])
+
+
+@pytest.mark.parametrize("key", TTA_KEYS)
+def test_augmented_forward_matches_reference(golden_dir, key):
+    """oracle.forward_augment against model(x, augment=True) of the unmodified reference (models/yolo.py:239-276) on non-square inputs"""
+    gold = torch.load(golden_dir / "tta.pt")[key]
+    name, nc, h, w, bs = tta_case(key)
+    layers, save, sd, strides = build(name, nc, 13)
+    x = torch.rand(bs, 3, h, w, generator=torch.Generator().manual_seed(8))
+    assert checksum(x) == gold["x_sum"]
+    with torch.no_grad():
+        pred = yo.forward_augment(layers, save, sd, x, strides)
+    assert pred.shape == gold["pred"].shape
+    torch.testing.assert_close(pred, gold["pred"], rtol=1e-5, atol=1e-5)

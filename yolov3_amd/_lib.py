@@ -119,6 +119,9 @@ _SIGNATURES = {
         C.c_int,
         [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     ),
+    "y3_scale_img": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
+    "y3_descale_pred": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_int32, C.c_int32,
+                                  C.c_void_p]),
     "y3_loss_level_obj": (C.c_int, [_P(Y3LossParams), C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "y3_conv2d_fwd_stats_rows": (C.c_int64, [_P(Y3ConvDesc), _P(Y3Tensor), _P(Y3Tensor)]),
     "y3_conv2d_fwd_stats": (C.c_int, [_P(Y3ConvDesc), _P(Y3Tensor), C.c_void_p, C.c_void_p, _P(Y3Tensor), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
@@ -134,6 +137,19 @@ _SIGNATURES = {
         [_P(Y3Tensor), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     ),
     "y3_bn_act_fwd": (C.c_int, [_P(Y3Tensor), C.c_void_p, C.c_void_p, _P(Y3Tensor), _P(Y3Tensor), C.c_int32, C.c_int32, C.c_void_p]),
+    "y3_bn_sum_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "y3_bn_finalize_devcount": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
+    "y3_bn_act_bwd_reduce": (
+        C.c_int,
+        [_P(Y3Tensor), _P(Y3Tensor), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
+    "y3_bn_act_bwd_apply": (
+        C.c_int,
+        [_P(Y3Tensor), _P(Y3Tensor), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, _P(Y3Tensor), _P(Y3Tensor), C.c_int32, C.c_void_p],
+    ),
     "y3_bn_act_bwd": (
         C.c_int,
         [_P(Y3Tensor), _P(Y3Tensor), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, _P(Y3Tensor), C.c_void_p, C.c_void_p, C.c_void_p],

@@ -178,6 +178,7 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(const T* __restrict
 //   MODE 2: + (dbeta, dgamma) of the BN backward        MODE 3: + fp32 copy of the even entries (bias gradient)
 struct BnFinalizeArgs {
     double count;
+    const double* count_dev;   // SyncBatchNorm: the all-reduced element count, read on the device (overrides `count` when set)
     const float* gamma;
     const float* beta;
     float eps, momentum;
@@ -188,7 +189,9 @@ struct BnFinalizeArgs {
     float* mean;
     float* invstd;
 };
-Y3_DEV void bn_finalize_channel(int c, double s0, double s1, const BnFinalizeArgs& f) {
+Y3_DEV void bn_finalize_channel(int c, double s0, double s1, const BnFinalizeArgs& fa) {
+    BnFinalizeArgs f = fa;
+    if (f.count_dev) f.count = *f.count_dev;
     const double mu = s0 / f.count;
     double var = s1 / f.count - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -1326,7 +1329,18 @@ extern "C" int y3_bn_stats(const y3_tensor* u, int32_t dtype, double* sums, void
 extern "C" int y3_bn_finalize(const double* sums, int64_t count, int32_t C, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                               float* running_var, float* scale, float* shift, float* mean, float* invstd, void* stream) {
     if (!sums || !scale || !shift || !mean || !invstd || count <= 0) Y3_FAIL("y3_bn_finalize: bad argument");
-    const BnFinalizeArgs f{(double)count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd};
+    const BnFinalizeArgs f{(double)count, nullptr, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd};
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, C, f);
+    Y3_CHECK_LAUNCH();
+    return 0;
+}
+
+// SyncBatchNorm form (reference train.py:270-272 `--sync-bn`): `sums` holds the totals all-reduced over the ranks, count_dev the all-reduced element count
+// (one fp64 on the device: no host round trip between the collective and the normalisation)
+extern "C" int y3_bn_finalize_devcount(const double* sums, const double* count_dev, int32_t C, const float* gamma, const float* beta, float eps, float momentum,
+                                       float* running_mean, float* running_var, float* scale, float* shift, float* mean, float* invstd, void* stream) {
+    if (!sums || !count_dev || !scale || !shift || !mean || !invstd) Y3_FAIL("y3_bn_finalize_devcount: bad argument");
+    const BnFinalizeArgs f{0.0, count_dev, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd};
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, C, f);
     Y3_CHECK_LAUNCH();
     return 0;
@@ -1358,7 +1372,7 @@ __global__ __launch_bounds__(256) void stat_rows_to_partials_kernel(const float*
 extern "C" int y3_bn_finalize_rows(const float* stat_rows, int64_t n_rows, int64_t count, int32_t C, double* sums, const float* gamma, const float* beta, float eps,
                                    float momentum, float* running_mean, float* running_var, float* scale, float* shift, float* mean, float* invstd, void* stream) {
     if (!stat_rows || !sums || !scale || !shift || !mean || !invstd || count <= 0 || n_rows <= 0 || n_rows > 0x7fffffffLL) Y3_FAIL("y3_bn_finalize_rows: bad argument");
-    const BnFinalizeArgs f{(double)count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd};
+    const BnFinalizeArgs f{(double)count, nullptr, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd};
     hipStream_t st = (hipStream_t)stream;
     if (n_rows > Y3_BN_PARTIAL_ROWS) {   // `sums` is a Y3_BN_SCRATCH_DOUBLES(C) buffer: two levels through its partial rows
         const int per = (int)((n_rows + Y3_BN_PARTIAL_ROWS - 1) / Y3_BN_PARTIAL_ROWS);
@@ -1373,6 +1387,24 @@ extern "C" int y3_bn_finalize_rows(const float* stat_rows, int64_t n_rows, int64
     return 0;
 }
 
+// the row sum of y3_bn_finalize_rows without the finalize: totals (sum, sum of squares) per channel in sums[0 .. 2C) -- what a SyncBatchNorm forward
+// all-reduces before y3_bn_finalize_devcount
+extern "C" int y3_bn_sum_rows(const float* stat_rows, int64_t n_rows, int32_t C, double* sums, void* stream) {
+    if (!stat_rows || !sums || n_rows <= 0 || n_rows > 0x7fffffffLL || C < 1) Y3_FAIL("y3_bn_sum_rows: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (n_rows > Y3_BN_PARTIAL_ROWS) {
+        const int per = (int)((n_rows + Y3_BN_PARTIAL_ROWS - 1) / Y3_BN_PARTIAL_ROWS);
+        const int blocks = (int)((n_rows + per - 1) / per);
+        hipLaunchKernelGGL(stat_rows_to_partials_kernel, dim3((unsigned)blocks), dim3(256), 0, st, stat_rows, (long long)n_rows, 2 * C, per, sums);
+        Y3_CHECK_LAUNCH();
+        hipLaunchKernelGGL((reduce_partials_kernel<0, double>), dim3((2 * C + 15) / 16), dim3(256), 0, st, sums, 2 * C, blocks, BnFinalizeArgs{}, (float*)nullptr, (float*)nullptr, 0, (const double*)nullptr);
+    } else {
+        hipLaunchKernelGGL((reduce_partials_kernel<0, float>), dim3((2 * C + 15) / 16), dim3(256), 0, st, sums, 2 * C, (int)n_rows, BnFinalizeArgs{}, (float*)nullptr, (float*)nullptr, 0, stat_rows);
+    }
+    Y3_CHECK_LAUNCH();
+    return 0;
+}
+
 // y3_bn_stats + y3_bn_finalize in two launches (the partial-row sum and the finalize share one kernel)
 extern "C" int y3_bn_stats_finalize(const y3_tensor* u, int32_t dtype, double* sums, const float* gamma, const float* beta, float eps, float momentum,
                                     float* running_mean, float* running_var, float* scale, float* shift, float* mean, float* invstd, void* stream) {
@@ -1382,7 +1414,7 @@ extern "C" int y3_bn_stats_finalize(const y3_tensor* u, int32_t dtype, double* s
     if (bn_stats_launch(u, dtype, sums, st, grid)) return -1;
     const long long M = (long long)u->n * u->h * u->w;
     if (M <= 0) Y3_FAIL("y3_bn_stats_finalize: empty tensor");
-    const BnFinalizeArgs f{(double)M, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd};
+    const BnFinalizeArgs f{(double)M, nullptr, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd};
     hipLaunchKernelGGL(reduce_partials_kernel<1>, dim3((2 * u->c + 15) / 16), dim3(256), 0, st, sums, 2 * u->c, (int)grid, f, (float*)nullptr, (float*)nullptr, 0);
     Y3_CHECK_LAUNCH();
     return 0;
@@ -1407,14 +1439,21 @@ extern "C" int y3_bn_act_fwd(const y3_tensor* u, const float* scale, const float
     return 0;
 }
 
-static int bn_act_bwd_impl(const y3_tensor* u, const y3_tensor* dy, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t dtype,
-                           int32_t act, double* sums, const y3_tensor* du, float* dgamma, float* dbeta, const y3_tensor* gres, int32_t gres_accumulate, void* stream) {
-    if (!u || !dy || !scale || !shift || !mean || !invstd || !sums || !du) Y3_FAIL("y3_bn_act_bwd: null argument");
-    if (dy->n != u->n || dy->h != u->h || dy->w != u->w || dy->c != u->c || du->c != u->c || du->h != u->h) Y3_FAIL("y3_bn_act_bwd: shape mismatch");
+static int bn_act_bwd_check(const y3_tensor* u, const y3_tensor* dy, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t dtype,
+                            const double* sums) {
+    if (!u || !dy || !scale || !shift || !mean || !invstd || !sums) Y3_FAIL("y3_bn_act_bwd: null argument");
+    if (dy->n != u->n || dy->h != u->h || dy->w != u->w || dy->c != u->c) Y3_FAIL("y3_bn_act_bwd: shape mismatch");
     const int esz = esize(dtype);
-    if (!vec_ok(u, esz) || !vec_ok(dy, esz) || !vec_ok(du, esz)) Y3_FAIL("y3_bn_act_bwd: alignment");
-    if (gres && (gres->n != u->n || gres->h != u->h || gres->w != u->w || gres->c != u->c || !vec_ok(gres, esz))) Y3_FAIL("y3_bn_act_bwd: residual gradient shape / alignment");
-    if (gres && gres->data == dy->data) Y3_FAIL("y3_bn_act_bwd: the residual gradient must not alias dy");
+    if (!vec_ok(u, esz) || !vec_ok(dy, esz)) Y3_FAIL("y3_bn_act_bwd: alignment");
+    return 0;
+}
+
+// phase 1: per-channel sums of (dz, dz * xhat) over this rank's pixels -> sums[0 .. 2C) (totals), dbeta / dgamma, and the two means the apply pass
+// reads in partial row 0 (sums[2C .. 4C))
+static int bn_act_bwd_reduce_impl(const y3_tensor* u, const y3_tensor* dy, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t dtype,
+                                  int32_t act, double* sums, float* dgamma, float* dbeta, void* stream) {
+    if (bn_act_bwd_check(u, dy, scale, shift, mean, invstd, dtype, sums)) return -1;
+    const int esz = esize(dtype);
     const long long M = (long long)u->n * u->h * u->w;
     unsigned grid;
     if (reduce_geometry(u->c, esz, M, grid)) return -1;
@@ -1431,6 +1470,22 @@ static int bn_act_bwd_impl(const y3_tensor* u, const y3_tensor* dy, const float*
     fm.count = (double)M;
     hipLaunchKernelGGL(reduce_partials_kernel<2>, dim3((2 * u->c + 15) / 16), dim3(256), 0, st, sums, 2 * u->c, (int)grid, fm, dbeta, dgamma, 0);
     Y3_CHECK_LAUNCH();
+    return 0;
+}
+
+// phase 2: du = gamma invstd (dz - mean(dz) - xhat mean(dz xhat)) with the means in sums[2C .. 4C) (the caller's all-reduced ones under SyncBatchNorm)
+static int bn_act_bwd_apply_impl(const y3_tensor* u, const y3_tensor* dy, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t dtype,
+                                 int32_t act, const double* sums, const y3_tensor* du, const y3_tensor* gres, int32_t gres_accumulate, void* stream) {
+    if (bn_act_bwd_check(u, dy, scale, shift, mean, invstd, dtype, sums)) return -1;
+    if (!du) Y3_FAIL("y3_bn_act_bwd: null argument");
+    if (du->c != u->c || du->h != u->h) Y3_FAIL("y3_bn_act_bwd: shape mismatch");
+    const int esz = esize(dtype);
+    if (!vec_ok(du, esz)) Y3_FAIL("y3_bn_act_bwd: alignment");
+    if (gres && (gres->n != u->n || gres->h != u->h || gres->w != u->w || gres->c != u->c || !vec_ok(gres, esz))) Y3_FAIL("y3_bn_act_bwd: residual gradient shape / alignment");
+    if (gres && gres->data == dy->data) Y3_FAIL("y3_bn_act_bwd: the residual gradient must not alias dy");
+    const long long M = (long long)u->n * u->h * u->w;
+    hipStream_t st = (hipStream_t)stream;
+    const bool nt = M * u->c * esz >= Y3_NT_BYTES;
     unsigned egrid;
     if (elementwise_geometry(u->c, esz, M, egrid)) return -1;
 #define Y3_BN_APPLY(SILU, NT) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, SILU, NT>), dim3(egrid), dim3(256), 0, st, (const T*)u->data, u->pitch, (const T*)dy->data, \
@@ -1440,6 +1495,23 @@ static int bn_act_bwd_impl(const y3_tensor* u, const y3_tensor* dy, const float*
 #undef Y3_BN_APPLY
     Y3_CHECK_LAUNCH();
     return 0;
+}
+
+static int bn_act_bwd_impl(const y3_tensor* u, const y3_tensor* dy, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t dtype,
+                           int32_t act, double* sums, const y3_tensor* du, float* dgamma, float* dbeta, const y3_tensor* gres, int32_t gres_accumulate, void* stream) {
+    if (!du) Y3_FAIL("y3_bn_act_bwd: null argument");
+    if (bn_act_bwd_reduce_impl(u, dy, scale, shift, mean, invstd, dtype, act, sums, dgamma, dbeta, stream)) return -1;
+    return bn_act_bwd_apply_impl(u, dy, scale, shift, mean, invstd, dtype, act, sums, du, gres, gres_accumulate, stream);
+}
+
+// the two phases on their own: a SyncBatchNorm backward all-reduces the totals between them and writes the global means into sums[2C .. 4C)
+extern "C" int y3_bn_act_bwd_reduce(const y3_tensor* u, const y3_tensor* dy, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t dtype,
+                                    int32_t act, double* sums, float* dgamma, float* dbeta, void* stream) {
+    return bn_act_bwd_reduce_impl(u, dy, scale, shift, mean, invstd, dtype, act, sums, dgamma, dbeta, stream);
+}
+extern "C" int y3_bn_act_bwd_apply(const y3_tensor* u, const y3_tensor* dy, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t dtype,
+                                   int32_t act, const double* sums, const y3_tensor* du, const y3_tensor* gres, int32_t gres_accumulate, void* stream) {
+    return bn_act_bwd_apply_impl(u, dy, scale, shift, mean, invstd, dtype, act, sums, du, gres, gres_accumulate, stream);
 }
 
 extern "C" int y3_bn_act_bwd(const y3_tensor* u, const y3_tensor* dy, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t dtype,

@@ -136,6 +136,66 @@ __global__ __launch_bounds__(256) void match_detections_kernel(const float* __re
     }
 }
 
+// ---- test-time augmentation edges (reference models/yolo.py:239-276 _forward_augment) ---------------------------------------------
+// scale_img (upstream ultralytics.utils.torch_utils.scale_img, un-vendored; restated in oracle/upstream.py): the batch, optionally mirrored left-right
+// (`x.flip(3)`, models/yolo.py:246), resized with F.interpolate(mode="bilinear", align_corners=False) to (ih, iw) = (int(h ratio), int(w ratio)) and padded
+// on the right / bottom with 0.447 to the next multiple of the largest stride.  Source index of output o: max(0, (o + 0.5) * in / out - 0.5), fp32 weights,
+// the four products summed in torch's order (row pairs first), one rounding to T at the end.  NCHW in, NCHW out (the model's ingest kernel reads NCHW).
+struct ScaleImgArgs {
+    const void* src;
+    void* dst;
+    int planes, h, w, ih, iw, oh, ow, flip;
+    float rh, rw, pad;
+};
+template <typename T> __global__ __launch_bounds__(256) void scale_img_kernel(const ScaleImgArgs a) {
+    const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (ox >= a.ow || oy >= a.oh) return;
+    const bool inside = ox < a.iw && oy < a.ih;
+    int y0 = 0, x0 = 0, y1 = 0, x1 = 0;
+    float ly = 0.f, lx = 0.f;
+    if (inside) {
+        const float sy = fmaxf(a.rh * ((float)oy + 0.5f) - 0.5f, 0.0f), sx = fmaxf(a.rw * ((float)ox + 0.5f) - 0.5f, 0.0f);
+        y0 = (int)sy; x0 = (int)sx;
+        y1 = y0 + (y0 < a.h - 1 ? 1 : 0);
+        x1 = x0 + (x0 < a.w - 1 ? 1 : 0);
+        ly = sy - (float)y0; lx = sx - (float)x0;
+        if (a.flip) { x0 = a.w - 1 - x0; x1 = a.w - 1 - x1; }   // the mirrored image's column j is column w - 1 - j of the source
+    }
+    const float hy = 1.0f - ly, hx = 1.0f - lx;
+    const T* src = (const T*)a.src;
+    T* dst = (T*)a.dst;
+    for (int pl = blockIdx.z; pl < a.planes; pl += gridDim.z) {
+        float v = a.pad;
+        if (inside) {
+            const T* s = src + (long long)pl * a.h * a.w;
+            const float v00 = to_f32<T>(s[(long long)y0 * a.w + x0]), v01 = to_f32<T>(s[(long long)y0 * a.w + x1]);
+            const float v10 = to_f32<T>(s[(long long)y1 * a.w + x0]), v11 = to_f32<T>(s[(long long)y1 * a.w + x1]);
+            v = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+        }
+        dst[((long long)pl * a.oh + oy) * a.ow + ox] = from_f32<T>(v);
+    }
+}
+
+// _descale_pred + the row selection of _clip_augmented (models/yolo.py:253-276) in one pass: rows [row0, row0 + nrows) of every image of one scale's
+// decoded prediction (bs, src_rows, no) land at rows [dst_row0, ...) of the concatenated (bs, dst_rows, no) result with xywh / scale and, for a mirrored
+// pass, x = img_w - x (flip 3) or y = img_h - y (flip 2); every step rounded to T like the in-place tensor ops of the reference.
+template <typename T> __global__ __launch_bounds__(256) void descale_pred_kernel(const T* __restrict__ src, int src_rows, int no, int row0, int nrows, float scale, int flip, float img_h,
+                                                                                   float img_w, T* __restrict__ dst, int dst_rows, int dst_row0, long long total) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int col = (int)(idx % no);
+    const long long rr = idx / no;
+    const int r = (int)(rr % nrows), img = (int)(rr / nrows);
+    float v = to_f32<T>(src[((long long)img * src_rows + row0 + r) * no + col]);
+    if (col < 4) {
+        v = rt<T>(v / scale);
+        if (flip == 3 && col == 0) v = rt<T>(img_w - v);
+        if (flip == 2 && col == 1) v = rt<T>(img_h - v);
+    }
+    dst[((long long)img * dst_rows + dst_row0 + r) * no + col] = from_f32<T>(v);
+}
+
 }  // namespace
 
 extern "C" int y3_scale_boxes(float* rows, int64_t img_stride, int32_t row_stride, const int32_t* counts, int32_t bs, int32_t max_rows, const float* params, void* stream) {
@@ -172,6 +232,46 @@ extern "C" int y3_letterbox_u8(const uint8_t* src, int32_t h0, int32_t w0, int32
     a.scale_x = 1.0 / ((double)new_w / (double)w0);
     a.scale_y = 1.0 / ((double)new_h / (double)h0);
     hipLaunchKernelGGL(letterbox_u8_kernel, dim3((unsigned)((W1 + 63) / 64), (unsigned)((H1 + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+    Y3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int y3_scale_img(const void* src, int32_t dtype, int32_t n, int32_t c, int32_t h, int32_t w, int32_t ih, int32_t iw, int32_t oh, int32_t ow, int32_t flip_lr, float pad_value,
+                            void* dst, void* stream) {
+    if (!src || !dst) Y3_FAIL("y3_scale_img: null argument");
+    if (n < 0 || c < 1 || h < 1 || w < 1 || ih < 1 || iw < 1 || oh < ih || ow < iw) Y3_FAIL("y3_scale_img: bad geometry (%dx%dx%dx%d -> %dx%d in %dx%d)", n, c, h, w, ih, iw, oh, ow);
+    if ((long long)n * c > 0x7fffffffLL) Y3_FAIL("y3_scale_img: too many planes");
+    if (n == 0) return 0;
+    ScaleImgArgs a;
+    a.src = src; a.dst = dst; a.planes = n * c; a.h = h; a.w = w; a.ih = ih; a.iw = iw; a.oh = oh; a.ow = ow; a.flip = flip_lr ? 1 : 0;
+    a.rh = (float)h / (float)ih;   // torch's area_pixel_compute_scale without a scale factor: input size / output size
+    a.rw = (float)w / (float)iw;
+    a.pad = pad_value;
+    const dim3 grid((unsigned)((ow + 63) / 64), (unsigned)((oh + 3) / 4), (unsigned)(a.planes < 64 ? a.planes : 64));
+    switch (dtype) {
+        case Y3_F32: hipLaunchKernelGGL(scale_img_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+        case Y3_F16: hipLaunchKernelGGL(scale_img_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+        case Y3_BF16: hipLaunchKernelGGL(scale_img_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, a); break;
+        default: Y3_FAIL("y3_scale_img: unsupported dtype %d", dtype);
+    }
+    Y3_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int y3_descale_pred(const void* src, int32_t dtype, int32_t bs, int32_t src_rows, int32_t no, int32_t row0, int32_t nrows, float scale, int32_t flip, float img_h, float img_w,
+                               void* dst, int32_t dst_rows, int32_t dst_row0, void* stream) {
+    if (!src || !dst) Y3_FAIL("y3_descale_pred: null argument");
+    if (bs < 0 || no < 5 || row0 < 0 || nrows < 0 || row0 + nrows > src_rows || dst_row0 < 0 || dst_row0 + nrows > dst_rows) Y3_FAIL("y3_descale_pred: bad geometry");
+    if (!(scale > 0.0f) || (flip != 0 && flip != 2 && flip != 3)) Y3_FAIL("y3_descale_pred: scale %g / flip %d unsupported (flip: 0 none, 2 up-down, 3 left-right)", (double)scale, flip);
+    const long long total = (long long)bs * nrows * no;
+    if (total == 0) return 0;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    switch (dtype) {
+        case Y3_F32: hipLaunchKernelGGL(descale_pred_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, src_rows, no, row0, nrows, scale, flip, img_h, img_w, (float*)dst, dst_rows, dst_row0, total); break;
+        case Y3_F16: hipLaunchKernelGGL(descale_pred_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)src, src_rows, no, row0, nrows, scale, flip, img_h, img_w, (_Float16*)dst, dst_rows, dst_row0, total); break;
+        case Y3_BF16: hipLaunchKernelGGL(descale_pred_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, src_rows, no, row0, nrows, scale, flip, img_h, img_w, (bf16_t*)dst, dst_rows, dst_row0, total); break;
+        default: Y3_FAIL("y3_descale_pred: unsupported dtype %d", dtype);
+    }
     Y3_CHECK_LAUNCH();
     return 0;
 }

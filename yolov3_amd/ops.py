@@ -5,6 +5,8 @@ from __future__ import annotations
 import ctypes as C
 from dataclasses import dataclass
 
+import math
+
 import torch
 
 from . import _lib
@@ -368,6 +370,33 @@ def match_detections_raw(dets: torch.Tensor, img_stride: int, row_stride: int, c
                                          labels.data_ptr() if labels.numel() else None, offsets.data_ptr(), iouv.data_ptr(), int(iouv.numel()), correct.data_ptr(), stream_ptr()),
           "y3_match_detections")
     return correct
+
+
+def scale_img(img: torch.Tensor, ratio: float = 1.0, same_shape: bool = False, gs: int = 32, flip_lr: bool = False) -> torch.Tensor:
+    """upstream scale_img (the resize + pad of reference models/yolo.py:246), fused with the left-right mirror of the same line: (n, c, h, w) ->
+    (n, c, ceil(h ratio / gs) gs, ceil(w ratio / gs) gs).  ratio 1.0 without a mirror returns `img` itself, like upstream."""
+    if ratio == 1.0 and not flip_lr:
+        return img
+    require_gpu(img, "scale_img")
+    if img.dim() != 4 or img.dtype not in (torch.float32, torch.float16, torch.bfloat16):
+        raise TypeError("scale_img expects a floating (n, c, h, w) batch")
+    img = img.contiguous()
+    n, c, h, w = img.shape
+    ih, iw = (h, w) if ratio == 1.0 else (int(h * ratio), int(w * ratio))
+    oh, ow = (ih, iw) if (same_shape or ratio == 1.0) else (math.ceil(h * ratio / gs) * gs, math.ceil(w * ratio / gs) * gs)
+    out = torch.empty(n, c, oh, ow, dtype=img.dtype, device=img.device)
+    check(_lib.lib().y3_scale_img(img.data_ptr(), dtype_code(img.dtype), n, c, h, w, ih, iw, oh, ow, int(bool(flip_lr)), 0.447, out.data_ptr(), stream_ptr()), "y3_scale_img")
+    return out
+
+
+def descale_pred_into(pred: torch.Tensor, row0: int, nrows: int, scale: float, flip, img_size, out: torch.Tensor, out_row0: int):
+    """rows [row0, row0 + nrows) of the decoded prediction (bs, rows, no) of one augmentation pass, de-scaled / de-mirrored (reference models/yolo.py:253-267),
+    into rows [out_row0, ...) of the concatenated result."""
+    require_gpu(pred, "_descale_pred")
+    if pred.dim() != 3 or out.dim() != 3 or pred.dtype != out.dtype or not pred.is_contiguous() or not out.is_contiguous() or pred.shape[0] != out.shape[0] or pred.shape[2] != out.shape[2]:
+        raise TypeError("descale_pred_into expects contiguous (bs, rows, no) tensors of one dtype")
+    check(_lib.lib().y3_descale_pred(pred.data_ptr(), dtype_code(pred.dtype), pred.shape[0], pred.shape[1], pred.shape[2], int(row0), int(nrows), float(scale), int(flip or 0),
+                                     float(img_size[0]), float(img_size[1]), out.data_ptr(), out.shape[1], int(out_row0), stream_ptr()), "y3_descale_pred")
 
 
 def letterbox_u8(src_hwc: torch.Tensor, dst_batch: torch.Tensor, index: int, new_h: int, new_w: int, top: int, left: int, color: int = 114):

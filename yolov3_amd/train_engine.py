@@ -106,6 +106,31 @@ class ConvUnit(_Unit):
         self.pair_pack = need_dx and plan.dtype in (torch.float16, torch.bfloat16) and not (self.s == 2 and self.k == 3)
         self.bank_fwd = self.bank_dgrad = None   # persistent filter banks filled by the plan's one-launch packing (TrainPlan.pack_jobs)
 
+    def sync_group(self):
+        """the process group of a torch.nn.SyncBatchNorm layer (reference train.py:270-272: --sync-bn converts every BatchNorm2d before DDP wraps the
+        model) when there is more than one rank in it, else False: the layer then behaves like nn.BatchNorm2d, as torch's does"""
+        bn = self.m.bn
+        if not isinstance(bn, nn.SyncBatchNorm) or not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            return False
+        group = bn.process_group   # None = the default group
+        return (group,) if torch.distributed.get_world_size(group) > 1 else False
+
+    def _sync_forward_stats(self, group):
+        """sums[0 .. 2C) hold this rank's (sum, sum of squares): all-reduce them together with the element count, finalize with the global count"""
+        bn, c2 = self.m.bn, 2 * self.cout
+        pack = torch.empty(c2 + 1, dtype=torch.float64, device=self.plan.device)
+        pack[:c2].copy_(self.sums[:c2])
+        pack[c2] = float(self.count)
+        torch.distributed.all_reduce(pack, group=group[0])
+        self.sums[:c2].copy_(pack[:c2])
+        self.count_all = pack[c2:]   # kept for the backward of this step
+        check(
+            _lib.lib().y3_bn_finalize_devcount(self.sums.data_ptr(), self.count_all.data_ptr(), self.cout, bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps),
+                                               float(bn.momentum), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
+                                               self.mean.data_ptr(), self.invstd.data_ptr(), ops.stream_ptr()),
+            "y3_bn_finalize_devcount",
+        )
+
     def generic_dgrad(self) -> bool:
         """the data gradient runs as ONE launch of the forward conv kernels on the flipped bank (not the stride-2 parity classes)"""
         return self.need_dx and not (self.s == 2 and self.k == 3 and self.plan.dtype != torch.float32)
@@ -113,7 +138,7 @@ class ConvUnit(_Unit):
     def fused_stem_bwd(self) -> bool:
         """layer 0 through y3_stem_bn_bwd_wgrad (Y3_STEM_BWD=0: BatchNorm backward + generic filter gradient, for A/B runs)"""
         return (self.use_stem and self.plan.x_nchw is not None and not self.need_dx and self.res is None and self.cout == 32 and self.ci_real <= 3
-                and os.environ.get("Y3_STEM_BWD", "1") != "0")
+                and os.environ.get("Y3_STEM_BWD", "1") != "0" and not self.sync_group())   # (SyncBatchNorm: the two-phase backward below)
 
     def fwd(self):
         m, bn = self.m, self.m.bn
@@ -124,6 +149,7 @@ class ConvUnit(_Unit):
         dcode = ops.dtype_code(self.plan.dtype)
         ut = self.u.y3()
         stats_in_epilogue = False
+        sync = self.sync_group()
         if self.use_stem and self.plan.x_nchw is not None:
             # layer 0 straight from the caller's NCHW image (csrc/stem.hip); the NHWC copy is still made for the filter gradient
             filt = ops.pack_filter_stem(m.conv.weight, self.cout, self.plan.dtype)
@@ -132,12 +158,16 @@ class ConvUnit(_Unit):
                 rows = ops.stem_conv_stats_rows(xi.shape[0], xi.shape[2], xi.shape[3])
                 buf = self.plan.stat_buffer(rows * 2 * self.cout)
                 n_rows = ops.stem_conv_stats(xi, filt, self.zero_bias, self.u, buf, rows)
-                check(
-                    L.y3_bn_finalize_rows(buf.data_ptr(), n_rows, self.count, self.cout, self.sums.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps),
-                                          float(bn.momentum), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
-                                          self.mean.data_ptr(), self.invstd.data_ptr(), st),
-                    "y3_bn_finalize_rows",
-                )
+                if sync:
+                    check(L.y3_bn_sum_rows(buf.data_ptr(), n_rows, self.cout, self.sums.data_ptr(), st), "y3_bn_sum_rows")
+                    self._sync_forward_stats(sync)
+                else:
+                    check(
+                        L.y3_bn_finalize_rows(buf.data_ptr(), n_rows, self.count, self.cout, self.sums.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps),
+                                              float(bn.momentum), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
+                                              self.mean.data_ptr(), self.invstd.data_ptr(), st),
+                        "y3_bn_finalize_rows",
+                    )
                 stats_in_epilogue = True
             else:
                 ops.stem_conv(self.plan.x_nchw, filt, self.zero_bias, self.u, act=False)
@@ -155,16 +185,23 @@ class ConvUnit(_Unit):
                     self.stat_rows = ops.conv2d_stats_rows(self.x.view, self.u, self.k, self.s, workspace=ws)
                 buf = self.plan.stat_buffer(self.stat_rows * 2 * self.cout)
                 n_rows = ops.conv2d_stats(self.x.view, filt, self.zero_bias, self.u, self.k, self.s, buf, self.stat_rows, workspace=ws)
-                check(
-                    L.y3_bn_finalize_rows(buf.data_ptr(), n_rows, self.count, self.cout, self.sums.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps),
-                                          float(bn.momentum), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
-                                          self.mean.data_ptr(), self.invstd.data_ptr(), st),
-                    "y3_bn_finalize_rows",
-                )
+                if sync:
+                    check(L.y3_bn_sum_rows(buf.data_ptr(), n_rows, self.cout, self.sums.data_ptr(), st), "y3_bn_sum_rows")
+                    self._sync_forward_stats(sync)
+                else:
+                    check(
+                        L.y3_bn_finalize_rows(buf.data_ptr(), n_rows, self.count, self.cout, self.sums.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps),
+                                              float(bn.momentum), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
+                                              self.mean.data_ptr(), self.invstd.data_ptr(), st),
+                        "y3_bn_finalize_rows",
+                    )
                 stats_in_epilogue = True
             else:
                 ops.conv2d(self.x.view, filt, self.zero_bias, self.u, self.k, self.s, act=False, workspace=self.plan.conv_ws)
-        if not stats_in_epilogue:
+        if not stats_in_epilogue and sync:
+            check(L.y3_bn_stats(C.byref(ut), dcode, self.sums.data_ptr(), st), "y3_bn_stats")
+            self._sync_forward_stats(sync)
+        elif not stats_in_epilogue:
             check(
                 L.y3_bn_stats_finalize(C.byref(ut), dcode, self.sums.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps), float(bn.momentum),
                                        bn.running_mean.data_ptr(), bn.running_var.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(), self.mean.data_ptr(),
@@ -197,7 +234,31 @@ class ConvUnit(_Unit):
             return
         du = self.plan.scratch_like(self.u)
         ut, gt, dt = self.u.y3(), gy.y3(), du.y3()
-        if self.res is not None:  # out = act(bn(conv)) + res  ->  d res (+)= d out, written by the pass that reads d out anyway
+        sync = self.sync_group()
+        if sync:
+            # SyncBatchNorm: du needs the means of (dz, dz xhat) over EVERY rank's pixels; dgamma / dbeta stay this rank's sums (the gradient
+            # exchange averages them with the other parameter gradients, as DDP does around torch's SyncBatchNorm)
+            c2 = 2 * self.cout
+            check(
+                L.y3_bn_act_bwd_reduce(C.byref(ut), C.byref(gt), self.scale.data_ptr(), self.shift.data_ptr(), self.mean.data_ptr(), self.invstd.data_ptr(), dcode, self.act,
+                                       self.sums.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), st),
+                "y3_bn_act_bwd_reduce",
+            )
+            tot = self.sums[:c2].clone()
+            torch.distributed.all_reduce(tot, group=sync[0])
+            self.sums[c2 : 2 * c2].copy_(tot / self.count_all)
+            grt = None
+            if self.res is not None:
+                gr = self.res.grad()
+                grt = gr.y3()
+            check(
+                L.y3_bn_act_bwd_apply(C.byref(ut), C.byref(gt), self.scale.data_ptr(), self.shift.data_ptr(), self.mean.data_ptr(), self.invstd.data_ptr(), dcode, self.act,
+                                      self.sums.data_ptr(), C.byref(dt), C.byref(grt) if grt is not None else None, int(self.res.is_ready()) if self.res is not None else 0, st),
+                "y3_bn_act_bwd_apply",
+            )
+            if self.res is not None:
+                self.res.mark_ready()
+        elif self.res is not None:  # out = act(bn(conv)) + res  ->  d res (+)= d out, written by the pass that reads d out anyway
             gr = self.res.grad()
             grt = gr.y3()
             check(

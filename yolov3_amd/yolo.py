@@ -223,8 +223,47 @@ class DetectionModel(BaseModel):
 
     def forward(self, x, augment=False, profile=False, visualize=False):
         if augment:
-            raise NotImplementedError("test-time augmentation is outside the accelerated hot path")
+            return self._forward_augment(x)
         return self._forward_once(x, profile, visualize)
+
+    def _forward_augment(self, x):
+        """Test-time augmentation (reference :239-276): the batch at scales 1 / 0.83 / 0.67, the middle one mirrored left-right, each through the
+        engine; the decoded predictions de-scaled / de-mirrored and concatenated without the stride-32 rows of the full-size pass and the stride-8
+        rows of the smallest one (_clip_augmented).  The mirror + resize + pad and the de-scale + row selection are one kernel each
+        (csrc/val_edge.hip); the concatenated tensor is written once."""
+        if self.training:
+            raise RuntimeError("augmented inference is an eval-mode path (the reference indexes the decoded prediction of eval mode)")
+        from . import ops
+
+        img_size = x.shape[-2:]
+        scales, flips = [1, 0.83, 0.67], [None, 3, None]
+        gs = int(self.stride.max())
+        det = self.model[-1]
+        nl, no = det.nl, det.no
+        g = sum(4**k for k in range(nl))
+        strides = [int(v) for v in self.stride.tolist()]
+        # the row windows first (the decoded prediction of an (h, w) pass has na * sum_l (h / s_l)(w / s_l) rows): the result is allocated once and every
+        # pass is de-scaled into its window as soon as it is through the engine
+        windows = []
+        for i, si in enumerate(scales):
+            h, w = (img_size if si == 1 else (math.ceil(d * si / gs) * gs for d in img_size))
+            rows = det.na * sum((h // s) * (w // s) for s in strides)
+            lo, hi = 0, rows
+            if i == 0:
+                hi = rows - (rows // g) * 1                    # without the tail: the coarsest level of the full-size pass
+            if i == len(scales) - 1:
+                lo = (rows // g) * 4 ** (nl - 1)               # without the head: the finest level of the smallest pass
+            windows.append((rows, lo, hi - lo))
+        out, off = None, 0
+        for (rows, lo, n), si, fi in zip(windows, scales, flips):
+            yi = self._forward_once(ops.scale_img(x, si, gs=gs, flip_lr=fi == 3))[0]
+            if yi.shape[1] != rows or yi.shape[2] != no:
+                raise RuntimeError(f"augmented pass at scale {si}: {tuple(yi.shape)} rows, expected {rows} x {no}")
+            if out is None:
+                out = torch.empty(yi.shape[0], sum(w[2] for w in windows), no, dtype=yi.dtype, device=yi.device)
+            ops.descale_pred_into(yi.contiguous(), lo, n, si, fi, img_size, out, off)
+            off += n
+        return out, None
 
     def _initialize_biases(self, cf=None):
         """Detect bias prior (reference :282-292): obj += log(8/(640/s)^2), cls += log(0.6/(nc-0.99999))."""
