@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void match_detections_kernel(const float* __re
 // ---- test-time augmentation edges (reference models/yolo.py:239-276 _forward_augment) ---------------------------------------------
 // scale_img (upstream ultralytics.utils.torch_utils.scale_img, un-vendored; restated in oracle/upstream.py): the batch, optionally mirrored left-right
 // (`x.flip(3)`, models/yolo.py:246), resized with F.interpolate(mode="bilinear", align_corners=False) to (ih, iw) = (int(h ratio), int(w ratio)) and padded
-// on the right / bottom with 0.447 to the next multiple of the largest stride.  Source index of output o: max(0, (o + 0.5) * in / out - 0.5), fp32 weights,
+// on the right / bottom with 0.447 to the next multiple of the largest stride.  Source index of output o: max(0, fma(in / out, o + 0.5, -0.5)), fp32 weights,
 // the four products summed in torch's order (row pairs first), one rounding to T at the end.  NCHW in, NCHW out (the model's ingest kernel reads NCHW).
 struct ScaleImgArgs {
     const void* src;
@@ -155,7 +155,9 @@ template <typename T> __global__ __launch_bounds__(256) void scale_img_kernel(co
     int y0 = 0, x0 = 0, y1 = 0, x1 = 0;
     float ly = 0.f, lx = 0.f;
     if (inside) {
-        const float sy = fmaxf(a.rh * ((float)oy + 0.5f) - 0.5f, 0.0f), sx = fmaxf(a.rw * ((float)ox + 0.5f) - 0.5f, 0.0f);
+        // scale * (o + 0.5) - 0.5 as ONE fused multiply-add, like torch's kernels (the file is built with -ffp-contract=off; two roundings move the
+        // weights by an ulp of the index: 1.7e-6 on the goldens instead of 1.2e-7)
+        const float sy = fmaxf(fmaf(a.rh, (float)oy + 0.5f, -0.5f), 0.0f), sx = fmaxf(fmaf(a.rw, (float)ox + 0.5f, -0.5f), 0.0f);
         y0 = (int)sy; x0 = (int)sx;
         y1 = y0 + (y0 < a.h - 1 ? 1 : 0);
         x1 = x0 + (x0 < a.w - 1 ? 1 : 0);
