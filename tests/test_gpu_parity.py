@@ -1951,6 +1951,9 @@ BENCH_WGRAD_CASES = [
     ("L4cv2_64_128_160", (64, 160, 160, 64, 128, 3, 1), (128, 1)),
     ("L3_64_128_s2_320", (64, 320, 320, 64, 128, 3, 2), (128, 1)),
     ("L2cv1_64_32_1x1_320", (64, 320, 320, 64, 32, 1, 1), (128, 0)),
+    # the 64-filter tiles of the 640x640 / 320x320 maps: stride 1 / 2, the ragged third column tile of 288 columns, 6.5 M pixels
+    ("L1_32_64_s2_640", (64, 640, 640, 32, 64, 3, 2), (128, 0)),
+    ("L2cv2_32_64_320", (64, 320, 320, 32, 64, 3, 1), (128, 0)),
 ]
 
 
