@@ -962,6 +962,53 @@ def test_conv_wgrad_and_dgrad_vs_autograd(dev, dtype, name, shape, kw):
     assert e_w < tol and e_b < max(tol, 2e-3) and e_x < tol, f"{name} {dtype}: wgrad {e_w:.2e} bias {e_b:.2e} dgrad {e_x:.2e}"
 
 
+STRIP_WGRAD_CASES = [
+    # name, (n, h, w, cin, cout, k, s), K-steps per block (knob wgrad_strip; 2 = the host's plan)
+    ("c32_s1_one_strip", (2, 20, 64, 32, 64, 3, 1), 2),
+    ("c32_s1_ragged_strips_walk7", (3, 19, 150, 32, 64, 3, 1), 7),      # 3 strips, the last 22 pixels wide; blocks cross strips and images
+    ("c32_s2_walk5", (2, 46, 200, 32, 64, 3, 2), 5),                    # stride 2: two new input rows per K-step, 100 output columns
+    ("c32_s2_odd", (2, 37, 131, 32, 64, 3, 2), 3),                      # odd input sizes: the last input row / column only under some taps
+    ("c64_s1_two_halves_walk9", (2, 24, 96, 64, 128, 3, 1), 9),         # 128 filters = two 64-filter blocks per strip
+    ("c64_s2_walk4", (2, 40, 140, 64, 128, 3, 2), 4),
+    ("c64_s1_tall_one_block", (1, 70, 64, 64, 128, 3, 1), 70),          # one block walks a whole strip: the row ring wraps many times
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name,shape,per", STRIP_WGRAD_CASES, ids=[c[0] for c in STRIP_WGRAD_CASES])
+def test_conv_wgrad_strip_vs_autograd(dev, tune, dtype, name, shape, per):
+    """the strip-walking filter-gradient kernel (csrc/wgrad_strip.h: all nine taps from three resident input rows, one block per 64-pixel column strip
+    segment) against torch autograd in fp32 on the same rounded operands, and against the tile kernel it replaces on these shapes (knob 0)"""
+    _lib, ops = _ops()
+    n, h, w, cin, cout, k, s = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, cin, h, w, generator=g).to(dtype).float()
+    wt = torch.zeros(cout, cin, k, k, requires_grad=True)
+    y = F.conv2d(x, wt, None, stride=s, padding=1)
+    gy = torch.randn(y.shape, generator=g).to(dtype).float()
+    y.backward(gy)
+    xv = ops.View.alloc(n, h, w, cin, dtype, dev)
+    ops.nchw_to_nhwc(x.to(dev), xv)
+    gv = ops.View.alloc(n, y.shape[2], y.shape[3], cout, dtype, dev)
+    ops.nchw_to_nhwc(gy.to(dev), gv)
+    tune("wgrad_strip", per)
+    tile, blocks, _ = ops.conv2d_wgrad_plan(xv, cout, k, s)
+    assert tile == 3 and blocks >= 1, (tile, blocks)
+    dw, _ = ops.conv2d_wgrad(xv, gv, k, s, cout, cin)
+    dw2, _ = ops.conv2d_wgrad(xv, gv, k, s, cout, cin)
+    tune("wgrad_strip", 0)
+    assert ops.conv2d_wgrad_plan(xv, cout, k, s)[0] == 128
+    dw_old, _ = ops.conv2d_wgrad(xv, gv, k, s, cout, cin)
+    torch.cuda.synchronize()
+    assert torch.equal(dw, dw2), "not run-to-run deterministic"
+    ref = wt.grad
+    scale = ref.abs().max().item()
+    e_w = (dw.cpu() - ref).abs().max().item() / scale
+    e_o = (dw.cpu() - dw_old.cpu()).abs().max().item() / scale
+    # same products, fp32 accumulation in another order: 1e-6-level against autograd and against the tile kernel
+    assert e_w < 2e-5 and e_o < 2e-5, f"{name} {dtype}: vs autograd {e_w:.2e}, vs tile kernel {e_o:.2e}"
+
+
 BIG_WGRAD_CASES = [
     ("3x3s1_80", (4, 80, 80, 128, 256, 3, 1)),        # 5 column tiles (4.5 used), slices chosen for one round of 256 blocks
     ("3x3s2_odd", (16, 67, 63, 128, 256, 3, 2)),      # stride 2, odd extents: halo + ragged last K-step
@@ -1948,12 +1995,12 @@ BENCH_WGRAD_CASES = [
     ("L8cv2_256_512_40", (64, 40, 40, 256, 512, 3, 1), (256, 1)),
     ("L10cv2_512_1024_20", (64, 20, 20, 512, 1024, 3, 1), (256, 1)),
     ("L5_128_256_s2_160", (64, 160, 160, 128, 256, 3, 2), (256, 1)),
-    ("L4cv2_64_128_160", (64, 160, 160, 64, 128, 3, 1), (128, 1)),
-    ("L3_64_128_s2_320", (64, 320, 320, 64, 128, 3, 2), (128, 1)),
+    ("L4cv2_64_128_160", (64, 160, 160, 64, 128, 3, 1), (3, 0)),      # tile 3 = the strip kernel (wgrad_strip.h)
+    ("L3_64_128_s2_320", (64, 320, 320, 64, 128, 3, 2), (3, 0)),
     ("L2cv1_64_32_1x1_320", (64, 320, 320, 64, 32, 1, 1), (128, 0)),
     # the 64-filter tiles of the 640x640 / 320x320 maps: stride 1 / 2, the ragged third column tile of 288 columns, 6.5 M pixels
-    ("L1_32_64_s2_640", (64, 640, 640, 32, 64, 3, 2), (128, 0)),
-    ("L2cv2_32_64_320", (64, 320, 320, 32, 64, 3, 1), (128, 0)),
+    ("L1_32_64_s2_640", (64, 640, 640, 32, 64, 3, 2), (3, 0)),
+    ("L2cv2_32_64_320", (64, 320, 320, 32, 64, 3, 1), (3, 0)),
 ]
 
 

@@ -379,11 +379,23 @@ def test_wgrad_geometry_fills_whole_rounds():
         assert nbytes % (256 * 256 * 4) == 0 and blocks % tiles == 0, (cin, cout, hw, nbytes)
         rounds = -(-blocks // 256)
         assert rounds <= 2 and blocks / (256 * rounds) >= 0.98, f"{cin}->{cout}@{hw}: {blocks} blocks"
-    for cin, cout, k, hw in [(64, 128, 3, 160), (256, 128, 1, 80), (32, 64, 3, 320), (1024, 512, 1, 20)]:
+    for cin, cout, k, hw in [(128, 64, 3, 160), (256, 128, 1, 80), (64, 32, 1, 320), (1024, 512, 1, 20)]:
         x = Y3Tensor(4096, 64, hw, hw, cin, cin)
         nbytes = L.y3_conv2d_wgrad_workspace_bytes(C.byref(_desc(_lib.Y3_F16, k, 1, cin, cout)), C.byref(x))
         tiles = -(-cout // 128) * -(-(k * k * cin) // 128)
         assert nbytes % (128 * 128 * 4 * tiles) == 0, (cin, cout, k, hw)
+    # the 3x3 layers with 32 -> 64 / 64 -> 128 channels on the large maps: the strip kernel (csrc/wgrad_strip.h) -- one [9 cin][64] fp32 partial tile per
+    # persistent block and 64-filter half, 3 / 2 / 2 / 1 blocks per CU (what the LDS holds)
+    tile, slices, xg = C.c_int32(0), C.c_int64(0), C.c_int32(0)
+    for cin, cout, s, hw, blocks in [(32, 64, 1, 320, 768), (32, 64, 2, 640, 512), (64, 128, 1, 160, 256), (64, 128, 2, 320, 128)]:
+        x = Y3Tensor(4096, 64, hw, hw, cin, cin)
+        d = _desc(_lib.Y3_F16, 3, s, cin, cout)
+        assert L.y3_conv2d_wgrad_plan(C.byref(d), C.byref(x), C.byref(tile), C.byref(slices), C.byref(xg)) == 0
+        assert tile.value == 3 and xg.value == 0 and abs(slices.value - blocks) <= blocks // 50, (cin, cout, s, slices.value)
+        assert L.y3_conv2d_wgrad_workspace_bytes(C.byref(d), C.byref(x)) >= slices.value * (cout // 64) * 9 * cin * 64 * 4
+    # ... a small launch of the same layer stays on the tile kernel (too few K-steps per block to amortise the partial tiles)
+    x = Y3Tensor(4096, 2, 64, 64, 32, 32)
+    assert L.y3_conv2d_wgrad_plan(C.byref(_desc(_lib.Y3_F16, 3, 1, 32, 64)), C.byref(x), C.byref(tile), C.byref(slices), C.byref(xg)) == 0 and tile.value == 128
 
 
 def test_map_parity_helpers_on_cpu():

@@ -1,6 +1,6 @@
 """Filter-gradient launches of the batch-64 train step, timed per shape with knob arms interleaved (same process, same box).
 
-    python tools/wgrad_lab.py [--arms "wgrad_xcd=2;wgrad_xcd=3"] [--shapes L1,L2cv2,...]
+    python tools/wgrad_lab.py [--arms "wgrad_strip=0;wgrad_strip=1"] [--shapes L1,L2cv2,...]
 
 Prints median / min microseconds per arm (y3_conv2d_wgrad = the tile kernel + the slice sum), the algorithmic HBM rate (x + du read once) and TFLOP/s."""
 import argparse
@@ -29,7 +29,7 @@ SHAPES = {
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--arms", default="wgrad_xcd=2;wgrad_xcd=3")
+    ap.add_argument("--arms", default="wgrad_strip=0;wgrad_strip=1")
     ap.add_argument("--shapes", default="L1,L2cv1,L2cv2,L4cv1,L3,L4cv2")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--reps", type=int, default=6)

@@ -1633,6 +1633,8 @@ static bool wgrad_use_big(const y3_conv_desc* d, long long M) {
     if (mode == 3) return shape_ok;
     return shape_ok && d->ksize * d->ksize * d->cin >= 1152 && M >= 16384;
 }
+#include "wgrad_strip.h"
+
 static void wgrad_geometry(const y3_conv_desc* d, long long M, int& n_ct, int& n_nt, long long& slices, long long& per, int& tsh) {
     if (wgrad_use_big(d, M)) {
         tsh = 8;
@@ -1688,6 +1690,11 @@ extern "C" int y3_conv2d_wgrad_plan(const y3_conv_desc* d, const y3_tensor* x, i
         *tile = 0; *slices_out = 0; *xcd_grouped = 0;
         return 0;
     }
+    StripPlan sp;
+    if (strip_plan(d, x->n, x->h, x->w, d->cout, d->cin, false, sp)) {   // (the query has no real channel counts: the padded ones, which is what these layers have)
+        *tile = 3; *slices_out = sp.blocks; *xcd_grouped = 0;             // tile 3 = the 3x3 strip kernel (wgrad_strip.h)
+        return 0;
+    }
     int n_ct, n_nt, tsh;
     long long slices, per;
     wgrad_geometry(d, M, n_ct, n_nt, slices, per, tsh);
@@ -1704,7 +1711,10 @@ extern "C" size_t y3_conv2d_wgrad_workspace_bytes(const y3_conv_desc* d, const y
     int n_ct, n_nt, tsh;
     long long slices, per;
     wgrad_geometry(d, (long long)x->n * Ho * Wo, n_ct, n_nt, slices, per, tsh);
-    return ((size_t)slices * n_ct * n_nt * sizeof(float)) << (2 * tsh);
+    size_t need = ((size_t)slices * n_ct * n_nt * sizeof(float)) << (2 * tsh);
+    StripPlan sp;
+    if (strip_plan(d, x->n, x->h, x->w, d->cout, d->cin, false, sp) && sp.ws_bytes > need) need = sp.ws_bytes;
+    return need;
 }
 
 extern "C" int y3_conv2d_wgrad(const y3_conv_desc* d, const y3_tensor* x, const y3_tensor* du, int32_t cout_real, int32_t cin_real, float* dw_oihw, float* dbias,
@@ -1720,6 +1730,22 @@ extern "C" int y3_conv2d_wgrad(const y3_conv_desc* d, const y3_tensor* x, const 
     const long long M = (long long)x->n * Ho * Wo;
     const bool force_direct = wgrad_mode() == 4;
     const long long xb = (((long long)x->n * x->h * x->w - 1) * x->pitch + x->c) * 2, db_ = ((M - 1) * du->pitch + du->c) * 2;
+    StripPlan sp;
+    if (!force_direct && xb < 0x7fffffffLL && db_ < 0x7fffffffLL && strip_plan(d, x->n, x->h, x->w, cout_real, cin_real, dbias != nullptr, sp)) {
+        if (!workspace || workspace_bytes < sp.ws_bytes || (((uintptr_t)workspace) & 15)) Y3_FAIL("y3_conv2d_wgrad: workspace too small or not 16-byte aligned");
+        StripArgs a;
+        memset(&a, 0, sizeof(a));
+        a.x = x->data; a.du = du->data; a.part = (float*)workspace;
+        a.N = x->n; a.H = x->h; a.W = x->w; a.xpitch = x->pitch; a.Ho = Ho; a.Wo = Wo; a.dpitch = du->pitch;
+        a.x_bytes = (unsigned)xb; a.du_bytes = (unsigned)db_;
+        a.strips = sp.strips; a.T = sp.T; a.per = sp.per;
+        a.dv_ho = y3_make_divisor(Ho); a.dv_strips = y3_make_divisor(sp.strips);
+        if (d->dtype == Y3_F16) launch_strip_t<f16_t>(d, a, sp.blocks, st); else launch_strip_t<bf16_t>(d, a, sp.blocks, st);
+        Y3_CHECK_LAUNCH();
+        hipLaunchKernelGGL(wgrad_strip_reduce_kernel, dim3(nblk((long long)9 * d->cin * d->cout / 4)), dim3(256), 0, st, (const float*)workspace, sp.blocks, d->cin, d->cout, dw_oihw);
+        Y3_CHECK_LAUNCH();
+        return 0;
+    }
     if (d->dtype != Y3_F32 && !force_direct && xb < 0x7fffffffLL && db_ < 0x7fffffffLL) {
         WgradArgs a;
         memset(&a, 0, sizeof(a));
