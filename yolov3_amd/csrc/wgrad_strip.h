@@ -57,7 +57,7 @@ template <int CIN, int S> struct StripGeom {
 template <int CIN> constexpr int strip_threads() { return (CIN == 32 ? 3 : 9) * 64; }   // (no comma inside __launch_bounds__'s macro argument)
 
 template <typename T, int CIN, int S>
-__global__ __launch_bounds__(strip_threads<CIN>()) void wgrad_strip_kernel(const StripArgs p) {
+__global__ __launch_bounds__(strip_threads<CIN>(), 3) void wgrad_strip_kernel(const StripArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef StripGeom<CIN, S> G;
     constexpr int COUT = G::COUT;
