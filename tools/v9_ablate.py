@@ -11,9 +11,9 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 ABL = ROOT / "yolov3_amd" / "lib" / "libyolov3_hip_abl.so"
-import sys as _s
 ARMS = [(0, "full kernel"), (1, "no filter requests"), (2, "no patch requests"), (3, "no pixel-fragment reads"), (4, "no filter-fragment reads"),
-        (5, "no fragment reads"), (6, "no MFMAs"), (7, "MFMAs only"), (8, "no epilogue"), (9, "filters by register loads"), (10, "reads first, then MFMAs"), (11, "two reads per MFMA gap"), (12, "filters by fragment-shaped register loads"), (13, "filter fragments read last")]
+        (5, "no fragment reads"), (6, "no MFMAs"), (7, "MFMAs only"), (8, "no epilogue")]
+# (arms 9-13 of profiles/r03_v9_ablation.txt -- register-load filters, other interleavings -- came from lab hooks that were removed with the round-3 clean-up)
 
 
 def build():

@@ -43,7 +43,8 @@ template <int N> Y3_DEV void v9_wait_vm() { __builtin_amdgcn_s_waitcnt((N & 15) 
 
 // ABL (tools/v9_ablate.py, -DY3_ABLATE builds only; 0 in the shipped library): the K loop without one of its parts, garbage results, only the
 // launch time means something.  1: no filter requests; 2: no patch requests; 3: no pixel-fragment reads; 4: no filter-fragment reads; 5: no
-// fragment reads; 6: no MFMAs; 7: MFMAs only; 8: no epilogue; 9: filter fragments by 1 KiB register loads instead of LDS-DMA + ds_read; 10 / 11: other interleavings (reads first; two reads per MFMA gap), results exact
+// fragment reads; 6: no MFMAs; 7: MFMAs only; 8: no epilogue.  (Arms 9-13 of profiles/r03_v9_ablation.txt -- filter fragments by register loads, other
+// read / MFMA interleavings -- were measured with the lab hooks up to commit 3ead9b8 and removed: none of them is a candidate without a fragment-ordered bank.)
 template <typename T, int MP, int XQ, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void conv_igemm_v9_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -141,26 +142,6 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_v9_kernel(const ConvArgs p)
         const int dst = go ? V9_PATCH + buf * V9_PB + q * 1024 : V9_DUMP + wv * 1024;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(smem + dst), 16, xsrc[i], cbyte, 0, 0);
     };
-    // ABL 9 (lab): the filter operand straight into registers in MFMA-fragment order (1 KiB contiguous per instruction, what a fragment-packed
-    // bank would allow) instead of LDS-DMA + ds_read: inline asm so that the waitcnt pass does not see an ordinary load beside the DMA
-    frag Aring[(ABL == 9 || ABL == 12) ? 3 : 1][4];
-    u32x4 wdesc = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)p.w)), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)p.w >> 32)),
-                   p.w_bytes, 0x00020000u};
-    const unsigned wlin = (unsigned)(((long long)(ct * 256 + wv * 64) * p.Kpad) * 2) + (unsigned)lane * 16u;
-    // ABL 12: the same register loads in FRAGMENT shape from the row-major bank as it is (lane -> row frow of 32-row block a, 16 bytes of k-group fk + 2 kk)
-    unsigned wfrag[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) wfrag[j] = (unsigned)(((long long)(ct * 256 + wv * 64 + (j & 1) * 32 + frow) * p.Kpad) * 2) + (unsigned)((j >> 1) * 32 + fk * 16);
-    auto ld_w = [&](int kbyte, auto ST) {
-        constexpr int st = decltype(ST)::value < ((ABL == 9 || ABL == 12) ? 3 : 1) ? decltype(ST)::value : 0;   // (only called in the ABL 9 / 12 instantiations)
-        auto& ring = Aring;   // (operands of an asm statement alone do not make a generic lambda capture a variable)
-        const unsigned wl = wlin;
-        const u32x4 wd = wdesc;
-        unsigned wf[4] = {wfrag[0], wfrag[1], wfrag[2], wfrag[3]};
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(ring[st][j]) : "v"(ABL == 12 ? wf[j] : wl + (unsigned)(j * 1024)), "s"(wd), "s"(kbyte) : "memory");
-    };
     auto mma = [&](const frag (&af)[MC], const frag (&bf)[MP]) {
 #pragma unroll
         for (int a = 0; a < MC; ++a)
@@ -173,13 +154,8 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_v9_kernel(const ConvArgs p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the bias loads share the counter
 #pragma unroll
     for (int i = 0; i < NXP; ++i) dma_x(i, 0, 0, true);
-    if constexpr (ABL == 9 || ABL == 12) {
-        ld_w(0, IC<0>{});
-        ld_w(p.Cin * 2, IC<1>{});
-    } else {
-        dma_w(0, 0);
-        dma_w(p.Cin * 2, 1);
-    }
+    dma_w(0, 0);
+    dma_w(p.Cin * 2, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     frag A0[MC], B0[MP], A1[MC], B1[MP];
@@ -197,12 +173,10 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_v9_kernel(const ConvArgs p)
             constexpr int ntap = (tap + 1) % 9, ndh = ntap / 3, ndw = ntap % 3;
             constexpr int tap2 = (tap + 2) % 9;
             // ---- phase 1: MFMAs of substep 0 | fragment reads of substep 1, filter tile of K-step s + 2 (stage (s + 2) % 3 = (tap + 2) % 3: 9 % 3 == 0)
-            if constexpr (ABL == 9 || ABL == 12) {
-                A0[0] = Aring[tap % 3][0]; A0[1] = Aring[tap % 3][1]; A1[0] = Aring[tap % 3][2]; A1[1] = Aring[tap % 3][3];
-            } else if constexpr (ABL == 4 || ABL == 5 || ABL == 7) {
+            if constexpr (ABL == 4 || ABL == 5 || ABL == 7) {
 #pragma unroll
                 for (int a = 0; a < MC; ++a) asm volatile("" : "=v"(A1[a]));
-            } else if constexpr (ABL != 13) {
+            } else {
 #pragma unroll
                 for (int a = 0; a < MC; ++a) A1[a] = *(const frag*)(smem + a_k1 + a * 2048 + (tap % 3) * V9_STAGE);
             }
@@ -213,12 +187,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_v9_kernel(const ConvArgs p)
 #pragma unroll
                 for (int b = 0; b < MP; ++b) B1[b] = *(const frag*)(smem + bb[dh][b] + dw * V9_PITCH + 32);
             }
-            if constexpr (ABL == 13) {   // lab: the filter fragments read AFTER the pixel fragments
-#pragma unroll
-                for (int a = 0; a < MC; ++a) A1[a] = *(const frag*)(smem + a_k1 + a * 2048 + (tap % 3) * V9_STAGE);
-            }
-            if constexpr (ABL == 9 || ABL == 12) ld_w((tap2 * p.Cin + (cb + (tap + 2 >= 9 ? 1 : 0)) * 32) * 2, IC<tap2 % 3>{});
-            else if constexpr (ABL != 1 && ABL != 7) dma_w((tap2 * p.Cin + (cb + (tap + 2 >= 9 ? 1 : 0)) * 32) * 2, tap2 % 3);
+            if constexpr (ABL != 1 && ABL != 7) dma_w((tap2 * p.Cin + (cb + (tap + 2 >= 9 ? 1 : 0)) * 32) * 2, tap2 % 3);
             if constexpr (ABL != 6) mma(A0, B0);
             else {
 #pragma unroll
@@ -226,23 +195,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_v9_kernel(const ConvArgs p)
 #pragma unroll
                 for (int b = 0; b < MP; ++b) asm volatile("" :: "v"(B0[b]));
             }
-            if constexpr (ABL == 10) {   // lab: reads and requests first, then the MFMAs
-                __builtin_amdgcn_sched_group_barrier(0x100, MC + MP, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, MC * MP, 0);
-            } else if constexpr (ABL == 11) {   // lab: two reads per MFMA gap
-#pragma unroll
-                for (int i = 0; i < (MC + MP + 1) / 2; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, MC * MP - (MC + MP + 1) / 2 - 4, 0);
-            } else {
+            {
 #pragma unroll
                 for (int i = 0; i < MC + MP; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
@@ -270,11 +223,10 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_v9_kernel(const ConvArgs p)
                     for (int b = 0; b < MP; ++b) bb[d][b] += bufd;
                 bufd = -bufd;
             }
-            if constexpr (ABL == 9 || ABL == 12) {
-            } else if constexpr (ABL == 4 || ABL == 5 || ABL == 7) {
+            if constexpr (ABL == 4 || ABL == 5 || ABL == 7) {
 #pragma unroll
                 for (int a = 0; a < MC; ++a) asm volatile("" : "=v"(A0[a]));
-            } else if constexpr (ABL != 13) {
+            } else {
 #pragma unroll
                 for (int a = 0; a < MC; ++a) A0[a] = *(const frag*)(smem + a_k0 + a * 2048 + (ntap % 3) * V9_STAGE);
             }
@@ -284,10 +236,6 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_v9_kernel(const ConvArgs p)
             } else {
 #pragma unroll
                 for (int b = 0; b < MP; ++b) B0[b] = *(const frag*)(smem + bb[ndh][b] + ndw * V9_PITCH);
-            }
-            if constexpr (ABL == 13) {
-#pragma unroll
-                for (int a = 0; a < MC; ++a) A0[a] = *(const frag*)(smem + a_k0 + a * 2048 + (ntap % 3) * V9_STAGE);
             }
             if constexpr (tap < 7 && ABL != 2 && ABL != 7) {
 #pragma unroll
@@ -300,25 +248,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_v9_kernel(const ConvArgs p)
 #pragma unroll
                 for (int b = 0; b < MP; ++b) asm volatile("" :: "v"(B1[b]));
             }
-            if constexpr (ABL == 10) {
-                __builtin_amdgcn_sched_group_barrier(0x100, MC + MP, 0);
-                if constexpr (tap < 7) __builtin_amdgcn_sched_group_barrier(0x020, XQ, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, MC * MP, 0);
-            } else if constexpr (ABL == 11) {
-#pragma unroll
-                for (int i = 0; i < (MC + MP + 1) / 2; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                }
-                if constexpr (tap < 7) {
-#pragma unroll
-                    for (int x = 0; x < XQ; ++x) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                    }
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, MC * MP - (MC + MP + 1) / 2 - (tap < 7 ? XQ : 0), 0);
-            } else {
+            {
 #pragma unroll
                 for (int i = 0; i < MC + MP; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -447,7 +377,7 @@ template <typename T> int launch_v9(ConvArgs& a, hipStream_t st) {
 #ifdef Y3_ABLATE
     if (const char* e = getenv("Y3_V9_ABL")) {   // lab build only
         const int abl = atoi(e);
-        if (pl.mp == 7 && !two && abl >= 1 && abl <= 13) {
+        if (pl.mp == 7 && !two && abl >= 1 && abl <= 8) {
             switch (abl) {
                 case 1: hipLaunchKernelGGL((conv_igemm_v9_kernel<T, 7, 1, 1>), grid, block, 0, st, a); break;
                 case 2: hipLaunchKernelGGL((conv_igemm_v9_kernel<T, 7, 1, 2>), grid, block, 0, st, a); break;
@@ -456,11 +386,6 @@ template <typename T> int launch_v9(ConvArgs& a, hipStream_t st) {
                 case 5: hipLaunchKernelGGL((conv_igemm_v9_kernel<T, 7, 1, 5>), grid, block, 0, st, a); break;
                 case 6: hipLaunchKernelGGL((conv_igemm_v9_kernel<T, 7, 1, 6>), grid, block, 0, st, a); break;
                 case 7: hipLaunchKernelGGL((conv_igemm_v9_kernel<T, 7, 1, 7>), grid, block, 0, st, a); break;
-                case 9: hipLaunchKernelGGL((conv_igemm_v9_kernel<T, 7, 1, 9>), grid, block, 0, st, a); break;
-                case 10: hipLaunchKernelGGL((conv_igemm_v9_kernel<T, 7, 1, 10>), grid, block, 0, st, a); break;
-                case 11: hipLaunchKernelGGL((conv_igemm_v9_kernel<T, 7, 1, 11>), grid, block, 0, st, a); break;
-                case 12: hipLaunchKernelGGL((conv_igemm_v9_kernel<T, 7, 1, 12>), grid, block, 0, st, a); break;
-                case 13: hipLaunchKernelGGL((conv_igemm_v9_kernel<T, 7, 1, 13>), grid, block, 0, st, a); break;
                 default: hipLaunchKernelGGL((conv_igemm_v9_kernel<T, 7, 1, 8>), grid, block, 0, st, a); break;
             }
             Y3_CHECK_LAUNCH();

@@ -54,10 +54,12 @@ template <int CIN, int S> struct StripGeom {
     static_assert(CIN == 32 || CIN == 64, "instantiated shapes");
 };
 
-template <int CIN> constexpr int strip_threads() { return (CIN == 32 ? 3 : 9) * 64; }   // (no comma inside __launch_bounds__'s macro argument)
+template <int CIN> constexpr int strip_threads() { return (CIN == 32 ? 3 : 9) * 64; }   // (no bare comma inside __launch_bounds__'s macro arguments)
+// waves per SIMD the register budget must allow: what the LDS lets a CU hold -- 3 / 2 / 2 / 1 blocks of 3 / 3 / 9 / 9 waves over 4 SIMDs
+template <int CIN, int S> constexpr int strip_waves_per_simd() { return CIN == 32 ? (S == 1 ? 3 : 2) : (S == 1 ? 5 : 3); }
 
 template <typename T, int CIN, int S>
-__global__ __launch_bounds__(strip_threads<CIN>(), 3) void wgrad_strip_kernel(const StripArgs p) {
+__global__ __launch_bounds__(strip_threads<CIN>(), (strip_waves_per_simd<CIN, S>())) void wgrad_strip_kernel(const StripArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef StripGeom<CIN, S> G;
     constexpr int COUT = G::COUT;
