@@ -2321,6 +2321,65 @@ def test_conv_v9_statistics_rows(dev, tune):
     assert (tot[:, 1] - (u * u).sum(0)).abs().max().item() <= 1e-5 * (u * u).sum(0).max().item()
 
 
+# ------------------------------------------------------------------------------------------------ conv strip (register-resident filters, row ring)
+STRIP_CONV_CASES = [
+    # name, (n,h,w,cin,cout,k,s), kwargs, output rows per block (knob conv_strip; 2 = the host's plan)
+    ("c64_32_one_strip", (2, 20, 64, 64, 32, 3, 1), {}, 2),
+    ("c64_32_ragged_walk7", (3, 19, 150, 64, 32, 3, 1), {"act": False}, 7),           # 3 strips, the last 22 pixels wide; blocks cross strips and images
+    ("c64_32_dgrad_shape_walk5", (2, 33, 100, 64, 32, 3, 1), {"act": False}, 5),      # the data gradient of a 32 -> 64 layer
+    ("c64_32_sliced", (2, 17, 70, 64, 32, 3, 1), {"sliced": True}, 4),
+    ("c64_128_walk9", (2, 24, 96, 64, 128, 3, 1), {}, 9),
+    ("c64_128_tall_one_block", (1, 70, 64, 64, 128, 3, 1), {"act": False}, 70),       # one block walks a whole strip: the row ring wraps many times
+    ("c64_32_narrow_map", (4, 40, 13, 64, 32, 3, 1), {}, 3),                          # map narrower than a strip
+    ("c128_64_ksplit_walk6", (2, 30, 100, 128, 64, 3, 1), {"act": False}, 6),         # the data gradient of a 64 -> 128 layer: two waves split the 72 reduction steps
+    ("c128_64_ksplit_odd_rows", (3, 9, 64, 128, 64, 3, 1), {}, 5),                    # odd rows per block: the giver / taker roles of a pair differ from block to block
+    ("c128_64_ksplit_sliced_one_row", (1, 11, 70, 128, 64, 3, 1), {"sliced": True}, 3),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name,shape,kw,per", STRIP_CONV_CASES, ids=[c[0] for c in STRIP_CONV_CASES])
+def test_conv_strip_vs_fp32_reference(dev, tune, dtype, name, shape, kw, per):
+    """conv_strip.h (filters in registers, one new input row per output row of a 64-pixel column strip, nine taps as views of three resident rows, two
+    waves splitting the reduction at Cin = 128) against fp32 conv2d on the same rounded operands -- strips and images crossed inside a block, ragged
+    last strips, edge taps, bias + SiLU, sliced outputs; repeated launches bit-identical; and against the tile kernels it replaces."""
+    tune("conv_strip", per)
+    out, ref = run_conv(dev, dtype, *shape, algo=1, ws=True, expect="strip", repeat=2, **kw)
+    _conv_tol_check(name, dtype, out, ref)
+    tune("conv_strip", 0)
+    old, _ = run_conv(dev, dtype, *shape, algo=1, ws=True, **kw)
+    assert (out - old).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 32), (128, 64)])
+def test_conv_strip_statistics_rows(dev, tune, cin, cout):
+    """BatchNorm statistics from the strip kernel: one row per block, pixel tile and K-split wave (accumulated in registers over the block's output rows),
+    their fp64 sum equals the statistics of the stored tensor; pixels beyond the ragged last strip are not counted"""
+    _lib, ops = _ops()
+    tune("conv_strip", 6)
+    n, h, w, k, s = 3, 21, 150, 3, 1
+    dtype = torch.float16
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(n, cin, h, w, generator=g).to(dtype)
+    wt = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    xv = ops.View.alloc(n, h, w, cin, dtype, dev)
+    ops.nchw_to_nhwc(x.to(dev), xv)
+    filt = ops.pack_filter(wt.to(dev), cout, cin, dtype)
+    zb = torch.zeros(cout, device=dev)
+    y1 = ops.View.alloc(n, h, w, cout, dtype, dev)
+    rows = ops.conv2d_stats_rows(xv, y1, k, s)
+    blocks = -(-(n * 3 * h) // 6)
+    assert rows == blocks * 2 * (2 if cin == 128 else 1), (rows, blocks)
+    buf = torch.full((rows * 2 * cout,), float("nan"), device=dev)
+    assert ops.conv2d_stats(xv, filt, zb, y1, k, s, buf, rows) == rows and ops.last_conv_variant() == "strip"
+    torch.cuda.synchronize()
+    u = y1.as_nhwc().double().cpu().reshape(-1, cout)
+    tot = buf.view(rows, cout, 2).double().sum(0).cpu()
+    assert torch.isfinite(tot).all(), "a statistics row was not written"
+    assert (tot[:, 0] - u.sum(0)).abs().max().item() <= 1e-5 * u.abs().sum(0).max().item()
+    assert (tot[:, 1] - (u * u).sum(0)).abs().max().item() <= 1e-5 * (u * u).sum(0).max().item()
+
+
 @pytest.mark.parametrize("name,dtype", [("yolov3", torch.float32), ("yolov3-tiny", torch.float16)])
 def test_loss_autobalance_vs_oracle(dev, name, dtype):
     """ComputeLoss(autobalance=True) (reference utils/loss.py:121, :171-175; the oracle's restatement is pinned to the unmodified reference by

@@ -321,7 +321,7 @@ def test_conv_dispatch_variant_names_and_stat_rows():
     assert ws == 64 + 4096 + 2 * 256 * 256 * 256 * 4
     # (pixels per tile, statistics rows per tile); v9 plans 200 valid pixels per 224-pixel tile at these batches (whole rounds of the 256 CUs)
     tile_px = {"v7": (256, 4), "v6": (256, 2), "v3_bk64_128x128": (128, 2), "v3_bk32_128x128": (128, 2), "v3_bk32_128x256": (256, 2), "v3_bk32_64x256": (256, 2),
-               "v9_mp7": (200, 4)}
+               "v9_mp7": (200, 4), "strip": (0, 0)}
     shapes = [(32, 64, 3, 2, 640), (64, 32, 1, 1, 320), (32, 64, 3, 1, 320), (64, 128, 3, 2, 320), (128, 64, 1, 1, 160), (64, 128, 3, 1, 160), (128, 256, 3, 2, 160),
               (256, 128, 1, 1, 80), (128, 256, 3, 1, 80), (256, 512, 3, 2, 80), (512, 256, 1, 1, 40), (256, 512, 3, 1, 40), (512, 1024, 3, 2, 40), (1024, 512, 1, 1, 20),
               (512, 1024, 3, 1, 20), (768, 256, 1, 1, 40), (384, 128, 1, 1, 80), (256, 256, 1, 1, 80), (512, 256, 1, 1, 20)]
@@ -342,7 +342,17 @@ def test_conv_dispatch_variant_names_and_stat_rows():
             tp, per = tile_px[plain]
             m = bs * ho * ho
             if (cin, cout, k) == (64, 128, 3):
-                assert plain == ("v3_bk32_128x256" if s == 1 else "v3_bk64_128x128")   # round-2 sweep: profiles/r02_conv_variant_sweep.txt
+                # stride 1: the strip kernel with register-resident filters (conv_strip.h, profiles/r03_conv_strip_ab.txt; knob conv_strip = 0: the 128 x 256-pixel
+                # tile of the round-2 sweep); stride 2: profiles/r02_conv_variant_sweep.txt
+                assert plain == ("strip" if s == 1 else "v3_bk64_128x128")
+            if plain == "strip":
+                assert rows == 256 * 2, rows   # 256 persistent blocks (one per CU: 8 waves, 144 filter registers per lane), two pixel tiles each
+                assert L.y3_tune_set(b"conv_strip", 0) == 0
+                try:
+                    assert L.y3_conv2d_fwd_variant(C.byref(d), C.byref(x), C.byref(y), 0, 0, name, 64) == 0 and name.value == b"v3_bk32_128x256"
+                finally:
+                    L.y3_tune_reset()
+                continue
             assert rows == -(-m // tp) * per, f"{cin}->{cout} k{k} s{s} @{hin} bs{bs}: {rows} rows for {plain}"
             assert L.y3_conv2d_fwd_variant(C.byref(d), C.byref(x), C.byref(y), 0, ws, name, 64) == 0
             with_ws = name.value.decode()

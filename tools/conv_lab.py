@@ -37,6 +37,11 @@ SHAPES = [
     ("L2.cv2 32->64 @320", 320, 320, 32, 64, 3, 1, True),
     ("L3 64->128 s2 @320", 320, 320, 64, 128, 3, 2, False),
     ("L5 128->256 s2 @160", 160, 160, 128, 256, 3, 2, False),
+    # training-mode launches of the small-channel 3x3 layers (no residual in the conv; --noact): forward and data gradient (= the conv with the channels swapped)
+    ("T L2.cv2 32->64 @320", 320, 320, 32, 64, 3, 1, False),
+    ("T L2.cv2 dgrad 64->32 @320", 320, 320, 64, 32, 3, 1, False),
+    ("T L4.cv2 64->128 @160", 160, 160, 64, 128, 3, 1, False),
+    ("T L4.cv2 dgrad 128->64 @160", 160, 160, 128, 64, 3, 1, False),
 ]
 
 
@@ -47,6 +52,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--only", default="")
     ap.add_argument("--dtype", default="fp16")
+    ap.add_argument("--arms", default="", help='custom arms instead of the default three: "knob=value,knob=value;knob=value" (each with a workspace)')
+    ap.add_argument("--noact", action="store_true", help="no activation (the training-mode launches)")
     ap.add_argument("--sweep", action="store_true", help="also time the forced tile variants (knob conv = 4 / 5 / 6 / 15) and the forced v9 wave-tile widths")
     args = ap.parse_args()
     from yolov3_amd import ops
@@ -74,6 +81,8 @@ def main():
             rv.buf.copy_(torch.randn(rv.buf.numel(), generator=g).to(dev).to(dtype))
         flops = 2.0 * n * ho * wo * cout * cin * k * k
         arms = [("nows", None, {"conv_v9": 0}), ("no v9", ws, {"conv_v9": 0}), ("auto", ws, {})]
+        if args.arms:
+            arms = [(a, ws, dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in a.split(",") if kv)) for a in args.arms.split(";")]
         if args.sweep:
             arms += [(f"conv={v}", None, {"conv": v, "conv_v9": 0}) for v in (4, 6, 15)]
             if k == 3 and s == 1 and cout % 256 == 0:
@@ -87,7 +96,7 @@ def main():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(args.reps):
-                    ops.conv2d(xv, filt, bias, yv, k, s, True, rv, workspace=wsp)
+                    ops.conv2d(xv, filt, bias, yv, k, s, not args.noact, rv, workspace=wsp)
                 e1.record()
                 torch.cuda.synchronize()
                 ops.tune_reset()
@@ -101,8 +110,8 @@ def main():
             var = ops.conv_variant(xv, yv, k, s, res, workspace_bytes=wsp.numel() if wsp is not None else 0)
             ops.tune_reset()
             med, mn = statistics.median(times[arm]), min(times[arm])
-            diff = (outs[arm] - outs["nows"]).abs().max().item()
-            print(f"{name:28s} {arm:10s} {var:18s} {med:9.1f} {mn:9.1f} {flops / med / 1e6:10.1f} {flops / mn / 1e6:10.1f}   max|d vs nows| {diff:.3g}")
+            diff = (outs[arm] - outs[arms[0][0]]).abs().max().item()
+            print(f"{name:28s} {arm:10s} {var:18s} {med:9.1f} {mn:9.1f} {flops / med / 1e6:10.1f} {flops / mn / 1e6:10.1f}   max|d vs arm 0| {diff:.3g}")
         sys.stdout.flush()
     hdr = ws[:64].view(torch.int32).tolist()
     print("workspace ctl words (ticket, finished, error):", hdr[:3])

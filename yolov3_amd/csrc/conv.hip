@@ -61,6 +61,7 @@ struct ConvArgs {
     int v7_whole;  // conv_v7.h: blocks own whole tiles (no stream-K split)
     int v7_gc;     // conv_v7.h: filter-tile ranges per XCD group (1, 2, 4 or 8; divides n_ct)
     int v9_vp, v9_npiece;   // conv_v9.h: valid pixels per tile, 1 KiB pieces of its halo patch
+    int cs_strips, cs_T, cs_per;   // conv_strip.h: column strips per row, output rows in all, output rows per block
     unsigned dv_pw_mul, dv_pw_sh, dv_h1_mul, dv_h1_sh;   // conv_v9.h: reciprocals of W + 2 and H + 1
 #ifdef Y3_TIMELINE  // debug build only (tools/timeline.py): per-block wall-clock stamps
     unsigned long long* tl;
@@ -166,8 +167,11 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // the same coalesced pattern before the arithmetic starts and added in fp32.  One block barrier (the stage buffers must be
 // idle), no idle waves.  (The block-wide fp32 transpose this replaces cost 8-17 us per block with half of the waves parked
 // during the exp/rcp pass; a register-only variant with 32-byte runs lost on the residual layers: profiles/r01_conv_timeline.md.)
-template <typename T, int MC, int MP>
-Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MP], unsigned char* wl, int c_base, int m_base, int lane, int stat_row = -1, int m_end = 0x7fffffff) {
+// STAT_ACC (conv_strip.h: a wave calls this once per output row of its strip): the statistics are added to the caller's 16 registers `sacc` (8 sums, 8 sums of
+// squares of the lane's 8 filters) instead of being written; epilogue_stats_flush writes ONE row for all the calls.
+template <typename T, int MC, int MP, bool STAT_ACC = false>
+Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MP], unsigned char* wl, int c_base, int m_base, int lane, int stat_row = -1, int m_end = 0x7fffffff,
+                          float* sacc = nullptr) {
     typedef typename Mfma<T>::frag vec8;   // 8 x T = one 16-byte chunk
     constexpr int CH = MC * 4;          // 16-byte chunks per pixel row of this wave's slice
     constexpr int RB = CH * 16;         // row bytes
@@ -240,7 +244,7 @@ Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MP], unsigned cha
     const bool want_stats = p.stats != nullptr;   // kernel-uniform
     float st0[8], st1[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) st0[q] = st1[q] = 0.0f;
+    for (int q = 0; q < 8; ++q) { st0[q] = STAT_ACC ? sacc[q] : 0.0f; st1[q] = STAT_ACC ? sacc[8 + q] : 0.0f; }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int pl = i * PPI + rp;
@@ -267,7 +271,10 @@ Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MP], unsigned cha
                     __builtin_amdgcn_raw_buffer_store_b128(raw, rsrc_y, yoff[i] == OOB ? OOB : yoff[i] + (unsigned)((dy * p.Wo * 2 + dx) * p.ypitch) * 2u, 0, 0);
         }
     }
-    if (want_stats) {
+    if constexpr (STAT_ACC) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { sacc[q] = st0[q]; sacc[8 + q] = st1[q]; }
+    } else if (want_stats) {
         // lanes rp * CH + ch (rp < PPI) hold partial sums of the same 8 filters: butterfly over the rp bits, lane ch writes the row
 #pragma unroll
         for (int off = CH; off < 64; off <<= 1)
@@ -278,6 +285,22 @@ Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MP], unsigned cha
 #pragma unroll
             for (int q = 0; q < 8; q += 2) *(f32x4*)(row + q * 2) = f32x4{st0[q], st1[q], st0[q + 1], st1[q + 1]};
         }
+    }
+}
+
+// the row write of epilogue_wave<.., STAT_ACC = true>: `sacc` as that call left it, MC = the filter tiles of the wave (same lane -> filter mapping)
+template <int MC> Y3_DEV void epilogue_stats_flush(const ConvArgs& p, float* sacc, int c_base, int lane, int stat_row) {
+    constexpr int CH = MC * 4;
+    const int rp = lane / CH, ch = lane % CH;
+    const int c = c_base + ch * 8;
+#pragma unroll
+    for (int off = CH; off < 64; off <<= 1)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sacc[q] += __shfl_xor(sacc[q], off, 64);
+    if (rp == 0 && c + 8 <= p.Cout) {
+        float* row = p.stats + ((long long)stat_row * p.Cout + c) * 2;
+#pragma unroll
+        for (int q = 0; q < 8; q += 2) *(f32x4*)(row + q * 2) = f32x4{sacc[q], sacc[8 + q], sacc[q + 1], sacc[8 + q + 1]};
     }
 }
 
@@ -976,12 +999,17 @@ int launch_igemm(ConvArgs& a, hipStream_t st) {
 
 #include "conv_v7.h"
 #include "conv_v9.h"
+#include "conv_strip.h"
 
 template <typename T> int dispatch_igemm(ConvArgs& a, hipStream_t st) {
     const bool c64 = (a.Cin % 64) == 0, c32 = (a.Cin % 32) == 0;
     const int var = conv_variant();
     if (!(a.x_bytes && a.w_bytes && a.y_bytes && (!a.res || a.r_bytes)))
         Y3_FAIL("conv: a tensor exceeds the 2 GiB reach of a buffer descriptor (split the batch)");
+    {
+        CsPlan cs;
+        if (var == 3 && cs_plan(a, cs)) return launch_cs<T>(a, st);
+    }
     if (var == 3 && v9_eligible(a)) return launch_v9<T>(a, st);
     if (var == 3 && v7_eligible(a)) return launch_v7<T>(a, st);
     if (var >= 3 && a.Cout > 64 && c32) {

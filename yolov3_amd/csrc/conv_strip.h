@@ -1,0 +1,253 @@
+// conv_strip.h -- included by conv.hip INSIDE its anonymous namespace, after conv_v9.h (shares ConvArgs, Mfma, epilogue_wave, fdiv, ...).
+//
+// 3x3 / stride 1 / pad 1 convolutions with FEW channels on LARGE maps (reference models/yolov3.yaml:17-22, Bottleneck.cv2 of layers 2 and 4 in training
+// mode, models/common.py:57-81,150-165, and their data gradients, which are the same convolution with the channel counts swapped):
+// 64 -> 32, 64 -> 128 and 128 -> 64 channels at 320x320 / 160x160.
+//
+// Why (profiles/r03_wgrad_strip_ab.txt and the staged-byte accounting in csrc/wgrad_strip.h): the tile kernels stage the pixel operand once per TAP --
+// 9 x 64-128 B of `buffer_load ... lds` per pixel and filter tile for 64-128 B that exist -- and on these layers that request stream (10-13 TB/s of
+// staged bytes), not HBM and not the matrix pipe, is the bound: 32 -> 64 @320x320 runs at 0.41, its data gradient at 0.35 PFLOP/s.  Here:
+//   * the filters live in REGISTERS: a wave owns 32 filters and 36 of the 9 Cin / 16 reduction steps (36 MFMA A-fragments, 144 VGPRs), loaded once per
+//     block -- no filter staging, no filter fragment reads.  Cin = 128 has 72 steps: two waves share a (pixel tile, filter tile) and split them (KS = 2);
+//     after the MFMAs of an output row one of the two hands its 32 x 32 partial sums over through LDS and the other adds them and runs the epilogue, the
+//     roles alternating from row to row so that both do the same work;
+//   * a block walks down a column strip of MT x 32 pixels; an output row needs three input rows, which live in a ring of four row buffers -- ONE new input
+//     row is requested per output row (one K-step ahead) and the nine taps are nine views of the three resident rows (row buffer = kh, pixel shift = kw:
+//     instruction immediates).  Padding is free: out-of-image rows / columns are lanes with an out-of-range source offset (the descriptor lands zeros);
+//   * pixel rows have a pitch of (2 Cin + 16) bytes: the 32 lanes of a fragment read (consecutive pixels, 16 bytes each) fall on distinct bank quads, the
+//     conflict-free property conv_v9.h buys the same way (every 5th / 9th 16-byte slot of a request is a pad slot: an out-of-range lane);
+//   * waves = MT pixel tiles x Cout / 32 filter tiles (x KS); per output row a wave issues 36 ds_read_b128 + as many MFMAs and one epilogue_wave call
+//     (bias, SiLU, NHWC transpose through its private LDS slice, 16-byte stores); BatchNorm statistics accumulate in 16 registers over the block's rows and
+//     leave as ONE row per wave (epilogue_stats_flush) instead of one per 64 pixels;
+//   * persistent blocks over the linear index t = ((image, strip), row), like wgrad_strip.h.
+// Measured at batch 64 (profiles/r03_conv_strip_ab.txt): 64 -> 32 @320x320 762 -> 315 us, 64 -> 128 @160x160 327 -> 294 us; bit-identical outputs (the same
+// products added in the same order).  32 -> 64 itself (18 steps per epilogue call) measured level with the 64 x 256-pixel tile kernel and stays there.
+
+template <int CIN, int COUT, int MT> struct CsGeom {
+    static constexpr int KS = CIN > 64 ? 2 : 1;                          // waves that split the reduction of one (pixel tile, filter tile)
+    static constexpr int PXB = CIN * 2, PP = PXB + 16, SLOTS = PP / 16;   // pixel bytes, pitch, 16-byte slots per pixel (the last one is the pad)
+    static constexpr int SWP = MT * 32, NPX = SWP + 2;                    // strip width, input pixels of a row segment
+    static constexpr int XPIECES = (NPX * PP + 1023) / 1024, XROWB = XPIECES * 1024;
+    static constexpr int NSLOT = 4;                                       // three rows in use + the one being fetched
+    static constexpr int NT = COUT / 32, NW = MT * NT * KS;
+    static constexpr int KPT = CIN / 16, KF = 9 * KPT / KS;               // 16-wide reduction steps per tap / per wave
+    static constexpr int EPI = NW * 2048;                                 // the waves' transpose slices (32 pixels x 64 bytes)
+    static constexpr int PART = KS > 1 ? MT * NT * 4096 : 0;              // hand-over buffers of the K-split pairs (16 fp32 per lane)
+    static constexpr int XBASE = EPI + PART, LDS = XBASE + NSLOT * XROWB;
+    static_assert(KF <= 36 && (9 * KPT) % KS == 0, "144 filter registers per lane");
+    static constexpr int XPW = (XPIECES + NW - 1) / NW;
+};
+template <int CIN, int COUT, int MT> constexpr int cs_threads() { return CsGeom<CIN, COUT, MT>::NW * 64; }
+
+template <typename T, int CIN, int COUT, int MT>
+__global__ __launch_bounds__((cs_threads<CIN, COUT, MT>())) void conv_strip_kernel(const ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef CsGeom<CIN, COUT, MT> G;
+    constexpr int PP = G::PP, XROWB = G::XROWB, NW = G::NW, NT = G::NT, KF = G::KF, KPT = G::KPT, XPW = G::XPW, KS = G::KS;
+    typedef typename Mfma<T>::frag frag;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[G::LDS];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ks = wv % KS, pair = wv / KS;           // (K-split index, (pixel tile, filter tile) pair)
+    const int mt = pair / NT, nt = pair % NT;
+    const int frow = lane & 31, fk = lane >> 5;
+    const int t_begin = blockIdx.x * p.cs_per;
+    int t_end = t_begin + p.cs_per;
+    if (t_end > p.cs_T) t_end = p.cs_T;
+    if (t_begin >= t_end) return;
+    const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xffffffffu;
+
+    // ---- the wave's filters: rows nt 32 + frow of the packed bank, all 9 Cin reduction steps (lane: k-group fk of every 16-step)
+    frag fw[KF];
+    {
+        const T* wrow = (const T*)p.w + (size_t)(nt * 32 + frow) * p.Kpad + ks * (KF * 16) + fk * 8;
+#pragma unroll
+        for (int j = 0; j < KF; ++j) fw[j] = *(const frag*)(wrow + 16 * j);
+    }
+    f32x4 bz[4];   // the accumulators of every output row start at the bias of the lane's filters (8 g + 4 fk + q)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int cb = nt * 32 + 8 * g + 4 * fk;
+        bz[g] = (p.bias && ks == 0) ? *(const f32x4*)(p.bias + cb) : f32x4{0.f, 0.f, 0.f, 0.f};   // (K-split: the bias enters once)
+    }
+
+    // ---- staging role: request q = i NW + wave of a row buffer, lane -> LDS position q 1024 + 16 lane = (pixel e / SLOTS, slot e % SLOTS), e = q 64 + lane
+    int xj[XPW];
+    int xoffl[XPW];
+#pragma unroll
+    for (int i = 0; i < XPW; ++i) {
+        const int e = (i * NW + wv) * 64 + lane;
+        const int j = e / G::SLOTS, slot = e - j * G::SLOTS;
+        xj[i] = (slot < G::SLOTS - 1 && j < G::NPX) ? j : -1;      // pad slots and the tail of the last request fetch nothing
+        xoffl[i] = ((j - 1) * p.xpitch + slot * 8) * 2;            // relative to input pixel (row, w0)
+    }
+    // ---- fragment address of the wave's pixel tile: pixel mt 32 + frow of the strip, k-group fk; (row buffer, kw, 16-step of the tap) are added per read
+    const unsigned char* xfrag = smem + G::XBASE + (mt * 32 + frow) * PP + fk * 16;
+    unsigned char* slice = smem + wv * 2048;
+
+    float sacc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sacc[q] = 0.0f;
+
+    // ---- the walk (see wgrad_strip.h): (image, strip, row) of the output row requested next, ring slots of the three input rows of the current / next row
+    int tn = fdiv(t_begin, p.dv_pw_mul, p.dv_pw_sh);          // host: reciprocal of Ho
+    int row = t_begin - tn * p.Ho;
+    int img = fdiv(tn, p.dv_h1_mul, p.dv_h1_sh);              // host: reciprocal of the strips per row
+    int strip = tn - img * p.cs_strips;
+    int cur[3] = {0, 0, 0}, nxt[3] = {0, 0, 0};
+    int hp = 0;
+    int c_img = 0, c_strip = 0, c_row = 0;                    // the output row being computed (one behind the request cursor)
+    int n_img = 0, n_strip = 0, n_row = 0;
+    auto take = [&]() { const int s = hp; hp = (hp + 1) & 3; return s; };
+
+    auto request_row = [&](int hin, int slot, int w0) {
+        const bool rowok = (unsigned)hin < (unsigned)p.H;
+        const long long xbase = (((long long)img * p.H + hin) * p.W + w0) * p.xpitch * 2;
+#pragma unroll
+        for (int i = 0; i < XPW; ++i) {
+            if ((i + 1) * NW <= G::XPIECES || i * NW + wv < G::XPIECES) {
+                const int col = w0 - 1 + xj[i];
+                const bool ok = rowok && xj[i] >= 0 && (unsigned)col < (unsigned)p.W;
+                const unsigned off = ok ? (unsigned)(xbase + xoffl[i]) : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(smem + G::XBASE + slot * XROWB + (i * NW + wv) * 1024), 16, off, 0, 0, 0);
+            }
+        }
+    };
+    // requests of output row t (the cursor's): a fresh strip needs three rows (only ever called when no row buffer is in use), a continued one the new bottom row
+    auto issue = [&](bool fresh) {
+        const int w0 = strip * G::SWP;
+        if (fresh) {
+            nxt[0] = take(); nxt[1] = take(); nxt[2] = take();
+            request_row(row - 1, nxt[0], w0);
+            request_row(row, nxt[1], w0);
+            request_row(row + 1, nxt[2], w0);
+        } else {
+            nxt[0] = nxt[1]; nxt[1] = nxt[2]; nxt[2] = take();
+            request_row(row + 1, nxt[2], w0);
+        }
+        n_img = img; n_strip = strip; n_row = row;
+        if (++row == p.Ho) {
+            row = 0;
+            if (++strip == p.cs_strips) { strip = 0; ++img; }
+        }
+    };
+
+    auto compute = [&](auto KSC, int t) {
+        constexpr int KSI = decltype(KSC)::value;   // the wave's K-split index: its reduction steps are KSI KF .. KSI KF + KF - 1
+        f32x16 acc[1][1];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[0][0][4 * g + q] = bz[g][q];
+        const unsigned char* xr[3] = {xfrag + cur[0] * XROWB, xfrag + cur[1] * XROWB, xfrag + cur[2] * XROWB};
+        // fragment reads run D 16-steps ahead of the MFMAs that consume them (a window of D fragments: the filters hold most of the registers)
+        constexpr int D = 6;
+        frag xf[D];
+        auto ld = [&](auto J) -> frag {
+            constexpr int j = KSI * KF + decltype(J)::value;
+            constexpr int tap = j / KPT, kh = tap / 3, kw = tap % 3, sub = j % KPT;
+            return *(const frag*)(xr[kh] + kw * PP + sub * 32);
+        };
+        static_for<D>([&](auto J) { xf[decltype(J)::value] = ld(J); });
+        static_for<KF>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            acc[0][0] = Mfma<T>::run(fw[j], xf[j % D], acc[0][0]);
+            if constexpr (j + D < KF) xf[j % D] = ld(IC<j + D>{});
+        });
+        if constexpr (KS > 1) {
+            // the pair's two partial sums meet in LDS: the giver of this row stores its 16 registers, the taker adds them (roles alternate row by row)
+            f32x4* part = (f32x4*)(smem + G::EPI + pair * 4096);
+            const bool giver = ((t ^ KSI) & 1) != 0;
+            if (giver) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) part[g * 64 + lane] = f32x4{acc[0][0][4 * g], acc[0][0][4 * g + 1], acc[0][0][4 * g + 2], acc[0][0][4 * g + 3]};
+            }
+            __builtin_amdgcn_s_barrier();
+            if (giver) return;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 o = part[g * 64 + lane];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[0][0][4 * g + q] += o[q];
+            }
+        }
+        const int m_row = (c_img * p.Ho + c_row) * p.Wo;
+        const int m_base = m_row + c_strip * G::SWP + mt * 32;
+        epilogue_wave<T, 1, 1, true>(p, acc, slice, nt * 32, m_base, lane, -1, m_row + p.Wo, sacc);
+    };
+
+    // one output row per iteration: its input rows have landed (requested an iteration ago); the next row's new input row is requested before the MFMAs.
+    // A row that starts a new strip finds every row buffer busy or stale: its three rows are requested after the current row's reads (a second barrier), rare.
+    issue(true);
+    for (int t = t_begin; t < t_end; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // row t's input rows are in LDS for every wave; nobody reads the buffers of row t - 1 any more
+        cur[0] = nxt[0]; cur[1] = nxt[1]; cur[2] = nxt[2];
+        c_img = n_img; c_strip = n_strip; c_row = n_row;
+        const bool more = t + 1 < t_end;
+        const bool fresh = more && row == 0;
+        if (more && !fresh) issue(false);
+        if constexpr (KS == 1) compute(IC<0>{}, t);
+        else if (ks == 0) compute(IC<0>{}, t);
+        else compute(IC<1>{}, t);
+        if (fresh) {
+            __builtin_amdgcn_s_barrier();   // every wave is done with this strip's row buffers
+            issue(true);
+        }
+    }
+    if (p.stats) epilogue_stats_flush<1>(p, sacc, nt * 32, lane, (blockIdx.x * MT + mt) * KS + ks);
+#endif
+}
+
+struct CsPlan {
+    int blocks, per, strips, T, mt;
+};
+// knob "conv_strip": 1 on, 0 off, 2 also small launches, N > 2: N output rows per block (tests)
+static bool cs_plan(const ConvArgs& a, CsPlan& pl) {
+    const long long mode = y3_knob(Y3K_CONV_STRIP);
+    if (mode == 0 || a.ups || a.res) return false;
+    if (a.ks != 3 || a.stride != 1 || a.pad != 1 || a.dil_shift != 0 || a.ntaps != 9 || a.omul != 1 || a.ooh != 0 || a.oow != 0) return false;
+    if (a.H != a.Ho || a.W != a.Wo || a.oH != a.Ho || a.oW != a.Wo) return false;
+    if (!((a.Cin == 64 && a.Cout == 32) || (a.Cin == 64 && a.Cout == 128) || (a.Cin == 128 && a.Cout == 64))) return false;
+    if (!a.x_bytes || !a.w_bytes || !a.y_bytes) return false;
+    for (int t = 0; t < 9; ++t)
+        if (a.tdh[t] != t / 3 || a.tdw[t] != t % 3) return false;
+    pl.mt = 2;
+    const int swp = pl.mt * 32;
+    pl.strips = (a.W + swp - 1) / swp;
+    const long long T = (long long)a.N * pl.strips * a.Ho;
+    if (T < 1 || T > 0x3fffffffLL) return false;
+    // blocks a CU holds (CsGeom::LDS = 44 / 56 / 104 KiB for 64 -> 32 / 64 -> 128 / 128 -> 64; 2 / 8 / 8 waves per block, two waves per SIMD: 144 filter
+    // registers per lane)
+    const int per_cu = a.Cout == 32 ? 3 : 1;
+    const int nblk = v7_cu_count() * per_cu;
+    if (mode == 1 && T < 24LL * nblk) return false;   // every block amortises its filter load and its statistics row over >= 24 output rows
+    pl.per = mode > 2 ? (int)mode : (int)((T + nblk - 1) / nblk);
+    if (pl.per < 1) pl.per = 1;
+    pl.blocks = (int)((T + pl.per - 1) / pl.per);
+    pl.T = (int)T;
+    return true;
+}
+
+template <typename T> int launch_cs(ConvArgs& a, hipStream_t st) {
+    CsPlan pl;
+    if (!cs_plan(a, pl)) Y3_FAIL("conv strip: no plan (internal)");
+    a.cs_strips = pl.strips; a.cs_T = pl.T; a.cs_per = pl.per;
+    set_divisors(a);
+    magic_u31(a.Ho, a.dv_pw_mul, a.dv_pw_sh);          // this kernel divides the row index by Ho and by the strips per row
+    magic_u31(pl.strips, a.dv_h1_mul, a.dv_h1_sh);
+    a.n_pt = pl.blocks;
+    a.n_ct = 1;
+    a.stat_wp = pl.mt * (a.Cin > 64 ? 2 : 1);   // one statistics row per block, pixel tile and K-split wave
+    g_last_variant = "strip";
+    if (a.dry) return 0;
+    const dim3 grid((unsigned)pl.blocks);
+    if (a.Cin == 128) hipLaunchKernelGGL((conv_strip_kernel<T, 128, 64, 2>), grid, dim3(cs_threads<128, 64, 2>()), 0, st, a);
+    else if (a.Cout == 32) hipLaunchKernelGGL((conv_strip_kernel<T, 64, 32, 2>), grid, dim3(cs_threads<64, 32, 2>()), 0, st, a);
+    else hipLaunchKernelGGL((conv_strip_kernel<T, 64, 128, 2>), grid, dim3(cs_threads<64, 128, 2>()), 0, st, a);
+    Y3_CHECK_LAUNCH();
+    return 0;
+}
