@@ -1009,6 +1009,55 @@ def test_conv_wgrad_strip_vs_autograd(dev, tune, dtype, name, shape, per):
     assert e_w < 2e-5 and e_o < 2e-5, f"{name} {dtype}: vs autograd {e_w:.2e}, vs tile kernel {e_o:.2e}"
 
 
+STRIP_QUAD_CASES = [
+    # name, (n, h, w) of the 32-channel gradient, du rows per block (knob conv_strip; 2 = the host's plan)
+    ("one_strip", (2, 40, 128), 2),
+    ("ragged_strips_walk7", (3, 38, 300), 7),        # du is 19 x 150: 3 strips, the last 22 pixels wide; blocks cross strips and images
+    ("tall_one_block", (1, 140, 128), 70),           # one block walks a whole strip: the row ring wraps many times
+    ("narrow_map", (4, 80, 26), 3),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name,shape,per", STRIP_QUAD_CASES, ids=[c[0] for c in STRIP_QUAD_CASES])
+def test_conv_dgrad_s2_strip_quad_vs_autograd(dev, tune, dtype, name, shape, per):
+    """the stride-2 data gradient of a 32 -> 64 layer through conv_strip_quad_kernel (csrc/conv_strip.h: du rows staged once for the nine (tap, parity class)
+    pairs, the four classes' filters in registers) against torch autograd on the same rounded operands, write and accumulate forms, and against the
+    tile kernel (knob conv_strip = 0: v3_quad)"""
+    _lib, ops = _ops()
+    n, h, w = shape
+    cin, cout = 32, 64
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(n, cin, h, w, generator=g).to(dtype).float().requires_grad_(True)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)).to(dtype).float()
+    y = F.conv2d(x, wt, None, stride=2, padding=1)
+    gy = torch.randn(y.shape, generator=g).to(dtype).float()
+    y.backward(gy)
+    gv = ops.View.alloc(n, y.shape[2], y.shape[3], cout, dtype, dev)
+    ops.nchw_to_nhwc(gy.to(dev), gv)
+    tune("conv_strip", per)
+    g2 = ops.View.alloc(n, h, w, cin, dtype, dev)
+    g2.buf.fill_(float("nan"))
+    ops.conv2d_dgrad_s2(wt.to(dev), gv, g2, accumulate=False)
+    assert ops.last_conv_variant() == "strip_quad", ops.last_conv_variant()
+    new = g2.as_nhwc().clone()
+    tol = {torch.float16: 2e-3, torch.bfloat16: 1.5e-2}[dtype]
+    d2 = new.float().cpu().permute(0, 3, 1, 2)
+    assert (d2 - x.grad).abs().max().item() / x.grad.abs().max().item() < tol, "strip_quad (write)"
+    ops.conv2d_dgrad_s2(wt.to(dev), gv, g2, accumulate=True)   # a residual: the tile kernels
+    assert ops.last_conv_variant() != "strip_quad"
+    d3 = g2.as_nhwc().float().cpu().permute(0, 3, 1, 2)
+    assert (d3 - 2 * x.grad).abs().max().item() / x.grad.abs().max().item() < 2 * tol, "accumulate"
+    tune("conv_strip", 0)
+    g3 = ops.View.alloc(n, h, w, cin, dtype, dev)
+    g3.buf.fill_(float("nan"))
+    ops.conv2d_dgrad_s2(wt.to(dev), gv, g3, accumulate=False)
+    assert ops.last_conv_variant() == "v3_quad"
+    torch.cuda.synchronize()
+    # (the nine (tap, class) products of a pixel are summed shift by shift here, tap by tap there: equal to rounding)
+    assert (g3.as_nhwc().float() - new.float()).abs().max().item() <= tol * x.grad.abs().max().item(), "strip_quad and v3_quad differ"
+
+
 BIG_WGRAD_CASES = [
     ("3x3s1_80", (4, 80, 80, 128, 256, 3, 1)),        # 5 column tiles (4.5 used), slices chosen for one round of 256 blocks
     ("3x3s2_odd", (16, 67, 63, 128, 256, 3, 2)),      # stride 2, odd extents: halo + ragged last K-step

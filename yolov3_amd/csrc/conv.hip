@@ -1402,6 +1402,8 @@ extern "C" int y3_conv2d_dgrad_s2(int32_t dtype, const y3_tensor* du, const void
     const bool quad_on = y3_knob(Y3K_DGRAD_QUAD) != 0;
     bool quad = quad_on && live[0] && live[1] && live[2] && live[3] && cls[0].M == cls[3].M && cls[1].M == cls[3].M && cls[2].M == cls[3].M;
     if (quad) {
+        CsPlan sp;
+        if (cq_plan(cls, sp)) return dtype == Y3_F16 ? launch_cq<f16_t>(cls, st) : launch_cq<bf16_t>(cls, st);   // conv_strip.h: du rows staged once for the nine (tap, class) pairs
         int big = 0;
         for (int i = 1; i < 4; ++i)
             if (cls[i].ntaps > cls[big].ntaps) big = i;

@@ -251,3 +251,227 @@ template <typename T> int launch_cs(ConvArgs& a, hipStream_t st) {
     Y3_CHECK_LAUNCH();
     return 0;
 }
+
+// ---- the stride-2 data gradient on the same plan ---------------------------------------------------------------------------------------------------
+// dx of a 3x3 / stride-2 convolution (reference models/yolov3.yaml:16,19: layers 1 and 3; y3_conv2d_dgrad_s2) = four stride-1 convolutions of du, one per
+// output-pixel parity (ph, pw), with 1 / 2 / 2 / 4 taps whose input offsets are (dh, dw) in {0, 1}^2 (S2Class in conv.hip): 9 (tap, class) pairs over FOUR
+// distinct shifted views of du.  The tile kernels (conv_igemm_v3_quad_kernel) stage a du tile once per tap and class -- 9 x 128-256 B per du pixel.  Here a
+// K-step is one du row of a 64-pixel strip: rows i and i + 1 are resident (ring of three, one new row per step), a wave reads each of the 4 x Cin / 16
+// shifted fragments ONCE and feeds it to every (tap, class) that uses it -- back-to-back MFMAs into up to four independent accumulators -- and the filters
+// of all four classes sit in registers (64 -> 32 channels: 36 fragments; layer 1 of yolov3, the largest data gradient of the step).  Every class is
+// rounded and stored straight from the accumulators at its output parity (output pixel (2 i + ph, 2 j + pw)).  (128 -> 64, layer 3, would need 72 fragments per filter
+// tile: two wave roles of 40 / 32 fragments spill at two waves per SIMD -- it stays on conv_igemm_v3_quad_kernel.)
+// class c = 2 ph + pw; whether it has a tap with input shift (dh, dw); its taps; its first filter fragment (in taps) in the wave's register bank
+constexpr bool cq_uses(int c, int dh, int dw) { return (dh == 0 || (c >> 1) == 1) && (dw == 0 || (c & 1) == 1); }
+constexpr int cq_taps(int c) { return ((c >> 1) + 1) * ((c & 1) + 1); }
+constexpr int cq_base(int c) {
+    int b = 0;
+    for (int i = 0; i < c; ++i) b += cq_taps(i);
+    return b;
+}
+
+template <int CIN, int COUT, int MT> struct CqGeom {
+    static constexpr int PXB = CIN * 2, PP = PXB + 16, SLOTS = PP / 16;
+    static constexpr int SWP = MT * 32, NPX = SWP + 1;                    // du pixels j .. j + 64 of a row
+    static constexpr int XPIECES = (NPX * PP + 1023) / 1024, XROWB = XPIECES * 1024;
+    static constexpr int NSLOT = 3;                                       // rows i, i + 1 in use + the one being fetched
+    static constexpr int KPT = CIN / 16;                                  // 16-wide reduction steps per tap
+    static constexpr int NT = COUT / 32, NW = MT * NT;
+    static_assert(9 * KPT <= 36, "all four classes' filters in 144 registers");
+    static constexpr int XBASE = 0, LDS = NSLOT * XROWB;
+    static constexpr int XPW = (XPIECES + NW - 1) / NW;
+};
+template <int CIN, int COUT, int MT> constexpr int cq_threads() { return CqGeom<CIN, COUT, MT>::NW * 64; }
+// what differs between the classes is the filter bank and the output parity: one ConvArgs (class 3's) + the four banks keep the scalar registers free
+struct CqArgs {
+    ConvArgs a;
+    const void* w[4];
+    int kpad[4];
+};
+
+template <typename T, int CIN, int COUT, int MT>
+__global__ __launch_bounds__((cq_threads<CIN, COUT, MT>()), 2) void conv_strip_quad_kernel(const CqArgs q) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef CqGeom<CIN, COUT, MT> G;
+    constexpr int PP = G::PP, XROWB = G::XROWB, NW = G::NW, NT = G::NT, KPT = G::KPT, XPW = G::XPW;
+    typedef typename Mfma<T>::frag frag;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[G::LDS];
+    const ConvArgs& p = q.a;   // the geometry every class shares: du, the strip walk (cs_*), Ho x Wo = the class image
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mt = wv / NT, nt = wv % NT;
+    const int frow = lane & 31, fk = lane >> 5;
+    const int t_begin = blockIdx.x * p.cs_per;
+    int t_end = t_begin + p.cs_per;
+    if (t_end > p.cs_T) t_end = p.cs_T;
+    if (t_begin >= t_end) return;
+    const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const auto rsrc_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)p.y_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xffffffffu;
+
+    // the four classes' filters: (class c, tap, 16-step) -> fragment (cq_base(c) + tap) KPT + sub
+    frag fw[9 * KPT];
+    static_for<4>([&](auto CC) {
+        constexpr int c = decltype(CC)::value, nf = cq_taps(c) * KPT, f0 = cq_base(c) * KPT;
+        const T* wrow = (const T*)q.w[c] + (size_t)(nt * 32 + frow) * q.kpad[c] + fk * 8;
+        static_for<nf>([&](auto J) { fw[f0 + decltype(J)::value] = *(const frag*)(wrow + 16 * decltype(J)::value); });
+    });
+
+    int xj[XPW];
+    int xoffl[XPW];
+#pragma unroll
+    for (int i = 0; i < XPW; ++i) {
+        const int e = (i * NW + wv) * 64 + lane;
+        const int j = e / G::SLOTS, slot = e - j * G::SLOTS;
+        xj[i] = (slot < G::SLOTS - 1 && j < G::NPX) ? j : -1;
+        xoffl[i] = (j * p.xpitch + slot * 8) * 2;                  // relative to du pixel (row, w0)
+    }
+    const unsigned char* xfrag = smem + G::XBASE + (mt * 32 + frow) * PP + fk * 16;
+
+    int tn = fdiv(t_begin, p.dv_pw_mul, p.dv_pw_sh);          // host: reciprocal of the class image's rows
+    int row = t_begin - tn * p.Ho;
+    int img = fdiv(tn, p.dv_h1_mul, p.dv_h1_sh);
+    int strip = tn - img * p.cs_strips;
+    int cur[2] = {0, 0}, nxt[2] = {0, 0};
+    int hp = 0;
+    int c_img = 0, c_strip = 0, c_row = 0, n_img = 0, n_strip = 0, n_row = 0;
+    auto take = [&]() { const int s = hp; hp = hp == 2 ? 0 : hp + 1; return s; };
+    auto request_row = [&](int hin, int slot, int w0) {
+        const bool rowok = (unsigned)hin < (unsigned)p.H;
+        const long long xbase = (((long long)img * p.H + hin) * p.W + w0) * p.xpitch * 2;
+#pragma unroll
+        for (int i = 0; i < XPW; ++i) {
+            if ((i + 1) * NW <= G::XPIECES || i * NW + wv < G::XPIECES) {
+                const bool ok = rowok && xj[i] >= 0 && w0 + xj[i] < p.W;
+                const unsigned off = ok ? (unsigned)(xbase + xoffl[i]) : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(smem + G::XBASE + slot * XROWB + (i * NW + wv) * 1024), 16, off, 0, 0, 0);
+            }
+        }
+    };
+    auto issue = [&](bool fresh) {
+        const int w0 = strip * G::SWP;
+        if (fresh) {
+            nxt[0] = take(); nxt[1] = take();
+            request_row(row, nxt[0], w0);
+            request_row(row + 1, nxt[1], w0);
+        } else {
+            nxt[0] = nxt[1]; nxt[1] = take();
+            request_row(row + 1, nxt[1], w0);
+        }
+        n_img = img; n_strip = strip; n_row = row;
+        if (++row == p.Ho) {
+            row = 0;
+            if (++strip == p.cs_strips) { strip = 0; ++img; }
+        }
+    };
+
+    // one du row: every shifted fragment (dh, dw, sub) is read once and multiplied into each class of the role that has a tap with that shift.
+    // Class c = (ph, pw): taps (ih, iw), ih < ph + 1, iw < pw + 1, with dh = (ph && ih == 0), dw = (pw && iw == 0); K index of the class = (ih nw + iw) Cin + ci.
+    auto compute = [&]() {
+        f32x16 acc[4][1][1];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[c][0][0][e] = 0.0f;
+        const unsigned char* xr[2] = {xfrag + cur[0] * XROWB, xfrag + cur[1] * XROWB};
+        static_for<4 * KPT>([&](auto V) {
+            constexpr int v = decltype(V)::value;
+            constexpr int shift = v / KPT, sub = v % KPT, dh = shift >> 1, dw = shift & 1;
+            const frag xf = *(const frag*)(xr[dh] + dw * PP + sub * 32);
+            static_for<4>([&](auto CC) {
+                constexpr int c = decltype(CC)::value, ph = c >> 1, pw = c & 1;
+                if constexpr (cq_uses(c, dh, dw)) {
+                    constexpr int ih = ph ? (dh ? 0 : 1) : 0, iw = pw ? (dw ? 0 : 1) : 0;
+                    acc[c][0][0] = Mfma<T>::run(fw[(cq_base(c) + ih * (pw + 1) + iw) * KPT + sub], xf, acc[c][0][0]);
+                }
+            });
+        });
+        // epilogue, straight from the registers (no bias, activation, residual or statistics in a data gradient; one call per 9 MFMAs, so the LDS transpose
+        // and the index arithmetic of epilogue_wave would dominate): pairs rounded to T, the halves swapped between the lane halves as in epilogue_wave --
+        // lane (pixel j, fk) then holds the 16-byte chunks 2 gp + fk (filters 8 chunk .. + 7) of its pixel and stores them at (2 i + ph, 2 j + pw)
+        const int jj = c_strip * G::SWP + mt * 32 + frow;
+        const bool pv = jj < p.Wo;
+        static_for<4>([&](auto CC) {
+            constexpr int c = decltype(CC)::value, ph = c >> 1, pw = c & 1;
+            const long long opix = ((long long)c_img * p.oH + 2 * c_row + ph) * p.oW + 2 * jj + pw;
+            const unsigned ybase = pv ? (unsigned)((opix * p.ypitch + nt * 32) * 2) : 0xffffffffu;
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                u32x4 ov;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(pack2<T>(acc[c][0][0][8 * gp + 2 * h], acc[c][0][0][8 * gp + 2 * h + 1]),
+                                                                    pack2<T>(acc[c][0][0][8 * gp + 4 + 2 * h], acc[c][0][0][8 * gp + 4 + 2 * h + 1]), false, false);
+                    ov[h] = (unsigned)sw[0];
+                    ov[2 + h] = (unsigned)sw[1];
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(ov, rsrc_y, pv ? ybase + (unsigned)((gp * 2 + fk) * 16) : 0xffffffffu, 0, 0);
+            }
+        });
+    };
+
+    issue(true);
+    for (int t = t_begin; t < t_end; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur[0] = nxt[0]; cur[1] = nxt[1];
+        c_img = n_img; c_strip = n_strip; c_row = n_row;
+        const bool more = t + 1 < t_end;
+        const bool fresh = more && row == 0;
+        if (more && !fresh) issue(false);
+        compute();
+        if (fresh) {
+            __builtin_amdgcn_s_barrier();
+            issue(true);
+        }
+    }
+#endif
+}
+
+// knob "conv_strip" as above.  Eligibility: the four classes share the geometry (even H, W: checked by the caller), no residual, (du channels, dx channels) =
+// (64, 32), enough du rows per block
+static bool cq_plan(const ConvArgs* cls, CsPlan& pl) {
+    const long long mode = y3_knob(Y3K_CONV_STRIP);
+    const ConvArgs& a = cls[3];
+    if (mode == 0 || a.res || a.ups || a.bias) return false;
+    if (!(a.Cin == 64 && a.Cout == 32)) return false;
+    for (int i = 0; i < 4; ++i)
+        if (!cls[i].x_bytes || !cls[i].w_bytes || !cls[i].y_bytes || cls[i].Ho != a.Ho || cls[i].Wo != a.Wo || cls[i].H != a.H || cls[i].W != a.W) return false;
+    if (a.Ho != a.H || a.Wo != a.W) return false;   // even gradient sizes: every class image is du's size
+    pl.mt = 2;
+    pl.strips = (a.Wo + 63) / 64;
+    const long long T = (long long)a.N * pl.strips * a.Ho;
+    if (T < 1 || T > 0x3fffffffLL) return false;
+    const int nblk = v7_cu_count() * 4;   // (CqGeom::LDS = 30 KiB, 2 waves per block, two waves per SIMD)
+    if (mode == 1 && T < 24LL * nblk) return false;
+    pl.per = mode > 2 ? (int)mode : (int)((T + nblk - 1) / nblk);
+    if (pl.per < 1) pl.per = 1;
+    pl.blocks = (int)((T + pl.per - 1) / pl.per);
+    pl.T = (int)T;
+    return true;
+}
+
+template <typename T> int launch_cq(ConvArgs* cls, hipStream_t st) {
+    CsPlan pl;
+    if (!cq_plan(cls, pl)) Y3_FAIL("conv strip (stride-2 data gradient): no plan (internal)");
+    CqArgs q;
+    for (int i = 0; i < 4; ++i) {
+        if (cls[i].ooh != (i >> 1) || cls[i].oow != (i & 1) || cls[i].omul != 2) Y3_FAIL("conv strip (stride-2 data gradient): class order (internal)");
+        q.w[i] = cls[i].w;
+        q.kpad[i] = cls[i].Kpad;
+    }
+    ConvArgs& a = cls[3];
+    a.cs_strips = pl.strips; a.cs_T = pl.T; a.cs_per = pl.per;
+    a.n_ct = 1; a.n_pt = pl.blocks;
+    set_divisors(a);
+    magic_u31(a.Ho, a.dv_pw_mul, a.dv_pw_sh);
+    magic_u31(pl.strips, a.dv_h1_mul, a.dv_h1_sh);
+    q.a = a;
+    g_last_variant = "strip_quad";
+    const dim3 grid((unsigned)pl.blocks);
+    hipLaunchKernelGGL((conv_strip_quad_kernel<T, 64, 32, 2>), grid, dim3(cq_threads<64, 32, 2>()), 0, st, q);
+    Y3_CHECK_LAUNCH();
+    return 0;
+}
