@@ -171,3 +171,29 @@ def test_train_plan_static_analysis_on_cpu():
     assert all(u.bank_fwd is not None for u in convs if not u.use_stem) and convs[0].use_stem and convs[0].bank_fwd is None
     r = TrainPlan(m, 1, 64, 64, torch.float32, torch.device("cpu"))
     assert r.pack_jobs is None
+
+
+def test_deferred_shortcut_gradient_state_machine():
+    """train_engine.Act: a Bottleneck's shortcut gradient is noted, not stored (defer), and handed to the next producer (take_deferred); it cannot be deferred
+    onto a tensor that already has a gradient, a channel slice, or another shape"""
+    import torch
+
+    from yolov3_amd.ops import View
+    from yolov3_amd.train_engine import Act
+
+    def view(n, h, w, c):
+        return View(torch.zeros(n * h * w * c, dtype=torch.float16), n, h, w, c, c, 0)
+
+    x, dy = Act(view(2, 4, 4, 16)), view(2, 4, 4, 16)
+    assert not x.is_ready() and x.take_deferred() is None
+    assert x.defer(dy) and x.is_ready() and x.deferred is dy
+    assert not x.defer(dy), "one deferred contribution at a time"
+    assert x.take_deferred() is dy and x.deferred is None and not x.is_ready()
+    x.mark_ready()
+    assert not x.defer(dy), "a stored gradient must be accumulated into"
+    x.drop_grad()
+    assert x.defer(dy)
+    x.drop_grad()
+    assert x.deferred is None and not x.is_ready()
+    assert not Act(view(2, 4, 4, 8)).defer(dy), "shape mismatch"
+    assert not x.slice(0, 8).defer(view(2, 4, 4, 8)), "slices of a concat buffer keep the stored form"

@@ -35,13 +35,37 @@ class Act:
         self.view = view
         self.g: View | None = None
         self.ready = False  # gradient buffer holds a value (first producer WRITES, later ones accumulate: no memset)
+        # a gradient contribution that is still another tensor (the shortcut of a Bottleneck: d out / d x = identity, so the contribution IS the output's
+        # gradient): the next producer adds it while it writes (`take_deferred`), anyone else sees it materialised by `grad()`
+        self.deferred: View | None = None
 
     def slice(self, coff, c):
         a = Act(self.view.slice(coff, c))
         a.parent, a.coff = self, coff
         return a
 
+    def defer(self, contribution: View) -> bool:
+        """note `contribution` as the (only, so far) gradient of this tensor without copying it; False when that is not possible here"""
+        if self.ready or self.deferred is not None or self.g is not None or getattr(self, "parent", None) is not None:
+            return False
+        v = self.view
+        if (contribution.n, contribution.h, contribution.w, contribution.c) != (v.n, v.h, v.w, v.c):
+            return False
+        self.deferred = contribution
+        return True
+
+    def take_deferred(self) -> View | None:
+        """the deferred contribution, handed to a producer that will WRITE grad() = its own result + this (and then mark_ready)"""
+        d, self.deferred = self.deferred, None
+        return d
+
     def grad(self) -> View:
+        if self.deferred is not None:   # someone needs the buffer itself: copy the deferred contribution in
+            d = self.take_deferred()
+            g = self.grad()
+            ops.copy_slice(d, g)
+            self.ready = True
+            return g
         if self.g is None:
             parent = getattr(self, "parent", None)
             if parent is not None:
@@ -59,7 +83,7 @@ class Act:
 
     def is_ready(self) -> bool:
         parent = getattr(self, "parent", None)
-        return self.ready or (parent is not None and parent.is_ready())
+        return self.ready or self.deferred is not None or (parent is not None and parent.is_ready())
 
     def mark_ready(self):
         self.ready = True
@@ -67,6 +91,7 @@ class Act:
     def drop_grad(self):
         self.g = None
         self.ready = False
+        self.deferred = None
 
 
 def _f32(t):
@@ -258,6 +283,15 @@ class ConvUnit(_Unit):
             )
             if self.res is not None:
                 self.res.mark_ready()
+        elif self.res is not None and not self.res.is_ready() and os.environ.get("Y3_DEFER_SHORTCUT", "1") != "0" and self.res.defer(gy):
+            # out = act(bn(conv)) + res and nothing has written d res yet: d res = d out + (what cv1's data gradient adds).  Nothing is stored here: the
+            # data-gradient launch of the other consumer of res (cv1 of the Bottleneck) takes d out as its residual operand and writes d res once --
+            # one pass over the tensor less per Bottleneck, 4.4 GB of the batch-64 step (Y3_DEFER_SHORTCUT=0: the stored form, for A/B runs)
+            check(
+                L.y3_bn_act_bwd(C.byref(ut), C.byref(gt), self.scale.data_ptr(), self.shift.data_ptr(), self.mean.data_ptr(), self.invstd.data_ptr(), dcode, self.act,
+                                self.sums.data_ptr(), C.byref(dt), dgamma.data_ptr(), dbeta.data_ptr(), st),
+                "y3_bn_act_bwd",
+            )
         elif self.res is not None:  # out = act(bn(conv)) + res  ->  d res (+)= d out, written by the pass that reads d out anyway
             gr = self.res.grad()
             grt = gr.y3()
@@ -282,15 +316,17 @@ class ConvUnit(_Unit):
         m = self.m
         if not self.need_dx:
             return
-        gx = self.x.grad()
         if not self.generic_dgrad():
+            gx = self.x.grad()
             ops.conv2d_dgrad_s2(m.conv.weight, du, gx, accumulate=self.x.is_ready())   # no zero-tap waste
         else:
+            deferred = self.x.take_deferred()   # (a Bottleneck's shortcut gradient: added by this launch, never stored on its own)
+            gx = self.x.grad()
             filt_d, self.filt_d = self.filt_d, None
             if filt_d is None:
                 filt_d = ops.pack_filter_dgrad(m.conv.weight, self.cout, self.cin, self.plan.dtype)
             zb = self.plan.zeros_f32(self.cin)
-            res = gx if self.x.is_ready() else None
+            res = deferred if deferred is not None else (gx if self.x.is_ready() else None)
             ops.conv2d(du, filt_d, zb, gx, self.k, 1, act=False, residual=res, in_dilation=self.s, workspace=self.plan.conv_ws)
         self.x.mark_ready()
 
