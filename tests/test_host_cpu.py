@@ -364,6 +364,17 @@ def test_conv_dispatch_variant_names_and_stat_rows():
                     assert L.y3_conv2d_fwd_variant(C.byref(d), C.byref(x), C.byref(y), 0, 0, name, 64) == 0 and name.value == b"v6"
                 finally:
                     L.y3_tune_reset()
+    # the training-mode launches of the small-channel 3x3 / stride-1 layers (conv_strip.h): 64 -> 32 and 128 -> 64 are the data gradients of layers 2.cv2 / 4.x.cv2;
+    # rows = blocks x pixel tiles (x 2 K-split waves at Cin = 128); small launches and residual launches stay on the tile kernels
+    for (cin, cout, hin, rows_want) in [(64, 32, 320, 768 * 2), (128, 64, 160, 256 * 2 * 2)]:
+        x, y = Y3Tensor(4096, 64, hin, hin, cin, cin), Y3Tensor(8192, 64, hin, hin, cout, cout)
+        d = _desc(_lib.Y3_F16, 3, 1, cin, cout)
+        assert L.y3_conv2d_fwd_variant(C.byref(d), C.byref(x), C.byref(y), 0, 0, name, 64) == 0 and name.value == b"strip", name.value
+        rows = L.y3_conv2d_fwd_stats_rows(C.byref(d), C.byref(x), C.byref(y))
+        assert abs(rows - rows_want) <= rows_want // 50, (cin, cout, rows)
+        assert L.y3_conv2d_fwd_variant(C.byref(d), C.byref(x), C.byref(y), 1, 0, name, 64) == 0 and name.value != b"strip"   # with a residual
+        xs, ys = Y3Tensor(4096, 2, 64, 64, cin, cin), Y3Tensor(8192, 2, 64, 64, cout, cout)
+        assert L.y3_conv2d_fwd_variant(C.byref(d), C.byref(xs), C.byref(ys), 0, 0, name, 64) == 0 and name.value != b"strip"  # too few rows per block
     # fp32 -> the direct kernel; a too-small workspace never selects the persistent kernel
     x, y = Y3Tensor(4096, 2, 20, 20, 512, 512), Y3Tensor(8192, 2, 20, 20, 1024, 1024)
     name = C.create_string_buffer(64)

@@ -15,13 +15,14 @@
 //     row is requested per output row (one K-step ahead) and the nine taps are nine views of the three resident rows (row buffer = kh, pixel shift = kw:
 //     instruction immediates).  Padding is free: out-of-image rows / columns are lanes with an out-of-range source offset (the descriptor lands zeros);
 //   * pixel rows have a pitch of (2 Cin + 16) bytes: the 32 lanes of a fragment read (consecutive pixels, 16 bytes each) fall on distinct bank quads, the
-//     conflict-free property conv_v9.h buys the same way (every 5th / 9th 16-byte slot of a request is a pad slot: an out-of-range lane);
+//     conflict-free property conv_v9.h buys the same way (every 9th / 17th 16-byte slot of a request is a pad slot: an out-of-range lane);
 //   * waves = MT pixel tiles x Cout / 32 filter tiles (x KS); per output row a wave issues 36 ds_read_b128 + as many MFMAs and one epilogue_wave call
 //     (bias, SiLU, NHWC transpose through its private LDS slice, 16-byte stores); BatchNorm statistics accumulate in 16 registers over the block's rows and
 //     leave as ONE row per wave (epilogue_stats_flush) instead of one per 64 pixels;
 //   * persistent blocks over the linear index t = ((image, strip), row), like wgrad_strip.h.
-// Measured at batch 64 (profiles/r03_conv_strip_ab.txt): 64 -> 32 @320x320 762 -> 315 us, 64 -> 128 @160x160 327 -> 294 us; bit-identical outputs (the same
-// products added in the same order).  32 -> 64 itself (18 steps per epilogue call) measured level with the 64 x 256-pixel tile kernel and stays there.
+// Measured at batch 64 (profiles/r03_conv_strip_ab.txt): 64 -> 32 @320x320 773 -> 314 us, 128 -> 64 @160x160 544 -> 342 us, 64 -> 128 @160x160 335 -> 314 us;
+// the KS = 1 forms are bit-identical to the tile kernels (the same products added in the same order).  32 -> 64 itself (18 steps per epilogue call)
+// measured level with the 64 x 256-pixel tile kernel and stays there.
 
 template <int CIN, int COUT, int MT> struct CsGeom {
     static constexpr int KS = CIN > 64 ? 2 : 1;                          // waves that split the reduction of one (pixel tile, filter tile)
