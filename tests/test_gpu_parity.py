@@ -1019,14 +1019,15 @@ STRIP_QUAD_CASES = [
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("chans", [(32, 64), (64, 128)], ids=["c32_64", "c64_128_two_roles"])
 @pytest.mark.parametrize("name,shape,per", STRIP_QUAD_CASES, ids=[c[0] for c in STRIP_QUAD_CASES])
-def test_conv_dgrad_s2_strip_quad_vs_autograd(dev, tune, dtype, name, shape, per):
-    """the stride-2 data gradient of a 32 -> 64 layer through conv_strip_quad_kernel (csrc/conv_strip.h: du rows staged once for the nine (tap, parity class)
+def test_conv_dgrad_s2_strip_quad_vs_autograd(dev, tune, dtype, chans, name, shape, per):
+    """the stride-2 data gradient of a 32 -> 64 / 64 -> 128 layer through conv_strip_quad_kernel (csrc/conv_strip.h: du rows staged once for the nine (tap, parity class)
     pairs, the four classes' filters in registers) against torch autograd on the same rounded operands, write and accumulate forms, and against the
     tile kernel (knob conv_strip = 0: v3_quad)"""
     _lib, ops = _ops()
     n, h, w = shape
-    cin, cout = 32, 64
+    cin, cout = chans   # of the layer: du has cout channels, the gradient cin (64 -> 128: two waves per (pixel tile, filter tile), split by parity class)
     g = torch.Generator().manual_seed(7)
     x = torch.randn(n, cin, h, w, generator=g).to(dtype).float().requires_grad_(True)
     wt = (torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)).to(dtype).float()

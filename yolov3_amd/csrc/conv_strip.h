@@ -259,15 +259,19 @@ template <typename T> int launch_cs(ConvArgs& a, hipStream_t st) {
 // distinct shifted views of du.  The tile kernels (conv_igemm_v3_quad_kernel) stage a du tile once per tap and class -- 9 x 128-256 B per du pixel.  Here a
 // K-step is one du row of a 64-pixel strip: rows i and i + 1 are resident (ring of three, one new row per step), a wave reads each of the 4 x Cin / 16
 // shifted fragments ONCE and feeds it to every (tap, class) that uses it -- back-to-back MFMAs into up to four independent accumulators -- and the filters
-// of all four classes sit in registers (64 -> 32 channels: 36 fragments; layer 1 of yolov3, the largest data gradient of the step).  Every class is
-// rounded and stored straight from the accumulators at its output parity (output pixel (2 i + ph, 2 j + pw)).  (128 -> 64, layer 3, would need 72 fragments per filter
-// tile: two wave roles of 40 / 32 fragments spill at two waves per SIMD -- it stays on conv_igemm_v3_quad_kernel.)
-// class c = 2 ph + pw; whether it has a tap with input shift (dh, dw); its taps; its first filter fragment (in taps) in the wave's register bank
+// of its classes sit in registers: 64 -> 32 channels (layer 1 of yolov3, the largest data gradient of the step) all four classes, 36 fragments; 128 -> 64
+// (layer 3) 72 fragments per filter tile, so two waves share a (pixel tile, filter tile) by CLASS -- role 0 owns classes {11, 00} (40 fragments, 5 MFMAs per
+// 16-step), role 1 {01, 10} (32 fragments, 4 MFMAs): no sums to exchange.  Every class is rounded and stored straight from the accumulators at its output
+// parity (output pixel (2 i + ph, 2 j + pw)).
+// class c = 2 ph + pw; whether it has a tap with input shift (dh, dw); its taps; whether wave role r owns it (one role: every class; two roles: {3, 0} / {1, 2});
+// its first filter fragment (in taps) in the role's register bank
 constexpr bool cq_uses(int c, int dh, int dw) { return (dh == 0 || (c >> 1) == 1) && (dw == 0 || (c & 1) == 1); }
 constexpr int cq_taps(int c) { return ((c >> 1) + 1) * ((c & 1) + 1); }
-constexpr int cq_base(int c) {
+constexpr bool cq_owns(int roles, int r, int c) { return roles == 1 || (r == 0 ? (c == 0 || c == 3) : (c == 1 || c == 2)); }
+constexpr int cq_base(int roles, int r, int c) {
     int b = 0;
-    for (int i = 0; i < c; ++i) b += cq_taps(i);
+    for (int i = 0; i < c; ++i)
+        if (cq_owns(roles, r, i)) b += cq_taps(i);
     return b;
 }
 
@@ -277,8 +281,10 @@ template <int CIN, int COUT, int MT> struct CqGeom {
     static constexpr int XPIECES = (NPX * PP + 1023) / 1024, XROWB = XPIECES * 1024;
     static constexpr int NSLOT = 3;                                       // rows i, i + 1 in use + the one being fetched
     static constexpr int KPT = CIN / 16;                                  // 16-wide reduction steps per tap
-    static constexpr int NT = COUT / 32, NW = MT * NT;
-    static_assert(9 * KPT <= 36, "all four classes' filters in 144 registers");
+    static constexpr int ROLES = 9 * KPT > 36 ? 2 : 1;                    // waves that share a (pixel tile, filter tile) by class
+    static constexpr int NT = COUT / 32, NW = MT * NT * ROLES;
+    static constexpr int MAXF = (ROLES == 1 ? 9 : 5) * KPT;               // filter fragments of the busiest role
+    static_assert(MAXF <= 40, "160 filter registers per lane");
     static constexpr int XBASE = 0, LDS = NSLOT * XROWB;
     static constexpr int XPW = (XPIECES + NW - 1) / NW;
 };
@@ -294,7 +300,7 @@ template <typename T, int CIN, int COUT, int MT>
 __global__ __launch_bounds__((cq_threads<CIN, COUT, MT>()), 2) void conv_strip_quad_kernel(const CqArgs q) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef CqGeom<CIN, COUT, MT> G;
-    constexpr int PP = G::PP, XROWB = G::XROWB, NW = G::NW, NT = G::NT, KPT = G::KPT, XPW = G::XPW;
+    constexpr int PP = G::PP, XROWB = G::XROWB, NW = G::NW, NT = G::NT, KPT = G::KPT, XPW = G::XPW, ROLES = G::ROLES;
     typedef typename Mfma<T>::frag frag;
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[G::LDS];
@@ -302,7 +308,8 @@ __global__ __launch_bounds__((cq_threads<CIN, COUT, MT>()), 2) void conv_strip_q
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int mt = wv / NT, nt = wv % NT;
+    const int role = wv % ROLES, pair = wv / ROLES;
+    const int mt = pair / NT, nt = pair % NT;
     const int frow = lane & 31, fk = lane >> 5;
     const int t_begin = blockIdx.x * p.cs_per;
     int t_end = t_begin + p.cs_per;
@@ -312,13 +319,22 @@ __global__ __launch_bounds__((cq_threads<CIN, COUT, MT>()), 2) void conv_strip_q
     const auto rsrc_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)p.y_bytes, 0x00020000);
     constexpr unsigned OOB = 0xffffffffu;
 
-    // the four classes' filters: (class c, tap, 16-step) -> fragment (cq_base(c) + tap) KPT + sub
-    frag fw[9 * KPT];
-    static_for<4>([&](auto CC) {
-        constexpr int c = decltype(CC)::value, nf = cq_taps(c) * KPT, f0 = cq_base(c) * KPT;
-        const T* wrow = (const T*)q.w[c] + (size_t)(nt * 32 + frow) * q.kpad[c] + fk * 8;
-        static_for<nf>([&](auto J) { fw[f0 + decltype(J)::value] = *(const frag*)(wrow + 16 * decltype(J)::value); });
-    });
+    // the role's filters: (class c, tap, 16-step) -> fragment (cq_base(c) + tap) KPT + sub
+    frag fw[G::MAXF];
+    auto load_filters = [&](auto ROLE) {
+        constexpr int R = decltype(ROLE)::value;
+        static_for<4>([&](auto CC) {
+            constexpr int c = decltype(CC)::value;
+            if constexpr (cq_owns(ROLES, R, c)) {
+                constexpr int nf = cq_taps(c) * KPT, f0 = cq_base(ROLES, R, c) * KPT;
+                const T* wrow = (const T*)q.w[c] + (size_t)(nt * 32 + frow) * q.kpad[c] + fk * 8;
+                static_for<nf>([&](auto J) { fw[f0 + decltype(J)::value] = *(const frag*)(wrow + 16 * decltype(J)::value); });
+            }
+        });
+    };
+    if constexpr (ROLES == 1) load_filters(IC<0>{});
+    else if (role == 0) load_filters(IC<0>{});
+    else load_filters(IC<1>{});
 
     int xj[XPW];
     int xoffl[XPW];
@@ -370,8 +386,9 @@ __global__ __launch_bounds__((cq_threads<CIN, COUT, MT>()), 2) void conv_strip_q
 
     // one du row: every shifted fragment (dh, dw, sub) is read once and multiplied into each class of the role that has a tap with that shift.
     // Class c = (ph, pw): taps (ih, iw), ih < ph + 1, iw < pw + 1, with dh = (ph && ih == 0), dw = (pw && iw == 0); K index of the class = (ih nw + iw) Cin + ci.
-    auto compute = [&]() {
-        f32x16 acc[4][1][1];
+    auto compute = [&](auto ROLE) {
+        constexpr int R = decltype(ROLE)::value;
+        f32x16 acc[4][1][1];   // (the classes of the other role are never touched: dead)
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -380,14 +397,18 @@ __global__ __launch_bounds__((cq_threads<CIN, COUT, MT>()), 2) void conv_strip_q
         static_for<4 * KPT>([&](auto V) {
             constexpr int v = decltype(V)::value;
             constexpr int shift = v / KPT, sub = v % KPT, dh = shift >> 1, dw = shift & 1;
-            const frag xf = *(const frag*)(xr[dh] + dw * PP + sub * 32);
-            static_for<4>([&](auto CC) {
-                constexpr int c = decltype(CC)::value, ph = c >> 1, pw = c & 1;
-                if constexpr (cq_uses(c, dh, dw)) {
-                    constexpr int ih = ph ? (dh ? 0 : 1) : 0, iw = pw ? (dw ? 0 : 1) : 0;
-                    acc[c][0][0] = Mfma<T>::run(fw[(cq_base(c) + ih * (pw + 1) + iw) * KPT + sub], xf, acc[c][0][0]);
-                }
-            });
+            constexpr bool used = (cq_owns(ROLES, R, 0) && cq_uses(0, dh, dw)) || (cq_owns(ROLES, R, 1) && cq_uses(1, dh, dw)) ||
+                                  (cq_owns(ROLES, R, 2) && cq_uses(2, dh, dw)) || (cq_owns(ROLES, R, 3) && cq_uses(3, dh, dw));
+            if constexpr (used) {
+                const frag xf = *(const frag*)(xr[dh] + dw * PP + sub * 32);
+                static_for<4>([&](auto CC) {
+                    constexpr int c = decltype(CC)::value, ph = c >> 1, pw = c & 1;
+                    if constexpr (cq_owns(ROLES, R, c) && cq_uses(c, dh, dw)) {
+                        constexpr int ih = ph ? (dh ? 0 : 1) : 0, iw = pw ? (dw ? 0 : 1) : 0;
+                        acc[c][0][0] = Mfma<T>::run(fw[(cq_base(ROLES, R, c) + ih * (pw + 1) + iw) * KPT + sub], xf, acc[c][0][0]);
+                    }
+                });
+            }
         });
         // epilogue, straight from the registers (no bias, activation, residual or statistics in a data gradient; one call per 9 MFMAs, so the LDS transpose
         // and the index arithmetic of epilogue_wave would dominate): pairs rounded to T, the halves swapped between the lane halves as in epilogue_wave --
@@ -396,19 +417,21 @@ __global__ __launch_bounds__((cq_threads<CIN, COUT, MT>()), 2) void conv_strip_q
         const bool pv = jj < p.Wo;
         static_for<4>([&](auto CC) {
             constexpr int c = decltype(CC)::value, ph = c >> 1, pw = c & 1;
-            const long long opix = ((long long)c_img * p.oH + 2 * c_row + ph) * p.oW + 2 * jj + pw;
-            const unsigned ybase = pv ? (unsigned)((opix * p.ypitch + nt * 32) * 2) : 0xffffffffu;
+            if constexpr (cq_owns(ROLES, R, c)) {
+                const long long opix = ((long long)c_img * p.oH + 2 * c_row + ph) * p.oW + 2 * jj + pw;
+                const unsigned ybase = pv ? (unsigned)((opix * p.ypitch + nt * 32) * 2) : 0xffffffffu;
 #pragma unroll
-            for (int gp = 0; gp < 2; ++gp) {
-                u32x4 ov;
+                for (int gp = 0; gp < 2; ++gp) {
+                    u32x4 ov;
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const auto sw = __builtin_amdgcn_permlane32_swap(pack2<T>(acc[c][0][0][8 * gp + 2 * h], acc[c][0][0][8 * gp + 2 * h + 1]),
-                                                                    pack2<T>(acc[c][0][0][8 * gp + 4 + 2 * h], acc[c][0][0][8 * gp + 4 + 2 * h + 1]), false, false);
-                    ov[h] = (unsigned)sw[0];
-                    ov[2 + h] = (unsigned)sw[1];
+                    for (int h = 0; h < 2; ++h) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(pack2<T>(acc[c][0][0][8 * gp + 2 * h], acc[c][0][0][8 * gp + 2 * h + 1]),
+                                                                        pack2<T>(acc[c][0][0][8 * gp + 4 + 2 * h], acc[c][0][0][8 * gp + 4 + 2 * h + 1]), false, false);
+                        ov[h] = (unsigned)sw[0];
+                        ov[2 + h] = (unsigned)sw[1];
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(ov, rsrc_y, pv ? ybase + (unsigned)((gp * 2 + fk) * 16) : 0xffffffffu, 0, 0);
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(ov, rsrc_y, pv ? ybase + (unsigned)((gp * 2 + fk) * 16) : 0xffffffffu, 0, 0);
             }
         });
     };
@@ -422,7 +445,9 @@ __global__ __launch_bounds__((cq_threads<CIN, COUT, MT>()), 2) void conv_strip_q
         const bool more = t + 1 < t_end;
         const bool fresh = more && row == 0;
         if (more && !fresh) issue(false);
-        compute();
+        if constexpr (ROLES == 1) compute(IC<0>{});
+        else if (role == 0) compute(IC<0>{});
+        else compute(IC<1>{});
         if (fresh) {
             __builtin_amdgcn_s_barrier();
             issue(true);
@@ -432,12 +457,12 @@ __global__ __launch_bounds__((cq_threads<CIN, COUT, MT>()), 2) void conv_strip_q
 }
 
 // knob "conv_strip" as above.  Eligibility: the four classes share the geometry (even H, W: checked by the caller), no residual, (du channels, dx channels) =
-// (64, 32), enough du rows per block
+// (64, 32) or (128, 64), enough du rows per block
 static bool cq_plan(const ConvArgs* cls, CsPlan& pl) {
     const long long mode = y3_knob(Y3K_CONV_STRIP);
     const ConvArgs& a = cls[3];
     if (mode == 0 || a.res || a.ups || a.bias) return false;
-    if (!(a.Cin == 64 && a.Cout == 32)) return false;
+    if (!((a.Cin == 64 && a.Cout == 32) || (a.Cin == 128 && a.Cout == 64))) return false;
     for (int i = 0; i < 4; ++i)
         if (!cls[i].x_bytes || !cls[i].w_bytes || !cls[i].y_bytes || cls[i].Ho != a.Ho || cls[i].Wo != a.Wo || cls[i].H != a.H || cls[i].W != a.W) return false;
     if (a.Ho != a.H || a.Wo != a.W) return false;   // even gradient sizes: every class image is du's size
@@ -445,7 +470,7 @@ static bool cq_plan(const ConvArgs* cls, CsPlan& pl) {
     pl.strips = (a.Wo + 63) / 64;
     const long long T = (long long)a.N * pl.strips * a.Ho;
     if (T < 1 || T > 0x3fffffffLL) return false;
-    const int nblk = v7_cu_count() * 4;   // (CqGeom::LDS = 30 KiB, 2 waves per block, two waves per SIMD)
+    const int nblk = v7_cu_count() * (a.Cin == 64 ? 4 : 1);   // (CqGeom::LDS = 30 / 54 KiB, 2 / 8 waves per block, two waves per SIMD)
     if (mode == 1 && T < 24LL * nblk) return false;
     pl.per = mode > 2 ? (int)mode : (int)((T + nblk - 1) / nblk);
     if (pl.per < 1) pl.per = 1;
@@ -472,7 +497,8 @@ template <typename T> int launch_cq(ConvArgs* cls, hipStream_t st) {
     q.a = a;
     g_last_variant = "strip_quad";
     const dim3 grid((unsigned)pl.blocks);
-    hipLaunchKernelGGL((conv_strip_quad_kernel<T, 64, 32, 2>), grid, dim3(cq_threads<64, 32, 2>()), 0, st, q);
+    if (cls[3].Cin == 64) hipLaunchKernelGGL((conv_strip_quad_kernel<T, 64, 32, 2>), grid, dim3(cq_threads<64, 32, 2>()), 0, st, q);
+    else hipLaunchKernelGGL((conv_strip_quad_kernel<T, 128, 64, 2>), grid, dim3(cq_threads<128, 64, 2>()), 0, st, q);
     Y3_CHECK_LAUNCH();
     return 0;
 }
