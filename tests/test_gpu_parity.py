@@ -2384,6 +2384,9 @@ STRIP_CONV_CASES = [
     ("c128_64_ksplit_walk6", (2, 30, 100, 128, 64, 3, 1), {"act": False}, 6),         # the data gradient of a 64 -> 128 layer: two waves split the 72 reduction steps
     ("c128_64_ksplit_odd_rows", (3, 9, 64, 128, 64, 3, 1), {}, 5),                    # odd rows per block: the giver / taker roles of a pair differ from block to block
     ("c128_64_ksplit_sliced_one_row", (1, 11, 70, 128, 64, 3, 1), {"sliced": True}, 3),
+    ("c64_128_s2_walk5", (2, 40, 200, 64, 128, 3, 2), {}, 5),                         # stride 2: two new input rows per output row, even / odd pixel halves
+    ("c64_128_s2_odd_sizes", (3, 37, 131, 64, 128, 3, 2), {"act": False}, 4),         # odd input sizes: the last input row / column only under some taps
+    ("c64_128_s2_tall_sliced", (1, 150, 128, 64, 128, 3, 2), {"sliced": True}, 75),   # one block walks a whole strip: the five-slot ring wraps many times
 ]
 
 

@@ -342,14 +342,15 @@ def test_conv_dispatch_variant_names_and_stat_rows():
             tp, per = tile_px[plain]
             m = bs * ho * ho
             if (cin, cout, k) == (64, 128, 3):
-                # stride 1: the strip kernel with register-resident filters (conv_strip.h, profiles/r03_conv_strip_ab.txt; knob conv_strip = 0: the 128 x 256-pixel
-                # tile of the round-2 sweep); stride 2: profiles/r02_conv_variant_sweep.txt
-                assert plain == ("strip" if s == 1 else "v3_bk64_128x128")
+                # the strip kernel with register-resident filters (conv_strip.h, profiles/r03_conv_strip_ab.txt; knob conv_strip = 0: the tiles of the round-2
+                # sweep, profiles/r02_conv_variant_sweep.txt)
+                assert plain == "strip"
             if plain == "strip":
                 assert rows == 256 * 2, rows   # 256 persistent blocks (one per CU: 8 waves, 144 filter registers per lane), two pixel tiles each
                 assert L.y3_tune_set(b"conv_strip", 0) == 0
                 try:
-                    assert L.y3_conv2d_fwd_variant(C.byref(d), C.byref(x), C.byref(y), 0, 0, name, 64) == 0 and name.value == b"v3_bk32_128x256"
+                    assert L.y3_conv2d_fwd_variant(C.byref(d), C.byref(x), C.byref(y), 0, 0, name, 64) == 0
+                    assert name.value == (b"v3_bk32_128x256" if s == 1 else b"v3_bk64_128x128")
                 finally:
                     L.y3_tune_reset()
                 continue

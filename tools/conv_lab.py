@@ -42,6 +42,7 @@ SHAPES = [
     ("T L2.cv2 dgrad 64->32 @320", 320, 320, 64, 32, 3, 1, False),
     ("T L4.cv2 64->128 @160", 160, 160, 64, 128, 3, 1, False),
     ("T L4.cv2 dgrad 128->64 @160", 160, 160, 128, 64, 3, 1, False),
+    ("T L3 64->128 s2 @320", 320, 320, 64, 128, 3, 2, False),
 ]
 
 

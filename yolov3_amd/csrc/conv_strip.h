@@ -1,6 +1,6 @@
 // conv_strip.h -- included by conv.hip INSIDE its anonymous namespace, after conv_v9.h (shares ConvArgs, Mfma, epilogue_wave, fdiv, ...).
 //
-// 3x3 / stride 1 / pad 1 convolutions with FEW channels on LARGE maps (reference models/yolov3.yaml:17-22, Bottleneck.cv2 of layers 2 and 4 in training
+// 3x3 / pad 1 convolutions (stride 1, and 64 -> 128 at stride 2: layer 3) with FEW channels on LARGE maps (reference models/yolov3.yaml:17-22, Bottleneck.cv2 of layers 2 and 4 in training
 // mode, models/common.py:57-81,150-165, and their data gradients, which are the same convolution with the channel counts swapped):
 // 64 -> 32, 64 -> 128 and 128 -> 64 channels at 320x320 / 160x160.
 //
@@ -24,12 +24,15 @@
 // the KS = 1 forms are bit-identical to the tile kernels (the same products added in the same order).  32 -> 64 itself (18 steps per epilogue call)
 // measured level with the 64 x 256-pixel tile kernel and stays there.
 
-template <int CIN, int COUT, int MT> struct CsGeom {
+template <int CIN, int COUT, int MT, int S = 1> struct CsGeom {
     static constexpr int KS = CIN > 64 ? 2 : 1;                          // waves that split the reduction of one (pixel tile, filter tile)
     static constexpr int PXB = CIN * 2, PP = PXB + 16, SLOTS = PP / 16;   // pixel bytes, pitch, 16-byte slots per pixel (the last one is the pad)
-    static constexpr int SWP = MT * 32, NPX = SWP + 2;                    // strip width, input pixels of a row segment
+    static constexpr int SWP = MT * 32, NPX = S * SWP + (S == 1 ? 2 : 1); // strip width (output pixels), input pixels of a row segment
+    // stride 2: output pixel m reads input pixels 2 m + kw -- the even and the odd input pixels of a row sit in two halves of the row buffer, so that the 32
+    // lanes of a fragment read are consecutive pixels of one half (kw = 0 / 2: even half at m / m + 1, kw = 1: odd half at m)
+    static constexpr int NEVEN = S == 1 ? NPX : SWP + 1;                  // pixels of the first half
     static constexpr int XPIECES = (NPX * PP + 1023) / 1024, XROWB = XPIECES * 1024;
-    static constexpr int NSLOT = 4;                                       // three rows in use + the one being fetched
+    static constexpr int NSLOT = S == 1 ? 4 : 5;                          // three rows in use + the S being fetched
     static constexpr int NT = COUT / 32, NW = MT * NT * KS;
     static constexpr int KPT = CIN / 16, KF = 9 * KPT / KS;               // 16-wide reduction steps per tap / per wave
     static constexpr int EPI = NW * 2048;                                 // the waves' transpose slices (32 pixels x 64 bytes)
@@ -38,12 +41,12 @@ template <int CIN, int COUT, int MT> struct CsGeom {
     static_assert(KF <= 36 && (9 * KPT) % KS == 0, "144 filter registers per lane");
     static constexpr int XPW = (XPIECES + NW - 1) / NW;
 };
-template <int CIN, int COUT, int MT> constexpr int cs_threads() { return CsGeom<CIN, COUT, MT>::NW * 64; }
+template <int CIN, int COUT, int MT> constexpr int cs_threads() { return CsGeom<CIN, COUT, MT>::NW * 64; }   // (the same for both strides)
 
-template <typename T, int CIN, int COUT, int MT>
+template <typename T, int CIN, int COUT, int MT, int S = 1>
 __global__ __launch_bounds__((cs_threads<CIN, COUT, MT>())) void conv_strip_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    typedef CsGeom<CIN, COUT, MT> G;
+    typedef CsGeom<CIN, COUT, MT, S> G;
     constexpr int PP = G::PP, XROWB = G::XROWB, NW = G::NW, NT = G::NT, KF = G::KF, KPT = G::KPT, XPW = G::XPW, KS = G::KS;
     typedef typename Mfma<T>::frag frag;
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -81,9 +84,10 @@ __global__ __launch_bounds__((cs_threads<CIN, COUT, MT>())) void conv_strip_kern
 #pragma unroll
     for (int i = 0; i < XPW; ++i) {
         const int e = (i * NW + wv) * 64 + lane;
-        const int j = e / G::SLOTS, slot = e - j * G::SLOTS;
-        xj[i] = (slot < G::SLOTS - 1 && j < G::NPX) ? j : -1;      // pad slots and the tail of the last request fetch nothing
-        xoffl[i] = ((j - 1) * p.xpitch + slot * 8) * 2;            // relative to input pixel (row, w0)
+        const int pos = e / G::SLOTS, slot = e - pos * G::SLOTS;   // position in the row buffer
+        const int j = S == 1 ? pos : (pos < G::NEVEN ? 2 * pos : 2 * (pos - G::NEVEN) + 1);   // input pixel of the segment (stride 2: even half, then odd half)
+        xj[i] = (slot < G::SLOTS - 1 && pos < G::NPX) ? j : -1;    // pad slots and the tail of the last request fetch nothing
+        xoffl[i] = ((j - 1) * p.xpitch + slot * 8) * 2;            // relative to input pixel (row, w0 S)
     }
     // ---- fragment address of the wave's pixel tile: pixel mt 32 + frow of the strip, k-group fk; (row buffer, kw, 16-step of the tap) are added per read
     const unsigned char* xfrag = smem + G::XBASE + (mt * 32 + frow) * PP + fk * 16;
@@ -102,9 +106,9 @@ __global__ __launch_bounds__((cs_threads<CIN, COUT, MT>())) void conv_strip_kern
     int hp = 0;
     int c_img = 0, c_strip = 0, c_row = 0;                    // the output row being computed (one behind the request cursor)
     int n_img = 0, n_strip = 0, n_row = 0;
-    auto take = [&]() { const int s = hp; hp = (hp + 1) & 3; return s; };
+    auto take = [&]() { const int s = hp; hp = hp + 1 == G::NSLOT ? 0 : hp + 1; return s; };
 
-    auto request_row = [&](int hin, int slot, int w0) {
+    auto request_row = [&](int hin, int slot, int w0) {   // w0: first INPUT column under the strip (output column x stride)
         const bool rowok = (unsigned)hin < (unsigned)p.H;
         const long long xbase = (((long long)img * p.H + hin) * p.W + w0) * p.xpitch * 2;
 #pragma unroll
@@ -119,15 +123,19 @@ __global__ __launch_bounds__((cs_threads<CIN, COUT, MT>())) void conv_strip_kern
     };
     // requests of output row t (the cursor's): a fresh strip needs three rows (only ever called when no row buffer is in use), a continued one the new bottom row
     auto issue = [&](bool fresh) {
-        const int w0 = strip * G::SWP;
+        const int w0 = strip * G::SWP * S;
         if (fresh) {
             nxt[0] = take(); nxt[1] = take(); nxt[2] = take();
-            request_row(row - 1, nxt[0], w0);
-            request_row(row, nxt[1], w0);
-            request_row(row + 1, nxt[2], w0);
-        } else {
+            request_row(row * S - 1, nxt[0], w0);
+            request_row(row * S, nxt[1], w0);
+            request_row(row * S + 1, nxt[2], w0);
+        } else if (S == 1) {
             nxt[0] = nxt[1]; nxt[1] = nxt[2]; nxt[2] = take();
             request_row(row + 1, nxt[2], w0);
+        } else {   // stride 2: the bottom row of the previous output row is the top row of this one
+            nxt[0] = nxt[2]; nxt[1] = take(); nxt[2] = take();
+            request_row(row * 2, nxt[1], w0);
+            request_row(row * 2 + 1, nxt[2], w0);
         }
         n_img = img; n_strip = strip; n_row = row;
         if (++row == p.Ho) {
@@ -150,7 +158,8 @@ __global__ __launch_bounds__((cs_threads<CIN, COUT, MT>())) void conv_strip_kern
         auto ld = [&](auto J) -> frag {
             constexpr int j = KSI * KF + decltype(J)::value;
             constexpr int tap = j / KPT, kh = tap / 3, kw = tap % 3, sub = j % KPT;
-            return *(const frag*)(xr[kh] + kw * PP + sub * 32);
+            constexpr int px = S == 1 ? kw : (kw == 1 ? G::NEVEN : kw / 2);   // buffer position of the tap relative to the lane's pixel
+            return *(const frag*)(xr[kh] + px * PP + sub * 32);
         };
         static_for<D>([&](auto J) { xf[decltype(J)::value] = ld(J); });
         static_for<KF>([&](auto J) {
@@ -210,15 +219,15 @@ struct CsPlan {
 static bool cs_plan(const ConvArgs& a, CsPlan& pl) {
     const long long mode = y3_knob(Y3K_CONV_STRIP);
     if (mode == 0 || a.ups || a.res) return false;
-    if (a.ks != 3 || a.stride != 1 || a.pad != 1 || a.dil_shift != 0 || a.ntaps != 9 || a.omul != 1 || a.ooh != 0 || a.oow != 0) return false;
-    if (a.H != a.Ho || a.W != a.Wo || a.oH != a.Ho || a.oW != a.Wo) return false;
-    if (!((a.Cin == 64 && a.Cout == 32) || (a.Cin == 64 && a.Cout == 128) || (a.Cin == 128 && a.Cout == 64))) return false;
+    if (a.ks != 3 || (a.stride != 1 && a.stride != 2) || a.pad != 1 || a.dil_shift != 0 || a.ntaps != 9 || a.omul != 1 || a.ooh != 0 || a.oow != 0) return false;
+    if (a.Ho != (a.H - 1) / a.stride + 1 || a.Wo != (a.W - 1) / a.stride + 1 || a.oH != a.Ho || a.oW != a.Wo) return false;
+    if (a.stride == 1 ? !((a.Cin == 64 && a.Cout == 32) || (a.Cin == 64 && a.Cout == 128) || (a.Cin == 128 && a.Cout == 64)) : !(a.Cin == 64 && a.Cout == 128)) return false;
     if (!a.x_bytes || !a.w_bytes || !a.y_bytes) return false;
     for (int t = 0; t < 9; ++t)
         if (a.tdh[t] != t / 3 || a.tdw[t] != t % 3) return false;
     pl.mt = 2;
     const int swp = pl.mt * 32;
-    pl.strips = (a.W + swp - 1) / swp;
+    pl.strips = (a.Wo + swp - 1) / swp;
     const long long T = (long long)a.N * pl.strips * a.Ho;
     if (T < 1 || T > 0x3fffffffLL) return false;
     // blocks a CU holds (CsGeom::LDS = 44 / 56 / 104 KiB for 64 -> 32 / 64 -> 128 / 128 -> 64; 2 / 8 / 8 waves per block, two waves per SIMD: 144 filter
@@ -246,7 +255,8 @@ template <typename T> int launch_cs(ConvArgs& a, hipStream_t st) {
     g_last_variant = "strip";
     if (a.dry) return 0;
     const dim3 grid((unsigned)pl.blocks);
-    if (a.Cin == 128) hipLaunchKernelGGL((conv_strip_kernel<T, 128, 64, 2>), grid, dim3(cs_threads<128, 64, 2>()), 0, st, a);
+    if (a.stride == 2) hipLaunchKernelGGL((conv_strip_kernel<T, 64, 128, 2, 2>), grid, dim3(cs_threads<64, 128, 2>()), 0, st, a);
+    else if (a.Cin == 128) hipLaunchKernelGGL((conv_strip_kernel<T, 128, 64, 2>), grid, dim3(cs_threads<128, 64, 2>()), 0, st, a);
     else if (a.Cout == 32) hipLaunchKernelGGL((conv_strip_kernel<T, 64, 32, 2>), grid, dim3(cs_threads<64, 32, 2>()), 0, st, a);
     else hipLaunchKernelGGL((conv_strip_kernel<T, 64, 128, 2>), grid, dim3(cs_threads<64, 128, 2>()), 0, st, a);
     Y3_CHECK_LAUNCH();
