@@ -232,7 +232,7 @@ BASELINE_CONV_CASES = [
     ("L10cv1_1024_512_20", (32, 20, 20, 1024, 512, 1, 1), {}, "v3_bk64_128x128"),
     ("L6cv1_256_128_80", (32, 80, 80, 256, 128, 1, 1), {}, "v3_bk32_128x128"),
     ("L4cv2_64_128_160", (32, 160, 160, 64, 128, 3, 1), {"residual": True}, "v3_bk32_128x256"),
-    ("L3_64_128_s2_320", (32, 320, 320, 64, 128, 3, 2), {}, "v3_bk64_128x128"),
+    ("L3_64_128_s2_320", (32, 320, 320, 64, 128, 3, 2), {}, "strip"),   # conv_strip.h, stride-2 form (round 3)
     ("head255_20", (32, 20, 20, 1024, 256, 1, 1), {"cout_real": 255, "act": False}, "v3_bk64_128x128"),
     ("head255_80", (32, 80, 80, 256, 256, 1, 1), {"cout_real": 255, "act": False}, "v3_bk32_128x128"),
     ("head1110_40_c5", (8, 40, 40, 1024, 1112, 1, 1), {"cout_real": 1110, "act": False}, None),
