@@ -64,7 +64,8 @@ const char* y3_last_error(void);
  * 6 / 15 force a tile variant), "conv_v7" (1 auto, 0 off, 2 every eligible shape), "v7_grid" (0 auto, N > 0 grid cap, -1 whole tiles,
  * -2 stream-K), "v7_gc" (0 auto, 1 / 2 / 4 / 8), "conv_ahead" (3 / 2: K-steps the LDS-DMA requests run ahead), "bn_nt_bytes" (threshold of
  * the non-temporal BatchNorm passes), "wgrad" (0 per-shape, 2 128-tile, 3 256-tile, 4 direct fp32), "wgrad_xcd" (0..3), "dgrad_quad"
- * (1 / 0), "spp_direct" (0 / 1), "conv_v9" (1 auto, 0 off, 2 every eligible shape), "v9_mp" / "v9_vp" (0 auto; forced tile width / valid pixels per tile: tests).  The environment variable Y3_TUNE="key=value,key=value" is read once when the library is first used.
+ * (1 / 0), "spp_direct" (0 / 1), "conv_v9" (1 auto, 0 off, 2 every eligible shape), "v9_mp" / "v9_vp" (0 auto; forced tile width / valid pixels per tile: tests), "wgrad_strip" / "conv_strip" (1 the strip-walking kernels of csrc/wgrad_strip.h / conv_strip.h on the
+ * small-channel 3x3 layers, 0 off, 2 also small launches, N > 2: N rows per block -- tests).  The environment variable Y3_TUNE="key=value,key=value" is read once when the library is first used.
  * Process-wide, not stream-ordered: set a knob before enqueueing the launches it should affect. */
 int y3_tune_set(const char* key, int64_t value); /* 0, or -1 for an unknown key */
 int64_t y3_tune_get(const char* key);            /* INT64_MIN for an unknown key */
@@ -352,7 +353,8 @@ int y3_conv2d_dgrad_s2(int32_t dtype, const y3_tensor* du, const void* packed4, 
  * (dtype, ksize, stride, cin, cout = padded sizes of x / du); dw is (cout_real, cin_real, k, k) fp32, overwritten. */
 size_t y3_conv2d_wgrad_workspace_bytes(const y3_conv_desc* desc, const y3_tensor* x);
 /* dry run: the geometry y3_conv2d_wgrad launches for (desc, x) -- tile edge (128 / 256; 0 = direct fp32 kernel), number of pixel
- * slices (split-K over n*ho*wo) and whether a slice's tiles are grouped per XCD (knob "wgrad_xcd") */
+ * slices (split-K over n*ho*wo) and whether a slice's tiles are grouped per XCD (knob "wgrad_xcd"); tile 3 = the 3x3 strip kernel (csrc/wgrad_strip.h),
+ * slices = its persistent blocks */
 int y3_conv2d_wgrad_plan(const y3_conv_desc* desc, const y3_tensor* x, int32_t* tile, int64_t* slices, int32_t* xcd_grouped);
 int y3_conv2d_wgrad(const y3_conv_desc* desc, const y3_tensor* x, const y3_tensor* du, int32_t cout_real, int32_t cin_real,
                     float* dw_oihw, float* dbias /* may be NULL */, void* workspace, size_t workspace_bytes, void* stream);
