@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define Y3_ABI_VERSION 1
+#define Y3_ABI_VERSION 2
 
 typedef enum { Y3_F16 = 0, Y3_BF16 = 1, Y3_F32 = 2, Y3_U8 = 3 } y3_dtype;
 typedef enum { Y3_ACT_NONE = 0, Y3_ACT_SILU = 1 } y3_act;

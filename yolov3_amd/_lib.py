@@ -11,6 +11,7 @@ LIB_PATH = Path(os.environ["Y3_LIB"]) if os.environ.get("Y3_LIB") else _PKG / "l
 
 Y3_F16, Y3_BF16, Y3_F32, Y3_U8 = 0, 1, 2, 3
 Y3_ACT_NONE, Y3_ACT_SILU = 0, 1
+ABI_VERSION = 2   # include/yolov3_hip.h::Y3_ABI_VERSION (2: round-3 export set -- tune / SyncBN / TTA / wgrad_plan added, y3_bn_act_bwd_apply takes sums + 2C)
 Y3_ALGO_AUTO, Y3_ALGO_MFMA, Y3_ALGO_DIRECT = 0, 1, 2
 
 
@@ -218,8 +219,8 @@ def lib() -> C.CDLL:
         except AttributeError as e:
             raise Y3Error(f"{LIB_PATH} does not export {name}; rebuild with `python -m yolov3_amd.build --force`") from e
         fn.restype, fn.argtypes = res, args
-    if handle.y3_abi_version() != 1:
-        raise Y3Error(f"ABI version mismatch: library reports {handle.y3_abi_version()}, bindings expect 1")
+    if handle.y3_abi_version() != ABI_VERSION:
+        raise Y3Error(f"ABI version mismatch: library reports {handle.y3_abi_version()}, bindings expect {ABI_VERSION}")
     _lib = handle
     return handle
 

@@ -463,14 +463,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_v7_kernel(const ConvArgs p)
 #endif
 }
 
-static int v7_cu_count() {
-    static const int n = [] {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        return cus;
-    }();
-    return n;
-}
+static int v7_cu_count() { return y3_cu_count(); }
 
 // patch pieces per wave for an image width (rows needed: 256 + 2 W + 2, one piece = 16 rows, 8 waves): 0 = too wide for v7
 static int v7_xp(int W) {

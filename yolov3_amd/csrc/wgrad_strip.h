@@ -305,7 +305,7 @@ static bool strip_plan(const y3_conv_desc* d, int n, int h, int w, int cout_real
     if (T > 0x3fffffffLL || T < 1) return false;
     const int halves = d->cout / 64;
     const int per_cu = d->cin == 32 ? (d->stride == 1 ? 3 : 2) : (d->stride == 1 ? 2 : 1);   // blocks the LDS of a CU holds (StripGeom::LDS)
-    int nblk = 256 * per_cu / halves;   // per filter half
+    int nblk = y3_cu_count() * per_cu / halves;   // per filter half
     if (nblk < 64) nblk = 64;
     if (mode == 1 && T < 16LL * nblk) return false;   // at least 16 K-steps per block
     pl.per = mode > 2 ? (int)mode : (int)((T + nblk - 1) / nblk);   // (knob > 2: that many K-steps per block -- tests walk strip / image boundaries inside a block)

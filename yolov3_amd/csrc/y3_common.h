@@ -118,6 +118,15 @@ static inline y3_divisor y3_make_divisor(int d) {
 Y3_DEV int y3_fdiv(int n, y3_divisor d) { return d.mul ? (int)(__umulhi((unsigned)n, d.mul) >> (d.sh - 1)) : n; }
 
 static inline int y3_ceil_div(int a, int b) { return (a + b - 1) / b; }
+// compute units of the current device (persistent grids and tile plans are sized from it: 256 on a whole MI355X, fewer on a partition)
+static inline int y3_cu_count() {
+    static const int n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        return cus;
+    }();
+    return n;
+}
 static inline size_t y3_round_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 
 // packed filter geometry (see conv.hip): rows padded to 128 filters, K padded to 64

@@ -40,7 +40,8 @@ class _LossFn(torch.autograd.Function):
         ptrs = (C.c_void_p * len(preds))(*[t.data_ptr() for t in preds])
         check(L.y3_loss_fwd(C.byref(P), ops.dtype_code(dtype), ptrs, tg.data_ptr() if nt else None, nt, out4.data_ptr(), ws.data_ptr(), need, ops.stream_ptr()), "y3_loss_fwd")
         ctx.crit, ctx.P, ctx.ws, ctx.tg, ctx.need = crit, P, ws, tg, need
-        crit._last_fwd = (P, ops.dtype_code(dtype), nt, ws, need)   # ComputeLoss(autobalance=True) reads the per-level objectness losses out of it
+        if crit.autobalance:   # ComputeLoss(autobalance=True) reads the per-level objectness losses out of the workspace right after this call and drops it
+            crit._last_fwd = (P, ops.dtype_code(dtype), nt, ws, need)
         ctx.save_for_backward(*preds)
         ctx.mark_non_differentiable(out4)
         return out4[0:1].clone(), out4
@@ -112,7 +113,7 @@ class ComputeLoss:
             # utils/loss.py:171-175: every level's weight moves towards 1 / its objectness loss (after this call's loss was formed with the old
             # weights), then all are normalised by the stride-16 level's.  The reference pays one host sync per level (`obji.item()`); here one
             # read-back of nl floats per call
-            P, dcode, nt, ws, need = self._last_fwd
+            (P, dcode, nt, ws, need), self._last_fwd = self._last_fwd, None   # (the criterion does not pin the workspace beyond this read)
             obj = torch.empty(self.nl, dtype=torch.float32, device=ws.device)
             check(_lib.lib().y3_loss_level_obj(C.byref(P), dcode, nt, ws.data_ptr(), need, obj.data_ptr(), ops.stream_ptr()), "y3_loss_level_obj")
             for i, oi in enumerate(obj.tolist()):

@@ -137,13 +137,18 @@ class GradBuckets:
         base = tensors[0]._base
         if base is None or base.dim() != 1 or base.dtype != torch.float32:
             return None
-        lo, hi = None, None
+        lo, hi, covered = None, None, 0
         for t in tensors:
             if t._base is not base or not t.is_contiguous() or t.dtype != torch.float32:
                 return None
             o = t.storage_offset() - base.storage_offset()
             lo = o if lo is None else min(lo, o)
             hi = o + t.numel() if hi is None else max(hi, o + t.numel())
+            covered += (t.numel() + 63) // 64 * 64   # the arena hands out 64-element-aligned slices (TrainPlan.grad_alloc)
+        # the members must TILE [lo, hi): a range that merely spans them could swallow an arena slice that has not been handed over yet (a kernel
+        # may still be writing it, and its own bucket would average it a second time) -- only the last member's pad may be missing
+        if not (hi - lo <= covered < hi - lo + 64):
+            return None
         return base, lo, hi
 
     def _reduce(self, flat):

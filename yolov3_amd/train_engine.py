@@ -538,6 +538,7 @@ class TrainPlan:
             else:
                 raise NotImplementedError(type(k).__name__)
         self.params = list(model.parameters())
+        self.param_ids = tuple(id(p) for p in self.params)   # run_model_train rebuilds the plan when a Parameter object is replaced
         self.x_nchw = None
         self.x_version = 0
 
@@ -798,6 +799,11 @@ def run_model_train(model, x: torch.Tensor):
         while True:
             key = ("train", n, h, w, dtype, x.device.index, slot)
             cand = pc.get(key)
+            if cand is not None and not cand.outstanding and cand.param_ids != tuple(id(p) for p in model.parameters()):
+                # a Parameter OBJECT was replaced since the plan captured them (re-created head, pruning, `m.conv.weight = nn.Parameter(..)`): the
+                # plan's backward would return None for it -- rebuild (in-place updates keep the ids and re-use the plan: banks are re-packed per forward)
+                del pc.plans[key]
+                cand = None
             if cand is None or not cand.outstanding:
                 plan = cand
                 break
