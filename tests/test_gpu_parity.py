@@ -2092,6 +2092,109 @@ def test_conv_wgrad_benchmark_shapes_fp16(dev, name, shape, plan):
     assert e_w < 2e-5, f"{name}: wgrad {e_w:.2e}"
 
 
+BENCH_TRAIN_CONV_CASES = [
+    # name, kind, (n, h, w, cin, cout, k, s) of the FORWARD layer, variant the dispatcher must pick for that launch.  kind: "fwd_stats" = the training
+    # forward (no activation, BatchNorm statistics rows from the epilogue), "dgrad" = the data gradient through the forward kernel on the flipped bank
+    # (accumulating into dx through the residual port), "dgrad_s2" = the four parity classes of a stride-2 data gradient
+    ("L8cv2_fwd_stats", "fwd_stats", (64, 40, 40, 256, 512, 3, 1), "v10"),
+    ("L10cv2_fwd_stats", "fwd_stats", (64, 20, 20, 512, 1024, 3, 1), "v10"),
+    ("L6cv2_fwd_stats", "fwd_stats", (64, 80, 80, 128, 256, 3, 1), "v10"),
+    ("L8cv2_dgrad", "dgrad", (64, 40, 40, 256, 512, 3, 1), "v10"),
+    ("L10cv2_dgrad", "dgrad", (64, 20, 20, 512, 1024, 3, 1), "v10"),
+    ("L4cv2_fwd_stats", "fwd_stats", (64, 160, 160, 64, 128, 3, 1), "strip"),
+    ("L3_s2_fwd_stats", "fwd_stats", (64, 320, 320, 64, 128, 3, 2), "strip"),
+    ("L2cv2_dgrad", "dgrad", (64, 320, 320, 32, 64, 3, 1), "strip"),
+    ("L4cv2_dgrad", "dgrad", (64, 160, 160, 64, 128, 3, 1), "strip"),
+    ("L1_dgrad_s2", "dgrad_s2", (64, 640, 640, 32, 64, 3, 2), "strip_quad"),      # dx = 64 x 640 x 640 x 32 = 1.68 GB: the tensor closest to a descriptor's 2 GiB reach
+    ("L3_dgrad_s2", "dgrad_s2", (64, 320, 320, 64, 128, 3, 2), "strip_quad"),
+    ("L5_dgrad_s2", "dgrad_s2", (64, 160, 160, 128, 256, 3, 2), "v3_quad"),
+]
+
+
+@pytest.mark.parametrize("name,kind,shape,variant", BENCH_TRAIN_CONV_CASES, ids=[c[0] for c in BENCH_TRAIN_CONV_CASES])
+def test_conv_train_launches_benchmark_shapes_fp16(dev, name, kind, shape, variant):
+    """The forward-with-statistics and data-gradient conv launches of the benchmarked train step at ITS shapes (batch 64; round-3 review: only the filter
+    gradients were covered there): the dispatched kernel variant is asserted, a subset of output channels spread over the MFMA blocks / waves of a filter
+    tile is compared with fp32 conv2d on the same rounded operands over ALL pixels (cost ~ subset / channels of the layer, image chunks bound the host
+    memory), and the statistics rows summed in fp64 equal the statistics of the stored tensor."""
+    _lib, ops = _ops()
+    n, h, w, cin, cout, k, s = shape
+    dtype = torch.float16
+    ho, wo = (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
+    g = torch.Generator(device=dev).manual_seed(21)
+    gc = torch.Generator().manual_seed(22)
+    wt = (torch.randn(cout, cin, k, k, generator=gc) / math.sqrt(cin * k * k)).to(dtype).float()
+    chunk = 4 if h >= 320 else 8
+
+    def pick(c):
+        return sorted({0, 37 % c, 70 % c, (c // 2 + 2) % c, (c - 89) % c, c - 1})
+
+    if kind == "fwd_stats":
+        xv = ops.View.alloc(n, h, w, cin, dtype, dev)
+        xv.buf.normal_(generator=g)
+        filt = ops.pack_filter(wt.to(dev), cout, cin, dtype)
+        yv = ops.View.alloc(n, ho, wo, cout, dtype, dev)
+        yv.buf.fill_(float("nan"))
+        rows = ops.conv2d_stats_rows(xv, yv, k, s)
+        buf = torch.full((rows * 2 * cout,), float("nan"), device=dev)
+        assert ops.conv2d_stats(xv, filt, torch.zeros(cout, device=dev), yv, k, s, buf, rows) == rows
+        assert ops.last_conv_variant() == variant, f"{name}: dispatcher picked {ops.last_conv_variant()}"
+        torch.cuda.synchronize()
+        sel = pick(cout)
+        xn, yn = xv.as_nhwc(), yv.as_nhwc()
+        bad, worst = 0, 0.0
+        for i0 in range(0, n, chunk):
+            ref = F.conv2d(xn[i0 : i0 + chunk].permute(0, 3, 1, 2).float().cpu(), wt[sel], None, stride=s, padding=k // 2)
+            got = yn[i0 : i0 + chunk][..., sel].permute(0, 3, 1, 2).float().cpu()
+            err = (got - ref).abs()
+            bad += (err > 2.0**-10 * ref.abs() + 2e-3).sum().item()
+            worst = max(worst, err.max().item())
+        assert bad == 0, f"{name}: {bad} outputs outside tolerance, max abs err {worst:.3g}"
+        y2 = yn.reshape(-1, cout)
+        s0 = torch.zeros(cout, dtype=torch.float64, device=dev)
+        s1 = torch.zeros(cout, dtype=torch.float64, device=dev)
+        a0 = torch.zeros(cout, dtype=torch.float64, device=dev)
+        step = 1 << 18
+        for r0 in range(0, y2.shape[0], step):
+            u = y2[r0 : r0 + step].double()
+            s0 += u.sum(0); s1 += (u * u).sum(0); a0 += u.abs().sum(0)
+        assert torch.isfinite(s0).all(), "the output holds a non-finite value (an unwritten pixel)"
+        tot = buf.view(rows, cout, 2).double().sum(0)
+        assert torch.isfinite(tot).all(), "a statistics row was not written"
+        assert (tot[:, 0] - s0).abs().max().item() <= 1e-5 * a0.max().item()
+        assert (tot[:, 1] - s1).abs().max().item() <= 1e-5 * s1.max().item()
+        return
+
+    # data gradients: du (n, ho, wo, cout) -> dx (n, h, w, cin) = conv_transpose(du, w)
+    gv = ops.View.alloc(n, ho, wo, cout, dtype, dev)
+    gv.buf.normal_(generator=g)
+    gx = ops.View.alloc(n, h, w, cin, dtype, dev)
+    sel = pick(cin)
+    if kind == "dgrad":
+        gx.buf.normal_(generator=g)   # what the fan-out already accumulated: the launch adds to it through the residual port
+        base = gx.as_nhwc()[..., sel].float().cpu()
+        filt_d = ops.pack_filter_dgrad(wt.to(dev), cout, cin, dtype)
+        ops.conv2d(gv, filt_d, torch.zeros(cin, device=dev), gx, k, 1, act=False, residual=gx, in_dilation=s)
+    else:
+        gx.buf.fill_(float("nan"))
+        base = None
+        ops.conv2d_dgrad_s2(wt.to(dev), gv, gx, accumulate=False)
+    assert ops.last_conv_variant() == variant, f"{name}: dispatcher picked {ops.last_conv_variant()}"
+    torch.cuda.synchronize()
+    gn, xn = gv.as_nhwc(), gx.as_nhwc()
+    bad, worst = 0, 0.0
+    for i0 in range(0, n, chunk):
+        du = gn[i0 : i0 + chunk].permute(0, 3, 1, 2).float().cpu()
+        ref = F.conv_transpose2d(du, wt[:, sel], None, stride=s, padding=k // 2, output_padding=(h - ((ho - 1) * s - 2 * (k // 2) + k), w - ((wo - 1) * s - 2 * (k // 2) + k)))
+        if base is not None:
+            ref = ref + base[i0 : i0 + chunk].permute(0, 3, 1, 2)
+        got = xn[i0 : i0 + chunk][..., sel].permute(0, 3, 1, 2).float().cpu()
+        err = (got - ref).abs()
+        bad += (~(err <= 2.0**-10 * ref.abs() + 4e-3)).sum().item()   # (NaN = an unwritten pixel counts as bad)
+        worst = max(worst, err.max().item())
+    assert bad == 0, f"{name}: {bad} gradient elements outside tolerance, max abs err {worst:.3g}"
+
+
 def _bn_reference(u, dy, gamma, beta, eps, act, res):
     """fp64 torch reference of train-mode act(bn(u)) (+ res) and its backward (du, dgamma, dbeta), NHWC (M, C) operands"""
     u = u.double().requires_grad_(True)
@@ -2369,6 +2472,100 @@ def test_conv_v9_statistics_rows(dev, tune):
     assert torch.isfinite(tot).all(), "a statistics row was not written"
     assert (tot[:, 0] - u.sum(0)).abs().max().item() <= 1e-5 * u.abs().sum(0).max().item()
     assert (tot[:, 1] - (u * u).sum(0)).abs().max().item() <= 1e-5 * (u * u).sum(0).max().item()
+
+
+# ------------------------------------------------------------------------------------------------ conv v10 (persistent, register-resident filter fragments)
+V10_CASES = [
+    # name, (n,h,w,cin,cout,k,s), kwargs, knobs (v10_mp cap, v10_blocks per filter tile; 0 = the host's plan)
+    ("plan_20x20_res", (8, 20, 20, 256, 512, 3, 1), {"residual": True}, (0, 0)),                  # 100 column blocks: 16 blocks per filter tile, runs of 6 / 7
+    ("two_blocks_walk_5_tiles", (6, 20, 20, 64, 256, 3, 1), {}, (0, 2)),                          # runs of 38 / 37: bodies 8 / 7, tiles cross rows and images, 2 channel blocks
+    ("tiny_images_one_cb", (40, 7, 5, 32, 256, 3, 1), {"residual": True}, (7, 3)),               # 35-pixel images, ncb = 1 (every channel block is a tile's last), ragged tail
+    ("odd_cb_parity", (3, 21, 19, 96, 256, 3, 1), {"sliced": True}, (6, 2)),                      # 3 channel blocks: tiles start in alternating patch buffers
+    ("w80_two_requests", (2, 80, 80, 64, 256, 3, 1), {}, (7, 0)),                                 # 36+ patch pieces: two request slots per tap
+    ("one_column_block_tiles", (1, 40, 40, 128, 512, 3, 1), {"act": False}, (0, 50)),             # 32 valid pixels in a 192-pixel body
+    ("one_block_walks_all", (2, 13, 26, 160, 256, 3, 1), {}, (0, 1)),                             # 22 column blocks (the last with 4 pixels) in one block: 8 + 7 + 7, 5 channel blocks
+    ("w160_mp6", (1, 160, 160, 32, 256, 3, 1), {"residual": True}, (6, 0)),
+    ("four_filter_tiles", (4, 20, 20, 128, 1024, 3, 1), {"residual": True}, (0, 0)),
+    ("mixed_7_6_runs", (13, 20, 20, 64, 512, 3, 1), {}, (0, 25)),                                 # 163 column blocks over 25 blocks: runs of 7 / 6 -> both bodies in one launch
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name,shape,kw,knobs", V10_CASES, ids=[c[0] for c in V10_CASES])
+def test_conv_v10_vs_fp32_reference(dev, tune, dtype, name, shape, kw, knobs):
+    """conv_v10.h (persistent blocks over 32-pixel column blocks, bodies of 6 / 7 / 8 column blocks, filter fragments by register loads from the
+    fragment-ordered copy of the bank, the next tile's first patch requested under the last channel block) against fp32 conv2d on the same rounded
+    operands: tiles that cross rows and image boundaries, edge taps, 1 .. 8 channel blocks (odd counts flip the patch-buffer parity from tile to
+    tile), one and two request slots per tap, single-column-block tiles, ragged tails, residual / sliced outputs; repeated launches bit-identical."""
+    mp, blocks = knobs
+    tune("conv_v10", 2)
+    tune("v10_mp", mp)
+    tune("v10_blocks", blocks)
+    out, ref = run_conv(dev, dtype, *shape, algo=1, ws=True, expect="v10", repeat=2, **kw)
+    _conv_tol_check(name, dtype, out, ref)
+
+
+def test_conv_v10_statistics_rows(dev, tune):
+    """BatchNorm statistics rows from the v10 epilogue (four rows per tile: one per 64-pixel pass, zero rows for the passes a narrower body does not
+    have; only valid pixels counted): their fp64 sum equals the statistics of the stored tensor."""
+    _lib, ops = _ops()
+    tune("conv_v10", 2)
+    tune("v10_blocks", 3)
+    n, h, w, cin, cout, k, s = 5, 20, 20, 64, 256, 3, 1
+    dtype = torch.float16
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(n, cin, h, w, generator=g).to(dtype)
+    wt = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    xv = ops.View.alloc(n, h, w, cin, dtype, dev)
+    ops.nchw_to_nhwc(x.to(dev), xv)
+    filt = ops.pack_filter(wt.to(dev), cout, cin, dtype)
+    zb = torch.zeros(cout, device=dev)
+    y1 = ops.View.alloc(n, h, w, cout, dtype, dev)
+    rows = ops.conv2d_stats_rows(xv, y1, k, s)
+    assert rows == 9 * 4, rows   # 63 column blocks over 3 blocks: runs of 21 = 3 tiles of 7
+    buf = torch.full((rows * 2 * cout,), float("nan"), device=dev)
+    assert ops.conv2d_stats(xv, filt, zb, y1, k, s, buf, rows) == rows and ops.last_conv_variant() == "v10"
+    torch.cuda.synchronize()
+    u = y1.as_nhwc().double().cpu().reshape(-1, cout)
+    tot = buf.view(rows, cout, 2).double().sum(0).cpu()
+    assert torch.isfinite(tot).all(), "a statistics row was not written"
+    assert (tot[:, 0] - u.sum(0)).abs().max().item() <= 1e-5 * u.abs().sum(0).max().item()
+    assert (tot[:, 1] - (u * u).sum(0)).abs().max().item() <= 1e-5 * (u * u).sum(0).max().item()
+    xr = x.float()
+    ref = F.conv2d(xr, wt.to(dtype).float(), None, padding=1)
+    assert (y1.as_nhwc().float().cpu().permute(0, 3, 1, 2) - ref).abs().max().item() < 2e-2
+
+
+def test_pack_filter_fragment_copy(dev):
+    """Every packer writes the fragment-ordered copy conv_v10.h reads behind the row-major bank of a 3x3 layer with rows % 256 == 0 and channels % 32 == 0
+    (y3_frag_index): element (row, tap, channel) of the bank sits at ((((row / 64) nk + 9 cb + tap) 4 + 2 kk + a) 64 + 32 fk + row % 32) 8 + e."""
+    _lib, ops = _ops()
+    cout, cin = 256, 64
+    g = torch.Generator().manual_seed(3)
+    wt = torch.randn(cout, cin, 3, 3, generator=g)
+    for dtype in (torch.float16, torch.bfloat16):
+        rows_kpad = cout * 9 * cin
+        assert ops.packed_filter_elems(cout, cin, 3) == 2 * rows_kpad and ops.packed_filter_elems(cout, cin, 1) == cout * cin and ops.packed_filter_elems(128, cin, 3) == 128 * 9 * cin
+        bank = ops.pack_filter(wt.to(dev), cout, cin, dtype)
+        std = bank[:rows_kpad].view(cout, 9, cin).cpu()
+        assert torch.equal(std, wt.permute(0, 2, 3, 1).reshape(cout, 9, cin).to(dtype))
+        nk = 9 * (cin // 32)
+        frag = bank[rows_kpad:].view(cout // 64, nk, 2, 2, 2, 32, 8).cpu()   # [tile-wave][K-step = 9 cb + tap][kk][a][fk][row][e]
+        want = std.view(cout // 64, 2, 32, 9, cin // 32, 2, 2, 8)            # [tw][a][row][tap][cb][kk][fk][e]
+        want = want.permute(0, 4, 3, 5, 1, 6, 2, 7).reshape(cout // 64, nk, 2, 2, 2, 32, 8)
+        assert torch.equal(frag, want)
+        f2, d2 = ops.pack_filter_pair(wt.to(dev), cout, cin, dtype)
+        assert torch.equal(f2.view(torch.int16), bank.view(torch.int16))
+        assert torch.equal(d2.view(torch.int16), ops.pack_filter_dgrad(wt.to(dev), cout, cin, dtype).view(torch.int16))
+        # the data-gradient bank of a 256 -> 256 layer carries the copy too (rows = cin)
+        w2 = torch.randn(256, 256, 3, 3, generator=g)
+        dg = ops.pack_filter_dgrad(w2.to(dev), 256, 256, dtype)
+        assert dg.numel() == 2 * 256 * 9 * 256
+        dstd = dg[: 256 * 9 * 256].view(256, 9, 256).cpu()
+        assert torch.equal(dstd, w2.flip(2, 3).permute(1, 2, 3, 0).reshape(256, 9, 256).to(dtype))
+        dfrag = dg[256 * 9 * 256 :].view(4, 72, 2, 2, 2, 32, 8).cpu()
+        dwant = dstd.view(4, 2, 32, 9, 8, 2, 2, 8).permute(0, 4, 3, 5, 1, 6, 2, 7).reshape(4, 72, 2, 2, 2, 32, 8)
+        assert torch.equal(dfrag, dwant)
 
 
 # ------------------------------------------------------------------------------------------------ conv strip (register-resident filters, row ring)

@@ -65,7 +65,7 @@ def main():
     g = torch.Generator().manual_seed(0)
     print(f"{'shape':28s} {'arm':10s} {'variant':18s} {'med us':>9s} {'min us':>9s} {'TF/s(med)':>10s} {'TF/s(min)':>10s}")
     for name, h, w, cin, cout, k, s, res in SHAPES:
-        if args.only and args.only not in name:
+        if args.only and not any(o in name for o in args.only.split(",")):
             continue
         n = args.batch
         ho, wo = (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
@@ -81,7 +81,7 @@ def main():
             rv = ops.View.alloc(n, ho, wo, cout, dtype, dev)
             rv.buf.copy_(torch.randn(rv.buf.numel(), generator=g).to(dev).to(dtype))
         flops = 2.0 * n * ho * wo * cout * cin * k * k
-        arms = [("nows", None, {"conv_v9": 0}), ("no v9", ws, {"conv_v9": 0}), ("auto", ws, {})]
+        arms = [("nows", None, {"conv_v9": 0, "conv_v10": 0}), ("no v9/v10", ws, {"conv_v9": 0, "conv_v10": 0}), ("v9", ws, {"conv_v10": 0}), ("auto", ws, {})]
         if args.arms:
             arms = [(a, ws, dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in a.split(",") if kv)) for a in args.arms.split(";")]
         if args.sweep:

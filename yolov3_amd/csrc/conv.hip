@@ -61,6 +61,7 @@ struct ConvArgs {
     int v7_whole;  // conv_v7.h: blocks own whole tiles (no stream-K split)
     int v7_gc;     // conv_v7.h: filter-tile ranges per XCD group (1, 2, 4 or 8; divides n_ct)
     int v9_vp, v9_npiece;   // conv_v9.h: valid pixels per tile, 1 KiB pieces of its halo patch
+    int v10_B, v10_q, v10_r, v10_nt_hi, v10_nt_lo;   // conv_v10.h: blocks per filter tile, 32-pixel column blocks per block (+ 1 for the first r), tiles per block for the two run lengths
     int cs_strips, cs_T, cs_per;   // conv_strip.h: column strips per row, output rows in all, output rows per block
     unsigned dv_pw_mul, dv_pw_sh, dv_h1_mul, dv_h1_sh;   // conv_v9.h: reciprocals of W + 2 and H + 1
 #ifdef Y3_TIMELINE  // debug build only (tools/timeline.py): per-block wall-clock stamps
@@ -959,7 +960,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvArgs p) {
 // OIHW fp32 -> packed [rows][Kpad] T, K = (kh, kw, cin_pad)
 template <typename T>
 __global__ void pack_filter_kernel(const float* __restrict__ src, int cout_src, int cin_src, int ks, int cin, int rows,
-                                   int kpad, T* __restrict__ dst) {
+                                   int kpad, T* __restrict__ dst, int frag) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long total = (long long)rows * kpad;
     if (idx >= total) return;
@@ -972,6 +973,7 @@ __global__ void pack_filter_kernel(const float* __restrict__ src, int cout_src, 
         if (ci < cin_src) v = src[(((long long)co * cin_src + ci) * ks + kh) * ks + kw];
     }
     dst[idx] = from_f32<T>(v);
+    if (frag && k < 9 * cin) dst[total + y3_frag_index(co, k, cin)] = from_f32<T>(v);   // the copy conv_v10.h reads
 }
 
 template <typename T, int BK, int WAVES_C, int WAVES_P, int MC, int MP, bool SMALLC>
@@ -999,6 +1001,7 @@ int launch_igemm(ConvArgs& a, hipStream_t st) {
 
 #include "conv_v7.h"
 #include "conv_v9.h"
+#include "conv_v10.h"
 #include "conv_strip.h"
 
 template <typename T> int dispatch_igemm(ConvArgs& a, hipStream_t st) {
@@ -1010,6 +1013,7 @@ template <typename T> int dispatch_igemm(ConvArgs& a, hipStream_t st) {
         CsPlan cs;
         if (var == 3 && cs_plan(a, cs)) return launch_cs<T>(a, st);
     }
+    if (var == 3 && v10_eligible(a)) return launch_v10<T>(a, st);
     if (var == 3 && v9_eligible(a)) return launch_v9<T>(a, st);
     if (var == 3 && v7_eligible(a)) return launch_v7<T>(a, st);
     if (var >= 3 && a.Cout > 64 && c32) {
@@ -1059,7 +1063,7 @@ template <typename T> int launch_direct(ConvArgs& a, hipStream_t st) {
 }  // namespace
 
 extern "C" size_t y3_packed_filter_elems(int32_t cout, int32_t cin, int32_t ksize) {
-    return (size_t)y3_filter_rows(cout) * (size_t)y3_filter_kpad(cin, ksize);
+    return (size_t)y3_filter_rows(cout) * (size_t)y3_filter_kpad(cin, ksize) * (y3_filter_has_frag(cout, cin, ksize) ? 2 : 1);
 }
 
 extern "C" int y3_pack_filter(const float* w, int32_t cout_src, int32_t cin_src, int32_t ks, int32_t cout, int32_t cin,
@@ -1070,10 +1074,11 @@ extern "C" int y3_pack_filter(const float* w, int32_t cout_src, int32_t cin_src,
     const long long total = (long long)rows * kpad;
     const dim3 grid((unsigned)((total + 255) / 256));
     hipStream_t st = (hipStream_t)stream;
+    const int frag = y3_filter_has_frag(cout, cin, ks) ? 1 : 0;   // 3x3 banks of >= 256-filter layers: a second, fragment-ordered copy behind the row-major one
     switch (dtype) {
-        case Y3_F16: hipLaunchKernelGGL((pack_filter_kernel<f16_t>), grid, dim3(256), 0, st, w, cout_src, cin_src, ks, cin, rows, kpad, (f16_t*)packed); break;
-        case Y3_BF16: hipLaunchKernelGGL((pack_filter_kernel<bf16_t>), grid, dim3(256), 0, st, w, cout_src, cin_src, ks, cin, rows, kpad, (bf16_t*)packed); break;
-        case Y3_F32: hipLaunchKernelGGL((pack_filter_kernel<float>), grid, dim3(256), 0, st, w, cout_src, cin_src, ks, cin, rows, kpad, (float*)packed); break;
+        case Y3_F16: hipLaunchKernelGGL((pack_filter_kernel<f16_t>), grid, dim3(256), 0, st, w, cout_src, cin_src, ks, cin, rows, kpad, (f16_t*)packed, frag); break;
+        case Y3_BF16: hipLaunchKernelGGL((pack_filter_kernel<bf16_t>), grid, dim3(256), 0, st, w, cout_src, cin_src, ks, cin, rows, kpad, (bf16_t*)packed, frag); break;
+        case Y3_F32: hipLaunchKernelGGL((pack_filter_kernel<float>), grid, dim3(256), 0, st, w, cout_src, cin_src, ks, cin, rows, kpad, (float*)packed, frag); break;
         default: Y3_FAIL("y3_pack_filter: bad dtype %d", dtype);
     }
     Y3_CHECK_LAUNCH();

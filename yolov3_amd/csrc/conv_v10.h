@@ -1,0 +1,391 @@
+// conv_v10.h -- included by conv.hip INSIDE its anonymous namespace, after conv_v7.h (shares ConvArgs, Mfma, epilogue_wave, fdiv, ...).
+//
+// v10: the 3x3 / stride 1 / pad 1 convolutions with Cout % 256 == 0 and Cin % 32 == 0 (reference models/common.py:57-81 Conv inside
+// Bottleneck.cv2, models/yolov3.yaml:23-31 and the 3x3 convs of the head; their data gradients run through the same kernel on the flipped
+// bank) with ONE wave per SIMD, PERSISTENT blocks and the filter operand in registers.  It keeps what round 3's v9 measured as right --
+// 4 waves, wave tile 64 filters x MP*32 pixels with the accumulators in AGPRs, the pixel operand as a halo patch in PADDED-IMAGE order
+// with an 80-byte row pitch (position Q(n, h, w) = (n (H + 1) + h + 1) (W + 2) + w + 1: one zero row between images, one zero column on
+// either side of a row, the zeros landed by out-of-range `buffer_load ... lds` lanes; tap (dh, dw) of EVERY pixel is patch row
+// r(m) + dh (W + 2) + dw, so dw * 80 and the k-substep are instruction immediates and there are no edge masks) -- and changes the three
+// things its ablation (profiles/r03_v9_ablation.txt) priced:
+//   * FILTER FRAGMENTS BY REGISTER LOADS.  The packed bank of an eligible layer carries a second, fragment-ordered copy
+//     (y3_frag_index, y3_common.h): the 4 KiB a wave needs for one K-step are contiguous and lane-ordered, so a K-step's filter operand is
+//     four 1 KiB `buffer_load_dwordx4` into a ring of three register sets, two K-steps ahead.  No LDS-DMA requests, no LDS stages and no
+//     `ds_read` for that operand: 14 instead of 18 fragment reads per K-step (measured -7 % as ablation arm 9).
+//   * PERSISTENT BLOCKS OVER 32-PIXEL COLUMN BLOCKS.  The pixel axis is cut into column blocks of 32 pixels; the blocks of a filter tile
+//     share them evenly (q or q + 1 each) and every block cuts ITS run into tiles of 6 / 7 / 8 column blocks (three bodies in one
+//     kernel).  v9 planned equal tiles (200 valid of 224 computed pixels at batch 32: 12 % of the MFMA issue multiplied padding); here
+//     12800 k pixels become runs of 13 (7 + 6) or 25 (7 + 6 + 6 + 6) column blocks: computed = valid.
+//   * NO PER-TILE PROLOGUE.  While a block multiplies the last channel block of a tile it requests the first channel block of its NEXT
+//     tile into the other patch buffer, and the filter ring simply wraps (the next tile has the same filter rows): the next tile's first
+//     K-step has its operands when the epilogue ends.  The epilogue transposes through a slice of its own, so nothing waits for it.
+//
+// LDS (144 KiB, one block per CU): [2 x 54 KiB patch buffers][4 x 1 KiB dump slots for request slots with nothing to fetch][4 x 8 KiB epilogue slices].
+
+constexpr int V10_PB = 54 * 1024;
+constexpr int V10_DUMP = 2 * V10_PB;
+constexpr int V10_SLICE = V10_DUMP + 4 * 1024;
+constexpr int V10_LDS = V10_SLICE + 4 * 8192;
+constexpr int V10_PITCH = 80;
+constexpr int V10_MAXPIECE = V10_PB / 1024;
+static_assert(V10_LDS <= 163840, "the LDS of a CU");
+
+// `s_waitcnt vmcnt(N)` through the builtin (the waitcnt pass parses it; an asm statement is invisible to it and it would add its own
+// conservative waits in front of the next requests -- profiles/r02_conv_v8.md): simm16 = vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14
+template <int N> Y3_DEV void v10_wait_vm() { __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14)); }
+
+template <typename T, int XQ>
+__global__ __launch_bounds__(256, 1) void conv_igemm_v10_kernel(const ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int MC = 2;
+    constexpr int NXP = 7 * XQ;   // patch request slots per wave and channel block: XQ in each of taps 0..6
+    typedef typename Mfma<T>::frag frag;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[V10_LDS];   // the ONLY LDS object
+
+    const int tid = threadIdx.x;
+    const int lane0 = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int PW = p.W + 2;
+    const int ncb = p.cin_blocks;
+
+    // ---- this block's share: filter tile ct (slowest: the blocks of one XCD share a filter tile, its rows stay in that L2) and a run of column blocks
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int ct = fdiv(lin, p.dv_ct_mul, p.dv_ct_sh);   // host: the divisor is v10_B here
+    const int bi = lin - ct * p.v10_B;
+    const bool big = bi < p.v10_r;
+    const int c_run = p.v10_q + (big ? 1 : 0);
+    const int c_start = bi * p.v10_q + (big ? bi : p.v10_r);
+    const int nt = big ? p.v10_nt_hi : p.v10_nt_lo;
+    const int tile_base = big ? bi * p.v10_nt_hi : p.v10_r * p.v10_nt_hi + (bi - p.v10_r) * p.v10_nt_lo;
+    const int tq = c_run / nt, tr = c_run - tq * nt;   // the run as nt tiles of tq (+ 1 for the first tr) column blocks
+
+    const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    // the fragment-ordered copy follows the row-major bank
+    const auto rsrc_wf = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)p.w + p.w_bytes), 0, (int)p.w_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;   // stays out of range when a channel-block offset is added
+
+    // geometry of tile t: first / end pixel, padded position of the first pixel, 1 KiB pieces of its halo patch
+    auto tile_geom = [&](int t, int& m0, int& m1, int& Qf, int& npiece) {
+        const int sz = tq + (t < tr ? 1 : 0);
+        const int c0 = c_start + t * tq + (t < tr ? t : tr);
+        m0 = c0 * 32;
+        m1 = min(m0 + sz * 32, p.M);
+        int n, h, w;
+        pix_coords(m0, p, n, h, w);
+        Qf = (n * (p.H + 1) + h + 1) * PW + w + 1;
+        pix_coords(m1 - 1, p, n, h, w);
+        const int Ql = (n * (p.H + 1) + h + 1) * PW + w + 1;
+        npiece = ((Ql - Qf + 2 * PW + 3) * V10_PITCH + 1023) >> 10;   // patch rows Qf - PW - 1 .. Ql + PW + 1
+    };
+
+    // ---- per-lane sources of this wave's patch pieces (piece q = 4 i + wave; 64 lanes x 16 B: 12.8 patch rows of 4 data slots + 1 pad slot)
+    unsigned xsrc[NXP];
+    auto set_xsrc = [&](int Q0, int npiece) {
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+#pragma unroll
+        for (int i = 0; i < NXP; ++i) {
+            const int q = i * 4 + wv;
+            const int e = q * 64 + lane;
+            const int pos = e / 5, slot = e - pos * 5;
+            const int Qa = Q0 + pos;
+            const int Qc = Qa > 0 ? Qa : 0;
+            const int R = (int)(__umulhi((unsigned)Qc, p.dv_pw_mul) >> (p.dv_pw_sh - 1));   // (W + 2 and H + 1 are never 1: no mul == 0 form, no branch)
+            const int C = Qc - R * PW;
+            const int n = (int)(__umulhi((unsigned)R, p.dv_h1_mul) >> (p.dv_h1_sh - 1));
+            const int hh = R - n * (p.H + 1);
+            const bool ok = (slot < 4) & (q < npiece) & (Qa >= 0) & (C >= 1) & (C <= p.W) & (hh >= 1) & (n < p.N);
+            xsrc[i] = ok ? (unsigned)((((n * p.H + hh - 1) * p.W + (C - 1)) * p.xpitch + slot * 8) * 2) : OOB;
+        }
+    };
+    // slot i of the wave -> patch buffer `buf`; go = false (wave-uniform): nothing to fetch, the piece goes to the dump slot
+    auto dma_x = [&](int i, int cbyte, int buf, int npiece, bool live) {
+        const int q = i * 4 + wv;
+        const bool go = live && q < npiece;
+        const int dst = go ? buf * V10_PB + q * 1024 : V10_DUMP + wv * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(smem + dst), 16, xsrc[i], cbyte, 0, 0);
+    };
+
+    // ---- filter operand: ring of three K-steps x 4 fragments (j = 2 kk + a: k-substep kk, filter rows 32 a .. 32 a + 31 of the wave's 64), one 1 KiB load each
+    u32x4 Ar[3][4];
+    const int a_base = (ct * 4 + wv) * p.nk * 4096;   // this wave's stream: nk K-steps of 4 KiB in the order the loop consumes them (channel block, tap)
+    const int a_wrap = p.nk * 4096;
+    int a_next = 0;
+    unsigned a_lane = 0;   // lane * 16, set per tile (see run_tile: nothing lane-derived is kept across a tile's epilogue)
+    auto a_load = [&](auto SLOT) {
+        constexpr int sl = decltype(SLOT)::value;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Ar[sl][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_wf, a_lane, a_base + a_next + j * 1024, 0);
+        a_next += 4096;
+        if (a_next == a_wrap) a_next = 0;   // (the loads of a tile's last two K-steps fetch K-steps 0 / 1 again and are dropped: a ring kept across the epilogue is a ring spilled)
+    };
+
+    int par = 0;   // patch buffer of the current channel block (alternates per channel block, across tiles too)
+
+    // ---- one tile of MP column blocks: K loop + epilogue.  On entry: the patch of its channel block 0 is visible in buffer `par`, xsrc are this tile's
+    // sources.  On exit the same holds for the next tile (has_next).
+    auto run_tile = [&](auto MPC, const int m0, const int m1, const int Qf, const int npiece, const int stat_row0, const bool has_next, const int nQf,
+                        const int nnpiece) {
+        constexpr int MP = decltype(MPC)::value;
+        constexpr int NPASS = (MP + 1) / 2;
+        // the lane id behind an opaque move: everything derived from it (fragment rows, patch offsets, the epilogue's store pattern) is re-derived per tile
+        // instead of being hoisted out of the tile loop and spilled around the K loop (first cut: 170-200 spilled registers, each reload an exposed round
+        // trip in the epilogue: +40 us per tile)
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const int frow = lane & 31, fk = lane >> 5;
+        // filter fragments of K-steps 0 and 1: in flight under the set-up below
+        a_lane = (unsigned)lane * 16u;
+        a_next = 0;
+        a_load(IC<0>{});
+        a_load(IC<1>{});
+        // pixels: column block b, tap row dh -> patch row (Q(m) - Qf) + dh PW; columns beyond the tile's valid pixels re-read its last pixel
+        int bb[3][MP];
+#pragma unroll
+        for (int b = 0; b < MP; ++b) {
+            int m = m0 + b * 32 + frow;
+            m = m < m1 ? m : m1 - 1;
+            int n, h, w;
+            pix_coords(m, p, n, h, w);
+            const int r = (n * (p.H + 1) + h + 1) * PW + w + 1 - Qf;
+#pragma unroll
+            for (int dh = 0; dh < 3; ++dh) bb[dh][b] = par * V10_PB + (r + dh * PW) * V10_PITCH + fk * 16;
+        }
+        // the accumulators start at the bias of their filter (lane holds filters 8g + 4fk + q of each 32-filter tile)
+        f32x16 acc[MC][MP];
+#pragma unroll
+        for (int a = 0; a < MC; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cbias = ct * 256 + (wv * MC + a) * 32 + 8 * g + 4 * fk;
+                const f32x4 bz = *(const f32x4*)(p.bias + cbias);   // (Cout % 256 == 0 and the C ABI requires a bias: no guards, no branches around the accumulators' first values)
+#pragma unroll
+                for (int b = 0; b < MP; ++b)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[a][b][4 * g + q] = bz[q];
+            }
+        frag B0[MP], B1[MP];
+#pragma unroll
+        for (int b = 0; b < MP; ++b) B0[b] = *(const frag*)(smem + bb[0][b]);
+        int bufd = par ? -V10_PB : V10_PB;   // what moves the pixel bases to the other patch buffer
+
+        int cb = 0;
+        do {   // (ncb >= 1: a zero-trip path would make the register allocator keep the accumulators' first values on the stack for it)
+            const bool lastcb = cb + 1 == ncb;
+            int np_req = npiece, cbyte = (cb + 1) * 64;
+            bool live = true;
+            if (lastcb) {   // the requests of this channel block fetch channel block 0 of the block's next tile
+                live = has_next;
+                np_req = nnpiece;
+                cbyte = 0;
+                if (has_next) set_xsrc(nQf - PW - 1, nnpiece);
+            }
+            const int nbuf = par ^ 1;
+            static_for<9>([&](auto TAP) {
+                constexpr int tap = decltype(TAP)::value;
+                constexpr int dh = tap / 3, dw = tap % 3;
+                constexpr int ntap = (tap + 1) % 9, ndh = ntap / 3, ndw = ntap % 3;
+                // ---- phase 1: MFMAs of substep 0 | pixel fragments of substep 1, filter fragments of K-step s + 2 (ring slot (s + 2) % 3 = (tap + 2) % 3: 9 % 3 == 0)
+#pragma unroll
+                for (int b = 0; b < MP; ++b) B1[b] = *(const frag*)(smem + bb[dh][b] + dw * V10_PITCH + 32);
+                a_load(IC<(tap + 2) % 3>{});
+#pragma unroll
+                for (int a = 0; a < MC; ++a)
+#pragma unroll
+                    for (int b = 0; b < MP; ++b) acc[a][b] = Mfma<T>::run(__builtin_bit_cast(frag, Ar[tap % 3][a]), B0[b], acc[a][b]);
+                {
+#pragma unroll
+                    for (int i = 0; i < MP; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one LDS read
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // one load
+                    }
+                    if constexpr (MC * MP - MP - 4 > 0) __builtin_amdgcn_sched_group_barrier(0x008, MC * MP - MP - 4, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- phase 2: MFMAs of substep 1 | pixel fragments of (K-step s + 1, substep 0), patch requests of the next channel block
+                v10_wait_vm<4>();   // everything but the 4 loads of phase 1: the ring slot of K-step s + 1 (loaded a K-step ago), patch pieces of earlier taps
+                if constexpr (tap == 8) {
+                    // the next channel block: its patch pieces (requested in taps 0..6, retired by the counted waits since) become visible to the
+                    // other waves, and every wave is done reading this block's buffer (its last reads, B1 above, have returned) before anyone
+                    // requests into it again
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+#pragma unroll
+                    for (int d = 0; d < 3; ++d)
+#pragma unroll
+                        for (int b = 0; b < MP; ++b) bb[d][b] += bufd;
+                    bufd = -bufd;
+                }
+#pragma unroll
+                for (int b = 0; b < MP; ++b) B0[b] = *(const frag*)(smem + bb[ndh][b] + ndw * V10_PITCH);
+                if constexpr (tap < 7) {
+#pragma unroll
+                    for (int x = 0; x < XQ; ++x) dma_x(tap * XQ + x, cbyte, nbuf, np_req, live);
+                }
+#pragma unroll
+                for (int a = 0; a < MC; ++a)
+#pragma unroll
+                    for (int b = 0; b < MP; ++b) acc[a][b] = Mfma<T>::run(__builtin_bit_cast(frag, Ar[tap % 3][2 + a]), B1[b], acc[a][b]);
+                {
+#pragma unroll
+                    for (int i = 0; i < MP; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    if constexpr (tap < 7) {
+#pragma unroll
+                        for (int x = 0; x < XQ; ++x) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        }
+                    }
+                    if constexpr (MC * MP - MP - (tap < 7 ? XQ : 0) > 0) __builtin_amdgcn_sched_group_barrier(0x008, MC * MP - MP - (tap < 7 ? XQ : 0), 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            par ^= 1;
+        } while (++cb < ncb);
+
+        // ---- epilogue: passes of 64 pixels through the wave's own transpose slice (nothing else lives there: the patch of the next tile keeps landing)
+        unsigned char* slice = smem + V10_SLICE + wv * 8192;
+        int lane_e = lane0;   // (again opaque: the store pattern is derived here, after the K loop, not kept alive through it)
+        asm volatile("" : "+v"(lane_e));
+#pragma unroll
+        for (int hb = 0; hb < NPASS; ++hb) {
+            if constexpr (MP % 2 == 1) {
+                if (hb == NPASS - 1) {
+                    f32x16 part[MC][1];
+#pragma unroll
+                    for (int a = 0; a < MC; ++a) part[a][0] = acc[a][MP - 1];
+                    epilogue_wave<T, MC, 1>(p, part, slice, ct * 256 + wv * MC * 32, m0 + hb * 64, lane_e, stat_row0 + hb, m1);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    continue;
+                }
+            }
+            f32x16 part[MC][2];
+#pragma unroll
+            for (int a = 0; a < MC; ++a) { part[a][0] = acc[a][2 * hb]; part[a][1] = acc[a][2 * hb + 1]; }
+            epilogue_wave<T, MC, 2>(p, part, slice, ct * 256 + wv * MC * 32, m0 + hb * 64, lane_e, stat_row0 + hb, m1);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();   // the slice is private to the wave: its reads of one pass precede the writes of the next
+        }
+        // a tile owns four statistics rows (one per 64-pixel pass of the widest body): the passes this body does not have are zero rows
+        if (p.stats != nullptr && NPASS < 4 && lane_e < 8) {
+            const int c = ct * 256 + wv * MC * 32 + lane_e * 8;
+            if (c + 8 <= p.Cout) {
+#pragma unroll
+                for (int hb = NPASS; hb < 4; ++hb) {
+                    float* row = p.stats + ((long long)(stat_row0 + hb) * p.Cout + c) * 2;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *(f32x4*)(row + q * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+    };
+
+    // ---- prologue of the block: the whole patch of (tile 0, channel block 0)
+    int m0, m1, Qf, npiece;
+    tile_geom(0, m0, m1, Qf, npiece);
+    set_xsrc(Qf - PW - 1, npiece);
+#pragma unroll
+    for (int i = 0; i < NXP; ++i) dma_x(i, 0, 0, npiece, true);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    int t = 0;
+    do {
+        const bool has_next = t + 1 < nt;
+        int nm0 = 0, nm1 = 1, nQf = 0, nnp = 0;
+        if (has_next) tile_geom(t + 1, nm0, nm1, nQf, nnp);
+        const int sz = tq + (t < tr ? 1 : 0);
+        const int srow = (tile_base + t) * 4;
+        if (sz >= 8) run_tile(IC<8>{}, m0, m1, Qf, npiece, srow, has_next, nQf, nnp);
+        else if (sz == 7) run_tile(IC<7>{}, m0, m1, Qf, npiece, srow, has_next, nQf, nnp);
+        else run_tile(IC<6>{}, m0, m1, Qf, npiece, srow, has_next, nQf, nnp);
+        m0 = nm0; m1 = nm1; Qf = nQf; npiece = nnp;
+    } while (++t < nt);
+#endif
+}
+
+// The host's plan: blocks per filter tile (B), column blocks per block (q, + 1 for the first r), the widest body whose worst-case halo patch fits the
+// patch buffer, tiles per block for the two run lengths.
+struct V10Plan {
+    int B, q, r, mp_max, nt_hi, nt_lo, n_tiles, xq;
+};
+static int v10_patch_pieces(const ConvArgs& a, int mp) {   // worst case over tile positions: (vp - 1) pixels + 2 pad columns per row crossing + a zero row per image crossing + the halo
+    const int vp = mp * 32, PW = a.W + 2;
+    const int rc = (vp - 1 + a.W - 1) / a.W, ic = (vp - 1 + a.H * a.W - 1) / (a.H * a.W);
+    const int npos = (vp - 1) + 2 * rc + PW * ic + 2 * PW + 3;
+    return (npos * V10_PITCH + 1023) / 1024;
+}
+static bool v10_plan(const ConvArgs& a, V10Plan& pl) {
+    const int n_ct = a.Cout / 256, cus = y3_cu_count();
+    const int CB = (a.M + 31) / 32;
+    if (n_ct < 1 || CB < 1) return false;
+    const int force_mp = (int)y3_knob(Y3K_V10_MP), force_b = (int)y3_knob(Y3K_V10_BLOCKS);
+    pl.mp_max = 0;
+    for (int mp = 8; mp >= 6; --mp) {
+        if (force_mp >= 6 && force_mp <= 8 && mp > force_mp) continue;
+        if (v10_patch_pieces(a, mp) <= V10_MAXPIECE) { pl.mp_max = mp; break; }
+    }
+    if (!pl.mp_max) return false;
+    pl.xq = v10_patch_pieces(a, pl.mp_max) > 28 ? 2 : 1;
+    int B = cus / n_ct;
+    if (B < 1) B = 1;
+    if (B > CB / 6) B = CB / 6 > 0 ? CB / 6 : 1;   // at least 6 column blocks (one narrowest body) per block where the launch has them
+    if (force_b > 0) B = force_b < CB ? force_b : CB;
+    pl.B = B;
+    pl.q = CB / B;
+    pl.r = CB % B;
+    pl.nt_lo = (pl.q + pl.mp_max - 1) / pl.mp_max;
+    pl.nt_hi = (pl.q + 1 + pl.mp_max - 1) / pl.mp_max;
+    pl.n_tiles = pl.r * pl.nt_hi + (B - pl.r) * pl.nt_lo;
+    return true;
+}
+
+static bool v10_eligible(const ConvArgs& a) {
+    if (y3_knob(Y3K_CONV_V10) == 0 || a.ups) return false;
+    if (a.ks != 3 || a.stride != 1 || a.pad != 1 || a.dil_shift != 0 || a.ntaps != 9 || a.omul != 1 || a.ooh != 0 || a.oow != 0) return false;
+    if (a.H != a.Ho || a.W != a.Wo || a.oH != a.Ho || a.oW != a.Wo) return false;
+    if (!y3_filter_has_frag(a.Cout, a.Cin, a.ks)) return false;   // Cin % 32 == 0, Cout % 256 == 0: the bank carries the fragment-ordered copy
+    if (!a.x_bytes || !a.w_bytes || !a.y_bytes || (a.res && !a.r_bytes)) return false;
+    if (2ll * a.w_bytes >= 0x7fffffffLL) return false;
+    for (int t = 0; t < 9; ++t)
+        if (a.tdh[t] != t / 3 || a.tdw[t] != t % 3) return false;
+    if ((long long)(a.N + 1) * (a.H + 1) * (a.W + 2) >= 0x7fffffffLL) return false;
+    if ((long long)(a.Cout / 256) * 4 * 9 * (a.Cin / 32) * 4096 >= 0x7fffffffLL) return false;
+    if (a.Cin < 128 && y3_knob(Y3K_CONV_V10) != 2) return false;   // K = 288 / 576: the strip kernels and the small tiles (conv_strip.h, v3)
+    // below a quarter round of 256-pixel tiles the K-split of conv_v7.h (small batches) is what fills the chip
+    if ((long long)y3_ceil_div(a.M, 256) * (a.Cout / 256) < 64 && y3_knob(Y3K_CONV_V10) != 2) return false;
+    V10Plan pl;
+    return v10_plan(a, pl);
+}
+
+template <typename T> int launch_v10(ConvArgs& a, hipStream_t st) {
+    V10Plan pl;
+    if (!v10_plan(a, pl)) Y3_FAIL("conv v10: no tile plan (internal)");
+    a.n_ct = a.Cout / 256;
+    a.n_pt = pl.n_tiles;
+    a.v10_B = pl.B; a.v10_q = pl.q; a.v10_r = pl.r; a.v10_nt_hi = pl.nt_hi; a.v10_nt_lo = pl.nt_lo;
+    set_divisors(a);
+    magic_u31(pl.B, a.dv_ct_mul, a.dv_ct_sh);   // this kernel divides the block id by the blocks per filter tile
+    magic_u31(a.W + 2, a.dv_pw_mul, a.dv_pw_sh);
+    magic_u31(a.H + 1, a.dv_h1_mul, a.dv_h1_sh);
+    a.cin_blocks = a.Cin / 32;
+    a.nk = 9 * a.cin_blocks;
+    a.stat_wp = 4;   // statistics rows per tile: one per 64-pixel epilogue pass of the widest body (narrower bodies write zero rows)
+    g_last_variant = "v10";
+    if (a.dry) return 0;
+    const dim3 grid((unsigned)(a.n_ct * pl.B)), block(256);
+    if (pl.xq == 2) hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1>), grid, block, 0, st, a);
+    Y3_CHECK_LAUNCH();
+    return 0;
+}

@@ -914,7 +914,7 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ 
 
 // OIHW fp32 -> data-gradient filter bank: rows = cin, K = (kh', kw', cout) with the taps flipped
 template <typename T>
-__global__ void pack_filter_dgrad_kernel(const float* __restrict__ src, int cout_src, int cin_src, int ks, int cout, int rows, int kpad, T* __restrict__ dst) {
+__global__ void pack_filter_dgrad_kernel(const float* __restrict__ src, int cout_src, int cin_src, int ks, int cout, int rows, int kpad, T* __restrict__ dst, int frag) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long total = (long long)rows * kpad;
     if (idx >= total) return;
@@ -927,6 +927,7 @@ __global__ void pack_filter_dgrad_kernel(const float* __restrict__ src, int cout
         if (co < cout_src) v = src[(((long long)co * cin_src + ci) * ks + kh) * ks + kw];
     }
     dst[idx] = from_f32<T>(v);
+    if (frag && k < 9 * cout) dst[total + y3_frag_index(ci, k, cout)] = from_f32<T>(v);   // the copy conv_v10.h reads (y3_common.h)
 }
 
 // both filter banks of a training step from the fp32 master weights in one launch: the forward bank [cout][kh][kw][cin] and the
@@ -944,6 +945,7 @@ __global__ void pack_filter_pair_kernel(const float* __restrict__ src, int cout_
             if (ci < cin_src) v = src[(((long long)co * cin_src + ci) * ks + kh) * ks + kw];
         }
         dst_f[idx] = from_f32<T>(v);
+        if (y3_filter_has_frag(cout, cin, ks) && k < 9 * cin) dst_f[(long long)rows_f * kpad_f + y3_frag_index(co, k, cin)] = from_f32<T>(v);   // the copies conv_v10.h reads
     }
     if (idx < (long long)rows_d * kpad_d) {
         const int k = (int)(idx % kpad_d), ci = (int)(idx / kpad_d);
@@ -954,6 +956,7 @@ __global__ void pack_filter_pair_kernel(const float* __restrict__ src, int cout_
             if (co < cout_src) v = src[(((long long)co * cin_src + ci) * ks + kh) * ks + kw];
         }
         dst_d[idx] = from_f32<T>(v);
+        if (y3_filter_has_frag(cin, cout, ks) && k < 9 * cout) dst_d[(long long)rows_d * kpad_d + y3_frag_index(ci, k, cout)] = from_f32<T>(v);
     }
 }
 
@@ -982,6 +985,7 @@ __global__ __launch_bounds__(256) void pack_filter_jobs_kernel(const y3_pack_job
             if (ci < j.cin_src) v = src[(((long long)co * j.cin_src + ci) * ks + kh) * ks + kw];
         }
         ((T*)j.packed_fwd)[idx] = from_f32<T>(v);
+        if (y3_filter_has_frag(cout, cin, ks) && k < 9 * cin) ((T*)j.packed_fwd)[(long long)rows_f * kpad_f + y3_frag_index(co, k, cin)] = from_f32<T>(v);
     }
     if (j.packed_dgrad && idx < (long long)rows_d * kpad_d) {
         const int k = (int)(idx % kpad_d), ci = (int)(idx / kpad_d);
@@ -992,6 +996,7 @@ __global__ __launch_bounds__(256) void pack_filter_jobs_kernel(const y3_pack_job
             if (co < j.cout_src) v = src[(((long long)co * j.cin_src + ci) * ks + kh) * ks + kw];
         }
         ((T*)j.packed_dgrad)[idx] = from_f32<T>(v);
+        if (y3_filter_has_frag(cin, cout, ks) && k < 9 * cout) ((T*)j.packed_dgrad)[(long long)rows_d * kpad_d + y3_frag_index(ci, k, cout)] = from_f32<T>(v);
     }
 }
 
@@ -1585,7 +1590,8 @@ extern "C" int y3_pack_filter_dgrad(const float* w, int32_t cout_src, int32_t ci
     const int rows = y3_filter_rows(cin), kpad = y3_filter_kpad(cout, ks);
     const long long total = (long long)rows * kpad;
     hipStream_t st = (hipStream_t)stream;
-    Y3_DISPATCH_T(dtype, hipLaunchKernelGGL((pack_filter_dgrad_kernel<T>), dim3(nblk(total)), dim3(256), 0, st, w, cout_src, cin_src, ks, cout, rows, kpad, (T*)packed));
+    Y3_DISPATCH_T(dtype, hipLaunchKernelGGL((pack_filter_dgrad_kernel<T>), dim3(nblk(total)), dim3(256), 0, st, w, cout_src, cin_src, ks, cout, rows, kpad, (T*)packed,
+                                    y3_filter_has_frag(cin, cout, ks) ? 1 : 0));
     Y3_CHECK_LAUNCH();
     return 0;
 }

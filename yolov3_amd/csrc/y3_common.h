@@ -132,3 +132,14 @@ static inline size_t y3_round_up(size_t a, size_t b) { return (a + b - 1) / b * 
 // packed filter geometry (see conv.hip): rows padded to 128 filters, K padded to 64
 static inline int y3_filter_rows(int cout) { return (int)y3_round_up((size_t)cout, 128); }
 static inline int y3_filter_kpad(int cin, int ksize) { return (int)y3_round_up((size_t)ksize * ksize * cin, 64); }
+// 3x3 banks with rows % 256 == 0 and channels % 32 == 0 carry a second copy behind the row-major one, in the order conv_v10.h consumes it: per
+// (256-row filter tile, 64-row wave, K-step) one 4 KiB block of four 1 KiB MFMA A fragments j = 2 kk + a (k-substep kk, rows 32 a .. 32 a + 31), lane = 32 fk + row
+// holding k-group 16 kk + 8 fk .. + 7 of the K-step's 32 channels; K-steps in loop order (channel block, tap).  Every packer writes both copies.
+__host__ __device__ static inline bool y3_filter_has_frag(int rows, int channels, int ksize) { return ksize == 3 && rows > 0 && (rows % 256) == 0 && channels > 0 && (channels % 32) == 0; }
+__host__ __device__ static inline long long y3_frag_index(int row, int k, int channels) {
+    const int tap = k / channels, ci = k - tap * channels;
+    const int cb = ci >> 5, kk = (ci >> 4) & 1, fk = (ci >> 3) & 1, e = ci & 7;
+    const int tw = row >> 6, a = (row >> 5) & 1, fr = row & 31;   // tw = 4 * filter tile + wave
+    const int nk = 9 * (channels >> 5);
+    return ((((long long)tw * nk + cb * 9 + tap) * 4 + (kk * 2 + a)) * 64 + fk * 32 + fr) * 8 + e;
+}

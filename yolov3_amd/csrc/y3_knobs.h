@@ -16,6 +16,9 @@ enum y3_knob_id {
     Y3K_V9_VP,          // "v9_vp":       0 the host's tile plan; > 0 force the valid pixels per tile (tests: tiles that cross rows and images)
     Y3K_WGRAD_STRIP,    // "wgrad_strip": 1 the strip-walking filter-gradient kernel for the 3x3 layers with 32 -> 64 / 64 -> 128 channels (wgrad_strip.h); 0 never; 2 also small launches; N > 2: N K-steps per block (tests)
     Y3K_CONV_STRIP,     // "conv_strip":  1 the strip-walking 3x3 kernel with register-resident filters for 32 -> 64 / 64 -> 32 / 64 -> 128 channels (conv_strip.h); 0 never; 2 also small launches; N > 2: N rows per block (tests)
+    Y3K_CONV_V10,       // "conv_v10":    1 the persistent one-wave-per-SIMD 3x3 kernel with register-resident filter fragments (conv_v10.h) for Cin >= 128 at a quarter round of tiles or more; 0 never; 2 every eligible shape
+    Y3K_V10_MP,         // "v10_mp":      0 the widest body whose halo patch fits; 6 / 7 / 8 cap the wave-tile width (32-pixel column blocks) of conv_v10.h (tests)
+    Y3K_V10_BLOCKS,     // "v10_blocks":  0 one block per CU; N > 0 blocks per filter tile (tests: blocks that walk many tiles, single-column-block tiles)
     Y3K_COUNT
 };
 long long y3_knob(int id);
