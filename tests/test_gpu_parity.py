@@ -177,7 +177,7 @@ V7_CASES = [   # every case has >= 32 (tile, channel block) units, the dispatche
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("name,shape,kw", V7_CASES, ids=[c[0] for c in V7_CASES])
 def test_conv_v7_streamk_vs_fp32_reference(dev, dtype, name, shape, kw, tune):
-    tune("conv_v9", 0)
+    tune("conv_v10", 0)
     tune("conv_v7", 2)     # also the Cin < 256 shapes the dispatcher leaves to the 128x128 kernels
     tune("v7_grid", -2)    # even K split whatever the tile count: every case crosses tile boundaries inside blocks
     out, ref = run_conv(dev, dtype, *shape, algo=1, ws=True, expect="v7", repeat=3, **kw)
@@ -191,7 +191,7 @@ def test_conv_request_depth_bit_identical(dev, tune, variant, shape):
     round-2 schedule).  Both schedules add the same products in the same order: bit-identical outputs -- for v7 with whole tiles and with
     the K split, launch after launch (a stage overwritten while a wave still reads it would show up here as a flip)."""
     outs = []
-    tune("conv_v9", 0)
+    tune("conv_v10", 0)
     if variant == "v6":
         tune("conv", 15)   # force the 256x256 v6 tile whatever the per-shape dispatch would pick at this small batch
     for grid in ((-1, -2) if variant == "v7" else (0,)):
@@ -208,7 +208,7 @@ def test_conv_v7_grid_sweep(dev, tune):
     """the same problem under different block counts (different K splits, down to whole tiles): every split sums the same
     products in fp32, so the results agree to accumulation-order noise and each one is inside the conv tolerance"""
     outs = []
-    tune("conv_v9", 0)
+    tune("conv_v10", 0)
     for grid, gc in ((-1, 1), (-2, 1), (7, 1), (24, 2), (61, 1), (-1, 2), (-2, 2), (0, 4)):   # 4 does not divide the 2 filter tiles: ignored
         tune("v7_grid", grid)
         tune("v7_gc", gc)   # filter-tile ranges per XCD group (the rectangle a group of blocks owns)
@@ -223,9 +223,9 @@ def test_conv_v7_grid_sweep(dev, tune):
 # bench actually runs (multi-round grids, XCD remap at 200-3200 blocks, ragged last tiles at M = 12800 / 51200 / 204800).
 BASELINE_CONV_CASES = [
     # name, (n,h,w,cin,cout,k,s), kwargs, variant with workspace
-    ("L6cv2_128_256_80", (32, 80, 80, 128, 256, 3, 1), {"residual": True}, "v3_bk64_128x128"),
-    ("L8cv2_256_512_40", (32, 40, 40, 256, 512, 3, 1), {"residual": True}, "v9_mp7"),
-    ("L10cv2_512_1024_20", (32, 20, 20, 512, 1024, 3, 1), {"residual": True}, "v9_mp7"),
+    ("L6cv2_128_256_80", (32, 80, 80, 128, 256, 3, 1), {"residual": True}, "v10"),
+    ("L8cv2_256_512_40", (32, 40, 40, 256, 512, 3, 1), {"residual": True}, "v10"),
+    ("L10cv2_512_1024_20", (32, 20, 20, 512, 1024, 3, 1), {"residual": True}, "v10"),
     ("L7_256_512_s2", (32, 80, 80, 256, 512, 3, 2), {}, "v6"),
     ("L9_512_1024_s2", (32, 40, 40, 512, 1024, 3, 2), {}, "v6"),
     ("L8cv1_512_256_40", (32, 40, 40, 512, 256, 1, 1), {}, "v6"),
@@ -236,8 +236,8 @@ BASELINE_CONV_CASES = [
     ("head255_20", (32, 20, 20, 1024, 256, 1, 1), {"cout_real": 255, "act": False}, "v3_bk64_128x128"),
     ("head255_80", (32, 80, 80, 256, 256, 1, 1), {"cout_real": 255, "act": False}, "v3_bk32_128x128"),
     ("head1110_40_c5", (8, 40, 40, 1024, 1112, 1, 1), {"cout_real": 1110, "act": False}, None),
-    ("c5_128_256_160", (8, 160, 160, 128, 256, 3, 1), {"residual": True}, "v3_bk64_128x128"),
-    ("c5_256_512_80", (8, 80, 80, 256, 512, 3, 1), {"residual": True}, "v9_mp7"),
+    ("c5_128_256_160", (8, 160, 160, 128, 256, 3, 1), {"residual": True}, "v10"),
+    ("c5_256_512_80", (8, 80, 80, 256, 512, 3, 1), {"residual": True}, "v10"),
     ("ups_route_20", (32, 20, 20, 512, 256, 1, 1), {"ups": True}, None),
 ]
 
@@ -665,7 +665,7 @@ HALF_BOUNDS = {torch.float16: dict(rms=0.001, mx=0.003, corr=0.99999), torch.bfl
 def test_model_half_vs_fp32_oracle_benchmark_shapes(dev, name, hw, bs, dtype):
     """The BENCHMARKED engines at their own resolution (640x640 fp16 yolov3 / yolov3-spp = configs[1] / [3]; bf16 at 640 and 1280 =
     configs[4]'s dtype and map sizes) against the fp32 CPU oracle: every conv launch goes through the variants the bench runs
-    (v9 / v7 / v6 / v3 with multi-round grids), and the error is bounded per level in relative RMS, max-abs and correlation."""
+    (v10 / v7 / v6 / v3 with multi-round grids), and the error is bounded per level in relative RMS, max-abs and correlation."""
     nc = 80 if hw == 640 else 365
     m, (layers, save, sd, strides) = build_pair(name, nc, 21, dev, dtype)
     x = torch.rand(bs, 3, hw, hw, generator=torch.Generator().manual_seed(6))
@@ -673,7 +673,7 @@ def test_model_half_vs_fp32_oracle_benchmark_shapes(dev, name, hw, bs, dtype):
     torch.cuda.synchronize()
     plan = next(iter(m._plans.values()))
     variants = {plan.conv_variant(ln) for ln in plan.launches if ln.flops and not ln.kernel}
-    assert any(v == "v7" or v.startswith("v9") for v in variants) and "direct" not in variants, variants
+    assert any(v == "v7" or v == "v10" for v in variants) and "direct" not in variants, variants
     with torch.no_grad():
         refp, refraw = yo.forward(layers, save, sd, x[: min(bs, 4)], strides, training=False)   # the oracle on the first images (CPU time)
     b = HALF_BOUNDS[dtype]
@@ -2171,10 +2171,15 @@ def test_conv_train_launches_benchmark_shapes_fp16(dev, name, kind, shape, varia
     gx = ops.View.alloc(n, h, w, cin, dtype, dev)
     sel = pick(cin)
     if kind == "dgrad":
-        gx.buf.normal_(generator=g)   # what the fan-out already accumulated: the launch adds to it through the residual port
-        base = gx.as_nhwc()[..., sel].float().cpu()
         filt_d = ops.pack_filter_dgrad(wt.to(dev), cout, cin, dtype)
-        ops.conv2d(gv, filt_d, torch.zeros(cin, device=dev), gx, k, 1, act=False, residual=gx, in_dilation=s)
+        if variant == "strip":   # cv2 of a Bottleneck: its input has one consumer, the gradient is written (the strip kernel has no residual port)
+            gx.buf.fill_(float("nan"))
+            base = None
+            ops.conv2d(gv, filt_d, torch.zeros(cin, device=dev), gx, k, 1, act=False, in_dilation=s)
+        else:
+            gx.buf.normal_(generator=g)   # what a fan-out already accumulated: the launch adds to it through the residual port
+            base = gx.as_nhwc()[..., sel].float().cpu()
+            ops.conv2d(gv, filt_d, torch.zeros(cin, device=dev), gx, k, 1, act=False, residual=gx, in_dilation=s)
     else:
         gx.buf.fill_(float("nan"))
         base = None
@@ -2396,7 +2401,7 @@ def test_conv_workspace_lost_handoff_is_loud_and_resettable(dev, tune):
     never published within the bounded spin -- every launch on that workspace writes NaN instead of a silently wrong sum, the host can
     read the flag (y3_conv_workspace_error) and re-arm the workspace (y3_conv_workspace_reset); afterwards the results are exact again."""
     _lib, ops = _ops()
-    tune("conv_v9", 0)
+    tune("conv_v10", 0)
     tune("v7_grid", -2)
     shape = (2, 20, 20, 256, 512, 3, 1)
     good, ref = run_conv(dev, torch.float16, *shape, algo=1, ws=True, expect="v7")
@@ -2411,67 +2416,6 @@ def test_conv_workspace_lost_handoff_is_loud_and_resettable(dev, tune):
     assert not ops.conv_workspace_error(ws)
     again, _ = run_conv(dev, torch.float16, *shape, algo=1, ws=True, expect="v7")
     assert torch.equal(again, good)
-
-
-# ------------------------------------------------------------------------------------------------ conv v9 (one wave per SIMD, padded-image halo patch)
-V9_CASES = [
-    # name, (n,h,w,cin,cout,k,s), kwargs, knobs (v9_mp, v9_vp; 0 = the host's plan)
-    ("plan_20x20_res", (8, 20, 20, 256, 512, 3, 1), {"residual": True}, (0, 0)),
-    ("mp8_vp256_rows_and_images", (6, 20, 20, 64, 256, 3, 1), {}, (8, 256)),             # tiles cross 12 rows and an image boundary
-    ("mp7_vp200_tiny_images", (40, 7, 5, 32, 256, 3, 1), {"residual": True}, (7, 200)),   # 35-pixel images: 5 image boundaries per tile, ncb = 1
-    ("mp6_vp192_odd_map", (3, 21, 19, 96, 256, 3, 1), {"sliced": True}, (6, 192)),        # 3 channel blocks, ragged last tile
-    ("mp7_vp201_w80_two_requests", (2, 80, 80, 64, 256, 3, 1), {}, (7, 201)),             # 36 patch pieces: two request slots per tap, vp not a multiple of anything
-    ("mp8_vp33_w40", (1, 40, 40, 128, 512, 3, 1), {"act": False}, (8, 33)),               # mostly-empty column blocks
-    ("mp7_vp224_1x1_image_rows", (2, 13, 26, 160, 256, 3, 1), {}, (7, 224)),
-    ("mp6_w160", (1, 160, 160, 32, 256, 3, 1), {"residual": True}, (6, 160)),
-]
-
-
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("name,shape,kw,knobs", V9_CASES, ids=[c[0] for c in V9_CASES])
-def test_conv_v9_vs_fp32_reference(dev, tune, dtype, name, shape, kw, knobs):
-    """conv_v9.h (one wave per SIMD, private filter stages, padded-image halo patch with an 80-byte pitch, 192 / 224 / 256-pixel tiles with an
-    arbitrary number of valid pixels) against fp32 conv2d on the same rounded operands: tiles that cross rows and image boundaries, edge
-    taps (zeros through out-of-range request lanes), 1 .. 8 channel blocks, one and two patch request slots per tap, ragged last tiles,
-    residual / sliced outputs; repeated launches bit-identical."""
-    mp, vp = knobs
-    tune("conv_v9", 2)
-    tune("v9_mp", mp)
-    tune("v9_vp", vp)
-    want = f"v9_mp{mp}" if mp else None
-    out, ref = run_conv(dev, dtype, *shape, algo=1, ws=True, expect=want, repeat=2, **kw)
-    _lib, ops = _ops()
-    assert ops.last_conv_variant().startswith("v9"), ops.last_conv_variant()
-    _conv_tol_check(name, dtype, out, ref)
-
-
-def test_conv_v9_statistics_rows(dev, tune):
-    """BatchNorm statistics rows from the v9 epilogue (one row per 64-pixel pass and pixel tile, only the tile's valid pixels counted):
-    their fp64 sum equals the statistics of the stored tensor."""
-    _lib, ops = _ops()
-    tune("conv_v9", 2)
-    tune("v9_mp", 7)
-    tune("v9_vp", 200)
-    n, h, w, cin, cout, k, s = 5, 20, 20, 64, 256, 3, 1
-    dtype = torch.float16
-    g = torch.Generator().manual_seed(4)
-    x = torch.randn(n, cin, h, w, generator=g).to(dtype)
-    wt = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
-    xv = ops.View.alloc(n, h, w, cin, dtype, dev)
-    ops.nchw_to_nhwc(x.to(dev), xv)
-    filt = ops.pack_filter(wt.to(dev), cout, cin, dtype)
-    zb = torch.zeros(cout, device=dev)
-    y1 = ops.View.alloc(n, h, w, cout, dtype, dev)
-    rows = ops.conv2d_stats_rows(xv, y1, k, s)
-    assert rows == 10 * 4, rows   # 2000 pixels / 200 per tile, 4 passes of 64 pixels
-    buf = torch.full((rows * 2 * cout,), float("nan"), device=dev)
-    assert ops.conv2d_stats(xv, filt, zb, y1, k, s, buf, rows) == rows and ops.last_conv_variant() == "v9_mp7"
-    torch.cuda.synchronize()
-    u = y1.as_nhwc().double().cpu().reshape(-1, cout)
-    tot = buf.view(rows, cout, 2).double().sum(0).cpu()
-    assert torch.isfinite(tot).all(), "a statistics row was not written"
-    assert (tot[:, 0] - u.sum(0)).abs().max().item() <= 1e-5 * u.abs().sum(0).max().item()
-    assert (tot[:, 1] - (u * u).sum(0)).abs().max().item() <= 1e-5 * (u * u).sum(0).max().item()
 
 
 # ------------------------------------------------------------------------------------------------ conv v10 (persistent, register-resident filter fragments)

@@ -2,8 +2,8 @@
 
     python tools/conv_lab.py [--rounds 7] [--reps 20] [--batch 32] [--only 3x3]
 
-Arms per shape (run-time knobs, y3_tune_set): "auto" = the dispatcher's choice with a workspace (v9 where eligible), "no v9" = knob
-conv_v9 = 0 (v7 / v6 / v3 as in round 2), "nows" = y3_conv2d_fwd without a workspace and without v9 (round-1 kernels).
+Arms per shape (run-time knobs, y3_tune_set): "auto" = the dispatcher's choice with a workspace (v10 where eligible), "no v10" = knob
+conv_v10 = 0 (v7 / v6 / v3 as in round 2), "nows" = y3_conv2d_fwd without a workspace and without v10 (round-1 kernels).
 Prints median / min microseconds per launch and TFLOP/s.  Inputs are random (DVFS: never time on zeros)."""
 import argparse
 import math
@@ -55,7 +55,7 @@ def main():
     ap.add_argument("--dtype", default="fp16")
     ap.add_argument("--arms", default="", help='custom arms instead of the default three: "knob=value,knob=value;knob=value" (each with a workspace)')
     ap.add_argument("--noact", action="store_true", help="no activation (the training-mode launches)")
-    ap.add_argument("--sweep", action="store_true", help="also time the forced tile variants (knob conv = 4 / 5 / 6 / 15) and the forced v9 wave-tile widths")
+    ap.add_argument("--sweep", action="store_true", help="also time the forced tile variants (knob conv = 4 / 5 / 6 / 15) and the forced v10 wave-tile widths")
     args = ap.parse_args()
     from yolov3_amd import ops
 
@@ -81,13 +81,13 @@ def main():
             rv = ops.View.alloc(n, ho, wo, cout, dtype, dev)
             rv.buf.copy_(torch.randn(rv.buf.numel(), generator=g).to(dev).to(dtype))
         flops = 2.0 * n * ho * wo * cout * cin * k * k
-        arms = [("nows", None, {"conv_v9": 0, "conv_v10": 0}), ("no v9/v10", ws, {"conv_v9": 0, "conv_v10": 0}), ("v9", ws, {"conv_v10": 0}), ("auto", ws, {})]
+        arms = [("nows", None, {"conv_v10": 0}), ("no v10", ws, {"conv_v10": 0}), ("auto", ws, {})]
         if args.arms:
             arms = [(a, ws, dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in a.split(",") if kv)) for a in args.arms.split(";")]
         if args.sweep:
-            arms += [(f"conv={v}", None, {"conv": v, "conv_v9": 0}) for v in (4, 6, 15)]
+            arms += [(f"conv={v}", None, {"conv": v, "conv_v10": 0}) for v in (4, 6, 15)]
             if k == 3 and s == 1 and cout % 256 == 0:
-                arms += [(f"v9 mp{m}", ws, {"conv_v9": 2, "v9_mp": m}) for m in (6, 7, 8)]
+                arms += [(f"v10 mp{m}", ws, {"conv_v10": 2, "v10_mp": m}) for m in (6, 7, 8)]
         times = {a[0]: [] for a in arms}
         outs = {}
         for rnd in range(args.rounds + 1):

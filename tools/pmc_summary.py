@@ -10,9 +10,7 @@ import sqlite3
 import sys
 
 NAMES = [  # (regex on the kernel symbol, bench.py name = "conv_igemm_" + the library's variant name)
-    (r"conv_igemm_v9_kernelIDF16_Li8E", "conv_igemm_v9_mp8"),
-    (r"conv_igemm_v9_kernelIDF16_Li7E", "conv_igemm_v9_mp7"),
-    (r"conv_igemm_v9_kernelIDF16_Li6E", "conv_igemm_v9_mp6"),
+    (r"conv_igemm_v10_kernelIDF16_", "conv_igemm_v10"),
     (r"conv_igemm_v7_kernelIDF16_", "conv_igemm_v7"),
     (r"conv_igemm_v6_kernelIDF16_", "conv_igemm_v6"),
     (r"conv_igemm_v3_kernelIDF16_Li64ELi2ELi2E", "conv_igemm_v3_bk64_128x128"),

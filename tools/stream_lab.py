@@ -48,7 +48,7 @@ def main():
         flops = 2.0 * n * h * w * cout * cin * k * k / (s * s)
         for arm in ("nows", "v7whole"):
             if arm == "v7whole":
-                ops.tune_set("v7_grid", -1); ops.tune_set("conv_v9", 0)
+                ops.tune_set("v7_grid", -1); ops.tune_set("conv_v10", 0)
             for S in (1, 2, 4, 8):
                 nb = n // S
                 xs, ys = [], []

@@ -42,7 +42,7 @@ def main():
         bias = torch.randn(cout, generator=g).to(dev)
         yv = ops.View.alloc(n, h, w, cout, torch.float16, dev)
         for sched in ("0",):
-            ops.tune_set("v7_grid", -1); ops.tune_set("conv_v9", 0)
+            ops.tune_set("v7_grid", -1); ops.tune_set("conv_v10", 0)
             tl = torch.zeros(64 * 8 * 8, dtype=torch.int64, device=dev)
             for _ in range(3):
                 ops.conv2d(xv, filt, bias, yv, 3, 1, True, None, workspace=ws)

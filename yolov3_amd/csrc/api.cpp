@@ -29,7 +29,7 @@ struct Knob {
 };
 const Knob kKnobs[] = {
     {"conv", 0}, {"conv_v7", 1}, {"v7_grid", 0}, {"v7_gc", 0}, {"conv_ahead", 3}, {"bn_nt_bytes", 128ll << 20},
-    {"wgrad", 0}, {"wgrad_xcd", 2}, {"dgrad_quad", 1}, {"spp_direct", 0}, {"conv_v9", 1}, {"v9_mp", 0}, {"v9_vp", 0}, {"wgrad_strip", 1}, {"conv_strip", 1},
+    {"wgrad", 0}, {"wgrad_xcd", 2}, {"dgrad_quad", 1}, {"spp_direct", 0}, {"wgrad_strip", 1}, {"conv_strip", 1},
     {"conv_v10", 1}, {"v10_mp", 0}, {"v10_blocks", 0},
 };
 constexpr int kCount = (int)(sizeof(kKnobs) / sizeof(kKnobs[0]));

@@ -60,10 +60,9 @@ struct ConvArgs {
     size_t ws_bytes;
     int v7_whole;  // conv_v7.h: blocks own whole tiles (no stream-K split)
     int v7_gc;     // conv_v7.h: filter-tile ranges per XCD group (1, 2, 4 or 8; divides n_ct)
-    int v9_vp, v9_npiece;   // conv_v9.h: valid pixels per tile, 1 KiB pieces of its halo patch
     int v10_B, v10_q, v10_r, v10_nt_hi, v10_nt_lo;   // conv_v10.h: blocks per filter tile, 32-pixel column blocks per block (+ 1 for the first r), tiles per block for the two run lengths
     int cs_strips, cs_T, cs_per;   // conv_strip.h: column strips per row, output rows in all, output rows per block
-    unsigned dv_pw_mul, dv_pw_sh, dv_h1_mul, dv_h1_sh;   // conv_v9.h: reciprocals of W + 2 and H + 1
+    unsigned dv_pw_mul, dv_pw_sh, dv_h1_mul, dv_h1_sh;   // conv_v10.h: reciprocals of W + 2 and H + 1
 #ifdef Y3_TIMELINE  // debug build only (tools/timeline.py): per-block wall-clock stamps
     unsigned long long* tl;
 #endif
@@ -1000,7 +999,6 @@ int launch_igemm(ConvArgs& a, hipStream_t st) {
 }
 
 #include "conv_v7.h"
-#include "conv_v9.h"
 #include "conv_v10.h"
 #include "conv_strip.h"
 
@@ -1014,7 +1012,6 @@ template <typename T> int dispatch_igemm(ConvArgs& a, hipStream_t st) {
         if (var == 3 && cs_plan(a, cs)) return launch_cs<T>(a, st);
     }
     if (var == 3 && v10_eligible(a)) return launch_v10<T>(a, st);
-    if (var == 3 && v9_eligible(a)) return launch_v9<T>(a, st);
     if (var == 3 && v7_eligible(a)) return launch_v7<T>(a, st);
     if (var >= 3 && a.Cout > 64 && c32) {
         // forced tiles (knob "conv", A/B runs)

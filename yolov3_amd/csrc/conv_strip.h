@@ -1,4 +1,4 @@
-// conv_strip.h -- included by conv.hip INSIDE its anonymous namespace, after conv_v9.h (shares ConvArgs, Mfma, epilogue_wave, fdiv, ...).
+// conv_strip.h -- included by conv.hip INSIDE its anonymous namespace, after conv_v10.h (shares ConvArgs, Mfma, epilogue_wave, fdiv, ...).
 //
 // 3x3 / pad 1 convolutions (stride 1, and 64 -> 128 at stride 2: layer 3) with FEW channels on LARGE maps (reference models/yolov3.yaml:17-22, Bottleneck.cv2 of layers 2 and 4 in training
 // mode, models/common.py:57-81,150-165, and their data gradients, which are the same convolution with the channel counts swapped):
@@ -15,7 +15,7 @@
 //     row is requested per output row (one K-step ahead) and the nine taps are nine views of the three resident rows (row buffer = kh, pixel shift = kw:
 //     instruction immediates).  Padding is free: out-of-image rows / columns are lanes with an out-of-range source offset (the descriptor lands zeros);
 //   * pixel rows have a pitch of (2 Cin + 16) bytes: the 32 lanes of a fragment read (consecutive pixels, 16 bytes each) fall on distinct bank quads, the
-//     conflict-free property conv_v9.h buys the same way (every 9th / 17th 16-byte slot of a request is a pad slot: an out-of-range lane);
+//     conflict-free property conv_v10.h buys the same way (every 9th / 17th 16-byte slot of a request is a pad slot: an out-of-range lane);
 //   * waves = MT pixel tiles x Cout / 32 filter tiles (x KS); per output row a wave issues 36 ds_read_b128 + as many MFMAs and one epilogue_wave call
 //     (bias, SiLU, NHWC transpose through its private LDS slice, 16-byte stores); BatchNorm statistics accumulate in 16 registers over the block's rows and
 //     leave as ONE row per wave (epilogue_stats_flush) instead of one per 64 pixels;

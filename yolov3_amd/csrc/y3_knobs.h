@@ -11,9 +11,6 @@ enum y3_knob_id {
     Y3K_WGRAD_XCD,      // "wgrad_xcd":   0 dispatch order; 1 a slice's tiles on one XCD for the 128-tile kernel; 2 + the 256-tile kernel; 3 all
     Y3K_DGRAD_QUAD,     // "dgrad_quad":  1 the four parity classes of a stride-2 data gradient in one launch; 0 four launches
     Y3K_SPP_DIRECT,     // "spp_direct":  1 SPP pools without the LDS pyramid
-    Y3K_CONV_V9,        // "conv_v9":     1 the one-wave-per-SIMD 3x3 kernel where a launch has at least a quarter round of tiles; 0 never; 2 every eligible shape
-    Y3K_V9_MP,          // "v9_mp":       0 the host's tile plan; 6 / 7 / 8 force the wave-tile width (32-pixel column blocks) of conv_v9.h (tests)
-    Y3K_V9_VP,          // "v9_vp":       0 the host's tile plan; > 0 force the valid pixels per tile (tests: tiles that cross rows and images)
     Y3K_WGRAD_STRIP,    // "wgrad_strip": 1 the strip-walking filter-gradient kernel for the 3x3 layers with 32 -> 64 / 64 -> 128 channels (wgrad_strip.h); 0 never; 2 also small launches; N > 2: N K-steps per block (tests)
     Y3K_CONV_STRIP,     // "conv_strip":  1 the strip-walking 3x3 kernel with register-resident filters for 32 -> 64 / 64 -> 32 / 64 -> 128 channels (conv_strip.h); 0 never; 2 also small launches; N > 2: N rows per block (tests)
     Y3K_CONV_V10,       // "conv_v10":    1 the persistent one-wave-per-SIMD 3x3 kernel with register-resident filter fragments (conv_v10.h) for Cin >= 128 at a quarter round of tiles or more; 0 never; 2 every eligible shape
