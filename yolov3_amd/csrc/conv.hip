@@ -169,7 +169,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // during the exp/rcp pass; a register-only variant with 32-byte runs lost on the residual layers: profiles/r01_conv_timeline.md.)
 // STAT_ACC (conv_strip.h: a wave calls this once per output row of its strip): the statistics are added to the caller's 16 registers `sacc` (8 sums, 8 sums of
 // squares of the lane's 8 filters) instead of being written; epilogue_stats_flush writes ONE row for all the calls.
-template <typename T, int MC, int MP, bool STAT_ACC = false>
+// IDENT (conv_v10.h: stride 1, no upsample scatter, no parity-class output): the output pixel index IS the GEMM column m, so the lane's store offsets are plain
+// arithmetic on m -- no (image, row, column) decomposition, no 64-bit products, no ds_bpermute from the MFMA layout to the store layout.
+template <typename T, int MC, int MP, bool STAT_ACC = false, bool IDENT = false>
 Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MP], unsigned char* wl, int c_base, int m_base, int lane, int stat_row = -1, int m_end = 0x7fffffff,
                           float* sacc = nullptr) {
     typedef typename Mfma<T>::frag vec8;   // 8 x T = one 16-byte chunk
@@ -188,14 +190,16 @@ Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MP], unsigned cha
     // output pixel index of the MFMA pixels this lane owns (-1: beyond M or beyond the tile's valid pixels), then re-distributed to the store layout
     const int mlim = m_end < p.M ? m_end : p.M;
     int opx[MP];
+    if constexpr (!IDENT) {
 #pragma unroll
-    for (int b = 0; b < MP; ++b) {
-        const int m = m_base + b * 32 + frow;
-        const int mm = m < mlim ? m : 0;
-        int n, ho, wo;
-        pix_coords(mm, p, n, ho, wo);
-        const int o = p.ups ? ((n * p.Ho * 2 + 2 * ho) * (p.Wo * 2) + 2 * wo) : (int)out_pix(n, ho, wo, p);
-        opx[b] = m < mlim ? o : -1;
+        for (int b = 0; b < MP; ++b) {
+            const int m = m_base + b * 32 + frow;
+            const int mm = m < mlim ? m : 0;
+            int n, ho, wo;
+            pix_coords(mm, p, n, ho, wo);
+            const int o = p.ups ? ((n * p.Ho * 2 + 2 * ho) * (p.Wo * 2) + 2 * wo) : (int)out_pix(n, ho, wo, p);
+            opx[b] = m < mlim ? o : -1;
+        }
     }
     const int c = c_base + ch * 8;
     const bool cv = c + 8 <= p.Cout;
@@ -204,7 +208,13 @@ Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MP], unsigned cha
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int pl = i * PPI + rp;    // pixel (row of the slice) this lane stores in step i
-        const int spx = __builtin_amdgcn_ds_bpermute((pl & 31) << 2, opx[(i * PPI) / 32]);
+        int spx;
+        if constexpr (IDENT) {
+            const int m = m_base + pl;
+            spx = m < mlim ? m : -1;
+        } else {
+            spx = __builtin_amdgcn_ds_bpermute((pl & 31) << 2, opx[(i * PPI) / 32]);
+        }
         const bool ok = cv && spx >= 0;
         yoff[i] = ok ? (unsigned)(spx * p.ypitch + c) * 2u : OOB;
         if (has_res) rres[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, ok ? (unsigned)(spx * p.rpitch + c) * 2u : OOB, 0, 0);
@@ -245,32 +255,42 @@ Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MP], unsigned cha
     float st0[8], st1[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) { st0[q] = STAT_ACC ? sacc[q] : 0.0f; st1[q] = STAT_ACC ? sacc[8 + q] : 0.0f; }
+    // the read-back / store loop, one straight-line copy per kernel-uniform case (written with the tests inside the loop the compiler kept a branch per store:
+    // ~25 scalar branches and their mask arithmetic per pass)
+    auto drain = [&](auto STATS, auto RES, auto UPS) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int pl = i * PPI + rp;
-        vec8 ov = *(const vec8*)(wl + pl * RB + ((ch ^ swz<MC * 32>(pl)) << 4));
-        if (want_stats && yoff[i] != OOB) {
+        for (int i = 0; i < NI; ++i) {
+            const int pl = i * PPI + rp;
+            vec8 ov = *(const vec8*)(wl + pl * RB + ((ch ^ swz<MC * 32>(pl)) << 4));
+            if constexpr (decltype(STATS)::value) {
+                if (yoff[i] != OOB) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { const float f = to_f32<T>(ov[q]); st0[q] += f; st1[q] += f * f; }
+                    for (int q = 0; q < 8; ++q) { const float f = to_f32<T>(ov[q]); st0[q] += f; st1[q] += f * f; }
+                }
+            }
+            if constexpr (decltype(RES)::value) {   // x + cv2(cv1(x)) in fp32, rounded once (what torch's half add does)
+                const vec8 rr = __builtin_bit_cast(vec8, rres[i]);
+                u32x4 sum;
+#pragma unroll
+                for (int q = 0; q < 8; q += 2) sum[q >> 1] = pack2<T>(to_f32<T>(ov[q]) + to_f32<T>(rr[q]), to_f32<T>(ov[q + 1]) + to_f32<T>(rr[q + 1]));
+                ov = __builtin_bit_cast(vec8, sum);
+            }
+            const u32x4 raw = __builtin_bit_cast(u32x4, ov);
+            if constexpr (!decltype(UPS)::value) {
+                __builtin_amdgcn_raw_buffer_store_b128(raw, rsrc_y, yoff[i], 0, 0);
+            } else {
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx)
+                        __builtin_amdgcn_raw_buffer_store_b128(raw, rsrc_y, yoff[i] == OOB ? OOB : yoff[i] + (unsigned)((dy * p.Wo * 2 + dx) * p.ypitch) * 2u, 0, 0);
+            }
         }
-        if (has_res) {   // x + cv2(cv1(x)) in fp32, rounded once (what torch's half add does)
-            const vec8 rr = __builtin_bit_cast(vec8, rres[i]);
-            u32x4 sum;
-#pragma unroll
-            for (int q = 0; q < 8; q += 2) sum[q >> 1] = pack2<T>(to_f32<T>(ov[q]) + to_f32<T>(rr[q]), to_f32<T>(ov[q + 1]) + to_f32<T>(rr[q + 1]));
-            ov = __builtin_bit_cast(vec8, sum);
-        }
-        const u32x4 raw = __builtin_bit_cast(u32x4, ov);
-        if (!p.ups) {
-            __builtin_amdgcn_raw_buffer_store_b128(raw, rsrc_y, yoff[i], 0, 0);
-        } else {
-#pragma unroll
-            for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 2; ++dx)
-                    __builtin_amdgcn_raw_buffer_store_b128(raw, rsrc_y, yoff[i] == OOB ? OOB : yoff[i] + (unsigned)((dy * p.Wo * 2 + dx) * p.ypitch) * 2u, 0, 0);
-        }
-    }
+    };
+    if (!IDENT && p.ups) drain(std::false_type{}, std::false_type{}, std::true_type{});   // (the scatter form takes neither a residual nor statistics: conv_fwd_impl)
+    else if (want_stats) { if (has_res) drain(std::true_type{}, std::true_type{}, std::false_type{}); else drain(std::true_type{}, std::false_type{}, std::false_type{}); }
+    else if (has_res) drain(std::false_type{}, std::true_type{}, std::false_type{});
+    else drain(std::false_type{}, std::false_type{}, std::false_type{});
     if constexpr (STAT_ACC) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) { sacc[q] = st0[q]; sacc[8 + q] = st1[q]; }

@@ -34,7 +34,10 @@ static_assert(V10_LDS <= 163840, "the LDS of a CU");
 // conservative waits in front of the next requests -- profiles/r02_conv_v8.md): simm16 = vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14
 template <int N> Y3_DEV void v10_wait_vm() { __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14)); }
 
-template <typename T, int XQ>
+// ABL (tools/v10_ablate.py, -DY3_ABLATE builds only; 0 in the shipped library): the kernel without one of its parts, garbage results, only the launch
+// time means something.  1: no epilogue; 2: the epilogue with its stores and residual loads dropped by the descriptors' bounds check; 4: no MFMAs;
+// 5: no fragment reads, no filter loads, no patch requests (MFMAs + epilogue only); 6: no filter loads; 7: no pixel-fragment reads; 8: no patch requests
+template <typename T, int XQ, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void conv_igemm_v10_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int MC = 2;
@@ -188,12 +191,18 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_v10_kernel(const ConvArgs p
                 constexpr int ntap = (tap + 1) % 9, ndh = ntap / 3, ndw = ntap % 3;
                 // ---- phase 1: MFMAs of substep 0 | pixel fragments of substep 1, filter fragments of K-step s + 2 (ring slot (s + 2) % 3 = (tap + 2) % 3: 9 % 3 == 0)
 #pragma unroll
-                for (int b = 0; b < MP; ++b) B1[b] = *(const frag*)(smem + bb[dh][b] + dw * V10_PITCH + 32);
-                a_load(IC<(tap + 2) % 3>{});
+                for (int b = 0; b < MP; ++b) {
+                    if constexpr (ABL == 5 || ABL == 7) asm volatile("" : "=v"(B1[b]));
+                    else B1[b] = *(const frag*)(smem + bb[dh][b] + dw * V10_PITCH + 32);
+                }
+                if constexpr (ABL != 5 && ABL != 6) a_load(IC<(tap + 2) % 3>{});
 #pragma unroll
                 for (int a = 0; a < MC; ++a)
 #pragma unroll
-                    for (int b = 0; b < MP; ++b) acc[a][b] = Mfma<T>::run(__builtin_bit_cast(frag, Ar[tap % 3][a]), B0[b], acc[a][b]);
+                    for (int b = 0; b < MP; ++b) {
+                        if constexpr (ABL == 4) asm volatile("" :: "v"(Ar[tap % 3][a]), "v"(B0[b]));
+                        else acc[a][b] = Mfma<T>::run(__builtin_bit_cast(frag, Ar[tap % 3][a]), B0[b], acc[a][b]);
+                    }
                 {
 #pragma unroll
                     for (int i = 0; i < MP; ++i) {
@@ -223,15 +232,21 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_v10_kernel(const ConvArgs p
                     bufd = -bufd;
                 }
 #pragma unroll
-                for (int b = 0; b < MP; ++b) B0[b] = *(const frag*)(smem + bb[ndh][b] + ndw * V10_PITCH);
-                if constexpr (tap < 7) {
+                for (int b = 0; b < MP; ++b) {
+                    if constexpr (ABL == 5 || ABL == 7) asm volatile("" : "=v"(B0[b]));
+                    else B0[b] = *(const frag*)(smem + bb[ndh][b] + ndw * V10_PITCH);
+                }
+                if constexpr (tap < 7 && ABL != 5 && ABL != 8) {
 #pragma unroll
                     for (int x = 0; x < XQ; ++x) dma_x(tap * XQ + x, cbyte, nbuf, np_req, live);
                 }
 #pragma unroll
                 for (int a = 0; a < MC; ++a)
 #pragma unroll
-                    for (int b = 0; b < MP; ++b) acc[a][b] = Mfma<T>::run(__builtin_bit_cast(frag, Ar[tap % 3][2 + a]), B1[b], acc[a][b]);
+                    for (int b = 0; b < MP; ++b) {
+                        if constexpr (ABL == 4) asm volatile("" :: "v"(Ar[tap % 3][2 + a]), "v"(B1[b]));
+                        else acc[a][b] = Mfma<T>::run(__builtin_bit_cast(frag, Ar[tap % 3][2 + a]), B1[b], acc[a][b]);
+                    }
                 {
 #pragma unroll
                     for (int i = 0; i < MP; ++i) {
@@ -253,9 +268,17 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_v10_kernel(const ConvArgs p
         } while (++cb < ncb);
 
         // ---- epilogue: passes of 64 pixels through the wave's own transpose slice (nothing else lives there: the patch of the next tile keeps landing)
+        if constexpr (ABL == 1) {   // keep the accumulators alive, store nothing
+#pragma unroll
+            for (int a = 0; a < MC; ++a)
+#pragma unroll
+                for (int b = 0; b < MP; ++b) asm volatile("" :: "v"(acc[a][b]));
+            return;
+        }
         unsigned char* slice = smem + V10_SLICE + wv * 8192;
         int lane_e = lane0;   // (again opaque: the store pattern is derived here, after the K loop, not kept alive through it)
         asm volatile("" : "+v"(lane_e));
+        auto passes = [&](const ConvArgs& pe) {
 #pragma unroll
         for (int hb = 0; hb < NPASS; ++hb) {
             if constexpr (MP % 2 == 1) {
@@ -263,7 +286,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_v10_kernel(const ConvArgs p
                     f32x16 part[MC][1];
 #pragma unroll
                     for (int a = 0; a < MC; ++a) part[a][0] = acc[a][MP - 1];
-                    epilogue_wave<T, MC, 1>(p, part, slice, ct * 256 + wv * MC * 32, m0 + hb * 64, lane_e, stat_row0 + hb, m1);
+                    epilogue_wave<T, MC, 1, false, true>(pe, part, slice, ct * 256 + wv * MC * 32, m0 + hb * 64, lane_e, stat_row0 + hb, m1);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     continue;
@@ -272,9 +295,17 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_v10_kernel(const ConvArgs p
             f32x16 part[MC][2];
 #pragma unroll
             for (int a = 0; a < MC; ++a) { part[a][0] = acc[a][2 * hb]; part[a][1] = acc[a][2 * hb + 1]; }
-            epilogue_wave<T, MC, 2>(p, part, slice, ct * 256 + wv * MC * 32, m0 + hb * 64, lane_e, stat_row0 + hb, m1);
+            epilogue_wave<T, MC, 2, false, true>(pe, part, slice, ct * 256 + wv * MC * 32, m0 + hb * 64, lane_e, stat_row0 + hb, m1);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();   // the slice is private to the wave: its reads of one pass precede the writes of the next
+        }
+        };
+        if constexpr (ABL == 2) {   // lab: every store / residual load out of range
+            ConvArgs q = p;
+            q.y_bytes = 0; q.r_bytes = 0;
+            passes(q);
+        } else {
+            passes(p);
         }
         // a tile owns four statistics rows (one per 64-pixel pass of the widest body): the passes this body does not have are zero rows
         if (p.stats != nullptr && NPASS < 4 && lane_e < 8) {
@@ -384,6 +415,37 @@ template <typename T> int launch_v10(ConvArgs& a, hipStream_t st) {
     g_last_variant = "v10";
     if (a.dry) return 0;
     const dim3 grid((unsigned)(a.n_ct * pl.B)), block(256);
+#ifdef Y3_ABLATE
+    if (const char* e = getenv("Y3_V10_ABL"); e && std::is_same<T, f16_t>::value) {   // lab build only (f16 instantiations)
+        typedef f16_t T;
+        const int abl = atoi(e);
+        if (pl.xq == 2) {
+            switch (abl) {
+                case 1: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, 1>), grid, block, 0, st, a); break;
+                case 2: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, 2>), grid, block, 0, st, a); break;
+                case 4: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, 4>), grid, block, 0, st, a); break;
+                case 5: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, 5>), grid, block, 0, st, a); break;
+                case 6: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, 6>), grid, block, 0, st, a); break;
+                case 7: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, 7>), grid, block, 0, st, a); break;
+                case 8: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, 8>), grid, block, 0, st, a); break;
+                default: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, 0>), grid, block, 0, st, a); break;
+            }
+        } else {
+            switch (abl) {
+                case 1: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, 1>), grid, block, 0, st, a); break;
+                case 2: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, 2>), grid, block, 0, st, a); break;
+                case 4: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, 4>), grid, block, 0, st, a); break;
+                case 5: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, 5>), grid, block, 0, st, a); break;
+                case 6: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, 6>), grid, block, 0, st, a); break;
+                case 7: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, 7>), grid, block, 0, st, a); break;
+                case 8: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, 8>), grid, block, 0, st, a); break;
+                default: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, 0>), grid, block, 0, st, a); break;
+            }
+        }
+        Y3_CHECK_LAUNCH();
+        return 0;
+    }
+#endif
     if (pl.xq == 2) hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1>), grid, block, 0, st, a);
     Y3_CHECK_LAUNCH();
