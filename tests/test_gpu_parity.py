@@ -223,8 +223,8 @@ def test_conv_v7_grid_sweep(dev, tune):
 # bench actually runs (multi-round grids, XCD remap at 200-3200 blocks, ragged last tiles at M = 12800 / 51200 / 204800).
 BASELINE_CONV_CASES = [
     # name, (n,h,w,cin,cout,k,s), kwargs, variant with workspace
-    ("L6cv2_128_256_80", (32, 80, 80, 128, 256, 3, 1), {"residual": True}, "v10"),
-    ("L8cv2_256_512_40", (32, 40, 40, 256, 512, 3, 1), {"residual": True}, "v10"),
+    ("L6cv2_128_256_80", (32, 80, 80, 128, 256, 3, 1), {"residual": True}, "v10h"),
+    ("L8cv2_256_512_40", (32, 40, 40, 256, 512, 3, 1), {"residual": True}, "v10h"),
     ("L10cv2_512_1024_20", (32, 20, 20, 512, 1024, 3, 1), {"residual": True}, "v10"),
     ("L7_256_512_s2", (32, 80, 80, 256, 512, 3, 2), {}, "v6"),
     ("L9_512_1024_s2", (32, 40, 40, 512, 1024, 3, 2), {}, "v6"),
@@ -237,7 +237,7 @@ BASELINE_CONV_CASES = [
     ("head255_80", (32, 80, 80, 256, 256, 1, 1), {"cout_real": 255, "act": False}, "v3_bk32_128x128"),
     ("head1110_40_c5", (8, 40, 40, 1024, 1112, 1, 1), {"cout_real": 1110, "act": False}, None),
     ("c5_128_256_160", (8, 160, 160, 128, 256, 3, 1), {"residual": True}, "v10"),
-    ("c5_256_512_80", (8, 80, 80, 256, 512, 3, 1), {"residual": True}, "v10"),
+    ("c5_256_512_80", (8, 80, 80, 256, 512, 3, 1), {"residual": True}, "v10h"),
     ("ups_route_20", (32, 20, 20, 512, 256, 1, 1), {"ups": True}, None),
 ]
 
@@ -673,7 +673,7 @@ def test_model_half_vs_fp32_oracle_benchmark_shapes(dev, name, hw, bs, dtype):
     torch.cuda.synchronize()
     plan = next(iter(m._plans.values()))
     variants = {plan.conv_variant(ln) for ln in plan.launches if ln.flops and not ln.kernel}
-    assert any(v == "v7" or v == "v10" for v in variants) and "direct" not in variants, variants
+    assert any(v in ("v7", "v10", "v10h") for v in variants) and "direct" not in variants, variants
     with torch.no_grad():
         refp, refraw = yo.forward(layers, save, sd, x[: min(bs, 4)], strides, training=False)   # the oracle on the first images (CPU time)
     b = HALF_BOUNDS[dtype]
@@ -2096,9 +2096,9 @@ BENCH_TRAIN_CONV_CASES = [
     # name, kind, (n, h, w, cin, cout, k, s) of the FORWARD layer, variant the dispatcher must pick for that launch.  kind: "fwd_stats" = the training
     # forward (no activation, BatchNorm statistics rows from the epilogue), "dgrad" = the data gradient through the forward kernel on the flipped bank
     # (accumulating into dx through the residual port), "dgrad_s2" = the four parity classes of a stride-2 data gradient
-    ("L8cv2_fwd_stats", "fwd_stats", (64, 40, 40, 256, 512, 3, 1), "v10"),
+    ("L8cv2_fwd_stats", "fwd_stats", (64, 40, 40, 256, 512, 3, 1), "v10h"),
     ("L10cv2_fwd_stats", "fwd_stats", (64, 20, 20, 512, 1024, 3, 1), "v10"),
-    ("L6cv2_fwd_stats", "fwd_stats", (64, 80, 80, 128, 256, 3, 1), "v10"),
+    ("L6cv2_fwd_stats", "fwd_stats", (64, 80, 80, 128, 256, 3, 1), "v10h"),
     ("L8cv2_dgrad", "dgrad", (64, 40, 40, 256, 512, 3, 1), "v10"),
     ("L10cv2_dgrad", "dgrad", (64, 20, 20, 512, 1024, 3, 1), "v10"),
     ("L4cv2_fwd_stats", "fwd_stats", (64, 160, 160, 64, 128, 3, 1), "strip"),
@@ -2434,27 +2434,32 @@ V10_CASES = [
 ]
 
 
+@pytest.mark.parametrize("half", [0, 1], ids=["one_block_per_cu", "two_half_blocks_per_cu"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("name,shape,kw,knobs", V10_CASES, ids=[c[0] for c in V10_CASES])
-def test_conv_v10_vs_fp32_reference(dev, tune, dtype, name, shape, kw, knobs):
+def test_conv_v10_vs_fp32_reference(dev, tune, dtype, name, shape, kw, knobs, half):
     """conv_v10.h (persistent blocks over 32-pixel column blocks, bodies of 6 / 7 / 8 column blocks, filter fragments by register loads from the
     fragment-ordered copy of the bank, the next tile's first patch requested under the last channel block) against fp32 conv2d on the same rounded
     operands: tiles that cross rows and image boundaries, edge taps, 1 .. 8 channel blocks (odd counts flip the patch-buffer parity from tile to
     tile), one and two request slots per tap, single-column-block tiles, ragged tails, residual / sliced outputs; repeated launches bit-identical."""
     mp, blocks = knobs
     tune("conv_v10", 2)
-    tune("v10_mp", mp)
+    tune("v10_half", half)   # 1: two blocks per CU with bodies of 3 / 4 column blocks and 32-pixel epilogue passes (the same kernel source, other geometry)
+    tune("v10_mp", {0: 0, 6: 3, 7: 4, 8: 4}[mp] if half else mp)
     tune("v10_blocks", blocks)
-    out, ref = run_conv(dev, dtype, *shape, algo=1, ws=True, expect="v10", repeat=2, **kw)
+    want = "v10h" if half and not (name == "w160_mp6") else "v10"   # (160-pixel rows: the halo patch of even 3 column blocks exceeds a half block's 31 KiB buffer)
+    out, ref = run_conv(dev, dtype, *shape, algo=1, ws=True, expect=want, repeat=2, **kw)
     _conv_tol_check(name, dtype, out, ref)
 
 
-def test_conv_v10_statistics_rows(dev, tune):
+@pytest.mark.parametrize("half", [0, 1])
+def test_conv_v10_statistics_rows(dev, tune, half):
     """BatchNorm statistics rows from the v10 epilogue (four rows per tile: one per 64-pixel pass, zero rows for the passes a narrower body does not
     have; only valid pixels counted): their fp64 sum equals the statistics of the stored tensor."""
     _lib, ops = _ops()
     tune("conv_v10", 2)
     tune("v10_blocks", 3)
+    tune("v10_half", half)
     n, h, w, cin, cout, k, s = 5, 20, 20, 64, 256, 3, 1
     dtype = torch.float16
     g = torch.Generator().manual_seed(4)
@@ -2466,9 +2471,9 @@ def test_conv_v10_statistics_rows(dev, tune):
     zb = torch.zeros(cout, device=dev)
     y1 = ops.View.alloc(n, h, w, cout, dtype, dev)
     rows = ops.conv2d_stats_rows(xv, y1, k, s)
-    assert rows == 9 * 4, rows   # 63 column blocks over 3 blocks: runs of 21 = 3 tiles of 7
+    assert rows == (18 if half else 9) * 4, rows   # 63 column blocks over 3 blocks: runs of 21 = 3 tiles of 7 (half-size blocks: 6 tiles of 4 / 3)
     buf = torch.full((rows * 2 * cout,), float("nan"), device=dev)
-    assert ops.conv2d_stats(xv, filt, zb, y1, k, s, buf, rows) == rows and ops.last_conv_variant() == "v10"
+    assert ops.conv2d_stats(xv, filt, zb, y1, k, s, buf, rows) == rows and ops.last_conv_variant() == ("v10h" if half else "v10")
     torch.cuda.synchronize()
     u = y1.as_nhwc().double().cpu().reshape(-1, cout)
     tot = buf.view(rows, cout, 2).double().sum(0).cpu()

@@ -321,12 +321,14 @@ def test_conv_dispatch_variant_names_and_stat_rows():
     assert ws == 64 + 4096 + 2 * 256 * 256 * 256 * 4
     # (pixels per tile, statistics rows per tile); v10 cuts the pixel axis into 32-pixel column blocks and a block's run of them into tiles of 6 / 7 / 8 (conv_v10.h)
     tile_px = {"v7": (256, 4), "v6": (256, 2), "v3_bk64_128x128": (128, 2), "v3_bk32_128x128": (128, 2), "v3_bk32_128x256": (256, 2), "v3_bk32_64x256": (256, 2),
-               "v10": (0, 4), "strip": (0, 0)}
+               "v10": (0, 4), "v10h": (0, 4), "strip": (0, 0)}
     shapes = [(32, 64, 3, 2, 640), (64, 32, 1, 1, 320), (32, 64, 3, 1, 320), (64, 128, 3, 2, 320), (128, 64, 1, 1, 160), (64, 128, 3, 1, 160), (128, 256, 3, 2, 160),
               (256, 128, 1, 1, 80), (128, 256, 3, 1, 80), (256, 512, 3, 2, 80), (512, 256, 1, 1, 40), (256, 512, 3, 1, 40), (512, 1024, 3, 2, 40), (1024, 512, 1, 1, 20),
               (512, 1024, 3, 1, 20), (768, 256, 1, 1, 40), (384, 128, 1, 1, 80), (256, 256, 1, 1, 80), (512, 256, 1, 1, 20)]
     v10_shapes = {(128, 256, 3, 1, 80), (256, 512, 3, 1, 40), (512, 1024, 3, 1, 20)}   # 3x3, stride 1, cin >= 128, cout % 256 == 0: the persistent one-wave-per-SIMD kernel (needs no workspace)
-    v10_tiles = {(32, 80): 256 * 4, (32, 40): 128 * 2, (32, 20): 64 * 1, (64, 80): 256 * 7, (64, 40): 128 * 4, (64, 20): 64 * 2}   # blocks per filter tile x tiles per block (runs of 25 / 12.5 / 6.25 and 50 / 25 / 12.5 column blocks)
+    # tiles per filter tile = sum over its blocks of the tiles per block.  Cin <= 256: two half-size blocks per CU with tiles of 3 / 4 column blocks ("v10h": runs of
+    # 12.5 / 6.25 and 25 / 12.5 column blocks); 512 -> 1024: one block per CU with tiles of 6 / 7 / 8 (runs of 6.25 / 12.5)
+    v10_tiles = {(32, 80): 256 * 4 + 256 * 3, (32, 40): 256 * 2, (32, 20): 64 * 1, (64, 80): 512 * 7, (64, 40): 128 * 4 + 128 * 3, (64, 20): 64 * 2}
     for bs in (32, 64):
         for cin, cout, k, s, hin in shapes:
             ho = (hin + 2 * (k // 2) - k) // s + 1
@@ -337,7 +339,7 @@ def test_conv_dispatch_variant_names_and_stat_rows():
             assert L.y3_conv2d_fwd_variant(C.byref(d), C.byref(x), C.byref(y), 0, 0, name, 64) == 0, L.y3_last_error()
             plain = name.value.decode()
             assert plain in tile_px and plain != "v7", plain
-            assert (plain == "v10") == ((cin, cout, k, s, hin) in v10_shapes), (cin, cout, k, s, hin, plain)
+            assert (plain in ("v10", "v10h")) == ((cin, cout, k, s, hin) in v10_shapes) and (plain == "v10h") == ((cin, cout, k, s, hin) in v10_shapes and cin <= 256), (cin, cout, k, s, hin, plain)
             rows = L.y3_conv2d_fwd_stats_rows(C.byref(d), C.byref(x), C.byref(y))
             assert rows > 0, L.y3_last_error()
             tp, per = tile_px[plain]
@@ -355,7 +357,7 @@ def test_conv_dispatch_variant_names_and_stat_rows():
                 finally:
                     L.y3_tune_reset()
                 continue
-            if plain == "v10":
+            if plain in ("v10", "v10h"):
                 assert rows == v10_tiles[(bs, hin)] * per, f"{cin}->{cout} @{hin} bs{bs}: {rows} rows"
             else:
                 assert rows == -(-m // tp) * per, f"{cin}->{cout} k{k} s{s} @{hin} bs{bs}: {rows} rows for {plain}"

@@ -7,7 +7,8 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "TCC_H
 done
 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/pmc_stats -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train > $R/gpurun_out/rocprof_stats.log 2>&1
 cd $R
-python tools/pmc_summary.py gpurun_out gpurun_out/pmc_summary_final.json
+grep -a '^{"metric"' gpurun_out/rocprof_stats.log | tail -1 > gpurun_out/pmc_bench_line.json
+python tools/pmc_summary.py gpurun_out gpurun_out/pmc_summary_final.json gpurun_out/pmc_bench_line.json
 python tools/kstats.py gpurun_out/pmc_stats "rocprofv3 --kernel-trace --stats : python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train (MI355X)" > gpurun_out/bench_kernel_stats_final.md
 head -12 gpurun_out/bench_kernel_stats_final.md
-rm -rf gpurun_out/pmc_*/
+rm -rf gpurun_out/pmc_*/ gpurun_out/pmc_stats

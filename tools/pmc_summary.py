@@ -1,5 +1,10 @@
 """Fold the rocprofv3 --pmc passes of tools/gpu_pmc.sh into profiles/<round>_pmc_summary.json (keys = bench.py's kernel-group names:
-"conv_igemm_" + y3_conv2d_fwd_variant).  python tools/pmc_summary.py <dir with pmc_*/ sub-dirs> <out.json>
+"conv_igemm_" + y3_conv2d_fwd_variant).  python tools/pmc_summary.py <dir with pmc_*/ sub-dirs> <out.json> [<bench.json of the same tree>]
+
+Every pass also carries the kernel-trace duration of its own dispatches: it is stored per counter group (`pass_avg_us`) next to the duration of the
+un-instrumented `--stats` run (`stats_avg_us`, the pmc_stats/ directory), and a pass whose duration deviates from that by more than 10 % is REFUSED
+(listed under `refused_passes`, its counters dropped): round 3 quoted an MFMA-busy fraction from a pass that ran 30 % slower than the kernel does.
+With a bench.py line the MFMA-busy cycles are split into useful (the launch's algorithmic FLOPs / 32768 per MFMA x 32 cycles) and padded.
 
 Per MI355X_MICROARCH.md (HBM / rocprofv3 section): one counter group per pass; FETCH_SIZE / WRITE_SIZE are reported in KiB;
 on gfx950 FETCH_SIZE counts 128-byte requests as 64 B -> read bytes = FETCH_SIZE x 1024 x 2; WRITE_SIZE x 1024 as is."""
@@ -26,9 +31,28 @@ NAMES = [  # (regex on the kernel symbol, bench.py name = "conv_igemm_" + the li
 ]
 
 
-def main(root, out):
+def _avg_durations(db):
+    """average kernel-trace duration (us) per bench.py kernel name over the dispatches of this database"""
+    acc = {}
+    for k, n, tot in db.execute("select name, count(*), sum(duration) from kernels group by name"):
+        for pat, name in NAMES:
+            if re.search(pat, k):
+                a = acc.setdefault(name, [0, 0.0])
+                a[0] += n
+                a[1] += tot
+                break
+    return {k: v[1] / v[0] / 1e3 for k, v in acc.items() if v[0]}
+
+
+def main(root, out, bench=None):
     res = {}
+    stats_us = {}
+    for d in glob.glob(root + "/pmc_stats/**/*.db", recursive=True):
+        stats_us = _avg_durations(sqlite3.connect(d))
+    refused = []
     for d in sorted(glob.glob(root + "/pmc_*/")):
+        if d.rstrip("/").endswith("pmc_stats"):
+            continue
         dbs = glob.glob(d + "**/*.db", recursive=True)
         if not dbs:
             continue
@@ -36,17 +60,31 @@ def main(root, out):
         tables = [r[0] for r in db.execute("select name from sqlite_master where type in ('table','view')")]
         if "counters_collection" not in tables:
             continue
+        pass_us = _avg_durations(db)
         for k, c, n, s, a in db.execute("select kernel_name, counter_name, count(*), sum(value), avg(value) from counters_collection group by kernel_name, counter_name"):
             for pat, name in NAMES:
                 if re.search(pat, k):
+                    if name in stats_us and name in pass_us and abs(pass_us[name] / stats_us[name] - 1.0) > 0.10:
+                        r = {"kernel": name, "counter": c, "pass_avg_us": round(pass_us[name], 2), "stats_avg_us": round(stats_us[name], 2)}
+                        if r not in refused:
+                            refused.append(r)
+                        break
                     rec = res.setdefault(name, {"symbol": re.sub(r"\(anonymous namespace\)::|_ZN12_GLOBAL__N_1\d+", "", k)[:90]})
                     prev = rec.get(c)
                     if prev:   # several symbols under one name (template instances): dispatch-weighted mean
                         tot = prev["dispatches"] + n
-                        rec[c] = {"dispatches": tot, "avg": (prev["avg"] * prev["dispatches"] + a * n) / tot}
+                        rec[c] = {"dispatches": tot, "avg": (prev["avg"] * prev["dispatches"] + a * n) / tot, "pass_avg_us": round(pass_us.get(name, 0.0), 2)}
                     else:
-                        rec[c] = {"dispatches": n, "avg": a}
+                        rec[c] = {"dispatches": n, "avg": a, "pass_avg_us": round(pass_us.get(name, 0.0), 2)}
+                    if name in stats_us:
+                        rec["stats_avg_us"] = round(stats_us[name], 2)
                     break
+    bj = None
+    if bench:
+        try:
+            bj = json.loads(open(bench).read().strip().splitlines()[-1])
+        except Exception:
+            bj = None
     for name, rec in res.items():
         if "FETCH_SIZE" in rec and "WRITE_SIZE" in rec:
             rec["hbm_read_bytes_per_launch"] = rec["FETCH_SIZE"]["avg"] * 1024 * 2
@@ -57,8 +95,18 @@ def main(root, out):
             rec["l2_hit_rate"] = h / (h + m) if h + m else None
         if "SQ_VALU_MFMA_BUSY_CYCLES" in rec and "GRBM_GUI_ACTIVE" in rec and rec["GRBM_GUI_ACTIVE"]["avg"]:
             # busy cycles are summed over the chip's 1024 SIMDs (32 per v_mfma_f32_32x32x16: checked against the launch FLOPs);
-            # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (value / 8 = the dispatch's wall cycles: 94 us -> 234k)
-            rec["mfma_busy_frac_of_simd_cycles"] = rec["SQ_VALU_MFMA_BUSY_CYCLES"]["avg"] / (rec["GRBM_GUI_ACTIVE"]["avg"] / 8 * 1024)
+            # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (value / 8 = the dispatch's wall cycles)
+            wall = rec["GRBM_GUI_ACTIVE"]["avg"] / 8
+            rec["mfma_busy_frac_of_simd_cycles"] = rec["SQ_VALU_MFMA_BUSY_CYCLES"]["avg"] / (wall * 1024)
+            pus = rec["GRBM_GUI_ACTIVE"].get("pass_avg_us")
+            if pus:
+                rec["grbm_cycles_per_us_of_the_pass"] = wall / pus   # = the shader clock in MHz the pass ran at
+            if bj and bj.get("roofline", {}).get("kernel", "").split("/")[0] == name:
+                useful = bj["roofline"]["algorithmic_gflop_per_launch"] * 1e9 / 32768.0 * 32.0   # cycles of the MFMAs the launch's algorithmic FLOPs need
+                rec["mfma_busy_useful_frac"] = useful / (wall * 1024)
+                rec["mfma_busy_padded_frac"] = rec["mfma_busy_frac_of_simd_cycles"] - rec["mfma_busy_useful_frac"]
+    if refused:
+        res["refused_passes"] = refused
     res["_doc"] = ("rocprofv3 --kernel-trace --pmc <one counter group per pass> -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline (MI355X, tools/gpu_pmc.sh + "
                    "tools/pmc_summary.py).  Averages per dispatch of the kernel SYMBOL (all filter sizes that symbol serves).  FETCH_SIZE/WRITE_SIZE in KiB as reported; "
                    "hbm_read_bytes applies the gfx950 correction of MI355X_MICROARCH.md (128-B requests counted as 64 B -> x2).  Keys are bench.py's kernel-instance names.")
@@ -69,4 +117,4 @@ def main(root, out):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)

@@ -217,7 +217,18 @@ Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MP], unsigned cha
         }
         const bool ok = cv && spx >= 0;
         yoff[i] = ok ? (unsigned)(spx * p.ypitch + c) * 2u : OOB;
-        if (has_res) rres[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, ok ? (unsigned)(spx * p.rpitch + c) * 2u : OOB, 0, 0);
+        if constexpr (!IDENT) {
+            if (has_res) rres[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, ok ? (unsigned)(spx * p.rpitch + c) * 2u : OOB, 0, 0);
+        }
+    }
+    if constexpr (IDENT) {   // (one uniform branch around the eight loads instead of one per load)
+        if (has_res) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int m = m_base + i * PPI + rp;
+                rres[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, yoff[i] != OOB ? (unsigned)(m * p.rpitch + c) * 2u : OOB, 0, 0);
+            }
+        }
     }
 
     // activation on whole accumulators (straight-line transcendentals + packed fp32, y3_common.h), pairs of consecutive filters rounded to T
@@ -262,11 +273,10 @@ Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MP], unsigned cha
         for (int i = 0; i < NI; ++i) {
             const int pl = i * PPI + rp;
             vec8 ov = *(const vec8*)(wl + pl * RB + ((ch ^ swz<MC * 32>(pl)) << 4));
-            if constexpr (decltype(STATS)::value) {
-                if (yoff[i] != OOB) {
+            if constexpr (decltype(STATS)::value) {   // (select, not a divergent branch: pixels beyond the tile / the tensor count as zeros)
+                const bool live = yoff[i] != OOB;
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) { const float f = to_f32<T>(ov[q]); st0[q] += f; st1[q] += f * f; }
-                }
+                for (int q = 0; q < 8; ++q) { const float f = live ? to_f32<T>(ov[q]) : 0.0f; st0[q] += f; st1[q] += f * f; }
             }
             if constexpr (decltype(RES)::value) {   // x + cv2(cv1(x)) in fp32, rounded once (what torch's half add does)
                 const vec8 rr = __builtin_bit_cast(vec8, rres[i]);

@@ -22,13 +22,22 @@
 //
 // LDS (144 KiB, one block per CU): [2 x 54 KiB patch buffers][4 x 1 KiB dump slots for request slots with nothing to fetch][4 x 8 KiB epilogue slices].
 
-constexpr int V10_PB = 54 * 1024;
-constexpr int V10_DUMP = 2 * V10_PB;
-constexpr int V10_SLICE = V10_DUMP + 4 * 1024;
-constexpr int V10_LDS = V10_SLICE + 4 * 8192;
+// HALF = false: one block per CU, bodies of 6 / 7 / 8 column blocks, 64-pixel epilogue passes.  HALF = true: TWO blocks per CU (<= 256 registers and 80 KiB of
+// LDS each: the two waves of a SIMD belong to different blocks, so one block's epilogue -- VALU, LDS transpose, stores: nothing the matrix pipe does -- runs beside
+// the other block's K loop), bodies of 3 / 4 column blocks, 32-pixel epilogue passes.
+template <bool HALF> struct V10Geom {
+    static constexpr int PB = HALF ? 31 * 1024 : 54 * 1024;       // one patch buffer
+    static constexpr int DUMP = 2 * PB;                           // dump slot(s) for request slots with nothing to fetch
+    static constexpr int DUMP_BYTES = HALF ? 1024 : 4 * 1024;     // (HALF: one slot shared by the four waves -- garbage over garbage)
+    static constexpr int SLICE = DUMP + DUMP_BYTES;               // epilogue transpose slices, one per wave
+    static constexpr int SLICE_BYTES = HALF ? 4096 : 8192;        // 32 / 64 pixels x 64 filters
+    static constexpr int LDS = SLICE + 4 * SLICE_BYTES;
+    static constexpr int MAXPIECE = PB / 1024;
+    static constexpr int MP_LO = HALF ? 3 : 6, MP_HI = HALF ? 4 : 8;
+    static constexpr int PASS = HALF ? 1 : 2;                     // column blocks per epilogue pass
+};
 constexpr int V10_PITCH = 80;
-constexpr int V10_MAXPIECE = V10_PB / 1024;
-static_assert(V10_LDS <= 163840, "the LDS of a CU");
+static_assert(V10Geom<false>::LDS <= 163840 && V10Geom<true>::LDS <= 81920, "the LDS of a CU / half of it");
 
 // `s_waitcnt vmcnt(N)` through the builtin (the waitcnt pass parses it; an asm statement is invisible to it and it would add its own
 // conservative waits in front of the next requests -- profiles/r02_conv_v8.md): simm16 = vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14
@@ -37,14 +46,16 @@ template <int N> Y3_DEV void v10_wait_vm() { __builtin_amdgcn_s_waitcnt((N & 15)
 // ABL (tools/v10_ablate.py, -DY3_ABLATE builds only; 0 in the shipped library): the kernel without one of its parts, garbage results, only the launch
 // time means something.  1: no epilogue; 2: the epilogue with its stores and residual loads dropped by the descriptors' bounds check; 4: no MFMAs;
 // 5: no fragment reads, no filter loads, no patch requests (MFMAs + epilogue only); 6: no filter loads; 7: no pixel-fragment reads; 8: no patch requests
-template <typename T, int XQ, int ABL = 0>
-__global__ __launch_bounds__(256, 1) void conv_igemm_v10_kernel(const ConvArgs p) {
+template <typename T, int XQ, bool HALF, int ABL = 0>
+__global__ __launch_bounds__(256, HALF ? 2 : 1) void conv_igemm_v10_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int MC = 2;
     constexpr int NXP = 7 * XQ;   // patch request slots per wave and channel block: XQ in each of taps 0..6
     typedef typename Mfma<T>::frag frag;
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[V10_LDS];   // the ONLY LDS object
+    typedef V10Geom<HALF> G;
+    constexpr int V10_PB = G::PB, V10_DUMP = G::DUMP, V10_SLICE = G::SLICE;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[G::LDS];   // the ONLY LDS object
 
     const int tid = threadIdx.x;
     const int lane0 = tid & 63;
@@ -106,7 +117,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_v10_kernel(const ConvArgs p
     auto dma_x = [&](int i, int cbyte, int buf, int npiece, bool live) {
         const int q = i * 4 + wv;
         const bool go = live && q < npiece;
-        const int dst = go ? buf * V10_PB + q * 1024 : V10_DUMP + wv * 1024;
+        const int dst = go ? buf * V10_PB + q * 1024 : V10_DUMP + (HALF ? 0 : wv * 1024);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(smem + dst), 16, xsrc[i], cbyte, 0, 0);
     };
 
@@ -131,7 +142,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_v10_kernel(const ConvArgs p
     auto run_tile = [&](auto MPC, const int m0, const int m1, const int Qf, const int npiece, const int stat_row0, const bool has_next, const int nQf,
                         const int nnpiece) {
         constexpr int MP = decltype(MPC)::value;
-        constexpr int NPASS = (MP + 1) / 2;
+        constexpr int NPASS = (MP + G::PASS - 1) / G::PASS;
         // the lane id behind an opaque move: everything derived from it (fragment rows, patch offsets, the epilogue's store pattern) is re-derived per tile
         // instead of being hoisted out of the tile loop and spilled around the K loop (first cut: 170-200 spilled registers, each reload an exposed round
         // trip in the epilogue: +40 us per tile)
@@ -209,11 +220,13 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_v10_kernel(const ConvArgs p
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one LDS read
                     }
+                    constexpr int NV1 = MC * MP - MP < 4 ? MC * MP - MP : 4;   // (the 3-column-block body has 3 MFMAs left for the 4 loads)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
+                    for (int i = 0; i < NV1; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // one load
                     }
+                    if constexpr (4 - NV1 > 0) __builtin_amdgcn_sched_group_barrier(0x020, 4 - NV1, 0);
                     if constexpr (MC * MP - MP - 4 > 0) __builtin_amdgcn_sched_group_barrier(0x008, MC * MP - MP - 4, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -275,29 +288,31 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_v10_kernel(const ConvArgs p
                 for (int b = 0; b < MP; ++b) asm volatile("" :: "v"(acc[a][b]));
             return;
         }
-        unsigned char* slice = smem + V10_SLICE + wv * 8192;
+        unsigned char* slice = smem + V10_SLICE + wv * G::SLICE_BYTES;
         int lane_e = lane0;   // (again opaque: the store pattern is derived here, after the K loop, not kept alive through it)
         asm volatile("" : "+v"(lane_e));
         auto passes = [&](const ConvArgs& pe) {
 #pragma unroll
         for (int hb = 0; hb < NPASS; ++hb) {
-            if constexpr (MP % 2 == 1) {
-                if (hb == NPASS - 1) {
+            if constexpr (G::PASS == 1 || MP % 2 == 1) {
+                if (G::PASS == 1 || hb == NPASS - 1) {   // a 32-pixel pass
                     f32x16 part[MC][1];
 #pragma unroll
-                    for (int a = 0; a < MC; ++a) part[a][0] = acc[a][MP - 1];
-                    epilogue_wave<T, MC, 1, false, true>(pe, part, slice, ct * 256 + wv * MC * 32, m0 + hb * 64, lane_e, stat_row0 + hb, m1);
+                    for (int a = 0; a < MC; ++a) part[a][0] = acc[a][hb * G::PASS];
+                    epilogue_wave<T, MC, 1, false, true>(pe, part, slice, ct * 256 + wv * MC * 32, m0 + hb * G::PASS * 32, lane_e, stat_row0 + hb, m1);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     continue;
                 }
             }
-            f32x16 part[MC][2];
+            if constexpr (G::PASS == 2) {
+                f32x16 part[MC][2];
 #pragma unroll
-            for (int a = 0; a < MC; ++a) { part[a][0] = acc[a][2 * hb]; part[a][1] = acc[a][2 * hb + 1]; }
-            epilogue_wave<T, MC, 2, false, true>(pe, part, slice, ct * 256 + wv * MC * 32, m0 + hb * 64, lane_e, stat_row0 + hb, m1);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();   // the slice is private to the wave: its reads of one pass precede the writes of the next
+                for (int a = 0; a < MC; ++a) { part[a][0] = acc[a][2 * hb]; part[a][1] = acc[a][2 * hb + 1]; }
+                epilogue_wave<T, MC, 2, false, true>(pe, part, slice, ct * 256 + wv * MC * 32, m0 + hb * 64, lane_e, stat_row0 + hb, m1);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();   // the slice is private to the wave: its reads of one pass precede the writes of the next
+            }
         }
         };
         if constexpr (ABL == 2) {   // lab: every store / residual load out of range
@@ -337,9 +352,14 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_v10_kernel(const ConvArgs p
         if (has_next) tile_geom(t + 1, nm0, nm1, nQf, nnp);
         const int sz = tq + (t < tr ? 1 : 0);
         const int srow = (tile_base + t) * 4;
-        if (sz >= 8) run_tile(IC<8>{}, m0, m1, Qf, npiece, srow, has_next, nQf, nnp);
-        else if (sz == 7) run_tile(IC<7>{}, m0, m1, Qf, npiece, srow, has_next, nQf, nnp);
-        else run_tile(IC<6>{}, m0, m1, Qf, npiece, srow, has_next, nQf, nnp);
+        if constexpr (HALF) {
+            if (sz >= 4) run_tile(IC<4>{}, m0, m1, Qf, npiece, srow, has_next, nQf, nnp);
+            else run_tile(IC<3>{}, m0, m1, Qf, npiece, srow, has_next, nQf, nnp);
+        } else {
+            if (sz >= 8) run_tile(IC<8>{}, m0, m1, Qf, npiece, srow, has_next, nQf, nnp);
+            else if (sz == 7) run_tile(IC<7>{}, m0, m1, Qf, npiece, srow, has_next, nQf, nnp);
+            else run_tile(IC<6>{}, m0, m1, Qf, npiece, srow, has_next, nQf, nnp);
+        }
         m0 = nm0; m1 = nm1; Qf = nQf; npiece = nnp;
     } while (++t < nt);
 #endif
@@ -348,7 +368,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_v10_kernel(const ConvArgs p
 // The host's plan: blocks per filter tile (B), column blocks per block (q, + 1 for the first r), the widest body whose worst-case halo patch fits the
 // patch buffer, tiles per block for the two run lengths.
 struct V10Plan {
-    int B, q, r, mp_max, nt_hi, nt_lo, n_tiles, xq;
+    int B, q, r, mp_max, nt_hi, nt_lo, n_tiles, xq, half;
 };
 static int v10_patch_pieces(const ConvArgs& a, int mp) {   // worst case over tile positions: (vp - 1) pixels + 2 pad columns per row crossing + a zero row per image crossing + the halo
     const int vp = mp * 32, PW = a.W + 2;
@@ -356,21 +376,24 @@ static int v10_patch_pieces(const ConvArgs& a, int mp) {   // worst case over ti
     const int npos = (vp - 1) + 2 * rc + PW * ic + 2 * PW + 3;
     return (npos * V10_PITCH + 1023) / 1024;
 }
-static bool v10_plan(const ConvArgs& a, V10Plan& pl) {
+static bool v10_plan_form(const ConvArgs& a, V10Plan& pl, bool half) {
     const int n_ct = a.Cout / 256, cus = y3_cu_count();
     const int CB = (a.M + 31) / 32;
     if (n_ct < 1 || CB < 1) return false;
     const int force_mp = (int)y3_knob(Y3K_V10_MP), force_b = (int)y3_knob(Y3K_V10_BLOCKS);
+    const int mp_lo = half ? V10Geom<true>::MP_LO : V10Geom<false>::MP_LO, mp_hi = half ? V10Geom<true>::MP_HI : V10Geom<false>::MP_HI;
+    const int maxpiece = half ? V10Geom<true>::MAXPIECE : V10Geom<false>::MAXPIECE;
+    pl.half = half ? 1 : 0;
     pl.mp_max = 0;
-    for (int mp = 8; mp >= 6; --mp) {
-        if (force_mp >= 6 && force_mp <= 8 && mp > force_mp) continue;
-        if (v10_patch_pieces(a, mp) <= V10_MAXPIECE) { pl.mp_max = mp; break; }
+    for (int mp = mp_hi; mp >= mp_lo; --mp) {
+        if (force_mp >= mp_lo && force_mp <= mp_hi && mp > force_mp) continue;
+        if (v10_patch_pieces(a, mp) <= maxpiece) { pl.mp_max = mp; break; }
     }
     if (!pl.mp_max) return false;
     pl.xq = v10_patch_pieces(a, pl.mp_max) > 28 ? 2 : 1;
-    int B = cus / n_ct;
+    int B = (half ? 2 : 1) * cus / n_ct;
     if (B < 1) B = 1;
-    if (B > CB / 6) B = CB / 6 > 0 ? CB / 6 : 1;   // at least 6 column blocks (one narrowest body) per block where the launch has them
+    if (B > CB / mp_lo) B = CB / mp_lo > 0 ? CB / mp_lo : 1;   // at least one narrowest body of column blocks per block where the launch has them
     if (force_b > 0) B = force_b < CB ? force_b : CB;
     pl.B = B;
     pl.q = CB / B;
@@ -379,6 +402,15 @@ static bool v10_plan(const ConvArgs& a, V10Plan& pl) {
     pl.nt_hi = (pl.q + 1 + pl.mp_max - 1) / pl.mp_max;
     pl.n_tiles = pl.r * pl.nt_hi + (B - pl.r) * pl.nt_lo;
     return true;
+}
+// knob v10_half: 0 one block per CU; 1 two half-size blocks per CU wherever that form fits; 2 (default) the measured choice: the half form up to 72 K-steps per
+// tile (Cin <= 256), where the epilogue + tile set-up it hides are 25-40 % of a tile (profiles/r04_conv_v10_half_ab.txt: 128 -> 256 @80x80 161 -> 140 us,
+// 256 -> 512 @40x40 138 -> 119 us at batch 32; 512 -> 1024 @20x20 level at batch 32 and 6 % behind at batch 64: twice the filter bytes per MFMA)
+static bool v10_plan(const ConvArgs& a, V10Plan& pl) {
+    const int mode = (int)y3_knob(Y3K_V10_HALF);
+    const bool half = mode == 1 || (mode == 2 && a.Cin <= 256);
+    if (half && v10_plan_form(a, pl, true)) return true;
+    return v10_plan_form(a, pl, false);
 }
 
 static bool v10_eligible(const ConvArgs& a) {
@@ -412,7 +444,7 @@ template <typename T> int launch_v10(ConvArgs& a, hipStream_t st) {
     a.cin_blocks = a.Cin / 32;
     a.nk = 9 * a.cin_blocks;
     a.stat_wp = 4;   // statistics rows per tile: one per 64-pixel epilogue pass of the widest body (narrower bodies write zero rows)
-    g_last_variant = "v10";
+    g_last_variant = pl.half ? "v10h" : "v10";
     if (a.dry) return 0;
     const dim3 grid((unsigned)(a.n_ct * pl.B)), block(256);
 #ifdef Y3_ABLATE
@@ -421,33 +453,36 @@ template <typename T> int launch_v10(ConvArgs& a, hipStream_t st) {
         const int abl = atoi(e);
         if (pl.xq == 2) {
             switch (abl) {
-                case 1: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, 1>), grid, block, 0, st, a); break;
-                case 2: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, 2>), grid, block, 0, st, a); break;
-                case 4: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, 4>), grid, block, 0, st, a); break;
-                case 5: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, 5>), grid, block, 0, st, a); break;
-                case 6: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, 6>), grid, block, 0, st, a); break;
-                case 7: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, 7>), grid, block, 0, st, a); break;
-                case 8: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, 8>), grid, block, 0, st, a); break;
-                default: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, 0>), grid, block, 0, st, a); break;
+                case 1: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, false, 1>), grid, block, 0, st, a); break;
+                case 2: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, false, 2>), grid, block, 0, st, a); break;
+                case 4: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, false, 4>), grid, block, 0, st, a); break;
+                case 5: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, false, 5>), grid, block, 0, st, a); break;
+                case 6: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, false, 6>), grid, block, 0, st, a); break;
+                case 7: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, false, 7>), grid, block, 0, st, a); break;
+                case 8: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, false, 8>), grid, block, 0, st, a); break;
+                default: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, false, 0>), grid, block, 0, st, a); break;
             }
         } else {
             switch (abl) {
-                case 1: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, 1>), grid, block, 0, st, a); break;
-                case 2: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, 2>), grid, block, 0, st, a); break;
-                case 4: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, 4>), grid, block, 0, st, a); break;
-                case 5: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, 5>), grid, block, 0, st, a); break;
-                case 6: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, 6>), grid, block, 0, st, a); break;
-                case 7: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, 7>), grid, block, 0, st, a); break;
-                case 8: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, 8>), grid, block, 0, st, a); break;
-                default: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, 0>), grid, block, 0, st, a); break;
+                case 1: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, false, 1>), grid, block, 0, st, a); break;
+                case 2: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, false, 2>), grid, block, 0, st, a); break;
+                case 4: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, false, 4>), grid, block, 0, st, a); break;
+                case 5: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, false, 5>), grid, block, 0, st, a); break;
+                case 6: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, false, 6>), grid, block, 0, st, a); break;
+                case 7: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, false, 7>), grid, block, 0, st, a); break;
+                case 8: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, false, 8>), grid, block, 0, st, a); break;
+                default: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, false, 0>), grid, block, 0, st, a); break;
             }
         }
         Y3_CHECK_LAUNCH();
         return 0;
     }
 #endif
-    if (pl.xq == 2) hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1>), grid, block, 0, st, a);
+    if (pl.half) {
+        if (pl.xq == 2) hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, true>), grid, block, 0, st, a);
+    } else if (pl.xq == 2) hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, false>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, false>), grid, block, 0, st, a);
     Y3_CHECK_LAUNCH();
     return 0;
 }

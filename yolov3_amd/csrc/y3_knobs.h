@@ -16,6 +16,7 @@ enum y3_knob_id {
     Y3K_CONV_V10,       // "conv_v10":    1 the persistent one-wave-per-SIMD 3x3 kernel with register-resident filter fragments (conv_v10.h) for Cin >= 128 at a quarter round of tiles or more; 0 never; 2 every eligible shape
     Y3K_V10_MP,         // "v10_mp":      0 the widest body whose halo patch fits; 6 / 7 / 8 cap the wave-tile width (32-pixel column blocks) of conv_v10.h (tests)
     Y3K_V10_BLOCKS,     // "v10_blocks":  0 one block per CU; N > 0 blocks per filter tile (tests: blocks that walk many tiles, single-column-block tiles)
+    Y3K_V10_HALF,       // "v10_half":    2 the measured choice (Cin <= 256); 0 one block per CU (bodies of 6 / 7 / 8 column blocks); 1 two half-size blocks per CU (bodies of 3 / 4) wherever the form fits
     Y3K_COUNT
 };
 long long y3_knob(int id);
