@@ -3,9 +3,9 @@ mkdir -p gpurun_out
 R=$PWD; cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   tag=$(echo $c | tr ' ' '_' | cut -c1-24)
-  timeout 600 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/pmc_$tag -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train > $R/gpurun_out/pmc_$tag.log 2>&1; echo "exit $?" >> $R/gpurun_out/pmc_$tag.log
+  timeout 600 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/pmc_$tag -o pmc -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train --no-clocks > $R/gpurun_out/pmc_$tag.log 2>&1; echo "exit $?" >> $R/gpurun_out/pmc_$tag.log
 done
-timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/pmc_stats -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train > $R/gpurun_out/rocprof_stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/pmc_stats -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train --no-clocks > $R/gpurun_out/rocprof_stats.log 2>&1
 cd $R
 grep -a '^{"metric"' gpurun_out/rocprof_stats.log | tail -1 > gpurun_out/pmc_bench_line.json
 python tools/pmc_summary.py gpurun_out gpurun_out/pmc_summary_final.json gpurun_out/pmc_bench_line.json

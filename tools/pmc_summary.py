@@ -15,7 +15,8 @@ import sqlite3
 import sys
 
 NAMES = [  # (regex on the kernel symbol, bench.py name = "conv_igemm_" + the library's variant name)
-    (r"conv_igemm_v10_kernelIDF16_", "conv_igemm_v10"),
+    (r"conv_igemm_v10_kernelIDF16_Li\dELb1E", "conv_igemm_v10h"),
+    (r"conv_igemm_v10_kernelIDF16_Li\dELb0E", "conv_igemm_v10"),
     (r"conv_igemm_v7_kernelIDF16_", "conv_igemm_v7"),
     (r"conv_igemm_v6_kernelIDF16_", "conv_igemm_v6"),
     (r"conv_igemm_v3_kernelIDF16_Li64ELi2ELi2E", "conv_igemm_v3_bk64_128x128"),
@@ -65,8 +66,8 @@ def main(root, out, bench=None):
             for pat, name in NAMES:
                 if re.search(pat, k):
                     if name in stats_us and name in pass_us and abs(pass_us[name] / stats_us[name] - 1.0) > 0.10:
-                        r = {"kernel": name, "counter": c, "pass_avg_us": round(pass_us[name], 2), "stats_avg_us": round(stats_us[name], 2)}
-                        if r not in refused:
+                        r = {"kernel": name, "counter": c, "pass_avg_us": round(pass_us[name], 2), "stats_avg_us": round(stats_us[name], 2), "avg_in_the_refused_pass": a}
+                        if not any(q["kernel"] == name and q["counter"] == c for q in refused):
                             refused.append(r)
                         break
                     rec = res.setdefault(name, {"symbol": re.sub(r"\(anonymous namespace\)::|_ZN12_GLOBAL__N_1\d+", "", k)[:90]})

@@ -46,6 +46,11 @@ template <int N> Y3_DEV void v10_wait_vm() { __builtin_amdgcn_s_waitcnt((N & 15)
 // ABL (tools/v10_ablate.py, -DY3_ABLATE builds only; 0 in the shipped library): the kernel without one of its parts, garbage results, only the launch
 // time means something.  1: no epilogue; 2: the epilogue with its stores and residual loads dropped by the descriptors' bounds check; 4: no MFMAs;
 // 5: no fragment reads, no filter loads, no patch requests (MFMAs + epilogue only); 6: no filter loads; 7: no pixel-fragment reads; 8: no patch requests
+#ifdef Y3_TIMELINE   // debug build (tools/v10_timeline.py): thread 0 of every block stamps the 100 MHz wall clock at block start and, per tile, at K-loop start / K-loop end / epilogue end
+#define V10_STAMP(i) do { if (p.tl && threadIdx.x == 0 && (i) < 64) p.tl[(long long)blockIdx.x * 64 + (i)] = wall_clock64(); } while (0)
+#else
+#define V10_STAMP(i) do { } while (0)
+#endif
 template <typename T, int XQ, bool HALF, int ABL = 0>
 __global__ __launch_bounds__(256, HALF ? 2 : 1) void conv_igemm_v10_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -183,6 +188,7 @@ __global__ __launch_bounds__(256, HALF ? 2 : 1) void conv_igemm_v10_kernel(const
 #pragma unroll
         for (int b = 0; b < MP; ++b) B0[b] = *(const frag*)(smem + bb[0][b]);
         int bufd = par ? -V10_PB : V10_PB;   // what moves the pixel bases to the other patch buffer
+        V10_STAMP(1 + 3 * (stat_row0 / 4 - tile_base));
 
         int cb = 0;
         do {   // (ncb >= 1: a zero-trip path would make the register allocator keep the accumulators' first values on the stack for it)
@@ -231,8 +237,10 @@ __global__ __launch_bounds__(256, HALF ? 2 : 1) void conv_igemm_v10_kernel(const
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- phase 2: MFMAs of substep 1 | pixel fragments of (K-step s + 1, substep 0), patch requests of the next channel block
-                v10_wait_vm<4>();   // everything but the 4 loads of phase 1: the ring slot of K-step s + 1 (loaded a K-step ago), patch pieces of earlier taps
+                // (no counted wait per K-step: the filter fragments are register loads, the compiler's own vmcnt in front of their first use -- two K-steps after
+                // the load -- is exact; v9 had to retire the LDS-DMA'd filter stage of K-step s + 1 here, one K-step after its request)
                 if constexpr (tap == 8) {
+                    v10_wait_vm<8>();   // everything but the filter loads of taps 7 and 8: the patch pieces of the next channel block (requested in taps 0..6) have landed
                     // the next channel block: its patch pieces (requested in taps 0..6, retired by the counted waits since) become visible to the
                     // other waves, and every wave is done reading this block's buffer (its last reads, B1 above, have returned) before anyone
                     // requests into it again
@@ -279,6 +287,7 @@ __global__ __launch_bounds__(256, HALF ? 2 : 1) void conv_igemm_v10_kernel(const
             });
             par ^= 1;
         } while (++cb < ncb);
+        V10_STAMP(2 + 3 * (stat_row0 / 4 - tile_base));
 
         // ---- epilogue: passes of 64 pixels through the wave's own transpose slice (nothing else lives there: the patch of the next tile keeps landing)
         if constexpr (ABL == 1) {   // keep the accumulators alive, store nothing
@@ -336,6 +345,7 @@ __global__ __launch_bounds__(256, HALF ? 2 : 1) void conv_igemm_v10_kernel(const
         }
     };
 
+    V10_STAMP(0);
     // ---- prologue of the block: the whole patch of (tile 0, channel block 0)
     int m0, m1, Qf, npiece;
     tile_geom(0, m0, m1, Qf, npiece);
@@ -360,6 +370,7 @@ __global__ __launch_bounds__(256, HALF ? 2 : 1) void conv_igemm_v10_kernel(const
             else if (sz == 7) run_tile(IC<7>{}, m0, m1, Qf, npiece, srow, has_next, nQf, nnp);
             else run_tile(IC<6>{}, m0, m1, Qf, npiece, srow, has_next, nQf, nnp);
         }
+        V10_STAMP(3 + 3 * t);
         m0 = nm0; m1 = nm1; Qf = nQf; npiece = nnp;
     } while (++t < nt);
 #endif
