@@ -180,6 +180,7 @@ def run_train(args, rank, world, dev, parallel, yo, batch, steps, warmup):
         loss = step()
     parallel.barrier()
     dt = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    group = parallel.describe(dev)   # (collective: every rank calls it) who took part, as the communicator sees it
     flops_img = train_flops_per_image(model, hw)
     tflops = flops_img * bs * steps / dt / 1e12   # per GPU
     # N = 1: what the gradient exchange costs the step when it runs beside the backward -- the same bucket / side-stream / event machinery as
@@ -215,7 +216,7 @@ def run_train(args, rank, world, dev, parallel, yo, batch, steps, warmup):
         "vs_baseline": None, "dtype": "f16" if args.dtype == "fp16" else "bf16", "data": "synthetic (seeded uniform images, Poisson(7) targets/img; random-init weights)",
         "config": {"workload": f"{args.model} train step {hw}x{hw} batch={bs}/GPU autocast {args.dtype}: fwd (batch-stat BN) + ComputeLoss + bwd + grad all-reduce + fused unscale/clip/SGD-nesterov/EMA [BASELINE configs[2]]",
                    "global_batch": world * bs, "parallelism": f"dp{world} (bucketed all-reduce overlapped with backward)"},
-        "final_loss": float(loss.detach()), "loss_scale": scaler.get_scale(), "gradient_exchange_1rank": exchange,
+        "final_loss": float(loss.detach()), "loss_scale": scaler.get_scale(), "gradient_exchange_1rank": exchange, "process_group": group,
         "roofline": {"bound": "mfma", "achieved": round(tflops, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / MFMA_PEAK_TFLOPS, 4),
                      "whole_step_frac": round(tflops / MFMA_PEAK_TFLOPS, 4), "gflop_per_image": round(flops_img / 1e9, 2),
                      "note": "whole step (fwd + dgrad + wgrad conv FLOPs per GPU / step time); kernel shares from the committed profile",
@@ -384,6 +385,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     dt = parallel.max_over_ranks(dt, dev)
+    group = parallel.describe(dev)   # (collective: every rank calls it) who took part, as the communicator sees it
 
     if rank == 0:
         # ---- leg split + per-kernel roofline (outside the timed region) ----
@@ -497,6 +499,7 @@ def main():
             "value": round(value, 2),
             "unit": "images/sec",
             "n_gpus": world,
+            "process_group": group,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),

@@ -107,7 +107,8 @@ def _worker(rank, world, port, q):
     parallel.barrier()
     mx = parallel.max_over_ranks(1.0 + r)
     lo, hi = parallel.shard_range(65, r, w)
-    q.put((r, w, mx, lo, hi))
+    g = parallel.describe()   # the process-group record bench.py attaches to its line: what the communicator saw
+    q.put((r, w, mx, lo, hi, g["backend"], g["world_size"], sorted(x["rank"] for x in g["ranks"]), len({x["pid"] for x in g["ranks"]})))
     parallel.finalize()
 
 
@@ -123,6 +124,7 @@ def test_replica_helpers_world2_gloo():
     [p.join(60) for p in procs]
     assert [r[:3] for r in res] == [(0, 2, 2.0), (1, 2, 2.0)]
     assert (res[0][3], res[0][4], res[1][3], res[1][4]) == (0, 33, 33, 65)
+    assert all(r[5:] == ("gloo", 2, [0, 1], 2) for r in res), res   # both ranks report the same two-process group
 
 
 def _ddp_worker(rank, world, port, q):

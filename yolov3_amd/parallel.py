@@ -58,6 +58,26 @@ def max_over_ranks(value: float, device=None) -> float:
     return float(t.item())
 
 
+def describe(device=None) -> dict:
+    """Self-evidence of the process group for a benchmark line: backend as torch reports it ("nccl" is RCCL on ROCm), the world size the
+    COMMUNICATOR sees (not the environment variable), and every rank's device (index, name, PCI bus id) gathered over the group -- an N-GPU
+    run proves that N ranks on N distinct devices took part."""
+    dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu"))
+    me = {"rank": env_rank()[0], "pid": os.getpid(), "device": str(dev)}
+    if dev.type == "cuda":
+        pr = torch.cuda.get_device_properties(dev)
+        me["name"] = pr.name
+        me["pci_bus_id"] = getattr(pr, "pci_bus_id", None)
+        me["uuid"] = str(getattr(pr, "uuid", ""))
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"backend": None, "world_size": 1, "ranks": [me]}
+    ranks = [None] * dist.get_world_size()
+    dist.all_gather_object(ranks, me)
+    backend = dist.get_backend()
+    return {"backend": backend + (" (RCCL)" if backend == "nccl" else ""), "world_size": dist.get_world_size(), "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0,
+            "distinct_devices": len({(r.get("pci_bus_id"), r.get("uuid"), r["device"]) for r in ranks}), "ranks": ranks}
+
+
 def shard_range(total: int, rank: int, world: int):
     """Contiguous shard [lo, hi) of `total` images for this rank (ragged tail goes to the low ranks), the
     replica analogue of the reference's DistributedSampler split (utils/dataloaders.py:115)."""
