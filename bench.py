@@ -207,7 +207,7 @@ def run_train(args, rank, world, dev, parallel, yo, batch, steps, warmup):
             model.grad_sync = None
     stats = {}
     try:   # kernel breakdown of the same step from the committed rocprofv3 --kernel-trace --stats run (bench.py cannot run the profiler)
-        stats = json.load(open(ROOT / "profiles" / "r03_train_step_kernel_groups.json"))
+        stats = json.load(open(ROOT / "profiles" / "r04_train_step_kernel_groups.json"))
     except (OSError, ValueError):
         pass
     rec = {
@@ -220,7 +220,7 @@ def run_train(args, rank, world, dev, parallel, yo, batch, steps, warmup):
         "roofline": {"bound": "mfma", "achieved": round(tflops, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / MFMA_PEAK_TFLOPS, 4),
                      "whole_step_frac": round(tflops / MFMA_PEAK_TFLOPS, 4), "gflop_per_image": round(flops_img / 1e9, 2),
                      "note": "whole step (fwd + dgrad + wgrad conv FLOPs per GPU / step time); kernel shares from the committed profile",
-                     "kernel_groups": stats.get("groups"), "dominant_kernel": stats.get("dominant"), "kernel_groups_source": "profiles/r03_train_step_kernel_groups.json" if stats else None},
+                     "kernel_groups": stats.get("groups"), "dominant_kernel": stats.get("dominant"), "kernel_groups_source": "profiles/r04_train_step_kernel_groups.json" if stats else None},
     }
     del model, opt, ema, crit
     torch.cuda.empty_cache()
@@ -425,7 +425,7 @@ def main():
         total_conv_flops = sum(g[0] for g in groups.values()) / 5
         total_kernel_s = sum(g[2] for g in groups.values()) / 5
         pmc, pmc_file = {}, None
-        for cand in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):   # HBM traffic per launch comes from the committed rocprofv3 --pmc passes (bench.py cannot run the profiler)
+        for cand in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):   # HBM traffic per launch comes from the committed rocprofv3 --pmc passes (bench.py cannot run the profiler)
             try:
                 pmc = json.load(open(ROOT / "profiles" / cand)).get(dom.rsplit("/", 1)[0], {})  # PMC averages are per kernel symbol
             except OSError:

@@ -71,7 +71,10 @@ int y3_tune_set(const char* key, int64_t value); /* 0, or -1 for an unknown key 
 int64_t y3_tune_get(const char* key);            /* INT64_MIN for an unknown key */
 void y3_tune_reset(void);                        /* defaults + Y3_TUNE again */
 
-/* number of elements (of `dtype`) of a packed filter bank for (cout, cin, ksize) */
+/* number of elements (of `dtype`) of a packed filter bank for (cout, cin, ksize).  ALWAYS size banks with this call: a 3x3 bank with cout % 256 == 0 and
+ * cin % 32 == 0 is TWO copies -- the row-major one every kernel reads, followed by a fragment-ordered one (per 64-row wave and K-step a contiguous 4 KiB block
+ * of four MFMA A fragments) that the persistent 3x3 kernel loads straight into registers (csrc/conv_v10.h, csrc/y3_common.h::y3_frag_index).  Every packer
+ * below (y3_pack_filter, _dgrad, _pair, _jobs) writes both (ABI version 2). */
 size_t y3_packed_filter_elems(int32_t cout, int32_t cin, int32_t ksize);
 /* OIHW fp32 (cout_src x cin_src x k x k) -> packed [cout_pad][k*k*cin_pad (+K pad)] in `dtype`;
  * `cout`/`cin` are the padded logical sizes used by y3_conv2d_fwd (>= the source sizes; pad = 0).
@@ -95,7 +98,7 @@ int y3_conv_workspace_reset(void* workspace, size_t workspace_bytes, void* strea
 int y3_conv2d_fwd_ws(const y3_conv_desc* desc, const y3_tensor* x, const void* packed_filter, const float* bias,
                      const y3_tensor* residual /* may be NULL */, const y3_tensor* y, void* workspace, size_t workspace_bytes,
                      void* stream);
-/* Which kernel variant the dispatcher picks for this problem ("v7", "v6", "v3_bk64_128x128", ..., "direct"); launches nothing.
+/* Which kernel variant the dispatcher picks for this problem ("v10", "v10h", "v7", "v6", "v3_bk64_128x128", "strip", ..., "direct"); launches nothing.
  * The parity tests assert it so that a tolerance is always attached to the kernel that actually ran. */
 int y3_conv2d_fwd_variant(const y3_conv_desc* desc, const y3_tensor* x, const y3_tensor* y, int32_t has_residual,
                           size_t workspace_bytes, char* name, size_t name_capacity);
