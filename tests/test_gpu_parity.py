@@ -1387,11 +1387,10 @@ def test_config5_1280_objects365_bf16_vs_fp32_engine(dev):
         pb, rawb = mb(x.to(dev).to(torch.bfloat16))
     torch.cuda.synchronize()
     assert tuple(pb.shape) == (1, 100800, 370) and pb.dtype == torch.bfloat16
-    for a, b in zip(rawb, raw32):
-        a, b = a.float().cpu(), b.cpu()
-        rel = (a - b).abs().max().item() / b.abs().max().item()
-        corr = torch.corrcoef(torch.stack((a.flatten(), b.flatten())))[0, 1].item()
-        assert rel < 0.25 and corr > 0.99, f"bf16 vs fp32 engine: rel-to-max {rel:.3f}, correlation {corr:.5f}"
+    bnd = HALF_BOUNDS[torch.bfloat16]   # the bounds of the oracle comparison at this resolution (test_model_half_vs_fp32_oracle_benchmark_shapes), not a looser one
+    for lvl, (a, b) in enumerate(zip(rawb, raw32)):
+        rms, mx, corr = _rel_errors(a.float().cpu(), b.cpu())
+        assert rms < bnd["rms"] and mx < bnd["mx"] and corr > bnd["corr"], f"bf16 vs fp32 engine, level {lvl}: rel RMS {rms:.4g} max/range {mx:.4g} corr {corr:.6f}"
     got = non_max_suppression(pb, 0.001, 0.6, multi_label=True, max_det=300)
     want = yo.non_max_suppression(pb.cpu(), 0.001, 0.6, multi_label=True, max_det=300)
     _cmp_nms(got, want, "1280/365")
