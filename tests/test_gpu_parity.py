@@ -2347,8 +2347,8 @@ def test_bn_passes_on_a_tensor_beyond_the_nontemporal_threshold(dev):
     assert dmax <= 1.5 * 2.0 ** -10, f"bn_act_bwd: {dmax:.3e}"
 
 
-@pytest.mark.parametrize("adt", [torch.float16, torch.bfloat16])
-def test_train_step_640_autocast_vs_oracle_autograd(dev, adt):
+@pytest.mark.parametrize("adt,force_v10", [(torch.float16, 0), (torch.bfloat16, 0), (torch.float16, 1)], ids=["fp16", "bf16", "fp16_every_3x3_on_v10"])
+def test_train_step_640_autocast_vs_oracle_autograd(dev, tune, monkeypatch, adt, force_v10):
     """BASELINE configs[2] resolution: one autocast training step of yolov3 at 640 x 640, batch 4 -- 1.6 M / 409 600 / ... / 1 600 pixel maps,
     i.e. the fused stem backward, the 256-tile filter gradients with many pixel slices, v7 with statistics rows, the one-launch stride-2 data
     gradients and the two-level statistics sums at real map sizes -- against torch autograd over the fp32 CPU oracle: loss, and the
@@ -2367,16 +2367,37 @@ def test_train_step_640_autocast_vs_oracle_autograd(dev, adt):
     loss_ref, _, _ = yo.compute_loss(raws_ref, tg, sd[[k for k in sd if k.endswith("anchors")][0]], hyp, nc)
     loss_ref.backward()
     crit = ComputeLoss(m)
+    # which conv kernels the step ran: at batch 4 the dispatcher gives the 80 x 80 maps to v10h and the 40 x 40 / 20 x 20 maps (below a quarter round of tiles) to
+    # v7's K split; the third parametrisation forces every eligible 3 x 3 launch -- forward with statistics AND data gradient -- onto v10 / v10h, the kernels the
+    # batch-64 benchmark runs there
+    _lib, ops = _ops()
+    if force_v10:
+        tune("conv_v10", 2)
+    seen = set()
+    for fn in ("conv2d", "conv2d_stats"):
+        orig = getattr(ops, fn)
+
+        def wrapped(*a, __orig=orig, **kw):
+            r = __orig(*a, **kw)
+            seen.add(ops.last_conv_variant())
+            return r
+
+        monkeypatch.setattr(ops, fn, wrapped)
     with torch.autocast("cuda", dtype=adt):
         raws = m(x.to(dev))
         loss, _ = crit(raws, tg.to(dev))
     (loss * 128.0).backward()
     torch.cuda.synchronize()
+    assert "v10h" in seen and ("v10" in seen) == bool(force_v10) and ("v7" in seen) != bool(force_v10), seen
     rel = abs(loss.item() - loss_ref.item()) / loss_ref.item()
     cos_min, worst, norm_worst = 1.0, None, (0.0, None)
+    dot = n_hip = n_ref = 0.0   # the whole gradient as one vector
     for k, p_ in m.named_parameters():
         ref = sdg[k].grad
         assert p_.grad is not None and torch.isfinite(p_.grad).all(), k
+        if ref is not None:
+            gd, rd = p_.grad.double().cpu().flatten() / 128.0, ref.double().flatten()
+            dot += float(gd @ rd); n_hip += float(gd @ gd); n_ref += float(rd @ rd)
         if ref is None or ref.numel() < 4096:
             continue
         gq = p_.grad.float().cpu() / 128.0
@@ -2386,12 +2407,18 @@ def test_train_step_640_autocast_vs_oracle_autograd(dev, adt):
             cos_min, worst = cq, k
         if nr > norm_worst[0]:
             norm_worst = (nr, k)
-    print(f"[train 640 {adt}] loss rel err {rel:.2e}, min gradient cosine {cos_min:.4f} at {worst}, worst norm ratio error {norm_worst[0]:.3f} at {norm_worst[1]}")
-    # measured (round 3, MI355X): fp16 loss 1e-7, min cosine 0.9947, worst norm error 0.5 %; bf16 loss 1e-5, min cosine 0.938, norm 2.1 %.
-    # (bf16 keeps 8 mantissa bits: the MIN over ~60 tensors is set by the BatchNorm backward's mean subtraction, which amplifies the relative
-    #  rounding noise of du; two builds that differ only in fp32 instruction selection move it by ~0.01 -- hence the margin)
+    cos_all = dot / math.sqrt(n_hip * n_ref)
+    print(f"[train 640 {adt}] loss rel err {rel:.2e}, whole-gradient cosine {cos_all:.5f}, min per-tensor cosine {cos_min:.4f} at {worst}, worst norm ratio error {norm_worst[0]:.3f} at {norm_worst[1]}")
+    # measured (MI355X, rounds 3 / 4): fp16 loss 1e-7 .. 6e-6, whole-gradient cosine 0.9973, min per-tensor cosine 0.9947 .. 0.9951, worst norm error 0.5 %;
+    # bf16 loss 1e-5 .. 5e-5, whole-gradient cosine 0.941, min per-tensor cosine 0.922 .. 0.938 (0.967 at 128 x 128), norm 2.1 .. 3.3 %.
+    # Where the bf16 bound comes from: 1 - cos = noise^2 / (2 signal^2).  If EVERY rounding error of the step scaled with the mantissa (2^-8 against 2^-11: x 64
+    # in noise^2), the fp16 figure 1 - 0.9951 would put bf16 at 1 / sqrt(1 + 64 * 2 * 0.0049) = 0.78: that is the floor of the model.  The hardware sits above
+    # it (0.92 .. 0.97: the fp32 accumulations and the fp64 statistics do not scale), and moves by ~0.01-0.02 between builds that differ only in summation order
+    # (the round-4 kernel moved the minimum from 0.938 to 0.922).  Asserted: per tensor 0.88 (between the derived floor and the lowest value seen), and the
+    # whole gradient -- what the optimizer step follows -- 0.92 / 0.995
     assert rel < (1e-4 if adt == torch.float16 else 1e-3)
-    assert cos_min > (0.99 if adt == torch.float16 else 0.92), f"gradient direction: cosine {cos_min:.4f} at {worst}"
+    assert cos_min > (0.99 if adt == torch.float16 else 0.88), f"gradient direction: cosine {cos_min:.4f} at {worst}"
+    assert cos_all > (0.995 if adt == torch.float16 else 0.92), f"whole-gradient cosine {cos_all:.5f}"
     assert norm_worst[0] < (0.02 if adt == torch.float16 else 0.06), norm_worst
 
 
