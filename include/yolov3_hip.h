@@ -61,10 +61,9 @@ const char* y3_last_error(void);
 
 /* Run-time tuning knobs: every A/B hook of the library in one table (no counterpart in the reference; ATen's equivalents are
  * torch.backends.cudnn.benchmark and friends).  Defaults are the measured-best settings.  Keys: "conv" (0 per-shape dispatch, 2 / 4 / 5 /
- * 6 / 15 force a tile variant), "conv_v7" (1 auto, 0 off, 2 every eligible shape), "v7_grid" (0 auto, N > 0 grid cap, -1 whole tiles,
- * -2 stream-K), "v7_gc" (0 auto, 1 / 2 / 4 / 8), "conv_ahead" (3 / 2: K-steps the LDS-DMA requests run ahead), "bn_nt_bytes" (threshold of
+ * 6 / 15 force a tile variant), "conv_ahead" (3 / 2: K-steps the LDS-DMA requests run ahead), "bn_nt_bytes" (threshold of
  * the non-temporal BatchNorm passes), "wgrad" (0 per-shape, 2 128-tile, 3 256-tile, 4 direct fp32), "wgrad_xcd" (0..3), "dgrad_quad"
- * (1 / 0), "spp_direct" (0 / 1), "conv_v10" (1 auto, 0 off, 2 every eligible shape), "v10_mp" / "v10_blocks" (0 auto; widest wave tile / blocks per filter tile of csrc/conv_v10.h: tests), "v10_half" (2 auto, 0 one block per CU, 1 two half-size blocks per CU), "wgrad_strip" / "conv_strip" (1 the strip-walking kernels of csrc/wgrad_strip.h / conv_strip.h on the
+ * (1 / 0), "spp_direct" (0 / 1), "conv_v10" (1 auto, 0 off, 2 every eligible shape), "v10_mp" / "v10_blocks" (0 auto; widest wave tile / blocks per filter tile of csrc/conv_v10.h: tests), "v10_half" (2 auto, 0 one block per CU, 1 two half-size blocks per CU), "v10_ksplit" (1 small launches with a workspace, 0 never, 2 every eligible launch) / "v10_slices" (0 auto; forced slice count: tests), "wgrad_strip" / "conv_strip" (1 the strip-walking kernels of csrc/wgrad_strip.h / conv_strip.h on the
  * small-channel 3x3 layers, 0 off, 2 also small launches, N > 2: N rows per block -- tests).  The environment variable Y3_TUNE="key=value,key=value" is read once when the library is first used.
  * Process-wide, not stream-ordered: set a knob before enqueueing the launches it should affect. */
 int y3_tune_set(const char* key, int64_t value); /* 0, or -1 for an unknown key */
@@ -84,21 +83,21 @@ int y3_pack_filter(const float* w_oihw, int32_t cout_src, int32_t cin_src, int32
 
 int y3_conv2d_fwd(const y3_conv_desc* desc, const y3_tensor* x, const void* packed_filter, const float* bias,
                   const y3_tensor* residual /* may be NULL */, const y3_tensor* y, void* stream);
-/* The same call with a caller-owned scratch buffer of y3_conv_workspace_bytes() bytes (256-byte aligned, ZERO-FILLED ONCE when it
- * is allocated, used by one stream at a time): unlocks the persistent stream-K kernel for the 3x3 / stride-1 layers with
- * cout % 256 == 0 (models/common.py:150-165 Bottleneck.cv2, the 3x3 convs of the head) -- the block grid is the CU count, tiles
- * cut by a block's share of the K loop are completed through fp32 partial tiles in the workspace.  Results are deterministic
- * (fixed split, fixed summation order).  Layers the kernel does not cover run exactly as y3_conv2d_fwd. */
+/* The same call with a caller-owned scratch buffer of y3_conv_workspace_bytes() bytes (256-byte aligned, used by one stream at a time): unlocks the K-split
+ * form of the persistent 3x3 kernel for SMALL launches of the 3x3 / stride-1 layers with cout % 256 == 0 (models/common.py:150-165 Bottleneck.cv2, the 3x3
+ * convs of the head; batch 1-4 at 640x640) -- the channel blocks of every tile are cut into slices, every (tile, slice) writes fp32 partial sums into the
+ * workspace and a second launch adds them in slice order and applies bias / SiLU / residual / statistics.  Results are deterministic (fixed split, fixed
+ * summation order).  Launches the form does not cover run exactly as y3_conv2d_fwd. */
 size_t y3_conv_workspace_bytes(void);
-/* A K-split hand-off that never arrived (bounded spin in the finisher: a preempted or hung producer block) is LOUD: the tile is
- * written as NaN and a sticky flag in the workspace makes every later launch on it write NaN too.  y3_conv_workspace_error reads the
- * flag (synchronises `stream`; *error = 0 / 1), y3_conv_workspace_reset re-arms the workspace header (stream-ordered). */
+/* Kept from ABI version 1, where a stream-K kernel handed partial tiles from block to block through the workspace and a hand-off that never arrived set a
+ * sticky flag: the K split of round 4 has no hand-off (two launches, nothing spins).  y3_conv_workspace_error always reports 0, y3_conv_workspace_reset does
+ * nothing; both still validate their arguments. */
 int y3_conv_workspace_error(const void* workspace, size_t workspace_bytes, int32_t* error, void* stream);
 int y3_conv_workspace_reset(void* workspace, size_t workspace_bytes, void* stream);
 int y3_conv2d_fwd_ws(const y3_conv_desc* desc, const y3_tensor* x, const void* packed_filter, const float* bias,
                      const y3_tensor* residual /* may be NULL */, const y3_tensor* y, void* workspace, size_t workspace_bytes,
                      void* stream);
-/* Which kernel variant the dispatcher picks for this problem ("v10", "v10h", "v7", "v6", "v3_bk64_128x128", "strip", ..., "direct"); launches nothing.
+/* Which kernel variant the dispatcher picks for this problem ("v10", "v10h", "v10k", "v6", "v3_bk64_128x128", "strip", ..., "direct"); launches nothing.
  * The parity tests assert it so that a tolerance is always attached to the kernel that actually ran. */
 int y3_conv2d_fwd_variant(const y3_conv_desc* desc, const y3_tensor* x, const y3_tensor* y, int32_t has_residual,
                           size_t workspace_bytes, char* name, size_t name_capacity);

@@ -157,66 +157,97 @@ def _conv_tol_check(name, dtype, out, ref):
     assert bad == 0, f"{name} {dtype}: {bad}/{err.numel()} outside tolerance, max abs err {err.max():.4g}, ref max {ref.abs().max():.3g}"
 
 
-# The persistent stream-K / halo-patch kernel (csrc/conv_v7.h) at small sizes chosen to hit its edge logic: ragged last pixel tile,
-# image borders inside a tile, several images per tile, every patch depth (XP 3/4/5 by image width), one-unit-per-block splits
-# (a tile summed from many slabs), residual / no activation / channel-slice output.
-V7_CASES = [   # every case has >= 32 (tile, channel block) units, the dispatcher's floor for the persistent kernel
-    ("w20_two_ct", (6, 20, 20, 64, 512, 3, 1), {}),
-    ("w13_ragged", (40, 11, 13, 96, 256, 3, 1), {"residual": True}),
-    ("w40_noact", (2, 40, 40, 128, 256, 3, 1), {"act": False}),
-    ("w80_xp4", (1, 33, 80, 128, 256, 3, 1), {"residual": True}),
-    ("w160_xp5", (1, 30, 160, 64, 256, 3, 1), {}),
-    ("w190_xp5_max", (1, 24, 190, 64, 256, 3, 1), {}),
-    ("deep_k_split", (2, 20, 20, 512, 1024, 3, 1), {"residual": True}),
-    ("sliced_out", (8, 24, 20, 128, 256, 3, 1), {"sliced": True}),
-    ("h1_rows", (40, 1, 70, 96, 256, 3, 1), {}),
-    ("w1_cols", (30, 90, 1, 96, 256, 3, 1), {}),
+# The K-split form of the persistent 3x3 kernel (conv_v10.h SPLIT + conv_v10_reduce_kernel: small launches) at sizes chosen to hit its edge logic: ragged last
+# tile, image borders inside a tile, several images per tile, wide maps (the half-size geometry does not fit: full-size bodies), one channel block per slice, uneven
+# slices, residual / no activation / channel-slice output.  (Round 2's stream-K kernel conv_v7.h served these launches until round 4.)
+KSPLIT_CASES = [
+    # name, (n,h,w,cin,cout,k,s), kwargs, slices (knob v10_slices; 0 = the host's plan), expected variant
+    ("w20_two_ct", (6, 20, 20, 64, 512, 3, 1), {}, 0, "v10k"),
+    ("w13_ragged_3_slices_of_3", (40, 11, 13, 96, 256, 3, 1), {"residual": True}, 3, "v10k"),
+    ("w40_noact", (2, 40, 40, 128, 256, 3, 1), {"act": False}, 0, "v10k"),
+    ("w80_two_requests", (1, 33, 80, 128, 256, 3, 1), {"residual": True}, 3, "v10k"),          # 4 channel blocks in 3 slices: 2 + 1 + 1
+    ("w160_full_size_bodies", (1, 30, 160, 64, 256, 3, 1), {}, 2, "v10k"),                      # the 31 KiB patch buffer of the half form does not hold 160-pixel rows
+    ("w190_too_wide", (1, 24, 190, 64, 256, 3, 1), {}, 0, None),                               # no form fits: the tile kernels take it
+    ("deep_k_16_slices", (2, 20, 20, 512, 1024, 3, 1), {"residual": True}, 16, "v10k"),         # one channel block per slice
+    ("sliced_out", (8, 24, 20, 128, 256, 3, 1), {"sliced": True}, 0, "v10k"),
+    ("h1_rows", (40, 1, 70, 96, 256, 3, 1), {}, 2, "v10k"),
+    ("w1_cols", (30, 90, 1, 96, 256, 3, 1), {}, 0, "v10k"),
 ]
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("name,shape,kw", V7_CASES, ids=[c[0] for c in V7_CASES])
-def test_conv_v7_streamk_vs_fp32_reference(dev, dtype, name, shape, kw, tune):
-    tune("conv_v10", 0)
-    tune("conv_v7", 2)     # also the Cin < 256 shapes the dispatcher leaves to the 128x128 kernels
-    tune("v7_grid", -2)    # even K split whatever the tile count: every case crosses tile boundaries inside blocks
-    out, ref = run_conv(dev, dtype, *shape, algo=1, ws=True, expect="v7", repeat=3, **kw)
+@pytest.mark.parametrize("name,shape,kw,slices,variant", KSPLIT_CASES, ids=[c[0] for c in KSPLIT_CASES])
+def test_conv_v10_ksplit_vs_fp32_reference(dev, dtype, name, shape, kw, slices, variant, tune):
+    tune("conv_v10", 2)      # also the Cin < 128 shapes the dispatcher leaves to the small tiles
+    tune("v10_ksplit", 2)    # the K-split form whatever the tile count
+    tune("v10_slices", slices)
+    out, ref = run_conv(dev, dtype, *shape, algo=1, ws=True, expect=variant, repeat=3, **kw)
     _conv_tol_check(name, dtype, out, ref)
 
 
-@pytest.mark.parametrize("variant,shape", [("v7", (3, 40, 40, 256, 512, 3, 1)), ("v6", (3, 40, 40, 256, 512, 3, 2)), ("v6", (4, 40, 40, 512, 256, 1, 1))],
-                         ids=["v7_3x3", "v6_3x3_s2", "v6_1x1"])
-def test_conv_request_depth_bit_identical(dev, tune, variant, shape):
-    """knob "conv_ahead": the LDS-DMA requests of the 256x256 kernels run 3 K-steps ahead of the MFMAs (default, round 3) or 2 (the
-    round-2 schedule).  Both schedules add the same products in the same order: bit-identical outputs -- for v7 with whole tiles and with
-    the K split, launch after launch (a stage overwritten while a wave still reads it would show up here as a flip)."""
+@pytest.mark.parametrize("shape", [(3, 40, 40, 256, 512, 3, 2), (4, 40, 40, 512, 256, 1, 1)], ids=["v6_3x3_s2", "v6_1x1"])
+def test_conv_request_depth_bit_identical(dev, tune, shape):
+    """knob "conv_ahead": the LDS-DMA requests of the 256x256 kernel run 3 K-steps ahead of the MFMAs (default, round 3) or 2 (the
+    round-2 schedule).  Both schedules add the same products in the same order: bit-identical outputs, launch after launch (a stage
+    overwritten while a wave still reads it would show up here as a flip)."""
     outs = []
-    tune("conv_v10", 0)
-    if variant == "v6":
-        tune("conv", 15)   # force the 256x256 v6 tile whatever the per-shape dispatch would pick at this small batch
-    for grid in ((-1, -2) if variant == "v7" else (0,)):
-        tune("v7_grid", grid)
-        for ahead in (3, 2):
-            tune("conv_ahead", ahead)
-            out, ref = run_conv(dev, torch.float16, *shape, algo=1, ws=True, expect=variant, repeat=3, residual=shape[6] == 1 and shape[5] == 3)
-            _conv_tol_check(f"{variant} ahead{ahead} grid{grid}", torch.float16, out, ref)
-            outs.append(out)
-        assert torch.equal(outs[-1], outs[-2]), f"request depth 3 differs from depth 2 ({variant}, grid {grid})"
-
-
-def test_conv_v7_grid_sweep(dev, tune):
-    """the same problem under different block counts (different K splits, down to whole tiles): every split sums the same
-    products in fp32, so the results agree to accumulation-order noise and each one is inside the conv tolerance"""
-    outs = []
-    tune("conv_v10", 0)
-    for grid, gc in ((-1, 1), (-2, 1), (7, 1), (24, 2), (61, 1), (-1, 2), (-2, 2), (0, 4)):   # 4 does not divide the 2 filter tiles: ignored
-        tune("v7_grid", grid)
-        tune("v7_gc", gc)   # filter-tile ranges per XCD group (the rectangle a group of blocks owns)
-        out, ref = run_conv(dev, torch.float16, 4, 20, 20, 256, 512, 3, 1, algo=1, ws=True, expect="v7", repeat=2, residual=True)
-        _conv_tol_check(f"grid{grid} gc{gc}", torch.float16, out, ref)
+    tune("conv", 15)   # force the 256x256 v6 tile whatever the per-shape dispatch would pick at this small batch
+    for ahead in (3, 2):
+        tune("conv_ahead", ahead)
+        out, ref = run_conv(dev, torch.float16, *shape, algo=1, ws=True, expect="v6", repeat=3)
+        _conv_tol_check(f"v6 ahead{ahead}", torch.float16, out, ref)
         outs.append(out)
-    for o in outs[1:]:
-        assert (o - outs[0]).abs().max().item() <= 2.0**-9 * max(1.0, outs[0].abs().max().item())
+    assert torch.equal(outs[-1], outs[-2]), "request depth 3 differs from depth 2"
+
+
+def test_conv_v10_ksplit_slice_sweep(dev, tune):
+    """the same small problem under 1 .. 8 slices of its 8 channel blocks (the default dispatch picks the K-split form here: below a quarter round of tiles, with a
+    workspace): every split sums the same products in fp32, so the results agree to accumulation-order noise, each one is inside the conv tolerance, repeated
+    launches are bit-identical, and one slice reproduces the unsplit kernel's sums exactly"""
+    outs = {}
+    for sl in (0, 1, 2, 3, 5, 8):
+        tune("v10_slices", sl)
+        out, ref = run_conv(dev, torch.float16, 4, 20, 20, 256, 512, 3, 1, algo=1, ws=True, expect="v10k", repeat=2, residual=True)
+        _conv_tol_check(f"slices {sl}", torch.float16, out, ref)
+        outs[sl] = out
+    for sl, o in outs.items():
+        assert (o - outs[0]).abs().max().item() <= 2.0**-9 * max(1.0, outs[0].abs().max().item()), sl
+    tune("v10_slices", 0)
+    tune("v10_ksplit", 0)
+    tune("conv_v10", 2)
+    whole, _ = run_conv(dev, torch.float16, 4, 20, 20, 256, 512, 3, 1, algo=1, ws=True, expect="v10h", residual=True)
+    assert (outs[1] - whole).abs().max().item() <= 2.0**-10 * max(1.0, whole.abs().max().item())   # (same fp32 sums; the slab sum rounds once like the epilogue)
+
+
+@pytest.mark.parametrize("slices", [0, 3])
+def test_conv_v10_ksplit_statistics_rows(dev, tune, slices):
+    """BatchNorm statistics rows of the K-split form come from the slab sum (one row per 64-pixel block, ragged last block): their fp64 sum equals the statistics
+    of the stored tensor"""
+    _lib, ops = _ops()
+    tune("v10_slices", slices)
+    n, h, w, cin, cout, k, s = 3, 20, 19, 128, 256, 3, 1
+    dtype = torch.float16
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(n, cin, h, w, generator=g).to(dtype)
+    wt = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    xv = ops.View.alloc(n, h, w, cin, dtype, dev)
+    ops.nchw_to_nhwc(x.to(dev), xv)
+    filt = ops.pack_filter(wt.to(dev), cout, cin, dtype)
+    zb = torch.zeros(cout, device=dev)
+    y1 = ops.View.alloc(n, h, w, cout, dtype, dev)
+    ws = conv_ws(dev)
+    rows = ops.conv2d_stats_rows(xv, y1, k, s, workspace=ws)
+    assert rows == -(-n * h * w // 64), rows
+    buf = torch.full((rows * 2 * cout,), float("nan"), device=dev)
+    assert ops.conv2d_stats(xv, filt, zb, y1, k, s, buf, rows, workspace=ws) == rows and ops.last_conv_variant() == "v10k"
+    torch.cuda.synchronize()
+    u = y1.as_nhwc().double().cpu().reshape(-1, cout)
+    tot = buf.view(rows, cout, 2).double().sum(0).cpu()
+    assert torch.isfinite(tot).all(), "a statistics row was not written"
+    assert (tot[:, 0] - u.sum(0)).abs().max().item() <= 1e-5 * u.abs().sum(0).max().item()
+    assert (tot[:, 1] - (u * u).sum(0)).abs().max().item() <= 1e-5 * (u * u).sum(0).max().item()
+    ref = F.conv2d(x.float(), wt.to(dtype).float(), None, padding=1)
+    assert (y1.as_nhwc().float().cpu().permute(0, 3, 1, 2) - ref).abs().max().item() < 2e-2
 
 
 # BASELINE.json configs[1] / configs[3] / configs[4] layer shapes at their benchmarked batch: the branches of dispatch_igemm that the
@@ -665,7 +696,7 @@ HALF_BOUNDS = {torch.float16: dict(rms=0.001, mx=0.003, corr=0.99999), torch.bfl
 def test_model_half_vs_fp32_oracle_benchmark_shapes(dev, name, hw, bs, dtype):
     """The BENCHMARKED engines at their own resolution (640x640 fp16 yolov3 / yolov3-spp = configs[1] / [3]; bf16 at 640 and 1280 =
     configs[4]'s dtype and map sizes) against the fp32 CPU oracle: every conv launch goes through the variants the bench runs
-    (v10 / v7 / v6 / v3 with multi-round grids), and the error is bounded per level in relative RMS, max-abs and correlation."""
+    (v10 / v10h / v10k / v6 / v3 with multi-round grids), and the error is bounded per level in relative RMS, max-abs and correlation."""
     nc = 80 if hw == 640 else 365
     m, (layers, save, sd, strides) = build_pair(name, nc, 21, dev, dtype)
     x = torch.rand(bs, 3, hw, hw, generator=torch.Generator().manual_seed(6))
@@ -673,7 +704,7 @@ def test_model_half_vs_fp32_oracle_benchmark_shapes(dev, name, hw, bs, dtype):
     torch.cuda.synchronize()
     plan = next(iter(m._plans.values()))
     variants = {plan.conv_variant(ln) for ln in plan.launches if ln.flops and not ln.kernel}
-    assert any(v in ("v7", "v10", "v10h") for v in variants) and "direct" not in variants, variants
+    assert any(v in ("v10k", "v10", "v10h") for v in variants) and "direct" not in variants, variants
     with torch.no_grad():
         refp, refraw = yo.forward(layers, save, sd, x[: min(bs, 4)], strides, training=False)   # the oracle on the first images (CPU time)
     b = HALF_BOUNDS[dtype]
@@ -2350,7 +2381,7 @@ def test_bn_passes_on_a_tensor_beyond_the_nontemporal_threshold(dev):
 @pytest.mark.parametrize("adt,force_v10", [(torch.float16, 0), (torch.bfloat16, 0), (torch.float16, 1)], ids=["fp16", "bf16", "fp16_every_3x3_on_v10"])
 def test_train_step_640_autocast_vs_oracle_autograd(dev, tune, monkeypatch, adt, force_v10):
     """BASELINE configs[2] resolution: one autocast training step of yolov3 at 640 x 640, batch 4 -- 1.6 M / 409 600 / ... / 1 600 pixel maps,
-    i.e. the fused stem backward, the 256-tile filter gradients with many pixel slices, v7 with statistics rows, the one-launch stride-2 data
+    i.e. the fused stem backward, the 256-tile filter gradients with many pixel slices, the K-split form with statistics rows, the one-launch stride-2 data
     gradients and the two-level statistics sums at real map sizes -- against torch autograd over the fp32 CPU oracle: loss, and the
     direction and norm of every large parameter gradient."""
     from yolov3_amd import ComputeLoss
@@ -2368,7 +2399,7 @@ def test_train_step_640_autocast_vs_oracle_autograd(dev, tune, monkeypatch, adt,
     loss_ref.backward()
     crit = ComputeLoss(m)
     # which conv kernels the step ran: at batch 4 the dispatcher gives the 80 x 80 maps to v10h and the 40 x 40 / 20 x 20 maps (below a quarter round of tiles) to
-    # v7's K split; the third parametrisation forces every eligible 3 x 3 launch -- forward with statistics AND data gradient -- onto v10 / v10h, the kernels the
+    # the K-split form v10k; the third parametrisation forces every eligible 3 x 3 launch -- forward with statistics AND data gradient -- onto v10 / v10h, the kernels the
     # batch-64 benchmark runs there
     _lib, ops = _ops()
     if force_v10:
@@ -2388,7 +2419,7 @@ def test_train_step_640_autocast_vs_oracle_autograd(dev, tune, monkeypatch, adt,
         loss, _ = crit(raws, tg.to(dev))
     (loss * 128.0).backward()
     torch.cuda.synchronize()
-    assert "v10h" in seen and ("v10" in seen) == bool(force_v10) and ("v7" in seen) != bool(force_v10), seen
+    assert "v10h" in seen and ("v10" in seen) == bool(force_v10) and ("v10k" in seen) != bool(force_v10), seen
     rel = abs(loss.item() - loss_ref.item()) / loss_ref.item()
     cos_min, worst, norm_worst = 1.0, None, (0.0, None)
     dot = n_hip = n_ref = 0.0   # the whole gradient as one vector
@@ -2420,28 +2451,6 @@ def test_train_step_640_autocast_vs_oracle_autograd(dev, tune, monkeypatch, adt,
     assert cos_min > (0.99 if adt == torch.float16 else 0.88), f"gradient direction: cosine {cos_min:.4f} at {worst}"
     assert cos_all > (0.995 if adt == torch.float16 else 0.92), f"whole-gradient cosine {cos_all:.5f}"
     assert norm_worst[0] < (0.02 if adt == torch.float16 else 0.06), norm_worst
-
-
-def test_conv_workspace_lost_handoff_is_loud_and_resettable(dev, tune):
-    """The sticky error flag of the K-split workspace (conv_v7.h): once set -- here by hand, in production by a finisher whose producer
-    never published within the bounded spin -- every launch on that workspace writes NaN instead of a silently wrong sum, the host can
-    read the flag (y3_conv_workspace_error) and re-arm the workspace (y3_conv_workspace_reset); afterwards the results are exact again."""
-    _lib, ops = _ops()
-    tune("conv_v10", 0)
-    tune("v7_grid", -2)
-    shape = (2, 20, 20, 256, 512, 3, 1)
-    good, ref = run_conv(dev, torch.float16, *shape, algo=1, ws=True, expect="v7")
-    ws = conv_ws(dev)
-    assert not ops.conv_workspace_error(ws)
-    hdr = ws[:64].view(torch.int32)
-    hdr[2] = 1   # V7Ctl::error
-    bad, _ = run_conv(dev, torch.float16, *shape, algo=1, ws=True, expect="v7", check_ws=False)
-    assert torch.isnan(bad).all(), "a poisoned workspace must not produce finite tiles"
-    assert ops.conv_workspace_error(ws)
-    ops.conv_workspace_reset(ws)
-    assert not ops.conv_workspace_error(ws)
-    again, _ = run_conv(dev, torch.float16, *shape, algo=1, ws=True, expect="v7")
-    assert torch.equal(again, good)
 
 
 # ------------------------------------------------------------------------------------------------ conv v10 (persistent, register-resident filter fragments)

@@ -322,7 +322,7 @@ def test_conv_dispatch_variant_names_and_stat_rows():
     ws = L.y3_conv_workspace_bytes()
     assert ws == 64 + 4096 + 2 * 256 * 256 * 256 * 4
     # (pixels per tile, statistics rows per tile); v10 cuts the pixel axis into 32-pixel column blocks and a block's run of them into tiles of 6 / 7 / 8 (conv_v10.h)
-    tile_px = {"v7": (256, 4), "v6": (256, 2), "v3_bk64_128x128": (128, 2), "v3_bk32_128x128": (128, 2), "v3_bk32_128x256": (256, 2), "v3_bk32_64x256": (256, 2),
+    tile_px = {"v6": (256, 2), "v3_bk64_128x128": (128, 2), "v3_bk32_128x128": (128, 2), "v3_bk32_128x256": (256, 2), "v3_bk32_64x256": (256, 2),
                "v10": (0, 4), "v10h": (0, 4), "strip": (0, 0)}
     shapes = [(32, 64, 3, 2, 640), (64, 32, 1, 1, 320), (32, 64, 3, 1, 320), (64, 128, 3, 2, 320), (128, 64, 1, 1, 160), (64, 128, 3, 1, 160), (128, 256, 3, 2, 160),
               (256, 128, 1, 1, 80), (128, 256, 3, 1, 80), (256, 512, 3, 2, 80), (512, 256, 1, 1, 40), (256, 512, 3, 1, 40), (512, 1024, 3, 2, 40), (1024, 512, 1, 1, 20),
@@ -340,7 +340,7 @@ def test_conv_dispatch_variant_names_and_stat_rows():
             name = C.create_string_buffer(64)
             assert L.y3_conv2d_fwd_variant(C.byref(d), C.byref(x), C.byref(y), 0, 0, name, 64) == 0, L.y3_last_error()
             plain = name.value.decode()
-            assert plain in tile_px and plain != "v7", plain
+            assert plain in tile_px, plain
             assert (plain in ("v10", "v10h")) == ((cin, cout, k, s, hin) in v10_shapes) and (plain == "v10h") == ((cin, cout, k, s, hin) in v10_shapes and cin <= 256), (cin, cout, k, s, hin, plain)
             rows = L.y3_conv2d_fwd_stats_rows(C.byref(d), C.byref(x), C.byref(y))
             assert rows > 0, L.y3_last_error()
@@ -366,13 +366,22 @@ def test_conv_dispatch_variant_names_and_stat_rows():
             assert L.y3_conv2d_fwd_variant(C.byref(d), C.byref(x), C.byref(y), 0, ws, name, 64) == 0
             with_ws = name.value.decode()
             assert with_ws == plain, (cin, cout, k, s, hin, with_ws)
-            if (cin, cout, k, s, hin) in v10_shapes and cin >= 256:   # knob conv_v10 = 0: the persistent halo-patch kernel of round 2 when a workspace is given
+            if (cin, cout, k, s, hin) in v10_shapes and cin >= 256:   # knob conv_v10 = 0: the 256 x 256 tile kernel of round 1, with or without a workspace
                 assert L.y3_tune_set(b"conv_v10", 0) == 0
                 try:
-                    assert L.y3_conv2d_fwd_variant(C.byref(d), C.byref(x), C.byref(y), 0, ws, name, 64) == 0 and name.value == b"v7"
+                    assert L.y3_conv2d_fwd_variant(C.byref(d), C.byref(x), C.byref(y), 0, ws, name, 64) == 0 and name.value == b"v6"
                     assert L.y3_conv2d_fwd_variant(C.byref(d), C.byref(x), C.byref(y), 0, 0, name, 64) == 0 and name.value == b"v6"
                 finally:
                     L.y3_tune_reset()
+    # small launches (below a quarter round of 256-pixel tiles): with a workspace the K-split form of conv_v10.h ("v10k": statistics rows = 64-pixel blocks of the
+    # slab sum), without one the tile kernels
+    for bs, cin, cout, hin in [(1, 512, 1024, 20), (4, 256, 512, 40), (2, 128, 256, 80)]:
+        x, y = Y3Tensor(4096, bs, hin, hin, cin, cin), Y3Tensor(8192, bs, hin, hin, cout, cout)
+        d = _desc(_lib.Y3_F16, 3, 1, cin, cout)
+        name = C.create_string_buffer(64)
+        assert L.y3_conv2d_fwd_variant(C.byref(d), C.byref(x), C.byref(y), 0, ws, name, 64) == 0 and name.value == b"v10k", name.value
+        assert L.y3_conv2d_fwd_stats_rows_ws(C.byref(d), C.byref(x), C.byref(y), ws) == -(-bs * hin * hin // 64)
+        assert L.y3_conv2d_fwd_variant(C.byref(d), C.byref(x), C.byref(y), 0, 0, name, 64) == 0 and name.value in (b"v6", b"v3_bk64_128x128"), name.value
     # the training-mode launches of the small-channel 3x3 / stride-1 layers (conv_strip.h): 64 -> 32 and 128 -> 64 are the data gradients of layers 2.cv2 / 4.x.cv2;
     # rows = blocks x pixel tiles (x 2 K-split waves at Cin = 128); small launches and residual launches stay on the tile kernels
     for (cin, cout, hin, rows_want) in [(64, 32, 320, 768 * 2), (128, 64, 160, 256 * 2 * 2)]:

@@ -18,6 +18,7 @@
 
 #include <stdlib.h>
 #include <type_traits>
+#include <utility>
 #include <string.h>
 
 namespace {
@@ -56,10 +57,10 @@ struct ConvArgs {
     float* stats;
     int stat_wp;   // waves along the pixel axis of the launched variant
     int dry;       // geometry only (y3_conv2d_fwd_stats_rows): fill n_pt / stat_wp, launch nothing
-    void* ws;      // scratch of the persistent stream-K kernel (conv_v7.h): control words, arrival flags, fp32 partial tiles; may be null
+    void* ws;      // the caller's scratch (y3_conv2d_fwd_ws): fp32 slabs of the K-split form of conv_v10.h; may be null
     size_t ws_bytes;
-    int v7_whole;  // conv_v7.h: blocks own whole tiles (no stream-K split)
-    int v7_gc;     // conv_v7.h: filter-tile ranges per XCD group (1, 2, 4 or 8; divides n_ct)
+    int v10_S;     // conv_v10.h SPLIT form: slices of the channel blocks
+    unsigned dv_sl_mul, dv_sl_sh;   // reciprocal of the blocks per slice
     int v10_B, v10_q, v10_r, v10_nt_hi, v10_nt_lo;   // conv_v10.h: blocks per filter tile, 32-pixel column blocks per block (+ 1 for the first r), tiles per block for the two run lengths
     int cs_strips, cs_T, cs_per;   // conv_strip.h: column strips per row, output rows in all, output rows per block
     unsigned dv_pw_mul, dv_pw_sh, dv_h1_mul, dv_h1_sh;   // conv_v10.h: reciprocals of W + 2 and H + 1
@@ -1028,7 +1029,12 @@ int launch_igemm(ConvArgs& a, hipStream_t st) {
     return 0;
 }
 
-#include "conv_v7.h"
+template <int I> struct IC {
+    static constexpr int value = I;
+};
+template <typename F, int... Is> Y3_DEV void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(IC<Is>{}), ...); }
+template <int N, typename F> Y3_DEV void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 #include "conv_v10.h"
 #include "conv_strip.h"
 
@@ -1041,8 +1047,9 @@ template <typename T> int dispatch_igemm(ConvArgs& a, hipStream_t st) {
         CsPlan cs;
         if (var == 3 && cs_plan(a, cs)) return launch_cs<T>(a, st);
     }
+    if (var == 3 && y3_knob(Y3K_V10_KSPLIT) == 2 && v10k_eligible(a)) return launch_v10k<T>(a, st);   // (tests: the K-split form on any eligible launch)
     if (var == 3 && v10_eligible(a)) return launch_v10<T>(a, st);
-    if (var == 3 && v7_eligible(a)) return launch_v7<T>(a, st);
+    if (var == 3 && v10k_eligible(a)) return launch_v10k<T>(a, st);
     if (var >= 3 && a.Cout > 64 && c32) {
         // forced tiles (knob "conv", A/B runs)
         if (var == 4) return launch_v3<T, 32, 2, 4>(a, st);   // 128c x 256p, BK 32
@@ -1239,22 +1246,21 @@ extern "C" int y3_conv2d_fwd(const y3_conv_desc* d, const y3_tensor* x, const vo
     return conv_fwd_impl(d, x, filt, bias, res, y, nullptr, 0, nullptr, 0, stream);
 }
 
-// ---- the same convolution with a scratch buffer: unlocks the persistent stream-K kernel (conv_v7.h) where it applies ----
-extern "C" size_t y3_conv_workspace_bytes(void) { return V7_HDR_BYTES + 2 * (size_t)V7_MAX_BLOCKS * V7_SLAB_BYTES; }   // a published + a private slab per block
+// ---- the same convolution with a scratch buffer: unlocks the K-split form of conv_v10.h for small launches ----
+constexpr size_t Y3_CONV_WS_BYTES = 64 + 4 * 1024 + 2 * (size_t)256 * 256 * 256 * 4;   // 134 MB: the size round 2 fixed (callers allocate it once per plan)
+extern "C" size_t y3_conv_workspace_bytes(void) { return Y3_CONV_WS_BYTES; }
 
-// the sticky hand-off flag of the stream-K path (conv_v7.h: a finisher whose producer never published poisons its tile and every later
-// launch on the workspace): y3_conv_workspace_error reads it (synchronises `stream`), y3_conv_workspace_reset re-arms the header
+// Round 2's stream-K kernel kept a sticky "lost hand-off" flag in the workspace header.  The K split of round 4 has no hand-off (two launches, nothing spins):
+// the two calls stay in the ABI, the flag is always 0
 extern "C" int y3_conv_workspace_error(const void* workspace, size_t workspace_bytes, int32_t* error, void* stream) {
-    if (!workspace || !error || workspace_bytes < V7_HDR_BYTES) Y3_FAIL("y3_conv_workspace_error: bad argument");
-    V7Ctl h;
-    Y3_HIP(hipMemcpyAsync(&h, workspace, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
-    Y3_HIP(hipStreamSynchronize((hipStream_t)stream));
-    *error = (int32_t)h.error;
+    if (!workspace || !error || workspace_bytes < V10_WS_SLABS) Y3_FAIL("y3_conv_workspace_error: bad argument");
+    (void)stream;
+    *error = 0;
     return 0;
 }
 extern "C" int y3_conv_workspace_reset(void* workspace, size_t workspace_bytes, void* stream) {
-    if (!workspace || workspace_bytes < V7_HDR_BYTES) Y3_FAIL("y3_conv_workspace_reset: bad argument");
-    Y3_HIP(hipMemsetAsync(workspace, 0, V7_HDR_BYTES, (hipStream_t)stream));
+    if (!workspace || workspace_bytes < V10_WS_SLABS) Y3_FAIL("y3_conv_workspace_reset: bad argument");
+    (void)stream;
     return 0;
 }
 

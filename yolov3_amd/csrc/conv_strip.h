@@ -233,7 +233,7 @@ static bool cs_plan(const ConvArgs& a, CsPlan& pl) {
     // blocks a CU holds (CsGeom::LDS = 44 / 56 / 104 KiB for 64 -> 32 / 64 -> 128 / 128 -> 64; 2 / 8 / 8 waves per block, two waves per SIMD: 144 filter
     // registers per lane)
     const int per_cu = a.Cout == 32 ? 3 : 1;
-    const int nblk = v7_cu_count() * per_cu;
+    const int nblk = y3_cu_count() * per_cu;
     if (mode == 1 && T < 24LL * nblk) return false;   // every block amortises its filter load and its statistics row over >= 24 output rows
     pl.per = mode > 2 ? (int)mode : (int)((T + nblk - 1) / nblk);
     if (pl.per < 1) pl.per = 1;
@@ -480,7 +480,7 @@ static bool cq_plan(const ConvArgs* cls, CsPlan& pl) {
     pl.strips = (a.Wo + 63) / 64;
     const long long T = (long long)a.N * pl.strips * a.Ho;
     if (T < 1 || T > 0x3fffffffLL) return false;
-    const int nblk = v7_cu_count() * (a.Cin == 64 ? 4 : 1);   // (CqGeom::LDS = 30 / 54 KiB, 2 / 8 waves per block, two waves per SIMD)
+    const int nblk = y3_cu_count() * (a.Cin == 64 ? 4 : 1);   // (CqGeom::LDS = 30 / 54 KiB, 2 / 8 waves per block, two waves per SIMD)
     if (mode == 1 && T < 24LL * nblk) return false;
     pl.per = mode > 2 ? (int)mode : (int)((T + nblk - 1) / nblk);
     if (pl.per < 1) pl.per = 1;

@@ -1,4 +1,4 @@
-// conv_v10.h -- included by conv.hip INSIDE its anonymous namespace, after conv_v7.h (shares ConvArgs, Mfma, epilogue_wave, fdiv, ...).
+// conv_v10.h -- included by conv.hip INSIDE its anonymous namespace (shares ConvArgs, Mfma, epilogue_wave, fdiv, IC / static_for, ...).
 //
 // v10: the 3x3 / stride 1 / pad 1 convolutions with Cout % 256 == 0 and Cin % 32 == 0 (reference models/common.py:57-81 Conv inside
 // Bottleneck.cv2, models/yolov3.yaml:23-31 and the 3x3 convs of the head; their data gradients run through the same kernel on the flipped
@@ -19,6 +19,12 @@
 //   * NO PER-TILE PROLOGUE.  While a block multiplies the last channel block of a tile it requests the first channel block of its NEXT
 //     tile into the other patch buffer, and the filter ring simply wraps (the next tile has the same filter rows): the next tile's first
 //     K-step has its operands when the epilogue ends.  The epilogue transposes through a slice of its own, so nothing waits for it.
+//
+//   * SMALL LAUNCHES: K SPLIT (SPLIT form, "v10k").  Below a quarter round of tiles (batch 1-4 at 640 x 640) the tiles alone do not fill the chip.  The channel
+//     blocks of every tile are then cut into S slices, a block multiplies ONE slice of its tiles and writes the fp32 accumulators into slab s of the caller's
+//     workspace ([slice][pixel][filter]); a second launch (conv_v10_reduce_kernel) sums the slabs in slice order and applies what the epilogue applies -- bias,
+//     SiLU, rounding, statistics rows, residual.  Two launches, fixed summation order, bit-deterministic, nothing to spin on.  (It replaces round 2's stream-K
+//     kernel conv_v7.h -- published slabs, arrival flags, a bounded spin and a sticky error flag for the hand-off that never came -- deleted in round 4.)
 //
 // LDS (144 KiB, one block per CU): [2 x 54 KiB patch buffers][4 x 1 KiB dump slots for request slots with nothing to fetch][4 x 8 KiB epilogue slices].
 
@@ -51,7 +57,9 @@ template <int N> Y3_DEV void v10_wait_vm() { __builtin_amdgcn_s_waitcnt((N & 15)
 #else
 #define V10_STAMP(i) do { } while (0)
 #endif
-template <typename T, int XQ, bool HALF, int ABL = 0>
+constexpr size_t V10_WS_SLABS = 8192;   // byte offset of the fp32 slabs in the conv workspace (the first bytes were round 2's control words: left alone)
+
+template <typename T, int XQ, bool HALF, bool SPLIT = false, int ABL = 0>
 __global__ __launch_bounds__(256, HALF ? 2 : 1) void conv_igemm_v10_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int MC = 2;
@@ -69,7 +77,16 @@ __global__ __launch_bounds__(256, HALF ? 2 : 1) void conv_igemm_v10_kernel(const
     const int ncb = p.cin_blocks;
 
     // ---- this block's share: filter tile ct (slowest: the blocks of one XCD share a filter tile, its rows stay in that L2) and a run of column blocks
-    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    int lin = xcd_remap(blockIdx.x, gridDim.x);
+    int cb0 = 0, cb1 = ncb, slice = 0;   // SPLIT: this block's slice of the channel blocks (the slices of one (filter tile, run) are `per` block ids apart)
+    if constexpr (SPLIT) {
+        const int per = p.n_ct * p.v10_B;
+        slice = fdiv(lin, p.dv_sl_mul, p.dv_sl_sh);
+        lin -= slice * per;
+        const int cq = ncb / p.v10_S, cr = ncb - cq * p.v10_S;
+        cb0 = slice * cq + (slice < cr ? slice : cr);
+        cb1 = cb0 + cq + (slice < cr ? 1 : 0);
+    }
     const int ct = fdiv(lin, p.dv_ct_mul, p.dv_ct_sh);   // host: the divisor is v10_B here
     const int bi = lin - ct * p.v10_B;
     const bool big = bi < p.v10_r;
@@ -156,7 +173,7 @@ __global__ __launch_bounds__(256, HALF ? 2 : 1) void conv_igemm_v10_kernel(const
         const int frow = lane & 31, fk = lane >> 5;
         // filter fragments of K-steps 0 and 1: in flight under the set-up below
         a_lane = (unsigned)lane * 16u;
-        a_next = 0;
+        a_next = cb0 * 9 * 4096;
         a_load(IC<0>{});
         a_load(IC<1>{});
         // pixels: column block b, tap row dh -> patch row (Q(m) - Qf) + dh PW; columns beyond the tile's valid pixels re-read its last pixel
@@ -178,7 +195,8 @@ __global__ __launch_bounds__(256, HALF ? 2 : 1) void conv_igemm_v10_kernel(const
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int cbias = ct * 256 + (wv * MC + a) * 32 + 8 * g + 4 * fk;
-                const f32x4 bz = *(const f32x4*)(p.bias + cbias);   // (Cout % 256 == 0 and the C ABI requires a bias: no guards, no branches around the accumulators' first values)
+                f32x4 bz = {0.f, 0.f, 0.f, 0.f};   // SPLIT: the bias is added once, by the slab sum
+                if constexpr (!SPLIT) bz = *(const f32x4*)(p.bias + cbias);   // (Cout % 256 == 0 and the C ABI requires a bias: no guards, no branches around the accumulators' first values)
 #pragma unroll
                 for (int b = 0; b < MP; ++b)
 #pragma unroll
@@ -190,15 +208,15 @@ __global__ __launch_bounds__(256, HALF ? 2 : 1) void conv_igemm_v10_kernel(const
         int bufd = par ? -V10_PB : V10_PB;   // what moves the pixel bases to the other patch buffer
         V10_STAMP(1 + 3 * (stat_row0 / 4 - tile_base));
 
-        int cb = 0;
-        do {   // (ncb >= 1: a zero-trip path would make the register allocator keep the accumulators' first values on the stack for it)
-            const bool lastcb = cb + 1 == ncb;
+        int cb = cb0;
+        do {   // (at least one channel block: a zero-trip path would make the register allocator keep the accumulators' first values on the stack for it)
+            const bool lastcb = cb + 1 == cb1;
             int np_req = npiece, cbyte = (cb + 1) * 64;
             bool live = true;
-            if (lastcb) {   // the requests of this channel block fetch channel block 0 of the block's next tile
+            if (lastcb) {   // the requests of this channel block fetch the first channel block of the block's next tile
                 live = has_next;
                 np_req = nnpiece;
-                cbyte = 0;
+                cbyte = cb0 * 64;
                 if (has_next) set_xsrc(nQf - PW - 1, nnpiece);
             }
             const int nbuf = par ^ 1;
@@ -286,9 +304,24 @@ __global__ __launch_bounds__(256, HALF ? 2 : 1) void conv_igemm_v10_kernel(const
                 __builtin_amdgcn_sched_barrier(0);
             });
             par ^= 1;
-        } while (++cb < ncb);
+        } while (++cb < cb1);
         V10_STAMP(2 + 3 * (stat_row0 / 4 - tile_base));
 
+        if constexpr (SPLIT) {   // the fp32 accumulators go into slab `slice` as they are: [pixel][filter], four consecutive filters of a pixel per 16-byte store
+            float* slab = (float*)((unsigned char*)p.ws + V10_WS_SLABS) + (size_t)slice * (size_t)p.M * (size_t)p.Cout;
+#pragma unroll
+            for (int b = 0; b < MP; ++b) {
+                const int m = m0 + b * 32 + frow;
+                if (m < m1) {
+                    float* row = slab + (size_t)m * p.Cout + ct * 256 + wv * 64 + 4 * fk;
+#pragma unroll
+                    for (int a = 0; a < MC; ++a)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) *(f32x4*)(row + a * 32 + 8 * g) = f32x4{acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
+                }
+            }
+            return;
+        }
         // ---- epilogue: passes of 64 pixels through the wave's own transpose slice (nothing else lives there: the patch of the next tile keeps landing)
         if constexpr (ABL == 1) {   // keep the accumulators alive, store nothing
 #pragma unroll
@@ -351,7 +384,7 @@ __global__ __launch_bounds__(256, HALF ? 2 : 1) void conv_igemm_v10_kernel(const
     tile_geom(0, m0, m1, Qf, npiece);
     set_xsrc(Qf - PW - 1, npiece);
 #pragma unroll
-    for (int i = 0; i < NXP; ++i) dma_x(i, 0, 0, npiece, true);
+    for (int i = 0; i < NXP; ++i) dma_x(i, cb0 * 64, 0, npiece, true);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
@@ -376,10 +409,70 @@ __global__ __launch_bounds__(256, HALF ? 2 : 1) void conv_igemm_v10_kernel(const
 #endif
 }
 
+// The second launch of the SPLIT form: y[m][c] = round(act(bias[c] + sum over slices of slab[s][m][c])) (+ residual), slices in order; a block owns 64 pixels x 256
+// filters (thread = 8 consecutive filters of one pixel per pass, 8 pixels per pass), so its statistics row -- per-filter (sum, sum of squares) of the values as
+// STORED, before the residual, exactly what epilogue_wave counts -- needs no atomics: per-thread sums over the passes, then the 8 pixel lanes in lane order.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_v10_reduce_kernel(const ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef typename Mfma<T>::frag vec8;
+    __shared__ float red[8][32][16];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.y * 256 + tx * 8;
+    const float* slab = (const float*)((const unsigned char*)p.ws + V10_WS_SLABS);
+    const size_t sl = (size_t)p.M * (size_t)p.Cout;
+    const f32x4 b0 = *(const f32x4*)(p.bias + c), b1 = *(const f32x4*)(p.bias + c + 4);
+    float st0[8], st1[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) st0[q] = st1[q] = 0.0f;
+    for (int pass = 0; pass < 8; ++pass) {
+        const int m = blockIdx.x * 64 + pass * 8 + ty;
+        if (m >= p.M) break;
+        const float* src = slab + (size_t)m * p.Cout + c;
+        f32x8 v = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        for (int s = 0; s < p.v10_S; ++s) {
+            const f32x4 lo = *(const f32x4*)(src + (size_t)s * sl), hi = *(const f32x4*)(src + (size_t)s * sl + 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { v[q] += lo[q]; v[4 + q] += hi[q]; }
+        }
+        if (p.act == Y3_ACT_SILU) silu_vec<f32x8, 8>(v);
+        u32x4 ov;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ov[q] = pack2<T>(v[2 * q], v[2 * q + 1]);
+        vec8 o = __builtin_bit_cast(vec8, ov);
+        if (p.stats != nullptr) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const float f = to_f32<T>(o[q]); st0[q] += f; st1[q] += f * f; }
+        }
+        if (p.res != nullptr) {   // x + cv2(cv1(x)) in fp32, rounded once
+            const vec8 rr = *(const vec8*)((const T*)p.res + (size_t)m * p.rpitch + c);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ov[q] = pack2<T>(to_f32<T>(o[2 * q]) + to_f32<T>(rr[2 * q]), to_f32<T>(o[2 * q + 1]) + to_f32<T>(rr[2 * q + 1]));
+        }
+        *(u32x4*)((T*)p.y + (size_t)m * p.ypitch + c) = ov;
+    }
+    if (p.stats != nullptr) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { red[ty][tx][q] = st0[q]; red[ty][tx][8 + q] = st1[q]; }
+        __syncthreads();
+        if (ty == 0) {
+            float* row = p.stats + ((long long)blockIdx.x * p.Cout + c) * 2;
+#pragma unroll
+            for (int q = 0; q < 8; q += 2) {
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+                for (int y = 0; y < 8; ++y) { a0 += red[y][tx][q]; a1 += red[y][tx][8 + q]; a2 += red[y][tx][q + 1]; a3 += red[y][tx][8 + q + 1]; }
+                *(f32x4*)(row + q * 2) = f32x4{a0, a1, a2, a3};
+            }
+        }
+    }
+#endif
+}
+
 // The host's plan: blocks per filter tile (B), column blocks per block (q, + 1 for the first r), the widest body whose worst-case halo patch fits the
 // patch buffer, tiles per block for the two run lengths.
 struct V10Plan {
-    int B, q, r, mp_max, nt_hi, nt_lo, n_tiles, xq, half;
+    int B, q, r, mp_max, nt_hi, nt_lo, n_tiles, xq, half, S;
 };
 static int v10_patch_pieces(const ConvArgs& a, int mp) {   // worst case over tile positions: (vp - 1) pixels + 2 pad columns per row crossing + a zero row per image crossing + the halo
     const int vp = mp * 32, PW = a.W + 2;
@@ -395,6 +488,7 @@ static bool v10_plan_form(const ConvArgs& a, V10Plan& pl, bool half) {
     const int mp_lo = half ? V10Geom<true>::MP_LO : V10Geom<false>::MP_LO, mp_hi = half ? V10Geom<true>::MP_HI : V10Geom<false>::MP_HI;
     const int maxpiece = half ? V10Geom<true>::MAXPIECE : V10Geom<false>::MAXPIECE;
     pl.half = half ? 1 : 0;
+    pl.S = 1;
     pl.mp_max = 0;
     for (int mp = mp_hi; mp >= mp_lo; --mp) {
         if (force_mp >= mp_lo && force_mp <= mp_hi && mp > force_mp) continue;
@@ -424,7 +518,8 @@ static bool v10_plan(const ConvArgs& a, V10Plan& pl) {
     return v10_plan_form(a, pl, false);
 }
 
-static bool v10_eligible(const ConvArgs& a) {
+// the shapes the kernel can run at all (either form)
+static bool v10_shape_ok(const ConvArgs& a) {
     if (y3_knob(Y3K_CONV_V10) == 0 || a.ups) return false;
     if (a.ks != 3 || a.stride != 1 || a.pad != 1 || a.dil_shift != 0 || a.ntaps != 9 || a.omul != 1 || a.ooh != 0 || a.oow != 0) return false;
     if (a.H != a.Ho || a.W != a.Wo || a.oH != a.Ho || a.oW != a.Wo) return false;
@@ -436,55 +531,77 @@ static bool v10_eligible(const ConvArgs& a) {
     if ((long long)(a.N + 1) * (a.H + 1) * (a.W + 2) >= 0x7fffffffLL) return false;
     if ((long long)(a.Cout / 256) * 4 * 9 * (a.Cin / 32) * 4096 >= 0x7fffffffLL) return false;
     if (a.Cin < 128 && y3_knob(Y3K_CONV_V10) != 2) return false;   // K = 288 / 576: the strip kernels and the small tiles (conv_strip.h, v3)
-    // below a quarter round of 256-pixel tiles the K-split of conv_v7.h (small batches) is what fills the chip
-    if ((long long)y3_ceil_div(a.M, 256) * (a.Cout / 256) < 64 && y3_knob(Y3K_CONV_V10) != 2) return false;
+    return true;
+}
+// a quarter round of 256-pixel tiles or more: whole tiles fill the chip
+static bool v10_big_enough(const ConvArgs& a) { return (long long)y3_ceil_div(a.M, 256) * (a.Cout / 256) >= 64 || y3_knob(Y3K_CONV_V10) == 2; }
+
+static bool v10_eligible(const ConvArgs& a) {
+    if (!v10_shape_ok(a) || !v10_big_enough(a)) return false;
     V10Plan pl;
     return v10_plan(a, pl);
+}
+
+// SPLIT form (small launches, needs the caller's workspace): the half-size geometry where its patch fits (more, smaller tiles), S slices of the channel blocks so that
+// (filter tiles x blocks x slices) reaches the resident block count; knob v10_slices forces S (tests)
+static bool v10k_plan(const ConvArgs& a, V10Plan& pl) {
+    if (!v10_plan_form(a, pl, true) && !v10_plan_form(a, pl, false)) return false;
+    const int ncb = a.Cin / 32, cus = y3_cu_count();
+    const long long nb1 = (long long)(a.Cout / 256) * pl.B;
+    const long long target = (long long)(pl.half ? 2 : 1) * cus;
+    long long S = (target + nb1 - 1) / nb1;
+    const long long force = y3_knob(Y3K_V10_SLICES);
+    if (force > 0) S = force;
+    if (S > ncb) S = ncb;
+    const size_t per = (size_t)a.M * (size_t)a.Cout * 4;
+    if (!a.ws || a.ws_bytes <= V10_WS_SLABS || per == 0) return false;
+    const long long fit = (long long)((a.ws_bytes - V10_WS_SLABS) / per);
+    if (S > fit) S = fit;
+    if (S < 2 && force != 1) return false;   // one slice: nothing to split (the tile kernels take it)
+    if (S < 1) return false;
+    pl.S = (int)S;
+    return nb1 * S <= 0x7fffffffLL;
+}
+static bool v10k_eligible(const ConvArgs& a) {
+    if (y3_knob(Y3K_V10_KSPLIT) == 0 || !v10_shape_ok(a) || (v10_big_enough(a) && y3_knob(Y3K_V10_KSPLIT) != 2)) return false;
+    V10Plan pl;
+    return v10k_plan(a, pl);
+}
+
+static void v10_fill_args(ConvArgs& a, const V10Plan& pl) {
+    a.n_ct = a.Cout / 256;
+    a.n_pt = pl.n_tiles;
+    a.v10_B = pl.B; a.v10_q = pl.q; a.v10_r = pl.r; a.v10_nt_hi = pl.nt_hi; a.v10_nt_lo = pl.nt_lo; a.v10_S = pl.S;
+    set_divisors(a);
+    magic_u31(pl.B, a.dv_ct_mul, a.dv_ct_sh);   // this kernel divides the block id by the blocks per filter tile
+    magic_u31(a.n_ct * pl.B, a.dv_sl_mul, a.dv_sl_sh);   // ... and (SPLIT) by the blocks per slice
+    magic_u31(a.W + 2, a.dv_pw_mul, a.dv_pw_sh);
+    magic_u31(a.H + 1, a.dv_h1_mul, a.dv_h1_sh);
+    a.cin_blocks = a.Cin / 32;
+    a.nk = 9 * a.cin_blocks;
 }
 
 template <typename T> int launch_v10(ConvArgs& a, hipStream_t st) {
     V10Plan pl;
     if (!v10_plan(a, pl)) Y3_FAIL("conv v10: no tile plan (internal)");
-    a.n_ct = a.Cout / 256;
-    a.n_pt = pl.n_tiles;
-    a.v10_B = pl.B; a.v10_q = pl.q; a.v10_r = pl.r; a.v10_nt_hi = pl.nt_hi; a.v10_nt_lo = pl.nt_lo;
-    set_divisors(a);
-    magic_u31(pl.B, a.dv_ct_mul, a.dv_ct_sh);   // this kernel divides the block id by the blocks per filter tile
-    magic_u31(a.W + 2, a.dv_pw_mul, a.dv_pw_sh);
-    magic_u31(a.H + 1, a.dv_h1_mul, a.dv_h1_sh);
-    a.cin_blocks = a.Cin / 32;
-    a.nk = 9 * a.cin_blocks;
+    v10_fill_args(a, pl);
     a.stat_wp = 4;   // statistics rows per tile: one per 64-pixel epilogue pass of the widest body (narrower bodies write zero rows)
     g_last_variant = pl.half ? "v10h" : "v10";
     if (a.dry) return 0;
     const dim3 grid((unsigned)(a.n_ct * pl.B)), block(256);
 #ifdef Y3_ABLATE
-    if (const char* e = getenv("Y3_V10_ABL"); e && std::is_same<T, f16_t>::value) {   // lab build only (f16 instantiations)
-        typedef f16_t T;
+    if (const char* e = getenv("Y3_V10_ABL"); e && std::is_same<T, f16_t>::value && !pl.half) {   // lab build only (f16, one block per CU)
+        typedef f16_t TT;
         const int abl = atoi(e);
+#define Y3_V10_ABL_CASE(XQV, N) case N: hipLaunchKernelGGL((conv_igemm_v10_kernel<TT, XQV, false, false, N>), grid, block, 0, st, a); break;
         if (pl.xq == 2) {
-            switch (abl) {
-                case 1: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, false, 1>), grid, block, 0, st, a); break;
-                case 2: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, false, 2>), grid, block, 0, st, a); break;
-                case 4: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, false, 4>), grid, block, 0, st, a); break;
-                case 5: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, false, 5>), grid, block, 0, st, a); break;
-                case 6: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, false, 6>), grid, block, 0, st, a); break;
-                case 7: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, false, 7>), grid, block, 0, st, a); break;
-                case 8: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, false, 8>), grid, block, 0, st, a); break;
-                default: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, false, 0>), grid, block, 0, st, a); break;
-            }
+            switch (abl) { Y3_V10_ABL_CASE(2, 1) Y3_V10_ABL_CASE(2, 2) Y3_V10_ABL_CASE(2, 4) Y3_V10_ABL_CASE(2, 5) Y3_V10_ABL_CASE(2, 6) Y3_V10_ABL_CASE(2, 7) Y3_V10_ABL_CASE(2, 8)
+                default: hipLaunchKernelGGL((conv_igemm_v10_kernel<TT, 2, false, false, 0>), grid, block, 0, st, a); break; }
         } else {
-            switch (abl) {
-                case 1: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, false, 1>), grid, block, 0, st, a); break;
-                case 2: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, false, 2>), grid, block, 0, st, a); break;
-                case 4: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, false, 4>), grid, block, 0, st, a); break;
-                case 5: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, false, 5>), grid, block, 0, st, a); break;
-                case 6: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, false, 6>), grid, block, 0, st, a); break;
-                case 7: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, false, 7>), grid, block, 0, st, a); break;
-                case 8: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, false, 8>), grid, block, 0, st, a); break;
-                default: hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, false, 0>), grid, block, 0, st, a); break;
-            }
+            switch (abl) { Y3_V10_ABL_CASE(1, 1) Y3_V10_ABL_CASE(1, 2) Y3_V10_ABL_CASE(1, 4) Y3_V10_ABL_CASE(1, 5) Y3_V10_ABL_CASE(1, 6) Y3_V10_ABL_CASE(1, 7) Y3_V10_ABL_CASE(1, 8)
+                default: hipLaunchKernelGGL((conv_igemm_v10_kernel<TT, 1, false, false, 0>), grid, block, 0, st, a); break; }
         }
+#undef Y3_V10_ABL_CASE
         Y3_CHECK_LAUNCH();
         return 0;
     }
@@ -494,6 +611,27 @@ template <typename T> int launch_v10(ConvArgs& a, hipStream_t st) {
         else hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, true>), grid, block, 0, st, a);
     } else if (pl.xq == 2) hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, false>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, false>), grid, block, 0, st, a);
+    Y3_CHECK_LAUNCH();
+    return 0;
+}
+
+// SPLIT form: the tile kernel over (slice, filter tile, run) blocks, then the slab sum
+template <typename T> int launch_v10k(ConvArgs& a, hipStream_t st) {
+    V10Plan pl;
+    if (!v10k_plan(a, pl)) Y3_FAIL("conv v10k: no plan (internal)");
+    v10_fill_args(a, pl);
+    a.n_pt = y3_ceil_div(a.M, 64);   // statistics rows: one per 64-pixel block of the slab sum
+    a.stat_wp = 1;
+    g_last_variant = "v10k";
+    if (a.dry) return 0;
+    const dim3 grid((unsigned)(a.n_ct * pl.B * pl.S)), block(256);
+    if (pl.half) {
+        if (pl.xq == 2) hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, true, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, true, true>), grid, block, 0, st, a);
+    } else if (pl.xq == 2) hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, false, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 1, false, true>), grid, block, 0, st, a);
+    Y3_CHECK_LAUNCH();
+    hipLaunchKernelGGL((conv_v10_reduce_kernel<T>), dim3((unsigned)y3_ceil_div(a.M, 64), (unsigned)a.n_ct), dim3(256), 0, st, a);
     Y3_CHECK_LAUNCH();
     return 0;
 }

@@ -2,10 +2,7 @@
 #pragma once
 enum y3_knob_id {
     Y3K_CONV = 0,       // "conv":        0 per-shape dispatch; 2 register-staged v2; 4 / 5 / 6 the v3 tiles 128x256 / 128x128 BK32 / 128x128 BK64; 15 v6
-    Y3K_CONV_V7,        // "conv_v7":     1 where it measured ahead; 0 never; 2 every eligible shape (also Cin < 256)
-    Y3K_V7_GRID,        // "v7_grid":     0 auto; N > 0 caps the persistent grid; -1 whole tiles; -2 even K split (stream-K)
-    Y3K_V7_GC,          // "v7_gc":       0 auto; 1 / 2 / 4 / 8 filter-tile ranges per XCD group
-    Y3K_CONV_AHEAD,     // "conv_ahead":  K-steps the LDS-DMA requests of v6 / v7 / wgrad_big run ahead of the MFMAs (3; 2 = the round-2 schedule)
+    Y3K_CONV_AHEAD,     // "conv_ahead":  K-steps the LDS-DMA requests of v6 / wgrad_big run ahead of the MFMAs (3; 2 = the round-2 schedule)
     Y3K_BN_NT_BYTES,    // "bn_nt_bytes": tensors at least this large take the non-temporal forms of the elementwise BatchNorm passes
     Y3K_WGRAD,          // "wgrad":       0 per-shape; 2 the 128x128 kernel; 3 the 256x256 kernel wherever the shape allows; 4 the direct fp32 kernel
     Y3K_WGRAD_XCD,      // "wgrad_xcd":   0 dispatch order; 1 a slice's tiles on one XCD for the 128-tile kernel; 2 + the 256-tile kernel; 3 all
@@ -17,6 +14,8 @@ enum y3_knob_id {
     Y3K_V10_MP,         // "v10_mp":      0 the widest body whose halo patch fits; 6 / 7 / 8 cap the wave-tile width (32-pixel column blocks) of conv_v10.h (tests)
     Y3K_V10_BLOCKS,     // "v10_blocks":  0 one block per CU; N > 0 blocks per filter tile (tests: blocks that walk many tiles, single-column-block tiles)
     Y3K_V10_HALF,       // "v10_half":    2 the measured choice (Cin <= 256); 0 one block per CU (bodies of 6 / 7 / 8 column blocks); 1 two half-size blocks per CU (bodies of 3 / 4) wherever the form fits
+    Y3K_V10_KSPLIT,     // "v10_ksplit":  1 small launches (below a quarter round of tiles, workspace given) run conv_v10.h's K-split form; 0 never; 2 every eligible launch (tests)
+    Y3K_V10_SLICES,     // "v10_slices":  0 as many slices of the channel blocks as fill the chip; N > 0 force N (tests: uneven splits, one channel block per slice)
     Y3K_COUNT
 };
 long long y3_knob(int id);
