@@ -34,7 +34,7 @@ def main():
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
     ws = ops.conv_workspace(dev)
-    cases = [("3x3 512->1024 @20x20 bs32 (v7)", 32, 20, 20, 512, 1024, 3), ("3x3 128->256 @80x80 bs32 (v3)", 32, 80, 80, 128, 256, 3), ("1x1 256->128 @80x80 bs32", 32, 80, 80, 256, 128, 1)]
+    cases = [("3x3 512->1024 @20x20 bs32 (v10)", 32, 20, 20, 512, 1024, 3), ("3x3 128->256 @80x80 bs32 (v10h)", 32, 80, 80, 128, 256, 3), ("1x1 256->128 @80x80 bs32", 32, 80, 80, 256, 128, 1)]
     for name, n, h, w, cin, cout, k in cases:
         xv = ops.View.alloc(n, h, w, cin, torch.float16, dev)
         ops.nchw_to_nhwc(torch.randn(n, cin, h, w, generator=g).to(dev), xv)

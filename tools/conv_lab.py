@@ -3,7 +3,7 @@
     python tools/conv_lab.py [--rounds 7] [--reps 20] [--batch 32] [--only 3x3]
 
 Arms per shape (run-time knobs, y3_tune_set): "auto" = the dispatcher's choice with a workspace (v10 where eligible), "no v10" = knob
-conv_v10 = 0 (v7 / v6 / v3 as in round 2), "nows" = y3_conv2d_fwd without a workspace and without v10 (round-1 kernels).
+conv_v10 = 0 (v6 / v3), "nows" = y3_conv2d_fwd without a workspace and without v10 (round-1 kernels).
 Prints median / min microseconds per launch and TFLOP/s.  Inputs are random (DVFS: never time on zeros)."""
 import argparse
 import math

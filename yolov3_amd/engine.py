@@ -244,7 +244,7 @@ class Plan:
         self.activation_bytes = total
         L = _lib.lib()
         dcode = ops.dtype_code(self.dtype)
-        # scratch of the persistent stream-K conv kernel: one per plan (the plan's launches run in order on one stream)
+        # scratch of the K-split conv form (small launches): one per plan (the plan's launches run in order on one stream)
         self.workspace = ops.conv_workspace(self.device) if self.dtype != torch.float32 and any(k == "conv" for k, _ in self.steps) else None
         ws_ptr, ws_bytes = (self.workspace.data_ptr(), self.workspace.numel()) if self.workspace is not None else (None, 0)
         for kind, kw in self.steps:

@@ -96,7 +96,7 @@ def pack_filter(w_oihw: torch.Tensor, cout: int, cin: int, dtype: torch.dtype) -
 
 
 def conv_workspace(device) -> torch.Tensor:
-    """Scratch of the persistent stream-K conv kernel (y3_conv2d_fwd_ws): zero-filled once here, owned by whoever runs convs on ONE
+    """Scratch of the K-split form of the persistent 3x3 kernel (y3_conv2d_fwd_ws: fp32 slabs for small launches): allocated once here, owned by whoever runs convs on ONE
     stream at a time (a compiled plan keeps its own)."""
     return torch.zeros(int(_lib.lib().y3_conv_workspace_bytes()), dtype=torch.uint8, device=device)
 
