@@ -793,6 +793,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_big_kernel(const WgradArgs p) {
 
     const int steps = (m_end_i - (int)m_begin + BKP - 1) / BKP;
     const int half = wv >> 2;   // 0: leading half, 1: trailing half (one barrier interval behind)
+    // a wave whose 128 columns lie beyond the last (tap, channel) column multiplies nothing: 9 * 128 = 1152 columns are 4.5 tiles, so on the 128 -> 256 layers the
+    // `wn = 1` waves of the fifth column tile -- 10 % of the launch's MFMAs -- only stage their share of the operands and keep the barriers (round 4: the chip is
+    // power-bound under these kernels, matrix work that multiplies zeros costs time)
+    const bool idle = nt * 256 + wn * 128 >= p.ks * p.ks * p.Cin;
     dma(0);
     if (steps > 1) dma(1);
     if (steps > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -803,18 +807,22 @@ __global__ __launch_bounds__(512, 2) void wgrad_big_kernel(const WgradArgs p) {
         const bool more = it + 2 < steps;
         if (more) dma((it + 2) & 3);   // requests first: issuing them behind the 24 fragment reads measured +0.85 ms per batch-64 step
         frag a0[2], b0[4], a1[2], b1[4];
-        load_frags(it & 3, std::integral_constant<int, 0>{}, a0, b0);
-        load_frags(it & 3, std::integral_constant<int, 1>{}, a1, b1);
+        if (!idle) {
+            load_frags(it & 3, std::integral_constant<int, 0>{}, a0, b0);
+            load_frags(it & 3, std::integral_constant<int, 1>{}, a1, b1);
+        }
         if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         // ---- MMA(it) ----
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
-        lds_wait6(a0[0], a0[1], b0[0], b0[1], b0[2], b0[3]);   // the fragment reads landed while the wave sat at the barrier
-        lds_wait6(a1[0], a1[1], b1[0], b1[1], b1[2], b1[3]);
-        mma(a0, b0);
-        mma(a1, b1);
+        if (!idle) {
+            lds_wait6(a0[0], a0[1], b0[0], b0[1], b0[2], b0[3]);   // the fragment reads landed while the wave sat at the barrier
+            lds_wait6(a1[0], a1[1], b1[0], b1[1], b1[2], b1[3]);
+            mma(a0, b0);
+            mma(a1, b1);
+        }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -822,6 +830,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_big_kernel(const WgradArgs p) {
     if (!half) __builtin_amdgcn_s_barrier();  // re-align: every wave has passed 2 steps + 2 barriers
 
     // D[row = co][col = n] -> partial tile [n][co] (each lane owns 4 consecutive co: one 16-byte store)
+    if (idle) return;   // (the reduce never reads columns beyond the last tap)
     const int frow = lane & 31, fk = lane >> 5;
     float* tile = p.part + ((size_t)slice_id * gridDim.x + tile_id) * (256 * 256);
 #pragma unroll
