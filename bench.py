@@ -34,9 +34,14 @@ MFMA_PEAK_TFLOPS = 2500.0  # dense fp16/bf16, /opt/skills/guides/MI355X_MICROARC
 HBM_PEAK_GBS = 8000.0
 
 
-def per_kernel_times(plan, reps=5):
+# launch geometries of ONE kernel source are one roofline group: conv_v10.h runs as "v10" (one block per CU), "v10h" (two half-size blocks per CU) and "v10k" (K split
+# for small launches); `roofline.forms` keeps them apart
+KERNEL_FAMILY = {"v10h": "v10", "v10k": "v10"}
+
+
+def per_kernel_times(plan, reps=5, forms=None):
     """HIP-event timing of every launch of the compiled plan on the stream the kernels run on (torch's current
-    stream).  Returns {variant: [flops, bytes, seconds, launches]} averaged over `reps` passes."""
+    stream).  Returns {kernel group: [flops, bytes, seconds, launches]} averaged over `reps` passes; `forms` (a dict) receives the same per dispatched variant name."""
     from yolov3_amd import ops
 
     stream = ops.stream_ptr()
@@ -55,7 +60,12 @@ def per_kernel_times(plan, reps=5):
                 key = ln.kernel + "/3x3"
             elif ln.flops:
                 w = ln.keep[4]
-                key = f"conv_igemm_{plan.conv_variant(ln)}/{w.k}x{w.k}"   # the variant name comes from the library's own dispatcher (y3_conv2d_fwd_variant)
+                var = plan.conv_variant(ln)   # the variant name comes from the library's own dispatcher (y3_conv2d_fwd_variant)
+                key = f"conv_igemm_{KERNEL_FAMILY.get(var, var)}/{w.k}x{w.k}"
+                if forms is not None and (var in KERNEL_FAMILY or var in KERNEL_FAMILY.values()):
+                    if True:
+                        f = forms.setdefault(f"{var}/{w.k}x{w.k}", [0.0, 0.0, 0.0, 0])
+                        f[0] += ln.flops; f[1] += ln.bytes; f[2] += e0.elapsed_time(e1) * 1e-3; f[3] += 1
             else:
                 key = ln.label.split(".")[-1]
             a = acc.setdefault(key, [0.0, 0.0, 0.0, 0])
@@ -417,7 +427,8 @@ def main():
         t_nms_own = timed(lambda: non_max_suppression(pred, **nms_kw))
         cand_own = y3ops.nms_raw.last_candidates / bs
         plan = next(iter(model._plans.values()))
-        groups = per_kernel_times(plan)
+        forms = {}
+        groups = per_kernel_times(plan, forms=forms)
         if args.profile_layers:
             model(x, profile=True)
         dom = max((k for k in groups if groups[k][0] > 0), key=lambda k: groups[k][2])
@@ -450,10 +461,12 @@ def main():
             "frac": round(fl / sec / 1e12 / MFMA_PEAK_TFLOPS, 4) if bound == "mfma" else round(by / sec / 1e9 / HBM_PEAK_GBS, 4),
             "traffic": round(pmc["hbm_bytes_per_launch"]) if "hbm_bytes_per_launch" in pmc else None,
             "traffic_source": f"profiles/{pmc_file} (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, avg per launch of this kernel symbol)" if pmc else None,
-            "traffic_launch_set": f"all {sym_launches // 5} launches per forward of kernel symbol {sym}",
+            "traffic_launch_set": f"all {sym_launches // 5} launches per forward of kernel source {sym} (every instantiation)",
             "algorithmic_bytes_per_launch_same_set": round(sym_bytes / max(sym_launches, 1)),
             "traffic_over_algorithmic": round(pmc["hbm_bytes_per_launch"] / (sym_bytes / max(sym_launches, 1)), 3) if "hbm_bytes_per_launch" in pmc else None,
             "mfma_busy_frac_pmc": round(pmc["mfma_busy_frac_of_simd_cycles"], 4) if "mfma_busy_frac_of_simd_cycles" in pmc else None,
+            "forms": {k: {"ms": round(g[2] / 5 * 1e3, 3), "launches": g[3] // 5, "tflops": round(g[0] / g[2] / 1e12, 1), "frac": round(g[0] / g[2] / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+                      for k, g in sorted(forms.items(), key=lambda kv: -kv[1][2])},   # the launch geometries of the dominant kernel source, apart
             "algorithmic_bytes_per_launch": round(by / nl),
             "launches_per_forward": nl // 5,
             "avg_launch_us": round(sec / nl * 1e6, 2),

@@ -16,8 +16,7 @@ import sqlite3
 import sys
 
 NAMES = [  # (regex on the kernel symbol, bench.py name = "conv_igemm_" + the library's variant name)
-    (r"conv_igemm_v10_kernelIDF16_Li\dELb1E", "conv_igemm_v10h"),
-    (r"conv_igemm_v10_kernelIDF16_Li\dELb0E", "conv_igemm_v10"),
+    (r"conv_igemm_v10_kernelIDF16_", "conv_igemm_v10"),   # every launch geometry of the source (one block per CU, two half-size blocks, K split): bench.py's group
     (r"conv_igemm_v6_kernelIDF16_", "conv_igemm_v6"),
     (r"conv_igemm_v3_kernelIDF16_Li64ELi2ELi2E", "conv_igemm_v3_bk64_128x128"),
     (r"conv_igemm_v3_kernelIDF16_Li32ELi2ELi2E", "conv_igemm_v3_bk32_128x128"),
