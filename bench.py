@@ -484,18 +484,31 @@ def main():
         # to -- same FLOPs, no halo gather, no bias / SiLU / residual epilogue -- measured here, after the timed region, rank 0 at N = 1 only
         if world == 1 and bound == "mfma" and dom.endswith("/3x3"):
             try:
-                ln = max((l for l in plan.launches if l.flops and not getattr(l, "kernel", "") and f"conv_igemm_{plan.conv_variant(l)}/3x3" == dom), key=lambda l: l.flops)
-                d_, xt_, yt_ = ln.keep[0], ln.keep[1], ln.keep[2]
-                Mg, Ng, Kg = yt_.n * yt_.h * yt_.w, d_.cout, 9 * d_.cin
-                ga = torch.randn(Mg, Kg, device=dev, dtype=dtype)
-                gb = torch.randn(Ng, Kg, device=dev, dtype=dtype)
-                for _ in range(3):
-                    torch.matmul(ga, gb.t())
-                t_g = timed(lambda: torch.matmul(ga, gb.t()), n=10)
-                roofline["vendor_gemm_same_shape"] = {"M": Mg, "N": Ng, "K": Kg, "us": round(t_g * 1e6, 1), "tflops": round(2.0 * Mg * Ng * Kg / t_g / 1e12, 1),
-                                                      "frac": round(2.0 * Mg * Ng * Kg / t_g / 1e12 / MFMA_PEAK_TFLOPS, 4),
-                                                      "note": "torch.matmul(A, B^T) fp16/bf16 random operands: hipBLASLt on the GEMM the largest launch of the dominant group is equivalent to (no im2col / halo, no fused epilogue)"}
-                del ga, gb
+                # every distinct GEMM shape of the dominant group, with how many of its launches have that shape: the launch-weighted vendor rate is what the group's
+                # average rate stands beside
+                shapes = {}
+                for l in plan.launches:
+                    if l.flops and not getattr(l, "kernel", ""):
+                        var = plan.conv_variant(l)
+                        if f"conv_igemm_{KERNEL_FAMILY.get(var, var)}/3x3" == dom:
+                            d_, yt_ = l.keep[0], l.keep[2]
+                            key = (yt_.n * yt_.h * yt_.w, d_.cout, 9 * d_.cin)
+                            shapes[key] = shapes.get(key, 0) + 1
+                per_shape, t_all, f_all = [], 0.0, 0.0
+                for (Mg, Ng, Kg), cnt in sorted(shapes.items(), key=lambda kv: -kv[1])[:4]:
+                    ga = torch.randn(Mg, Kg, device=dev, dtype=dtype)
+                    gb = torch.randn(Ng, Kg, device=dev, dtype=dtype)
+                    for _ in range(3):
+                        torch.matmul(ga, gb.t())
+                    t_g = timed(lambda: torch.matmul(ga, gb.t()), n=10)
+                    fl_g = 2.0 * Mg * Ng * Kg
+                    per_shape.append({"M": Mg, "N": Ng, "K": Kg, "launches": cnt, "us": round(t_g * 1e6, 1), "tflops": round(fl_g / t_g / 1e12, 1)})
+                    t_all += cnt * t_g
+                    f_all += cnt * fl_g
+                    del ga, gb
+                roofline["vendor_gemm_same_shape"] = {"tflops": round(f_all / t_all / 1e12, 1), "frac": round(f_all / t_all / 1e12 / MFMA_PEAK_TFLOPS, 4), "per_shape": per_shape,
+                                                      "note": "torch.matmul(A, B^T) fp16/bf16 random operands: hipBLASLt on the plain GEMMs the launches of the dominant group are equivalent to "
+                                                              "(no im2col / halo, no fused epilogue), launch-weighted like `achieved`"}
             except Exception as e:  # noqa: BLE001
                 roofline["vendor_gemm_same_shape"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()   # rank 0 at N = 1 only
