@@ -545,7 +545,10 @@ class TrainPlan:
         # Y3_WGRAD_STREAM=1: filter gradients on a second HIP stream.  Measured at batch 64: backward 48.7 -> 48.0 ms, optimizer wait
         # +0.35 ms -- both kernel families fill the chip on their own, the hardware runs the two queues mostly back to back --
         # so the default keeps everything on the compute stream
-        self.wgrad_stream = torch.cuda.Stream(device=device) if (device.type == "cuda" and os.environ.get("Y3_WGRAD_STREAM", "0") == "1") else None
+        self.wgrad_stream = None
+        if device.type == "cuda" and os.environ.get("Y3_WGRAD_STREAM", "0") == "1":
+            n_cus = int(os.environ.get("Y3_WGRAD_CUS", "0"))   # > 0: the side stream is confined to that many CUs (ops.masked_stream; tools/wgrad_overlap_ab.py)
+            self.wgrad_stream = ops.masked_stream(device, n_cus) if n_cus > 0 else torch.cuda.Stream(device=device)
         # Y3_BN_EPILOGUE=0: statistics by a separate reduction pass over u (A/B runs); fp32 plans always take that path
         self.epilogue_stats = dtype in (torch.float16, torch.bfloat16) and os.environ.get("Y3_BN_EPILOGUE", "1") != "0"
 
@@ -594,6 +597,9 @@ class TrainPlan:
         if self._arena is None or self._arena_off + n_al > self._arena.numel():
             self._arena = torch.empty(max(self._arena_numel, n_al), dtype=torch.float32, device=self.device)
             self._arena_off = 0
+            if self.wgrad_stream is not None:   # written on the side stream, read on the compute stream, whichever pool it came from
+                self._arena.record_stream(self.wgrad_stream)
+                self._arena.record_stream(self._bwd_stream)
         t = self._arena[self._arena_off:self._arena_off + n].view(shape)
         self._arena_off += n_al
         return t
@@ -615,7 +621,7 @@ class TrainPlan:
         du.buf.record_stream(side)   # scratch of this layer: keep it from being recycled while the side stream still reads it
         with torch.cuda.stream(side):
             side.wait_event(ev)
-            dw, db = ops.conv2d_wgrad(x, du, k, s, co_real, ci_real, want_bias=b_param is not None)
+            dw, db = ops.conv2d_wgrad(x, du, k, s, co_real, ci_real, want_bias=b_param is not None, alloc=self.grad_alloc)   # arena slices in host order, as on one stream
             dw.record_stream(cur)
             grads[w_param] = dw      # handed over under the side stream: a gradient sink that launches collectives waits for the right stream
             if b_param is not None:
@@ -689,6 +695,7 @@ class TrainPlan:
         sync = getattr(self.model, "grad_sync", None)  # parallel.GradBuckets: overlapped gradient all-reduce
         grads = _GradSink(sync, sum(p.numel() * 4 for p in self.params))
         self._arena, self._arena_off = None, 0          # a new arena per backward (see grad_alloc)
+        self._bwd_stream = torch.cuda.current_stream() if self.wgrad_stream is not None else None
         for a in self.acts:
             a.drop_grad()
         with torch.no_grad():
