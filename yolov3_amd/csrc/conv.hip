@@ -93,14 +93,6 @@ template <int BK> Y3_DEV int swz(int row) {
     return (row / R) % S;
 }
 
-// Bijective remap of the hardware block id so that consecutive logical tiles share an XCD.
-Y3_DEV int xcd_remap(int b, int nb) {
-    const int xcd = b & 7, i = b >> 3;
-    const int q = nb >> 3, r = nb & 7;
-    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + i;
-}
-
 // forced tile variant for A/B runs (knob "conv", y3_common.h); 3 = per-shape dispatch
 static int conv_variant() {
     const int v = (int)y3_knob(Y3K_CONV);

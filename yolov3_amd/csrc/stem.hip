@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int b = blockIdx.x;
+    int b = blockIdx.x;   // (XCD-grouped tile ids as in stem_pair_kernel were measured on this non-persistent grid: 3 % slower at batch 64, profiles/r04_tile_xcd_ab.txt)
     const int tw = b % p.tiles_w; b /= p.tiles_w;
     const int th = b % p.tiles_h;
     const int n = b / p.tiles_h;
@@ -207,6 +207,7 @@ struct PairArgs {
     void* y;            // NHWC (N, Ho, Wo, 64) view
     int N, Cin, H, W, Ho, Wo, ypitch, act0, act1, kpad1;
     int tiles_w, tiles_h, n_tiles;
+    int xcd;            // 1: block b starts at tile xcd_remap(b) (knob "tile_xcd")
     float divisor;
 #ifdef Y3_TIMELINE
     unsigned long long* tl;
@@ -329,12 +330,16 @@ __global__ __launch_bounds__(256, 2) void stem_pair_kernel(const PairArgs p) {
             }
         }
     };
-    if ((int)blockIdx.x < p.n_tiles) fetch(blockIdx.x);
+    // the tiles of a round (gridDim.x consecutive ids) are spread so that every XCD walks 64 NEIGHBOURING tiles (6.4 tile rows of the image): the halo rows and the
+    // 128-byte lines that horizontally adjacent patches share are then fetched once per XCD and round instead of once per tile (dispatch order puts tile t on XCD t % 8:
+    // PMC 280 MB read per batch-32 launch for a 79 MB image)
+    const int first = p.xcd ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    if (first < p.n_tiles) fetch(first);
 #ifdef Y3_TIMELINE
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
 #endif
-    for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+    for (int tile = first; tile < p.n_tiles; tile += gridDim.x) {
         int b = tile;
         const int tw = b % p.tiles_w; b /= p.tiles_w;
         const int th = b % p.tiles_h;
@@ -480,6 +485,7 @@ struct BneckArgs {
     void* y;            // NHWC (N, H, W, C)
     int N, H, W, xpitch, ypitch, act1, act2, add, kpad1, kpad2;
     int tiles_w, tiles_h, n_tiles;
+    int xcd;            // 1: block b starts at tile xcd_remap(b) (knob "tile_xcd")
     unsigned x_bytes;   // extent of x for the buffer descriptor of the LDS-DMA loads
 };
 constexpr int BC = 32, RC = BC + 2;               // output columns per tile, columns of the cv1 region
@@ -581,8 +587,9 @@ __global__ __launch_bounds__(C * 4, C == 64 ? 2 : 1) void bneck_pair_kernel(cons
             if (c >= RC) { c -= RC; r += 1; }
         }
     };
-    if ((int)blockIdx.x < p.n_tiles) fetch(blockIdx.x);
-    for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+    const int first = p.xcd ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;   // XCD-grouped tile ids: see stem_pair_kernel
+    if (first < p.n_tiles) fetch(first);
+    for (int tile = first; tile < p.n_tiles; tile += gridDim.x) {
         int b = tile;
         const int tw = b % p.tiles_w; b /= p.tiles_w;
         const int th = b % p.tiles_h;
@@ -908,6 +915,7 @@ extern "C" int y3_stem_pair_fwd(const void* x_nchw, int32_t src_dtype, int32_t n
     const long long tiles = (long long)a.tiles_w * a.tiles_h * n;
     if (tiles > 0x7fffffffLL) Y3_FAIL("y3_stem_pair_fwd: too many tiles");
     a.n_tiles = (int)tiles;
+    a.xcd = y3_knob(Y3K_TILE_XCD) != 0;
     a.divisor = divisor;
 #ifdef Y3_TIMELINE
     a.tl = g_pair_tl;
@@ -938,6 +946,7 @@ extern "C" int y3_bneck_pair_fwd(const y3_tensor* x, const void* packed1, const 
     const long long tiles = (long long)a.tiles_w * a.tiles_h * x->n;
     if (tiles > 0x7fffffffLL || (long long)x->n * x->h * x->w > 0x7fffffffLL) Y3_FAIL("y3_bneck_pair_fwd: too many pixels");
     a.n_tiles = (int)tiles;
+    a.xcd = y3_knob(Y3K_TILE_XCD) != 0;
     const long long xb = (((long long)x->n * x->h * x->w - 1) * x->pitch + x->c) * 2;
     if (xb >= 0x7fffffffLL) Y3_FAIL("y3_bneck_pair_fwd: input beyond the 2 GiB reach of a buffer descriptor (split the batch)");
     a.x_bytes = (unsigned)xb;

@@ -43,6 +43,15 @@ void y3_set_error(const char* fmt, ...);
 #include "y3_knobs.h"
 
 // ---- scalar conversions ----------------------------------------------------------------------
+// Bijective remap of the hardware block id (workgroup i runs on XCD i % 8) so that consecutive LOGICAL ids share an XCD: XCD x owns the ids
+// [x * nb / 8, (x + 1) * nb / 8) -- neighbouring tiles then meet in one L2 (conv.hip, conv_v10.h, the persistent tile loops of stem.hip)
+Y3_DEV int xcd_remap(int b, int nb) {
+    const int xcd = b & 7, i = b >> 3;
+    const int q = nb >> 3, r = nb & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + i;
+}
+
 template <typename T> Y3_DEV float to_f32(T v);
 template <> Y3_DEV float to_f32<f16_t>(f16_t v) { return (float)v; }
 template <> Y3_DEV float to_f32<bf16_t>(bf16_t v) { return (float)v; }
