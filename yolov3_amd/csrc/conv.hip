@@ -62,6 +62,9 @@ struct ConvArgs {
     int v10_S;     // conv_v10.h SPLIT form: slices of the channel blocks
     unsigned dv_sl_mul, dv_sl_sh;   // reciprocal of the blocks per slice
     int v10_B, v10_q, v10_r, v10_nt_hi, v10_nt_lo;   // conv_v10.h: blocks per filter tile, 32-pixel column blocks per block (+ 1 for the first r), tiles per block for the two run lengths
+    int v10_tq_h, v10_tr_h, v10_tq_l, v10_tr_l;      // ... a run of q + 1 / q column blocks as nt_hi / nt_lo tiles of tq (+ 1 for the first tr) column blocks
+    int v10_g;                                       // ... blocks per interleave group (the blocks of a filter tile that share an XCD); 1 = every block walks its own contiguous run
+    unsigned dv_g_mul, dv_g_sh;                      // reciprocal of v10_g
     int cs_strips, cs_T, cs_per;   // conv_strip.h: column strips per row, output rows in all, output rows per block
     unsigned dv_pw_mul, dv_pw_sh, dv_h1_mul, dv_h1_sh;   // conv_v10.h: reciprocals of W + 2 and H + 1
 #ifdef Y3_TIMELINE  // debug build only (tools/timeline.py): per-block wall-clock stamps

@@ -90,11 +90,20 @@ __global__ __launch_bounds__(256, HALF ? 2 : 1) void conv_igemm_v10_kernel(const
     const int ct = fdiv(lin, p.dv_ct_mul, p.dv_ct_sh);   // host: the divisor is v10_B here
     const int bi = lin - ct * p.v10_B;
     const bool big = bi < p.v10_r;
-    const int c_run = p.v10_q + (big ? 1 : 0);
-    const int c_start = bi * p.v10_q + (big ? bi : p.v10_r);
     const int nt = big ? p.v10_nt_hi : p.v10_nt_lo;
     const int tile_base = big ? bi * p.v10_nt_hi : p.v10_r * p.v10_nt_hi + (bi - p.v10_r) * p.v10_nt_lo;
-    const int tq = c_run / nt, tr = c_run - tq * nt;   // the run as nt tiles of tq (+ 1 for the first tr) column blocks
+    const int tq = big ? p.v10_tq_h : p.v10_tq_l, tr = big ? p.v10_tr_h : p.v10_tr_l;   // the block's share as nt tiles of tq (+ 1 for the first tr) column blocks
+    // WHICH column blocks: the v10_g blocks of a group (= the blocks of this filter tile on one XCD) own one contiguous range of the pixel axis and take its tiles
+    // round-robin -- in round t the group works on v10_g NEIGHBOURING tiles, so the two halo rows a tile shares with each neighbour are requested by blocks of the same
+    // XCD at the same channel-block step and meet in its L2 (a block walking a contiguous run of its own re-fetched them a tile later, after ~26 MB of other traffic
+    // had passed through the 4 MB).  Tile (t, block i of the group) starts behind the rounds before it and the blocks before it in its round; the first rg blocks of a
+    // group are the ones with the longer share.  v10_g == 1 is the contiguous run (c_start + t tq + min(t, tr)).
+    const int grp = fdiv(bi, p.dv_g_mul, p.dv_g_sh);
+    const int g0 = grp * p.v10_g, gi = bi - g0;
+    const int gsz = min(p.v10_g, p.v10_B - g0);
+    const int rg = max(0, min(gsz, p.v10_r - g0)), sg = gsz - rg;
+    const int gs = g0 * p.v10_q + min(g0, p.v10_r);
+    const int i_hi = min(gi, rg), i_lo = max(gi - rg, 0);
 
     const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
     // the fragment-ordered copy follows the row-major bank
@@ -104,7 +113,10 @@ __global__ __launch_bounds__(256, HALF ? 2 : 1) void conv_igemm_v10_kernel(const
     // geometry of tile t: first / end pixel, padded position of the first pixel, 1 KiB pieces of its halo patch
     auto tile_geom = [&](int t, int& m0, int& m1, int& Qf, int& npiece) {
         const int sz = tq + (t < tr ? 1 : 0);
-        const int c0 = c_start + t * tq + (t < tr ? t : tr);
+        const int th = min(t, p.v10_nt_hi), tl = min(t, p.v10_nt_lo);   // rounds before t in which the long / short shares had a tile
+        const int hi_t = t < p.v10_nt_hi ? p.v10_tq_h + (t < p.v10_tr_h ? 1 : 0) : 0;
+        const int lo_t = t < p.v10_nt_lo ? p.v10_tq_l + (t < p.v10_tr_l ? 1 : 0) : 0;
+        const int c0 = gs + rg * (th * p.v10_tq_h + min(th, p.v10_tr_h)) + sg * (tl * p.v10_tq_l + min(tl, p.v10_tr_l)) + i_hi * hi_t + i_lo * lo_t;
         m0 = c0 * 32;
         m1 = min(m0 + sz * 32, p.M);
         int n, h, w;
@@ -572,6 +584,15 @@ static void v10_fill_args(ConvArgs& a, const V10Plan& pl) {
     a.n_ct = a.Cout / 256;
     a.n_pt = pl.n_tiles;
     a.v10_B = pl.B; a.v10_q = pl.q; a.v10_r = pl.r; a.v10_nt_hi = pl.nt_hi; a.v10_nt_lo = pl.nt_lo; a.v10_S = pl.S;
+    a.v10_tq_h = (pl.q + 1) / pl.nt_hi; a.v10_tr_h = (pl.q + 1) % pl.nt_hi;
+    a.v10_tq_l = pl.nt_lo ? pl.q / pl.nt_lo : 0; a.v10_tr_l = pl.nt_lo ? pl.q % pl.nt_lo : 0;
+    // interleave group = the blocks of one filter tile that xcd_remap puts on one XCD (an eighth of the grid; the whole filter tile when it has fewer); knob v10_group: 0 = contiguous runs
+    const long long nb = (long long)a.n_ct * pl.B * pl.S;
+    int g = y3_knob(Y3K_V10_GROUP) ? (int)(nb / 8) : 1;
+    if (g > pl.B) g = pl.B;
+    if (g < 1) g = 1;
+    a.v10_g = g;
+    magic_u31(g, a.dv_g_mul, a.dv_g_sh);
     set_divisors(a);
     magic_u31(pl.B, a.dv_ct_mul, a.dv_ct_sh);   // this kernel divides the block id by the blocks per filter tile
     magic_u31(a.n_ct * pl.B, a.dv_sl_mul, a.dv_sl_sh);   // ... and (SPLIT) by the blocks per slice

@@ -16,6 +16,7 @@ enum y3_knob_id {
     Y3K_V10_HALF,       // "v10_half":    2 the measured choice (Cin <= 256); 0 one block per CU (bodies of 6 / 7 / 8 column blocks); 1 two half-size blocks per CU (bodies of 3 / 4) wherever the form fits
     Y3K_V10_KSPLIT,     // "v10_ksplit":  1 small launches (below a quarter round of tiles, workspace given) run conv_v10.h's K-split form; 0 never; 2 every eligible launch (tests)
     Y3K_V10_SLICES,     // "v10_slices":  0 as many slices of the channel blocks as fill the chip; N > 0 force N (tests: uneven splits, one channel block per slice)
+    Y3K_V10_GROUP,      // "v10_group":   1 the blocks of a filter tile on one XCD take the tiles of their common pixel range round-robin (neighbouring tiles in flight together: halo rows meet in that L2); 0 every block walks a contiguous run
     Y3K_TILE_XCD,       // "tile_xcd":    1 the persistent tile loops of stem_pair / bneck_pair walk XCD-grouped tile ids (64 neighbouring tiles per XCD and round: halo rows and
                         //                shared cache lines meet in one L2); 0 dispatch order (A/B)
     Y3K_COUNT
