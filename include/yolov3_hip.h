@@ -101,6 +101,12 @@ int y3_conv2d_fwd_ws(const y3_conv_desc* desc, const y3_tensor* x, const void* p
  * The parity tests assert it so that a tolerance is always attached to the kernel that actually ran. */
 int y3_conv2d_fwd_variant(const y3_conv_desc* desc, const y3_tensor* x, const y3_tensor* y, int32_t has_residual,
                           size_t workspace_bytes, char* name, size_t name_capacity);
+/* The tile plan of the persistent 3x3 kernel (csrc/conv_v10.h: "v10", "v10h", "v10k") for this problem; launches nothing.  One record of four int32 per tile of ONE filter
+ * tile -- (block of the filter tile, tile of that block, first 32-pixel column block, column blocks) -- computed by the functions the kernel itself runs, so a host test can
+ * check that the tiles cover the pixel axis exactly once and that the blocks sharing an XCD work on neighbouring tiles (knob "v10_group").  `records` may be NULL
+ * (count only); *column_blocks = ceil(N Ho Wo / 32), *group_blocks = blocks per interleave group.  Fails when the dispatcher picks another kernel for the problem. */
+int y3_conv_v10_tiles(const y3_conv_desc* desc, const y3_tensor* x, const y3_tensor* y, size_t workspace_bytes, int32_t* records,
+                      int64_t capacity, int64_t* n_tiles, int32_t* column_blocks, int32_t* group_blocks);
 /* Name of the variant the last convolution / data-gradient call of the calling thread launched ("v3_quad": the four output-parity
  * classes of y3_conv2d_dgrad_s2 in one launch). */
 int y3_conv_last_variant(char* name, size_t name_cap);

@@ -503,3 +503,82 @@ def test_grad_sink_flushes_the_bucket_before_the_tail_of_the_backward():
     # 3.5 tails seen after the 4th gradient = total - 1 tail: flushed right there, the remaining two gradients fill the last (small) bucket
     assert kinds == ["add", "add", "add", "add", "flush", "add", "add"], kinds
     assert _GradSink(None).result() == {}
+
+
+def test_conv_v10_tiles_cover_the_pixel_axis_and_neighbours_share_a_round():
+    """y3_conv_v10_tiles enumerates the tiles of csrc/conv_v10.h with the functions the kernel itself runs (v10_share / v10_tile_cols).  For the benchmark's shapes,
+    odd batch sizes (ragged shares: two share lengths, two tile counts), forced block counts / body widths and the K-split form: the tiles of a filter tile cover the
+    column blocks of the pixel axis exactly once, no tile is wider than the body allows, and -- knob v10_group -- the blocks of a group (the blocks xcd_remap puts on one
+    XCD) hold NEIGHBOURING tiles in every round, so the halo rows two tiles share are requested in one L2 at the same time; v10_group = 0 gives every block a contiguous
+    run of its own (the order before the knob)."""
+    import ctypes as C
+
+    from yolov3_amd import _lib
+    from yolov3_amd._lib import Y3Tensor
+
+    L = _lib.lib()
+    ws = L.y3_conv_workspace_bytes()
+
+    def tiles(bs, cin, cout, hw, workspace=0):
+        x, y, d = Y3Tensor(4096, bs, hw, hw, cin, cin), Y3Tensor(8192, bs, hw, hw, cout, cout), _desc(_lib.Y3_F16, 3, 1, cin, cout)
+        n, cb, g = C.c_int64(0), C.c_int32(0), C.c_int32(0)
+        assert L.y3_conv_v10_tiles(C.byref(d), C.byref(x), C.byref(y), workspace, None, 0, C.byref(n), C.byref(cb), C.byref(g)) == 0, L.y3_last_error()
+        rec = (C.c_int32 * (4 * n.value))()
+        assert L.y3_conv_v10_tiles(C.byref(d), C.byref(x), C.byref(y), workspace, rec, n.value, C.byref(n), C.byref(cb), C.byref(g)) == 0
+        name = C.create_string_buffer(64)
+        assert L.y3_conv2d_fwd_variant(C.byref(d), C.byref(x), C.byref(y), 0, workspace, name, 64) == 0
+        return [tuple(rec[4 * i:4 * i + 4]) for i in range(n.value)], cb.value, g.value, name.value.decode()
+
+    def check(recs, cb, g, max_body, grouped):
+        assert cb == sum(r[3] for r in recs)
+        pos = 0
+        for _, _, c0, sz in sorted(recs, key=lambda r: r[2]):   # exact cover, no overlap, no gap
+            assert c0 == pos and 1 <= sz <= max_body, (c0, pos, sz)
+            pos += sz
+        assert pos == cb
+        per_block = {}
+        for bi, t, c0, sz in recs:
+            per_block.setdefault(bi, []).append((t, c0, sz))
+        if not grouped:
+            for bi, ts in per_block.items():   # a contiguous run per block
+                ts.sort()
+                assert all(ts[i][1] + ts[i][2] == ts[i + 1][1] for i in range(len(ts) - 1)), bi
+            return
+        # round t of a group: its blocks, in block order, hold consecutive tiles
+        n_blocks = max(per_block) + 1
+        for g0 in range(0, n_blocks, g):
+            rounds = {}
+            for bi in range(g0, min(g0 + g, n_blocks)):
+                for t, c0, sz in per_block[bi]:
+                    rounds.setdefault(t, []).append((bi, c0, sz))
+            end_prev = None
+            for t in sorted(rounds):
+                r = sorted(rounds[t])
+                assert all(r[i][1] + r[i][2] == r[i + 1][1] for i in range(len(r) - 1)), (g0, t)   # neighbours within the round
+                if end_prev is not None:
+                    assert r[0][1] == end_prev, (g0, t)                                            # the next round continues where this one ended
+                end_prev = r[-1][1] + r[-1][2]
+
+    try:
+        for knob in (1, 0):
+            assert L.y3_tune_set(b"v10_group", knob) == 0
+            for bs, cin, cout, hw in [(32, 128, 256, 80), (32, 256, 512, 40), (32, 512, 1024, 20), (64, 128, 256, 80), (64, 512, 1024, 20), (37, 128, 256, 80), (29, 256, 512, 40),
+                                      (51, 512, 1024, 20), (8, 128, 256, 160), (13, 256, 256, 52)]:
+                recs, cb, g, name = tiles(bs, cin, cout, hw)
+                assert name in ("v10", "v10h") and cb == (bs * hw * hw + 31) // 32, (name, cb)
+                n_ct, blocks = cout // 256, max(r[0] for r in recs) + 1   # filter tiles, blocks per filter tile (two per CU in the half form, fewer on short pixel axes)
+                assert blocks <= 256 * (2 if name == "v10h" else 1) // n_ct
+                assert g == (max(1, min(n_ct * blocks // 8, blocks)) if knob else 1), (g, name, n_ct, blocks)   # an eighth of the grid = what xcd_remap puts on one XCD
+                check(recs, cb, g, 4 if name == "v10h" else 8, bool(knob))
+            # forced geometries of the GPU tests: few blocks walking many tiles, single-column-block bodies, the K-split form of a small launch
+            for blocks, mp in ((3, 0), (7, 6), (50, 0)):
+                assert L.y3_tune_set(b"v10_blocks", blocks) == 0 and L.y3_tune_set(b"v10_mp", mp) == 0 and L.y3_tune_set(b"conv_v10", 2) == 0
+                recs, cb, g, name = tiles(3, 128, 256, 38)
+                assert len({r[0] for r in recs}) == min(blocks, cb)
+                check(recs, cb, g, 8, bool(knob))
+                assert L.y3_tune_set(b"v10_blocks", 0) == 0 and L.y3_tune_set(b"v10_mp", 0) == 0 and L.y3_tune_set(b"conv_v10", 1) == 0
+            recs, cb, g, name = tiles(2, 256, 512, 40, workspace=ws)
+            assert name == "v10k"
+            check(recs, cb, g, 8, bool(knob))
+    finally:
+        L.y3_tune_reset()

@@ -85,6 +85,7 @@ _SIGNATURES = {
     "y3_conv2d_fwd_ws": (C.c_int, [_P(Y3ConvDesc), _P(Y3Tensor), C.c_void_p, C.c_void_p, _P(Y3Tensor), _P(Y3Tensor), C.c_void_p, C.c_size_t, C.c_void_p]),
     "y3_conv_last_variant": (C.c_int, [C.c_char_p, C.c_size_t]),
     "y3_conv2d_fwd_variant": (C.c_int, [_P(Y3ConvDesc), _P(Y3Tensor), _P(Y3Tensor), C.c_int32, C.c_size_t, C.c_char_p, C.c_size_t]),
+    "y3_conv_v10_tiles": (C.c_int, [_P(Y3ConvDesc), _P(Y3Tensor), _P(Y3Tensor), C.c_size_t, _P(C.c_int32), C.c_int64, _P(C.c_int64), _P(C.c_int32), _P(C.c_int32)]),
     "y3_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P(Y3Tensor), C.c_void_p]),
     "y3_nhwc_to_nchw": (C.c_int, [_P(Y3Tensor), C.c_int32, C.c_void_p, C.c_void_p]),
     "y3_maxpool2d": (C.c_int, [_P(Y3Tensor), _P(Y3Tensor), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

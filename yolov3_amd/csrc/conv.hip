@@ -1279,6 +1279,32 @@ extern "C" int y3_conv2d_fwd_variant(const y3_conv_desc* d, const y3_tensor* x, 
     return 0;
 }
 
+// The tiles of the persistent 3x3 kernel for this problem, as its blocks compute them (nothing is launched): one record (block of the filter tile, tile of the block,
+// first 32-pixel column block, column blocks) per tile of ONE filter tile, from the very functions the kernel runs (v10_share / v10_tile_cols, conv_v10.h)
+extern "C" int y3_conv_v10_tiles(const y3_conv_desc* d, const y3_tensor* x, const y3_tensor* y, size_t workspace_bytes, int32_t* records, int64_t capacity, int64_t* n_tiles,
+                                 int32_t* column_blocks, int32_t* group_blocks) {
+    if (!n_tiles) Y3_FAIL("y3_conv_v10_tiles: null argument");
+    alignas(256) static const float dummy[64] = {0.0f};   // geometry only: never dereferenced
+    g_v10_dry_valid = false;
+    const int rc = conv_fwd_impl(d, x, (const void*)dummy, dummy, nullptr, y, nullptr, 0, nullptr, 1, nullptr, workspace_bytes ? (void*)dummy : nullptr, workspace_bytes);
+    if (rc) return rc;
+    if (!g_v10_dry_valid) Y3_FAIL("y3_conv_v10_tiles: the dispatcher picks '%s' for this problem, not conv_v10.h", g_last_variant);
+    const ConvArgs& a = g_v10_dry;
+    int64_t n = 0;
+    for (int bi = 0; bi < a.v10_B; ++bi) {
+        const V10Share sh = v10_share(a, bi, bi / a.v10_g);
+        for (int t = 0; t < sh.nt; ++t, ++n) {
+            int c0, sz;
+            v10_tile_cols(a, sh, t, c0, sz);
+            if (records && n < capacity) { records[4 * n] = bi; records[4 * n + 1] = t; records[4 * n + 2] = c0; records[4 * n + 3] = sz; }
+        }
+    }
+    *n_tiles = n;
+    if (column_blocks) *column_blocks = (a.M + 31) / 32;
+    if (group_blocks) *group_blocks = a.v10_g;
+    return 0;
+}
+
 // name of the kernel variant the LAST conv / data-gradient call of this thread launched ("v3_quad" = the four parity classes of a
 // stride-2 data gradient in one launch): tests assert the path they mean to exercise
 extern "C" int y3_conv_last_variant(char* name, size_t name_cap) {

@@ -59,6 +59,45 @@ template <int N> Y3_DEV void v10_wait_vm() { __builtin_amdgcn_s_waitcnt((N & 15)
 #endif
 constexpr size_t V10_WS_SLABS = 8192;   // byte offset of the fp32 slabs in the conv workspace (the first bytes were round 2's control words: left alone)
 
+// ---- which column blocks a block computes (host + device: the kernel and y3_conv_v10_tiles -- the CPU test of the tiling -- run the same arithmetic) --------------------
+// Block bi of a filter tile computes nt tiles of tq (+ 1 for the first tr) 32-pixel column blocks: q + 1 column blocks in nt_hi tiles for the first r blocks ("long
+// share"), q in nt_lo tiles for the others.  WHICH column blocks: the v10_g blocks of a group (= the blocks of this filter tile on one XCD) own one contiguous range of
+// the pixel axis and take its tiles round-robin -- in round t the group works on v10_g NEIGHBOURING tiles, so the two halo rows a tile shares with each neighbour are
+// requested by blocks of the same XCD at the same channel-block step and meet in its L2 (a block walking a contiguous run of its own re-fetched them a tile later,
+// after ~26 MB of other traffic had passed through the 4 MB).  Tile (t, block i of the group) starts behind the rounds before it and the blocks before it in its
+// round; the first rg blocks of a group are the ones with the long share.  v10_g == 1 is the contiguous run (bi q + min(bi, r) + t tq + min(t, tr)).
+__host__ __device__ inline int v10_imin(int a, int b) { return a < b ? a : b; }
+__host__ __device__ inline int v10_imax(int a, int b) { return a > b ? a : b; }
+struct V10Share {
+    bool big;                     // long share
+    int nt, tile_base, tq, tr;    // tiles, index of the first one among the filter tile's tiles (statistics rows), column blocks per tile (+ 1 for the first tr)
+    int gs, rg, sg, i_hi, i_lo;   // group: first column block, blocks with the long / short share, blocks of either kind in front of this one
+};
+__host__ __device__ inline V10Share v10_share(const ConvArgs& p, int bi, int grp) {   // grp = bi / p.v10_g (the caller divides: multiply-shift on the device)
+    V10Share s;
+    s.big = bi < p.v10_r;
+    s.nt = s.big ? p.v10_nt_hi : p.v10_nt_lo;
+    s.tile_base = s.big ? bi * p.v10_nt_hi : p.v10_r * p.v10_nt_hi + (bi - p.v10_r) * p.v10_nt_lo;
+    s.tq = s.big ? p.v10_tq_h : p.v10_tq_l;
+    s.tr = s.big ? p.v10_tr_h : p.v10_tr_l;
+    const int g0 = grp * p.v10_g, gi = bi - g0;
+    const int gsz = v10_imin(p.v10_g, p.v10_B - g0);
+    s.rg = v10_imax(0, v10_imin(gsz, p.v10_r - g0));
+    s.sg = gsz - s.rg;
+    s.gs = g0 * p.v10_q + v10_imin(g0, p.v10_r);
+    s.i_hi = v10_imin(gi, s.rg);
+    s.i_lo = v10_imax(gi - s.rg, 0);
+    return s;
+}
+// tile t of the share: first column block and column blocks
+__host__ __device__ inline void v10_tile_cols(const ConvArgs& p, const V10Share& s, int t, int& c0, int& sz) {
+    sz = s.tq + (t < s.tr ? 1 : 0);
+    const int th = v10_imin(t, p.v10_nt_hi), tl = v10_imin(t, p.v10_nt_lo);   // rounds before t in which the long / short shares had a tile
+    const int hi_t = t < p.v10_nt_hi ? p.v10_tq_h + (t < p.v10_tr_h ? 1 : 0) : 0;
+    const int lo_t = t < p.v10_nt_lo ? p.v10_tq_l + (t < p.v10_tr_l ? 1 : 0) : 0;
+    c0 = s.gs + s.rg * (th * p.v10_tq_h + v10_imin(th, p.v10_tr_h)) + s.sg * (tl * p.v10_tq_l + v10_imin(tl, p.v10_tr_l)) + s.i_hi * hi_t + s.i_lo * lo_t;
+}
+
 template <typename T, int XQ, bool HALF, bool SPLIT = false, int ABL = 0>
 __global__ __launch_bounds__(256, HALF ? 2 : 1) void conv_igemm_v10_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -89,21 +128,8 @@ __global__ __launch_bounds__(256, HALF ? 2 : 1) void conv_igemm_v10_kernel(const
     }
     const int ct = fdiv(lin, p.dv_ct_mul, p.dv_ct_sh);   // host: the divisor is v10_B here
     const int bi = lin - ct * p.v10_B;
-    const bool big = bi < p.v10_r;
-    const int nt = big ? p.v10_nt_hi : p.v10_nt_lo;
-    const int tile_base = big ? bi * p.v10_nt_hi : p.v10_r * p.v10_nt_hi + (bi - p.v10_r) * p.v10_nt_lo;
-    const int tq = big ? p.v10_tq_h : p.v10_tq_l, tr = big ? p.v10_tr_h : p.v10_tr_l;   // the block's share as nt tiles of tq (+ 1 for the first tr) column blocks
-    // WHICH column blocks: the v10_g blocks of a group (= the blocks of this filter tile on one XCD) own one contiguous range of the pixel axis and take its tiles
-    // round-robin -- in round t the group works on v10_g NEIGHBOURING tiles, so the two halo rows a tile shares with each neighbour are requested by blocks of the same
-    // XCD at the same channel-block step and meet in its L2 (a block walking a contiguous run of its own re-fetched them a tile later, after ~26 MB of other traffic
-    // had passed through the 4 MB).  Tile (t, block i of the group) starts behind the rounds before it and the blocks before it in its round; the first rg blocks of a
-    // group are the ones with the longer share.  v10_g == 1 is the contiguous run (c_start + t tq + min(t, tr)).
-    const int grp = fdiv(bi, p.dv_g_mul, p.dv_g_sh);
-    const int g0 = grp * p.v10_g, gi = bi - g0;
-    const int gsz = min(p.v10_g, p.v10_B - g0);
-    const int rg = max(0, min(gsz, p.v10_r - g0)), sg = gsz - rg;
-    const int gs = g0 * p.v10_q + min(g0, p.v10_r);
-    const int i_hi = min(gi, rg), i_lo = max(gi - rg, 0);
+    const V10Share sh = v10_share(p, bi, fdiv(bi, p.dv_g_mul, p.dv_g_sh));   // (comment above v10_share)
+    const int nt = sh.nt, tile_base = sh.tile_base, tq = sh.tq, tr = sh.tr;
 
     const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
     // the fragment-ordered copy follows the row-major bank
@@ -112,11 +138,8 @@ __global__ __launch_bounds__(256, HALF ? 2 : 1) void conv_igemm_v10_kernel(const
 
     // geometry of tile t: first / end pixel, padded position of the first pixel, 1 KiB pieces of its halo patch
     auto tile_geom = [&](int t, int& m0, int& m1, int& Qf, int& npiece) {
-        const int sz = tq + (t < tr ? 1 : 0);
-        const int th = min(t, p.v10_nt_hi), tl = min(t, p.v10_nt_lo);   // rounds before t in which the long / short shares had a tile
-        const int hi_t = t < p.v10_nt_hi ? p.v10_tq_h + (t < p.v10_tr_h ? 1 : 0) : 0;
-        const int lo_t = t < p.v10_nt_lo ? p.v10_tq_l + (t < p.v10_tr_l ? 1 : 0) : 0;
-        const int c0 = gs + rg * (th * p.v10_tq_h + min(th, p.v10_tr_h)) + sg * (tl * p.v10_tq_l + min(tl, p.v10_tr_l)) + i_hi * hi_t + i_lo * lo_t;
+        int c0, sz;
+        v10_tile_cols(p, sh, t, c0, sz);
         m0 = c0 * 32;
         m1 = min(m0 + sz * 32, p.M);
         int n, h, w;
@@ -481,6 +504,9 @@ __global__ __launch_bounds__(256) void conv_v10_reduce_kernel(const ConvArgs p) 
 #endif
 }
 
+static thread_local ConvArgs g_v10_dry;              // the arguments a dry run of this kernel filled (y3_conv_v10_tiles)
+static thread_local bool g_v10_dry_valid = false;
+
 // The host's plan: blocks per filter tile (B), column blocks per block (q, + 1 for the first r), the widest body whose worst-case halo patch fits the
 // patch buffer, tiles per block for the two run lengths.
 struct V10Plan {
@@ -608,7 +634,7 @@ template <typename T> int launch_v10(ConvArgs& a, hipStream_t st) {
     v10_fill_args(a, pl);
     a.stat_wp = 4;   // statistics rows per tile: one per 64-pixel epilogue pass of the widest body (narrower bodies write zero rows)
     g_last_variant = pl.half ? "v10h" : "v10";
-    if (a.dry) return 0;
+    if (a.dry) { g_v10_dry = a; g_v10_dry_valid = true; return 0; }
     const dim3 grid((unsigned)(a.n_ct * pl.B)), block(256);
 #ifdef Y3_ABLATE
     if (const char* e = getenv("Y3_V10_ABL"); e && std::is_same<T, f16_t>::value && !pl.half) {   // lab build only (f16, one block per CU)
@@ -644,7 +670,7 @@ template <typename T> int launch_v10k(ConvArgs& a, hipStream_t st) {
     a.n_pt = y3_ceil_div(a.M, 64);   // statistics rows: one per 64-pixel block of the slab sum
     a.stat_wp = 1;
     g_last_variant = "v10k";
-    if (a.dry) return 0;
+    if (a.dry) { g_v10_dry = a; g_v10_dry_valid = true; return 0; }
     const dim3 grid((unsigned)(a.n_ct * pl.B * pl.S)), block(256);
     if (pl.half) {
         if (pl.xq == 2) hipLaunchKernelGGL((conv_igemm_v10_kernel<T, 2, true, true>), grid, block, 0, st, a);
