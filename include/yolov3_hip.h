@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define Y3_ABI_VERSION 2
+#define Y3_ABI_VERSION 3
 
 typedef enum { Y3_F16 = 0, Y3_BF16 = 1, Y3_F32 = 2, Y3_U8 = 3 } y3_dtype;
 typedef enum { Y3_ACT_NONE = 0, Y3_ACT_SILU = 1 } y3_act;
@@ -235,7 +235,7 @@ int y3_match_detections(const float* dets, int64_t img_stride, int32_t row_strid
  * shape and dtype as preds[i]) with d(out4[0]) / d preds[i] * grad_out[0] (grad_out: DEVICE scalar or NULL = 1).
  * Duplicate matches of one cell: tobj takes the LAST match in the reference's list order (CPU index_put), box/cls
  * gradients accumulate.  A target whose image index is outside [0, bs) or whose class is outside [0, nc) (the reference raises an
- * IndexError on the host) is skipped and turns out4 into NaN: the step fails loudly instead of reading out of bounds.  gr = 1, autobalance off, sort_obj_iou off (the reference's defaults). */
+ * IndexError on the host) is skipped and turns out4 into NaN: the step fails loudly instead of reading out of bounds.  gr = 1 (the reference's value); autobalance: y3_loss_level_obj below. */
 typedef struct {
     int32_t nl, na, nc, bs;
     int32_t ny[5], nx[5];
@@ -246,6 +246,8 @@ typedef struct {
     float cls_pw, obj_pw;               /* BCE pos_weight */
     float cp, cn;                       /* smooth_bce(label_smoothing) */
     float fl_gamma;                     /* 0 = plain BCE */
+    int32_t sort_obj_iou;               /* ComputeLoss.sort_obj_iou (:101,156-158): a cell matched by several targets keeps its LARGEST iou as objectness target
+                                           (the reference writes tobj in ascending-iou order); 0 = the last match in list order wins, the reference's default (ABI 3) */
 } y3_loss_params;
 size_t y3_loss_workspace_bytes(const y3_loss_params* p, int32_t nt);
 int y3_loss_fwd(const y3_loss_params* p, int32_t dtype, const void* const* preds, const float* targets, int32_t nt,

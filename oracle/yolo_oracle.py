@@ -346,12 +346,13 @@ def build_targets(shapes, targets, anchors_grid, anchor_t=4.0):
     return out
 
 
-def compute_loss(p, targets, anchors_grid, hyp, nc, balance=None, autobalance_ssi=None):
+def compute_loss(p, targets, anchors_grid, hyp, nc, balance=None, autobalance_ssi=None, sort_obj_iou=False):
     """reference utils/loss.py:131-181 with criteria from :104-129 (BCEWithLogits with pos_weight,
     label smoothing, balance [4,1,0.4] for 3 levels else first nl of [4,1,.25,.06,.02]; gr=1).
     FocalLoss (:31-63) applied when hyp['fl_gamma']>0.  `balance`: the per-level objectness weights to use (a list that is UPDATED IN PLACE
     when `autobalance_ssi` is given: utils/loss.py:171-175, each level's weight moves by 1e-4 towards 1 / its objectness loss after that
     level's term was added, then all are divided by the weight of the stride-16 level `autobalance_ssi`).
+    `sort_obj_iou`: ComputeLoss.sort_obj_iou (:101, :156-158; default False).
     Returns (loss(1,), items(3,), aux) where loss=(lbox+lobj+lcls)*bs (:181)."""
     nl = len(p)
     if balance is None:
@@ -383,7 +384,11 @@ def compute_loss(p, targets, anchors_grid, hyp, nc, balance=None, autobalance_ss
             pwh = (pwh.sigmoid() * 2) ** 2 * anch
             iou = upstream.bbox_iou(torch.cat((pxy, pwh), 1), tbox, CIoU=True).squeeze(-1)
             lbox = lbox + (1.0 - iou).mean()
-            tobj[b, a, gj, gi] = iou.detach().clamp(0).type(tobj.dtype)
+            iou_t = iou.detach().clamp(0).type(tobj.dtype)
+            if sort_obj_iou:   # utils/loss.py:156-158: written in ascending-iou order -- of several matches of one cell the largest iou stays
+                j = iou_t.argsort()
+                b, a, gj, gi, iou_t = b[j], a[j], gj[j], gi[j], iou_t[j]
+            tobj[b, a, gj, gi] = iou_t
             if nc > 1:
                 t = torch.full_like(pcls, cn)
                 t[range(n), tcls] = cp

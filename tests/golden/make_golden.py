@@ -162,7 +162,11 @@ def gen_nms_goldens(ns):
 
 def gen_loss_goldens(ns):
     out = {}
-    for name, nc, hw, bs, nt_mode in [("yolov3", 80, 128, 3, "synth"), ("yolov3-tiny", 80, 96, 2, "synth"), ("yolov3", 80, 64, 2, "empty"), ("yolov3", 5, 64, 2, "dups"), ("yolov3", 5, 64, 2, "edges")]:
+    # ("...-sorted": ComputeLoss.sort_obj_iou = True, utils/loss.py:101,156-158 -- the duplicate-cell case keeps another iou than the default order does)
+    for name, nc, hw, bs, nt_mode in [("yolov3", 80, 128, 3, "synth"), ("yolov3-tiny", 80, 96, 2, "synth"), ("yolov3", 80, 64, 2, "empty"), ("yolov3", 5, 64, 2, "dups"), ("yolov3", 5, 64, 2, "edges"),
+                                      ("yolov3", 5, 64, 2, "dups_sorted")]:
+        sort_iou = nt_mode.endswith("_sorted")
+        key_mode, nt_mode = nt_mode, nt_mode.replace("_sorted", "")
         m, sd, layers, save, strides = build_ref_model(ns, name, nc, seed=13)
         hyp = dict(HYP)
         nl = len(strides)
@@ -171,6 +175,7 @@ def gen_loss_goldens(ns):
         hyp["obj"] *= (hw / 640) ** 2 * 3 / nl
         m.hyp = hyp
         crit = ns.ComputeLoss(m)
+        crit.sort_obj_iou = sort_iou
         p = [t.requires_grad_(True) for t in yo.synth_raw_predictions([(bs, 3, hw // s, hw // s, nc + 5) for s in strides], seed=31)]
         if nt_mode == "synth":
             tg = yo.synth_targets(bs, nc, seed=1)
@@ -188,7 +193,7 @@ def gen_loss_goldens(ns):
             )
         loss, items = crit(p, tg)
         loss.backward()
-        out[f"{name}-nc{nc}-{hw}-{nt_mode}"] = {
+        out[f"{name}-nc{nc}-{hw}-{key_mode}"] = {
             "hyp": hyp,
             "p_sum": sum(checksum(t.detach()) for t in p),
             "bs": bs,
@@ -198,7 +203,7 @@ def gen_loss_goldens(ns):
             "grads": [t.grad.clone() for t in p],
             "anchors_grid": m.model[-1].anchors.clone(),
         }
-        print("loss", name, nc, hw, nt_mode, float(loss), items.tolist())
+        print("loss", name, nc, hw, key_mode, float(loss), items.tolist())
     torch.save(out, OUT / "loss.pt")
 
 

@@ -737,7 +737,7 @@ def _loss_setup(dev, name, nc, hw, hyp):
     return m, ComputeLoss(m)
 
 
-LOSS_CASES = ["yolov3-nc80-128-synth", "yolov3-tiny-nc80-96-synth", "yolov3-nc80-64-empty", "yolov3-nc5-64-dups", "yolov3-nc5-64-edges"]
+LOSS_CASES = ["yolov3-nc80-128-synth", "yolov3-tiny-nc80-96-synth", "yolov3-nc80-64-empty", "yolov3-nc5-64-dups", "yolov3-nc5-64-edges", "yolov3-nc5-64-dups_sorted"]
 
 
 @pytest.mark.parametrize("key", LOSS_CASES)
@@ -747,6 +747,7 @@ def test_loss_vs_reference_golden(dev, golden_dir, key):
     name, nc, hw, mode = key.rsplit("-", 3)
     nc, hw = int(nc[2:]), int(hw)
     m, crit = _loss_setup(dev, name, nc, hw, rec["hyp"])
+    crit.sort_obj_iou = mode.endswith("_sorted")   # ComputeLoss.sort_obj_iou (utils/loss.py:101,156-158): a cell matched several times keeps its largest iou
     strides = [int(s) for s in m.stride.tolist()]
     bs = rec["bs"]
     p_cpu = yo.synth_raw_predictions([(bs, 3, hw // s, hw // s, nc + 5) for s in strides], seed=31)
@@ -763,7 +764,7 @@ def test_loss_vs_reference_golden(dev, golden_dir, key):
         torch.testing.assert_close(a.grad.cpu(), b, rtol=1e-4, atol=1e-7)
 
 
-@pytest.mark.parametrize("variant", ["fp32_scaled_grad", "focal", "smoothing_pw", "fp16"])
+@pytest.mark.parametrize("variant", ["fp32_scaled_grad", "focal", "smoothing_pw", "fp16", "sort_obj_iou"])
 def test_loss_vs_oracle_variants(dev, variant):
     hyp = dict(box=0.05, cls=0.5, cls_pw=1.0, obj=1.0, obj_pw=1.0, anchor_t=4.0, fl_gamma=0.0, label_smoothing=0.0)
     if variant == "focal":
@@ -774,9 +775,15 @@ def test_loss_vs_oracle_variants(dev, variant):
     m, crit = _loss_setup(dev, "yolov3", nc, hw, hyp)
     p_cpu = yo.synth_raw_predictions([(bs, 3, hw // s, hw // s, nc + 5) for s in (8, 16, 32)], seed=5)
     tg = yo.synth_targets(bs, nc, seed=3)
+    if variant == "sort_obj_iou":   # ComputeLoss.sort_obj_iou (utils/loss.py:156-158) on cells matched twice by boxes of different size: the larger iou must stay
+        tg = torch.cat((tg, tg[: tg.shape[0] // 2] * torch.tensor([1, 1, 1, 1, 0.8, 1.25])))
+        crit.sort_obj_iou = True
+        plain = yo.compute_loss([t.clone() for t in p_cpu], tg, m.model[-1].anchors.cpu(), hyp, nc)[1]
     dtype = torch.float16 if variant == "fp16" else torch.float32
     p_ref = [t.to(dtype).float().clone().requires_grad_(True) for t in p_cpu]
-    ref_loss, ref_items, _ = yo.compute_loss(p_ref, tg, m.model[-1].anchors.cpu(), hyp, nc)
+    ref_loss, ref_items, _ = yo.compute_loss(p_ref, tg, m.model[-1].anchors.cpu(), hyp, nc, sort_obj_iou=variant == "sort_obj_iou")
+    if variant == "sort_obj_iou":
+        assert abs(float(plain[1]) - float(ref_items[1])) > 1e-5 * float(ref_items[1]), "the case does not distinguish the two orders"
     scale = 1024.0 if variant in ("fp32_scaled_grad", "fp16") else 1.0  # GradScaler-style upstream gradient
     (ref_loss * scale).sum().backward()
     p = [t.detach().to(dev).to(dtype).requires_grad_(True) for t in p_cpu]

@@ -168,7 +168,7 @@ def test_nms_c_equals_numpy():
     assert torch.equal(a, b)
 
 
-LOSS_CASES = ["yolov3-nc80-128-synth", "yolov3-tiny-nc80-96-synth", "yolov3-nc80-64-empty", "yolov3-nc5-64-dups", "yolov3-nc5-64-edges"]
+LOSS_CASES = ["yolov3-nc80-128-synth", "yolov3-tiny-nc80-96-synth", "yolov3-nc80-64-empty", "yolov3-nc5-64-dups", "yolov3-nc5-64-edges", "yolov3-nc5-64-dups_sorted"]
 
 
 @pytest.mark.parametrize("key", LOSS_CASES)
@@ -180,8 +180,12 @@ def test_loss_matches_reference(golden_dir, key):
     bs = rec["bs"]
     p = [t.requires_grad_(True) for t in yo.synth_raw_predictions([(bs, 3, hw // s, hw // s, nc + 5) for s in strides], seed=31)]
     assert sum(checksum(t.detach()) for t in p) == rec["p_sum"]
-    loss, items, _ = yo.compute_loss(p, rec["targets"], rec["anchors_grid"], rec["hyp"], nc)
+    loss, items, _ = yo.compute_loss(p, rec["targets"], rec["anchors_grid"], rec["hyp"], nc, sort_obj_iou=mode.endswith("_sorted"))   # (ComputeLoss.sort_obj_iou, utils/loss.py:156-158)
     loss.backward()
+    if mode == "dups_sorted":   # the case is only worth something when the order matters
+        other = torch.load(golden_dir / "loss.pt")["yolov3-nc5-64-dups"]
+        assert abs(float(other["items"][1]) - float(rec["items"][1])) > 5e-6
+        assert any(not torch.equal(a, b) for a, b in zip(other["grads"], rec["grads"]))
     torch.testing.assert_close(loss, rec["loss"], rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(items, rec["items"], rtol=1e-6, atol=1e-6)
     for a, b in zip(p, rec["grads"]):

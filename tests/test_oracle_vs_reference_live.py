@@ -72,7 +72,7 @@ def test_nms_oracle_equals_reference_on_fresh_seeds(ref):
 
 def test_compute_loss_oracle_equals_reference_on_fresh_targets(ref):
     """ComputeLoss (reference utils/loss.py:98-244) == oracle.compute_loss -- value, items and d loss / d predictions -- on target
-    sets the golden file does not hold: 8 seeds, focal / label-smoothing / pos_weight variants, yolov3 and yolov3-tiny heads."""
+    sets the golden file does not hold: 8 seeds, focal / label-smoothing / pos_weight variants, yolov3 and yolov3-tiny heads, the last four with sort_obj_iou and duplicated cells."""
     import yaml
     from pathlib import Path
 
@@ -93,13 +93,16 @@ def test_compute_loss_oracle_equals_reference_on_fresh_targets(ref):
         hyp["obj"] *= (hw / 640) ** 2 * 3 / nl
         m.hyp = hyp
         crit = ref.ComputeLoss(m)
+        crit.sort_obj_iou = sort_iou = i >= 4   # the second pass over the four heads: ComputeLoss.sort_obj_iou (utils/loss.py:101,156-158)
         shapes = [(bs, 3, hw // int(s), hw // int(s), nc + 5) for s in strides]
         tg = yo.synth_targets(bs, nc, seed=70 + i)
+        if sort_iou:   # duplicate cells with different boxes, so that the order of the writes matters
+            tg = torch.cat((tg, tg[: max(1, tg.shape[0] // 3)] * torch.tensor([1, 1, 1, 1, 0.8, 1.25])))
         p_ref = [t.requires_grad_(True) for t in yo.synth_raw_predictions(shapes, seed=50 + i)]
         loss_ref, items_ref = crit(p_ref, tg)
         loss_ref.backward()
         p = [t.requires_grad_(True) for t in yo.synth_raw_predictions(shapes, seed=50 + i)]
-        loss, items, _ = yo.compute_loss(p, tg, m.model[-1].anchors.clone(), hyp, nc)
+        loss, items, _ = yo.compute_loss(p, tg, m.model[-1].anchors.clone(), hyp, nc, sort_obj_iou=sort_iou)
         loss.backward()
         torch.testing.assert_close(loss, loss_ref.detach(), rtol=1e-6, atol=1e-6)
         torch.testing.assert_close(items, items_ref, rtol=1e-6, atol=1e-6)

@@ -11,7 +11,7 @@ LIB_PATH = Path(os.environ["Y3_LIB"]) if os.environ.get("Y3_LIB") else _PKG / "l
 
 Y3_F16, Y3_BF16, Y3_F32, Y3_U8 = 0, 1, 2, 3
 Y3_ACT_NONE, Y3_ACT_SILU = 0, 1
-ABI_VERSION = 2   # include/yolov3_hip.h::Y3_ABI_VERSION (2: round-3 export set -- tune / SyncBN / TTA / wgrad_plan added, y3_bn_act_bwd_apply takes sums + 2C)
+ABI_VERSION = 3   # include/yolov3_hip.h::Y3_ABI_VERSION (2: round-3 export set -- tune / SyncBN / TTA / wgrad_plan added, y3_bn_act_bwd_apply takes sums + 2C; 3: y3_loss_params.sort_obj_iou)
 Y3_ALGO_AUTO, Y3_ALGO_MFMA, Y3_ALGO_DIRECT = 0, 1, 2
 
 
@@ -65,6 +65,7 @@ class Y3LossParams(C.Structure):
         ("cp", C.c_float),
         ("cn", C.c_float),
         ("fl_gamma", C.c_float),
+        ("sort_obj_iou", C.c_int32),
     ]
 
 

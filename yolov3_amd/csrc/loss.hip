@@ -230,6 +230,18 @@ __global__ __launch_bounds__(256) void loss_match_kernel(LossDev P, int lvl, con
     }
 }
 
+// ComputeLoss.sort_obj_iou (utils/loss.py:156-158): the matches are permuted into ascending-iou order before `tobj[b, a, gj, gi] = iou`, so a cell matched several times
+// keeps its LARGEST iou.  The winner slot of a cell stays the election above (it only names where the cell's gradient rows accumulate); every other slot of the cell raises
+// the winner's iou to its own -- non-negative floats order like their bit patterns, so an integer atomicMax is exact and independent of the order the slots arrive in.
+__global__ void loss_cell_max_iou_kernel(LevelWs W) {
+    const int key = blockIdx.x * 256 + threadIdx.x;
+    if (key >= W.slots) return;
+    const int cell = W.slot_cell[key];
+    if (cell < 0) return;
+    const int owner = W.winner[cell];
+    if (owner != key) atomicMax((int*)&W.slot_iou[owner], __float_as_int(W.slot_iou[key]));
+}
+
 template <typename T> __global__ void loss_tobj_kernel(LevelWs W) {
     const int key = blockIdx.x * 256 + threadIdx.x;
     if (key >= W.slots) return;
@@ -414,6 +426,10 @@ int loss_fwd(const y3_loss_params* p, const void* const* preds, const float* tar
         if (W.slots > 0) {
             hipLaunchKernelGGL((loss_match_kernel<T, 0>), dim3((W.slots + 3) / 4), dim3(256), 0, st, D, i, (const T*)preds[i], targets, W, (const float*)nullptr);
             Y3_CHECK_LAUNCH();
+            if (p->sort_obj_iou) {
+                hipLaunchKernelGGL(loss_cell_max_iou_kernel, dim3((W.slots + 255) / 256), dim3(256), 0, st, W);
+                Y3_CHECK_LAUNCH();
+            }
             hipLaunchKernelGGL((loss_tobj_kernel<T>), dim3((W.slots + 255) / 256), dim3(256), 0, st, W);
             Y3_CHECK_LAUNCH();
         }

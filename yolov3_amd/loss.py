@@ -101,6 +101,7 @@ class ComputeLoss:
         P.cls_pw, P.obj_pw = float(h["cls_pw"]), float(h["obj_pw"])
         P.cp, P.cn = float(self.cp), float(self.cn)
         P.fl_gamma = float(h.get("fl_gamma", 0.0))
+        P.sort_obj_iou = int(bool(self.sort_obj_iou))   # (utils/loss.py:101: a class attribute the caller may set on the instance)
         return P
 
     def __call__(self, p, targets):
