@@ -880,7 +880,8 @@ namespace {
 template <typename T> int dispatch_pair(const PairArgs& a, int sdt, long long tiles, hipStream_t st) {
     // persistent: 2 blocks per CU, tiles in a grid-stride loop.  (Three blocks per CU -- 168 VGPRs, the per-lane tables spilled -- and a
     // staggered start of the blocks that share a CU were measured and dropped: the kernel is bound by VALU issue, profiles/r02_stem_pair.md)
-    const int blocks = tiles < 512 ? (int)tiles : 512;
+    const int cap = 2 * y3_cu_count();
+    const int blocks = tiles < cap ? (int)tiles : cap;
     switch (sdt) {
         case Y3_F16: hipLaunchKernelGGL((stem_pair_kernel<T, f16_t>), dim3((unsigned)blocks), dim3(256), 0, st, a); break;
         case Y3_BF16: hipLaunchKernelGGL((stem_pair_kernel<T, bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, a); break;
@@ -950,7 +951,7 @@ extern "C" int y3_bneck_pair_fwd(const y3_tensor* x, const void* packed1, const 
     const long long xb = (((long long)x->n * x->h * x->w - 1) * x->pitch + x->c) * 2;
     if (xb >= 0x7fffffffLL) Y3_FAIL("y3_bneck_pair_fwd: input beyond the 2 GiB reach of a buffer descriptor (split the batch)");
     a.x_bytes = (unsigned)xb;
-    const int cap = c == 64 ? 512 : 256;   // persistent: 2 blocks of 4 waves / 1 block of 8 waves per CU
+    const int cap = (c == 64 ? 2 : 1) * y3_cu_count();   // persistent: 2 blocks of 4 waves / 1 block of 8 waves per CU
     const int blocks = tiles < cap ? (int)tiles : cap;
     hipStream_t st = (hipStream_t)stream;
     if (dtype != Y3_F16 && dtype != Y3_BF16) Y3_FAIL("y3_bneck_pair_fwd: f16/bf16 only");

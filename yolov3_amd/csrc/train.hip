@@ -1577,7 +1577,8 @@ extern "C" int y3_stem_bn_bwd_wgrad(const void* x_nchw, int32_t src_dtype, int32
     const long long tiles = (long long)a.tiles_w * a.tiles_h * n;
     a.n_tiles = (int)tiles;
     a.divisor = divisor;
-    const int blocks = tiles < 1024 ? (int)tiles : 1024;   // persistent: 4 blocks per CU
+    const int cap = 4 * y3_cu_count() < 1024 ? 4 * y3_cu_count() : 1024;   // persistent: 4 blocks per CU (the workspace holds 1024 partial tiles)
+    const int blocks = tiles < cap ? (int)tiles : cap;
 #define Y3_SB(TT, SS) do { if (act == Y3_ACT_SILU) hipLaunchKernelGGL((stem_bn_bwd_wgrad_kernel<TT, SS, true>), dim3(blocks), dim3(256), 0, st, a); \
                            else hipLaunchKernelGGL((stem_bn_bwd_wgrad_kernel<TT, SS, false>), dim3(blocks), dim3(256), 0, st, a); } while (0)
 #define Y3_SB_SRC(TT) switch (src_dtype) { case Y3_F16: Y3_SB(TT, f16_t); break; case Y3_BF16: Y3_SB(TT, bf16_t); break; case Y3_F32: Y3_SB(TT, float); break; \
