@@ -580,5 +580,16 @@ def test_conv_v10_tiles_cover_the_pixel_axis_and_neighbours_share_a_round():
             recs, cb, g, name = tiles(2, 256, 512, 40, workspace=ws)
             assert name == "v10k"
             check(recs, cb, g, 8, bool(knob))
+            # random problems, every eligible shape forced onto the kernel (small launches included: one block per few column blocks, single-tile shares)
+            import random
+            rnd = random.Random(7 + knob)
+            assert L.y3_tune_set(b"conv_v10", 2) == 0
+            for _ in range(150):
+                bs, hw = rnd.randint(1, 70), rnd.choice([13, 20, 26, 40, 52, 76, 80, 104])
+                cin, cout = rnd.choice([(128, 256), (256, 512), (512, 1024), (256, 256), (128, 512), (384, 768)])
+                recs, cb, g, name = tiles(bs, cin, cout, hw)
+                assert name in ("v10", "v10h") and cb == (bs * hw * hw + 31) // 32
+                check(recs, cb, g, 4 if name == "v10h" else 8, bool(knob))
+            assert L.y3_tune_set(b"conv_v10", 1) == 0
     finally:
         L.y3_tune_reset()
