@@ -286,6 +286,30 @@ def clocks_under_load(fn, seconds=2.5):
             "samples": len(rows), "source": "rocm-smi --showclocks --showpower sampled while the forward runs back to back (after the timed region)"}
 
 
+def self_launch_needed(gpus: int, env) -> bool:
+    """--gpus N > 1 and no torch.distributed.run environment around this process: bench.py has to start the ranks itself"""
+    return gpus > 1 and "WORLD_SIZE" not in env and "RANK" not in env
+
+
+def self_launch_command(gpus: int, argv, port: int):
+    """the command the driver would have typed: one rank per GPU of ONE node, rendezvous on 127.0.0.1 (the container hostname may not resolve)"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+            str(Path(__file__).resolve()), *argv]
+
+
+def self_launch(gpus: int, argv) -> int:
+    import socket
+    import subprocess
+
+    with socket.socket() as s:   # a free rendezvous port (two bench.py launchers on one node must not meet)
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL / device-tensor sharing between the ranks needs dmabuf IPC on this host driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(self_launch_command(gpus, argv, port), env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -308,6 +332,11 @@ def main():
     ap.add_argument("--dist-backend", default=None, choices=["nccl", "gloo"],
                     help="process-group backend (default nccl = RCCL; gloo: plumbing smoke with several ranks on fewer GPUs, tools/gpu_dist_smoke.sh)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` on its own (no torch.distributed.run around it): become the launcher -- one rank per GPU on this node, rendezvous on
+    # 127.0.0.1 (the reference's train.py:672-683 is launched the same way).  The ranks' stdout is ours: rank 0's single JSON line passes through.
+    if self_launch_needed(args.gpus, os.environ):
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
 
     # stdout carries exactly ONE line, the JSON record: libraries that chat on fd 1 (RCCL prints a version banner when a communicator is
     # created) go to stderr for the rest of the process, the record is written to the saved descriptor

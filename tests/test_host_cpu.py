@@ -593,3 +593,27 @@ def test_conv_v10_tiles_cover_the_pixel_axis_and_neighbours_share_a_round():
             assert L.y3_tune_set(b"conv_v10", 1) == 0
     finally:
         L.y3_tune_reset()
+
+
+def test_bench_launches_its_own_ranks_when_asked_for_several_gpus(tmp_path):
+    """`python bench.py --gpus N` with no torch.distributed.run around it starts N ranks itself (127.0.0.1 rendezvous, one rank per GPU) -- the driver's scaling run
+    may use either spelling.  Without a GPU every rank stops at "bench.py needs an MI355X" AFTER the process group formed: the launcher path was taken, the group had
+    world size 2, and nothing reached the hot path on a CPU."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+
+    assert not bench.self_launch_needed(1, {})
+    assert bench.self_launch_needed(2, {"PATH": "x"})
+    assert not bench.self_launch_needed(2, {"WORLD_SIZE": "2", "RANK": "0"})   # under torch.distributed.run: the ranks do not launch again
+    cmd = bench.self_launch_command(4, ["--gpus", "4", "--steps", "3"], 29555)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    if torch.cuda.is_available():
+        pytest.skip("the GPU form of this run is tools/gpu_dist_smoke.sh")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--no-train", "--no-cpu-baseline"], capture_output=True, text=True,
+                       timeout=300, env=env, cwd=str(tmp_path))
+    assert p.returncode != 0
+    assert p.stdout.strip() == ""                                   # no JSON line from a run that measured nothing
+    assert p.stderr.count("bench.py needs an MI355X") >= 2, p.stderr[-2000:]   # both ranks were started and each got as far as the device check
+    assert "AssertionError" not in p.stderr
