@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define Y3_ABI_VERSION 3
+#define Y3_ABI_VERSION 4
 
 typedef enum { Y3_F16 = 0, Y3_BF16 = 1, Y3_F32 = 2, Y3_U8 = 3 } y3_dtype;
 typedef enum { Y3_ACT_NONE = 0, Y3_ACT_SILU = 1 } y3_act;
@@ -89,11 +89,6 @@ int y3_conv2d_fwd(const y3_conv_desc* desc, const y3_tensor* x, const void* pack
  * workspace and a second launch adds them in slice order and applies bias / SiLU / residual / statistics.  Results are deterministic (fixed split, fixed
  * summation order).  Launches the form does not cover run exactly as y3_conv2d_fwd. */
 size_t y3_conv_workspace_bytes(void);
-/* Kept from ABI version 1, where a stream-K kernel handed partial tiles from block to block through the workspace and a hand-off that never arrived set a
- * sticky flag: the K split of round 4 has no hand-off (two launches, nothing spins).  y3_conv_workspace_error always reports 0, y3_conv_workspace_reset does
- * nothing; both still validate their arguments. */
-int y3_conv_workspace_error(const void* workspace, size_t workspace_bytes, int32_t* error, void* stream);
-int y3_conv_workspace_reset(void* workspace, size_t workspace_bytes, void* stream);
 int y3_conv2d_fwd_ws(const y3_conv_desc* desc, const y3_tensor* x, const void* packed_filter, const float* bias,
                      const y3_tensor* residual /* may be NULL */, const y3_tensor* y, void* workspace, size_t workspace_bytes,
                      void* stream);

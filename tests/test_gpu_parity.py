@@ -105,10 +105,8 @@ def run_conv(dev, dtype, n, h, w, cin, cout, k, s, act=True, residual=False, ups
             first = cur
         else:
             assert torch.equal(first, cur), f"launch {r} differs from launch 0 (non-deterministic or stale workspace state)"
-    if ws and check_ws:
-        hdr = wsp[:64].view(torch.int32)
-        assert hdr[2].item() == 0, "stream-K kernel reported a lost producer (spin bound hit)"
-        assert hdr[0].item() == 0 and hdr[1].item() == 0 and int(wsp[64:64 + 4096].view(torch.int32).abs().sum()) == 0, "workspace control words not re-armed"
+    if ws and check_ws:   # the K-split form only uses the slabs behind the first 8 KiB of the workspace: the head stays as the caller zero-filled it
+        assert int(wsp[:8192].view(torch.int32).abs().sum()) == 0, "the conv wrote into the head of its workspace"
     out = yv.as_nhwc().float().cpu().permute(0, 3, 1, 2)[:, :cout_real]
     if sliced:
         full = big.as_nhwc().float().cpu()
@@ -825,6 +823,42 @@ def test_loss_full_size_properties(dev):
         others = a.clone()
         others[..., 4] = 0
         assert (others.abs().sum(-1) > 0).float().mean().item() < 0.05  # only matched cells carry box/cls gradient
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_loss_backward_is_bit_deterministic_on_duplicated_cells(dev, dtype):
+    """The reference trains under torch.use_deterministic_algorithms(True) (train.py:191, utils/general.py:191-205).  The loss backward has no floating-point atomics:
+    every matched slot writes its own gradient row and the winner slot of a cell that several slots matched adds the rows in slot order (loss_scatter_kernel).
+    Targets stacked three deep on the same cells (every cell matched 3+ times, by boxes of different size) with shuffled rows: five backward passes are bit-identical,
+    and the summed rows agree with the oracle's autograd (which accumulates duplicates by index_put)."""
+    hyp = dict(box=0.05, cls=0.5, cls_pw=1.0, obj=1.0, obj_pw=1.0, anchor_t=4.0, fl_gamma=0.0, label_smoothing=0.0)
+    nc, hw, bs = 80, 320, 8
+    m, crit = _loss_setup(dev, "yolov3", nc, hw, hyp)
+    p_cpu = yo.synth_raw_predictions([(bs, 3, hw // s, hw // s, nc + 5) for s in (8, 16, 32)], seed=11)
+    base = yo.synth_targets(bs, nc, seed=6)
+    tg = torch.cat((base, base * torch.tensor([1, 1, 1, 1, 0.9, 1.1]), base * torch.tensor([1, 1, 1, 1, 1.15, 0.85])))
+    tg[:, 1] = tg[:, 1].round().clamp(0, nc - 1)
+    tg = tg[torch.randperm(tg.shape[0], generator=torch.Generator().manual_seed(1))]
+    p = [t.to(dev).to(dtype).requires_grad_(True) for t in p_cpu]
+    runs = []
+    for r in range(5):
+        for t in p:
+            t.grad = None
+        loss, _ = crit(p, tg.to(dev))
+        (loss * 512.0).sum().backward()
+        torch.cuda.synchronize()
+        runs.append([t.grad.clone() for t in p])
+        if r == 1:   # other work in between: the order in which waves retire changes, the sums must not
+            torch.randn(1 << 22, device=dev).sort()
+    for other in runs[1:]:
+        for a, b in zip(runs[0], other):
+            assert torch.equal(a, b), "loss backward differs between two runs on the same inputs"
+    if dtype == torch.float32:
+        p_ref = [t.clone().requires_grad_(True) for t in p_cpu]
+        ref_loss, _, _ = yo.compute_loss(p_ref, tg, m.model[-1].anchors.cpu(), hyp, nc)
+        (ref_loss * 512.0).sum().backward()
+        for a, b in zip(runs[0], p_ref):
+            torch.testing.assert_close(a.cpu(), b.grad, rtol=1e-4, atol=1e-6 * 512.0)
 
 
 # ------------------------------------------------------------------------------------------------ training
@@ -1857,9 +1891,9 @@ avg = grads(True)
 ref = own.clone()
 torch.distributed.all_reduce(ref)
 ref /= world
-# (the two backward passes of a rank run the same kernels on the same data; fp32 atomics of the loss backward may land in another order when
-#  two processes share one GPU: 3e-7 observed on gradients of magnitude 1e-2..1)
-assert float((avg - ref).abs().max()) <= 1e-5 * float(ref.abs().max()), (float((avg - ref).abs().max()), float(ref.abs().max()))
+# (the two backward passes of a rank run the same kernels on the same data and nothing in them depends on the order waves retire in -- the loss backward
+#  sums duplicated cells in slot order, no atomics -- so the averaged gradients equal the mean of the unsynchronised ones bit for bit, also with two processes on one GPU)
+assert torch.equal(avg, ref), (float((avg - ref).abs().max()), float(ref.abs().max()))
 print("rank", rank, "ok")
 parallel.finalize()
 """)
@@ -2404,7 +2438,6 @@ def test_train_step_640_autocast_vs_oracle_autograd(dev, tune, monkeypatch, adt,
     raws_ref = yo.forward(layers, save, sdg, x, strides, training=True)
     loss_ref, _, _ = yo.compute_loss(raws_ref, tg, sd[[k for k in sd if k.endswith("anchors")][0]], hyp, nc)
     loss_ref.backward()
-    crit = ComputeLoss(m)
     # which conv kernels the step ran: at batch 4 the dispatcher gives the 80 x 80 maps to v10h and the 40 x 40 / 20 x 20 maps (below a quarter round of tiles) to
     # the K-split form v10k; the third parametrisation forces every eligible 3 x 3 launch -- forward with statistics AND data gradient -- onto v10 / v10h, the kernels the
     # batch-64 benchmark runs there
@@ -2421,31 +2454,51 @@ def test_train_step_640_autocast_vs_oracle_autograd(dev, tune, monkeypatch, adt,
             return r
 
         monkeypatch.setattr(ops, fn, wrapped)
-    with torch.autocast("cuda", dtype=adt):
-        raws = m(x.to(dev))
-        loss, _ = crit(raws, tg.to(dev))
-    (loss * 128.0).backward()
-    torch.cuda.synchronize()
+    import copy
+
+    m_off = copy.deepcopy(m) if adt == torch.bfloat16 else None   # the same weights for the A/B arm without conv_v10.h (its own plan: the statistics rows differ by variant)
+
+    def run_step(model):
+        with torch.autocast("cuda", dtype=adt):
+            raws = model(x.to(dev))
+            loss_, _ = ComputeLoss(model)(raws, tg.to(dev))
+        (loss_ * 128.0).backward()
+        torch.cuda.synchronize()
+        cmin, wk, nworst = 1.0, None, (0.0, None)
+        dot = n_hip = n_ref = 0.0   # the whole gradient as one vector
+        for k, p_ in model.named_parameters():
+            ref = sdg[k].grad
+            assert p_.grad is not None and torch.isfinite(p_.grad).all(), k
+            if ref is not None:
+                gd, rd = p_.grad.double().cpu().flatten() / 128.0, ref.double().flatten()
+                dot += float(gd @ rd); n_hip += float(gd @ gd); n_ref += float(rd @ rd)
+            if ref is None or ref.numel() < 4096:
+                continue
+            gq = p_.grad.float().cpu() / 128.0
+            cq = torch.nn.functional.cosine_similarity(gq.flatten(), ref.flatten(), dim=0).item()
+            nr = abs(gq.norm().item() / ref.norm().item() - 1.0)
+            if cq < cmin:
+                cmin, wk = cq, k
+            if nr > nworst[0]:
+                nworst = (nr, k)
+        return loss_, cmin, wk, nworst, dot / math.sqrt(n_hip * n_ref)
+
+    loss, cos_min, worst, norm_worst, cos_all = run_step(m)
     assert "v10h" in seen and ("v10" in seen) == bool(force_v10) and ("v10k" in seen) != bool(force_v10), seen
     rel = abs(loss.item() - loss_ref.item()) / loss_ref.item()
-    cos_min, worst, norm_worst = 1.0, None, (0.0, None)
-    dot = n_hip = n_ref = 0.0   # the whole gradient as one vector
-    for k, p_ in m.named_parameters():
-        ref = sdg[k].grad
-        assert p_.grad is not None and torch.isfinite(p_.grad).all(), k
-        if ref is not None:
-            gd, rd = p_.grad.double().cpu().flatten() / 128.0, ref.double().flatten()
-            dot += float(gd @ rd); n_hip += float(gd @ gd); n_ref += float(rd @ rd)
-        if ref is None or ref.numel() < 4096:
-            continue
-        gq = p_.grad.float().cpu() / 128.0
-        cq = torch.nn.functional.cosine_similarity(gq.flatten(), ref.flatten(), dim=0).item()
-        nr = abs(gq.norm().item() / ref.norm().item() - 1.0)
-        if cq < cos_min:
-            cos_min, worst = cq, k
-        if nr > norm_worst[0]:
-            norm_worst = (nr, k)
-    cos_all = dot / math.sqrt(n_hip * n_ref)
+    if m_off is not None:
+        # same box, same weights, same batch: the step with every launch of conv_v10.h handed back to the tile kernels it replaced.  The absolute bf16 bounds below sit
+        # near the floor of the model; THIS is the assert that tracks the kernel: v10 / v10h / v10k may not be further from the fp32 gradient than the v6 / v3 path
+        # by more than the summation-order noise (round-4 advisor finding)
+        m_off.hyp = hyp
+        m_off.train()
+        tune("conv_v10", 0)
+        seen.clear()
+        _, cos_min_off, worst_off, _, cos_all_off = run_step(m_off)
+        assert not (seen & {"v10", "v10h", "v10k"}), seen
+        print(f"[train 640 {adt}] without conv_v10: whole-gradient cosine {cos_all_off:.5f}, min per-tensor cosine {cos_min_off:.4f} at {worst_off}")
+        assert cos_all >= cos_all_off - 0.01, f"whole-gradient cosine {cos_all:.5f} with conv_v10, {cos_all_off:.5f} without"
+        assert cos_min >= cos_min_off - 0.03, f"min per-tensor cosine {cos_min:.4f} with conv_v10, {cos_min_off:.4f} without"
     print(f"[train 640 {adt}] loss rel err {rel:.2e}, whole-gradient cosine {cos_all:.5f}, min per-tensor cosine {cos_min:.4f} at {worst}, worst norm ratio error {norm_worst[0]:.3f} at {norm_worst[1]}")
     # measured (MI355X, rounds 3 / 4): fp16 loss 1e-7 .. 6e-6, whole-gradient cosine 0.9973, min per-tensor cosine 0.9947 .. 0.9951, worst norm error 0.5 %;
     # bf16 loss 1e-5 .. 5e-5, whole-gradient cosine 0.941, min per-tensor cosine 0.922 .. 0.938 (0.967 at 128 x 128), norm 2.1 .. 3.3 %.

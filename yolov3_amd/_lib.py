@@ -11,7 +11,8 @@ LIB_PATH = Path(os.environ["Y3_LIB"]) if os.environ.get("Y3_LIB") else _PKG / "l
 
 Y3_F16, Y3_BF16, Y3_F32, Y3_U8 = 0, 1, 2, 3
 Y3_ACT_NONE, Y3_ACT_SILU = 0, 1
-ABI_VERSION = 3   # include/yolov3_hip.h::Y3_ABI_VERSION (2: round-3 export set -- tune / SyncBN / TTA / wgrad_plan added, y3_bn_act_bwd_apply takes sums + 2C; 3: y3_loss_params.sort_obj_iou)
+ABI_VERSION = 4   # include/yolov3_hip.h::Y3_ABI_VERSION (2: round-3 export set -- tune / SyncBN / TTA / wgrad_plan added, y3_bn_act_bwd_apply takes sums + 2C; 3: y3_loss_params.sort_obj_iou;
+                  # 4: y3_conv_workspace_error / _reset removed (no-ops since the stream-K kernel went), the loss workspace grew by one int per slot)
 Y3_ALGO_AUTO, Y3_ALGO_MFMA, Y3_ALGO_DIRECT = 0, 1, 2
 
 
@@ -81,8 +82,6 @@ _SIGNATURES = {
     "y3_pack_filter": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "y3_conv2d_fwd": (C.c_int, [_P(Y3ConvDesc), _P(Y3Tensor), C.c_void_p, C.c_void_p, _P(Y3Tensor), _P(Y3Tensor), C.c_void_p]),
     "y3_conv_workspace_bytes": (C.c_size_t, []),
-    "y3_conv_workspace_error": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
-    "y3_conv_workspace_reset": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "y3_conv2d_fwd_ws": (C.c_int, [_P(Y3ConvDesc), _P(Y3Tensor), C.c_void_p, C.c_void_p, _P(Y3Tensor), _P(Y3Tensor), C.c_void_p, C.c_size_t, C.c_void_p]),
     "y3_conv_last_variant": (C.c_int, [C.c_char_p, C.c_size_t]),
     "y3_conv2d_fwd_variant": (C.c_int, [_P(Y3ConvDesc), _P(Y3Tensor), _P(Y3Tensor), C.c_int32, C.c_size_t, C.c_char_p, C.c_size_t]),

@@ -1245,20 +1245,6 @@ extern "C" int y3_conv2d_fwd(const y3_conv_desc* d, const y3_tensor* x, const vo
 constexpr size_t Y3_CONV_WS_BYTES = 64 + 4 * 1024 + 2 * (size_t)256 * 256 * 256 * 4;   // 134 MB: the size round 2 fixed (callers allocate it once per plan)
 extern "C" size_t y3_conv_workspace_bytes(void) { return Y3_CONV_WS_BYTES; }
 
-// Round 2's stream-K kernel kept a sticky "lost hand-off" flag in the workspace header.  The K split of round 4 has no hand-off (two launches, nothing spins):
-// the two calls stay in the ABI, the flag is always 0
-extern "C" int y3_conv_workspace_error(const void* workspace, size_t workspace_bytes, int32_t* error, void* stream) {
-    if (!workspace || !error || workspace_bytes < V10_WS_SLABS) Y3_FAIL("y3_conv_workspace_error: bad argument");
-    (void)stream;
-    *error = 0;
-    return 0;
-}
-extern "C" int y3_conv_workspace_reset(void* workspace, size_t workspace_bytes, void* stream) {
-    if (!workspace || workspace_bytes < V10_WS_SLABS) Y3_FAIL("y3_conv_workspace_reset: bad argument");
-    (void)stream;
-    return 0;
-}
-
 extern "C" int y3_conv2d_fwd_ws(const y3_conv_desc* d, const y3_tensor* x, const void* filt, const float* bias, const y3_tensor* res, const y3_tensor* y, void* workspace,
                                 size_t workspace_bytes, void* stream) {
     if (workspace && ((uintptr_t)workspace & 255)) Y3_FAIL("y3_conv2d_fwd_ws: the workspace must be 256-byte aligned");

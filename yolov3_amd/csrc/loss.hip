@@ -9,7 +9,10 @@
 //   * no compaction is needed, one wavefront evaluates one slot (lanes parallel over the nc class logits);
 //   * "last writer wins" of  tobj[b,a,gj,gi] = iou  (utils/loss.py:161, CPU index_put semantics) becomes
 //     atomicMax(winner[cell], key): deterministic and identical to the CPU oracle;
-//   * sums are reduced in slot order by a fixed tree -> run-to-run deterministic loss values.
+//   * sums are reduced in slot order by a fixed tree -> run-to-run deterministic loss values;
+//   * the backward has no floating-point atomics either: every matched slot writes its gradient row into its OWN row of `side`, and the
+//     winner slot of a cell that several slots matched adds those rows in ascending slot order (loss_scatter_kernel) -- bit-identical
+//     gradients run to run, what the reference gets under torch.use_deterministic_algorithms(True) (train.py:191, utils/general.py:191-205).
 // Objectness BCE is one streaming pass over the strided channel-4 plane per level (HBM-bound).
 // All math is fp32 on values loaded from p (for f16/bf16 inputs this is at least as accurate as the reference's
 // autocast path, whose oracle is the fp32 CPU path anyway); tobj is rounded through p's dtype like the reference.
@@ -34,7 +37,8 @@ struct LevelWs {
     float* slot_iou;    // slots            clamp(ciou, 0)
     float* slot_lbox;   // slots            1 - ciou
     float* slot_lcls;   // slots            sum_c BCE(pcls_c, t_c)
-    float* side;        // slots * no       fp32 gradient accumulators of matched cells (backward)
+    float* side;        // slots * no       fp32 gradient rows, one per matched slot (backward)
+    int* slot_dup;      // slots            backward: 1 on a winner slot whose cell is matched by other slots too
     float* obj_part;    // obj_blocks       per-block partial sums of the objectness BCE
     float* sums;        // 4                [n_matches, sum(1-ciou), sum cls bce, sum obj bce]
     long long cells;
@@ -215,18 +219,18 @@ __global__ __launch_bounds__(256) void loss_match_kernel(LossDev P, int lvl, con
             atomicMax(&W.winner[cell], key);
         }
     } else {
-        // d loss / d row accumulated on the cell's winner slot: duplicates sum, as autograd's index backward does
+        // d loss / d row of THIS slot into its own row of `side` (plain stores); a slot that shares its cell with the winner flags the winner, whose
+        // scatter pass then adds the rows of the cell in slot order (duplicates sum, as autograd's index backward does -- in a fixed order)
         const float scale_box = scales[lvl * 3 + 0], scale_cls = scales[lvl * 3 + 1];
         const int owner = W.winner[cell];
-        float* __restrict__ acc = W.side + (long long)owner * no;
-        if (lane < 4) atomicAdd(&acc[lane], -scale_box * ds[lane]);  // lbox = mean(1 - ciou)
-        if (P.nc > 1) {
-            for (int c = lane; c < P.nc; c += 64) {
-                float l, d;
-                bce_logits(to_f32<T>(row[5 + c]), c == m.c ? P.cp : P.cn, P.cls_pw, P.fl_gamma, l, d);
-                atomicAdd(&acc[5 + c], scale_cls * d);
-            }
+        float* __restrict__ acc = W.side + (long long)key * no;
+        if (lane < 4) acc[lane] = -scale_box * ds[lane];  // lbox = mean(1 - ciou)
+        for (int c = lane; c < P.nc; c += 64) {
+            float l, d = 0.0f;
+            if (P.nc > 1) bce_logits(to_f32<T>(row[5 + c]), c == m.c ? P.cp : P.cn, P.cls_pw, P.fl_gamma, l, d);   // (one class: no class loss, the row's entry is 0)
+            acc[5 + c] = scale_cls * d;
         }
+        if (lane == 0 && owner != key) W.slot_dup[owner] = 1;   // (every writer stores the same value)
     }
 }
 
@@ -305,7 +309,10 @@ __global__ __launch_bounds__(256) void loss_obj_kernel(LossDev P, int lvl, const
     }
 }
 
-// matched cells: gradient rows from the fp32 side accumulators (winner slots only), channel 4 untouched
+// matched cells: gradient rows from the fp32 slot rows (winner slots only), channel 4 untouched.  A cell matched once takes its row as it is.  A cell matched
+// several times (flagged by loss_match_kernel<1>) sums the rows of ALL its slots in ascending slot order: the slots of cell (b, a, gj, gi) can only be the keys
+// (o * na + a) * nt + t, so the winner's wave walks those 5 * nt candidates 64 at a time and adds the rows of the ones whose slot_cell is this cell -- a fixed
+// order, no atomics, bit-identical from run to run.
 template <typename T> __global__ __launch_bounds__(256) void loss_scatter_kernel(LossDev P, LevelWs W, T* __restrict__ gp) {
     const int lane = threadIdx.x & 63;
     const int key = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -313,10 +320,32 @@ template <typename T> __global__ __launch_bounds__(256) void loss_scatter_kernel
     const int cell = W.slot_cell[key];
     if (cell < 0 || W.winner[cell] != key) return;
     const int no = P.nc + 5;
-    const float* __restrict__ acc = W.side + (long long)key * no;
     T* __restrict__ row = gp + (long long)cell * no;
-    for (int ch = lane; ch < no; ch += 64)
-        if (ch != 4) row[ch] = from_f32<T>(acc[ch]);
+    if (!W.slot_dup[key]) {
+        const float* __restrict__ acc = W.side + (long long)key * no;
+        for (int ch = lane; ch < no; ch += 64)
+            if (ch != 4) row[ch] = from_f32<T>(acc[ch]);
+        return;
+    }
+    const int nt = P.nt, na = P.na;
+    const int a = (key / nt) % na;
+    for (int ch0 = 0; ch0 < no; ch0 += 64) {
+        const int ch = ch0 + lane;
+        float sum = 0.0f;
+        for (int o = 0; o < 5; ++o) {
+            const int kbase = (o * na + a) * nt;
+            for (int t0 = 0; t0 < nt; t0 += 64) {
+                const int t = t0 + lane;
+                unsigned long long hit = __ballot(t < nt && W.slot_cell[kbase + t] == cell);
+                while (hit) {   // (wave-uniform: ascending target index = ascending slot key)
+                    const int j = __builtin_ctzll(hit);
+                    hit &= hit - 1;
+                    if (ch < no) sum += W.side[(long long)(kbase + t0 + j) * no + ch];
+                }
+            }
+        }
+        if (ch < no && ch != 4) row[ch] = from_f32<T>(sum);
+    }
 }
 
 // deterministic single-block reductions: slot arrays (in slot order) and objectness partials
@@ -380,6 +409,7 @@ size_t carve_level(LevelWs& W, unsigned char* base, size_t off, const y3_loss_pa
     W.slot_lbox = (float*)take((size_t)(W.slots + 1) * 4);
     W.slot_lcls = (float*)take((size_t)(W.slots + 1) * 4);
     W.side = (float*)take((size_t)(W.slots + 1) * no * 4);
+    W.slot_dup = (int*)take((size_t)(W.slots + 1) * 4);
     W.obj_part = (float*)take((size_t)W.obj_blocks * 4);
     W.sums = (float*)take(16);
     return off;
@@ -489,7 +519,7 @@ int loss_bwd(const y3_loss_params* p, const void* const* preds, const float* tar
         hipLaunchKernelGGL((loss_obj_kernel<T, 1>), dim3((unsigned)((elems + per_block - 1) / per_block)), dim3(256), 0, st, D, i, (const T*)preds[i], W, (T*)grads[i], scales);
         Y3_CHECK_LAUNCH();
         if (W.slots > 0) {
-            Y3_HIP(hipMemsetAsync(W.side, 0, (size_t)W.slots * no * 4, st));
+            Y3_HIP(hipMemsetAsync(W.slot_dup, 0, (size_t)W.slots * 4, st));   // (the slot rows need no zero fill: every matched slot writes its whole row)
             hipLaunchKernelGGL((loss_match_kernel<T, 1>), dim3((W.slots + 3) / 4), dim3(256), 0, st, D, i, (const T*)preds[i], targets, W, (const float*)scales);
             Y3_CHECK_LAUNCH();
             hipLaunchKernelGGL((loss_scatter_kernel<T>), dim3((W.slots + 3) / 4), dim3(256), 0, st, D, W, (T*)grads[i]);

@@ -127,17 +127,6 @@ def conv_workspace(device) -> torch.Tensor:
     return torch.zeros(int(_lib.lib().y3_conv_workspace_bytes()), dtype=torch.uint8, device=device)
 
 
-def conv_workspace_error(ws: torch.Tensor) -> bool:
-    """True when a K-split hand-off on this workspace was lost (its tiles were written as NaN); synchronises the current stream"""
-    e = C.c_int32(0)
-    check(_lib.lib().y3_conv_workspace_error(ws.data_ptr(), ws.numel(), C.byref(e), stream_ptr()), "y3_conv_workspace_error")
-    return bool(e.value)
-
-
-def conv_workspace_reset(ws: torch.Tensor):
-    check(_lib.lib().y3_conv_workspace_reset(ws.data_ptr(), ws.numel(), stream_ptr()), "y3_conv_workspace_reset")
-
-
 def conv2d(x: View, filt: torch.Tensor, bias: torch.Tensor, y: View, k: int, stride: int, act: bool, residual: View | None = None, upsample2x: bool = False,
            algo: int = _lib.Y3_ALGO_AUTO, in_dilation: int = 0, workspace: torch.Tensor | None = None):
     d = Y3ConvDesc(dtype_code(x.buf.dtype), k, stride, _lib.Y3_ACT_SILU if act else _lib.Y3_ACT_NONE, int(upsample2x), algo, x.c, y.c, in_dilation)
