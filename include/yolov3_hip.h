@@ -54,6 +54,9 @@ typedef struct {
     int32_t in_dilation; /* 0/1 = plain; 2 = x is a virtual zero-interleaved (2h x 2w) image: data-gradient of a
                             stride-2 conv = stride-1 conv of the dilated output gradient with the flipped, transposed
                             filter (y3_pack_filter_dgrad); y's height/width then give the gradient's size */
+    int64_t filter_elems; /* elements of `dtype` the caller's packed bank holds (ABI 4).  Non-zero: a bank shorter than y3_packed_filter_elems(cout, cin, ksize)
+                             is refused -- e.g. one sized rows x Kpad by the ABI-1 rule, without the fragment-ordered second copy the persistent 3x3 kernel
+                             reads behind the row-major one.  0 = unchecked: the caller vouches for the size */
 } y3_conv_desc;
 
 int y3_abi_version(void);

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(lib):
     nm = subprocess.check_output(["nm", "-D", "--defined-only", str(_lib.LIB_PATH)], text=True)
     exported = set(re.findall(r" T (y3_[a-z0-9_]+)", nm))
     assert declared <= exported, declared - exported
-    assert lib.y3_abi_version() == 3
+    assert lib.y3_abi_version() == 4 == _lib.ABI_VERSION
 
 
 def test_argument_validation_is_loud_and_gpu_free(lib):
@@ -45,6 +45,16 @@ def test_argument_validation_is_loud_and_gpu_free(lib):
     t2 = _lib.Y3Tensor(1 << 20, 1, 8, 8, 32, 32)
     assert lib.y3_conv2d_fwd(C.byref(d), C.byref(t2), 1 << 20, 1 << 20, None, C.byref(t), None) != 0
     assert b"channels" in lib.y3_last_error()
+    # ABI 4: a bank shorter than y3_packed_filter_elems (e.g. sized rows x Kpad by the ABI-1 rule: no fragment-ordered second copy behind it) is refused before
+    # anything could read past its end; a bias that is not 16-byte aligned (conv_v10.h loads it as f32x4) likewise
+    d3 = _lib.Y3ConvDesc(_lib.Y3_F16, 3, 1, 1, 0, 0, 128, 256, 0, 256 * 1152)
+    tx, ty = _lib.Y3Tensor(1 << 20, 2, 20, 20, 128, 128), _lib.Y3Tensor(1 << 20, 2, 20, 20, 256, 256)
+    assert lib.y3_packed_filter_elems(256, 128, 3) == 2 * 256 * 1152
+    assert lib.y3_conv2d_fwd(C.byref(d3), C.byref(tx), 1 << 20, 1 << 20, None, C.byref(ty), None) != 0
+    assert b"y3_packed_filter_elems" in lib.y3_last_error()
+    d3.filter_elems = 2 * 256 * 1152
+    assert lib.y3_conv2d_fwd(C.byref(d3), C.byref(tx), 1 << 20, (1 << 20) + 4, None, C.byref(ty), None) != 0
+    assert b"16-byte aligned" in lib.y3_last_error()
     p = _lib.Y3NmsParams(0.6, 1.5, 1, 0, 300, 30000, 7680.0, 0)
     assert lib.y3_nms(1 << 20, 0, 1, 10, 80, C.byref(p), None, 1 << 20, 1 << 20, 1 << 20, 0, 1 << 20, 1 << 20, None) != 0
     assert b"Invalid Confidence threshold" in lib.y3_last_error()

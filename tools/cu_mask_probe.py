@@ -1,4 +1,4 @@
-"""What a CU-masked HIP stream (ops.masked_stream) gives one kernel when nothing else runs: one MFMA-bound launch (the 512 -> 1024 3x3 filter gradient at batch 64)
+"""What a CU-masked HIP stream (masked_stream) gives one kernel when nothing else runs: one MFMA-bound launch (the 512 -> 1024 3x3 filter gradient at batch 64)
 and one HBM-bound pass (y3_bn_act_fwd over a 420 MB tensor) per mask size.  Usage: python tools/cu_mask_probe.py"""
 import ctypes as C, sys, time
 from pathlib import Path
@@ -6,6 +6,8 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from yolov3_amd import _lib, ops
 from yolov3_amd.ops import View
+sys.path.insert(0, str(Path(__file__).resolve().parent / "lab"))
+from cu_mask import masked_stream
 
 dev = torch.device("cuda:0")
 dt = torch.float16
@@ -38,7 +40,7 @@ def timed(fn, st, reps=20):
 
 
 print(f"{'stream':>12s} {'wgrad us':>10s} {'bn pass us':>11s} {'GB/s':>8s}")
-for name, st in [("plain", torch.cuda.Stream(device=dev))] + [(f"mask {n}", ops.masked_stream(dev, n)) for n in (256, 248, 224, 192, 160, 128, 96, 64, 32)] + \
-        [("mask 64@192", ops.masked_stream(dev, 64, 192)), ("mask 32@0 x", ops.masked_stream(dev, 32, 32))]:
+for name, st in [("plain", torch.cuda.Stream(device=dev))] + [(f"mask {n}", masked_stream(dev, n)) for n in (256, 248, 224, 192, 160, 128, 96, 64, 32)] + \
+        [("mask 64@192", masked_stream(dev, 64, 192)), ("mask 32@0 x", masked_stream(dev, 32, 32))]:
     tw, tb = timed(wgrad, st), timed(bn, st)
     print(f"{name:>12s} {tw:10.1f} {tb:11.1f} {2 * u.buf.numel() * 2 / tb / 1e3:8.0f}", flush=True)

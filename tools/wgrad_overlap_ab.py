@@ -1,5 +1,5 @@
 """A/B of the batch-64 train step (bench.py's step) with the filter gradients on a second HIP stream -- unconfined, or confined to N CUs by a CU mask
-(ops.masked_stream) so that the CUs outside the mask stay free for the HBM-bound BatchNorm passes of the backward's critical chain.  One process, interleaved
+(masked_stream) so that the CUs outside the mask stay free for the HBM-bound BatchNorm passes of the backward's critical chain.  One process, interleaved
 rounds, the plan rebuilt per arm.  Usage: python tools/wgrad_overlap_ab.py [--batch 64] [--rounds 2] [--steps 6] [--arms base,s,s+m192,s+hp]"""
 import argparse, json, os, sys, time
 from pathlib import Path
@@ -9,6 +9,8 @@ from oracle import yolo_oracle as yo   # seeded synthetic targets only
 from yolov3_amd import ComputeLoss, DetectionModel
 from yolov3_amd.engine import plan_cache
 from yolov3_amd.optim import FusedSGD, GradScaler, ModelEMA, smart_param_groups
+sys.path.insert(0, str(Path(__file__).resolve().parent / "lab"))
+from cu_mask import masked_stream
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
@@ -28,6 +30,7 @@ scaler = GradScaler(init_scale=1024.0)
 x = torch.rand(args.batch, 3, args.imgsz, args.imgsz, generator=torch.Generator().manual_seed(0)).to(dev)
 tg = yo.synth_targets(args.batch, 80, seed=1).to(dev)
 hp_stream = torch.cuda.Stream(device=dev, priority=-1)
+MASK_CUS = 0
 
 
 def step():
@@ -43,9 +46,9 @@ def step():
 
 def set_arm(arm):
     """arm = tokens joined by '+': base (one stream) | s (filter gradients on a side stream) | mN (that stream confined to N CUs) | hp (compute work on a high-priority stream)"""
-    for k in ("Y3_WGRAD_STREAM", "Y3_WGRAD_CUS"):
-        os.environ.pop(k, None)
-    hp = False
+    global MASK_CUS
+    os.environ.pop("Y3_WGRAD_STREAM", None)
+    hp, MASK_CUS = False, 0
     for tok in arm.split("+"):
         if tok == "base":
             continue
@@ -55,7 +58,7 @@ def set_arm(arm):
         elif tok == "hp":
             hp = True
         elif tok[0] == "m":
-            os.environ["Y3_WGRAD_CUS"] = tok[1:]
+            MASK_CUS = int(tok[1:])
         else:
             raise SystemExit(f"unknown arm token {tok}")
     pc = plan_cache(model)
@@ -68,8 +71,12 @@ def run(arm):
     hp = set_arm(arm)
     ctx = torch.cuda.stream(hp_stream) if hp else torch.cuda.stream(torch.cuda.current_stream())
     with ctx:
-        for _ in range(2):
-            step()
+        step()   # builds the plan
+        if MASK_CUS:
+            for k, pl in plan_cache(model).plans.items():
+                if k[0] == "train":
+                    pl.wgrad_stream = masked_stream(dev, MASK_CUS)
+        step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):

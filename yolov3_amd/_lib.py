@@ -31,6 +31,7 @@ class Y3ConvDesc(C.Structure):
         ("cin", C.c_int32),
         ("cout", C.c_int32),
         ("in_dilation", C.c_int32),
+        ("filter_elems", C.c_int64),   # elements the packed bank holds (0 = unchecked); ctypes pads to offset 40 like the C compiler
     ]
 
 

@@ -1143,9 +1143,13 @@ static int conv_fwd_impl(const y3_conv_desc* d, const y3_tensor* x, const void* 
     const int vec = 16 / esz;
     if (d->dtype != Y3_F32) {
         if ((x->pitch % vec) || (y->pitch % vec) || (res && (res->pitch % vec)) || ((uintptr_t)x->data & 15) || ((uintptr_t)y->data & 15) ||
-            (res && ((uintptr_t)res->data & 15)) || ((uintptr_t)filt & 15))
-            Y3_FAIL("y3_conv2d_fwd: tensors must be 16-byte aligned with pitch %% %d == 0", vec);
+            (res && ((uintptr_t)res->data & 15)) || ((uintptr_t)filt & 15) || ((uintptr_t)bias & 15))   // (conv_v10.h loads the bias as f32x4)
+            Y3_FAIL("y3_conv2d_fwd: tensors, filter bank and bias must be 16-byte aligned with pitch %% %d == 0", vec);
     }
+    // a bank without the fragment-ordered second copy (sized rows x Kpad by the ABI-1 rule, or an old cached one) would be read past its end by conv_v10.h
+    if (d->filter_elems != 0 && (uint64_t)d->filter_elems < (uint64_t)y3_packed_filter_elems(d->cout, d->cin, d->ksize))
+        Y3_FAIL("y3_conv2d_fwd: the packed filter bank holds %lld elements, (cout %d, cin %d, k %d) needs %llu (size banks with y3_packed_filter_elems)",
+                (long long)d->filter_elems, d->cout, d->cin, d->ksize, (unsigned long long)y3_packed_filter_elems(d->cout, d->cin, d->ksize));
     if ((long long)x->n * Ho * Wo * (d->upsample2x ? 4 : 1) > 0x7fffffffLL) Y3_FAIL("y3_conv2d_fwd: too many output pixels");
 
     ConvArgs a;

@@ -127,14 +127,18 @@ static inline y3_divisor y3_make_divisor(int d) {
 Y3_DEV int y3_fdiv(int n, y3_divisor d) { return d.mul ? (int)(__umulhi((unsigned)n, d.mul) >> (d.sh - 1)) : n; }
 
 static inline int y3_ceil_div(int a, int b) { return (a + b - 1) / b; }
-// compute units of the current device (persistent grids and tile plans are sized from it: 256 on a whole MI355X, fewer on a partition)
+// compute units of the CURRENT device (persistent grids and tile plans are sized from it: 256 on a whole MI355X, fewer on a partition).  Cached per device
+// ordinal: a process that drives several devices or partitions of different size (CPX / NPS modes) gets each one's own count
 static inline int y3_cu_count() {
-    static const int n = [] {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        return cus;
-    }();
-    return n;
+    constexpr int MAXD = 64;
+    static int cache[MAXD] = {0};   // 0 = not asked yet (a racing first call stores the same value)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    if (dev < MAXD && cache[dev] > 0) return cache[dev];
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    if (dev < MAXD) cache[dev] = cus;
+    return cus;
 }
 static inline size_t y3_round_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 

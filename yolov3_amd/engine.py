@@ -250,7 +250,7 @@ class Plan:
         for kind, kw in self.steps:
             if kind == "conv":
                 x, y, w, res = kw["x"].real(), kw["y"].real(), kw["w"], kw["res"]
-                d = Y3ConvDesc(dcode, w.k, w.s, _lib.Y3_ACT_SILU if w.act else _lib.Y3_ACT_NONE, int(kw["ups"]), _lib.Y3_ALGO_AUTO, w.cin, w.cout, 0)
+                d = Y3ConvDesc(dcode, w.k, w.s, _lib.Y3_ACT_SILU if w.act else _lib.Y3_ACT_NONE, int(kw["ups"]), _lib.Y3_ALGO_AUTO, w.cin, w.cout, 0, w.filt.numel())
                 xt, yt = x.y3(), y.y3()
                 rt = res.real().y3() if res is not None else None
                 ho = (x.h + 2 * (w.k // 2) - w.k) // w.s + 1

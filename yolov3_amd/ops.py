@@ -34,32 +34,6 @@ def stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-_MASKED_STREAMS = {}
-
-
-def masked_stream(device, n_cus: int, first: int = 0):
-    """HIP stream whose kernels may only occupy CUs [first, first + n_cus) of the CU-mask bit vector (hipExtStreamCreateWithCUMask), as a torch stream.
-    The training plan runs its filter gradients there (TrainPlan.wgrad_stream): the CUs outside the mask stay free for the kernels of the compute stream,
-    so the HBM-bound BatchNorm passes of the backward's critical chain run BESIDE the MFMA-bound filter-gradient kernels instead of queueing behind them.
-    One stream per (device, n_cus, first) and process; the handle lives as long as the process."""
-    key = (torch.device(device).index or 0, int(n_cus), int(first))
-    st = _MASKED_STREAMS.get(key)
-    if st is None:
-        hip = C.CDLL("libamdhip64.so")
-        total = torch.cuda.get_device_properties(device).multi_processor_count
-        words = max(1, (total + 31) // 32)
-        mask = (C.c_uint32 * words)()
-        for b in range(int(first), min(total, int(first) + int(n_cus))):
-            mask[b // 32] |= 1 << (b % 32)
-        handle = C.c_void_p()
-        with torch.cuda.device(device):
-            rc = hip.hipExtStreamCreateWithCUMask(C.byref(handle), C.c_uint32(words), mask)
-        if rc != 0 or not handle.value:
-            raise RuntimeError(f"hipExtStreamCreateWithCUMask({n_cus} of {total} CUs) failed: hipError {rc}")
-        st = _MASKED_STREAMS[key] = torch.cuda.ExternalStream(handle.value, device=device)
-    return st
-
-
 def tune_set(key: str, value: int):
     """run-time knob of the library (y3_tune_set: A/B hooks, test coverage of size-gated forms); process-wide"""
     check(_lib.lib().y3_tune_set(key.encode(), int(value)), "y3_tune_set")
@@ -129,7 +103,7 @@ def conv_workspace(device) -> torch.Tensor:
 
 def conv2d(x: View, filt: torch.Tensor, bias: torch.Tensor, y: View, k: int, stride: int, act: bool, residual: View | None = None, upsample2x: bool = False,
            algo: int = _lib.Y3_ALGO_AUTO, in_dilation: int = 0, workspace: torch.Tensor | None = None):
-    d = Y3ConvDesc(dtype_code(x.buf.dtype), k, stride, _lib.Y3_ACT_SILU if act else _lib.Y3_ACT_NONE, int(upsample2x), algo, x.c, y.c, in_dilation)
+    d = Y3ConvDesc(dtype_code(x.buf.dtype), k, stride, _lib.Y3_ACT_SILU if act else _lib.Y3_ACT_NONE, int(upsample2x), algo, x.c, y.c, in_dilation, filt.numel())
     xt, yt = x.y3(), y.y3()
     rt = residual.y3() if residual is not None else None
     if workspace is not None:
@@ -440,7 +414,7 @@ def conv2d_stats_rows(x: View, y: View, k: int, stride: int, workspace: torch.Te
 def conv2d_stats(x: View, filt: torch.Tensor, bias: torch.Tensor, y: View, k: int, stride: int, stat_rows: torch.Tensor, capacity_rows: int,
                  workspace: torch.Tensor | None = None) -> int:
     """y = conv(x) (no activation) + per-(pixel tile, wave) rows of (sum, sum of squares) per filter in stat_rows (fp32)."""
-    d = Y3ConvDesc(dtype_code(x.buf.dtype), k, stride, _lib.Y3_ACT_NONE, 0, _lib.Y3_ALGO_AUTO, x.c, y.c, 0)
+    d = Y3ConvDesc(dtype_code(x.buf.dtype), k, stride, _lib.Y3_ACT_NONE, 0, _lib.Y3_ALGO_AUTO, x.c, y.c, 0, filt.numel())
     xt, yt = x.y3(), y.y3()
     n = C.c_int64(0)
     if workspace is not None:

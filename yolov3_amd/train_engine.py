@@ -546,9 +546,9 @@ class TrainPlan:
         # +0.35 ms -- both kernel families fill the chip on their own, the hardware runs the two queues mostly back to back --
         # so the default keeps everything on the compute stream
         self.wgrad_stream = None
+        self._bwd_stream = None   # the stream backward() runs on while a side stream is in use (grad_alloc records the arena on both)
         if device.type == "cuda" and os.environ.get("Y3_WGRAD_STREAM", "0") == "1":
-            n_cus = int(os.environ.get("Y3_WGRAD_CUS", "0"))   # > 0: the side stream is confined to that many CUs (ops.masked_stream; tools/wgrad_overlap_ab.py)
-            self.wgrad_stream = ops.masked_stream(device, n_cus) if n_cus > 0 else torch.cuda.Stream(device=device)
+            self.wgrad_stream = torch.cuda.Stream(device=device)   # (a lab tool may swap in a CU-masked stream: tools/lab/cu_mask.py, tools/wgrad_overlap_ab.py)
         # Y3_BN_EPILOGUE=0: statistics by a separate reduction pass over u (A/B runs); fp32 plans always take that path
         self.epilogue_stats = dtype in (torch.float16, torch.bfloat16) and os.environ.get("Y3_BN_EPILOGUE", "1") != "0"
 
@@ -599,7 +599,7 @@ class TrainPlan:
             self._arena_off = 0
             if self.wgrad_stream is not None:   # written on the side stream, read on the compute stream, whichever pool it came from
                 self._arena.record_stream(self.wgrad_stream)
-                self._arena.record_stream(self._bwd_stream)
+                self._arena.record_stream(self._bwd_stream if self._bwd_stream is not None else torch.cuda.current_stream())
         t = self._arena[self._arena_off:self._arena_off + n].view(shape)
         self._arena_off += n_al
         return t
@@ -819,6 +819,9 @@ def run_model_train(model, x: torch.Tensor):
                 slot = min(range(pc.MAX_TRAIN), key=lambda s_: getattr(pc.plans.get(("train", n, h, w, dtype, x.device.index, s_)), "last_forward", -1))
                 key = ("train", n, h, w, dtype, x.device.index, slot)
                 plan = pc.get(key)
+                if plan is not None and plan.param_ids != tuple(id(p) for p in model.parameters()):   # (the same staleness test as the idle-slot path: round-4 advisor finding)
+                    del pc.plans[key]
+                    plan = None
                 break
         if plan is None:
             plan = TrainPlan(model, n, h, w, dtype, x.device)
