@@ -160,17 +160,33 @@ def test_train_plan_static_analysis_on_cpu():
     import torch
 
     from yolov3_amd import DetectionModel
-    from yolov3_amd.train_engine import ConvUnit, TrainPlan
+    from yolov3_amd.train_engine import ConvUnit, TrainPlan, TrainSlot
 
     m = DetectionModel("yolov3.yaml", nc=80).train()
-    p = TrainPlan(m, 1, 64, 64, torch.float16, torch.device("cpu"))
+    cpu = torch.device("cpu")
+    slot = TrainSlot(torch.float16, cpu)
+    p = TrainPlan.build(m, 1, 64, 64, torch.float16, cpu, slot)
     convs = [u for u in p.units if isinstance(u, ConvUnit)]
     assert len(convs) == 72
     jobs = p.pack_jobs.jobs
     assert len(jobs) == 71 + 3 and sum(1 for j in jobs if j[2] is not None) == 66 + 3   # 5 stride-2 3x3 units keep their parity-class banks
     assert all(u.bank_fwd is not None for u in convs if not u.use_stem) and convs[0].use_stem and convs[0].bank_fwd is None
-    r = TrainPlan(m, 1, 64, 64, torch.float32, torch.device("cpu"))
+    r = TrainPlan.build(m, 1, 64, 64, torch.float32, cpu, TrainSlot(torch.float32, cpu))
     assert r.pack_jobs is None
+    # multi-scale training (reference train.py:394-399): every shape of a slot is a set of views into ONE arena sized for the largest shape seen, and packs into the
+    # SAME filter banks -- a change of shape allocates nothing once the largest shape has run
+    assert slot.arena_allocations == 1 and p.x_in.view.buf.data_ptr() >= slot.arena.data_ptr()
+    big = TrainPlan.build(m, 1, 128, 128, torch.float16, cpu, slot, siblings=[p])
+    assert slot.arena_allocations == 2 and big.slot_generation == slot.generation == p.slot_generation   # p was pointed at the new arena, not rebuilt
+    lo, hi = slot.arena.data_ptr(), slot.arena.data_ptr() + slot.arena.numel()
+    small = TrainPlan.build(m, 1, 96, 64, torch.float16, cpu, slot, siblings=[p, big])
+    assert slot.arena_allocations == 2 and small.slot_generation == slot.generation and slot.arena.numel() == big._act_off
+    for pl in (p, big, small):
+        spans = sorted((a.view.buf.data_ptr(), a.view.buf.data_ptr() + a.view.buf.numel() * 2) for a in pl.acts if getattr(a, "parent", None) is None)
+        spans += [(u.u.buf.data_ptr(), u.u.buf.data_ptr() + u.u.buf.numel() * 2) for u in pl.units if isinstance(u, ConvUnit)]
+        spans.sort()
+        assert all(lo <= a and b <= hi for a, b in spans) and all(b0 <= a1 for (_, b0), (a1, _) in zip(spans, spans[1:])), "views leave the arena or overlap"
+    assert len(slot.pack_jobs.jobs) == 71 + 3 and big.units[1].bank_fwd is small.units[1].bank_fwd   # one set of banks for all shapes
 
 
 def test_deferred_shortcut_gradient_state_machine():

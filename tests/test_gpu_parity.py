@@ -1902,6 +1902,56 @@ parallel.finalize()
     assert out.returncode == 0 and out.stdout.count("ok") == 2, out.stdout + out.stderr
 
 
+def test_multi_scale_training_reuses_one_arena(dev):
+    """The reference's --multi-scale training (train.py:394-399) draws a new size from [0.5, 1.5] x imgsz in steps of the grid size for EVERY batch: 21 sizes at
+    imgsz 640.  All of them stay compiled (PlanCache.MAX_TRAIN_SHAPES >= 24) as views into ONE activation arena per slot: after the first pass over the sizes no plan
+    is built, the arena is not re-allocated, and a size that comes round again gives bit-identical gradients (nothing of another shape's run leaks into it)."""
+    import random
+
+    from yolov3_amd import ComputeLoss, train_engine
+    from yolov3_amd.engine import plan_cache
+
+    hyp = dict(box=0.05, cls=0.5, cls_pw=1.0, obj=1.0, obj_pw=1.0, anchor_t=4.0, fl_gamma=0.0, label_smoothing=0.0)
+    m, _ = build_pair("yolov3-tiny", 80, 41, dev, torch.float32)
+    m.train()
+    m.hyp = hyp
+    for mod in m.modules():   # frozen running statistics: a shape's second visit sees the same state as its first
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.momentum = 0.0
+    crit = ComputeLoss(m)
+    imgsz, gs, bs = 640, 32, 2
+    sizes = sorted({random.Random(s_).randrange(int(imgsz * 0.5), int(imgsz * 1.5) + gs) // gs * gs for s_ in range(4000)})
+    assert len(sizes) == 21 and sizes[0] == 320 and sizes[-1] == 960
+    tg = yo.synth_targets(bs, 80, seed=5).to(dev)
+
+    def grads(sz):
+        x = torch.rand(bs, 3, sz, sz, generator=torch.Generator().manual_seed(sz)).to(dev)
+        m.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            loss, _ = crit(m(x), tg)
+        (loss * 64.0).backward()
+        return torch.cat([p_.grad.flatten() for p_ in m.parameters()])
+
+    order = sizes[:]
+    random.Random(7).shuffle(order)
+    first = {sz: grads(sz) for sz in order}
+    torch.cuda.synchronize()
+    pc = plan_cache(m)
+    slot = pc.train_slots(torch.float16, dev, train_engine.TrainSlot)[0]
+    builds, allocs, ptr = train_engine.PLAN_BUILDS, slot.arena_allocations, slot.arena.data_ptr()
+    assert sum(1 for k in pc.plans if k[0] == "train") == 21, [k for k in pc.plans if k[0] == "train"]
+    random.Random(8).shuffle(order)
+    for sz in order + order[::-1]:
+        g = grads(sz)
+        assert torch.equal(g, first[sz]), f"{sz} x {sz}: gradients changed between two visits of the shape"
+    torch.cuda.synchronize()
+    assert train_engine.PLAN_BUILDS == builds, f"{train_engine.PLAN_BUILDS - builds} plans were rebuilt in the second / third pass"
+    assert slot.arena_allocations == allocs and slot.arena.data_ptr() == ptr
+    # the arena holds the largest shape exactly once, not the sum of the shapes
+    big = pc.plans[("train", bs, 960, 960, torch.float16, dev.index, 0)]
+    assert slot.arena.numel() == big._act_off
+
+
 def test_loss_rejects_out_of_range_targets(dev):
     """a target with image index >= bs (or < 0) or class >= nc used to index out of bounds in the match kernels; the
     reference raises an IndexError.  Here the row is dropped on the device and the loss comes back NaN (no host sync to raise

@@ -675,19 +675,22 @@ class PlanCache:
     shared by all eval plans and live as long as the parameters are not modified."""
 
     MAX_EVAL = int(os.environ.get("Y3_MAX_PLANS", "6"))
-    MAX_TRAIN = int(os.environ.get("Y3_MAX_TRAIN_PLANS", "2"))          # outstanding forwards per shape
-    MAX_TRAIN_SHAPES = int(os.environ.get("Y3_MAX_TRAIN_SHAPES", "3"))   # distinct (batch, h, w, dtype) training shapes kept compiled
+    MAX_TRAIN = int(os.environ.get("Y3_MAX_TRAIN_PLANS", "2"))          # training slots = forwards that may be outstanding at once (train_engine.TrainSlot)
+    MAX_TRAIN_SHAPES = int(os.environ.get("Y3_MAX_TRAIN_SHAPES", "24"))  # distinct (batch, h, w, dtype) training shapes kept compiled: the reference's multi-scale training
+                                                                          # draws from ~21 sizes (train.py:394-399); a plan is views into its slot's arena, not buffers
 
     def __init__(self):
         self.plans: "OrderedDict" = OrderedDict()
         self.weights: dict = {}
         self.weights_version = None
+        self.slots: dict = {}   # (dtype, device index) -> [TrainSlot] * MAX_TRAIN
         self.lock = threading.Lock()
 
     def clear(self):
         with self.lock:
             self.plans.clear()
             self.weights.clear()
+            self.slots.clear()
             self.weights_version = None
 
     def get(self, key):
@@ -696,6 +699,19 @@ class PlanCache:
             self.plans.move_to_end(key)
         return plan
 
+    def train_slots(self, dtype, device, slot_cls):
+        """the MAX_TRAIN training slots of (activation dtype, device): each owns one activation arena, sized for the largest shape it has run, and the filter banks"""
+        key = (dtype, device.index)
+        sl = self.slots.get(key)
+        if sl is None:
+            sl = self.slots[key] = [slot_cls(dtype, device, i) for i in range(self.MAX_TRAIN)]
+        return sl
+
+    def drop_train_slot(self, slot):
+        """forget the compiled plans of one training slot that are stale (built on an arena / for Parameter objects the slot has replaced since)"""
+        for k in [k for k, p in self.plans.items() if k[0] == "train" and getattr(p, "slot", None) is slot and p.slot_generation != slot.generation]:
+            del self.plans[k]
+
     def put(self, key, plan):
         self.plans[key] = plan
         if key[0] != "train":
@@ -703,9 +719,7 @@ class PlanCache:
             for k in same[: max(0, len(same) - self.MAX_EVAL)]:
                 del self.plans[k]   # the activation pool / workspace go back to torch's allocator once the last launch that uses them has run
             return
-        # training plans: MAX_TRAIN slots per SHAPE (a slot = one outstanding forward, train_engine.run_model_train) and at most
-        # MAX_TRAIN_SHAPES shapes (multi-scale training, a short last batch), least recently used shape first -- a global cap of two plans
-        # rebuilt a plan (and its zeroed conv workspace) on every change of shape (round-2 advisor finding)
+        # training plans: one per (shape, slot) and at most MAX_TRAIN_SHAPES shapes (multi-scale training, a short last batch), least recently used shape first
         shapes = []
         for k in self.plans:
             if k[0] == "train" and k[1:6] not in shapes:

@@ -117,7 +117,7 @@ class ConvUnit(_Unit):
         self.co_real, self.ci_real = conv.out_channels, conv.in_channels
         v = y.view
         dev, dt = plan.device, plan.dtype
-        self.u = View.alloc(v.n, v.h, v.w, self.cout, dt, dev)
+        self.u = plan.alloc_view(v.n, v.h, v.w, self.cout)
         C_ = self.cout
         self.sums = plan.bn_sums(C_)   # shared by every unit of the plan: each pass consumes its sums before the next launch is queued (one stream)
         self.scale, self.shift, self.mean, self.invstd = (torch.empty(C_, dtype=torch.float32, device=dev) for _ in range(4))
@@ -338,7 +338,7 @@ class HeadUnit(_Unit):
         self.plan, self.conv, self.det, self.x, self.label = plan, conv, det, x, label
         v = x.view
         self.cout = _pad8(conv.out_channels)
-        self.head = View.alloc(v.n, v.h, v.w, self.cout, plan.dtype, plan.device)
+        self.head = plan.alloc_view(v.n, v.h, v.w, self.cout)
         self.raw = None
         self.bank_fwd = self.bank_dgrad = None
         self.filt_d = None
@@ -426,19 +426,93 @@ class SPPPoolUnit(_Unit):
             self.x.mark_ready()
 
 
+class TrainSlot:
+    """What the training plans of one (model, activation dtype, device, slot index) share: ONE activation arena sized for the largest shape seen, the persistent
+    filter banks (re-packed from the fp32 masters at every forward, whatever the shape), the conv workspace and the small scratch buffers.
+
+    Why: the reference's multi-scale training (train.py:394-399) draws a new size from ~21 (imgsz 640: 320 .. 960 in steps of 32) for EVERY batch.  A plan that owned its
+    activations cost 12-55 GB per shape, so only three shapes could stay compiled and every step rebuilt a plan and re-allocated its buffers.  Now a plan is a list of
+    views into the slot's arena plus a few KB of per-layer vectors: two dozen shapes stay compiled (PlanCache.MAX_TRAIN_SHAPES) and a change of shape allocates nothing
+    once the largest shape has been seen.  A slot runs one forward at a time: while the backward of a grad-enabled forward is outstanding the slot is busy and
+    another forward (a second micro-batch, a no_grad pass) takes the next slot (PlanCache.MAX_TRAIN of them) -- run_model_train."""
+
+    def __init__(self, dtype, device, index=0):
+        self.dtype, self.device, self.index = dtype, device, index
+        self.arena: torch.Tensor | None = None
+        self.generation = 0          # bumped when the arena is replaced: plans built on the old one are stale
+        self.arena_allocations = 0   # how often the arena was (re)allocated (tests: no growth after the largest shape)
+        self.active = None           # weakref to the plan whose forward ran last in this slot
+        self.last_forward = -1
+        self.param_ids = None
+        self.pack_jobs = None
+        self._banks: dict = {}
+        self._conv_ws = None
+        self._bn_sums = self._stat_buf = self._stem_bwd_ws = None
+        self._zeros: dict = {}
+        self._ones: dict = {}
+
+    def busy(self) -> bool:
+        pl = self.active() if self.active is not None else None
+        return pl is not None and pl.outstanding
+
+    def take_over(self, plan):
+        """`plan` runs its forward in this slot now: whatever another plan saved here is gone (its backward raises instead of computing garbage)"""
+        old = self.active() if self.active is not None else None
+        if old is not None and old is not plan and old.outstanding:
+            old.generation += 1
+            old.outstanding = False
+        self.active = weakref.ref(plan)
+
+    def reset(self, param_ids):
+        """the model's Parameter objects changed: banks keyed by the old tensors are dropped, every plan of the slot is stale"""
+        self.param_ids = param_ids
+        self.pack_jobs, self._banks = None, {}
+        self.generation += 1
+
+    def grow(self, nbytes: int):
+        self.arena = None   # (release first: the old arena may be most of the free memory)
+        self.arena = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        self.generation += 1
+        self.arena_allocations += 1
+
+    def carve(self, off: int, nbytes: int, dtype):
+        if self.arena is None or off + nbytes > self.arena.numel():
+            return None
+        return self.arena[off:off + nbytes].view(dtype)
+
+    def banks(self, w, cout, cin, want_fwd, want_dgrad):
+        """persistent (forward bank, data-gradient bank) of weight tensor `w`, registered once per slot with the one-launch packer"""
+        if self.pack_jobs is None:
+            self.pack_jobs = ops.PackJobs(self.dtype, self.device)
+        key = (id(w), cout, cin, bool(want_fwd), bool(want_dgrad))
+        b = self._banks.get(key)
+        if b is None:
+            b = self._banks[key] = self.pack_jobs.add(w, cout, cin, want_fwd, want_dgrad)
+        return b
+
+    def conv_ws(self):
+        if self._conv_ws is None:
+            self._conv_ws = ops.conv_workspace(self.device)
+        return self._conv_ws
+
+
 _FORWARD_TICK = 0
+PLAN_BUILDS = 0   # TrainPlan constructions in this process (tests of the multi-scale path count them)
 
 
 class TrainPlan:
-    def __init__(self, model, n, h, w, dtype, device):
+    def __init__(self, model, n, h, w, dtype, device, slot: "TrainSlot | None" = None):
         from .yolo import Detect
 
+        global PLAN_BUILDS
+        PLAN_BUILDS += 1
         self.model, self.n, self.h, self.w, self.dtype, self.device = model, n, h, w, dtype, device
+        self.slot = slot if slot is not None else TrainSlot(dtype, device)   # (on its own -- tests, tools -- use TrainPlan.build(..., TrainSlot(dtype, device)): a private slot)
+        self.slot_generation = self.slot.generation
+        self._act_off, self._overflow, self._carved = 0, False, []   # bump allocation inside the slot's arena (alloc_view)
         self.units: list[_Unit] = []
         self.heads: list[HeadUnit] = []
         self.acts: list[Act] = []
-        self._zeros: dict = {}
-        self._ones: dict = {}
         layers = list(model.model)
         hw = graph_hw(model, h, w)
         src = [_sources(i, m.f) for i, m in enumerate(layers)]
@@ -465,7 +539,7 @@ class TrainPlan:
         self._max_c = max(_pad8(mod.out_channels) for mod in model.modules() if isinstance(mod, nn.Conv2d))
 
         def new_act(i_hw, c):
-            a = Act(View.alloc(n, i_hw[0], i_hw[1], c, dtype, device))
+            a = Act(self.alloc_view(n, i_hw[0], i_hw[1], c))
             self.acts.append(a)
             return a
 
@@ -489,7 +563,7 @@ class TrainPlan:
             return placed[i]
 
         cin0 = _pad8(model.yaml.get("ch", 3))
-        self.x_in = Act(View.alloc(n, h, w, cin0, dtype, device))
+        self.x_in = Act(self.alloc_view(n, h, w, cin0))
         out: dict[int, Act] = {-1: self.x_in}
         pad_of = {}
         for i, m in enumerate(layers):
@@ -559,31 +633,79 @@ class TrainPlan:
         self._bn_counters = [u.m.bn.num_batches_tracked for u in self.units if isinstance(u, ConvUnit) and u.m.bn.num_batches_tracked is not None]
         # scratch of the persistent conv kernel (forward + data-gradient launches of the 3x3 layers with >= 256 channels); one per plan:
         # every conv launch of the plan runs on the compute stream
-        self.conv_ws = ops.conv_workspace(device) if dtype in (torch.float16, torch.bfloat16) else None
+        self.conv_ws = self.slot.conv_ws() if dtype in (torch.float16, torch.bfloat16) else None   # (one per slot: a slot runs one plan at a time, on one stream)
         self._arena, self._arena_off = None, 0
         self._arena_numel = sum((p.numel() + 63) // 64 * 64 for p in self.params)
-        # all filter banks of a step in one launch (Y3_PACK_JOBS=0: one launch per layer, as before)
+        # all filter banks of a step in one launch (Y3_PACK_JOBS=0: one launch per layer, as before); the banks belong to the slot: every shape packs into the same ones
         self.pack_jobs, self.banks_fresh = None, False
         if dtype in (torch.float16, torch.bfloat16) and os.environ.get("Y3_PACK_JOBS", "1") != "0":
-            self.pack_jobs = ops.PackJobs(dtype, device)
             for u in self.units:
                 if isinstance(u, ConvUnit) and not u.use_stem:
-                    u.bank_fwd, u.bank_dgrad = self.pack_jobs.add(u.m.conv.weight, u.cout, u.cin, True, u.pair_pack)
+                    u.bank_fwd, u.bank_dgrad = self.slot.banks(u.m.conv.weight, u.cout, u.cin, True, u.pair_pack)
             for hd in self.heads:
-                hd.bank_fwd, hd.bank_dgrad = self.pack_jobs.add(hd.conv.weight, hd.cout, hd.x.view.c, True, True)
+                hd.bank_fwd, hd.bank_dgrad = self.slot.banks(hd.conv.weight, hd.cout, hd.x.view.c, True, True)
+            self.pack_jobs = self.slot.pack_jobs
         self.last_forward = 0
         self.generation = 0        # bumped by every forward: the saved activations belong to exactly one forward
         self.outstanding = False   # a grad-enabled forward ran and its backward has not: the saved state must not be overwritten
 
     # -- helpers ---------------------------------------------------------------------------------
+    @classmethod
+    def build(cls, model, n, h, w, dtype, device, slot: "TrainSlot", siblings=()):
+        """a plan on `slot`.  When the slot's arena is too small for this shape it is re-allocated at this shape's size and every plan of the slot (`siblings`: the
+        compiled plans of the other shapes) is pointed at the new one -- same offsets, nothing is rebuilt"""
+        plan = cls(model, n, h, w, dtype, device, slot)
+        if plan._overflow:
+            others = [p for p in siblings if p is not plan and p.slot is slot]
+            for p in others:
+                p.unbind()           # (the old arena is released BEFORE the new one is allocated: it may be most of the free memory)
+            slot.grow(plan._act_off)
+            for p in others + [plan]:
+                p.rebind()
+        return plan
+
+    def alloc_view(self, n, h, w, c) -> View:
+        """an NHWC activation buffer of this plan: the next 256-byte aligned range of the slot's arena.  Beyond the arena's end the view stays unbound and the plan
+        only counts (`_overflow`): build() then grows the arena to the counted size and binds the views (rebind)"""
+        esz = torch.empty(0, dtype=self.dtype).element_size()
+        nbytes = n * h * w * c * esz
+        off = self._act_off
+        self._act_off = off + (nbytes + 255) // 256 * 256
+        buf = self.slot.carve(off, nbytes, self.dtype)
+        if buf is None:
+            self._overflow = True
+            buf = torch.empty(0, dtype=self.dtype, device=self.device)
+        v = View(buf, n, h, w, c, c, 0)
+        self._carved.append((v, off, nbytes))
+        return v
+
+    def unbind(self):
+        empty = torch.empty(0, dtype=self.dtype, device=self.device)
+        for v, _, _ in self._carved:
+            v.buf = empty
+        for a in self.acts:
+            if getattr(a, "parent", None) is not None:
+                a.view.buf = empty
+
+    def rebind(self):
+        """point every activation view at the slot's CURRENT arena (same offsets): after the arena grew for a larger shape.  Nothing caches a device pointer of an
+        activation between launches (the y3_tensor descriptors are made per call), so this is all there is to moving a plan"""
+        for v, off, nbytes in self._carved:
+            v.buf = self.slot.carve(off, nbytes, self.dtype)
+            assert v.buf is not None, "the arena is smaller than a plan that was built on it"
+        for a in self.acts:   # channel slices of a Concat buffer share their parent's storage
+            if getattr(a, "parent", None) is not None:
+                a.view.buf = a.parent.view.buf
+        self._overflow = False
+        self.slot_generation = self.slot.generation
+
     def bn_sums(self, c):
-        """fp64 scratch of the BatchNorm reductions (totals + per-block partial rows), one buffer for the whole plan."""
-        t = getattr(self, "_bn_sums", None)
-        if t is None or t.numel() < (1 + ops.BN_PARTIAL_ROWS) * 2 * c:
-            if t is not None:
-                raise RuntimeError("bn_sums must be sized by the widest layer first")
-            t = self._bn_sums = ops.bn_scratch(self._max_c, self.device)
-        return t
+        """fp64 scratch of the BatchNorm reductions (totals + per-block partial rows), one buffer for the whole slot (every pass consumes its sums before the next
+        launch is queued: one stream)."""
+        sl = self.slot
+        if sl._bn_sums is None or sl._bn_sums.numel() < (1 + ops.BN_PARTIAL_ROWS) * 2 * max(c, self._max_c):
+            sl._bn_sums = ops.bn_scratch(max(c, self._max_c), self.device)
+        return sl._bn_sums
 
     def grad_alloc(self, shape):
         """fp32 gradient tensor of `shape`: a slice of this backward's flat arena, handed out in the order the backward produces
@@ -629,28 +751,28 @@ class TrainPlan:
                 grads[b_param] = db
 
     def stem_bwd_ws(self):
-        t = getattr(self, "_stem_bwd_ws", None)
-        if t is None:
-            t = self._stem_bwd_ws = ops.stem_bwd_workspace(self.device)
-        return t
+        sl = self.slot
+        if sl._stem_bwd_ws is None:
+            sl._stem_bwd_ws = ops.stem_bwd_workspace(self.device)
+        return sl._stem_bwd_ws
 
     def stat_buffer(self, n_floats):
-        """fp32 scratch for the conv epilogue's statistics rows, shared by all units (stream-ordered reuse)."""
-        t = getattr(self, "_stat_buf", None)
-        if t is None or t.numel() < n_floats:
-            t = self._stat_buf = torch.empty(n_floats, dtype=torch.float32, device=self.device)
-        return t
+        """fp32 scratch for the conv epilogue's statistics rows, shared by all units of the slot (stream-ordered reuse)."""
+        sl = self.slot
+        if sl._stat_buf is None or sl._stat_buf.numel() < n_floats:
+            sl._stat_buf = torch.empty(n_floats, dtype=torch.float32, device=self.device)
+        return sl._stat_buf
 
     def zeros_f32(self, c):
-        t = self._zeros.get(c)
+        t = self.slot._zeros.get(c)
         if t is None:
-            t = self._zeros[c] = torch.zeros(c, dtype=torch.float32, device=self.device)
+            t = self.slot._zeros[c] = torch.zeros(c, dtype=torch.float32, device=self.device)
         return t
 
     def ones_f32(self, c):
-        t = self._ones.get(c)
+        t = self.slot._ones.get(c)
         if t is None:
-            t = self._ones[c] = torch.ones(c, dtype=torch.float32, device=self.device)
+            t = self.slot._ones[c] = torch.ones(c, dtype=torch.float32, device=self.device)
         return t
 
     def scratch_like(self, v: View) -> View:
@@ -671,7 +793,7 @@ class TrainPlan:
     def forward(self, x: torch.Tensor):
         global _FORWARD_TICK
         _FORWARD_TICK += 1
-        self.last_forward = _FORWARD_TICK   # recency across plans (the slot choice in run_model_train)
+        self.last_forward = self.slot.last_forward = _FORWARD_TICK   # recency across slots (the slot choice in run_model_train)
         self.generation += 1
         self.x_nchw = x if x.dtype in (torch.float32, torch.float16, torch.bfloat16, torch.uint8) else None
         self.x_version = x._version
@@ -777,8 +899,8 @@ class _TrainFn(torch.autograd.Function):
             # torch autograd would have kept this forward's saved tensors alive; the static plan keeps ONE set per plan
             raise RuntimeError(
                 "yolov3_amd: backward of a training forward whose saved activations were overwritten by a later forward of the same "
-                f"shape (forward #{ctx.generation}, plan is at #{plan.generation}). More than Y3_MAX_TRAIN_PLANS (default 2) forwards of one "
-                "shape were outstanding at once; call backward() before the next forward, or raise the limit.")
+                f"model (forward #{ctx.generation}, plan is at #{plan.generation}). More than Y3_MAX_TRAIN_PLANS (default 2) forwards "
+                "were outstanding at once; call backward() before the next forward, or raise the limit.")
         grads = plan.backward(graws)
         plan.outstanding = False
         return (None, None, *grads)
@@ -799,33 +921,30 @@ def run_model_train(model, x: torch.Tensor):
     pc = plan_cache(model)
     grad = torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters())
     with pc.lock:
-        plan, slot = None, 0
-        # a forward whose backward is still outstanding keeps its plan (two micro-batches whose losses are summed, a no_grad pass
-        # between forward and backward): take the first idle plan of this shape, else a new slot; when every slot is busy the least
-        # recently used one is re-used and its stale backward raises (see _TrainFn.backward)
-        while True:
-            key = ("train", n, h, w, dtype, x.device.index, slot)
-            cand = pc.get(key)
-            if cand is not None and not cand.outstanding and cand.param_ids != tuple(id(p) for p in model.parameters()):
-                # a Parameter OBJECT was replaced since the plan captured them (re-created head, pruning, `m.conv.weight = nn.Parameter(..)`): the
-                # plan's backward would return None for it -- rebuild (in-place updates keep the ids and re-use the plan: banks are re-packed per forward)
-                del pc.plans[key]
-                cand = None
-            if cand is None or not cand.outstanding:
-                plan = cand
-                break
-            slot += 1
-            if slot >= pc.MAX_TRAIN:
-                slot = min(range(pc.MAX_TRAIN), key=lambda s_: getattr(pc.plans.get(("train", n, h, w, dtype, x.device.index, s_)), "last_forward", -1))
-                key = ("train", n, h, w, dtype, x.device.index, slot)
-                plan = pc.get(key)
-                if plan is not None and plan.param_ids != tuple(id(p) for p in model.parameters()):   # (the same staleness test as the idle-slot path: round-4 advisor finding)
-                    del pc.plans[key]
-                    plan = None
-                break
+        # A slot (TrainSlot: activation arena + filter banks, shared by every shape) runs one forward at a time.  A forward whose backward is still outstanding keeps
+        # its slot busy (two micro-batches whose losses are summed, a no_grad pass between forward and backward): take the first idle slot; when every slot is busy
+        # the least recently used one is taken over and the stale backward raises (see _TrainFn.backward)
+        slots = pc.train_slots(dtype, x.device, TrainSlot)
+        slot = next((sl for sl in slots if not sl.busy()), None)
+        if slot is None:
+            slot = min(slots, key=lambda sl: sl.last_forward)
+        ids = tuple(id(p) for p in model.parameters())
+        if slot.param_ids != ids:
+            # a Parameter OBJECT was replaced since the slot captured them (re-created head, pruning, `m.conv.weight = nn.Parameter(..)`): a plan's backward would
+            # return None for it and the banks would be packed from the old tensor -- start over (in-place updates keep the ids: banks are re-packed per forward)
+            had = slot.param_ids is not None
+            slot.reset(ids)
+            if had:
+                pc.drop_train_slot(slot)
+        key = ("train", n, h, w, dtype, x.device.index, slot.index)
+        plan = pc.get(key)
+        if plan is not None and (plan.slot_generation != slot.generation or plan.param_ids != ids):
+            del pc.plans[key]   # built on an arena that has been replaced since / for other Parameter objects
+            plan = None
         if plan is None:
-            plan = TrainPlan(model, n, h, w, dtype, x.device)
-            pc.put(key, plan)
+            plan = TrainPlan.build(model, n, h, w, dtype, x.device, slot, siblings=[p for k, p in pc.plans.items() if k[0] == "train"])   # (a larger shape grows the arena
+            pc.put(key, plan)                                                                                                      #  and re-points the slot's other plans)
+        slot.take_over(plan)
         plan.outstanding = grad
     if not grad:
         with torch.no_grad():
