@@ -206,7 +206,7 @@ def lib() -> C.CDLL:
     binds to (same SONAME libamdhip64.so.7): streams and device pointers then belong to one runtime."""
     global _lib
     if _lib is not None:
-        return _lib
+        return _lib if _call_timer is None else _call_timer
     import torch  # noqa: F401  (must precede the dlopen, see docstring)
 
     if not LIB_PATH.exists():
@@ -225,6 +225,66 @@ def lib() -> C.CDLL:
         raise Y3Error(f"ABI version mismatch: library reports {handle.y3_abi_version()}, bindings expect {ABI_VERSION}")
     _lib = handle
     return handle
+
+
+_call_timer = None
+# exports that launch nothing (sizes, plans, names, knobs): not timed
+_QUERIES = frozenset((
+    "y3_abi_version", "y3_last_error", "y3_tune_set", "y3_tune_get", "y3_tune_reset", "y3_packed_filter_elems", "y3_conv_workspace_bytes", "y3_conv_last_variant",
+    "y3_conv2d_fwd_variant", "y3_nms_workspace_bytes", "y3_loss_workspace_bytes", "y3_conv2d_fwd_stats_rows", "y3_conv2d_fwd_stats_rows_ws", "y3_pack_job_blocks",
+    "y3_packed_filter_dgrad_s2_elems", "y3_conv2d_wgrad_workspace_bytes", "y3_conv2d_wgrad_plan", "y3_packed_filter_stem_elems", "y3_stem_bn_bwd_wgrad_workspace_bytes",
+    "y3_stem_conv_stats_rows", "y3_conv_v10_tiles", "y3_sgd_tensor_record_bytes"))
+
+
+class CallTimer:
+    """HIP-event timing of every C-ABI call made while the timer is installed (`with CallTimer() as t: step()`), on the stream the kernels are launched on (torch's
+    current stream: what ops.stream_ptr() hands to the library).  bench.py uses it to split ONE training step into kernel families in the run that reports it,
+    instead of quoting a profile taken elsewhere.  `by_function()` -> {C function: [milliseconds, calls]} once the stream has drained."""
+
+    def __init__(self):
+        self.records = []   # (function name, start event, end event)
+        self._fns = {}
+
+    def __getattr__(self, name):   # stands in for the ctypes handle: lib().y3_xxx(...)
+        fn = self._fns.get(name)
+        if fn is None:
+            import torch
+
+            raw = getattr(_lib, name)
+            if name in _QUERIES:
+                fn = raw          # queries: nothing is launched
+            else:
+                def fn(*a, raw_=raw, name_=name):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    r = raw_(*a)
+                    e1.record()
+                    self.records.append((name_, e0, e1))
+                    return r
+            self._fns[name] = fn
+        return fn
+
+    def __enter__(self):
+        global _call_timer
+        lib()   # (loaded before the proxy stands in for it)
+        _call_timer = self
+        return self
+
+    def __exit__(self, *exc):
+        global _call_timer
+        _call_timer = None
+        return False
+
+    def by_function(self):
+        import torch
+
+        torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1 in self.records:
+            a = out.setdefault(name, [0.0, 0])
+            a[0] += e0.elapsed_time(e1)
+            a[1] += 1
+        return out
 
 
 def check(status: int, what: str = ""):
