@@ -219,25 +219,23 @@ def run_train(args, rank, world, dev, parallel, yo, batch, steps, warmup):
             model.grad_sync = None
     # kernel families of ONE more step, measured here: HIP events around every C-ABI call of the step on the stream it runs on (_lib.CallTimer), after the timed steps
     groups, timed_step_ms = None, None
-    if rank == 0:
-        from yolov3_amd import _lib as y3lib
+    from yolov3_amd import _lib as y3lib
 
-        try:
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            with y3lib.CallTimer() as ct:
-                step()
-            e1.record()
-            by_fn = ct.by_function()
-            timed_step_ms = round(e0.elapsed_time(e1), 3)
-            groups = train_call_families(by_fn)
-            lib_ms = sum(g["ms_per_step"] for g in groups.values())
-            groups["outside the library (torch glue, gaps)"] = {"ms_per_step": round(timed_step_ms - lib_ms, 3), "calls_per_step": 0}
-        except Exception as e:  # noqa: BLE001
-            groups = {"error": f"{type(e).__name__}: {e}"[:300]}
-    if world > 1:
-        parallel.barrier()
+    try:   # (every rank runs the extra step -- it contains the gradient collectives -- rank 0's record is the one reported)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        with y3lib.CallTimer() as ct:
+            step()
+        e1.record()
+        by_fn = ct.by_function()
+        timed_step_ms = round(e0.elapsed_time(e1), 3)
+        groups = train_call_families(by_fn)
+        lib_ms = sum(g["ms_per_step"] for g in groups.values())
+        groups["outside the library (torch glue, gaps)"] = {"ms_per_step": round(timed_step_ms - lib_ms, 3), "calls_per_step": 0}
+    except Exception as e:  # noqa: BLE001
+        groups = {"error": f"{type(e).__name__}: {e}"[:300]}
+    parallel.barrier()
     rec = {
         "metric": "images/sec (640x640) train step", "value": round(world * bs * steps / dt, 2), "unit": "images/sec", "n_gpus": world,
         "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",

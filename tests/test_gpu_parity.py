@@ -1883,7 +1883,9 @@ tg = yo.synth_targets(4, 80, seed=20 + rank).to(dev)
 def grads(sync):
     m.grad_sync = parallel.GradBuckets(bucket_bytes=8 << 20) if sync else None
     m.zero_grad(set_to_none=True)
-    crit(m(x), tg)[0].backward()
+    with torch.autocast("cuda", dtype=torch.float16):   # the product path: MFMA kernels, fixed-order reductions (the fp32 parity path's direct filter gradient uses fp32 atomics)
+        loss = crit(m(x), tg)[0]
+    (loss * 64.0).backward()
     torch.cuda.synchronize()
     return torch.cat([p.grad.flatten() for p in m.parameters()])
 own = grads(False)

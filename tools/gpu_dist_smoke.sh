@@ -4,10 +4,10 @@
 # Outputs: gpurun_out/${TAG}_dist_smoke_{infer,train}.json (copy into profiles/).
 TAG=${1:-r05}
 mkdir -p gpurun_out
-timeout 600 python3 bench.py --gpus 2 --steps 3 --warmup 1 --batch 4 --train-batch 4 --train-steps 2 --dist-backend gloo --no-cpu-baseline --no-clocks \
+timeout 200 python3 bench.py --gpus 2 --train-timeout 90 --steps 3 --warmup 1 --batch 4 --train-batch 4 --train-steps 2 --dist-backend gloo --no-cpu-baseline --no-clocks \
   > gpurun_out/${TAG}_dist_smoke_infer.json 2> gpurun_out/dist_smoke_infer.err; echo "infer exit $?"
 tail -c 600 gpurun_out/${TAG}_dist_smoke_infer.json | cut -c1-600; echo
-timeout 600 python3 bench.py --gpus 2 --mode train --steps 2 --warmup 1 --batch 4 --dist-backend gloo > gpurun_out/${TAG}_dist_smoke_train.json 2> gpurun_out/dist_smoke_train.err; echo "train exit $?"
+timeout 150 python3 bench.py --gpus 2 --mode train --steps 2 --warmup 1 --batch 4 --dist-backend gloo > gpurun_out/${TAG}_dist_smoke_train.json 2> gpurun_out/dist_smoke_train.err; echo "train exit $?"
 python3 -c "
 import json
 for f in ('gpurun_out/${TAG}_dist_smoke_infer.json', 'gpurun_out/${TAG}_dist_smoke_train.json'):
