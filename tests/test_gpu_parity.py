@@ -573,6 +573,28 @@ def test_nms_capacity_overflow_retry_and_big_boxes(dev):
     _cmp_nms(non_max_suppression(big.to(dev), **kw), yo.non_max_suppression(big, **kw), "big boxes")
 
 
+@pytest.mark.parametrize("max_det", [37, 64, 65, 300, 1000])
+@pytest.mark.parametrize("agnostic", [False, True])
+def test_nms_blocked_greedy_many_kept_boxes(dev, max_det, agnostic):
+    """nms_greedy_kernel walks a segment in blocks of 64 boxes (suppression rows of a block in parallel, one wave resolves them in order, the block's kept boxes
+    suppress what follows).  The load that made the one-box-at-a-time loop slow -- boxes that rarely suppress each other, hundreds kept per segment, like the
+    predictions of the benchmark's model -- with the kept count crossing max_det inside a block, at a block boundary and never; segments of 1 .. 4000 boxes
+    (3 classes + one image with a single box; agnostic: one segment per image).  Bit-exact against the oracle's torchvision loop."""
+    from yolov3_amd import non_max_suppression
+
+    g = torch.Generator().manual_seed(100 + max_det)
+    bs, n_rows, nc = 3, 4000, 3
+    pred = torch.zeros(bs, n_rows, 5 + nc)
+    pred[..., :2] = torch.rand(bs, n_rows, 2, generator=g) * 600 + 20
+    pred[..., 2:4] = torch.rand(bs, n_rows, 2, generator=g) * 50 + 8      # 8 .. 58 px boxes on a 640 px image: a few neighbours overlap by > 0.6, most do not
+    pred[..., 4] = torch.rand(bs, n_rows, generator=g) * 0.9 + 0.05
+    pred[..., 5:] = torch.rand(bs, n_rows, nc, generator=g)
+    pred[1, :, 5 + 1] = 0.0                                                 # image 1: class 1 has no candidates (an empty segment between two full ones)
+    pred[2, 1:, 4] = 0.0                                                    # image 2: one box in all
+    kw = dict(conf_thres=0.25, iou_thres=0.6, multi_label=True, max_det=max_det, agnostic=agnostic)
+    _cmp_nms(non_max_suppression(pred.to(dev), **kw), yo.non_max_suppression(pred, **kw), f"max_det {max_det} agnostic {agnostic}")
+
+
 def test_nms_properties(dev):
     """size-independent properties: idempotence (NMS of survivors keeps them all), score order, max_det cap"""
     from yolov3_amd import non_max_suppression

@@ -287,54 +287,102 @@ Y3_DEV long long lower_bound_u64(const unsigned long long* __restrict__ a, long 
     return lo;
 }
 
-// greedy NMS of one (image, segment); positions refer to sorted-1 order (ws.sbox / ws.keep)
+// greedy NMS of one (image, segment); positions refer to sorted-1 order (ws.sbox / ws.keep).
+//
+// The answer is torchvision's CPU loop (visit the boxes in score order; a box that no KEPT earlier box overlaps by more than the threshold is kept and suppresses
+// later ones; stop after max_det kept).  Round 1-4 ran that loop one kept box at a time -- three block barriers and a pass over the remaining boxes per kept box:
+// ~1.2 us each, 0.4 ms for a batch whose boxes rarely suppress each other (the model's own predictions: up to max_det kept per class, profiles/r05_bench_kernel_stats_b.md).
+// Now the segment is walked in blocks of 64 boxes:
+//   1. the block's 64 x 64 suppression bits (bit j of row i: box i would suppress box j > i) are computed by all 256 threads at once (16 pairs each);
+//   2. ONE wave resolves the block sequentially out of registers (row i lives in lane i; v_readlane, no memory in the chain): box i is kept unless an earlier kept
+//      box -- of an earlier block (bits in `removed`) or of this one -- suppressed it; the kept count stops the walk at max_det exactly where the loop would;
+//   3. the block's kept boxes (<= 64, in LDS) suppress the boxes of all later blocks in parallel.
+// The same IoU expression on the same operands decides every bit (inter / (area_i + area_j - inter) as a float, compared with the double threshold), so the
+// kept set is the loop's, bit for bit; four barriers per 64 boxes instead of three per kept box.
 __global__ __launch_bounds__(256) void nms_greedy_kernel(NmsWs ws, int nseg, double iou_thr, int max_det, int max_nms, const unsigned long long* __restrict__ key2,
                                                           const unsigned* __restrict__ pos2) {
     __shared__ unsigned removed[(1 << RANK_BITS) / 32];  // 32768 bits = 4 KiB
-    __shared__ int s_next;
+    __shared__ float4 blk[64];                            // the current block's boxes
+    __shared__ unsigned long long srow[64];               // their suppression rows inside the block
+    __shared__ unsigned long long s_keepm;                // which of them were kept
+    __shared__ int s_kept;                                // kept so far in the segment
     const int img = blockIdx.x / nseg, seg = blockIdx.x % nseg;
     const unsigned long long kbase = ((unsigned long long)img << (CLS_BITS + RANK_BITS)) | ((unsigned long long)seg << RANK_BITS);
     const long long lo = lower_bound_u64(key2, ws.cap, kbase);
     const long long hi = lower_bound_u64(key2, ws.cap, kbase + (1ull << RANK_BITS));
     const int n = (int)(hi - lo);
     if (n <= 0) return;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int w = tid; w < (n + 31) / 32; w += 256) removed[w] = 0u;
-    __syncthreads();
+    if (tid == 0) s_kept = 0;
     const unsigned* __restrict__ pos = pos2 + lo;
-    int cur = 0, kept = 0;
-    while (cur < n && kept < max_det) {
-        const unsigned pi = pos[cur];
-        if (tid == 0) ws.keep[pi] = 1;
-        ++kept;
-        const float4 bi = ws.sbox[pi];
-        const float iarea = (bi.z - bi.x) * (bi.w - bi.y);
-        for (int j = cur + 1 + tid; j < n; j += 256) {
-            if (removed[j >> 5] & (1u << (j & 31))) continue;
-            const float4 bj = ws.sbox[pos[j]];
-            const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
-            const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
-            float w = xx2 - xx1, h = yy2 - yy1;
-            w = w > 0.0f ? w : 0.0f;
-            h = h > 0.0f ? h : 0.0f;
-            const float inter = w * h;
-            const float jarea = (bj.z - bj.x) * (bj.w - bj.y);
-            const float ovr = inter / (iarea + jarea - inter);
-            if ((double)ovr > iou_thr) atomicOr(&removed[j >> 5], 1u << (j & 31));
+    auto suppresses = [&](const float4 bi, const float iarea, const float4 bj) {   // torchvision's test, operand for operand
+        const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
+        const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
+        float w = xx2 - xx1, h = yy2 - yy1;
+        w = w > 0.0f ? w : 0.0f;
+        h = h > 0.0f ? h : 0.0f;
+        const float inter = w * h;
+        const float jarea = (bj.z - bj.x) * (bj.w - bj.y);
+        const float ovr = inter / (iarea + jarea - inter);
+        return (double)ovr > iou_thr;
+    };
+    for (int base = 0; base < n; base += 64) {
+        const int cnt = n - base < 64 ? n - base : 64;
+        __syncthreads();   // `removed` as the blocks before this one left it (first trip: zeroed); blk / srow free
+        const unsigned long long rem_in = (unsigned long long)removed[base >> 5] | ((unsigned long long)removed[(base >> 5) + 1] << 32);   // (uniform; bits beyond n are 0)
+        const unsigned long long valid = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
+        if ((rem_in & valid) == valid) continue;   // every box of the block is already suppressed (uniform)
+        if (tid < 64) {
+            if (tid < cnt) blk[tid] = ws.sbox[pos[base + tid]];
+            srow[tid] = 0ull;
         }
         __syncthreads();
-        if (tid == 0) {
-            int nx = cur + 1;
-            while (nx < n) {
-                const unsigned wbits = ~removed[nx >> 5] & (0xffffffffu << (nx & 31));
-                if (wbits) { nx = (nx & ~31) + __builtin_ctz(wbits); break; }
-                nx = (nx & ~31) + 32;
+        // 1. suppression rows: lane i of wave w tests box i against boxes 16 w .. 16 w + 15 of the block (only j > i matters)
+        if (lane < cnt) {
+            const float4 bi = blk[lane];
+            const float iarea = (bi.z - bi.x) * (bi.w - bi.y);
+            unsigned long long bits = 0ull;
+#pragma unroll 4
+            for (int q = 0; q < 16; ++q) {
+                const int j = wv * 16 + q;
+                if (j > lane && j < cnt && suppresses(bi, iarea, blk[j])) bits |= 1ull << j;
             }
-            s_next = nx < n ? nx : n;
+            if (bits) atomicOr(&srow[lane], bits);
         }
         __syncthreads();
-        cur = s_next;
+        // 2. sequential resolve by wave 0, out of registers
+        if (wv == 0) {
+            const unsigned long long row = srow[lane];
+            const int row_lo = (int)(unsigned)row, row_hi = (int)(unsigned)(row >> 32);
+            unsigned long long rem = rem_in, keepm = 0ull;
+            int kept = s_kept;
+            for (int i = 0; i < cnt && kept < max_det; ++i) {
+                if (!((rem >> i) & 1ull)) {
+                    keepm |= 1ull << i;
+                    ++kept;
+                    rem |= (unsigned long long)(unsigned)__builtin_amdgcn_readlane(row_lo, i) | ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(row_hi, i) << 32);
+                }
+            }
+            if ((keepm >> lane) & 1ull) ws.keep[pos[base + lane]] = 1;
+            if (lane == 0) { s_keepm = keepm; s_kept = kept; }
+        }
         __syncthreads();
+        const unsigned long long keepm = s_keepm;
+        if (s_kept >= max_det) break;   // (uniform) later boxes can never be kept: the loop stops here too
+        // 3. the kept boxes of this block against every box behind the block
+        if (keepm)
+            for (int j = base + 64 + tid; j < n; j += 256) {
+                if (removed[j >> 5] & (1u << (j & 31))) continue;
+                const float4 bj = ws.sbox[pos[j]];
+                unsigned long long km = keepm;
+                while (km) {
+                    const int i = __builtin_ctzll(km);
+                    km &= km - 1ull;
+                    const float4 bi = blk[i];
+                    if (suppresses(bi, (bi.z - bi.x) * (bi.w - bi.y), bj)) { atomicOr(&removed[j >> 5], 1u << (j & 31)); break; }
+                }
+            }
     }
 }
 
