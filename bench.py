@@ -564,7 +564,7 @@ def main():
         total_conv_flops = sum(g[0] for g in groups.values()) / 5
         total_kernel_s = sum(g[2] for g in groups.values()) / 5
         pmc, pmc_file = {}, None
-        for cand in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):   # HBM traffic per launch comes from the committed rocprofv3 --pmc passes (bench.py cannot run the profiler)
+        for cand in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):   # HBM traffic per launch comes from the committed rocprofv3 --pmc passes (bench.py cannot run the profiler)
             try:
                 pmc = json.load(open(ROOT / "profiles" / cand)).get(dom.rsplit("/", 1)[0], {})  # PMC averages are per kernel symbol
             except OSError:

@@ -73,7 +73,8 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(const T* __restrict
                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                double* __restrict__ sums) {
     constexpr int V = V16<T>::N;
-    __shared__ double red[256 * 2];
+    constexpr int RP = 258;               // plane pitch in doubles: 516 dwords = 4 banks apart, so the 2 V planes one channel group's entries sit in never share a bank
+    __shared__ double red[RP * 2 * V];    // 33 KiB (16-bit T) / 16.5 KiB (fp32)
     const int CG = C / V;
     const int PL = 256 / CG;
     const int tid = threadIdx.x;
@@ -156,19 +157,22 @@ __global__ __launch_bounds__(256) void channel_reduce_kernel(const T* __restrict
 #pragma unroll
         for (int q = 0; q < V; ++q) { a0[q] += (double)f0[q / 2][q & 1]; a1[q] += (double)f1[q / 2][q & 1]; }
     }
-    // reduce over pixel lanes: one channel at a time through LDS (keeps LDS at 4 KiB)
+    // reduce over pixel lanes: every thread drops its 2 V sums into LDS ([entry][thread]: conflict-free), ONE barrier, then thread j adds the PL pixel lanes of entry j
+    // (channel j / 2, sum j & 1) in lane order -- the same order, hence the same bits, as the per-channel rounds this replaces (2 V barriers and a serial PL-long
+    // loop each: ~10 us at the end of every block, and every block of these one-round grids ends at the same time -- a quarter of a 45 us launch on the 80 x 80 maps)
+#pragma unroll
     for (int q = 0; q < V; ++q) {
-        red[tid * 2] = a0[q];
-        red[tid * 2 + 1] = a1[q];
-        __syncthreads();
-        if (pl == 0) {
-            double s0 = 0.0, s1 = 0.0;
-            for (int k = 0; k < PL; ++k) { s0 += red[(k * CG + cg) * 2]; s1 += red[(k * CG + cg) * 2 + 1]; }
-            double* part = sums + (size_t)(1 + blockIdx.x) * 2 * C;   // row 0 = totals, rows 1.. = per-block partials
-            part[(cg * V + q) * 2] = s0;
-            part[(cg * V + q) * 2 + 1] = s1;
-        }
-        __syncthreads();
+        red[(2 * q) * RP + tid] = a0[q];
+        red[(2 * q + 1) * RP + tid] = a1[q];
+    }
+    __syncthreads();
+    double* part = sums + (size_t)(1 + blockIdx.x) * 2 * C;   // row 0 = totals, rows 1.. = per-block partials
+    for (int j = tid; j < 2 * C; j += 256) {
+        const int c = j >> 1, cgj = c / V, q = c - cgj * V;
+        const double* src = red + (2 * q + (j & 1)) * RP + cgj;
+        double sacc = 0.0;
+        for (int k = 0; k < PL; ++k) sacc += src[k * CG];
+        part[j] = sacc;
     }
 }
 
