@@ -183,6 +183,37 @@ def test_conv_v10_ksplit_vs_fp32_reference(dev, dtype, name, shape, kw, slices, 
     _conv_tol_check(name, dtype, out, ref)
 
 
+# conv_1x1s.h ("s1x1"): persistent 1x1 kernel, filters in registers, a producer wave streaming the pixels through three fragment-ordered LDS stages.  Every
+# instantiation; pixel counts that end inside a stage, inside an epilogue pass and inside a column block; fewer stages than CUs and more; residual, no activation,
+# channel-slice output.  (knob conv_1x1s = 2: also below the pixel count where the dispatcher would pick it)
+S1X1_CASES = [
+    # name, (n,h,w,cin,cout,k,s), kwargs
+    ("k16_256_128_many_stages", (9, 80, 80, 256, 128, 1, 1), {}),                        # 900 stages of 64 pixels on 256 blocks: 3-4 per block
+    ("k16_ragged_res", (3, 37, 29, 256, 128, 1, 1), {"residual": True}),                # 3219 pixels: the last stage holds 19
+    ("k24_384_128_sliced_noact", (2, 40, 40, 384, 128, 1, 1), {"sliced": True, "act": False}),
+    ("k8_128_64_two_pixel_waves", (5, 33, 31, 128, 64, 1, 1), {"residual": True}),      # stages of 128 pixels, two waves along the pixels
+    ("k8_128_256_two_filter_groups", (4, 24, 24, 128, 256, 1, 1), {}),                  # a consumer wave multiplies the stage once per filter group
+    ("k4_64_128_four_passes", (2, 50, 50, 64, 128, 1, 1), {"act": False}),              # stages of 256 pixels: four epilogue passes per stage
+    ("k16_one_pixel", (1, 1, 1, 256, 128, 1, 1), {}),
+    ("k2_32_64_stages_of_512", (3, 40, 44, 32, 64, 1, 1), {"residual": True}),         # 5280 pixels: 10 stages and a third of one
+    ("k4_64_32_four_pixel_waves", (2, 36, 36, 64, 32, 1, 1), {}),
+    ("k16_256_255_head", (2, 30, 30, 256, 256, 1, 1), {"cout_real": 255, "act": False}),
+    ("k8_128_384_three_filter_groups", (2, 30, 30, 128, 384, 1, 1), {"residual": True, "act": False}),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name,shape,kw", S1X1_CASES, ids=[c[0] for c in S1X1_CASES])
+def test_conv_s1x1_vs_fp32_reference(dev, tune, dtype, name, shape, kw):
+    tune("conv_1x1s", 2)
+    out, ref = run_conv(dev, dtype, *shape, algo=1, expect="s1x1", repeat=2, **kw)
+    _conv_tol_check(name, dtype, out, ref)
+    # the same launch on the tile kernels: same products, another summation order
+    tune("conv_1x1s", 0)
+    out0, _ = run_conv(dev, dtype, *shape, algo=1, **kw)
+    assert (out - out0).abs().max().item() <= (2.0 ** -7 if dtype == torch.float16 else 2.0 ** -4) * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("shape", [(3, 40, 40, 256, 512, 3, 2), (4, 40, 40, 512, 256, 1, 1)], ids=["v6_3x3_s2", "v6_1x1"])
 def test_conv_request_depth_bit_identical(dev, tune, shape):
     """knob "conv_ahead": the LDS-DMA requests of the 256x256 kernel run 3 K-steps ahead of the MFMAs (default, round 3) or 2 (the
@@ -259,11 +290,13 @@ BASELINE_CONV_CASES = [
     ("L9_512_1024_s2", (32, 40, 40, 512, 1024, 3, 2), {}, "v6"),
     ("L8cv1_512_256_40", (32, 40, 40, 512, 256, 1, 1), {}, "v6"),
     ("L10cv1_1024_512_20", (32, 20, 20, 1024, 512, 1, 1), {}, "v3_bk64_128x128"),
-    ("L6cv1_256_128_80", (32, 80, 80, 256, 128, 1, 1), {}, "v3_bk32_128x128"),
+    ("L6cv1_256_128_80", (32, 80, 80, 256, 128, 1, 1), {}, "s1x1"),   # conv_1x1s.h (round 5): the HBM-bound 1x1 layers
     ("L4cv2_64_128_160", (32, 160, 160, 64, 128, 3, 1), {"residual": True}, "v3_bk32_128x256"),
     ("L3_64_128_s2_320", (32, 320, 320, 64, 128, 3, 2), {}, "strip"),   # conv_strip.h, stride-2 form (round 3)
     ("head255_20", (32, 20, 20, 1024, 256, 1, 1), {"cout_real": 255, "act": False}, "v3_bk64_128x128"),
-    ("head255_80", (32, 80, 80, 256, 256, 1, 1), {"cout_real": 255, "act": False}, "v3_bk32_128x128"),
+    ("head255_80", (32, 80, 80, 256, 256, 1, 1), {"cout_real": 255, "act": False}, "s1x1"),
+    ("L26cv1_384_128_80", (32, 80, 80, 384, 128, 1, 1), {}, "s1x1"),
+    ("L4cv1_128_64_160", (32, 160, 160, 128, 64, 1, 1), {}, "s1x1"),
     ("head1110_40_c5", (8, 40, 40, 1024, 1112, 1, 1), {"cout_real": 1110, "act": False}, None),
     ("c5_128_256_160", (8, 160, 160, 128, 256, 3, 1), {"residual": True}, "v10"),
     ("c5_256_512_80", (8, 80, 80, 256, 512, 3, 1), {"residual": True}, "v10h"),
@@ -1514,17 +1547,23 @@ STAT_CASES = [
     ("v2_small_cin", (1, 20, 20, 16, 32, 3, 1)),
     ("cout_not_tile_multiple", (2, 24, 24, 64, 200, 3, 1)),
     ("many_rows_two_level_sum", (8, 96, 96, 32, 64, 3, 1)),   # 576 rows > 512: first-level sums into the fp64 partial rows
+    ("s1x1_k16", (3, 37, 29, 256, 128, 1, 1)),                 # conv_1x1s.h (forced: knob conv_1x1s = 2): one row per (stage, pixel wave, epilogue pass), ragged last stage
+    ("s1x1_two_filter_groups", (2, 30, 30, 128, 256, 1, 1)),
+    ("s1x1_two_pixel_waves", (2, 33, 31, 128, 64, 1, 1)),
+    ("s1x1_four_passes", (1, 50, 50, 64, 128, 1, 1)),
 ]
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("name,shape", STAT_CASES, ids=[c[0] for c in STAT_CASES])
-def test_conv_epilogue_bn_statistics(dev, dtype, name, shape):
+def test_conv_epilogue_bn_statistics(dev, tune, dtype, name, shape):
     """y3_conv2d_fwd_stats: same output as y3_conv2d_fwd (bit-exact) and per-(tile, wave) rows whose fp64 sum equals the
     per-channel (sum, sum of squares) of the STORED output (1e-5 relative: fp32 partial sums over <= 128 pixels), for every
     tile variant incl. ragged pixel / filter tiles; then y3_bn_finalize_rows against nn.BatchNorm2d's batch statistics."""
     _lib, ops = _ops()
     n, h, w, cin, cout, k, s = shape
+    if name.startswith("s1x1"):
+        tune("conv_1x1s", 2)
     g = torch.Generator().manual_seed(4)
     x = torch.randn(n, cin, h, w, generator=g).to(dtype)
     wt = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
@@ -1535,6 +1574,7 @@ def test_conv_epilogue_bn_statistics(dev, dtype, name, shape):
     zb = torch.zeros(cout, device=dev)
     y0 = ops.View.alloc(n, ho, wo, cout, dtype, dev)
     ops.conv2d(xv, filt, zb, y0, k, s, act=False)
+    assert (ops.last_conv_variant() == "s1x1") == name.startswith("s1x1"), ops.last_conv_variant()
     y1 = ops.View.alloc(n, ho, wo, cout, dtype, dev)
     rows = ops.conv2d_stats_rows(xv, y1, k, s)
     buf = torch.full((rows * 2 * cout,), float("nan"), device=dev)

@@ -335,7 +335,7 @@ def test_conv_dispatch_variant_names_and_stat_rows():
     assert ws == 64 + 4096 + 2 * 256 * 256 * 256 * 4
     # (pixels per tile, statistics rows per tile); v10 cuts the pixel axis into 32-pixel column blocks and a block's run of them into tiles of 6 / 7 / 8 (conv_v10.h)
     tile_px = {"v6": (256, 2), "v3_bk64_128x128": (128, 2), "v3_bk32_128x128": (128, 2), "v3_bk32_128x256": (256, 2), "v3_bk32_64x256": (256, 2),
-               "v10": (0, 4), "v10h": (0, 4), "strip": (0, 0)}
+               "v10": (0, 4), "v10h": (0, 4), "strip": (0, 0), "s1x1": (64, 1)}   # s1x1 (conv_1x1s.h): one row per epilogue pass of 64 pixels (whole stages here)
     shapes = [(32, 64, 3, 2, 640), (64, 32, 1, 1, 320), (32, 64, 3, 1, 320), (64, 128, 3, 2, 320), (128, 64, 1, 1, 160), (64, 128, 3, 1, 160), (128, 256, 3, 2, 160),
               (256, 128, 1, 1, 80), (128, 256, 3, 1, 80), (256, 512, 3, 2, 80), (512, 256, 1, 1, 40), (256, 512, 3, 1, 40), (512, 1024, 3, 2, 40), (1024, 512, 1, 1, 20),
               (512, 1024, 3, 1, 20), (768, 256, 1, 1, 40), (384, 128, 1, 1, 80), (256, 256, 1, 1, 80), (512, 256, 1, 1, 20)]
@@ -353,6 +353,8 @@ def test_conv_dispatch_variant_names_and_stat_rows():
             assert L.y3_conv2d_fwd_variant(C.byref(d), C.byref(x), C.byref(y), 0, 0, name, 64) == 0, L.y3_last_error()
             plain = name.value.decode()
             assert plain in tile_px, plain
+            # the HBM-bound 1x1 layers (Cin <= 384 at >= 32768 pixels): the persistent kernel with register-resident filters
+            assert (plain == "s1x1") == (k == 1 and cin <= 384), (cin, cout, k, s, hin, plain)
             assert (plain in ("v10", "v10h")) == ((cin, cout, k, s, hin) in v10_shapes) and (plain == "v10h") == ((cin, cout, k, s, hin) in v10_shapes and cin <= 256), (cin, cout, k, s, hin, plain)
             rows = L.y3_conv2d_fwd_stats_rows(C.byref(d), C.byref(x), C.byref(y))
             assert rows > 0, L.y3_last_error()

@@ -43,6 +43,13 @@ SHAPES = [
     ("T L4.cv2 64->128 @160", 160, 160, 64, 128, 3, 1, False),
     ("T L4.cv2 dgrad 128->64 @160", 160, 160, 128, 64, 3, 1, False),
     ("T L3 64->128 s2 @320", 320, 320, 64, 128, 3, 2, False),
+    # data gradients of the Bottleneck.cv1 layers (1x1, the shortcut's gradient as the residual operand)
+    ("T L6.cv1 dgrad 128->256 @80", 80, 80, 128, 256, 1, 1, True),
+    ("T L4.cv1 dgrad 64->128 @160", 160, 160, 64, 128, 1, 1, True),
+    ("T L2.cv1 64->32 @320", 320, 320, 64, 32, 1, 1, False),
+    ("T L2.cv1 dgrad 32->64 @320", 320, 320, 32, 64, 1, 1, True),
+    ("head 256->256 @80", 80, 80, 256, 256, 1, 1, False),
+    ("T L26.cv1 dgrad 128->384 @80", 80, 80, 128, 384, 1, 1, False),
 ]
 
 

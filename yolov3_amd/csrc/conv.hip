@@ -167,8 +167,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // squares of the lane's 8 filters) instead of being written; epilogue_stats_flush writes ONE row for all the calls.
 // IDENT (conv_v10.h: stride 1, no upsample scatter, no parity-class output): the output pixel index IS the GEMM column m, so the lane's store offsets are plain
 // arithmetic on m -- no (image, row, column) decomposition, no 64-bit products, no ds_bpermute from the MFMA layout to the store layout.
-template <typename T, int MC, int MP, bool STAT_ACC = false, bool IDENT = false>
-Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MP], unsigned char* wl, int c_base, int m_base, int lane, int stat_row = -1, int m_end = 0x7fffffff,
+// MPA, BOFF (conv_1x1s.h): the call covers column blocks BOFF .. BOFF + MP - 1 of the caller's MPA accumulator tiles, read in place (no per-pass copy).
+template <typename T, int MC, int MP, bool STAT_ACC = false, bool IDENT = false, int MPA = MP, int BOFF = 0>
+Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MPA], unsigned char* wl, int c_base, int m_base, int lane, int stat_row = -1, int m_end = 0x7fffffff,
                           float* sacc = nullptr) {
     typedef typename Mfma<T>::frag vec8;   // 8 x T = one 16-byte chunk
     constexpr int CH = MC * 4;          // 16-byte chunks per pixel row of this wave's slice
@@ -239,7 +240,7 @@ Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MP], unsigned cha
                 for (int gp = 0; gp < 2; ++gp) {
                     f32x8 v;   // filters 16gp + 4fk + (0..3) and 16gp + 8 + 4fk + (0..3)
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] = acc[a][b][8 * gp + q];
+                    for (int q = 0; q < 8; ++q) v[q] = acc[a][BOFF + b][8 * gp + q];
                     if (decltype(silu)::value) silu_vec<f32x8, 8>(v);
                     u32x4 ov;
 #pragma unroll
@@ -1032,6 +1033,7 @@ template <int N, typename F> Y3_DEV void static_for(F&& f) { static_for_impl(f, 
 
 #include "conv_v10.h"
 #include "conv_strip.h"
+#include "conv_1x1s.h"
 
 template <typename T> int dispatch_igemm(ConvArgs& a, hipStream_t st) {
     const bool c64 = (a.Cin % 64) == 0, c32 = (a.Cin % 32) == 0;
@@ -1041,6 +1043,10 @@ template <typename T> int dispatch_igemm(ConvArgs& a, hipStream_t st) {
     {
         CsPlan cs;
         if (var == 3 && cs_plan(a, cs)) return launch_cs<T>(a, st);
+    }
+    {
+        S1Plan s1;
+        if (var == 3 && s1_plan(a, s1)) return launch_s1<T>(a, s1, st);   // HBM-bound 1x1 layers: persistent blocks, filters in registers (conv_1x1s.h)
     }
     if (var == 3 && y3_knob(Y3K_V10_KSPLIT) == 2 && v10k_eligible(a)) return launch_v10k<T>(a, st);   // (tests: the K-split form on any eligible launch)
     if (var == 3 && v10_eligible(a)) return launch_v10<T>(a, st);

@@ -1,0 +1,191 @@
+// conv_1x1s.h -- included by conv.hip INSIDE its anonymous namespace (shares ConvArgs, Mfma, epilogue_wave, IC / static_for, ...).
+//
+// "s1x1": the HBM-bound 1x1 / stride-1 convolutions (reference models/common.py:150-165 Bottleneck.cv1 on the 80 x 80 / 160 x 160 maps and their data gradients:
+// 256 -> 128, 384 -> 128, 128 -> 64, 128 -> 256, 64 -> 128).  Per pixel they read Cin and write Cout values and multiply almost nothing: the tile kernels run them at
+// 4.0-4.3 TB/s (profiles/r05_conv_lab_1x1.txt) because every 128 x 128 tile fetches its filter tile again -- as many bytes through the LDS-DMA path as the pixels
+// themselves -- and pays a prologue (first stage exposed) and two barriers per K-step for a K loop of 4-8 steps.  Here:
+//   * PERSISTENT blocks (one per CU), the whole filter matrix of the layer in REGISTERS: a consumer wave holds its FG groups of 32 filters for all K (FG x K/16 MFMA A
+//     fragments, loaded once per block) and multiplies a stage's pixels once per group;
+//   * the pixel operand streams through a ring of three LDS stages laid out in fragment order ([32-pixel column block][16-channel K-step][lane]: 1 KiB per LDS-DMA
+//     instruction, a consumer's B fragment is one conflict-free ds_read_b128);
+//   * a fifth PRODUCER wave issues every LDS-DMA request of the block and does nothing else, so its vmcnt counts requests only: `s_waitcnt vmcnt(requests of one
+//     stage)` = "the stage before the youngest has landed" -- two stages (64 KiB at Cin = 256) in flight per CU at all times, one barrier per stage;
+//   * the epilogue is epilogue_wave's (bias in the accumulator, SiLU, residual, statistics rows, channel-slice stores) on passes of two column blocks.
+// Geometry per (FG, WC, KS): WC consumer waves along the filters (WC * FG * 32 = Cout), 4 / WC along the pixels; KS = Cin / 16 K-steps; a stage holds as many
+// 32-pixel column blocks as make 32 (48 at KS = 24) requests.
+
+template <int FG_, int WC_, int KS_> struct S1Geom {
+    static constexpr int FG = FG_, WC = WC_, KS = KS_;
+    static constexpr int WP = 4 / WC;                       // consumer waves along the pixel axis
+    static constexpr int TC = WC * FG * 32;                 // filters per block = Cout
+    static constexpr int IS = KS == 24 ? 48 : 32;           // LDS-DMA requests (1 KiB each) per stage
+    static constexpr int CB = IS / KS;                      // 32-pixel column blocks per stage
+    static constexpr int SP = CB * 32;                      // pixels per stage
+    static constexpr int MP = CB / WP;                      // column blocks per consumer wave and stage
+    static constexpr int NPASS = (MP + 1) / 2;              // epilogue passes (two column blocks each)
+    static constexpr int STAGE = IS * 1024;
+    static constexpr int NS = 3;
+    static constexpr int SLICE_BYTES = 2 * 32 * 64;         // one epilogue pass of a wave: 64 pixels x 32 filters
+    static constexpr int SLICE = NS * STAGE;
+    static constexpr int LDS = SLICE + 4 * SLICE_BYTES;
+    static_assert(CB * KS == IS && MP * WP == CB && MP >= 2 && MP % 2 == 0, "whole column blocks per wave, two per epilogue pass");
+    static_assert(LDS <= 163840, "the LDS of a CU");
+};
+
+template <int N> Y3_DEV void s1_wait_vm() { __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14)); }   // (conv_v10.h::v10_wait_vm)
+
+template <typename T, int FG, int WC, int KS>
+__global__ __launch_bounds__(320, 1) void conv_1x1s_kernel(const ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef S1Geom<FG, WC, KS> G;
+    typedef typename Mfma<T>::frag frag;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[G::LDS];   // the ONLY LDS object
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..3 consumers, 4 the producer
+    const int nb = (int)gridDim.x, b = (int)blockIdx.x;
+    const int n_stages = p.n_pt;
+    const int my = (n_stages - b + nb - 1) / nb;   // this block's stages: b, b + nb, ...  (host: nb <= n_stages)
+
+    if (wv == 4) {
+        // ---- producer: lane (pixel lane & 31, channel half lane >> 5) of request (column block cb, K-step ks) fetches 8 channels 16 ks + 8 (lane >> 5) .. of pixel
+        // 32 cb + (lane & 31) of the stage; the request lands as the 1 KiB the consumers read as ONE B fragment per lane
+        const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+        constexpr unsigned OOB = 0x80000000u;   // stays out of range when the K-step offset is added: the piece lands as zeros
+        const int pl = lane & 31, fk = lane >> 5;
+        auto issue = [&](int j) {
+            const int m0 = (b + j * nb) * G::SP;
+            unsigned char* dst = smem + (j % G::NS) * G::STAGE;
+#pragma unroll
+            for (int cb = 0; cb < G::CB; ++cb) {
+                const int m = m0 + cb * 32 + pl;
+                const unsigned vo = (j < my && m < p.M) ? (unsigned)((m * p.xpitch + fk * 8) * 2) : OOB;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(dst + (cb * KS + ks) * 1024), 16, vo, ks * 32, 0, 0);
+            }
+        };
+        issue(0);
+        issue(1);
+        for (int j = 0; j < my; ++j) {
+            s1_wait_vm<G::IS>();              // only the requests of stage j + 1 are younger than stage j's: stage j has landed
+            __builtin_amdgcn_s_barrier();     // ... and is published; every consumer is done with stage j - 1, whose slot stage j + 2 takes
+            issue(j + 2);                     // (beyond the block's last stage: out-of-range requests, so that the count above stays exact)
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of this wave is in flight into an LDS that the next workgroup may own
+        return;
+    }
+
+    // ---- consumers
+    const int wc = wv / G::WP, wp = wv % G::WP;
+    const int frow = lane & 31, fk = lane >> 5;
+    const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+    frag Wr[FG][KS];   // the wave's filters for all K: row (wc FG + fg) 32 + frow, channels 16 ks + 8 fk ..
+#pragma unroll
+    for (int fg = 0; fg < FG; ++fg)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const unsigned off = (unsigned)((((wc * FG + fg) * 32 + frow) * p.Kpad + ks * 16 + fk * 8) * 2);
+            Wr[fg][ks] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, off, 0, 0));
+        }
+    f32x4 bz[FG][4];   // the accumulators start at the bias of their filter (lane holds filters 8 g + 4 fk + q of each 32-filter group)
+#pragma unroll
+    for (int fg = 0; fg < FG; ++fg)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bz[fg][g] = *(const f32x4*)(p.bias + (wc * FG + fg) * 32 + 8 * g + 4 * fk);
+    unsigned char* slice = smem + G::SLICE + wv * G::SLICE_BYTES;
+
+    for (int j = 0; j < my; ++j) {
+        __builtin_amdgcn_s_barrier();   // stage j has landed for every wave
+        const unsigned char* st = smem + (j % G::NS) * G::STAGE + (wp * G::MP) * KS * 1024 + lane * 16;
+        const int s = b + j * nb;
+        const int m_wave = s * G::SP + wp * G::MP * 32;
+        // two column blocks and one filter group at a time: multiply, then the epilogue pass of those 64 pixels x 32 filters (32 accumulator registers live)
+        static_for<G::NPASS * FG>([&](auto IT) {
+            constexpr int hb = decltype(IT)::value / FG, fg = decltype(IT)::value % FG;
+            f32x16 acc[1][2];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[0][cb][4 * g + q] = bz[fg][g][q];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const frag B = *(const frag*)(st + ((2 * hb + cb) * KS + ks) * 1024);
+                    acc[0][cb] = Mfma<T>::run(Wr[fg][ks], B, acc[0][cb]);
+                }
+            epilogue_wave<T, 1, 2, false, true>(p, acc, slice, (wc * FG + fg) * 32, m_wave + hb * 64, lane, (s * G::WP + wp) * G::NPASS + hb, p.M);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();   // the slice is private to the wave: the reads of one pass precede the writes of the next
+        });
+    }
+#endif
+}
+
+// the (filter groups per wave, waves along the filters, K-steps) form of a layer, or false: not one of the HBM-bound 1x1 shapes
+struct S1Plan {
+    int fg, wc, ks, sp, wp, npass;
+};
+static bool s1_plan(const ConvArgs& a, S1Plan& pl) {
+    const long long mode = y3_knob(Y3K_CONV_1X1S);
+    if (mode == 0 || a.ups || a.dil_shift) return false;
+    if (a.ks != 1 || a.ntaps != 1 || a.stride != 1 || a.pad != 0 || a.tdh[0] != 0 || a.tdw[0] != 0) return false;
+    if (a.omul != 1 || a.ooh != 0 || a.oow != 0 || a.H != a.Ho || a.W != a.Wo || a.oH != a.Ho || a.oW != a.Wo) return false;
+    if (!a.x_bytes || !a.w_bytes || !a.y_bytes || (a.res && !a.r_bytes) || !a.bias) return false;
+    if (a.M < 32768 && mode != 2) return false;   // below that the launch is latency-bound and the tile kernels' many small blocks win
+    // WC consumer waves along the filters x FG groups of 32 filters per wave = Cout; the shapes of yolov3's Bottleneck.cv1 layers on the 80 x 80 ... 320 x 320 maps, their
+    // data gradients, the 80 x 80 Detect conv (255 -> 256 filters) and the cv1 after the second Concat (384 -> 128)
+    int fg, wc;
+    switch (a.Cout) {
+        case 32: fg = 1; wc = 1; break;
+        case 64: fg = 1; wc = 2; break;
+        case 128: fg = 1; wc = 4; break;
+        case 256: fg = 2; wc = 4; break;
+        case 384: fg = 3; wc = 4; break;
+        default: return false;
+    }
+    if (a.Cin != 32 && a.Cin != 64 && a.Cin != 128 && a.Cin != 256 && a.Cin != 384) return false;
+    {   // the instantiations that exist (launch_s1)
+        const int k = a.Cin / 16;
+        const bool ok = (fg == 1 && wc == 4 && (k == 4 || k == 16 || k == 24)) || (fg == 1 && wc == 2 && (k == 2 || k == 8)) || (fg == 1 && wc == 1 && k == 4) ||
+                        (fg == 2 && wc == 4 && (k == 8 || k == 16)) || (fg == 3 && wc == 4 && k == 8);
+        if (!ok) return false;
+    }
+    const int ks = a.Cin / 16;
+    const int is = ks == 24 ? 48 : 32;
+    pl.fg = fg; pl.wc = wc; pl.ks = ks;
+    pl.sp = is / ks * 32;
+    pl.wp = 4 / wc;
+    pl.npass = (is / ks / pl.wp + 1) / 2;
+    return true;
+}
+
+template <typename T> int launch_s1(ConvArgs& a, const S1Plan& pl, hipStream_t st) {
+    a.n_ct = 1;
+    a.n_pt = y3_ceil_div(a.M, pl.sp);          // stages
+    a.stat_wp = pl.wp * pl.npass;              // statistics rows per stage: one per (pixel wave, epilogue pass)
+    set_divisors(a);
+    g_last_variant = "s1x1";
+    if (a.dry) return 0;
+    const int cus = y3_cu_count();
+    const dim3 grid((unsigned)(a.n_pt < cus ? a.n_pt : cus)), block(320);
+#define Y3_S1_CASE(FG, WC, KS) if (pl.fg == FG && pl.wc == WC && pl.ks == KS) hipLaunchKernelGGL((conv_1x1s_kernel<T, FG, WC, KS>), grid, block, 0, st, a)
+    Y3_S1_CASE(1, 4, 16);        // 256 -> 128
+    else Y3_S1_CASE(1, 4, 24);   // 384 -> 128
+    else Y3_S1_CASE(1, 4, 4);    //  64 -> 128
+    else Y3_S1_CASE(1, 2, 8);    // 128 ->  64
+    else Y3_S1_CASE(1, 2, 2);    //  32 ->  64
+    else Y3_S1_CASE(1, 1, 4);    //  64 ->  32
+    else Y3_S1_CASE(2, 4, 8);    // 128 -> 256
+    else Y3_S1_CASE(2, 4, 16);   // 256 -> 256 (the 80 x 80 Detect conv and its data gradient)
+    else Y3_S1_CASE(3, 4, 8);    // 128 -> 384
+#undef Y3_S1_CASE
+    else Y3_FAIL("conv s1x1: no instantiation (internal)");
+    Y3_CHECK_LAUNCH();
+    return 0;
+}
