@@ -66,7 +66,7 @@ const char* y3_last_error(void);
  * torch.backends.cudnn.benchmark and friends).  Defaults are the measured-best settings.  Keys: "conv" (0 per-shape dispatch, 2 / 4 / 5 /
  * 6 / 15 force a tile variant), "conv_ahead" (3 / 2: K-steps the LDS-DMA requests run ahead), "bn_nt_bytes" (threshold of
  * the non-temporal BatchNorm passes), "wgrad" (0 per-shape, 2 128-tile, 3 256-tile, 4 direct fp32), "wgrad_xcd" (0..3), "dgrad_quad"
- * (1 / 0), "spp_direct" (0 / 1), "conv_v10" (1 auto, 0 off, 2 every eligible shape), "v10_mp" / "v10_blocks" (0 auto; widest wave tile / blocks per filter tile of csrc/conv_v10.h: tests), "v10_half" (2 auto, 0 one block per CU, 1 two half-size blocks per CU), "v10_ksplit" (1 small launches with a workspace, 0 never, 2 every eligible launch) / "v10_slices" (0 auto; forced slice count: tests), "v10_group" (1 the blocks of a filter tile on one XCD take the tiles of their common pixel range round-robin, 0 contiguous runs), "tile_xcd" (1 XCD-grouped tile ids in the persistent tile loops of csrc/stem.hip, 0 dispatch order), "wgrad_strip" / "conv_strip" (1 the strip-walking kernels of csrc/wgrad_strip.h / conv_strip.h on the
+ * (1 / 0), "spp_direct" (0 / 1), "conv_v10" (1 auto, 0 off, 2 every eligible shape), "v10_mp" / "v10_blocks" (0 auto; widest wave tile / blocks per filter tile of csrc/conv_v10.h: tests), "v10_half" (2 auto, 0 one block per CU, 1 two half-size blocks per CU), "v10_ksplit" (1 small launches with a workspace, 0 never, 2 every eligible launch) / "v10_slices" (0 auto; forced slice count: tests), "v10_group" (1 the blocks of a filter tile on one XCD take the tiles of their common pixel range round-robin, 0 contiguous runs), "tile_xcd" (1 XCD-grouped tile ids in the persistent tile loops of csrc/stem.hip, 0 dispatch order), "conv_1x1s" (1 the persistent 1x1 kernel with register-resident filters of csrc/conv_1x1s.h on the HBM-bound 1x1 layers, 0 the tile kernels, 2 also small launches), "wgrad_strip" / "conv_strip" (1 the strip-walking kernels of csrc/wgrad_strip.h / conv_strip.h on the
  * small-channel 3x3 layers, 0 off, 2 also small launches, N > 2: N rows per block -- tests).  The environment variable Y3_TUNE="key=value,key=value" is read once when the library is first used.
  * Process-wide, not stream-ordered: set a knob before enqueueing the launches it should affect. */
 int y3_tune_set(const char* key, int64_t value); /* 0, or -1 for an unknown key */
@@ -95,7 +95,7 @@ size_t y3_conv_workspace_bytes(void);
 int y3_conv2d_fwd_ws(const y3_conv_desc* desc, const y3_tensor* x, const void* packed_filter, const float* bias,
                      const y3_tensor* residual /* may be NULL */, const y3_tensor* y, void* workspace, size_t workspace_bytes,
                      void* stream);
-/* Which kernel variant the dispatcher picks for this problem ("v10", "v10h", "v10k", "v6", "v3_bk64_128x128", "strip", ..., "direct"); launches nothing.
+/* Which kernel variant the dispatcher picks for this problem ("v10", "v10h", "v10k", "s1x1", "v6", "v3_bk64_128x128", "strip", ..., "direct"); launches nothing.
  * The parity tests assert it so that a tolerance is always attached to the kernel that actually ran. */
 int y3_conv2d_fwd_variant(const y3_conv_desc* desc, const y3_tensor* x, const y3_tensor* y, int32_t has_residual,
                           size_t workspace_bytes, char* name, size_t name_capacity);
