@@ -12,7 +12,7 @@ import sys
 FAMILIES = [
     ("wgrad (filter gradients)", r"wgrad"),
     ("bn / activation passes", r"bn_act|channel_reduce|reduce_partials|bn_finalize|bn_stats"),
-    ("conv forward + data gradient (implicit GEMM)", r"conv_igemm|conv_strip|stem_conv|stem_pair|bneck_pair|conv_direct"),
+    ("conv forward + data gradient (implicit GEMM)", r"conv_igemm|conv_1x1s|conv_strip|stem_conv|stem_pair|bneck_pair|conv_direct|conv_v10_reduce"),
     ("filter packing", r"pack_filter|pack_dgrad"),
     ("loss", r"loss_"),
     ("optimizer (fused SGD / clip / EMA)", r"sgd|grad_norm|clip_coef"),

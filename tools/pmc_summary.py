@@ -22,6 +22,7 @@ NAMES = [  # (regex on the kernel symbol, bench.py name = "conv_igemm_" + the li
     (r"conv_igemm_v3_kernelIDF16_Li32ELi2ELi2E", "conv_igemm_v3_bk32_128x128"),
     (r"conv_igemm_v3_kernelIDF16_Li32ELi1ELi4E", "conv_igemm_v3_bk32_64x256"),
     (r"conv_igemm_v2_kernelIDF16_Li32ELi1ELi4ELi1ELi2ELb1E", "conv_igemm_v2_smallc"),
+    (r"conv_1x1s_kernelIDF16_", "conv_igemm_s1x1"),     # conv_1x1s.h (round 5): every instantiation of the persistent 1x1 kernel
     (r"stem_pair_kernel", "stem_pair"),
     (r"bneck_pair_kernel", "bneck_pair"),
     (r"stem_conv_kernel", "stem_conv"),
