@@ -199,6 +199,8 @@ S1X1_CASES = [
     ("k4_64_32_four_pixel_waves", (2, 36, 36, 64, 32, 1, 1), {}),
     ("k16_256_255_head", (2, 30, 30, 256, 256, 1, 1), {"cout_real": 255, "act": False}),
     ("k8_128_384_three_filter_groups", (2, 30, 30, 128, 384, 1, 1), {"residual": True, "act": False}),
+    ("k16_256_512_two_tiles_two_groups", (3, 40, 40, 256, 512, 1, 1), {"residual": True, "act": False}),
+    ("k16_256_768_three_tiles", (2, 20, 20, 256, 768, 1, 1), {"act": False}),
 ]
 
 
@@ -1551,6 +1553,7 @@ STAT_CASES = [
     ("s1x1_two_filter_groups", (2, 30, 30, 128, 256, 1, 1)),
     ("s1x1_two_pixel_waves", (2, 33, 31, 128, 64, 1, 1)),
     ("s1x1_four_passes", (1, 50, 50, 64, 128, 1, 1)),
+    ("s1x1_two_filter_tiles", (2, 33, 31, 256, 512, 1, 1)),     # 256 filters per block, the two blocks of a pixel range write the two halves of a row
 ]
 
 

@@ -50,6 +50,7 @@ SHAPES = [
     ("T L2.cv1 dgrad 32->64 @320", 320, 320, 32, 64, 1, 1, True),
     ("head 256->256 @80", 80, 80, 256, 256, 1, 1, False),
     ("T L26.cv1 dgrad 128->384 @80", 80, 80, 128, 384, 1, 1, False),
+    ("T L8.cv1 dgrad 256->512 @40", 40, 40, 256, 512, 1, 1, True),
 ]
 
 

@@ -22,13 +22,14 @@ template <int FG_, int WC_, int KS_> struct S1Geom {
     static constexpr int CB = IS / KS;                      // 32-pixel column blocks per stage
     static constexpr int SP = CB * 32;                      // pixels per stage
     static constexpr int MP = CB / WP;                      // column blocks per consumer wave and stage
-    static constexpr int NPASS = (MP + 1) / 2;              // epilogue passes (two column blocks each)
+    static constexpr int PB = MP >= 2 ? 2 : 1;              // column blocks per epilogue pass
+    static constexpr int NPASS = MP / PB;                   // epilogue passes per stage and wave
     static constexpr int STAGE = IS * 1024;
     static constexpr int NS = 3;
-    static constexpr int SLICE_BYTES = 2 * 32 * 64;         // one epilogue pass of a wave: 64 pixels x 32 filters
+    static constexpr int SLICE_BYTES = PB * 32 * 64;        // one epilogue pass of a wave: PB * 32 pixels x 32 filters
     static constexpr int SLICE = NS * STAGE;
     static constexpr int LDS = SLICE + 4 * SLICE_BYTES;
-    static_assert(CB * KS == IS && MP * WP == CB && MP >= 2 && MP % 2 == 0, "whole column blocks per wave, two per epilogue pass");
+    static_assert(CB * KS == IS && MP * WP == CB && MP >= 1 && MP % PB == 0, "whole column blocks per wave, whole passes");
     static_assert(LDS <= 163840, "the LDS of a CU");
 };
 
@@ -45,9 +46,12 @@ __global__ __launch_bounds__(320, 1) void conv_1x1s_kernel(const ConvArgs p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..3 consumers, 4 the producer
-    const int nb = (int)gridDim.x, b = (int)blockIdx.x;
+    // filter tile ct (n_ct > 1: Cout beyond what four waves keep in registers -- the blocks of one pixel range sit next to each other in the XCD-grouped id order, so the
+    // second .. n_ct-th read of a stage's pixels meets the first in that XCD's L2) and slot b of nb: the block's stages are b, b + nb, ...
+    const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int nb = (int)gridDim.x / p.n_ct, ct = lid % p.n_ct, b = lid / p.n_ct;
     const int n_stages = p.n_pt;
-    const int my = (n_stages - b + nb - 1) / nb;   // this block's stages: b, b + nb, ...  (host: nb <= n_stages)
+    const int my = (n_stages - b + nb - 1) / nb;   // (host: nb <= n_stages)
 
     if (wv == 4) {
         // ---- producer: lane (pixel lane & 31, channel half lane >> 5) of request (column block cb, K-step ks) fetches 8 channels 16 ks + 8 (lane >> 5) .. of pixel
@@ -87,14 +91,14 @@ __global__ __launch_bounds__(320, 1) void conv_1x1s_kernel(const ConvArgs p) {
     for (int fg = 0; fg < FG; ++fg)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const unsigned off = (unsigned)((((wc * FG + fg) * 32 + frow) * p.Kpad + ks * 16 + fk * 8) * 2);
+            const unsigned off = (unsigned)(((ct * G::TC + (wc * FG + fg) * 32 + frow) * p.Kpad + ks * 16 + fk * 8) * 2);
             Wr[fg][ks] = __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, off, 0, 0));
         }
     f32x4 bz[FG][4];   // the accumulators start at the bias of their filter (lane holds filters 8 g + 4 fk + q of each 32-filter group)
 #pragma unroll
     for (int fg = 0; fg < FG; ++fg)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) bz[fg][g] = *(const f32x4*)(p.bias + (wc * FG + fg) * 32 + 8 * g + 4 * fk);
+        for (int g = 0; g < 4; ++g) bz[fg][g] = *(const f32x4*)(p.bias + ct * G::TC + (wc * FG + fg) * 32 + 8 * g + 4 * fk);
     unsigned char* slice = smem + G::SLICE + wv * G::SLICE_BYTES;
 
     for (int j = 0; j < my; ++j) {
@@ -102,24 +106,24 @@ __global__ __launch_bounds__(320, 1) void conv_1x1s_kernel(const ConvArgs p) {
         const unsigned char* st = smem + (j % G::NS) * G::STAGE + (wp * G::MP) * KS * 1024 + lane * 16;
         const int s = b + j * nb;
         const int m_wave = s * G::SP + wp * G::MP * 32;
-        // two column blocks and one filter group at a time: multiply, then the epilogue pass of those 64 pixels x 32 filters (32 accumulator registers live)
+        // one epilogue pass (PB column blocks) and one filter group at a time: multiply, then hand the 32 x PB * 32 tile to the epilogue (16 PB accumulator registers live)
         static_for<G::NPASS * FG>([&](auto IT) {
             constexpr int hb = decltype(IT)::value / FG, fg = decltype(IT)::value % FG;
-            f32x16 acc[1][2];
+            f32x16 acc[1][G::PB];
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
+            for (int cb = 0; cb < G::PB; ++cb)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc[0][cb][4 * g + q] = bz[fg][g][q];
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
+            for (int cb = 0; cb < G::PB; ++cb)
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    const frag B = *(const frag*)(st + ((2 * hb + cb) * KS + ks) * 1024);
+                    const frag B = *(const frag*)(st + ((G::PB * hb + cb) * KS + ks) * 1024);
                     acc[0][cb] = Mfma<T>::run(Wr[fg][ks], B, acc[0][cb]);
                 }
-            epilogue_wave<T, 1, 2, false, true>(p, acc, slice, (wc * FG + fg) * 32, m_wave + hb * 64, lane, (s * G::WP + wp) * G::NPASS + hb, p.M);
+            epilogue_wave<T, 1, G::PB, false, true>(p, acc, slice, ct * G::TC + (wc * FG + fg) * 32, m_wave + hb * G::PB * 32, lane, (s * G::WP + wp) * G::NPASS + hb, p.M);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();   // the slice is private to the wave: the reads of one pass precede the writes of the next
         });
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(320, 1) void conv_1x1s_kernel(const ConvArgs p) {
 
 // the (filter groups per wave, waves along the filters, K-steps) form of a layer, or false: not one of the HBM-bound 1x1 shapes
 struct S1Plan {
-    int fg, wc, ks, sp, wp, npass;
+    int fg, wc, ks, sp, wp, npass, n_ct;
 };
 static bool s1_plan(const ConvArgs& a, S1Plan& pl) {
     const long long mode = y3_knob(Y3K_CONV_1X1S);
@@ -138,42 +142,54 @@ static bool s1_plan(const ConvArgs& a, S1Plan& pl) {
     if (a.omul != 1 || a.ooh != 0 || a.oow != 0 || a.H != a.Ho || a.W != a.Wo || a.oH != a.Ho || a.oW != a.Wo) return false;
     if (!a.x_bytes || !a.w_bytes || !a.y_bytes || (a.res && !a.r_bytes) || !a.bias) return false;
     if (a.M < 32768 && mode != 2) return false;   // below that the launch is latency-bound and the tile kernels' many small blocks win
-    // WC consumer waves along the filters x FG groups of 32 filters per wave = Cout; the shapes of yolov3's Bottleneck.cv1 layers on the 80 x 80 ... 320 x 320 maps, their
-    // data gradients, the 80 x 80 Detect conv (255 -> 256 filters) and the cv1 after the second Concat (384 -> 128)
-    int fg, wc;
-    switch (a.Cout) {
-        case 32: fg = 1; wc = 1; break;
-        case 64: fg = 1; wc = 2; break;
-        case 128: fg = 1; wc = 4; break;
-        case 256: fg = 2; wc = 4; break;
-        case 384: fg = 3; wc = 4; break;
-        default: return false;
+    // WC consumer waves along the filters x FG groups of 32 filters per wave = the filters of a block; n_ct blocks side by side where Cout is more than a block keeps in
+    // registers.  The shapes of yolov3's Bottleneck.cv1 layers on the 40 x 40 ... 320 x 320 maps, their data gradients, the 80 x 80 Detect conv (255 -> 256 filters) and the
+    // cv1 layers behind the two Concats.  Cin = 512 (the 40 x 40 cv1 layers, 128 filters per block and two blocks per pixel range) was built and measured: 29.1 us against
+    // v6's 27.1 at batch 32, level at batch 64 (profiles/r05_conv_lab_s1x1_c.txt) -- those launches stay on v6; 768 -> 256 does not fit (48 K-steps)
+    int fg, wc, n_ct = 1;
+    const int k = a.Cin / 16;
+    if ((a.Cin % 16) || k < 2) return false;
+    if (k == 16 && a.Cout > 256) {            // Cin = 256, Cout = 512 / 768 (data gradients of the 40 x 40 cv1 layers): 256 filters per block
+        if (a.Cout % 256) return false;
+        fg = 2; wc = 4; n_ct = a.Cout / 256;
+    } else {
+        switch (a.Cout) {
+            case 32: fg = 1; wc = 1; break;
+            case 64: fg = 1; wc = 2; break;
+            case 128: fg = 1; wc = 4; break;
+            case 256: fg = 2; wc = 4; break;
+            case 384: fg = 3; wc = 4; break;
+            default: return false;
+        }
     }
-    if (a.Cin != 32 && a.Cin != 64 && a.Cin != 128 && a.Cin != 256 && a.Cin != 384) return false;
+    if (n_ct > 8) return false;
     {   // the instantiations that exist (launch_s1)
-        const int k = a.Cin / 16;
         const bool ok = (fg == 1 && wc == 4 && (k == 4 || k == 16 || k == 24)) || (fg == 1 && wc == 2 && (k == 2 || k == 8)) || (fg == 1 && wc == 1 && k == 4) ||
                         (fg == 2 && wc == 4 && (k == 8 || k == 16)) || (fg == 3 && wc == 4 && k == 8);
         if (!ok) return false;
     }
-    const int ks = a.Cin / 16;
+    const int ks = k;
     const int is = ks == 24 ? 48 : 32;
-    pl.fg = fg; pl.wc = wc; pl.ks = ks;
-    pl.sp = is / ks * 32;
-    pl.wp = 4 / wc;
-    pl.npass = (is / ks / pl.wp + 1) / 2;
+    const int cb = is / ks, wp = 4 / wc, mp = cb / wp;
+    pl.fg = fg; pl.wc = wc; pl.ks = ks; pl.n_ct = n_ct;
+    pl.sp = cb * 32;
+    pl.wp = wp;
+    pl.npass = mp >= 2 ? mp / 2 : 1;
     return true;
 }
 
 template <typename T> int launch_s1(ConvArgs& a, const S1Plan& pl, hipStream_t st) {
-    a.n_ct = 1;
+    a.n_ct = pl.n_ct;
     a.n_pt = y3_ceil_div(a.M, pl.sp);          // stages
     a.stat_wp = pl.wp * pl.npass;              // statistics rows per stage: one per (pixel wave, epilogue pass)
     set_divisors(a);
     g_last_variant = "s1x1";
     if (a.dry) return 0;
     const int cus = y3_cu_count();
-    const dim3 grid((unsigned)(a.n_pt < cus ? a.n_pt : cus)), block(320);
+    int slots = cus / pl.n_ct;                 // blocks per filter tile
+    if (slots < 1) slots = 1;
+    if (slots > a.n_pt) slots = a.n_pt;
+    const dim3 grid((unsigned)(slots * pl.n_ct)), block(320);
 #define Y3_S1_CASE(FG, WC, KS) if (pl.fg == FG && pl.wc == WC && pl.ks == KS) hipLaunchKernelGGL((conv_1x1s_kernel<T, FG, WC, KS>), grid, block, 0, st, a)
     Y3_S1_CASE(1, 4, 16);        // 256 -> 128
     else Y3_S1_CASE(1, 4, 24);   // 384 -> 128
@@ -182,7 +198,7 @@ template <typename T> int launch_s1(ConvArgs& a, const S1Plan& pl, hipStream_t s
     else Y3_S1_CASE(1, 2, 2);    //  32 ->  64
     else Y3_S1_CASE(1, 1, 4);    //  64 ->  32
     else Y3_S1_CASE(2, 4, 8);    // 128 -> 256
-    else Y3_S1_CASE(2, 4, 16);   // 256 -> 256 (the 80 x 80 Detect conv and its data gradient)
+    else Y3_S1_CASE(2, 4, 16);   // 256 -> 256 n_ct (the 80 x 80 Detect conv and its data gradient; 256 -> 512: data gradients of the 40 x 40 cv1 layers)
     else Y3_S1_CASE(3, 4, 8);    // 128 -> 384
 #undef Y3_S1_CASE
     else Y3_FAIL("conv s1x1: no instantiation (internal)");
