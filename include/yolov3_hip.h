@@ -105,6 +105,15 @@ int y3_conv2d_fwd_variant(const y3_conv_desc* desc, const y3_tensor* x, const y3
  * (count only); *column_blocks = ceil(N Ho Wo / 32), *group_blocks = blocks per interleave group.  Fails when the dispatcher picks another kernel for the problem. */
 int y3_conv_v10_tiles(const y3_conv_desc* desc, const y3_tensor* x, const y3_tensor* y, size_t workspace_bytes, int32_t* records,
                       int64_t capacity, int64_t* n_tiles, int32_t* column_blocks, int32_t* group_blocks);
+/* Training forward of a 1x1 convolution whose INPUT is another layer's Conv + BatchNorm + activation (+ shortcut) output (reference models/common.py:75 Conv.forward inside
+ * Bottleneck.forward, :165): `u_in` is that layer's pre-BatchNorm tensor; the launch computes y_in = act(in_scale * u_in + in_shift) (+ in_shortcut) on the way in -- the
+ * arithmetic of y3_bn_act_fwd --, stores it to `y_in` once (the other consumers read it) and convolves it: y = conv1x1(y_in) + bias with statistics rows like
+ * y3_conv2d_fwd_stats.  Replaces the y3_bn_act_fwd launch of the producing layer and this layer's read of y_in.  Only the HBM-bound Bottleneck.cv1 shapes
+ * (cin / cout 64 / 32, 128 / 64, 256 / 128); y3_conv2d_fwd_bnin_rows returns the statistics rows, or -1 when the shape is not covered (the caller keeps the two launches). */
+int64_t y3_conv2d_fwd_bnin_rows(const y3_conv_desc* desc, const y3_tensor* u_in, const y3_tensor* y_in, const y3_tensor* y, int32_t has_shortcut);
+int y3_conv2d_fwd_bnin_stats(const y3_conv_desc* desc, const y3_tensor* u_in, const float* in_scale, const float* in_shift, int32_t in_act,
+                             const y3_tensor* in_shortcut /* may be NULL */, const y3_tensor* y_in, const void* packed_filter, const float* bias, const y3_tensor* y,
+                             float* stat_rows, int64_t capacity_rows, int64_t* n_rows, void* stream);
 /* Name of the variant the last convolution / data-gradient call of the calling thread launched ("v3_quad": the four output-parity
  * classes of y3_conv2d_dgrad_s2 in one launch). */
 int y3_conv_last_variant(char* name, size_t name_cap);

@@ -216,6 +216,70 @@ def test_conv_s1x1_vs_fp32_reference(dev, tune, dtype, name, shape, kw):
     assert (out - out0).abs().max().item() <= (2.0 ** -7 if dtype == torch.float16 else 2.0 ** -4) * max(1.0, ref.abs().max().item())
 
 
+BNIN_CASES = [
+    # name, (n, h, w, cin, cout), shortcut, SiLU
+    ("256_128_shortcut_ragged", (3, 37, 29, 256, 128), True, True),      # stages of 32 pixels (u + shortcut rows): 3219 pixels end inside a stage
+    ("256_128_plain", (2, 40, 40, 256, 128), False, True),               # stages of 64 pixels
+    ("256_128_many_stages", (20, 40, 40, 256, 128), True, True),         # 1000 stages on 256 blocks
+    ("128_64_shortcut", (5, 33, 31, 128, 64), True, True),               # two pixel waves, one column block each
+    ("128_64_plain_noact", (2, 50, 50, 128, 64), False, False),
+    ("64_32_plain", (2, 36, 36, 64, 32), False, True),                   # four pixel waves
+    ("one_pixel", (1, 1, 1, 256, 128), True, True),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name,shape,shortcut,silu", BNIN_CASES, ids=[c[0] for c in BNIN_CASES])
+def test_conv1x1_bn_in_consumer_matches_separate_passes(dev, dtype, name, shape, shortcut, silu):
+    """y3_conv2d_fwd_bnin_stats (conv_1x1s.h, IN form): the producing layer's act(scale u + shift) (+ shortcut) applied on the way into its 1x1 consumer.  Against the two launches
+    it replaces -- y3_bn_act_fwd, then y3_conv2d_fwd_stats on its output: the normalised tensor it stores, the convolution output and the statistics rows' sums are the SAME
+    bits (same arithmetic on the same operands, same K order), every pixel and channel."""
+    _lib, ops = _ops()
+    import ctypes as C
+
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(7)
+    M = n * h * w
+    u_in = ops.View.alloc(n, h, w, cin, dtype, dev)
+    u_in.buf.copy_((torch.randn(M * cin, generator=g) * 1.5).to(dtype))
+    res = None
+    if shortcut:
+        res = ops.View.alloc(n, h, w, cin, dtype, dev)
+        res.buf.copy_(torch.randn(M * cin, generator=g).to(dtype))
+    scale = (torch.rand(cin, generator=g) + 0.5).to(dev)
+    shift = torch.randn(cin, generator=g).to(dev) * 0.3
+    wt = torch.randn(cout, cin, 1, 1, generator=g) / math.sqrt(cin)
+    filt = ops.pack_filter(wt.to(dev), cout, cin, dtype)
+    zb = torch.zeros(cout, device=dev)
+    act = _lib.Y3_ACT_SILU if silu else _lib.Y3_ACT_NONE
+    # the two launches
+    y_ref = ops.View.alloc(n, h, w, cin, dtype, dev)
+    ut, yt = u_in.y3(), y_ref.y3()
+    rt = res.y3() if res is not None else None
+    _lib.check(_lib.lib().y3_bn_act_fwd(C.byref(ut), scale.data_ptr(), shift.data_ptr(), C.byref(rt) if rt is not None else None, C.byref(yt), ops.dtype_code(dtype), act,
+                                        ops.stream_ptr()), "y3_bn_act_fwd")
+    o_ref = ops.View.alloc(n, h, w, cout, dtype, dev)
+    rows_ref = ops.conv2d_stats_rows(y_ref, o_ref, 1, 1)
+    buf_ref = torch.full((rows_ref * 2 * cout,), float("nan"), device=dev)
+    ops.conv2d_stats(y_ref, filt, zb, o_ref, 1, 1, buf_ref, rows_ref)
+    # the one launch
+    y_f = ops.View.alloc(n, h, w, cin, dtype, dev)
+    y_f.buf.fill_(-7.0)
+    o_f = ops.View.alloc(n, h, w, cout, dtype, dev)
+    o_f.buf.fill_(-7.0)
+    rows = ops.conv1x1_bnin_rows(u_in, y_f, o_f, shortcut)
+    assert rows > 0
+    buf = torch.full((rows * 2 * cout,), float("nan"), device=dev)
+    got = ops.conv1x1_bnin_stats(u_in, scale, shift, act, res, y_f, filt, zb, o_f, buf, rows)
+    torch.cuda.synchronize()
+    assert got == rows and ops.last_conv_variant() == "s1x1_bn"
+    assert torch.equal(y_f.buf, y_ref.buf), f"normalised tensor differs: max {(y_f.buf.float() - y_ref.buf.float()).abs().max().item()}"
+    assert torch.equal(o_f.buf, o_ref.buf), f"conv output differs: max {(o_f.buf.float() - o_ref.buf.float()).abs().max().item()}"
+    tot, tot_ref = buf.view(rows, cout, 2).double().sum(0), buf_ref.view(rows_ref, cout, 2).double().sum(0)
+    assert torch.isfinite(tot).all(), "a statistics row was not written"
+    assert (tot - tot_ref).abs().max().item() <= 1e-6 * tot_ref.abs().max().item()
+
+
 @pytest.mark.parametrize("shape", [(3, 40, 40, 256, 512, 3, 2), (4, 40, 40, 512, 256, 1, 1)], ids=["v6_3x3_s2", "v6_1x1"])
 def test_conv_request_depth_bit_identical(dev, tune, shape):
     """knob "conv_ahead": the LDS-DMA requests of the 256x256 kernel run 3 K-steps ahead of the MFMAs (default, round 3) or 2 (the

@@ -67,6 +67,13 @@ struct ConvArgs {
     unsigned dv_g_mul, dv_g_sh;                      // reciprocal of v10_g
     int cs_strips, cs_T, cs_per;   // conv_strip.h: column strips per row, output rows in all, output rows per block
     unsigned dv_pw_mul, dv_pw_sh, dv_h1_mul, dv_h1_sh;   // conv_v10.h: reciprocals of W + 2 and H + 1
+    // conv_1x1s.h, input transform (training forward): x is the producing layer's pre-BatchNorm tensor u; the operand is y_in = act(in_scale u + in_shift) (+ in_res), stored to in_y
+    const float* in_scale;
+    const float* in_shift;
+    const void* in_res;
+    void* in_y;
+    int in_rpitch, in_ypitch, in_act;
+    unsigned in_r_bytes, in_y_bytes;
 #ifdef Y3_TIMELINE  // debug build only (tools/timeline.py): per-block wall-clock stamps
     unsigned long long* tl;
 #endif
@@ -1339,6 +1346,69 @@ extern "C" int y3_conv2d_fwd_stats_ws(const y3_conv_desc* d, const y3_tensor* x,
     return conv_fwd_impl(d, x, filt, bias, nullptr, y, stat_rows, capacity_rows, n_rows, 0, stream, workspace, workspace_bytes);
 }
 
+
+// ---- 1x1 convolution of act(in_scale * u + in_shift) (+ shortcut) with statistics rows: the training forward of a Bottleneck.cv1 that applies its producer's BatchNorm on the
+// way in (conv_1x1s.h IN form).  `u_in` is the producer's pre-BatchNorm tensor, `y_in` receives the normalised / activated tensor (the other consumers read it), `y` this
+// conv's own pre-BatchNorm output.  Shapes the form does not cover are refused (y3_conv2d_fwd_bnin_rows returns -1: the caller keeps the separate passes).
+static int bnin_fill(const y3_conv_desc* d, const y3_tensor* u_in, const float* in_scale, const float* in_shift, int32_t in_act, const y3_tensor* in_res, const y3_tensor* y_in,
+                     const void* filt, const float* bias, const y3_tensor* y, ConvArgs& a, S1Plan& pl) {
+    if (!d || !u_in || !y_in || !y) Y3_FAIL("y3_conv2d_fwd_bnin: null argument");
+    if (d->ksize != 1 || d->stride != 1 || d->upsample2x || d->in_dilation > 1 || (d->dtype != Y3_F16 && d->dtype != Y3_BF16)) Y3_FAIL("y3_conv2d_fwd_bnin: 1x1 / stride 1 / f16 or bf16 only");
+    if (u_in->c != d->cin || y->c != d->cout || y_in->c != d->cin) Y3_FAIL("y3_conv2d_fwd_bnin: channel mismatch");
+    if (y->n != u_in->n || y->h != u_in->h || y->w != u_in->w || y_in->n != u_in->n || y_in->h != u_in->h || y_in->w != u_in->w) Y3_FAIL("y3_conv2d_fwd_bnin: shape mismatch");
+    if (in_res && (in_res->n != u_in->n || in_res->h != u_in->h || in_res->w != u_in->w || in_res->c != d->cin)) Y3_FAIL("y3_conv2d_fwd_bnin: shortcut shape mismatch");
+    if ((u_in->pitch % 8) || (y->pitch % 8) || (y_in->pitch % 8) || (in_res && (in_res->pitch % 8)) || ((uintptr_t)u_in->data & 15) || ((uintptr_t)y->data & 15) ||
+        ((uintptr_t)y_in->data & 15) || (in_res && ((uintptr_t)in_res->data & 15)) || ((uintptr_t)filt & 15) || ((uintptr_t)bias & 15))
+        Y3_FAIL("y3_conv2d_fwd_bnin: tensors, filter bank and bias must be 16-byte aligned with pitch %% 8 == 0");
+    if (d->filter_elems != 0 && (uint64_t)d->filter_elems < (uint64_t)y3_packed_filter_elems(d->cout, d->cin, 1)) Y3_FAIL("y3_conv2d_fwd_bnin: packed filter bank too short");
+    const long long M = (long long)u_in->n * u_in->h * u_in->w;
+    auto ext = [&](const y3_tensor* t) { return ((M - 1) * t->pitch + t->c) * 2; };
+    if (M <= 0 || M > 0x7fffffffLL || ext(u_in) >= 0x7fffffffLL || ext(y) >= 0x7fffffffLL || ext(y_in) >= 0x7fffffffLL || (in_res && ext(in_res) >= 0x7fffffffLL))
+        Y3_FAIL("y3_conv2d_fwd_bnin: a tensor exceeds the 2 GiB reach of a buffer descriptor");
+    memset(&a, 0, sizeof(a));
+    a.x = u_in->data; a.w = filt; a.bias = bias; a.y = y->data;
+    a.N = u_in->n; a.H = u_in->h; a.W = u_in->w; a.Cin = d->cin; a.xpitch = u_in->pitch;
+    a.Ho = a.H; a.Wo = a.W; a.Cout = d->cout; a.ypitch = y->pitch;
+    a.ks = 1; a.stride = 1; a.pad = 0; a.act = d->act; a.ntaps = 1;
+    a.oH = a.Ho; a.oW = a.Wo; a.omul = 1;
+    a.M = (int)M;
+    a.Kpad = y3_filter_kpad(d->cin, 1);
+    a.x_bytes = (unsigned)ext(u_in); a.y_bytes = (unsigned)ext(y);
+    a.w_bytes = (unsigned)((long long)y3_filter_rows(d->cout) * a.Kpad * 2);
+    a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act;
+    a.in_res = in_res ? in_res->data : nullptr; a.in_rpitch = in_res ? in_res->pitch : 0; a.in_r_bytes = in_res ? (unsigned)ext(in_res) : 0u;
+    a.in_y = y_in->data; a.in_ypitch = y_in->pitch; a.in_y_bytes = (unsigned)ext(y_in);
+    if (!s1_plan(a, pl, in_res ? 2 : 1)) Y3_FAIL("y3_conv2d_fwd_bnin: shape not covered (cin %d, cout %d)", d->cin, d->cout);
+    return 0;
+}
+
+extern "C" int64_t y3_conv2d_fwd_bnin_rows(const y3_conv_desc* d, const y3_tensor* u_in, const y3_tensor* y_in, const y3_tensor* y, int32_t has_shortcut) {
+    alignas(256) static const float dummy[64] = {0.0f};   // geometry only: never dereferenced
+    y3_tensor r;
+    if (has_shortcut && y_in) { r = *y_in; r.data = (void*)dummy; }
+    ConvArgs a;
+    S1Plan pl;
+    if (bnin_fill(d, u_in, dummy, dummy, Y3_ACT_NONE, has_shortcut ? &r : nullptr, y_in, (const void*)dummy, dummy, y, a, pl)) return -1;
+    a.dry = 1;
+    if (d->dtype == Y3_F16 ? launch_s1<f16_t>(a, pl, nullptr) : launch_s1<bf16_t>(a, pl, nullptr)) return -1;
+    return (int64_t)a.n_pt * a.stat_wp;
+}
+
+extern "C" int y3_conv2d_fwd_bnin_stats(const y3_conv_desc* d, const y3_tensor* u_in, const float* in_scale, const float* in_shift, int32_t in_act, const y3_tensor* in_shortcut,
+                                        const y3_tensor* y_in, const void* filt, const float* bias, const y3_tensor* y, float* stat_rows, int64_t capacity_rows, int64_t* n_rows,
+                                        void* stream) {
+    if (!in_scale || !in_shift || !filt || !bias || !n_rows) Y3_FAIL("y3_conv2d_fwd_bnin_stats: null argument");
+    ConvArgs a;
+    S1Plan pl;
+    if (bnin_fill(d, u_in, in_scale, in_shift, in_act, in_shortcut, y_in, filt, bias, y, a, pl)) return -1;
+    const int64_t rows = (int64_t)y3_ceil_div(a.M, pl.sp) * pl.wp * pl.npass;
+    *n_rows = rows;
+    if (stat_rows) {
+        if (capacity_rows < rows) Y3_FAIL("y3_conv2d_fwd_bnin_stats: statistics buffer holds %lld rows, the launch writes %lld", (long long)capacity_rows, (long long)rows);
+        a.stats = stat_rows;
+    }
+    return d->dtype == Y3_F16 ? launch_s1<f16_t>(a, pl, (hipStream_t)stream) : launch_s1<bf16_t>(a, pl, (hipStream_t)stream);
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Data gradient of a 3x3 stride-2 pad-1 convolution without the 4x zero-tap waste of the dilated form: the gradient

@@ -14,12 +14,17 @@
 // Geometry per (FG, WC, KS): WC consumer waves along the filters (WC * FG * 32 = Cout), 4 / WC along the pixels; KS = Cin / 16 K-steps; a stage holds as many
 // 32-pixel column blocks as make 32 (48 at KS = 24) requests.
 
-template <int FG_, int WC_, int KS_> struct S1Geom {
-    static constexpr int FG = FG_, WC = WC_, KS = KS_;
+// IN (training forward, "consumer-side BatchNorm"): 0 the operand is the tensor as stored; 1 / 2 the operand is the PRE-BatchNorm output u of the producing layer and the kernel
+// applies that layer's act(scale u + shift) (2: + its shortcut tensor) on the way in, writes the result y once for the other consumers, and multiplies it -- the producing
+// layer's normalise pass and this layer's read of y disappear (reference models/common.py:75, :165).  A stage then holds u (and the shortcut rows) of half as many pixels.
+template <int FG_, int WC_, int KS_, int IN_ = 0> struct S1Geom {
+    static constexpr int FG = FG_, WC = WC_, KS = KS_, IN = IN_;
+    static constexpr int PARTS = IN == 2 ? 2 : 1;           // tensors staged per pixel
     static constexpr int WP = 4 / WC;                       // consumer waves along the pixel axis
-    static constexpr int TC = WC * FG * 32;                 // filters per block = Cout
+    static constexpr int TC = WC * FG * 32;                 // filters per block
     static constexpr int IS = KS == 24 ? 48 : 32;           // LDS-DMA requests (1 KiB each) per stage
-    static constexpr int CB = IS / KS;                      // 32-pixel column blocks per stage
+    static constexpr int CB = IS / KS / PARTS;              // 32-pixel column blocks per stage
+    static constexpr int NF = CB * KS;                      // B fragments (1 KiB) of a stage
     static constexpr int SP = CB * 32;                      // pixels per stage
     static constexpr int MP = CB / WP;                      // column blocks per consumer wave and stage
     static constexpr int PB = MP >= 2 ? 2 : 1;              // column blocks per epilogue pass
@@ -29,16 +34,17 @@ template <int FG_, int WC_, int KS_> struct S1Geom {
     static constexpr int SLICE_BYTES = PB * 32 * 64;        // one epilogue pass of a wave: PB * 32 pixels x 32 filters
     static constexpr int SLICE = NS * STAGE;
     static constexpr int LDS = SLICE + 4 * SLICE_BYTES;
-    static_assert(CB * KS == IS && MP * WP == CB && MP >= 1 && MP % PB == 0, "whole column blocks per wave, whole passes");
+    static_assert(CB * KS * PARTS == IS && MP * WP == CB && MP >= 1 && MP % PB == 0, "whole column blocks per wave, whole passes");
+    static_assert(IN == 0 || (NF % 4 == 0 && KS % 4 == 0), "the transform deals the fragments of a stage to the four consumer waves");
     static_assert(LDS <= 163840, "the LDS of a CU");
 };
 
 template <int N> Y3_DEV void s1_wait_vm() { __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14)); }   // (conv_v10.h::v10_wait_vm)
 
-template <typename T, int FG, int WC, int KS>
+template <typename T, int FG, int WC, int KS, int IN = 0>
 __global__ __launch_bounds__(320, 1) void conv_1x1s_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    typedef S1Geom<FG, WC, KS> G;
+    typedef S1Geom<FG, WC, KS, IN> G;
     typedef typename Mfma<T>::frag frag;
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[G::LDS];   // the ONLY LDS object
@@ -59,16 +65,24 @@ __global__ __launch_bounds__(320, 1) void conv_1x1s_kernel(const ConvArgs p) {
         const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
         constexpr unsigned OOB = 0x80000000u;   // stays out of range when the K-step offset is added: the piece lands as zeros
         const int pl = lane & 31, fk = lane >> 5;
+        const auto rsrc_r = __builtin_amdgcn_make_buffer_rsrc((void*)(IN == 2 ? p.in_res : p.x), 0, IN == 2 ? (int)p.in_r_bytes : 0, 0x00020000);
         auto issue = [&](int j) {
             const int m0 = (b + j * nb) * G::SP;
             unsigned char* dst = smem + (j % G::NS) * G::STAGE;
 #pragma unroll
             for (int cb = 0; cb < G::CB; ++cb) {
                 const int m = m0 + cb * 32 + pl;
-                const unsigned vo = (j < my && m < p.M) ? (unsigned)((m * p.xpitch + fk * 8) * 2) : OOB;
+                const bool ok = j < my && m < p.M;
+                const unsigned vo = ok ? (unsigned)((m * p.xpitch + fk * 8) * 2) : OOB;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(dst + (cb * KS + ks) * 1024), 16, vo, ks * 32, 0, 0);
+                if constexpr (IN == 2) {   // the shortcut rows of the same pixels, behind the stage's u fragments
+                    const unsigned vr = ok ? (unsigned)((m * p.in_rpitch + fk * 8) * 2) : OOB;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_r, (lds_ptr_t)(dst + (G::NF + cb * KS + ks) * 1024), 16, vr, ks * 32, 0, 0);
+                }
             }
         };
         issue(0);
@@ -77,6 +91,7 @@ __global__ __launch_bounds__(320, 1) void conv_1x1s_kernel(const ConvArgs p) {
             s1_wait_vm<G::IS>();              // only the requests of stage j + 1 are younger than stage j's: stage j has landed
             __builtin_amdgcn_s_barrier();     // ... and is published; every consumer is done with stage j - 1, whose slot stage j + 2 takes
             issue(j + 2);                     // (beyond the block's last stage: out-of-range requests, so that the count above stays exact)
+            if constexpr (IN != 0) __builtin_amdgcn_s_barrier();   // (the consumers' barrier between transforming the stage and multiplying it)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing of this wave is in flight into an LDS that the next workgroup may own
         return;
@@ -101,10 +116,51 @@ __global__ __launch_bounds__(320, 1) void conv_1x1s_kernel(const ConvArgs p) {
         for (int g = 0; g < 4; ++g) bz[fg][g] = *(const f32x4*)(p.bias + ct * G::TC + (wc * FG + fg) * 32 + 8 * g + 4 * fk);
     unsigned char* slice = smem + G::SLICE + wv * G::SLICE_BYTES;
 
+    // IN: the producing layer's scale / shift of the channels this wave transforms -- fragment f = wv + 4 i of a stage is K-step (wv + 4 i) % KS, i.e. one of KS / 4 K-steps
+    constexpr int NT = IN ? (KS / 4 > 0 ? KS / 4 : 1) : 1;
+    f32x2 isc[NT][4], ish[NT][4];
+    if constexpr (IN != 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = (wv + 4 * t) * 16 + fk * 8 + 2 * q;
+                isc[t][q] = f32x2{p.in_scale[c], p.in_scale[c + 1]};
+                ish[t][q] = f32x2{p.in_shift[c], p.in_shift[c + 1]};
+            }
+    }
+    const auto rsrc_iy = __builtin_amdgcn_make_buffer_rsrc((void*)(IN ? p.in_y : p.y), 0, IN ? (int)p.in_y_bytes : 0, 0x00020000);
+
     for (int j = 0; j < my; ++j) {
         __builtin_amdgcn_s_barrier();   // stage j has landed for every wave
-        const unsigned char* st = smem + (j % G::NS) * G::STAGE + (wp * G::MP) * KS * 1024 + lane * 16;
         const int s = b + j * nb;
+        if constexpr (IN != 0) {
+            // y = act(scale u + shift) (+ shortcut), the arithmetic of bn_act_fwd_kernel (train.hip): each consumer wave transforms a quarter of the stage's fragments IN PLACE
+            // and stores them -- a lane's fragment is 8 consecutive channels of one pixel: a 16-byte piece of y's row
+            unsigned char* su = smem + (j % G::NS) * G::STAGE + lane * 16;
+#pragma unroll
+            for (int i = 0; i < G::NF / 4; ++i) {
+                const int f = wv + 4 * i;                   // (wave-uniform)
+                const int cb = f / KS, ks = f - cb * KS;
+                typedef typename Mfma<T>::frag vec8;
+                const vec8 uu = *(const vec8*)(su + f * 1024);
+                vec8 rr;
+                if constexpr (IN == 2) rr = *(const vec8*)(su + (G::NF + f) * 1024);
+                u32x4 ov;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x2 z = f32x2{to_f32<T>(uu[2 * q]), to_f32<T>(uu[2 * q + 1])} * isc[i % NT][q] + ish[i % NT][q];
+                    if (p.in_act == Y3_ACT_SILU) z = z * sigmoid2(z);
+                    if constexpr (IN == 2) z += f32x2{to_f32<T>(rr[2 * q]), to_f32<T>(rr[2 * q + 1])};
+                    ov[q] = pack2<T>(z[0], z[1]);
+                }
+                *(u32x4*)(su + f * 1024) = ov;
+                const int m = s * G::SP + cb * 32 + frow;
+                __builtin_amdgcn_raw_buffer_store_b128(ov, rsrc_iy, m < p.M ? (unsigned)((m * p.in_ypitch + ks * 16 + fk * 8) * 2) : 0x80000000u, 0, 0);
+            }
+            __builtin_amdgcn_s_barrier();   // every fragment of the stage is y now
+        }
+        const unsigned char* st = smem + (j % G::NS) * G::STAGE + (wp * G::MP) * KS * 1024 + lane * 16;
         const int m_wave = s * G::SP + wp * G::MP * 32;
         // one epilogue pass (PB column blocks) and one filter group at a time: multiply, then hand the 32 x PB * 32 tile to the epilogue (16 PB accumulator registers live)
         static_for<G::NPASS * FG>([&](auto IT) {
@@ -133,15 +189,15 @@ __global__ __launch_bounds__(320, 1) void conv_1x1s_kernel(const ConvArgs p) {
 
 // the (filter groups per wave, waves along the filters, K-steps) form of a layer, or false: not one of the HBM-bound 1x1 shapes
 struct S1Plan {
-    int fg, wc, ks, sp, wp, npass, n_ct;
+    int fg, wc, ks, sp, wp, npass, n_ct, in;
 };
-static bool s1_plan(const ConvArgs& a, S1Plan& pl) {
+static bool s1_plan(const ConvArgs& a, S1Plan& pl, int in = 0) {   // in: 0 plain operand; 1 / 2 the producing layer's BatchNorm + activation (+ shortcut) applied on the way in
     const long long mode = y3_knob(Y3K_CONV_1X1S);
     if (mode == 0 || a.ups || a.dil_shift) return false;
     if (a.ks != 1 || a.ntaps != 1 || a.stride != 1 || a.pad != 0 || a.tdh[0] != 0 || a.tdw[0] != 0) return false;
     if (a.omul != 1 || a.ooh != 0 || a.oow != 0 || a.H != a.Ho || a.W != a.Wo || a.oH != a.Ho || a.oW != a.Wo) return false;
     if (!a.x_bytes || !a.w_bytes || !a.y_bytes || (a.res && !a.r_bytes) || !a.bias) return false;
-    if (a.M < 32768 && mode != 2) return false;   // below that the launch is latency-bound and the tile kernels' many small blocks win
+    if (a.M < 32768 && mode != 2 && !in) return false;   // below that the launch is latency-bound and the tile kernels' many small blocks win
     // WC consumer waves along the filters x FG groups of 32 filters per wave = the filters of a block; n_ct blocks side by side where Cout is more than a block keeps in
     // registers.  The shapes of yolov3's Bottleneck.cv1 layers on the 40 x 40 ... 320 x 320 maps, their data gradients, the 80 x 80 Detect conv (255 -> 256 filters) and the
     // cv1 layers behind the two Concats.  Cin = 512 (the 40 x 40 cv1 layers, 128 filters per block and two blocks per pixel range) was built and measured: 29.1 us against
@@ -168,10 +224,15 @@ static bool s1_plan(const ConvArgs& a, S1Plan& pl) {
                         (fg == 2 && wc == 4 && (k == 8 || k == 16)) || (fg == 3 && wc == 4 && k == 8);
         if (!ok) return false;
     }
+    if (in) {   // the forward cv1 shapes of the Bottlenecks: 64 -> 32, 128 -> 64, 256 -> 128
+        const bool ok = n_ct == 1 && fg == 1 && ((wc == 4 && k == 16) || (wc == 2 && k == 8) || (wc == 1 && k == 4 && in == 1));
+        if (!ok || !a.in_scale || !a.in_shift || !a.in_y || !a.in_y_bytes || (in == 2 && (!a.in_res || !a.in_r_bytes))) return false;
+    }
     const int ks = k;
     const int is = ks == 24 ? 48 : 32;
-    const int cb = is / ks, wp = 4 / wc, mp = cb / wp;
-    pl.fg = fg; pl.wc = wc; pl.ks = ks; pl.n_ct = n_ct;
+    const int cb = is / ks / (in == 2 ? 2 : 1), wp = 4 / wc, mp = cb / wp;
+    if (mp < 1) return false;
+    pl.fg = fg; pl.wc = wc; pl.ks = ks; pl.n_ct = n_ct; pl.in = in;
     pl.sp = cb * 32;
     pl.wp = wp;
     pl.npass = mp >= 2 ? mp / 2 : 1;
@@ -183,14 +244,15 @@ template <typename T> int launch_s1(ConvArgs& a, const S1Plan& pl, hipStream_t s
     a.n_pt = y3_ceil_div(a.M, pl.sp);          // stages
     a.stat_wp = pl.wp * pl.npass;              // statistics rows per stage: one per (pixel wave, epilogue pass)
     set_divisors(a);
-    g_last_variant = "s1x1";
+    g_last_variant = pl.in ? "s1x1_bn" : "s1x1";
     if (a.dry) return 0;
     const int cus = y3_cu_count();
     int slots = cus / pl.n_ct;                 // blocks per filter tile
     if (slots < 1) slots = 1;
     if (slots > a.n_pt) slots = a.n_pt;
     const dim3 grid((unsigned)(slots * pl.n_ct)), block(320);
-#define Y3_S1_CASE(FG, WC, KS) if (pl.fg == FG && pl.wc == WC && pl.ks == KS) hipLaunchKernelGGL((conv_1x1s_kernel<T, FG, WC, KS>), grid, block, 0, st, a)
+#define Y3_S1_CASE(FG, WC, KS) if (pl.in == 0 && pl.fg == FG && pl.wc == WC && pl.ks == KS) hipLaunchKernelGGL((conv_1x1s_kernel<T, FG, WC, KS>), grid, block, 0, st, a)
+#define Y3_S1_IN(FG, WC, KS, IN) if (pl.in == IN && pl.fg == FG && pl.wc == WC && pl.ks == KS) hipLaunchKernelGGL((conv_1x1s_kernel<T, FG, WC, KS, IN>), grid, block, 0, st, a)
     Y3_S1_CASE(1, 4, 16);        // 256 -> 128
     else Y3_S1_CASE(1, 4, 24);   // 384 -> 128
     else Y3_S1_CASE(1, 4, 4);    //  64 -> 128
@@ -200,6 +262,12 @@ template <typename T> int launch_s1(ConvArgs& a, const S1Plan& pl, hipStream_t s
     else Y3_S1_CASE(2, 4, 8);    // 128 -> 256
     else Y3_S1_CASE(2, 4, 16);   // 256 -> 256 n_ct (the 80 x 80 Detect conv and its data gradient; 256 -> 512: data gradients of the 40 x 40 cv1 layers)
     else Y3_S1_CASE(3, 4, 8);    // 128 -> 384
+    else Y3_S1_IN(1, 4, 16, 1);  // the same cv1 shapes behind a layer without / with a shortcut, that layer's BatchNorm + activation applied on the way in
+    else Y3_S1_IN(1, 4, 16, 2);
+    else Y3_S1_IN(1, 2, 8, 1);
+    else Y3_S1_IN(1, 2, 8, 2);
+    else Y3_S1_IN(1, 1, 4, 1);
+#undef Y3_S1_IN
 #undef Y3_S1_CASE
     else Y3_FAIL("conv s1x1: no instantiation (internal)");
     Y3_CHECK_LAUNCH();

@@ -411,6 +411,27 @@ def conv2d_stats_rows(x: View, y: View, k: int, stride: int, workspace: torch.Te
     return rows
 
 
+def conv1x1_bnin_rows(u_in: View, y_in: View, y: View, has_shortcut: bool) -> int:
+    """statistics rows of a conv1x1_bnin_stats launch of this shape, or -1 when the library's input-transform form (csrc/conv_1x1s.h) does not cover it"""
+    d = Y3ConvDesc(dtype_code(u_in.buf.dtype), 1, 1, _lib.Y3_ACT_NONE, 0, _lib.Y3_ALGO_AUTO, u_in.c, y.c, 0)
+    # geometry only (nothing is dereferenced): the views may not be bound to memory yet (TrainPlan builds before its arena exists)
+    ut, it, yt = (Y3Tensor(4096, v.n, v.h, v.w, v.c, v.pitch) for v in (u_in, y_in, y))
+    return int(_lib.lib().y3_conv2d_fwd_bnin_rows(C.byref(d), C.byref(ut), C.byref(it), C.byref(yt), int(bool(has_shortcut))))
+
+
+def conv1x1_bnin_stats(u_in: View, in_scale: torch.Tensor, in_shift: torch.Tensor, in_act: int, shortcut: View | None, y_in: View, filt: torch.Tensor, bias: torch.Tensor, y: View,
+                       stat_rows: torch.Tensor, capacity_rows: int) -> int:
+    """y_in = act(in_scale * u_in + in_shift) (+ shortcut), stored once, and y = conv1x1(y_in) with statistics rows -- one launch (the producing layer's BatchNorm applied on the
+    way into its 1x1 consumer: no normalise pass, no second read of y_in)."""
+    d = Y3ConvDesc(dtype_code(u_in.buf.dtype), 1, 1, _lib.Y3_ACT_NONE, 0, _lib.Y3_ALGO_AUTO, u_in.c, y.c, 0, filt.numel())
+    ut, it, yt = u_in.y3(), y_in.y3(), y.y3()
+    st = shortcut.y3() if shortcut is not None else None
+    n = C.c_int64(0)
+    check(_lib.lib().y3_conv2d_fwd_bnin_stats(C.byref(d), C.byref(ut), in_scale.data_ptr(), in_shift.data_ptr(), int(in_act), C.byref(st) if st is not None else None, C.byref(it),
+                                              filt.data_ptr(), bias.data_ptr(), C.byref(yt), stat_rows.data_ptr(), int(capacity_rows), C.byref(n), stream_ptr()), "y3_conv2d_fwd_bnin_stats")
+    return int(n.value)
+
+
 def conv2d_stats(x: View, filt: torch.Tensor, bias: torch.Tensor, y: View, k: int, stride: int, stat_rows: torch.Tensor, capacity_rows: int,
                  workspace: torch.Tensor | None = None) -> int:
     """y = conv(x) (no activation) + per-(pixel tile, wave) rows of (sum, sum of squares) per filter in stat_rows (fp32)."""

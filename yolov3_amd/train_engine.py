@@ -130,6 +130,11 @@ class ConvUnit(_Unit):
         # the data gradient of this unit runs through the generic dgrad bank (not the stride-2 parity-class banks, not layer 0)
         self.pair_pack = need_dx and plan.dtype in (torch.float16, torch.bfloat16) and not (self.s == 2 and self.k == 3)
         self.bank_fwd = self.bank_dgrad = None   # persistent filter banks filled by the plan's one-launch packing (TrainPlan.pack_jobs)
+        # consumer-side BatchNorm (TrainPlan._pair_bn_consumers): `bn_in` = the unit whose normalise + activation (+ shortcut) this 1x1 unit applies on the way in;
+        # `act_in_consumer` = this unit's own normalise pass runs inside its 1x1 consumer's launch
+        self.bn_in: ConvUnit | None = None
+        self.act_in_consumer = False
+        self.bnin_rows = -1
 
     def sync_group(self):
         """the process group of a torch.nn.SyncBatchNorm layer (reference train.py:270-272: --sync-bn converts every BatchNorm2d before DDP wraps the
@@ -203,7 +208,20 @@ class ConvUnit(_Unit):
                 filt, self.filt_d = ops.pack_filter_pair(m.conv.weight, self.cout, self.cin, self.plan.dtype)
             else:
                 filt = ops.pack_filter(m.conv.weight, self.cout, self.cin, self.plan.dtype)
-            if self.plan.epilogue_stats:
+            if self.bn_in is not None:
+                # the producer's BatchNorm + activation (+ shortcut) applied on the way in (csrc/conv_1x1s.h IN form): its normalised output is written once by THIS launch
+                pr = self.bn_in
+                buf = self.plan.stat_buffer(self.bnin_rows * 2 * self.cout)
+                n_rows = ops.conv1x1_bnin_stats(pr.u, pr.scale, pr.shift, pr.act, pr.res.view if pr.res is not None else None, pr.y.view, filt, self.zero_bias, self.u, buf,
+                                                self.bnin_rows)
+                check(
+                    L.y3_bn_finalize_rows(buf.data_ptr(), n_rows, self.count, self.cout, self.sums.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps),
+                                          float(bn.momentum), bn.running_mean.data_ptr(), bn.running_var.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr(),
+                                          self.mean.data_ptr(), self.invstd.data_ptr(), st),
+                    "y3_bn_finalize_rows",
+                )
+                stats_in_epilogue = True
+            elif self.plan.epilogue_stats:
                 # BatchNorm statistics taken in the conv epilogue (per-tile rows of sum / sum of squares): no separate pass over u
                 ws = self.plan.conv_ws
                 if self.stat_rows is None:
@@ -233,6 +251,8 @@ class ConvUnit(_Unit):
                                        self.invstd.data_ptr(), st),
                 "y3_bn_stats_finalize",
             )
+        if self.act_in_consumer:
+            return   # y = act(scale u + shift) (+ shortcut) is computed and stored by the 1x1 consumer's launch (the next unit)
         yt = self.y.view.y3()
         rt = self.res.view.y3() if self.res is not None else None
         check(L.y3_bn_act_fwd(C.byref(ut), self.scale.data_ptr(), self.shift.data_ptr(), C.byref(rt) if rt is not None else None, C.byref(yt), dcode, self.act, st),
@@ -611,6 +631,7 @@ class TrainPlan:
                 self.units.append(ConvUnit(self, k, ins[0], out[i], None, need_dx=src[i][0] >= 0, label=f"L{i}"))
             else:
                 raise NotImplementedError(type(k).__name__)
+        self._pair_bn_consumers()
         self.params = list(model.parameters())
         self.param_ids = tuple(id(p) for p in self.params)   # run_model_train rebuilds the plan when a Parameter object is replaced
         self.x_nchw = None
@@ -648,6 +669,24 @@ class TrainPlan:
         self.last_forward = 0
         self.generation = 0        # bumped by every forward: the saved activations belong to exactly one forward
         self.outstanding = False   # a grad-enabled forward ran and its backward has not: the saved state must not be overwritten
+
+    def _pair_bn_consumers(self):
+        """Consumer-side BatchNorm (round 5; Y3_BN_IN_CONSUMER=0: the separate passes, for A/B runs).  Where a Conv unit is IMMEDIATELY followed by a 1x1 Conv unit that reads its
+        output (Bottleneck.cv2 -> the next Bottleneck's cv1, a stride-2 Conv -> the first cv1 of its stage; reference models/common.py:150-165) and the library's input-transform
+        form covers the shape, the producer's normalise + activation (+ shortcut) pass is dropped: the consumer's launch reads the producer's pre-BatchNorm tensor, applies
+        scale / shift / SiLU / shortcut on the way in, stores the result once for the other consumers (the next shortcut, the filter gradient) and multiplies it.  One read of
+        the activation and one launch less per pair.  The backward is unchanged (it needs u and y as before)."""
+        if self.dtype not in (torch.float16, torch.bfloat16) or os.environ.get("Y3_BN_IN_CONSUMER", "1") == "0" or os.environ.get("Y3_BN_EPILOGUE", "1") == "0":
+            return
+        for pr, cu in zip(self.units, self.units[1:]):
+            if not (isinstance(pr, ConvUnit) and isinstance(cu, ConvUnit)) or cu.k != 1 or cu.s != 1 or cu.x is not pr.y or cu.use_stem or cu.res is not None:
+                continue
+            if getattr(pr.y, "parent", None) is not None or pr.sync_group() or cu.sync_group() or pr.act_in_consumer or pr.cout != pr.co_real:
+                continue
+            rows = ops.conv1x1_bnin_rows(pr.u, pr.y.view, cu.u, pr.res is not None)   # (a dry run of the library's plan: -1 = shape not covered)
+            if rows <= 0:
+                continue
+            cu.bn_in, cu.bnin_rows, pr.act_in_consumer = pr, rows, True
 
     # -- helpers ---------------------------------------------------------------------------------
     @classmethod
