@@ -16,14 +16,15 @@
 
 // IN (training forward, "consumer-side BatchNorm"): 0 the operand is the tensor as stored; 1 / 2 the operand is the PRE-BatchNorm output u of the producing layer and the kernel
 // applies that layer's act(scale u + shift) (2: + its shortcut tensor) on the way in, writes the result y once for the other consumers, and multiplies it -- the producing
-// layer's normalise pass and this layer's read of y disappear (reference models/common.py:75, :165).  A stage then holds u (and the shortcut rows) of half as many pixels.
+// layer's normalise pass and this layer's read of y disappear (reference models/common.py:75, :165).  u streams through the LDS stages like any operand; the shortcut rows do
+// not (a stage would hold half as many pixels and the per-stage costs would double): every consumer wave prefetches the shortcut fragments of its quarter of the NEXT stage
+// into registers while the current stage is multiplied.
 template <int FG_, int WC_, int KS_, int IN_ = 0> struct S1Geom {
     static constexpr int FG = FG_, WC = WC_, KS = KS_, IN = IN_;
-    static constexpr int PARTS = IN == 2 ? 2 : 1;           // tensors staged per pixel
     static constexpr int WP = 4 / WC;                       // consumer waves along the pixel axis
     static constexpr int TC = WC * FG * 32;                 // filters per block
     static constexpr int IS = KS == 24 ? 48 : 32;           // LDS-DMA requests (1 KiB each) per stage
-    static constexpr int CB = IS / KS / PARTS;              // 32-pixel column blocks per stage
+    static constexpr int CB = IS / KS;                      // 32-pixel column blocks per stage
     static constexpr int NF = CB * KS;                      // B fragments (1 KiB) of a stage
     static constexpr int SP = CB * 32;                      // pixels per stage
     static constexpr int MP = CB / WP;                      // column blocks per consumer wave and stage
@@ -33,9 +34,10 @@ template <int FG_, int WC_, int KS_, int IN_ = 0> struct S1Geom {
     static constexpr int NS = 3;
     static constexpr int SLICE_BYTES = PB * 32 * 64;        // one epilogue pass of a wave: PB * 32 pixels x 32 filters
     static constexpr int SLICE = NS * STAGE;
-    static constexpr int LDS = SLICE + 4 * SLICE_BYTES;
-    static_assert(CB * KS * PARTS == IS && MP * WP == CB && MP >= 1 && MP % PB == 0, "whole column blocks per wave, whole passes");
-    static_assert(IN == 0 || (NF % 4 == 0 && KS % 4 == 0), "the transform deals the fragments of a stage to the four consumer waves");
+    static constexpr int TAB = SLICE + 4 * SLICE_BYTES;     // IN: the producing layer's (scale, shift) per input channel, fp32
+    static constexpr int LDS = TAB + (IN ? 2 * KS * 16 * 4 : 0);
+    static_assert(CB * KS == IS && MP * WP == CB && MP >= 1 && MP % PB == 0, "whole column blocks per wave, whole passes");
+    static_assert(IN == 0 || NF % 4 == 0, "the transform deals the fragments of a stage to the four consumer waves");
     static_assert(LDS <= 163840, "the LDS of a CU");
 };
 
@@ -65,24 +67,16 @@ __global__ __launch_bounds__(320, 1) void conv_1x1s_kernel(const ConvArgs p) {
         const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
         constexpr unsigned OOB = 0x80000000u;   // stays out of range when the K-step offset is added: the piece lands as zeros
         const int pl = lane & 31, fk = lane >> 5;
-        const auto rsrc_r = __builtin_amdgcn_make_buffer_rsrc((void*)(IN == 2 ? p.in_res : p.x), 0, IN == 2 ? (int)p.in_r_bytes : 0, 0x00020000);
         auto issue = [&](int j) {
             const int m0 = (b + j * nb) * G::SP;
             unsigned char* dst = smem + (j % G::NS) * G::STAGE;
 #pragma unroll
             for (int cb = 0; cb < G::CB; ++cb) {
                 const int m = m0 + cb * 32 + pl;
-                const bool ok = j < my && m < p.M;
-                const unsigned vo = ok ? (unsigned)((m * p.xpitch + fk * 8) * 2) : OOB;
+                const unsigned vo = (j < my && m < p.M) ? (unsigned)((m * p.xpitch + fk * 8) * 2) : OOB;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(dst + (cb * KS + ks) * 1024), 16, vo, ks * 32, 0, 0);
-                if constexpr (IN == 2) {   // the shortcut rows of the same pixels, behind the stage's u fragments
-                    const unsigned vr = ok ? (unsigned)((m * p.in_rpitch + fk * 8) * 2) : OOB;
-#pragma unroll
-                    for (int ks = 0; ks < KS; ++ks)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_r, (lds_ptr_t)(dst + (G::NF + cb * KS + ks) * 1024), 16, vr, ks * 32, 0, 0);
-                }
             }
         };
         issue(0);
@@ -116,48 +110,64 @@ __global__ __launch_bounds__(320, 1) void conv_1x1s_kernel(const ConvArgs p) {
         for (int g = 0; g < 4; ++g) bz[fg][g] = *(const f32x4*)(p.bias + ct * G::TC + (wc * FG + fg) * 32 + 8 * g + 4 * fk);
     unsigned char* slice = smem + G::SLICE + wv * G::SLICE_BYTES;
 
-    // IN: the producing layer's scale / shift of the channels this wave transforms -- fragment f = wv + 4 i of a stage is K-step (wv + 4 i) % KS, i.e. one of KS / 4 K-steps
-    constexpr int NT = IN ? (KS / 4 > 0 ? KS / 4 : 1) : 1;
-    f32x2 isc[NT][4], ish[NT][4];
-    if constexpr (IN != 0) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c = (wv + 4 * t) * 16 + fk * 8 + 2 * q;
-                isc[t][q] = f32x2{p.in_scale[c], p.in_scale[c + 1]};
-                ish[t][q] = f32x2{p.in_shift[c], p.in_shift[c + 1]};
-            }
-    }
+    // IN: the producing layer's (scale, shift) table in LDS (published by the first stage's barrier), the shortcut fragments of this wave's quarter of a stage in registers
     const auto rsrc_iy = __builtin_amdgcn_make_buffer_rsrc((void*)(IN ? p.in_y : p.y), 0, IN ? (int)p.in_y_bytes : 0, 0x00020000);
+    const auto rsrc_ir = __builtin_amdgcn_make_buffer_rsrc((void*)(IN == 2 ? p.in_res : p.y), 0, IN == 2 ? (int)p.in_r_bytes : 0, 0x00020000);
+    constexpr int NQ = IN ? G::NF / 4 : 1;   // fragments of a stage per consumer wave: f = wv + 4 i
+    u32x4 rpre[NQ];
+    auto prefetch_shortcut = [&](int j) {
+        if constexpr (IN == 2) {
+            const int m0 = (b + j * nb) * G::SP;
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const int f = wv + 4 * i, cb = f / KS, ks = f - cb * KS;
+                const int m = m0 + cb * 32 + frow;
+                rpre[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_ir, (j < my && m < p.M) ? (unsigned)((m * p.in_rpitch + ks * 16 + fk * 8) * 2) : 0x80000000u, 0, 0);
+            }
+        }
+    };
+    if constexpr (IN != 0) {
+        float* tab = (float*)(smem + G::TAB);
+        for (int c = wv * 64 + lane; c < KS * 16; c += 256) { tab[c] = p.in_scale[c]; tab[KS * 16 + c] = p.in_shift[c]; }
+        prefetch_shortcut(0);
+    }
 
     for (int j = 0; j < my; ++j) {
+        if constexpr (IN != 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (first trip: this wave's part of the table is written)
         __builtin_amdgcn_s_barrier();   // stage j has landed for every wave
         const int s = b + j * nb;
         if constexpr (IN != 0) {
-            // y = act(scale u + shift) (+ shortcut), the arithmetic of bn_act_fwd_kernel (train.hip): each consumer wave transforms a quarter of the stage's fragments IN PLACE
-            // and stores them -- a lane's fragment is 8 consecutive channels of one pixel: a 16-byte piece of y's row
+            // y = act(scale u + shift) (+ shortcut), the arithmetic of bn_act_fwd_kernel (train.hip: y3_bn_act2): each consumer wave transforms a quarter of the stage's
+            // fragments IN PLACE and stores them -- a lane's fragment is 8 consecutive channels of one pixel: a 16-byte piece of y's row
             unsigned char* su = smem + (j % G::NS) * G::STAGE + lane * 16;
+            const float* tab = (const float*)(smem + G::TAB);
 #pragma unroll
-            for (int i = 0; i < G::NF / 4; ++i) {
+            for (int i = 0; i < NQ; ++i) {
                 const int f = wv + 4 * i;                   // (wave-uniform)
                 const int cb = f / KS, ks = f - cb * KS;
                 typedef typename Mfma<T>::frag vec8;
                 const vec8 uu = *(const vec8*)(su + f * 1024);
+                const int c0 = ks * 16 + fk * 8;
+                const f32x4 sc0 = *(const f32x4*)(tab + c0), sc1 = *(const f32x4*)(tab + c0 + 4), sh0 = *(const f32x4*)(tab + KS * 16 + c0), sh1 = *(const f32x4*)(tab + KS * 16 + c0 + 4);
+                const float scv[8] = {sc0[0], sc0[1], sc0[2], sc0[3], sc1[0], sc1[1], sc1[2], sc1[3]};
+                const float shv[8] = {sh0[0], sh0[1], sh0[2], sh0[3], sh1[0], sh1[1], sh1[2], sh1[3]};
                 vec8 rr;
-                if constexpr (IN == 2) rr = *(const vec8*)(su + (G::NF + f) * 1024);
+                if constexpr (IN == 2) rr = __builtin_bit_cast(vec8, rpre[i]);
                 u32x4 ov;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    f32x2 z = f32x2{to_f32<T>(uu[2 * q]), to_f32<T>(uu[2 * q + 1])} * isc[i % NT][q] + ish[i % NT][q];
-                    if (p.in_act == Y3_ACT_SILU) z = z * sigmoid2(z);
-                    if constexpr (IN == 2) z += f32x2{to_f32<T>(rr[2 * q]), to_f32<T>(rr[2 * q + 1])};
+                    f32x2 r2 = {0.0f, 0.0f};
+                    if constexpr (IN == 2) r2 = f32x2{to_f32<T>(rr[2 * q]), to_f32<T>(rr[2 * q + 1])};
+                    const f32x2 z = y3_bn_act2(f32x2{to_f32<T>(uu[2 * q]), to_f32<T>(uu[2 * q + 1])}, f32x2{scv[2 * q], scv[2 * q + 1]}, f32x2{shv[2 * q], shv[2 * q + 1]},
+                                               p.in_act == Y3_ACT_SILU, IN == 2, r2);
                     ov[q] = pack2<T>(z[0], z[1]);
                 }
                 *(u32x4*)(su + f * 1024) = ov;
                 const int m = s * G::SP + cb * 32 + frow;
-                __builtin_amdgcn_raw_buffer_store_b128(ov, rsrc_iy, m < p.M ? (unsigned)((m * p.in_ypitch + ks * 16 + fk * 8) * 2) : 0x80000000u, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(ov, rsrc_iy, m < p.M ? (unsigned)((m * p.in_ypitch + c0) * 2) : 0x80000000u, 0, 0);
             }
+            prefetch_shortcut(j + 1);       // in flight under this stage's multiplication
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's fragments are written (LDS only: the y stores and the prefetch stay in flight)
             __builtin_amdgcn_s_barrier();   // every fragment of the stage is y now
         }
         const unsigned char* st = smem + (j % G::NS) * G::STAGE + (wp * G::MP) * KS * 1024 + lane * 16;
@@ -230,7 +240,7 @@ static bool s1_plan(const ConvArgs& a, S1Plan& pl, int in = 0) {   // in: 0 plai
     }
     const int ks = k;
     const int is = ks == 24 ? 48 : 32;
-    const int cb = is / ks / (in == 2 ? 2 : 1), wp = 4 / wc, mp = cb / wp;
+    const int cb = is / ks, wp = 4 / wc, mp = cb / wp;
     if (mp < 1) return false;
     pl.fg = fg; pl.wc = wc; pl.ks = ks; pl.n_ct = n_ct; pl.in = in;
     pl.sp = cb * 32;

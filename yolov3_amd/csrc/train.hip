@@ -282,9 +282,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ u
         V16<T> o;
 #pragma unroll
         for (int q = 0; q < V / 2; ++q) {
-            f32x2 z = ld2<T>(x, 2 * q) * sc[q] + sh[q];
-            if (SILU) z = z * sigmoid2(z);
-            if (res) z += ld2<T>(r, 2 * q);
+            const f32x2 z = y3_bn_act2(ld2<T>(x, 2 * q), sc[q], sh[q], SILU, res != nullptr, res ? ld2<T>(r, 2 * q) : f32x2{0.0f, 0.0f});   // (shared with conv_1x1s.h)
             st2<T>(o, 2 * q, z);
         }
         stv<NTS, T>(y + m * ypitch + cg * V, o);

@@ -107,6 +107,15 @@ Y3_DEV f32x2 sigmoid2(f32x2 z) {
     return e;
 }
 Y3_DEV f32x2 silu_grad2(f32x2 z, f32x2 s) { return s + z * s * (1.0f - s); }   // d silu(z)/dz with s = sigmoid(z)
+// y = act(scale u + shift) (+ shortcut) on a channel pair: ONE definition for the normalise pass (train.hip::bn_act_fwd_kernel) and for the same arithmetic applied on the way
+// into a 1x1 consumer (conv_1x1s.h) -- explicit fused multiply-adds and no contraction across the shortcut's add, so both places round alike whatever the optimiser prefers
+Y3_DEV f32x2 y3_bn_act2(f32x2 u, f32x2 sc, f32x2 sh, bool silu, bool has_res, f32x2 r) {
+#pragma clang fp contract(off)
+    f32x2 z = {__builtin_fmaf(u[0], sc[0], sh[0]), __builtin_fmaf(u[1], sc[1], sh[1])};
+    if (silu) z = z * sigmoid2(z);
+    if (has_res) z = z + r;
+    return z;
+}
 
 // rows of per-block partial sums behind the 2*C totals of y3_bn_stats / y3_bn_act_bwd scratch buffers
 #define Y3_BN_PARTIAL_ROWS 512   // (2048 rows measured slower: the partial-row sum grows faster than the reduction gains)
