@@ -21,5 +21,5 @@ rm -rf $R/gpurun_out/trpmc; mkdir -p $R/gpurun_out/trpmc
 for c in FETCH_SIZE WRITE_SIZE; do
   Y3_NO_EXCHANGE_LEG=1 timeout 200 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/trpmc/pmc_$c -o pmc -- python $R/bench.py --mode train --batch 64 --steps 2 --warmup 1 > $R/gpurun_out/trpmc_$c.log 2>&1; echo "exit $?" >> $R/gpurun_out/trpmc_$c.log
 done
-cd $R && python tools/pmc_traffic.py gpurun_out/trpmc 3 > gpurun_out/${TAG}_train_step_traffic_by_kernel.txt 2> gpurun_out/train_pmc_traffic.err; head -12 gpurun_out/${TAG}_train_step_traffic_by_kernel.txt | cut -c1-200
+cd $R && python tools/pmc_traffic.py gpurun_out/trpmc 4 > gpurun_out/${TAG}_train_step_traffic_by_kernel.txt 2> gpurun_out/train_pmc_traffic.err; head -12 gpurun_out/${TAG}_train_step_traffic_by_kernel.txt | cut -c1-200
 rm -rf gpurun_out/trpmc
