@@ -348,7 +348,9 @@ int y3_pack_filter_pair(const float* w_oihw, int32_t cout_src, int32_t cin_src, 
                         int32_t dtype, void* packed_fwd, void* packed_dgrad, void* stream);
 /* y3_pack_filter_pair for MANY layers in one launch (the training step re-packs every layer's banks each step).  `jobs` is a DEVICE
  * array; job i occupies blocks [first_block, first_block + y3_pack_job_blocks(...)) of a grid of total_blocks 256-thread blocks, the
- * jobs laid out back to back in array order.  packed_fwd / packed_dgrad may be NULL (that bank is not wanted).  f16 / bf16. */
+ * jobs laid out back to back in array order.  packed_fwd / packed_dgrad may be NULL (that bank is not wanted).  f16 / bf16.
+ * Only the elements that come from a weight are written (source-indexed 32 x 32 tiles, round 5): ZERO-FILL a bank once when it is allocated -- its row / K
+ * padding is never touched afterwards. */
 typedef struct y3_pack_job {
     const float* w;          /* OIHW fp32 weights (nn.Conv2d.weight) */
     void* packed_fwd;        /* y3_packed_filter_elems(cout, cin, ksize) elements, or NULL */

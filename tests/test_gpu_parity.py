@@ -2254,21 +2254,39 @@ def test_pack_filter_jobs_matches_per_layer_packing(dev, dtype):
     banks = []
     for i, (w, (co, ci, k)) in enumerate(zip(ws, shapes)):
         banks.append(jobs.add(w, (co + 7) // 8 * 8, ci, True, i != 3))
-    for b in banks:
+    # the contract (round 5, source-indexed tiles): banks are zero-filled once by whoever allocates them (PackJobs.add does), the launch writes only the elements that
+    # come from a weight.  Run 1 on the zero-filled banks: bit-identical to the per-layer packers.  Run 2 on banks full of a sentinel: every weight element (and its
+    # fragment-ordered copy) is rewritten, the row / K padding keeps the sentinel -- exactly cout_src * cin_src * k * k (x 2 with the second copy) elements change
+    for sentinel in (None, 7.0):
+        if sentinel is not None:
+            for b in banks:
+                for t in b:
+                    if t is not None:
+                        t.fill_(sentinel)
+        jobs.run()
+        torch.cuda.synchronize()
+        for i, (w, (co, ci, k)) in enumerate(zip(ws, shapes)):
+            cop = (co + 7) // 8 * 8
+            f_ref, d_ref = ops.pack_filter_pair(w, cop, ci, dtype)
+            pairs = [(banks[i][0], f_ref, "forward", f_ref.numel() == 2 * ((cop + 127) // 128 * 128) * ((k * k * ci + 63) // 64 * 64))]   # (3x3 banks of 256-row / 32-channel multiples carry a second copy)
+            if i != 3:
+                pairs.append((banks[i][1], d_ref, "data-gradient", d_ref.numel() == 2 * ((ci + 127) // 128 * 128) * ((k * k * cop + 63) // 64 * 64)))
+                assert torch.equal(d_ref.view(torch.int16), ops.pack_filter_dgrad(w, cop, ci, dtype).view(torch.int16))
+            else:
+                assert banks[i][1] is None
+            for got, ref, what, two_copies in pairs:
+                if sentinel is None:
+                    assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), f"{what} bank {i}"
+                else:
+                    kept = got.float() == sentinel
+                    assert torch.equal(got[~kept].view(torch.int16), ref[~kept].view(torch.int16)), f"{what} bank {i}: a written element differs"
+                    assert int((ref[kept].float() != 0).sum()) == 0, f"{what} bank {i}: a weight element was not written"
+                    assert int((~kept).sum()) == co * ci * k * k * (2 if two_copies else 1), f"{what} bank {i}: padding was written"
+    for b in banks:   # back to the contract's state for the rest of the test
         for t in b:
             if t is not None:
-                t.fill_(float("nan"))
+                t.zero_()
     jobs.run()
-    torch.cuda.synchronize()
-    for i, (w, (co, ci, k)) in enumerate(zip(ws, shapes)):
-        cop = (co + 7) // 8 * 8
-        f_ref, d_ref = ops.pack_filter_pair(w, cop, ci, dtype)
-        assert torch.equal(banks[i][0].view(torch.int16), f_ref.view(torch.int16)), f"forward bank {i}"
-        if i != 3:
-            assert torch.equal(banks[i][1].view(torch.int16), d_ref.view(torch.int16)), f"data-gradient bank {i}"
-            assert torch.equal(d_ref.view(torch.int16), ops.pack_filter_dgrad(w, cop, ci, dtype).view(torch.int16))
-        else:
-            assert banks[i][1] is None
     # a weight tensor that moved: the job table follows
     jobs.jobs[1] = (ws[1].clone() * 2.0,) + jobs.jobs[1][1:]
     jobs.run()

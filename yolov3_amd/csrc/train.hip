@@ -971,11 +971,17 @@ __global__ void pack_filter_pair_kernel(const float* __restrict__ src, int cout_
     }
 }
 
-// Every layer's banks in ONE launch: the training step re-packs all filters each step (the fp32 master weights moved); 75 pack
-// launches of 4-40 us (0.8 ms per batch-64 step, most of it launch-to-launch latency) become one.  A block finds its job by a binary
-// search over the jobs' first block (wave-uniform scalar loads), then does pack_filter_pair_kernel's work.
+// Every layer's banks in ONE launch: the training step re-packs all filters each step (the fp32 master weights moved); 75 pack launches of 4-40 us (0.8 ms per
+// batch-64 step, most of it launch-to-launch latency) became one in round 3.  Round 5: SOURCE-indexed tiles.  The destination-indexed form (a thread per bank element,
+// like the single-layer packers above) gathered the weights with a stride of 9 floats for the forward bank and of 9 Cin floats for the data-gradient bank -- 1.6 GB of
+// reads for 248 MB of weights, 0.54 ms.  Now a block owns a 32-filter x 32-channel tile: it reads the tile's 32 x (32 k k) floats as 32 contiguous runs, keeps them as T
+// in LDS ([tap][filter][channel]) and writes the four destinations -- forward bank (32 consecutive channels of a (filter, tap) = 64 bytes), data-gradient bank (32
+// consecutive filters of a (channel, flipped tap)), and the fragment-ordered copies of either -- from there.  ONLY the elements that come from a weight are written: row
+// padding (filters / channels beyond the source's) and K padding stay what they are, so the caller zero-fills a bank ONCE when it allocates it (ops.PackJobs does).
+// A block finds its job by a binary search over the jobs' first block (wave-uniform scalar loads).
 template <typename T>
 __global__ __launch_bounds__(256) void pack_filter_jobs_kernel(const y3_pack_job* __restrict__ jobs, int n_jobs) {
+    __shared__ T tile[9][32][34];   // (34: the transposed read of the data-gradient pass walks the filter index: 17 dwords apart)
     int lo = 0, hi = n_jobs - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -983,31 +989,50 @@ __global__ __launch_bounds__(256) void pack_filter_jobs_kernel(const y3_pack_job
     }
     const y3_pack_job j = jobs[lo];
     const float* __restrict__ src = j.w;
-    const int ks = j.ksize, cin = j.cin, cout = j.cout;
-    const int rows_f = (cout + 127) / 128 * 128, kpad_f = (ks * ks * cin + 63) / 64 * 64;
-    const int rows_d = (cin + 127) / 128 * 128, kpad_d = (ks * ks * cout + 63) / 64 * 64;
-    const long long idx = (long long)((int)blockIdx.x - j.first_block) * 256 + threadIdx.x;
-    if (j.packed_fwd && idx < (long long)rows_f * kpad_f) {
-        const int k = (int)(idx % kpad_f), co = (int)(idx / kpad_f);
+    const int ks = j.ksize, KK = ks * ks, cin = j.cin, cout = j.cout;
+    const int n_tci = (cin + 31) / 32;
+    const int t = (int)blockIdx.x - j.first_block;
+    const int co0 = (t / n_tci) * 32, ci0 = (t % n_tci) * 32;
+    if (co0 >= j.cout_src || ci0 >= j.cin_src) return;   // a tile of padding only (uniform)
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 32 * 32 * KK; e += 256) {
+        const int co_l = e / (32 * KK), r = e - co_l * (32 * KK);
+        const int ci_l = r / KK, tap = r - ci_l * KK;
+        const int co = co0 + co_l, ci = ci0 + ci_l;
         float v = 0.0f;
-        if (co < j.cout_src && k < ks * ks * cin) {
-            const int tap = k / cin, ci = k - tap * cin;
-            const int kh = tap / ks, kw = tap - kh * ks;
-            if (ci < j.cin_src) v = src[(((long long)co * j.cin_src + ci) * ks + kh) * ks + kw];
-        }
-        ((T*)j.packed_fwd)[idx] = from_f32<T>(v);
-        if (y3_filter_has_frag(cout, cin, ks) && k < 9 * cin) ((T*)j.packed_fwd)[(long long)rows_f * kpad_f + y3_frag_index(co, k, cin)] = from_f32<T>(v);
+        if (co < j.cout_src && ci < j.cin_src) v = src[((long long)co * j.cin_src + ci) * KK + tap];
+        tile[tap][co_l][ci_l] = from_f32<T>(v);
     }
-    if (j.packed_dgrad && idx < (long long)rows_d * kpad_d) {
-        const int k = (int)(idx % kpad_d), ci = (int)(idx / kpad_d);
-        float v = 0.0f;
-        if (ci < j.cin_src && k < ks * ks * cout) {
-            const int tap = k / cout, co = k - tap * cout;
-            const int kh = ks - 1 - tap / ks, kw = ks - 1 - tap % ks;
-            if (co < j.cout_src) v = src[(((long long)co * j.cin_src + ci) * ks + kh) * ks + kw];
+    __syncthreads();
+    const int rows_f = (cout + 127) / 128 * 128, kpad_f = (KK * cin + 63) / 64 * 64;
+    const int rows_d = (cin + 127) / 128 * 128, kpad_d = (KK * cout + 63) / 64 * 64;
+    if (j.packed_fwd) {
+        T* __restrict__ dst = (T*)j.packed_fwd;
+        const bool frag = y3_filter_has_frag(cout, cin, ks);
+        for (int e = tid; e < 32 * 32 * KK; e += 256) {
+            const int ci_l = e & 31, co_l = (e >> 5) & 31, tap = e >> 10;
+            const int co = co0 + co_l, ci = ci0 + ci_l;
+            if (co < j.cout_src && ci < j.cin_src) {
+                const T v = tile[tap][co_l][ci_l];
+                const int k = tap * cin + ci;
+                dst[(long long)co * kpad_f + k] = v;
+                if (frag) dst[(long long)rows_f * kpad_f + y3_frag_index(co, k, cin)] = v;   // the copy conv_v10.h reads (y3_common.h)
+            }
         }
-        ((T*)j.packed_dgrad)[idx] = from_f32<T>(v);
-        if (y3_filter_has_frag(cin, cout, ks) && k < 9 * cout) ((T*)j.packed_dgrad)[(long long)rows_d * kpad_d + y3_frag_index(ci, k, cout)] = from_f32<T>(v);
+    }
+    if (j.packed_dgrad) {
+        T* __restrict__ dst = (T*)j.packed_dgrad;
+        const bool frag = y3_filter_has_frag(cin, cout, ks);
+        for (int e = tid; e < 32 * 32 * KK; e += 256) {
+            const int co_l = e & 31, ci_l = (e >> 5) & 31, tap = e >> 10;
+            const int co = co0 + co_l, ci = ci0 + ci_l;
+            if (co < j.cout_src && ci < j.cin_src) {
+                const T v = tile[tap][co_l][ci_l];
+                const int k = (KK - 1 - tap) * cout + co;   // flipped tap (kh, kw) -> (ks - 1 - kh, ks - 1 - kw)
+                dst[(long long)ci * kpad_d + k] = v;
+                if (frag) dst[(long long)rows_d * kpad_d + y3_frag_index(ci, k, cout)] = v;
+            }
+        }
     }
 }
 
@@ -1625,10 +1650,8 @@ extern "C" int y3_pack_filter_pair(const float* w, int32_t cout_src, int32_t cin
 
 // blocks a job of y3_pack_filter_jobs occupies (the caller lays the jobs out back to back: first_block = running sum)
 extern "C" int64_t y3_pack_job_blocks(int32_t ksize, int32_t cout, int32_t cin, int32_t want_fwd, int32_t want_dgrad) {
-    const long long tf = want_fwd ? (long long)y3_filter_rows(cout) * y3_filter_kpad(cin, ksize) : 0;
-    const long long td = want_dgrad ? (long long)y3_filter_rows(cin) * y3_filter_kpad(cout, ksize) : 0;
-    const long long total = tf > td ? tf : td;
-    return (total + 255) / 256;
+    (void)ksize; (void)want_fwd; (void)want_dgrad;
+    return (int64_t)((cout + 31) / 32) * ((cin + 31) / 32);   // one block per 32-filter x 32-channel tile of the weights
 }
 
 extern "C" int y3_pack_filter_jobs(const y3_pack_job* jobs_device, int32_t n_jobs, int64_t total_blocks, int32_t dtype, void* stream) {

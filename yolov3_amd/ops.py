@@ -459,8 +459,9 @@ class PackJobs:
 
     def add(self, w: torch.Tensor, cout: int, cin: int, want_fwd: bool = True, want_dgrad: bool = True):
         co, ci, k, _ = w.shape
-        fwd = torch.empty(packed_filter_elems(cout, cin, k), dtype=self.dtype, device=self.device) if want_fwd else None
-        dg = torch.empty(packed_filter_elems(cin, cout, k), dtype=self.dtype, device=self.device) if want_dgrad else None
+        # zero-filled ONCE: y3_pack_filter_jobs writes only the elements that come from a weight (the row / K padding of a bank stays zero)
+        fwd = torch.zeros(packed_filter_elems(cout, cin, k), dtype=self.dtype, device=self.device) if want_fwd else None
+        dg = torch.zeros(packed_filter_elems(cin, cout, k), dtype=self.dtype, device=self.device) if want_dgrad else None
         self.jobs.append((w, fwd, dg, cout, cin))
         self._table = None
         return fwd, dg
