@@ -174,9 +174,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // squares of the lane's 8 filters) instead of being written; epilogue_stats_flush writes ONE row for all the calls.
 // IDENT (conv_v10.h: stride 1, no upsample scatter, no parity-class output): the output pixel index IS the GEMM column m, so the lane's store offsets are plain
 // arithmetic on m -- no (image, row, column) decomposition, no 64-bit products, no ds_bpermute from the MFMA layout to the store layout.
-// MPA, BOFF (conv_1x1s.h): the call covers column blocks BOFF .. BOFF + MP - 1 of the caller's MPA accumulator tiles, read in place (no per-pass copy).
-template <typename T, int MC, int MP, bool STAT_ACC = false, bool IDENT = false, int MPA = MP, int BOFF = 0>
-Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MPA], unsigned char* wl, int c_base, int m_base, int lane, int stat_row = -1, int m_end = 0x7fffffff,
+template <typename T, int MC, int MP, bool STAT_ACC = false, bool IDENT = false>
+Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MP], unsigned char* wl, int c_base, int m_base, int lane, int stat_row = -1, int m_end = 0x7fffffff,
                           float* sacc = nullptr) {
     typedef typename Mfma<T>::frag vec8;   // 8 x T = one 16-byte chunk
     constexpr int CH = MC * 4;          // 16-byte chunks per pixel row of this wave's slice
@@ -247,7 +246,7 @@ Y3_DEV void epilogue_wave(const ConvArgs& p, f32x16 (&acc)[MC][MPA], unsigned ch
                 for (int gp = 0; gp < 2; ++gp) {
                     f32x8 v;   // filters 16gp + 4fk + (0..3) and 16gp + 8 + 4fk + (0..3)
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] = acc[a][BOFF + b][8 * gp + q];
+                    for (int q = 0; q < 8; ++q) v[q] = acc[a][b][8 * gp + q];
                     if (decltype(silu)::value) silu_vec<f32x8, 8>(v);
                     u32x4 ov;
 #pragma unroll
