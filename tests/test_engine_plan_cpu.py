@@ -217,7 +217,7 @@ def test_deferred_shortcut_gradient_state_machine():
 
 def test_train_plan_pairs_bn_consumers(monkeypatch):
     """Consumer-side BatchNorm (TrainPlan._pair_bn_consumers): a Conv unit immediately followed by the 1x1 Conv unit that reads its output hands its normalise + activation
-    (+ shortcut) pass to that unit's launch where the library's input-transform form covers the shape -- in yolov3 the first cv1 of the 320 / 160 / 80 stages behind their
+    (+ shortcut) pass to that unit's launch where the library's input-transform form covers the shape -- in yolov3 the first cv1 of the 160 / 80 stages behind their
     stride-2 Conv, and cv2 -> the next cv1 inside the 160 / 80 stages and the last neck block; never across a Concat slice, never for the 3x3 consumers."""
     import torch
 
@@ -228,12 +228,12 @@ def test_train_plan_pairs_bn_consumers(monkeypatch):
     m = DetectionModel("yolov3.yaml", nc=80).train()
     p = TrainPlan.build(m, 2, 640, 640, torch.float16, cpu, TrainSlot(torch.float16, cpu))
     pairs = [(u.bn_in.label, u.label, u.bn_in.res is not None) for u in p.units if isinstance(u, ConvUnit) and u.bn_in is not None]
-    assert pairs[:5] == [("L1", "L2.0.cv1", False), ("L3", "L4.0.cv1", False), ("L4.0.cv2", "L4.1.cv1", True), ("L5", "L6.0.cv1", False), ("L6.0.cv2", "L6.1.cv1", True)]
-    assert len(pairs) == 13 and pairs[-2:] == [("L26.0.cv2", "L27.0.cv1", False), ("L27.0.cv2", "L27.1.cv1", False)]
+    assert pairs[:4] == [("L3", "L4.0.cv1", False), ("L4.0.cv2", "L4.1.cv1", True), ("L5", "L6.0.cv1", False), ("L6.0.cv2", "L6.1.cv1", True)]   # (64 -> 32 behind layer 1: measured slower, not covered)
+    assert len(pairs) == 12 and pairs[-2:] == [("L26.0.cv2", "L27.0.cv1", False), ("L27.0.cv2", "L27.1.cv1", False)]
     for u in p.units:
         if isinstance(u, ConvUnit) and u.bn_in is not None:
             assert u.k == 1 and u.bn_in.act_in_consumer and u.x is u.bn_in.y and u.bnin_rows > 0 and u.cin <= 256
-    assert sum(1 for u in p.units if isinstance(u, ConvUnit) and u.act_in_consumer) == 13
+    assert sum(1 for u in p.units if isinstance(u, ConvUnit) and u.act_in_consumer) == 12
     # fp32 plans and Y3_BN_IN_CONSUMER=0 keep the separate passes
     r = TrainPlan.build(m, 2, 640, 640, torch.float32, cpu, TrainSlot(torch.float32, cpu))
     assert not any(isinstance(u, ConvUnit) and u.bn_in is not None for u in r.units)

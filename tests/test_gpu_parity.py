@@ -223,7 +223,6 @@ BNIN_CASES = [
     ("256_128_many_stages", (20, 40, 40, 256, 128), True, True),         # 1000 stages on 256 blocks
     ("128_64_shortcut", (5, 33, 31, 128, 64), True, True),               # two pixel waves, one column block each
     ("128_64_plain_noact", (2, 50, 50, 128, 64), False, False),
-    ("64_32_plain", (2, 36, 36, 64, 32), False, True),                   # four pixel waves
     ("one_pixel", (1, 1, 1, 256, 128), True, True),
 ]
 
