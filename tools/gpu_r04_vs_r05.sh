@@ -1,6 +1,8 @@
 # same box: the round-4 tree (git archive 89af238 in _r04tree/, its own library) against this tree -- two interleaved rounds of the inference line (r04's `value` is the
 # synthetic-tensor NMS form: compared with r05's `synthetic_nms_tensor.images_per_sec`; r05's own-output `value` beside it) and of the batch-64 train step
+# prepare once, here (the tree is git-ignored): mkdir _r04tree && git archive 89af238 | tar -x -C _r04tree && (cd _r04tree && python -c 'import __graft_entry__ as g; g.build()')
 mkdir -p gpurun_out
+[ -d _r04tree ] || { echo '_r04tree/ missing: see the line above'; exit 1; }
 out=gpurun_out/r05_same_box_r04_vs_r05.txt
 echo "# same box, interleaved; infer: python bench.py --steps 30 --warmup 5 --no-train --no-cpu-baseline --no-clocks; train: python bench.py --mode train --batch 64 --steps 10 --warmup 4" > $out
 R=$PWD
