@@ -162,7 +162,8 @@ def run_train(args, rank, world, dev, parallel, yo, batch, steps, warmup):
     model.hyp = dict(box=0.05, cls=0.5, cls_pw=1.0, obj=1.0, obj_pw=1.0, anchor_t=4.0, fl_gamma=0.0, label_smoothing=0.0)
     parallel.broadcast_parameters(model)
     if world > 1:
-        model.grad_sync = parallel.GradBuckets()
+        model.grad_sync = parallel.GradBuckets()   # the collective of a bucket: Y3_GRAD_EXCHANGE = all_reduce (default) | direct (parallel.GradBuckets)
+    sync_form = model.grad_sync.exchange if world > 1 else None
     crit = ComputeLoss(model)
     # the reference's optimizer step (train.py:414-422): unscale_ + clip_grad_norm_(10) + SGD(nesterov, 3 param groups) + EMA (rank 0),
     # here the fused 3-launch kernel; weight decay scaled by total batch / 64 (train.py:236-237)
@@ -241,7 +242,7 @@ def run_train(args, rank, world, dev, parallel, yo, batch, steps, warmup):
         "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f16" if args.dtype == "fp16" else "bf16", "data": "synthetic (seeded uniform images, Poisson(7) targets/img; random-init weights)",
         "config": {"workload": f"{args.model} train step {hw}x{hw} batch={bs}/GPU autocast {args.dtype}: fwd (batch-stat BN) + ComputeLoss + bwd + grad all-reduce + fused unscale/clip/SGD-nesterov/EMA [BASELINE configs[2]]",
-                   "global_batch": world * bs, "parallelism": f"dp{world} (bucketed all-reduce overlapped with backward)"},
+                   "global_batch": world * bs, "parallelism": f"dp{world} (bucketed gradient average overlapped with backward)", "gradient_exchange": sync_form},
         "final_loss": float(loss.detach()), "loss_scale": scaler.get_scale(), "gradient_exchange_1rank": exchange, "process_group": group,
         "roofline": {"bound": "mfma", "achieved": round(tflops, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / MFMA_PEAK_TFLOPS, 4),
                      "whole_step_frac": round(tflops / MFMA_PEAK_TFLOPS, 4), "gflop_per_image": round(flops_img / 1e9, 2),

@@ -1982,10 +1982,10 @@ def test_gradient_exchange_over_rccl_one_rank(dev):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("backend", ["nccl", "gloo"])
-def test_gradient_exchange_two_ranks(tmp_path, backend):
+@pytest.mark.parametrize("backend,exchange", [("nccl", "all_reduce"), ("gloo", "all_reduce"), ("nccl", "direct"), ("gloo", "direct")])
+def test_gradient_exchange_two_ranks(tmp_path, backend, exchange):
     """two ranks through torch.distributed.run: both ranks end with the same averaged gradients = mean of the two single-rank gradients, on
-    device buffers.  nccl (RCCL, one GPU per rank) needs two GPUs; gloo runs on the 1-GPU box too -- the two ranks share the device
+    device buffers, with either form of the bucket collective (parallel.GradBuckets: one all-reduce, or all-to-all + owner's sum + all-gather).  nccl (RCCL, one GPU per rank) needs two GPUs; gloo runs on the 1-GPU box too -- the two ranks share the device
     (parallel.local_device), the collective goes through the host: the same rendezvous, rank / device mapping, bucket, side-stream and
     SUM + divide code as a multi-GPU job, which is what has to work the first time the driver launches N > 1."""
     import subprocess
@@ -2011,7 +2011,7 @@ crit = ComputeLoss(m)
 x = torch.rand(4, 3, 128, 128, generator=torch.Generator().manual_seed(10 + rank)).to(dev)
 tg = yo.synth_targets(4, 80, seed=20 + rank).to(dev)
 def grads(sync):
-    m.grad_sync = parallel.GradBuckets(bucket_bytes=8 << 20) if sync else None
+    m.grad_sync = parallel.GradBuckets(bucket_bytes=8 << 20, exchange={exchange!r}) if sync else None
     m.zero_grad(set_to_none=True)
     with torch.autocast("cuda", dtype=torch.float16):   # the product path: MFMA kernels, fixed-order reductions (the fp32 parity path's direct filter gradient uses fp32 atomics)
         loss = crit(m(x), tg)[0]
@@ -2020,6 +2020,7 @@ def grads(sync):
     return torch.cat([p.grad.flatten() for p in m.parameters()])
 own = grads(False)
 avg = grads(True)
+assert m.grad_sync.collectives[{exchange!r}] >= 2 and sum(m.grad_sync.collectives.values()) == m.grad_sync.collectives[{exchange!r}], m.grad_sync.collectives
 ref = own.clone()
 torch.distributed.all_reduce(ref)
 ref /= world
@@ -2029,7 +2030,7 @@ assert torch.equal(avg, ref), (float((avg - ref).abs().max()), float(ref.abs().m
 print("rank", rank, "ok")
 parallel.finalize()
 """)
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(29533 + (exchange == "direct")), str(script)],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.count("ok") == 2, out.stdout + out.stderr
 

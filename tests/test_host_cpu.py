@@ -137,7 +137,10 @@ def test_replica_helpers_world2_gloo():
     assert all(r[5:] == ("gloo", 2, [0, 1], 2) for r in res), res   # both ranks report the same two-process group
 
 
-def _ddp_worker(rank, world, port, q):
+_DDP_SHAPES = [("a", (3, 5)), ("b", (7,)), ("c", (2, 2, 2)), ("d", (33,))]
+
+
+def _ddp_worker(rank, world, port, q, exchange, arena):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, str(ROOT))
     import torch
@@ -147,37 +150,63 @@ def _ddp_worker(rank, world, port, q):
     torch.manual_seed(rank)
     lin = torch.nn.Linear(8, 4)
     parallel.broadcast_parameters(lin, src=0)
-    gb = parallel.GradBuckets(bucket_bytes=64)  # tiny buckets -> several collectives
+    gb = parallel.GradBuckets(bucket_bytes=64, exchange=exchange)  # tiny buckets -> several collectives
     g = torch.Generator().manual_seed(100 + rank)
-    grads = {name: torch.randn(shape, generator=g) for name, shape in [("a", (3, 5)), ("b", (7,)), ("c", (2, 2, 2)), ("d", (33,))]}
+    grads = {name: torch.randn(shape, generator=g) for name, shape in _DDP_SHAPES}
+    if arena:   # the training plan's layout: 64-element slices of one flat fp32 tensor, handed over in the order they sit in it -> reduced in place
+        flat, off, views = torch.full((64 * 8,), float("nan")), 0, {}
+        for k in ["d", "c", "b", "a"]:
+            n = grads[k].numel()
+            views[k] = flat[off : off + n].view(grads[k].shape)
+            views[k].copy_(grads[k])
+            off += (n + 63) // 64 * 64
+        grads = views
     for k in ["d", "c", "b", "a"]:  # reverse layer order, like the backward plan
         gb.add(k, grads[k])
     out = gb.finish()
-    q.put((rank, {k: v.tolist() for k, v in out.items()}, lin.weight.detach().tolist()))
+    in_place = all(out[k].data_ptr() == grads[k].data_ptr() for k in out)
+    q.put((rank, {k: v.tolist() for k, v in out.items()}, lin.weight.detach().tolist(), dict(gb.collectives), in_place))
     parallel.finalize()
 
 
-def test_gradient_buckets_average_world2_gloo():
-    """the data-parallel exchange step (bucketed all-reduce average, DDP semantics) on 2 CPU ranks"""
+@pytest.mark.parametrize("world,exchange,arena", [(2, "all_reduce", False), (2, "all_reduce", True), (2, "direct", False), (2, "direct", True), (3, "direct", False)])
+def test_gradient_buckets_average_gloo(world, exchange, arena):
+    """the data-parallel exchange step (bucketed average, DDP semantics) on 2-3 CPU ranks: the all-reduce form and the two-phase direct form
+    (all-to-all of the shards, owner's sum, all-gather), flattened buckets and in-place ranges of a gradient arena"""
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 31500 + (os.getpid() * 7 + world * 3 + len(exchange) + arena) % 2000
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q, exchange, arena)) for r in range(world)]
     [p.start() for p in procs]
-    res = sorted((q.get(timeout=120) for _ in range(2)), key=lambda r: r[0])
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda r: r[0])
     [p.join(60) for p in procs]
-    exp = {}
-    for name, shape in [("a", (3, 5)), ("b", (7,)), ("c", (2, 2, 2)), ("d", (33,))]:
-        pass
-    gens = [torch.Generator().manual_seed(100 + r) for r in range(2)]
-    per_rank = [{name: torch.randn(shape, generator=g) for name, shape in [("a", (3, 5)), ("b", (7,)), ("c", (2, 2, 2)), ("d", (33,))]} for g in gens]
+    gens = [torch.Generator().manual_seed(100 + r) for r in range(world)]
+    per_rank = [{name: torch.randn(shape, generator=g) for name, shape in _DDP_SHAPES} for g in gens]
     for k in "abcd":
-        mean = (per_rank[0][k] + per_rank[1][k]) / 2
-        for r in range(2):
-            torch.testing.assert_close(torch.tensor(res[r][1][k]), mean)
-    assert res[0][2] == res[1][2]  # parameters broadcast from rank 0
+        tot = per_rank[0][k].clone()
+        for r in range(1, world):
+            tot += per_rank[r][k]            # rank order: what the direct form's owner computes
+        mean = tot * (1.0 / world) if exchange == "direct" else tot / world
+        for r in range(world):
+            got = torch.tensor(res[r][1][k])
+            if world == 2 or exchange == "direct":
+                assert torch.equal(got, mean), k
+            else:
+                torch.testing.assert_close(got, mean)
+            assert res[r][1][k] == res[0][1][k]   # replicas stay bit-identical
+    assert all(r[2] == res[0][2] for r in res)  # parameters broadcast from rank 0
+    for r in res:
+        assert r[3][exchange] >= 2 and r[3]["direct" if exchange == "all_reduce" else "all_reduce"] == 0, r[3]   # every bucket took the requested form
+        assert r[4] == arena   # arena slices are averaged where they lie; loose tensors come back as views of the flattened bucket
+
+
+def test_gradient_buckets_reject_unknown_exchange():
+    from yolov3_amd import parallel
+
+    with pytest.raises(ValueError, match="exchange"):
+        parallel.GradBuckets(exchange="ring")
 
 
 def test_reference_checkpoint_unpickles_into_hip_modules(tmp_path):

@@ -111,10 +111,26 @@ class GradBuckets:
     backward produces them (train_engine.TrainPlan.grad_alloc), so a bucket is a contiguous range of that arena and is
     all-reduced IN PLACE with ReduceOp.AVG (RCCL divides on the wire); the tensors autograd receives are views of the
     arena.  Gradients that are not arena views (or a bf16 wire) take the flatten / copy-back path.
+
+    `exchange` (or the environment variable Y3_GRAD_EXCHANGE) picks the collective of a bucket:
+      "all_reduce"  one RCCL all-reduce(AVG) per bucket (the default: RCCL chooses its rings / channels over the xGMI mesh);
+      "direct"      the two-phase exchange SURVEY 8(e) prices for the fully connected mesh: every rank owns 1/P of the bucket,
+                    phase 1 all-to-all sends each peer its shard (P-1 point-to-point transfers per rank, one per link, at once), the owner sums the
+                    P contributions in rank order and scales by 1/P, phase 2 all-gathers the averaged shards back in place.  Wire bytes per link and
+                    phase: bucket / P (31 MB for yolov3's 247.8 MB at P = 8) instead of a ring's 2 (P-1)/P x bucket over one link.  Every rank receives
+                    the owner's sum, so the replicas stay bit-identical whatever P is.  Needs one receive buffer of the bucket's size.
+                    Buckets whose length P does not divide take the all-reduce.  NOT measured on an 8-GPU node (the build box has one GPU): opt-in.
     """
 
-    def __init__(self, bucket_bytes: int = 64 << 20, wire_dtype: torch.dtype | None = None, group=None, force: bool = False):
+    EXCHANGES = ("all_reduce", "direct")
+
+    def __init__(self, bucket_bytes: int = 64 << 20, wire_dtype: torch.dtype | None = None, group=None, force: bool = False, exchange: str | None = None):
         self.bucket_bytes, self.wire_dtype, self.group = bucket_bytes, wire_dtype, group
+        self.exchange = exchange or os.environ.get("Y3_GRAD_EXCHANGE", "all_reduce")
+        if self.exchange not in self.EXCHANGES:
+            raise ValueError(f"GradBuckets: exchange {self.exchange!r} is not one of {self.EXCHANGES}")
+        self.collectives = {"all_reduce": 0, "direct": 0}   # buckets sent by each form since construction (tests, bench line)
+        self._recv = None          # the direct form's receive buffer (grown to the largest bucket, reused: collectives of one side stream run in order)
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.force = force   # run the bucket / side-stream / collective machinery even at world size 1 (single-GPU tests of the exchange step)
         self._pending: list = []   # (keys, tensors) of the bucket being filled
@@ -175,10 +191,32 @@ class GradBuckets:
         """average `flat` over the ranks, in place; returns the async work handle"""
         if not (dist.is_available() and dist.is_initialized()):
             return None
+        if self.exchange == "direct" and self.world > 1 and flat.numel() % self.world == 0 and flat.numel() > 0:
+            return self._reduce_direct(flat)
+        self.collectives["all_reduce"] += 1
         if dist.get_backend(self.group) == "nccl":
             return dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)   # RCCL averages on the wire: no divide pass
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         return (work, flat)   # gloo has no AVG: divide after the wait
+
+    def _reduce_direct(self, flat):
+        """all-to-all of the shards, the owner's rank-ordered sum x 1/P, all-gather in place (class docstring); returns the all-gather's handle.
+        Called on the side stream: wait() of the first phase orders that stream (not the host, with RCCL) behind the transfer."""
+        P, n = self.world, flat.numel() // self.world
+        rank = dist.get_rank(self.group)
+        if self._recv is None or self._recv.numel() < flat.numel() or self._recv.device != flat.device or self._recv.dtype != flat.dtype:
+            self._recv = torch.empty(flat.numel(), dtype=flat.dtype, device=flat.device)
+        recv = self._recv[: flat.numel()]
+        dist.all_to_all_single(recv, flat, group=self.group, async_op=True).wait()   # recv.view(P, n)[r] = rank r's copy of MY shard
+        mine = flat[rank * n : (rank + 1) * n]
+        parts = recv.view(P, n)
+        acc = parts[0].clone() if P > 1 else parts[0]
+        for r in range(1, P):        # fixed order 0 .. P-1 on the one rank that computes this shard
+            acc.add_(parts[r])
+        torch.mul(acc, 1.0 / P, out=mine)
+        self.collectives["direct"] += 1
+        nccl = dist.get_backend(self.group) == "nccl"
+        return dist.all_gather_into_tensor(flat, mine if nccl else mine.clone(), group=self.group, async_op=True)   # RCCL gathers in place (send == recv + rank x n)
 
     def _launch(self):
         if not self._pending:
@@ -200,12 +238,19 @@ class GradBuckets:
                 self._ranges.append((base, lo, hi))
 
         def issue():
+            direct = self.exchange == "direct" and self.world > 1
             if rng is not None:
                 base, lo, hi = rng
+                if direct:                  # the last member's own pad (the arena hands out 64-element slices) makes the length divisible by P = 2 .. 64
+                    hi = min(base.numel(), (hi + 63) // 64 * 64)
                 flat = base[lo:hi]          # padding between slices rides along (<= 252 B per tensor); the slices ARE the results
                 return flat, self._reduce(flat), None
             wire = self.wire_dtype or torch.float32
-            flat = torch.cat([t.reshape(-1).to(wire) for t in tensors])
+            parts = [t.reshape(-1).to(wire) for t in tensors]
+            n = sum(p.numel() for p in parts)
+            if direct and n % self.world:
+                parts.append(torch.zeros(self.world - n % self.world, dtype=wire, device=dev))
+            flat = torch.cat(parts)
             return flat, self._reduce(flat), [(t.shape, t.dtype) for t in tensors]
 
         if side is not None:
@@ -223,7 +268,7 @@ class GradBuckets:
         """Flush the last bucket, wait for every collective, return {key: averaged gradient}."""
         self._launch()
         for work, flat, keys, tensors, meta, side in self._inflight:
-            if isinstance(work, tuple):      # gloo: SUM + divide
+            if isinstance(work, tuple):      # gloo all-reduce: SUM + divide
                 work[0].wait()
                 flat.div_(self.world)
             elif work is not None:
