@@ -1,5 +1,7 @@
 # nms_candidates_kernel with batched row loads: full GPU suite + smoke on the new library, then the same box's inference line with the previous NMS object
 # (yolov3_amd/lib/libyolov3_hip_prev.so = HEAD's detect_nms.hip linked with the same other objects, via Y3_LIB) and the new one, interleaved
+# prepare here: git show <previous commit>:yolov3_amd/csrc/detect_nms.hip compiled with build()'s flags (-I yolov3_amd/csrc -I include) to an object, linked with the
+# other objects of yolov3_amd/build/ into yolov3_amd/lib/libyolov3_hip_prev.so (git-ignored, travels with the snapshot); delete it afterwards
 mkdir -p gpurun_out
 out=gpurun_out/r05_nms_row_batch_ab.txt
 timeout 1200 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/r05_pytest_gpu_full.log 2>&1; echo "pytest exit $?" | tee -a gpurun_out/r05_pytest_gpu_full.log
