@@ -251,6 +251,90 @@ print("ok")
     assert out.strip().endswith("ok")
 
 
+
+def _run_py(code, cwd):
+    return subprocess.check_output([sys.executable, "-c", code], cwd=cwd, text=True, stderr=subprocess.STDOUT)
+
+
+def test_attempt_load_inside_a_live_reference_process(tmp_path):
+    """the drop-in scenario itself (round-5 review, weak 1a): a process that has the REAL reference modules imported.
+    (i) real ``models.yolo`` imported first (train.py:50-51, hubconf.py:48): attempt_load still returns yolov3_amd classes and the real
+    modules stay what they were; (ii) only the real ``models.common`` imported (val.py:39, detect.py:46): attempt_load works and
+    ``from models.common import AutoShape, DetectMultiBackend`` (utils/general.py:432) still resolves to the reference's own;
+    (iii) an object of the reference's classes (built by the reference, or unpickled by its own torch.load) is re-classed by
+    compat.adopt and its parameters are untouched."""
+    from oracle import ref_shim
+
+    if not ref_shim.available():
+        pytest.skip("reference tree not present on this box")
+    ckpt = ROOT / "tests" / "golden" / "ref_tiny_w025_fp16.pt"
+    code = f"""
+import sys, torch
+sys.path.insert(0, {str(ROOT)!r})
+from oracle import ref_shim
+ns = ref_shim.load()                      # imports the unmodified models.yolo / models.common
+import models.yolo as real_yolo, models.common as real_common
+assert real_yolo.__file__.startswith('/root/reference')
+from yolov3_amd import compat, DetectionModel, Detect
+from yolov3_amd.common import Conv
+before = (sys.modules['models'], sys.modules['models.yolo'], sys.modules['models.common'])
+assert compat.install_aliases() is False and compat.install_aliases(force=True) is False
+m = compat.attempt_load({str(ckpt)!r}, device='cpu', fuse=False)
+assert type(m) is DetectionModel and type(m.model[-1]) is Detect and type(m.model[0]) is Conv, type(m)
+assert before == (sys.modules['models'], sys.modules['models.yolo'], sys.modules['models.common'])
+from models.common import AutoShape, DetectMultiBackend
+assert AutoShape.__module__ == 'models.common' and sys.modules['models.common'].__file__.startswith('/root/reference')
+# (iii) the reference's own torch.load gives the reference's classes; adopt re-classes them in place
+ref_obj = torch.load({str(ckpt)!r}, map_location='cpu', weights_only=False)['model']
+assert type(ref_obj) is real_yolo.DetectionModel
+sd = {{k: v.clone() for k, v in ref_obj.state_dict().items()}}
+ours = compat.adopt(ref_obj)
+assert type(ours) is DetectionModel and all(not type(x).__module__.startswith('models.') for x in ours.modules())
+assert set(sd) == set(ours.state_dict()) and all(torch.equal(sd[k], v) for k, v in ours.state_dict().items())
+assert type(ours.float().fuse()) is DetectionModel and not any('.bn.' in k for k in ours.state_dict())
+print('ok')
+"""
+    assert _run_py(code, tmp_path).strip().endswith("ok")
+    code2 = f"""
+import sys, torch
+sys.path.insert(0, {str(ROOT)!r})
+from oracle import ref_shim
+ref_shim.install()                        # stubs for the absent third-party packages + /root/reference on sys.path
+import models.common as real_common       # val.py:39 / detect.py:46 import models.common only
+assert 'models.yolo' not in sys.modules
+from yolov3_amd import compat, DetectionModel
+m = compat.attempt_load({str(ckpt)!r}, device='cpu')
+assert type(m) is DetectionModel
+assert sys.modules['models.common'] is real_common and 'models.yolo' not in sys.modules
+from models.common import AutoShape, DetectMultiBackend
+assert AutoShape.__module__ == 'models.common' and real_common.__file__.startswith('/root/reference')
+print('ok')
+"""
+    assert _run_py(code2, tmp_path).strip().endswith("ok")
+
+
+def test_alias_modules_only_in_a_process_without_the_reference(tmp_path):
+    """install_aliases is for plain torch.load in a bare process (the GPU box): there the aliases resolve the pickled paths, carry the
+    names utils/general.py:432 imports, and uninstall cleanly; attempt_load itself never touches sys.modules."""
+    ckpt = ROOT / "tests" / "golden" / "ref_tiny_w025_fp16.pt"
+    code = f"""
+import sys, torch
+sys.path.insert(0, {str(ROOT)!r})
+from yolov3_amd import compat, DetectionModel
+m = compat.attempt_load({str(ckpt)!r}, device='cpu')
+assert type(m) is DetectionModel and not any(k == 'models' or k.startswith('models.') for k in sys.modules)
+assert compat.install_aliases() is True
+from models.common import AutoShape, DetectMultiBackend, Conv
+from models.experimental import attempt_load
+obj = torch.load({str(ckpt)!r}, map_location='cpu', weights_only=False)['model']
+assert type(obj) is DetectionModel
+compat.uninstall_aliases()
+assert not any(k == 'models' or k.startswith('models.') for k in sys.modules)
+print('ok')
+"""
+    assert _run_py(code, tmp_path).strip().endswith("ok")
+
+
 # ------------------------------------------------------------------------------------------------ host logic of the val / detect edges
 def test_letterbox_geometry_matches_oracle_letterbox():
     """autoshape.letterbox_geometry (what the device letterbox is launched with) against the oracle's restatement of reference
