@@ -1262,10 +1262,11 @@ BIG_WGRAD_CASES = [
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("name,shape", BIG_WGRAD_CASES, ids=[c[0] for c in BIG_WGRAD_CASES])
-def test_conv_wgrad_256_tile_vs_autograd(dev, dtype, name, shape):
-    """the 8-wave 256x256-tile filter-gradient kernel (Cout % 256 == 0, K >= 1152, >= 16384 pixels: the shapes it is
-    dispatched for) against torch autograd in fp32 on the same rounded operands."""
+def test_conv_wgrad_256_tile_vs_autograd(dev, tune, dtype, name, shape):
+    """the 8-wave 256x256-tile filter-gradient kernel (Cout % 256 == 0, K >= 1152, >= 16384 pixels: since round 6 the stride-2 layers and
+    whatever wgrad_patch.h does not take -- forced here with knob wgrad_patch = 0) against torch autograd in fp32 on the same rounded operands."""
     _lib, ops = _ops()
+    tune("wgrad_patch", 0)
     n, h, w, cin, cout, k, s = shape
     g = torch.Generator().manual_seed(5)
     x = torch.randn(n, cin, h, w, generator=g).to(dtype).float()
@@ -1286,6 +1287,63 @@ def test_conv_wgrad_256_tile_vs_autograd(dev, dtype, name, shape):
     tol = {torch.float16: 2e-3, torch.bfloat16: 1.5e-2}[dtype]
     e_w = (dw.cpu() - wt.grad).abs().max().item() / wt.grad.abs().max().item()
     assert e_w < tol, f"{name} {dtype}: wgrad {e_w:.2e}"
+
+
+PATCH_WGRAD_CASES = [
+    # name, (n, h, w, cin, cout), channel-slice operands (pitch > C)
+    ("80x80_4tiles", (3, 80, 80, 128, 256), False),          # the 128 -> 256 layers: 4 block tiles, slices cross rows and images
+    ("40x40_16tiles", (5, 40, 40, 256, 512), False),
+    ("20x20_one_tile", (7, 20, 20, 64, 128), False),         # one block tile: every block is a slice of it; ring base wraps many times
+    ("odd_37x23", (3, 23, 37, 64, 128), False),              # odd extents: pad columns / rows at every phase of the 64-position stage
+    ("narrow_w5_tall", (2, 50, 5, 64, 128), False),          # W + 2 = 7: a stage spans 9 padded rows; back = 16
+    ("wide_w141", (1, 9, 141, 64, 128), False),              # the widest map the ring holds (back = 144, 352 mirrored rows)
+    ("one_row", (4, 1, 64, 64, 256), False),                 # H = 1: every position's vertical taps are pad rows
+    ("sliced_operands", (2, 26, 30, 128, 128), True),        # x and du are channel slices of wider buffers (Concat inputs, pitch > C)
+    ("tiny_one_stage", (1, 2, 3, 64, 128), False),           # 15 padded positions: one stage, one slice per tile
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name,shape,sliced", PATCH_WGRAD_CASES, ids=[c[0] for c in PATCH_WGRAD_CASES])
+def test_conv_wgrad_patch_vs_autograd(dev, tune, dtype, name, shape, sliced):
+    """the padded-position filter-gradient kernel (csrc/wgrad_patch.h: 3x3 / stride 1, Cin % 64 == 0, Cout % 128 == 0; x staged once per position in a mirrored
+    ring, the nine taps as row offsets) on every eligible shape (knob wgrad_patch = 2) against torch autograd in fp32 on the same rounded operands, against the
+    tile kernels it replaces (knob 0), and run to run (bit-identical: fixed slice order, no atomics)."""
+    _lib, ops = _ops()
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(n, cin, h, w, generator=g).to(dtype).float()
+    wt = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    y = F.conv2d(x, wt, None, stride=1, padding=1)
+    gy = torch.randn(y.shape, generator=g).to(dtype).float()
+    y.backward(gy)
+    if sliced:
+        xw = ops.View.alloc(n, h, w, cin + 64, dtype, dev)
+        xw.buf.fill_(float("nan"))
+        gw = ops.View.alloc(n, h, w, cout + 32, dtype, dev)
+        gw.buf.fill_(float("nan"))
+        xv, gv = xw.slice(32, cin), gw.slice(16, cout)
+    else:
+        xv, gv = ops.View.alloc(n, h, w, cin, dtype, dev), ops.View.alloc(n, h, w, cout, dtype, dev)
+    ops.nchw_to_nhwc(x.to(dev), xv)
+    ops.nchw_to_nhwc(gy.to(dev), gv)
+    tune("wgrad_patch", 2)
+    tile, slices, _ = ops.conv2d_wgrad_plan(xv, cout, 3, 1)
+    assert tile == 4 and slices >= 1, (tile, slices)
+    dw, _ = ops.conv2d_wgrad(xv, gv, 3, 1, cout, cin)
+    dw2, _ = ops.conv2d_wgrad(xv, gv, 3, 1, cout, cin)
+    tune("wgrad_patch", 0)
+    assert ops.conv2d_wgrad_plan(xv, cout, 3, 1)[0] in (128, 256)
+    dw_old, _ = ops.conv2d_wgrad(xv, gv, 3, 1, cout, cin)
+    torch.cuda.synchronize()
+    assert torch.equal(dw, dw2), "not run-to-run deterministic"
+    ref = wt.grad
+    scale = ref.abs().max().item()
+    e_w = (dw.cpu() - ref).abs().max().item() / scale
+    e_o = (dw.cpu() - dw_old.cpu()).abs().max().item() / scale
+    print(f"[wgrad_patch {name} {dtype}] slices {slices}: vs autograd {e_w:.2e}, vs tile kernel {e_o:.2e}")
+    # same products, fp32 accumulation in another order
+    assert e_w < 2e-5 and e_o < 2e-5, f"{name} {dtype}: vs autograd {e_w:.2e}, vs tile kernel {e_o:.2e}"
 
 
 def test_fused_sgd_vs_torch_reference(dev):
@@ -2313,9 +2371,9 @@ def test_map_parity_on_synthetic_scenes(dev):
 # (round-2 review: split-K slice counts, XCD-grouped grids, 16-byte non-temporal partial sums and the >= 128 MB BatchNorm forms ran in bench.py only)
 BENCH_WGRAD_CASES = [
     # name, (n, h, w, cin, cout, k, s), (tile edge, xcd-grouped) the dispatcher must pick
-    ("L6cv2_128_256_80", (64, 80, 80, 128, 256, 3, 1), (256, 1)),
-    ("L8cv2_256_512_40", (64, 40, 40, 256, 512, 3, 1), (256, 1)),
-    ("L10cv2_512_1024_20", (64, 20, 20, 512, 1024, 3, 1), (256, 1)),
+    ("L6cv2_128_256_80", (64, 80, 80, 128, 256, 3, 1), (4, 1)),       # tile 4 = the padded-position kernel (wgrad_patch.h)
+    ("L8cv2_256_512_40", (64, 40, 40, 256, 512, 3, 1), (4, 1)),
+    ("L10cv2_512_1024_20", (64, 20, 20, 512, 1024, 3, 1), (4, 1)),
     ("L5_128_256_s2_160", (64, 160, 160, 128, 256, 3, 2), (256, 1)),
     ("L4cv2_64_128_160", (64, 160, 160, 64, 128, 3, 1), (3, 0)),      # tile 3 = the strip kernel (wgrad_strip.h)
     ("L3_64_128_s2_320", (64, 320, 320, 64, 128, 3, 2), (3, 0)),

@@ -24,6 +24,8 @@ SHAPES = {
     "L5": (64, 160, 160, 128, 256, 3, 2),
     "L6cv1": (64, 80, 80, 256, 128, 1, 1),
     "L6cv2": (64, 80, 80, 128, 256, 3, 1),
+    "L8cv2": (64, 40, 40, 256, 512, 3, 1),
+    "L10cv2": (64, 20, 20, 512, 1024, 3, 1),
 }
 
 

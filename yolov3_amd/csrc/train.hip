@@ -1675,6 +1675,7 @@ static bool wgrad_use_big(const y3_conv_desc* d, long long M) {
     return shape_ok && d->ksize * d->ksize * d->cin >= 1152 && M >= 16384;
 }
 #include "wgrad_strip.h"
+#include "wgrad_patch.h"
 
 static void wgrad_geometry(const y3_conv_desc* d, long long M, int& n_ct, int& n_nt, long long& slices, long long& per, int& tsh) {
     if (wgrad_use_big(d, M)) {
@@ -1736,6 +1737,11 @@ extern "C" int y3_conv2d_wgrad_plan(const y3_conv_desc* d, const y3_tensor* x, i
         *tile = 3; *slices_out = sp.blocks; *xcd_grouped = 0;             // tile 3 = the 3x3 strip kernel (wgrad_strip.h)
         return 0;
     }
+    PatchPlan pp;
+    if (patch_plan(d, x->n, x->h, x->w, pp)) {
+        *tile = 4; *slices_out = pp.slices; *xcd_grouped = 1;             // tile 4 = the padded-position kernel (wgrad_patch.h)
+        return 0;
+    }
     int n_ct, n_nt, tsh;
     long long slices, per;
     wgrad_geometry(d, M, n_ct, n_nt, slices, per, tsh);
@@ -1755,6 +1761,8 @@ extern "C" size_t y3_conv2d_wgrad_workspace_bytes(const y3_conv_desc* d, const y
     size_t need = ((size_t)slices * n_ct * n_nt * sizeof(float)) << (2 * tsh);
     StripPlan sp;
     if (strip_plan(d, x->n, x->h, x->w, d->cout, d->cin, false, sp) && sp.ws_bytes > need) need = sp.ws_bytes;
+    PatchPlan pp;
+    if (patch_plan(d, x->n, x->h, x->w, pp) && pp.ws_bytes > need) need = pp.ws_bytes;
     return need;
 }
 
@@ -1787,7 +1795,11 @@ extern "C" int y3_conv2d_wgrad(const y3_conv_desc* d, const y3_tensor* x, const 
         Y3_CHECK_LAUNCH();
         return 0;
     }
-    if (d->dtype != Y3_F32 && !force_direct && xb < 0x7fffffffLL && db_ < 0x7fffffffLL) {
+    PatchPlan pp;
+    if (!force_direct && xb < 0x7fffffffLL && db_ < 0x7fffffffLL && patch_plan(d, x->n, x->h, x->w, pp)) {
+        if (!workspace || workspace_bytes < pp.ws_bytes || (((uintptr_t)workspace) & 15)) Y3_FAIL("y3_conv2d_wgrad: workspace too small or not 16-byte aligned");
+        if (launch_patch(d, x, du, cout_real, cin_real, dw_oihw, workspace, pp, (unsigned)xb, (unsigned)db_, st)) return -1;
+    } else if (d->dtype != Y3_F32 && !force_direct && xb < 0x7fffffffLL && db_ < 0x7fffffffLL) {
         WgradArgs a;
         memset(&a, 0, sizeof(a));
         a.x = x->data; a.du = du->data; a.dw = dw_oihw; a.part = (float*)workspace;

@@ -20,6 +20,7 @@ enum y3_knob_id {
     Y3K_TILE_XCD,       // "tile_xcd":    1 the persistent tile loops of stem_pair / bneck_pair walk XCD-grouped tile ids (64 neighbouring tiles per XCD and round: halo rows and
                         //                shared cache lines meet in one L2); 0 dispatch order (A/B)
     Y3K_CONV_1X1S,      // "conv_1x1s":   1 the persistent 1x1 kernel with register-resident filters (conv_1x1s.h) on the HBM-bound 1x1 layers (Cin <= 384, Cout <= 256, >= 32768 pixels); 0 never; 2 also small launches (tests)
+    Y3K_WGRAD_PATCH,    // "wgrad_patch": 1 the padded-position filter-gradient kernel (wgrad_patch.h) on the 3x3 / stride-1 layers with Cin % 64 == 0, Cout % 128 == 0 at >= 16384 pixels; 0 never (wgrad_big / wgrad_dma); 2 every eligible shape (tests)
     Y3K_COUNT
 };
 long long y3_knob(int id);
