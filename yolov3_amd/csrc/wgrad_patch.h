@@ -62,7 +62,10 @@ template <typename F, int... Is> Y3_DEV void wp_for_impl(F&& f, std::integer_seq
 template <int N, typename F> Y3_DEV void wp_for(F&& f) { wp_for_impl(f, std::make_integer_sequence<int, N>{}); }
 template <int N> Y3_DEV void wp_wait_vm() { __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14)); }
 
-template <typename T>
+// ABL (tools/wgrad_patch_ablate.py, -DY3_ABLATE builds only; 0 in the shipped library): the kernel without one of its parts -- garbage results, only the launch time
+// means something.  1: no requests in the loop; 2: no fragment reads in the loop; 3: no barrier / counted wait; 4: no request sources, no requests; 5: MFMAs only (2 + 3 + 4);
+// 6: no slab stores; 7: no MFMAs
+template <typename T, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void wgrad_patch_kernel(const PatchArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef typename std::conditional<std::is_same<T, f16_t>::value, f16x8, bf16x8>::type frag;
@@ -180,7 +183,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_patch_kernel(const PatchArgs p) 
     auto mfma = [&](auto I, const Frags& f) {
         constexpr int i = decltype(I)::value, a = i / 9, t = i % 9;
         const frag af = mk(f.al[a], f.ah[a]), bf = mk(f.bl[t], f.bh[t]);
-        if constexpr (i >= 16) {
+        if constexpr (ABL == 7) {
+            asm volatile("" :: "v"(af), "v"(bf));
+        } else if constexpr (i >= 16) {
             // 288 accumulator registers against 256 AGPRs: through the builtin the compiler keeps EVERY accumulator in the AGPR file and rotates the surplus through
             // VGPRs (first build: 832 v_accvgpr_* per 72 MFMAs).  The last two tiles therefore live in VGPRs, multiplied by the VGPR form of the instruction as asm
             // (nothing else touches their registers between two of these; the epilogue reads them behind explicit wait states).
@@ -199,14 +204,14 @@ __global__ __launch_bounds__(256, 1) void wgrad_patch_kernel(const PatchArgs p) 
             constexpr int i = decltype(I)::value;
             mfma(I, cur);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (2 * i < 22) {
+            if constexpr (2 * i < 22 && ABL != 2 && ABL != 5) {
                 read_op(WIC<2 * i>{}, KGN, nxt, a_n, b_n);
                 read_op(WIC<2 * i + 1>{}, KGN, nxt, a_n, b_n);
             }
-            if constexpr (with_dma) {
+            if constexpr (with_dma && ABL != 4 && ABL != 5) {
                 if constexpr (i == 1) rq_prep_du(s_req);
                 if constexpr (i == 3) rq_prep_x(4 * s_req + g0 + wv);
-                if constexpr (i >= 5 && i < 13) rq_issue(WIC<i - 5>{});
+                if constexpr (i >= 5 && i < 13 && ABL != 1) rq_issue(WIC<i - 5>{});
             }
             if constexpr (2 * i < 22 || (with_dma && i < 13)) __builtin_amdgcn_sched_barrier(0);
         });
@@ -233,9 +238,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_patch_kernel(const PatchArgs p) 
         landed(f0);
         kgroup(WIC<3>{}, WIC<0>{}, f0, f1, a_cur, b_cur, 0);
         landed(f1);
-        wp_wait_vm<8>();                       // stage s + 1 has landed (this wave's share; the barrier makes it everyone's)
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();          // ... and nobody reads stage s any more: its du buffer and the oldest ring rows are free
+        if constexpr (ABL != 3 && ABL != 5) {
+            wp_wait_vm<8>();                   // stage s + 1 has landed (this wave's share; the barrier makes it everyone's)
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();      // ... and nobody reads stage s any more: its du buffer and the oldest ring rows are free
+        }
         __builtin_amdgcn_sched_barrier(0);
         const int sn = s + 1;
         const unsigned a_nx = lane_a + (unsigned)((sn % WP_NST) * WP_DU_STAGE);
@@ -250,6 +257,13 @@ __global__ __launch_bounds__(256, 1) void wgrad_patch_kernel(const PatchArgs p) 
     // ---- the accumulators as they are: [wave][a][tap][g][lane] x 4 consecutive filters (D row = filter 8 g + 4 (lane >> 5) + j, column = channel lane & 31)
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the asm MFMAs' results (16 passes) before anything reads their registers
     float* slab = p.part + ((size_t)slice * p.tiles + tile) * WP_SLAB + (size_t)wv * (2 * 9 * 4 * 64 * 4) + lane * 4;
+    if constexpr (ABL == 6) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) asm volatile("" :: "v"(acc[a][t]));
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -260,12 +274,48 @@ __global__ __launch_bounds__(256, 1) void wgrad_patch_kernel(const PatchArgs p) 
 #endif
 }
 
-// dW (OIHW fp32) = sum over slices of the slabs, in slice order.  A thread owns one 16-byte unit of the slab layout (4 consecutive filters of one (tap, channel)), so every
-// slice is read fully coalesced with up to 8 loads in flight; the 4-byte OIHW writes happen once per element.
+// dW (OIHW fp32) = sum over slices of the slabs.  A unit is 16 bytes of the slab layout (4 consecutive filters of one (tap, channel)): consecutive threads read consecutive
+// units of a slice, fully coalesced, up to 8 loads in flight.  SG threads share a unit: thread sg sums the slices [sg per, (sg + 1) per) in order, the partial sums are added
+// in sg order through LDS -- a fixed tree, bit-identical from run to run.  (One thread per unit left the 128 -> 256 layers -- 4 tiles, 64 slices: 75 MB behind 73 728 threads --
+// latency-bound at 1.7 TB/s: 44 us.)  The 4-byte OIHW writes happen once per element.
+template <int SG>
 __global__ __launch_bounds__(256) void wgrad_patch_reduce_kernel(const float* __restrict__ part, int tiles, int n_cit, int slices, int cin_real, int cout_real,
                                                                    float* __restrict__ dw) {
-    const long long u = (long long)blockIdx.x * 256 + threadIdx.x;   // 16-byte unit
-    if (u >= (long long)tiles * (WP_SLAB / 4)) return;
+    constexpr int UPB = 256 / SG;
+    __shared__ f32x4 red[SG > 1 ? SG : 1][UPB];
+    const int ul = threadIdx.x % UPB, sg = threadIdx.x / UPB;
+    const long long u = (long long)blockIdx.x * UPB + ul;   // 16-byte unit
+    const bool live = u < (long long)tiles * (WP_SLAB / 4);
+    const int per = (slices + SG - 1) / SG;
+    const int s0 = sg * per, s1 = min(s0 + per, slices);
+    const size_t stride = (size_t)tiles * WP_SLAB;
+    f32x4 s4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (live) {
+        const float* src = part + u * 4;
+        int s = s0;
+        for (; s + 8 <= s1; s += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = __builtin_nontemporal_load((const f32x4*)(src + (size_t)(s + q) * stride));
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s4 += v[q];
+        }
+        if (s < s1) {
+            f32x4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (s + q < s1) v[q] = __builtin_nontemporal_load((const f32x4*)(src + (size_t)(s + q) * stride));
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (s + q < s1) s4 += v[q];
+        }
+    }
+    if constexpr (SG > 1) {
+        red[sg][ul] = s4;
+        __syncthreads();
+        if (sg != 0) return;
+#pragma unroll
+        for (int q = 1; q < SG; ++q) s4 += red[q][ul];
+    }
+    if (!live) return;
     const int tile = (int)(u / (WP_SLAB / 4)), r = (int)(u - (long long)tile * (WP_SLAB / 4));
     const int lane = r & 63, g = (r >> 6) & 3, at = r >> 8;          // at = (wave * 2 + a) * 9 + tap
     const int wa = at / 9, tap = at - wa * 9;
@@ -274,24 +324,6 @@ __global__ __launch_bounds__(256) void wgrad_patch_reduce_kernel(const float* __
     const int co = cot * 128 + (2 * wc + a) * 32 + 8 * g + 4 * (lane >> 5);
     const int ci = cit * 64 + cib * 32 + (lane & 31);
     if (co >= cout_real || ci >= cin_real) return;
-    const size_t stride = (size_t)tiles * WP_SLAB;
-    const float* src = part + u * 4;
-    f32x4 s4 = {0.0f, 0.0f, 0.0f, 0.0f};
-    int s = 0;
-    for (; s + 8 <= slices; s += 8) {
-        f32x4 v[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = __builtin_nontemporal_load((const f32x4*)(src + (size_t)(s + q) * stride));
-#pragma unroll
-        for (int q = 0; q < 8; ++q) s4 += v[q];
-    }
-    if (s < slices) {
-        f32x4 v[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) if (s + q < slices) v[q] = __builtin_nontemporal_load((const f32x4*)(src + (size_t)(s + q) * stride));
-#pragma unroll
-        for (int q = 0; q < 8; ++q) if (s + q < slices) s4 += v[q];
-    }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
         if (co + q < cout_real) dw[((long long)(co + q) * cin_real + ci) * 9 + tap] = s4[q];
@@ -340,11 +372,24 @@ static int launch_patch(const y3_conv_desc* d, const y3_tensor* x, const y3_tens
     a.back16 = pl.back16; a.ext = pl.ext; a.Qc = pl.Qc; a.per = pl.per; a.tiles = pl.tiles; a.n_cit = pl.n_cit;
     a.dv_pw = y3_make_divisor(a.PW); a.dv_ph = y3_make_divisor(a.PH); a.dv_tiles = y3_make_divisor(pl.tiles); a.dv_cit = y3_make_divisor(pl.n_cit);
     const unsigned blocks = (unsigned)(pl.tiles * pl.slices);
+#ifdef Y3_ABLATE
+    const char* e = getenv("Y3_WP_ABL");
+    const int abl = e ? atoi(e) : 0;
+#define Y3_WP_ARM(N) case N: hipLaunchKernelGGL((wgrad_patch_kernel<f16_t, N>), dim3(blocks), dim3(256), 0, st, a); break;
+    if (abl && d->dtype == Y3_F16) {
+        switch (abl) { Y3_WP_ARM(1) Y3_WP_ARM(2) Y3_WP_ARM(3) Y3_WP_ARM(4) Y3_WP_ARM(5) Y3_WP_ARM(6) Y3_WP_ARM(7) default: break; }
+    } else
+#endif
     if (d->dtype == Y3_F16) hipLaunchKernelGGL((wgrad_patch_kernel<f16_t>), dim3(blocks), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((wgrad_patch_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, a);
     Y3_CHECK_LAUNCH();
     const long long units = (long long)pl.tiles * (WP_SLAB / 4);
-    hipLaunchKernelGGL(wgrad_patch_reduce_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, (const float*)ws, pl.tiles, pl.n_cit, pl.slices, cin_real, cout_real, dw);
+    // threads per unit: enough of them to keep the slab reads in flight when there are few tiles and many slices
+    const int sg = (pl.slices >= 32 && units < 600000) ? 8 : ((pl.slices >= 8 && units < 1200000) ? 4 : 1);
+    const unsigned rblocks = (unsigned)((units + 256 / sg - 1) / (256 / sg));
+    if (sg == 8) hipLaunchKernelGGL(wgrad_patch_reduce_kernel<8>, dim3(rblocks), dim3(256), 0, st, (const float*)ws, pl.tiles, pl.n_cit, pl.slices, cin_real, cout_real, dw);
+    else if (sg == 4) hipLaunchKernelGGL(wgrad_patch_reduce_kernel<4>, dim3(rblocks), dim3(256), 0, st, (const float*)ws, pl.tiles, pl.n_cit, pl.slices, cin_real, cout_real, dw);
+    else hipLaunchKernelGGL(wgrad_patch_reduce_kernel<1>, dim3(rblocks), dim3(256), 0, st, (const float*)ws, pl.tiles, pl.n_cit, pl.slices, cin_real, cout_real, dw);
     Y3_CHECK_LAUNCH();
     return 0;
 }
