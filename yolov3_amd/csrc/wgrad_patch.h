@@ -12,18 +12,22 @@
 //     views of it.  Price: the pad positions are multiplied too (3.8 % of the MFMAs at 80 x 80, 7.6 % at 40 x 40, 15.5 % at 20 x 20 -- zeros, which cost issue slots but
 //     little power).
 //   * x lives in a RING of 512 positions per 32-channel plane, 64-byte rows (a transposing read group covers 4 rows x 64 B = 256 contiguous bytes whatever the row offset:
-//     conflict-free for every tap without a swizzle, so (k-substep, dw) are instruction immediates and dh is one of three base registers).  The first EXT = 64 + 2 BACK
-//     rows are mirrored behind the ring (their requests are issued twice), so a K-step's window base .. base + EXT never wraps and only the base is reduced mod 512.
+//     conflict-free for every tap without a swizzle).  A wave keeps one read address per (tap row dh, k-group) -- twelve per stage, each reduced mod 512 rows when the
+//     stage's base moves (two VALU operations, in MFMA gaps that carry no reads) -- and reaches (dw, k-half) by instruction immediates of at most 6 rows; the ring's first
+//     16 rows are mirrored behind it for those (one stage in eight issues its x requests twice).  (First cut: three addresses per stage and a mirror of 64 + 2 BACK rows --
+//     at 80 x 80 every second x request was issued twice and the others went to a dump slot to keep the request count fixed: 8 requests per wave and stage instead of 6.)
 //   * block tile = 128 filters x (9 taps x 64 channels); 4 waves, ONE PER SIMD, wave tile 64 filters x 9 taps x 32 channels = 288 accumulator registers: per
 //     16 positions a wave reads 2 + 9 fragments (22 ds_read_b64_tr_b16) for 18 MFMAs (wgrad_big: 24 for 16, from twice the waves), and a block stages 24 KiB per
 //     64 positions (288 MFMAs) where wgrad_big staged 32 KiB per 32 pixels (128 MFMAs): a third of the bytes per MFMA.
 //   * ONE block barrier per 64 positions (72 MFMAs per wave), placed between k-groups 2 and 3 of a stage: every fragment of the stage is in registers by then, so the
 //     stage's du buffer is free for the requests of stage s + 3 (three stages in flight) and the first fragments of stage s + 1 are read under k-group 3's MFMAs --
-//     no exposed read after the barrier.  Counted `vmcnt(8)`: every wave issues exactly 8 requests per stage (4 du planes, 2 x planes, 2 mirror copies or dump-slot fillers).
+//     no exposed read after the barrier.  Counted `vmcnt`: a wave issues 6 requests per stage (4 du planes, 2 x planes; 8 when its x group is the mirrored one) and waits
+//     for all but the youngest stage's.
 //   * split-K over contiguous position ranges, one fp32 slab per block in REGISTER order (every store instruction writes 1 KiB contiguous), summed in slice order
 //     by wgrad_patch_reduce_kernel: deterministic, no atomics.  The blocks of a slice are neighbours on one XCD (xcd_remap) and walk the same positions: the operand
 //     rows they share meet in that L2.
-// LDS: [3 x 16 KiB du stages][2 planes x 864 rows x 64 B][1 KiB dump slot] = 157 KiB, one block per CU.
+// LDS (129 KiB, one block per CU; the rings start at multiples of 32 KiB so that `& 0x7fc0` is the wrap): [plane 0: 32 KiB ring + 1 KiB mirror][du stage 0]
+// [plane 1 at 64 KiB: ring + mirror][du stages 1, 2].
 
 namespace {
 
@@ -35,7 +39,6 @@ struct PatchArgs {
     unsigned x_bytes, du_bytes;
     int PW, PH;             // W + 2, H + 1
     int back16;             // ceil16(W + 3): positions the x ring keeps behind (and requests ahead of) the du stage
-    int ext;                // 64 + 2 back16: mirrored rows
     int Qc;                 // padded positions walked in all (multiple of 64)
     int per;                // positions per slice (multiple of 64)
     int tiles, n_cit;       // (Cout / 128) (Cin / 64) block tiles, Cin / 64 of them per filter tile
@@ -46,14 +49,13 @@ constexpr int WP_KS = 64;                       // positions per stage
 constexpr int WP_NST = 3;                       // du stages
 constexpr int WP_DU_STAGE = WP_KS * 128 * 2;    // 16 KiB: 4 planes of [64 rows][32 filters]
 constexpr int WP_RING = 512;
-constexpr int WP_MAX_BACK = 144;
-constexpr int WP_PLANE_ROWS = WP_RING + 64 + 2 * WP_MAX_BACK;   // 864
-constexpr int WP_PLANE = WP_PLANE_ROWS * 64;
-constexpr int WP_XBASE = WP_NST * WP_DU_STAGE;
-constexpr int WP_DUMP = WP_XBASE + 2 * WP_PLANE;
-constexpr int WP_LDS = WP_DUMP + 1024;
+constexpr int WP_MAX_BACK = 144;                // 3 stages of requests + the window of a stage (64 + 2 back) fit the ring
+constexpr int WP_PLANE = 65536;                 // plane 1 - plane 0
+constexpr int WP_MIRROR = WP_RING * 64;         // the ring's first 16 rows again, behind it
+constexpr int WP_DU0 = WP_MIRROR + 2048, WP_DU1 = WP_PLANE + WP_MIRROR + 1024, WP_DU2 = WP_DU1 + WP_DU_STAGE;
+constexpr int WP_LDS = WP_DU2 + WP_DU_STAGE;
 constexpr int WP_SLAB = 128 * 576;              // floats per block
-static_assert(WP_LDS <= 163840, "the LDS of a CU");
+static_assert(WP_LDS <= 163840 && WP_DU0 + WP_DU_STAGE <= WP_PLANE, "the LDS of a CU");
 
 template <int I> struct WIC {
     static constexpr int value = I;
@@ -97,39 +99,45 @@ __global__ __launch_bounds__(256, 1) void wgrad_patch_kernel(const PatchArgs p) 
         asm volatile("" : "+v"(off));   // (computed for every lane: a select, not a branch around three multiplications)
         return ok ? off : OOB;
     };
-    // the requests of a stage, as pieces that ride in MFMA gaps: sources first (VALU), then eight requests
-    unsigned rq_du = OOB, rq_x = OOB, rq_x1 = OOB;
-    unsigned char *rq_dd = smem, *rq_d0 = smem, *rq_d1 = smem;
-    bool rq_mir = false;
+    // the requests of a stage, as pieces that ride in MFMA gaps: sources first (VALU), then six or eight requests
+    unsigned rq_du = OOB, rq_x = OOB;
+    unsigned char *rq_dd = smem, *rq_d0 = smem;
+    bool rq_mir = false;                        // wave-uniform: this x group is the ring's first one, whose rows exist twice
+    auto du_stage_off = [&](int s) -> int {
+        const int r = s % WP_NST;
+        return r == 0 ? WP_DU0 : (r == 1 ? WP_DU1 : WP_DU2);
+    };
     auto rq_prep_du = [&](int s) {              // this wave's 16 positions of stage s
         const int q = q0 + s * WP_KS + 16 * wv + rrow;
         rq_du = src_of(q, q < q1, p.dpitch, cot * 128 + rchunk * 8);
-        rq_dd = smem + (s % WP_NST) * WP_DU_STAGE + wv * 1024;
+        rq_dd = smem + du_stage_off(s) + wv * 1024;
     };
-    auto rq_prep_x = [&](int g) {               // x positions q0 - back16 + 16 g .. + 15 into ring rows 16 (g mod 32) (+ the mirror copy)
+    auto rq_prep_x = [&](int g) {               // x positions q0 - back16 + 16 g .. + 15 into ring rows 16 (g mod 32)
         rq_x = src_of(q0 - p.back16 + 16 * g + rrow, true, p.xpitch, cit * 64 + rchunk * 8);
         const int gi = g & (WP_RING / 16 - 1);
-        rq_mir = gi * 16 < p.ext;               // wave-uniform
-        rq_d0 = smem + WP_XBASE + gi * 1024;
-        rq_d1 = rq_mir ? rq_d0 + WP_RING * 64 : smem + WP_DUMP;
-        rq_x1 = rq_mir ? rq_x : OOB;
+        rq_mir = gi == 0;
+        rq_d0 = smem + gi * 1024;
     };
     auto rq_issue = [&](auto K) {
         constexpr int k = decltype(K)::value;
         if constexpr (k < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (lds_ptr_t)(rq_dd + k * 4096), 16, rq_du, k * 64, 0, 0);   // the four 32-filter planes
         else if constexpr (k == 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)rq_d0, 16, rq_x, 0, 0, 0);
         else if constexpr (k == 5) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(rq_d0 + WP_PLANE), 16, rq_x, 64, 0, 0);
-        else if constexpr (k == 6) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)rq_d1, 16, rq_x1, 0, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(rq_mir ? rq_d1 + WP_PLANE : rq_d1), 16, rq_x1, 64, 0, 0);
+        else if constexpr (k == 6) {
+            if (rq_mir) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(rq_d0 + WP_MIRROR), 16, rq_x, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(rq_d0 + WP_MIRROR + WP_PLANE), 16, rq_x, 64, 0, 0);
+            }
+        }
     };
     auto dma_x_group = [&](int g) {
         rq_prep_x(g);
-        wp_for<4>([&](auto K) { rq_issue(WIC<4 + decltype(K)::value>{}); });
+        wp_for<3>([&](auto K) { rq_issue(WIC<4 + decltype(K)::value>{}); });
     };
-    auto dma_stage = [&](int s) {               // 8 requests per wave
+    auto dma_stage = [&](int s) {
         rq_prep_du(s);
         rq_prep_x(4 * s + g0 + wv);
-        wp_for<8>([&](auto K) { rq_issue(K); });
+        wp_for<7>([&](auto K) { rq_issue(K); });
     };
 
     // ---- fragments (see wgrad_dma_kernel): 16-lane group gg reads channel block 16 (gg & 1) of a 32-wide MFMA tile for k-group gg >> 1; lane gi of the group addresses
@@ -139,10 +147,15 @@ __global__ __launch_bounds__(256, 1) void wgrad_patch_kernel(const PatchArgs p) 
     const int chan0 = (gg & 1) * 16 + 4 * (gi & 3);
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr_t)smem;
     const unsigned lane_a = lds0 + (2 * wc) * 4096 + krow0 * 64 + chan0 * 2;                       // + stage, a * 4096, kg * 1024, half * 256
-    unsigned lane_b[3];
+    // x: row (ring base + 16 kg + back16 - 1 + (dh - 1) PW + krow0) mod 512 of the wave's plane; (dw, half) are immediates of 0 .. 6 rows (the mirror's reach)
+    unsigned rc6[3];
 #pragma unroll
-    for (int dh = 0; dh < 3; ++dh)                                                                  // + ring base * 64, kg * 1024, dw * 64, half * 256
-        lane_b[dh] = lds0 + WP_XBASE + cib * WP_PLANE + (p.back16 - 1 + (dh - 1) * p.PW + krow0) * 64 + chan0 * 2;
+    for (int dh = 0; dh < 3; ++dh) rc6[dh] = (unsigned)((p.back16 - 1 + (dh - 1) * p.PW + krow0) << 6);
+    const unsigned lane_x = lds0 + cib * WP_PLANE + chan0 * 2;
+    auto b_addr_of = [&](int s, int kg, int dh) -> unsigned {
+        const unsigned t6 = (unsigned)((((s * WP_KS) + 16 * kg) & (WP_RING - 1)) << 6);
+        return ((rc6[dh] + t6) & 0x7fc0u) + lane_x;
+    };
 
     f32x16 acc[2][9];
 #pragma unroll
@@ -156,7 +169,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_patch_kernel(const PatchArgs p) 
         s16x4_t al[2], ah[2], bl[9], bh[9];
     };
     // read op r of a k-group: 0..3 the du fragments (a = r >> 1, half = r & 1), 4..21 the x fragments (tap = (r - 4) >> 1)
-    auto read_op = [&](auto R, auto KG, Frags& f, unsigned a_addr, const unsigned (&b_addr)[3]) {
+    auto read_op = [&](auto R, auto KG, Frags& f, unsigned a_addr, const unsigned (&b_addr)[3]) {   // b_addr: the three tap-row addresses of THIS k-group
         constexpr int r = decltype(R)::value, kg = decltype(KG)::value;
         if constexpr (r < 4) {
             constexpr int a = r >> 1, half = r & 1;
@@ -164,7 +177,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_patch_kernel(const PatchArgs p) 
             if constexpr (half) f.ah[a] = v; else f.al[a] = v;
         } else {
             constexpr int t = (r - 4) >> 1, half = r & 1, dh = t / 3, dw = t % 3;
-            const s16x4_t v = lds_read_tr16<kg * 1024 + dw * 64 + half * 256>(b_addr[dh]);
+            const s16x4_t v = lds_read_tr16<dw * 64 + half * 256>(b_addr[dh]);
             if constexpr (half) f.bh[t] = v; else f.bl[t] = v;
         }
     };
@@ -196,10 +209,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_patch_kernel(const PatchArgs p) 
             else acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[a][t], 0, 0, 0);
         }
     };
-    // one k-group: 18 MFMAs on `cur`; the 22 reads of k-group KGN (addresses a_n / b_n) ride in the gaps behind the first eleven.  DMA: the requests of stage
-    // s_req ride along too -- sources in gaps 1 and 3, one request in each of gaps 5 .. 12
-    auto kgroup = [&](auto KGN, auto DMA, Frags& cur, Frags& nxt, unsigned a_n, const unsigned (&b_n)[3], int s_req) {
-        constexpr bool with_dma = decltype(DMA)::value != 0;
+    // one k-group: 18 MFMAs on `cur`; the 22 reads of k-group KGN (addresses a_n / b_n) ride in the gaps behind the first eleven; hook(i) is what else rides in gap i
+    auto kgroup = [&](auto KGN, Frags& cur, Frags& nxt, unsigned a_n, const unsigned (&b_n)[3], auto&& hook) {
         wp_for<18>([&](auto I) {
             constexpr int i = decltype(I)::value;
             mfma(I, cur);
@@ -208,50 +219,68 @@ __global__ __launch_bounds__(256, 1) void wgrad_patch_kernel(const PatchArgs p) 
                 read_op(WIC<2 * i>{}, KGN, nxt, a_n, b_n);
                 read_op(WIC<2 * i + 1>{}, KGN, nxt, a_n, b_n);
             }
-            if constexpr (with_dma && ABL != 4 && ABL != 5) {
-                if constexpr (i == 1) rq_prep_du(s_req);
-                if constexpr (i == 3) rq_prep_x(4 * s_req + g0 + wv);
-                if constexpr (i >= 5 && i < 13 && ABL != 1) rq_issue(WIC<i - 5>{});
-            }
-            if constexpr (2 * i < 22 || (with_dma && i < 13)) __builtin_amdgcn_sched_barrier(0);
+            hook(I);
+            __builtin_amdgcn_sched_barrier(0);
         });
     };
+    auto no_hook = [](auto) {};
 
     // ---- prologue: the x groups behind stage 0 and three stages of requests
     for (int g = wv; g < g0; g += 4) dma_x_group(g);
     dma_stage(0);
     dma_stage(1);
     dma_stage(2);
-    wp_wait_vm<16>();
+    bool last8 = rq_mir;                       // requests of the youngest stage in flight: 8 or 6
+    wp_wait_vm<12>();                          // everything but (at most) the requests of stages 1 and 2
     __builtin_amdgcn_s_barrier();
 
     Frags f0, f1;
     memset(&f1, 0, sizeof(f1));
-    unsigned a_cur = lane_a, b_cur[3] = {lane_b[0], lane_b[1], lane_b[2]};
-    wp_for<22>([&](auto R) { read_op(R, WIC<0>{}, f0, a_cur, b_cur); });
+    unsigned a_cur = lane_a + WP_DU0;
+    unsigned bq[4][3];                         // the stage's twelve x read addresses
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg)
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh) bq[kg][dh] = b_addr_of(0, kg, dh);
+    wp_for<22>([&](auto R) { read_op(R, WIC<0>{}, f0, a_cur, bq[0]); });
     landed(f0);
 
     for (int s = 0; s < S; ++s) {
-        kgroup(WIC<1>{}, WIC<0>{}, f0, f1, a_cur, b_cur, 0);
+        const int sn = s + 1;
+        unsigned bn0[3];                       // k-group 0 of stage s + 1
+        kgroup(WIC<1>{}, f0, f1, a_cur, bq[1], no_hook);
         landed(f1);
-        kgroup(WIC<2>{}, WIC<0>{}, f1, f0, a_cur, b_cur, 0);
+        kgroup(WIC<2>{}, f1, f0, a_cur, bq[2], no_hook);
         landed(f0);
-        kgroup(WIC<3>{}, WIC<0>{}, f0, f1, a_cur, b_cur, 0);
+        kgroup(WIC<3>{}, f0, f1, a_cur, bq[3], [&](auto I) {
+            constexpr int i = decltype(I)::value;
+            if constexpr (i >= 12 && i < 15) bn0[i - 12] = b_addr_of(sn, 0, i - 12);
+        });
         landed(f1);
         if constexpr (ABL != 3 && ABL != 5) {
-            wp_wait_vm<8>();                   // stage s + 1 has landed (this wave's share; the barrier makes it everyone's)
+            if (last8) wp_wait_vm<8>(); else wp_wait_vm<6>();   // stage s + 1 has landed (this wave's share; the barrier makes it everyone's)
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();      // ... and nobody reads stage s any more: its du buffer and the oldest ring rows are free
         }
         __builtin_amdgcn_sched_barrier(0);
-        const int sn = s + 1;
-        const unsigned a_nx = lane_a + (unsigned)((sn % WP_NST) * WP_DU_STAGE);
-        const unsigned ring = (unsigned)(((sn * WP_KS) & (WP_RING - 1)) * 64);
-        const unsigned b_nx[3] = {lane_b[0] + ring, lane_b[1] + ring, lane_b[2] + ring};
-        kgroup(WIC<0>{}, WIC<1>{}, f1, f0, a_nx, b_nx, s + 3);   // k-group 3 of stage s | first fragments of stage s + 1, requests of stage s + 3
+        const unsigned a_nx = lane_a + (unsigned)du_stage_off(sn);
+        // k-group 3 of stage s | first fragments of stage s + 1, requests of stage s + 3 (sources in gaps 1 and 3, requests in gaps 5 .. 11), the other nine addresses
+        kgroup(WIC<0>{}, f1, f0, a_nx, bn0, [&](auto I) {
+            constexpr int i = decltype(I)::value;
+            if constexpr (ABL != 4 && ABL != 5) {
+                if constexpr (i == 1) rq_prep_du(s + 3);
+                if constexpr (i == 3) rq_prep_x(4 * (s + 3) + g0 + wv);
+                if constexpr (i >= 5 && i < 12 && ABL != 1) rq_issue(WIC<i - 5>{});
+            }
+            if constexpr (i >= 12 && i < 15) {
+#pragma unroll
+                for (int dh = 0; dh < 3; ++dh) bq[i - 11][dh] = b_addr_of(sn, i - 11, dh);
+            }
+        });
         landed(f0);
+        last8 = rq_mir;
         a_cur = a_nx;
-        b_cur[0] = b_nx[0]; b_cur[1] = b_nx[1]; b_cur[2] = b_nx[2];
+        bq[0][0] = bn0[0]; bq[0][1] = bn0[1]; bq[0][2] = bn0[2];
     }
 
     // ---- the accumulators as they are: [wave][a][tap][g][lane] x 4 consecutive filters (D row = filter 8 g + 4 (lane >> 5) + j, column = channel lane & 31)
@@ -330,7 +359,7 @@ __global__ __launch_bounds__(256) void wgrad_patch_reduce_kernel(const float* __
 }
 
 struct PatchPlan {
-    int tiles, n_cit, slices, per, Qc, back16, ext;
+    int tiles, n_cit, slices, per, Qc, back16;
     size_t ws_bytes;
 };
 
@@ -356,7 +385,6 @@ static bool patch_plan(const y3_conv_desc* d, int n, int h, int w, PatchPlan& pl
     pl.per = per_st * WP_KS;
     pl.Qc = stages * WP_KS;
     pl.back16 = back16;
-    pl.ext = WP_KS + 2 * back16;
     pl.ws_bytes = (size_t)pl.slices * pl.tiles * WP_SLAB * sizeof(float);
     return true;
 }
@@ -369,7 +397,7 @@ static int launch_patch(const y3_conv_desc* d, const y3_tensor* x, const y3_tens
     a.N = x->n; a.H = x->h; a.W = x->w; a.xpitch = x->pitch; a.dpitch = du->pitch;
     a.x_bytes = x_bytes; a.du_bytes = du_bytes;
     a.PW = x->w + 2; a.PH = x->h + 1;
-    a.back16 = pl.back16; a.ext = pl.ext; a.Qc = pl.Qc; a.per = pl.per; a.tiles = pl.tiles; a.n_cit = pl.n_cit;
+    a.back16 = pl.back16; a.Qc = pl.Qc; a.per = pl.per; a.tiles = pl.tiles; a.n_cit = pl.n_cit;
     a.dv_pw = y3_make_divisor(a.PW); a.dv_ph = y3_make_divisor(a.PH); a.dv_tiles = y3_make_divisor(pl.tiles); a.dv_cit = y3_make_divisor(pl.n_cit);
     const unsigned blocks = (unsigned)(pl.tiles * pl.slices);
 #ifdef Y3_ABLATE
