@@ -262,10 +262,11 @@ def train_main(args, rank, local_rank, world, dev, parallel, yo, print_record):
     parallel.finalize()
 
 
-def clocks_under_load(fn, seconds=2.5):
+def clocks_under_load(fn, seconds=2.5, per_call=1):
     """Shader clock and socket power while `fn` (one forward) runs back to back, sampled with rocm-smi from a thread.  Outside the timed
     region.  MI355X is power-capped under MFMA load: the sustained clock -- not the 2.4 GHz the 2.5 PFLOP/s peak is quoted at -- is what a
-    kernel's MFMA rate can be compared with (profiles/r02_clocks.md).  Returns None when rocm-smi is not usable."""
+    kernel's MFMA rate can be compared with (profiles/r02_clocks.md).  `per_call` = pipeline steps one call of `fn` runs (the sustained-throughput leg calls
+    it with the two-stream schedule: calls, steps and seconds are returned too).  Returns None when rocm-smi is not usable (the sustained leg still gets its counts)."""
     import re
     import subprocess
     import threading
@@ -284,24 +285,29 @@ def clocks_under_load(fn, seconds=2.5):
                 rows.append((int(c.group(1)), float(w.group(1)) if w else None))
 
     th = threading.Thread(target=sampler, daemon=True)
-    for _ in range(20):
+    for _ in range(20 // per_call if per_call < 20 else 1):
         fn()
     torch.cuda.synchronize()
     th.start()
+    calls = 0
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < seconds:
-        for _ in range(10):
+        for _ in range(max(1, 10 // per_call)):
             fn()
+            calls += 1
         torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
     stop.set()
     th.join(timeout=10)
     rows = [r for r in rows if r[0] > 500]   # a sample that caught the queue empty reads the idle clock
+    res = {"calls": calls, "steps": calls * per_call, "seconds": round(elapsed, 3)}
     if len(rows) < 3:
-        return None
+        return res if per_call > 1 else None
     clk = sorted(r[0] for r in rows)
     pw = sorted(r[1] for r in rows if r[1])
-    return {"sclk_mhz_median": clk[len(clk) // 2], "sclk_mhz_min": clk[0], "sclk_mhz_max": clk[-1], "socket_power_w_median": pw[len(pw) // 2] if pw else None,
-            "samples": len(rows), "source": "rocm-smi --showclocks --showpower sampled while the forward runs back to back (after the timed region)"}
+    res.update({"sclk_mhz_median": clk[len(clk) // 2], "sclk_mhz_min": clk[0], "sclk_mhz_max": clk[-1], "socket_power_w_median": pw[len(pw) // 2] if pw else None,
+                "samples": len(rows), "source": "rocm-smi --showclocks --showpower sampled while the load runs back to back (after the timed region)"})
+    return res
 
 
 def calibrate_detect_head(model, x, conf_thres=0.001, row_frac=0.20, strong_frac=0.03, cands_per_image=12000.0):
@@ -565,7 +571,7 @@ def main():
         total_conv_flops = sum(g[0] for g in groups.values()) / 5
         total_kernel_s = sum(g[2] for g in groups.values()) / 5
         pmc, pmc_file = {}, None
-        for cand in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):   # HBM traffic per launch comes from the committed rocprofv3 --pmc passes (bench.py cannot run the profiler)
+        for cand in ("r06_pmc_summary.json", "r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):   # HBM traffic per launch comes from the committed rocprofv3 --pmc passes (bench.py cannot run the profiler)
             try:
                 pmc = json.load(open(ROOT / "profiles" / cand)).get(dom.rsplit("/", 1)[0], {})  # PMC averages are per kernel symbol
             except OSError:
@@ -645,6 +651,14 @@ def main():
         roofline["whole_step_frac"] = round(total_conv_flops / (dt / args.steps) / 1e12 / MFMA_PEAK_TFLOPS, 4)   # conv FLOPs of one step / wall time of one step / 2.5 PF
         clk = None if args.no_clocks else clocks_under_load(lambda: model(x))
         roofline["clocks_under_load"] = clk
+        # the timed window is steps x ~6 ms on a chip whose clock follows a power budget: the same two-stream pipeline for >= 2 s, outside `value`
+        sustained = None
+        if not args.no_clocks and not args.no_overlap:
+            sus = clocks_under_load(lambda: run_steps(8), seconds=2.0, per_call=8)
+            if sus:
+                sustained = {"images_per_sec": round(bs * sus["steps"] / sus["seconds"], 2), "steps": sus["steps"], "seconds": sus["seconds"],
+                             "sclk_mhz_median": sus.get("sclk_mhz_median"), "socket_power_w_median": sus.get("socket_power_w_median"),
+                             "note": "forward(i + 1) beside NMS(i) of the model's own output, back to back for >= 2 s after the timed region (rank 0)"}
         if clk and bound == "mfma":   # the same MFMA peak at the clock the chip actually sustains under this load (power cap)
             peak_at_clk = MFMA_PEAK_TFLOPS * clk["sclk_mhz_median"] / 2400.0
             roofline["peak_at_sustained_clock"] = round(peak_at_clk, 1)
@@ -669,6 +683,8 @@ def main():
                 "parallelism": f"replicas x{world} (no data-path collective)",
                 "schedule": "sequential forward -> NMS(pred) per batch" if args.no_overlap else "NMS of batch i's predictions on a second HIP stream beside the forward of batch i+1 (every batch completes inside the timed region)",
             },
+            "sustained_images_per_sec": sustained["images_per_sec"] if sustained else None,
+            "sustained": sustained,
             "sequential_images_per_sec_per_gpu": seq,
             "legs_ms": {"forward+decode": round(t_fwd * 1e3, 3), "nms_on_model_output": round(t_nms_own * 1e3, 3), "nms_synthetic_pred": round(t_nms * 1e3, 3)},
             "nms_candidates_per_image": {"model_output": round(cand_own, 1), "synthetic_pred": round(cand_synth, 1)},

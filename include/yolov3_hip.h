@@ -403,6 +403,10 @@ int y3_sgd_step_dynamic(const void* tensor_table, int32_t n_tensors, int32_t n_c
                         void* stream);
 int y3_loss_scale_update(float* loss_scale, int32_t* growth_tracker, const int32_t* found_inf, float growth_factor,
                          float backoff_factor, int32_t growth_interval, void* stream);
+/* The owner's step of the two-phase gradient exchange that replaces a bucket's all-reduce on a fully connected xGMI mesh (reference: DDP's gradient
+   averaging, utils/torch_utils.py:60-72 smart_DDP / train.py:411): `parts` holds n_parts contributions of n floats each ([n_parts][n], what the all-to-all
+   of the shards delivered); out[i] = (parts[0][i] + ... + parts[n_parts - 1][i]) * scale, added in that order.  `out` may alias none of `parts`. */
+int y3_shard_mean(const float* parts, int32_t n_parts, int64_t n, float scale, float* out, void* stream);
 
 #ifdef __cplusplus
 }

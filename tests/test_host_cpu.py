@@ -528,19 +528,31 @@ def test_conv_dispatch_variant_names_and_stat_rows():
 
 
 def test_wgrad_geometry_fills_whole_rounds():
-    """y3_conv2d_wgrad_workspace_bytes exposes the filter-gradient launch geometry: the 256x256-tile kernel is chosen for the
-    long-K layers of yolov3 at batch 64 and its (tiles x pixel slices) fills 1 or 2 rounds of 256 CUs to >= 98 %; the other
-    layers keep 128x128 tiles (64 KiB partial tiles)."""
+    """y3_conv2d_wgrad_plan / _workspace_bytes expose the filter-gradient launch geometry: the padded-position kernel for the stride-1 long-K layers of
+    yolov3 at batch 64 (one block per CU), the 256x256-tile kernel for the stride-2 ones (its tiles x pixel slices fill 1 or 2 rounds of 256 CUs to >= 98 %);
+    the other layers keep 128x128 tiles (64 KiB partial tiles)."""
     import ctypes as C
 
     from yolov3_amd import _lib
     from yolov3_amd._lib import Y3Tensor
 
     L = _lib.lib()
-    big = {(128, 256, 80): 5, (256, 512, 40): 18, (512, 1024, 20): 72}      # (cin, cout, map) -> 256x256 tiles
+    tile, slices, xg = C.c_int32(0), C.c_int64(0), C.c_int32(0)
+    # round 6: the stride-1 long-K layers run the padded-position kernel (csrc/wgrad_patch.h, plan code 4): (Cout / 128)(Cin / 64) block tiles of 128 x 576 accumulators,
+    # as many position slices as give one block per CU, one 288 KiB slab per block
+    for (cin, cout, hw), (tiles, sl) in {(128, 256, 80): (4, 64), (256, 512, 40): (16, 16), (512, 1024, 20): (64, 4)}.items():
+        x = Y3Tensor(4096, 64, hw, hw, cin, cin)
+        d = _desc(_lib.Y3_F16, 3, 1, cin, cout)
+        assert L.y3_conv2d_wgrad_plan(C.byref(d), C.byref(x), C.byref(tile), C.byref(slices), C.byref(xg)) == 0
+        assert (tile.value, slices.value, xg.value) == (4, sl, 1), (cin, cout, hw, tile.value, slices.value)
+        assert L.y3_conv2d_wgrad_workspace_bytes(C.byref(d), C.byref(x)) >= tiles * sl * 128 * 576 * 4
+        stages = -(-((64 * (hw + 1) + 1) * (hw + 2)) // 64)
+        assert sl * -(-stages // sl) - stages < sl, "the slices differ by at most one 64-position stage"
+    # the stride-2 long-K layers keep the 256 x 256 tiles
+    big = {(128, 256, 160): 5, (256, 512, 80): 18, (512, 1024, 40): 72}      # (cin, cout, input map) -> 256x256 tiles
     for (cin, cout, hw), tiles in big.items():
         x = Y3Tensor(4096, 64, hw, hw, cin, cin)
-        nbytes = L.y3_conv2d_wgrad_workspace_bytes(C.byref(_desc(_lib.Y3_F16, 3, 1, cin, cout)), C.byref(x))
+        nbytes = L.y3_conv2d_wgrad_workspace_bytes(C.byref(_desc(_lib.Y3_F16, 3, 2, cin, cout)), C.byref(x))
         blocks = nbytes // (256 * 256 * 4)
         assert nbytes % (256 * 256 * 4) == 0 and blocks % tiles == 0, (cin, cout, hw, nbytes)
         rounds = -(-blocks // 256)
@@ -552,7 +564,6 @@ def test_wgrad_geometry_fills_whole_rounds():
         assert nbytes % (128 * 128 * 4 * tiles) == 0, (cin, cout, k, hw)
     # the 3x3 layers with 32 -> 64 / 64 -> 128 channels on the large maps: the strip kernel (csrc/wgrad_strip.h) -- one [9 cin][64] fp32 partial tile per
     # persistent block and 64-filter half, 3 / 2 / 2 / 1 blocks per CU (what the LDS holds)
-    tile, slices, xg = C.c_int32(0), C.c_int64(0), C.c_int32(0)
     for cin, cout, s, hw, blocks in [(32, 64, 1, 320, 768), (32, 64, 2, 640, 512), (64, 128, 1, 160, 256), (64, 128, 2, 320, 128)]:
         x = Y3Tensor(4096, 64, hw, hw, cin, cin)
         d = _desc(_lib.Y3_F16, 3, s, cin, cout)

@@ -4,6 +4,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
@@ -190,6 +191,7 @@ _SIGNATURES = {
     "y3_sgd_tensor_record_bytes": (C.c_size_t, []),
     "y3_sgd_step_dynamic": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "y3_loss_scale_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int32, C.c_void_p]),
+    "y3_shard_mean": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),
     "y3_sgd_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
@@ -209,7 +211,8 @@ def lib() -> C.CDLL:
     binds to (same SONAME libamdhip64.so.7): streams and device pointers then belong to one runtime."""
     global _lib
     if _lib is not None:
-        return _lib if _call_timer is None else _call_timer
+        t = _call_timer
+        return _lib if t is None or t.thread != threading.get_ident() else t   # a CallTimer times the thread that installed it, nobody else's calls
     import torch  # noqa: F401  (must precede the dlopen, see docstring)
 
     if not LIB_PATH.exists():
@@ -242,11 +245,16 @@ _QUERIES = frozenset((
 class CallTimer:
     """HIP-event timing of every C-ABI call made while the timer is installed (`with CallTimer() as t: step()`), on the stream the kernels are launched on (torch's
     current stream: what ops.stream_ptr() hands to the library).  bench.py uses it to split ONE training step into kernel families in the run that reports it,
-    instead of quoting a profile taken elsewhere.  `by_function()` -> {C function: [milliseconds, calls]} once the stream has drained."""
+    instead of quoting a profile taken elsewhere.  `by_function()` -> {C function: [milliseconds, calls]} once the stream has drained.  Bench-only: it times the calls of
+    the thread that installed it (other threads keep the plain handle), code that cached the real handle before bypasses it, and it stops recording at MAX_RECORDS."""
+
+    MAX_RECORDS = 100_000   # bench-only tool: a timer left installed around a long loop stops recording instead of growing without bound
 
     def __init__(self):
         self.records = []   # (function name, start event, end event)
         self._fns = {}
+        self.thread = threading.get_ident()   # calls of other threads (data loaders, an NMS thread, another model) go to the plain handle: lib()
+        self.dropped = 0
 
     def __getattr__(self, name):   # stands in for the ctypes handle: lib().y3_xxx(...)
         fn = self._fns.get(name)
@@ -258,6 +266,9 @@ class CallTimer:
                 fn = raw          # queries: nothing is launched
             else:
                 def fn(*a, raw_=raw, name_=name):
+                    if len(self.records) >= self.MAX_RECORDS:
+                        self.dropped += 1
+                        return raw_(*a)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     r = raw_(*a)
@@ -270,6 +281,7 @@ class CallTimer:
     def __enter__(self):
         global _call_timer
         lib()   # (loaded before the proxy stands in for it)
+        self.thread = threading.get_ident()
         _call_timer = self
         return self
 

@@ -208,6 +208,10 @@ static bool s1_plan(const ConvArgs& a, S1Plan& pl, int in = 0) {   // in: 0 plai
     if (a.omul != 1 || a.ooh != 0 || a.oow != 0 || a.H != a.Ho || a.W != a.Wo || a.oH != a.Ho || a.oW != a.Wo) return false;
     if (!a.x_bytes || !a.w_bytes || !a.y_bytes || (a.res && !a.r_bytes) || !a.bias) return false;
     if (a.M < 32768 && mode != 2 && !in) return false;   // below that the launch is latency-bound and the tile kernels' many small blocks win
+    // the IN form (consumer-side BatchNorm) replaces TWO launches, so it pays earlier -- but not at any size: with a handful of stages per persistent block (a short last
+    // batch, the 320-pixel end of multi-scale training) it is the one-block-per-CU regime the tile kernels were measured faster in; the caller keeps the separate passes
+    // (y3_conv2d_fwd_bnin_rows returns -1).  The committed A/Bs (profiles/r05_bn_in_pairs_probe.txt) are at >= 102 400 pixels.
+    if (a.M < 8192 && mode != 2 && in) return false;
     // WC consumer waves along the filters x FG groups of 32 filters per wave = the filters of a block; n_ct blocks side by side where Cout is more than a block keeps in
     // registers.  The shapes of yolov3's Bottleneck.cv1 layers on the 40 x 40 ... 320 x 320 maps, their data gradients, the 80 x 80 Detect conv (255 -> 256 filters) and the
     // cv1 layers behind the two Concats.  Cin = 512 (the 40 x 40 cv1 layers, 128 filters per block and two blocks per pixel range) was built and measured: 29.1 us against

@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(NmsWs ws, int nseg, dou
     const int n = (int)(hi - lo);
     if (n <= 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int w = tid; w < (n + 31) / 32; w += 256) removed[w] = 0u;
+    for (int w = tid; w < 2 * ((n + 63) / 64); w += 256) removed[w] = 0u;   // whole 64-box blocks: the walk below reads both words of a block
     if (tid == 0) s_kept = 0;
     const unsigned* __restrict__ pos = pos2 + lo;
     auto suppresses = [&](const float4 bi, const float iarea, const float4 bj) {   // torchvision's test, operand for operand
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void nms_greedy_kernel(NmsWs ws, int nseg, dou
     for (int base = 0; base < n; base += 64) {
         const int cnt = n - base < 64 ? n - base : 64;
         __syncthreads();   // `removed` as the blocks before this one left it (first trip: zeroed); blk / srow free
-        const unsigned long long rem_in = (unsigned long long)removed[base >> 5] | ((unsigned long long)removed[(base >> 5) + 1] << 32);   // (uniform; bits beyond n are 0)
+        const unsigned long long rem_in = (unsigned long long)removed[base >> 5] | ((unsigned long long)removed[(base >> 5) + 1] << 32);   // (uniform; the words of the last block are zeroed whole, bits beyond n stay 0)
         const unsigned long long valid = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
         if ((rem_in & valid) == valid) continue;   // every box of the block is already suppressed (uniform)
         if (tid < 64) {

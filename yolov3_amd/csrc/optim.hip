@@ -123,7 +123,33 @@ __global__ void loss_scale_update_kernel(float* __restrict__ scale, int* __restr
     }
 }
 
+// the owner's step of the two-phase gradient exchange (parallel.GradBuckets, exchange = "direct"): out[i] = (parts[0][i] + parts[1][i] + ... + parts[P-1][i]) * scale,
+// the P contributions added in rank order (every rank receives this one sum: replicas stay bit-identical), one pass, one launch
+__global__ __launch_bounds__(256) void shard_mean_kernel(const float* __restrict__ parts, int P, long long n, float scale, float* __restrict__ out) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 4 <= n && (((uintptr_t)parts | (uintptr_t)out) & 15) == 0 && (n & 3) == 0) {
+        f32x4 a = *(const f32x4*)(parts + i);
+        for (int r = 1; r < P; ++r) a += *(const f32x4*)(parts + (long long)r * n + i);
+        *(f32x4*)(out + i) = a * scale;
+        return;
+    }
+    for (long long j = i; j < n && j < i + 4; ++j) {
+        float a = parts[j];
+        for (int r = 1; r < P; ++r) a += parts[(long long)r * n + j];
+        out[j] = a * scale;
+    }
+}
+
 }  // namespace
+
+extern "C" int y3_shard_mean(const float* parts, int32_t n_parts, int64_t n, float scale, float* out, void* stream) {
+    if (!parts || !out || n_parts < 1 || n < 0) Y3_FAIL("y3_shard_mean: bad argument");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(shard_mean_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, parts, n_parts, (long long)n, scale, out);
+    Y3_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" size_t y3_sgd_tensor_record_bytes(void) { return sizeof(OptTensor); }
 

@@ -130,6 +130,7 @@ class GradBuckets:
         if self.exchange not in self.EXCHANGES:
             raise ValueError(f"GradBuckets: exchange {self.exchange!r} is not one of {self.EXCHANGES}")
         self.collectives = {"all_reduce": 0, "direct": 0}   # buckets sent by each form since construction (tests, bench line)
+        self._warned_fallback = False
         self._recv = None          # the direct form's receive buffer (grown to the largest bucket, reused: collectives of one side stream run in order)
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.force = force   # run the bucket / side-stream / collective machinery even at world size 1 (single-GPU tests of the exchange step)
@@ -191,8 +192,14 @@ class GradBuckets:
         """average `flat` over the ranks, in place; returns the async work handle"""
         if not (dist.is_available() and dist.is_initialized()):
             return None
-        if self.exchange == "direct" and self.world > 1 and flat.numel() % self.world == 0 and flat.numel() > 0:
-            return self._reduce_direct(flat)
+        if self.exchange == "direct" and self.world > 1 and flat.numel() > 0:
+            if flat.numel() % self.world == 0:
+                return self._reduce_direct(flat)
+            if not self._warned_fallback:
+                self._warned_fallback = True
+                import warnings
+
+                warnings.warn(f"GradBuckets(exchange='direct'): a bucket of {flat.numel()} elements is not divisible by the world size {self.world}; it takes the all-reduce")
         self.collectives["all_reduce"] += 1
         if dist.get_backend(self.group) == "nccl":
             return dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)   # RCCL averages on the wire: no divide pass
@@ -209,11 +216,17 @@ class GradBuckets:
         recv = self._recv[: flat.numel()]
         dist.all_to_all_single(recv, flat, group=self.group, async_op=True).wait()   # recv.view(P, n)[r] = rank r's copy of MY shard
         mine = flat[rank * n : (rank + 1) * n]
-        parts = recv.view(P, n)
-        acc = parts[0].clone() if P > 1 else parts[0]
-        for r in range(1, P):        # fixed order 0 .. P-1 on the one rank that computes this shard
-            acc.add_(parts[r])
-        torch.mul(acc, 1.0 / P, out=mine)
+        if flat.is_cuda and flat.dtype == torch.float32:
+            # the owner's sum: rank order 0 .. P-1, times 1 / P, one launch of the library (csrc/optim.hip::shard_mean_kernel) on the current (side) stream
+            from . import _lib, ops
+
+            _lib.check(_lib.lib().y3_shard_mean(recv.data_ptr(), P, n, 1.0 / P, mine.data_ptr(), ops.stream_ptr()), "y3_shard_mean")
+        else:                        # host tensors (the gloo tests) and reduced wire dtypes: the same sum in the same order with torch ops
+            parts = recv.view(P, n)
+            acc = parts[0].clone() if P > 1 else parts[0]
+            for r in range(1, P):
+                acc.add_(parts[r])
+            torch.mul(acc, 1.0 / P, out=mine)
         self.collectives["direct"] += 1
         nccl = dist.get_backend(self.group) == "nccl"
         return dist.all_gather_into_tensor(flat, mine if nccl else mine.clone(), group=self.group, async_op=True)   # RCCL gathers in place (send == recv + rank x n)
@@ -241,8 +254,9 @@ class GradBuckets:
             direct = self.exchange == "direct" and self.world > 1
             if rng is not None:
                 base, lo, hi = rng
-                if direct:                  # the last member's own pad (the arena hands out 64-element slices) makes the length divisible by P = 2 .. 64
-                    hi = min(base.numel(), (hi + 63) // 64 * 64)
+                if direct:                  # the last member's own pad (the arena hands out 64-element slices) makes the length divisible by P = 2 .. 64; another P
+                    hi = min(base.numel(), (hi + 63) // 64 * 64)   # (3, 6, ...) takes the all-reduce for this bucket (one warning): the elements behind `hi` are other
+                                                                   # tensors' slices, which the backward may be writing while this range is on the wire
                 flat = base[lo:hi]          # padding between slices rides along (<= 252 B per tensor); the slices ARE the results
                 return flat, self._reduce(flat), None
             wire = self.wire_dtype or torch.float32

@@ -832,6 +832,9 @@ class TrainPlan:
     def forward(self, x: torch.Tensor):
         global _FORWARD_TICK
         _FORWARD_TICK += 1
+        if self._overflow or self.slot_generation != self.slot.generation:
+            # a plan constructed directly (no TrainPlan.build: its views only counted bytes) or left behind when its slot's arena was re-allocated without it
+            raise RuntimeError("TrainPlan.forward: the plan is not bound to its slot's activation arena -- build plans with TrainPlan.build(model, n, h, w, dtype, device, slot)")
         self.last_forward = self.slot.last_forward = _FORWARD_TICK   # recency across slots (the slot choice in run_model_train)
         self.generation += 1
         self.x_nchw = x if x.dtype in (torch.float32, torch.float16, torch.bfloat16, torch.uint8) else None
