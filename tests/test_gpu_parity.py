@@ -229,13 +229,15 @@ BNIN_CASES = [
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("name,shape,shortcut,silu", BNIN_CASES, ids=[c[0] for c in BNIN_CASES])
-def test_conv1x1_bn_in_consumer_matches_separate_passes(dev, dtype, name, shape, shortcut, silu):
+def test_conv1x1_bn_in_consumer_matches_separate_passes(dev, tune, dtype, name, shape, shortcut, silu):
     """y3_conv2d_fwd_bnin_stats (conv_1x1s.h, IN form): the producing layer's act(scale u + shift) (+ shortcut) applied on the way into its 1x1 consumer.  Against the two launches
     it replaces -- y3_bn_act_fwd, then y3_conv2d_fwd_stats on its output: the normalised tensor it stores, the convolution output and the statistics rows' sums are the SAME
-    bits (same arithmetic on the same operands, same K order), every pixel and channel."""
+    bits (same arithmetic on the same operands, same K order), every pixel and channel.  (Knob conv_1x1s = 2: the dispatcher leaves launches below 8192 pixels to the
+    separate passes since round 6 -- most cases here are smaller.)"""
     _lib, ops = _ops()
     import ctypes as C
 
+    tune("conv_1x1s", 2)
     n, h, w, cin, cout = shape
     g = torch.Generator().manual_seed(7)
     M = n * h * w
@@ -2141,6 +2143,45 @@ def test_multi_scale_training_reuses_one_arena(dev):
     # the arena holds the largest shape exactly once, not the sum of the shapes
     big = pc.plans[("train", bs, 960, 960, torch.float16, dev.index, 0)]
     assert slot.arena.numel() == big._act_off
+
+
+@pytest.mark.parametrize("cfg,hw", [("yolov3-tiny", 160), ("yolov3", 128)])
+def test_filter_gradients_on_the_side_stream_are_bit_identical(dev, monkeypatch, cfg, hw):
+    """Round 6: the filter gradients of a backward run on a second HIP stream by default (train_engine.TrainPlan.wgrad; Y3_WGRAD_STREAM=0: one stream) -- nothing
+    downstream in the backward needs them.  Same kernels, same split-K order, one workspace used in stream order: every parameter gradient must equal the
+    single-stream backward's to the last bit, over several steps (the workspace and the gradient arena are re-used / re-allocated between them) and with other work
+    queued on the compute stream in between."""
+    from yolov3_amd import ComputeLoss
+    from yolov3_amd.engine import plan_cache
+    from yolov3_amd import train_engine
+
+    hyp = dict(box=0.05, cls=0.5, cls_pw=1.0, obj=1.0, obj_pw=1.0, anchor_t=4.0, fl_gamma=0.0, label_smoothing=0.0)
+    bs = 4
+    tg = yo.synth_targets(bs, 80, seed=5).to(dev)
+    out = {}
+    for arm in ("0", "1"):
+        monkeypatch.setenv("Y3_WGRAD_STREAM", arm)
+        m, _ = build_pair(cfg, 80, 41, dev, torch.float32)
+        m.train()
+        m.hyp = hyp
+        crit = ComputeLoss(m)
+        steps = []
+        for it in range(3):
+            x = torch.rand(bs, 3, hw, hw + 32 * (it % 2), generator=torch.Generator().manual_seed(it)).to(dev)   # two shapes: two plans of one slot share the workspace
+            m.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.float16):
+                loss, _ = crit(m(x), tg)
+            (loss * 64.0).backward()
+            junk = torch.randn(1 << 22, device=dev).sin_().sum()   # the compute stream moves on while the side stream may still be writing gradients
+            steps.append(torch.cat([p_.grad.flatten() for p_ in m.parameters()]).clone())
+            del junk
+        torch.cuda.synchronize()
+        pl = [v for k, v in plan_cache(m).plans.items() if k[0] == "train"]
+        assert pl and all((p_.wgrad_stream is not None) == (arm == "1") for p_ in pl), "the switch was not read"
+        out[arm] = steps
+    for it, (a, b) in enumerate(zip(out["0"], out["1"])):
+        assert torch.isfinite(a).all() and a.abs().sum() > 0
+        assert torch.equal(a, b), f"step {it}: max |d| {(a - b).abs().max().item():.3e}"
 
 
 def test_loss_rejects_out_of_range_targets(dev):

@@ -212,7 +212,7 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         t = _call_timer
-        return _lib if t is None or t.thread != threading.get_ident() else t   # a CallTimer times the thread that installed it, nobody else's calls
+        return _lib if t is None else t
     import torch  # noqa: F401  (must precede the dlopen, see docstring)
 
     if not LIB_PATH.exists():
@@ -245,15 +245,16 @@ _QUERIES = frozenset((
 class CallTimer:
     """HIP-event timing of every C-ABI call made while the timer is installed (`with CallTimer() as t: step()`), on the stream the kernels are launched on (torch's
     current stream: what ops.stream_ptr() hands to the library).  bench.py uses it to split ONE training step into kernel families in the run that reports it,
-    instead of quoting a profile taken elsewhere.  `by_function()` -> {C function: [milliseconds, calls]} once the stream has drained.  Bench-only: it times the calls of
-    the thread that installed it (other threads keep the plain handle), code that cached the real handle before bypasses it, and it stops recording at MAX_RECORDS."""
+    instead of quoting a profile taken elsewhere.  `by_function()` -> {C function: [milliseconds, calls]} once the stream has drained.  Bench-only: while it
+    is installed EVERY thread's calls are timed (autograd runs the backward on its own thread), each on the stream current in that thread; code that cached the real handle
+    before bypasses it; it stops recording at MAX_RECORDS."""
 
     MAX_RECORDS = 100_000   # bench-only tool: a timer left installed around a long loop stops recording instead of growing without bound
 
     def __init__(self):
         self.records = []   # (function name, start event, end event)
         self._fns = {}
-        self.thread = threading.get_ident()   # calls of other threads (data loaders, an NMS thread, another model) go to the plain handle: lib()
+        self._lock = threading.Lock()         # the backward of a step runs on autograd's own thread: every thread of the process is timed, appends are serialised
         self.dropped = 0
 
     def __getattr__(self, name):   # stands in for the ctypes handle: lib().y3_xxx(...)
@@ -273,7 +274,8 @@ class CallTimer:
                     e0.record()
                     r = raw_(*a)
                     e1.record()
-                    self.records.append((name_, e0, e1))
+                    with self._lock:
+                        self.records.append((name_, e0, e1))
                     return r
             self._fns[name] = fn
         return fn
@@ -281,7 +283,6 @@ class CallTimer:
     def __enter__(self):
         global _call_timer
         lib()   # (loaded before the proxy stands in for it)
-        self.thread = threading.get_ident()
         _call_timer = self
         return self
 

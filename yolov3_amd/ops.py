@@ -224,9 +224,16 @@ def conv2d_dgrad_s2(w_oihw: torch.Tensor, du: View, gx: View, accumulate: bool):
     check(L.y3_conv2d_dgrad_s2(dtype_code(dt), C.byref(dut), packed.data_ptr(), C.byref(gxt) if accumulate else None, C.byref(gxt), stream_ptr()), "y3_conv2d_dgrad_s2")
 
 
-def conv2d_wgrad(x: View, du: View, k: int, stride: int, cout_real: int, cin_real: int, want_bias: bool = False, alloc=None):
+def conv2d_wgrad_workspace_bytes(x: View, cout: int, k: int, stride: int) -> int:
+    d = Y3ConvDesc(dtype_code(x.buf.dtype), k, stride, 0, 0, 0, x.c, cout, 0)
+    xt = x.y3()
+    return int(_lib.lib().y3_conv2d_wgrad_workspace_bytes(C.byref(d), C.byref(xt)))
+
+
+def conv2d_wgrad(x: View, du: View, k: int, stride: int, cout_real: int, cin_real: int, want_bias: bool = False, alloc=None, workspace=None):
     """Filter gradient (cout_real, cin_real, k, k) fp32 (+ bias gradient) of a conv with input x and output-gradient du.
-    `alloc(shape)` supplies the output tensors (the training plan's per-backward gradient arena); default torch.empty."""
+    `alloc(shape)` supplies the output tensors (the training plan's per-backward gradient arena); default torch.empty.  `workspace`: a caller-owned uint8 buffer
+    for the split-K slabs (the training slot keeps one for all its layers: launches of one stream use it in order); default a fresh allocation per call."""
     d = Y3ConvDesc(dtype_code(x.buf.dtype), k, stride, 0, 0, 0, x.c, du.c, 0)
     if alloc is None:
         def alloc(shape):
@@ -235,7 +242,7 @@ def conv2d_wgrad(x: View, du: View, k: int, stride: int, cout_real: int, cin_rea
     db = alloc((cout_real,)) if want_bias else None
     xt, dt = x.y3(), du.y3()
     need = int(_lib.lib().y3_conv2d_wgrad_workspace_bytes(C.byref(d), C.byref(xt)))
-    ws = torch.empty(need, dtype=torch.uint8, device=x.buf.device)
+    ws = workspace if workspace is not None and workspace.numel() >= need else torch.empty(need, dtype=torch.uint8, device=x.buf.device)
     check(_lib.lib().y3_conv2d_wgrad(C.byref(d), C.byref(xt), C.byref(dt), cout_real, cin_real, dw.data_ptr(), db.data_ptr() if db is not None else None,
                                      ws.data_ptr(), need, stream_ptr()),
           "y3_conv2d_wgrad")

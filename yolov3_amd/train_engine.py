@@ -468,6 +468,7 @@ class TrainSlot:
         self._banks: dict = {}
         self._conv_ws = None
         self._bn_sums = self._stat_buf = self._stem_bwd_ws = None
+        self._wgrad_ws = None        # split-K slabs of the filter gradients: one buffer for every layer of the slot (the launches that use it are ordered on one stream)
         self._zeros: dict = {}
         self._ones: dict = {}
 
@@ -637,12 +638,13 @@ class TrainPlan:
         self.x_nchw = None
         self.x_version = 0
 
-        # Y3_WGRAD_STREAM=1: filter gradients on a second HIP stream.  Measured at batch 64: backward 48.7 -> 48.0 ms, optimizer wait
-        # +0.35 ms -- both kernel families fill the chip on their own, the hardware runs the two queues mostly back to back --
-        # so the default keeps everything on the compute stream
+        # Filter gradients on a second HIP stream (Y3_WGRAD_STREAM=0: one stream).  Nothing downstream in the backward needs them, so the data-gradient / BatchNorm chain
+        # does not wait for them.  Round 5 measured -1.0 ... -1.15 ms per batch-64 step once warm but +5 ms over the first ten steps (every launch took a fresh workspace
+        # under the side stream: a second allocator pool to fill) and left it opt-in; with the slot-owned workspace (wgrad_ws) nothing is allocated under the side stream
+        # and fresh processes gain from the first step: 55.87 -> 55.03 ms, same box, interleaved (profiles/r06_wgrad_stream_ab.txt).  Default since round 6.
         self.wgrad_stream = None
         self._bwd_stream = None   # the stream backward() runs on while a side stream is in use (grad_alloc records the arena on both)
-        if device.type == "cuda" and os.environ.get("Y3_WGRAD_STREAM", "0") == "1":
+        if device.type == "cuda" and os.environ.get("Y3_WGRAD_STREAM", "1") == "1":
             self.wgrad_stream = torch.cuda.Stream(device=device)   # (a lab tool may swap in a CU-masked stream: tools/lab/cu_mask.py, tools/wgrad_overlap_ab.py)
         # Y3_BN_EPILOGUE=0: statistics by a separate reduction pass over u (A/B runs); fp32 plans always take that path
         self.epilogue_stats = dtype in (torch.float16, torch.bfloat16) and os.environ.get("Y3_BN_EPILOGUE", "1") != "0"
@@ -770,24 +772,38 @@ class TrainPlan:
         stream (Y3_WGRAD_STREAM=1; see __init__ for the measurement).  `du` was produced on the current stream: the side
         stream waits for an event recorded here."""
         side = self.wgrad_stream
+        ws = self.wgrad_ws(ops.conv2d_wgrad_workspace_bytes(x, du.c, k, s))   # (taken on the compute stream: nothing is ever allocated under the side stream)
         if side is None:
-            dw, db = ops.conv2d_wgrad(x, du, k, s, co_real, ci_real, want_bias=b_param is not None, alloc=self.grad_alloc)
+            dw, db = ops.conv2d_wgrad(x, du, k, s, co_real, ci_real, want_bias=b_param is not None, alloc=self.grad_alloc, workspace=ws)
             grads[w_param] = dw
             if b_param is not None:
                 grads[b_param] = db
             return
         cur = torch.cuda.current_stream()
+        if self._arena is None:
+            self.grad_alloc((0,))     # the backward's gradient arena comes from the compute stream's pool too
         ev = torch.cuda.Event()
         ev.record(cur)
         du.buf.record_stream(side)   # scratch of this layer: keep it from being recycled while the side stream still reads it
         with torch.cuda.stream(side):
             side.wait_event(ev)
-            dw, db = ops.conv2d_wgrad(x, du, k, s, co_real, ci_real, want_bias=b_param is not None, alloc=self.grad_alloc)   # arena slices in host order, as on one stream
+            dw, db = ops.conv2d_wgrad(x, du, k, s, co_real, ci_real, want_bias=b_param is not None, alloc=self.grad_alloc, workspace=ws)   # arena slices in host order, as on one stream
             dw.record_stream(cur)
             grads[w_param] = dw      # handed over under the side stream: a gradient sink that launches collectives waits for the right stream
             if b_param is not None:
                 db.record_stream(cur)
                 grads[b_param] = db
+
+    def wgrad_ws(self, nbytes):
+        """the slot's filter-gradient workspace, grown to the largest layer's need (a step allocates nothing for the slabs; round 5 took a fresh buffer per launch --
+        on the side stream that filled a second allocator pool over the first ten steps)"""
+        sl = self.slot
+        if sl._wgrad_ws is None or sl._wgrad_ws.numel() < nbytes:
+            old = sl._wgrad_ws
+            if old is not None and self.wgrad_stream is not None:
+                old.record_stream(self.wgrad_stream)   # (launches of an earlier backward may still be using it there)
+            sl._wgrad_ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return sl._wgrad_ws
 
     def stem_bwd_ws(self):
         sl = self.slot
