@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define Y3_ABI_VERSION 4
+#define Y3_ABI_VERSION 5
 
 typedef enum { Y3_F16 = 0, Y3_BF16 = 1, Y3_F32 = 2, Y3_U8 = 3 } y3_dtype;
 typedef enum { Y3_ACT_NONE = 0, Y3_ACT_SILU = 1 } y3_act;
@@ -133,6 +133,14 @@ int64_t y3_stem_conv_stats_rows(int32_t n, int32_t h, int32_t w);
 int y3_stem_conv_fwd_stats(const void* x_nchw, int32_t src_dtype, int32_t n, int32_t cin, int32_t h, int32_t w, float divisor, const void* packed,
                            const float* bias, int32_t dtype, int32_t act, const y3_tensor* y, float* stat_rows, int64_t capacity_rows, int64_t* n_rows,
                            void* stream);
+/* Layer 0 of the training step by recomputation (round 6; models/common.py:75 `act(bn(conv(x)))`, models/yolov3.yaml:16): the pre-BatchNorm output of the first layer --
+ * 64 B per input pixel, the largest tensor of the step -- is never written.  y3_stem_conv_stats_only: the statistics rows of y3_stem_conv_fwd_stats without the
+ * store (`shape` = (n, h, w, filters); its data pointer is not used).  y3_stem_conv_fwd_bn: y = act(scale * u + shift) with u = the conv output rounded to the
+ * compute dtype, recomputed from the image -- bit for bit what y3_bn_act_fwd writes from a stored u. */
+int y3_stem_conv_stats_only(const void* x_nchw, int32_t src_dtype, int32_t n, int32_t cin, int32_t h, int32_t w, float divisor, const void* packed,
+                            int32_t dtype, const y3_tensor* shape, float* stat_rows, int64_t capacity_rows, int64_t* n_rows, void* stream);
+int y3_stem_conv_fwd_bn(const void* x_nchw, int32_t src_dtype, int32_t n, int32_t cin, int32_t h, int32_t w, float divisor, const void* packed,
+                        const float* scale, const float* shift, int32_t act, int32_t dtype, const y3_tensor* y, void* stream);
 /* Layers 0 + 1 of yolov3 / yolov3-spp in one kernel (models/yolov3.yaml:16-17: Conv(3,32,3,1) -> Conv(32,64,3,2)): layer 0's
  * output (the largest tensor of the network, single consumer) stays in LDS.  packed0 / bias0: 32 filters in the stem format
  * (y3_pack_filter_stem); packed1 / bias1: 64 filters over 32 channels in the generic format (y3_pack_filter); y: NHWC
@@ -340,6 +348,12 @@ int y3_stem_bn_bwd_wgrad(const void* x_nchw, int32_t src_dtype, int32_t n, int32
                          const y3_tensor* dy, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t dtype,
                          int32_t act, double* sums, float* dgamma /* may be NULL */, float* dbeta /* may be NULL */, float* dw_oihw,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* The same backward when the forward did not store u (y3_stem_conv_stats_only + y3_stem_conv_fwd_bn): both passes rebuild the tile's u from the image patch
+ * they stage anyway (the forward's MFMAs on the forward's operands: the same bits).  packed0: the stem-packed filters the forward used (y3_pack_filter_stem). */
+int y3_stem_bn_bwd_wgrad_recompute(const void* x_nchw, int32_t src_dtype, int32_t n, int32_t cin, int32_t h, int32_t w, float divisor, const void* packed0,
+                                   const y3_tensor* dy, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t dtype,
+                                   int32_t act, double* sums, float* dgamma /* may be NULL */, float* dbeta /* may be NULL */, float* dw_oihw,
+                                   void* workspace, size_t workspace_bytes, void* stream);
 /* OIHW fp32 -> filter bank of the data-gradient convolution: `cin` filters over (kh, kw, cout) with flipped taps. */
 int y3_pack_filter_dgrad(const float* w_oihw, int32_t cout_src, int32_t cin_src, int32_t ksize, int32_t cout, int32_t cin,
                          int32_t dtype, void* packed, void* stream);

@@ -2184,6 +2184,121 @@ def test_filter_gradients_on_the_side_stream_are_bit_identical(dev, monkeypatch,
         assert torch.equal(a, b), f"step {it}: max |d| {(a - b).abs().max().item():.3e}"
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(3, 70, 150), (2, 64, 64), (1, 5, 200)], ids=["ragged_tiles", "whole_tiles", "short_wide"])
+def test_stem_layer0_by_recomputation_matches_the_stored_path(dev, dtype, shape):
+    """Round 6: layer 0 of the training step without its pre-BatchNorm tensor (csrc/stem.hip: y3_stem_conv_stats_only + y3_stem_conv_fwd_bn; csrc/train.hip:
+    y3_stem_bn_bwd_wgrad_recompute).  Forward: the statistics rows and the normalised activation are the SAME BITS as the stored path's (stem_conv_stats, then
+    y3_bn_act_fwd on the stored u).  Backward: dW / dgamma / dbeta against the stored-u kernels (another order of the fp64 partial sums: 1e-6 level) and against
+    fp32 autograd of conv -> affine -> SiLU on the same rounded operands."""
+    _lib, ops = _ops()
+    import ctypes as C
+
+    L = _lib.lib()
+    n, h, w = shape
+    g = torch.Generator().manual_seed(17)
+    x = torch.rand(n, 3, h, w, generator=g)
+    wt = torch.randn(32, 3, 3, 3, generator=g) / math.sqrt(27)
+    xd = x.to(dev)
+    filt = ops.pack_filter_stem(wt.to(dev), 32, dtype)
+    zb = torch.zeros(32, device=dev)
+    rows_cap = ops.stem_conv_stats_rows(n, h, w)
+    # stored path
+    u = ops.View.alloc(n, h, w, 32, dtype, dev)
+    r_ref = torch.zeros(rows_cap * 64, device=dev)
+    nr = ops.stem_conv_stats(xd, filt, zb, u, r_ref, rows_cap)
+    mean = (torch.randn(32, generator=g) * 0.2).to(dev)
+    invstd = (torch.rand(32, generator=g) + 0.5).to(dev)
+    gamma = (torch.rand(32, generator=g) + 0.5).to(dev)
+    beta = (torch.randn(32, generator=g) * 0.3).to(dev)
+    scale = (gamma * invstd).contiguous()
+    shift = (beta - mean * gamma * invstd).contiguous()
+    y_ref = ops.View.alloc(n, h, w, 32, dtype, dev)
+    ut, yt = u.y3(), y_ref.y3()
+    _lib.check(L.y3_bn_act_fwd(C.byref(ut), scale.data_ptr(), shift.data_ptr(), None, C.byref(yt), ops.dtype_code(dtype), _lib.Y3_ACT_SILU, ops.stream_ptr()), "y3_bn_act_fwd")
+    # recomputation
+    r_new = torch.zeros(rows_cap * 64, device=dev)
+    like = ops.View(torch.empty(0, dtype=dtype, device=dev), n, h, w, 32, 32, 0)
+    assert ops.stem_conv_stats_only(xd, filt, like, r_new, rows_cap) == nr
+    y_new = ops.View.alloc(n, h, w, 32, dtype, dev)
+    y_new.buf.fill_(float("nan"))
+    ops.stem_conv_bn(xd, filt, scale, shift, _lib.Y3_ACT_SILU, y_new)
+    torch.cuda.synchronize()
+    assert torch.equal(r_new, r_ref), "statistics rows differ"
+    assert torch.equal(y_new.buf.view(torch.int16), y_ref.buf.view(torch.int16)), "normalised activation differs"
+    # backward
+    gy = ops.View.alloc(n, h, w, 32, dtype, dev)
+    gy.buf.copy_(torch.randn(n * h * w * 32, generator=g).to(dtype))
+    ws = ops.stem_bwd_workspace(dev)
+    outs = []
+    for arm in ("stored", "recompute"):
+        sums = ops.bn_scratch(32, dev)
+        dg, db, dw = torch.zeros(32, device=dev), torch.zeros(32, device=dev), torch.zeros(32, 3, 3, 3, device=dev)
+        if arm == "stored":
+            ops.stem_bn_bwd_wgrad(xd, u, gy, scale, shift, mean, invstd, _lib.Y3_ACT_SILU, sums, dg, db, dw, ws)
+        else:
+            ops.stem_bn_bwd_wgrad_recompute(xd, filt, gy, scale, shift, mean, invstd, _lib.Y3_ACT_SILU, sums, dg, db, dw, ws)
+            dw2 = torch.zeros_like(dw)
+            ops.stem_bn_bwd_wgrad_recompute(xd, filt, gy, scale, shift, mean, invstd, _lib.Y3_ACT_SILU, ops.bn_scratch(32, dev), torch.zeros(32, device=dev), torch.zeros(32, device=dev), dw2, ws)
+            torch.cuda.synchronize()
+            assert torch.equal(dw, dw2), "not run-to-run deterministic"
+        torch.cuda.synchronize()
+        outs.append((dg.cpu(), db.cpu(), dw.cpu()))
+    for a, b, what in zip(outs[0], outs[1], ("dgamma", "dbeta", "dw")):
+        e = (a - b).abs().max().item() / max(a.abs().max().item(), 1e-30)
+        assert e < 2e-5, f"{what}: stored vs recomputed {e:.2e}"
+    # fp32 autograd on the same rounded operands: u as stored, the BatchNorm backward written out with the given (mean, invstd) as constants
+    uf = u.as_nhwc().float().cpu()
+    gf = gy.as_nhwc().float().cpu()
+    z = uf * scale.cpu() + shift.cpu()
+    sg = torch.sigmoid(z)
+    dz = gf * (sg + z * sg * (1 - sg))
+    xh = (uf - mean.cpu()) * invstd.cpu()
+    M = n * h * w
+    db_ref = dz.sum((0, 1, 2))
+    dg_ref = (dz * xh).sum((0, 1, 2))
+    du = (scale.cpu() * (dz - db_ref / M - xh * (dg_ref / M))).to(dtype).float()
+    xr = x.to(dtype).float().requires_grad_(False)
+    wz = torch.zeros(32, 3, 3, 3, requires_grad=True)
+    F.conv2d(xr, wz, None, stride=1, padding=1).backward(du.permute(0, 3, 1, 2))
+    dgn, dbn, dwn = outs[1]
+    assert (dgn - dg_ref).abs().max().item() / dg_ref.abs().max().item() < 1e-4
+    assert (dbn - db_ref).abs().max().item() / db_ref.abs().max().item() < 1e-4
+    tol = 2e-3 if dtype == torch.float16 else 1.5e-2   # du is rounded to T in both; products of rounded operands, fp32 sums
+    assert (dwn - wz.grad).abs().max().item() / wz.grad.abs().max().item() < tol
+
+
+def test_train_step_with_and_without_layer0_recomputation(dev, monkeypatch):
+    """the whole step with Y3_STEM_RECOMPUTE = 0 / 1 (yolov3, 160 x 128, autocast fp16; the switch is off by default -- profiles/r06_stem_recompute_ab.txt): layer 0's
+    activation is bit-identical, so the loss and every gradient behind layer 0 are; layer 0's own three gradients differ by the order of its fp64 partial sums only"""
+    from yolov3_amd import ComputeLoss
+
+    hyp = dict(box=0.05, cls=0.5, cls_pw=1.0, obj=1.0, obj_pw=1.0, anchor_t=4.0, fl_gamma=0.0, label_smoothing=0.0)
+    tg = yo.synth_targets(4, 80, seed=5).to(dev)
+    x = torch.rand(4, 3, 160, 128, generator=torch.Generator().manual_seed(3)).to(dev)
+    res = {}
+    for arm in ("0", "1"):
+        monkeypatch.setenv("Y3_STEM_RECOMPUTE", arm)
+        m, _ = build_pair("yolov3", 80, 41, dev, torch.float32)
+        m.train()
+        m.hyp = hyp
+        crit = ComputeLoss(m)
+        with torch.autocast("cuda", dtype=torch.float16):
+            loss, _ = crit(m(x), tg)
+        (loss * 64.0).backward()
+        torch.cuda.synchronize()
+        res[arm] = (float(loss), {k: p_.grad.clone() for k, p_ in m.named_parameters()}, {k: v.clone() for k, v in m.state_dict().items() if "running" in k})
+    assert res["0"][0] == res["1"][0], (res["0"][0], res["1"][0])
+    for k, v in res["0"][2].items():
+        assert torch.equal(v, res["1"][2][k]), f"running statistics {k}"
+    for k, ga in res["0"][1].items():
+        gb = res["1"][1][k]
+        if k.startswith("model.0."):
+            assert (ga - gb).abs().max().item() <= 2e-5 * ga.abs().max().item(), k
+        else:
+            assert torch.equal(ga, gb), k
+
+
 def test_loss_rejects_out_of_range_targets(dev):
     """a target with image index >= bs (or < 0) or class >= nc used to index out of bounds in the match kernels; the
     reference raises an IndexError.  Here the row is dropped on the device and the loss comes back NaN (no host sync to raise

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(lib):
     nm = subprocess.check_output(["nm", "-D", "--defined-only", str(_lib.LIB_PATH)], text=True)
     exported = set(re.findall(r" T (y3_[a-z0-9_]+)", nm))
     assert declared <= exported, declared - exported
-    assert lib.y3_abi_version() == 4 == _lib.ABI_VERSION
+    assert lib.y3_abi_version() == 5 == _lib.ABI_VERSION
 
 
 def test_argument_validation_is_loud_and_gpu_free(lib):

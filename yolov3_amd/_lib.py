@@ -12,8 +12,9 @@ LIB_PATH = Path(os.environ["Y3_LIB"]) if os.environ.get("Y3_LIB") else _PKG / "l
 
 Y3_F16, Y3_BF16, Y3_F32, Y3_U8 = 0, 1, 2, 3
 Y3_ACT_NONE, Y3_ACT_SILU = 0, 1
-ABI_VERSION = 4   # include/yolov3_hip.h::Y3_ABI_VERSION (2: round-3 export set -- tune / SyncBN / TTA / wgrad_plan added, y3_bn_act_bwd_apply takes sums + 2C; 3: y3_loss_params.sort_obj_iou;
-                  # 4: y3_conv_workspace_error / _reset removed (no-ops since the stream-K kernel went), the loss workspace grew by one int per slot)
+ABI_VERSION = 5   # include/yolov3_hip.h::Y3_ABI_VERSION (2: round-3 export set -- tune / SyncBN / TTA / wgrad_plan added, y3_bn_act_bwd_apply takes sums + 2C; 3: y3_loss_params.sort_obj_iou;
+                  # 4: y3_conv_workspace_error / _reset removed (no-ops since the stream-K kernel went), the loss workspace grew by one int per slot;
+                  # 5: layer 0 by recomputation (y3_stem_conv_stats_only / _fwd_bn / y3_stem_bn_bwd_wgrad_recompute), y3_shard_mean, knob wgrad_patch)
 Y3_ALGO_AUTO, Y3_ALGO_MFMA, Y3_ALGO_DIRECT = 0, 1, 2
 
 
@@ -185,7 +186,13 @@ _SIGNATURES = {
     "y3_stem_bn_bwd_wgrad_workspace_bytes": (C.c_size_t, []),
     "y3_stem_bn_bwd_wgrad": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P(Y3Tensor), _P(Y3Tensor), C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "y3_stem_bn_bwd_wgrad_recompute": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, _P(Y3Tensor), C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "y3_stem_conv_stats_rows": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "y3_stem_conv_stats_only": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_int32, _P(Y3Tensor), C.c_void_p, C.c_int64,
+                                          C.c_void_p, C.c_void_p]),
+    "y3_stem_conv_fwd_bn": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                      _P(Y3Tensor), C.c_void_p]),
     "y3_stem_conv_fwd_stats": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, _P(Y3Tensor),
                                          C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "y3_sgd_tensor_record_bytes": (C.c_size_t, []),

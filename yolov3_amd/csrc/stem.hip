@@ -28,6 +28,12 @@ struct StemArgs {
     float divisor;
     float* stats;       // optional: row blockIdx.x of [Cout][2] floats = (sum, sum of squares) of the block's STORED values (training: BatchNorm
                         // batch statistics without a separate pass over the 64 B/pixel output)
+    // round 6, layer 0 of the training step by recomputation (the 64 B/pixel pre-BatchNorm tensor is never written):
+    //   y == nullptr: statistics only -- the rows are those of the values a store would have written, nothing is stored;
+    //   scale != nullptr: what is stored is act(scale u + shift) of the rounded conv output u, rounded again -- bit for bit what bn_act_fwd_kernel writes from the stored u
+    const float* scale;
+    const float* shift;
+    int act_bn;
 };
 
 constexpr int TR = 8, TW = 64;   // output rows x columns per block
@@ -104,6 +110,15 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemArgs p) {
     T* __restrict__ yg = (T*)p.y;
     const int rp = lane / CH, ch = lane % CH;
     const bool want_stats = p.stats != nullptr;   // kernel-uniform
+    const bool bn_apply = p.scale != nullptr;     // kernel-uniform
+    f32x2 bsc[4], bsh[4];
+    if (bn_apply && ch * 8 + 8 <= p.Cout) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bsc[q] = f32x2{p.scale[ch * 8 + 2 * q], p.scale[ch * 8 + 2 * q + 1]};
+            bsh[q] = f32x2{p.shift[ch * 8 + 2 * q], p.shift[ch * 8 + 2 * q + 1]};
+        }
+    }
     float st0[8], st1[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) st0[q] = st1[q] = 0.0f;
@@ -158,10 +173,22 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const StemArgs p) {
             const frag ov = *(const frag*)(wl + pl * RB + ((ch ^ (pl & (CH - 1))) << 4));
             const int gcol = col0 + j0 + pl;
             if (grow < p.H && gcol < p.W && ch * 8 + 8 <= p.Cout) {
-                *(frag*)(yg + ((long long)(n * p.H + grow) * p.W + gcol) * p.ypitch + ch * 8) = ov;
                 if (want_stats) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) { const float f = to_f32<T>(ov[q]); st0[q] += f; st1[q] += f * f; }
+                }
+                if (yg) {
+                    frag out = ov;
+                    if (bn_apply) {
+                        u32x4 w4;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x2 z = y3_bn_act2(f32x2{to_f32<T>(ov[2 * q]), to_f32<T>(ov[2 * q + 1])}, bsc[q], bsh[q], p.act_bn == Y3_ACT_SILU, false, f32x2{0.0f, 0.0f});
+                            w4[q] = pack2<T>(z[0], z[1]);
+                        }
+                        out = __builtin_bit_cast(frag, w4);
+                    }
+                    *(frag*)(yg + ((long long)(n * p.H + grow) * p.W + gcol) * p.ypitch + ch * 8) = out;
                 }
             }
         }
@@ -836,15 +863,17 @@ extern "C" int y3_pack_filter_stem(const float* w, int32_t cout_src, int32_t cin
 }
 
 static int stem_conv_impl(const void* x_nchw, int32_t src_dtype, int32_t n, int32_t cin, int32_t h, int32_t w, float divisor, const void* packed, const float* bias,
-                          int32_t dtype, int32_t act, const y3_tensor* y, float* stat_rows, int64_t capacity_rows, int64_t* n_rows, void* stream, const char* who) {
-    if (!x_nchw || !packed || !y || !y->data) Y3_FAIL("%s: null argument", who);
+                          int32_t dtype, int32_t act, const y3_tensor* y, float* stat_rows, int64_t capacity_rows, int64_t* n_rows, void* stream, const char* who,
+                          bool store = true, const float* bn_scale = nullptr, const float* bn_shift = nullptr, int32_t bn_act = Y3_ACT_NONE) {
+    if (!x_nchw || !packed || !y || (store && !y->data)) Y3_FAIL("%s: null argument", who);
     if (cin < 1 || cin > 4) Y3_FAIL("%s: %d input channels (1..4 supported)", who, cin);
     if (y->n != n || y->h != h || y->w != w) Y3_FAIL("%s: output must be (%d,%d,%d,*) for a stride-1 pad-1 3x3", who, n, h, w);
-    if ((y->c % 8) || y->c > 64 || (y->pitch % 8) || ((uintptr_t)y->data & 15) || ((uintptr_t)packed & 15)) Y3_FAIL("%s: 8..64 filters (multiple of 8), 16-byte aligned views", who);
+    if ((y->c % 8) || y->c > 64 || (y->pitch % 8) || (store && ((uintptr_t)y->data & 15)) || ((uintptr_t)packed & 15)) Y3_FAIL("%s: 8..64 filters (multiple of 8), 16-byte aligned views", who);
     if (!(divisor > 0.0f)) Y3_FAIL("%s: divisor must be positive", who);
     if ((long long)n * h * w > 0x7fffffffLL) Y3_FAIL("%s: too many pixels", who);
     StemArgs a;
-    a.x = x_nchw; a.w = packed; a.bias = bias; a.y = y->data;
+    a.x = x_nchw; a.w = packed; a.bias = bias; a.y = store ? y->data : nullptr;
+    a.scale = bn_scale; a.shift = bn_shift; a.act_bn = bn_act;
     a.N = n; a.Cin = cin; a.H = h; a.W = w; a.ypitch = y->pitch; a.Cout = y->c; a.act = act;
     a.tiles_w = (w + TW - 1) / TW; a.tiles_h = (h + TR - 1) / TR;
     a.divisor = divisor;
@@ -874,6 +903,20 @@ extern "C" int y3_stem_conv_fwd_stats(const void* x_nchw, int32_t src_dtype, int
                                       void* stream) {
     if (!stat_rows || !n_rows) Y3_FAIL("y3_stem_conv_fwd_stats: null statistics buffer");
     return stem_conv_impl(x_nchw, src_dtype, n, cin, h, w, divisor, packed, bias, dtype, act, y, stat_rows, capacity_rows, n_rows, stream, "y3_stem_conv_fwd_stats");
+}
+
+// statistics of layer 0's conv output WITHOUT writing it (round 6): `shape` gives (n, h, w, filters); its data pointer is not used
+extern "C" int y3_stem_conv_stats_only(const void* x_nchw, int32_t src_dtype, int32_t n, int32_t cin, int32_t h, int32_t w, float divisor, const void* packed, int32_t dtype,
+                                       const y3_tensor* shape, float* stat_rows, int64_t capacity_rows, int64_t* n_rows, void* stream) {
+    if (!stat_rows || !n_rows) Y3_FAIL("y3_stem_conv_stats_only: null statistics buffer");
+    return stem_conv_impl(x_nchw, src_dtype, n, cin, h, w, divisor, packed, nullptr, dtype, Y3_ACT_NONE, shape, stat_rows, capacity_rows, n_rows, stream, "y3_stem_conv_stats_only", false);
+}
+
+// y = act(scale u + shift) with u = the rounded conv output recomputed from the image: layer 0's normalised activation in one pass over the image
+extern "C" int y3_stem_conv_fwd_bn(const void* x_nchw, int32_t src_dtype, int32_t n, int32_t cin, int32_t h, int32_t w, float divisor, const void* packed, const float* scale,
+                                   const float* shift, int32_t act, int32_t dtype, const y3_tensor* y, void* stream) {
+    if (!scale || !shift) Y3_FAIL("y3_stem_conv_fwd_bn: null scale / shift");
+    return stem_conv_impl(x_nchw, src_dtype, n, cin, h, w, divisor, packed, nullptr, dtype, Y3_ACT_NONE, y, nullptr, 0, nullptr, stream, "y3_stem_conv_fwd_bn", true, scale, shift, act);
 }
 
 namespace {

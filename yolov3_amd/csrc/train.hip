@@ -1289,6 +1289,254 @@ __global__ __launch_bounds__(256, 4) void stem_bn_bwd_wgrad_kernel(const StemBwd
     }
 }
 
+// ---- layer 0 backward by RECOMPUTATION (round 6): u -- the 64 B/pixel pre-BatchNorm output of layer 0, 1.68 GB at batch 64 -- is not stored by the forward any more
+// (stem.hip: statistics-only pass + one pass that writes act(bn(u))).  Both backward passes rebuild the tile's u from the image patch they stage anyway: the patch goes
+// to LDS a second time as 4-channel pixels (the B operand of stem_conv_kernel), each wave multiplies its tile row (2 x 3 MFMAs with the stem-packed filters held in
+// registers) and writes the ROUNDED values -- the same MFMAs on the same operands in the same order as the forward, hence the same bits the stored tensor had -- as
+// [pixel][32 channels] rows into LDS, where the elementwise code reads them instead of global memory.
+//   REDUCE = true : (sum dz, sum dz xhat) per channel -> one partial row per block (rows 1 .. of `sums`, as channel_reduce_kernel writes them)
+//   REDUCE = false: du = BatchNorm + activation backward, dW += du (x) image patch (as stem_bn_bwd_wgrad_kernel)
+struct StemRecArgs {
+    StemBwdArgs b;
+    const void* w0;     // stem-packed layer-0 filters [32][3][16]
+    double* part_rows;  // REDUCE: sums + 64 (row 0 = totals)
+};
+constexpr int SR_PW = SB_TW + 4;   // 4-channel patch columns: one halo column each side + the 4th pixel of the widest fragment read (+ 1 spare)
+
+template <typename T, typename S, bool SILU, bool REDUCE>
+__global__ __launch_bounds__(256, 2) void stem_bwd_recompute_kernel(const StemRecArgs q) {
+    const StemBwdArgs& p = q.b;
+    typedef typename std::conditional<std::is_same<T, f16_t>::value, f16x8, bf16x8>::type frag;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) unsigned char duT[REDUCE ? 16 : 32 * SB_ROWB];
+    __shared__ __attribute__((aligned(16))) T patch[REDUCE ? 8 : 3 * 3 * (SB_TR + 2) * SB_TW];   // [kw][c][row][col] (the filter gradient's B operand)
+    __shared__ __attribute__((aligned(16))) unsigned char patch4[(SB_TR + 2) * SR_PW * 8];        // [row][col][4 channels] (conv0's B operand)
+    __shared__ __attribute__((aligned(16))) unsigned char utile[SB_TR * SB_TW * 64];             // u of the tile: [pixel][32 channels], 16-byte chunks XOR-swizzled by pixel
+    __shared__ double red[REDUCE ? 4 * 64 : 1];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = tid & 3;
+    f32x2 sc[4], sh[4], mu[4], is[4], m0[4], m1[4];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = cg * 8 + e;
+        sc[e / 2][e & 1] = p.scale[c]; sh[e / 2][e & 1] = p.shift[c]; mu[e / 2][e & 1] = p.mean[c]; is[e / 2][e & 1] = p.invstd[c];
+        if (!REDUCE) {
+            m0[e / 2][e & 1] = (float)(p.sums[c * 2] / p.count);
+            m1[e / 2][e & 1] = (float)(p.sums[c * 2 + 1] / p.count);
+        }
+    }
+    const int fn = lane & 31, kg = lane >> 5;
+    // conv0: lane (filter = fn, fk = kg) holds k = 8 fk + j of each filter row (stem_conv_kernel)
+    frag af[3];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) af[kh] = *(const frag*)((const T*)q.w0 + (fn * 3 + kh) * 16 + kg * 8);
+    // filter gradient roles (stem_bn_bwd_wgrad_kernel)
+    const int b_tap = fn / p.Cin, b_c = fn - b_tap * p.Cin;
+    const bool b_ok = fn < 9 * p.Cin;
+    const int b_kh = b_tap / 3, b_kw = b_tap - 3 * b_kh;
+    const int b_off = b_ok ? (((b_kw * 3 + b_c) * (SB_TR + 2) + wv + b_kh) * SB_TW + 8 * kg) : 0;
+    const int a_off = fn * SB_ROWB + (wv * SB_TW + 8 * kg) * 2;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    double a0[8], a1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a0[e] = a1[e] = 0.0;
+    const int hw = p.H * p.W;
+    const T* __restrict__ dg = (const T*)p.dy;
+    for (int e = tid; e < (SB_TR + 2) * SR_PW * 2; e += 256) ((unsigned*)patch4)[e] = 0u;   // channel 3 and the two spare columns stay zero for the block's life
+
+    // A block's phases are a serial chain (patch -> conv0 -> elementwise -> filter gradient): with the loads issued where they are used every tile started with a full
+    // HBM round trip and the first cut ran at 2.2 TB/s (1.50 ms for the reduction pass against 0.69 ms of the pass over the stored tensor).  Everything a tile reads
+    // from memory -- its image patch elements and its four 16-byte pieces of dy per thread -- is therefore requested one tile AHEAD into registers (stem_pair_kernel's
+    // scheme): the loads of tile i + 1 fly under the arithmetic of tile i.
+    constexpr int NEL = (3 * (SB_TR + 2) * (SB_TW + 2) + 255) / 256;   // patch elements per thread (Cin <= 3)
+    int pe_c[NEL], pe_r[NEL], pe_j[NEL];
+#pragma unroll
+    for (int k = 0; k < NEL; ++k) {
+        const int e = tid + k * 256;
+        const int jj = e % (SB_TW + 2);
+        const int t = e / (SB_TW + 2);
+        pe_r[k] = t % (SB_TR + 2);
+        pe_c[k] = e < p.Cin * (SB_TR + 2) * (SB_TW + 2) ? t / (SB_TR + 2) : -1;
+        pe_j[k] = jj;
+    }
+    S raw[NEL];
+    bool rin[NEL];
+    V16<T> gq[4];
+    bool gv[4];
+    auto fetch = [&](int tile) {
+        int b = tile;
+        const int tw = b % p.tiles_w; b /= p.tiles_w;
+        const int th = b % p.tiles_h;
+        const int n = b / p.tiles_h;
+        const int row0 = th * SB_TR, col0 = tw * SB_TW;
+        const S* __restrict__ xs = (const S*)p.x + (long long)n * p.Cin * hw;
+#pragma unroll
+        for (int k = 0; k < NEL; ++k) {
+            const int gh = row0 + pe_r[k] - 1, gw = col0 + pe_j[k] - 1;
+            rin[k] = pe_c[k] >= 0 && (unsigned)gh < (unsigned)p.H && (unsigned)gw < (unsigned)p.W;
+            if (rin[k]) raw[k] = xs[pe_c[k] * hw + gh * p.W + gw];
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int pi = (tid >> 2) + 64 * it;
+            const int r = pi >> 5, pj = pi & 31;
+            const int gh = row0 + r, gw = col0 + 2 * pj;
+            const long long pix = (long long)(n * p.H + gh) * p.W + gw;
+            gv[2 * it] = gh < p.H && gw < p.W;
+            gv[2 * it + 1] = gh < p.H && gw + 1 < p.W;
+            if (gv[2 * it]) gq[2 * it] = *(const V16<T>*)(dg + pix * p.dpitch + cg * 8);
+            if (gv[2 * it + 1]) gq[2 * it + 1] = *(const V16<T>*)(dg + (pix + 1) * p.dpitch + cg * 8);
+        }
+    };
+    if ((int)blockIdx.x < p.n_tiles) fetch(blockIdx.x);
+    __syncthreads();
+
+    for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+        // ---- this tile's image patch (requested one tile ago), rounded to T as the forward rounded it, into both layouts ----
+#pragma unroll
+        for (int k = 0; k < NEL; ++k) {
+            if (pe_c[k] < 0) continue;
+            const T tv = from_f32<T>(rin[k] ? stem_src_f32<S>(raw[k]) / p.divisor : 0.0f);
+            *(T*)(patch4 + ((pe_r[k] * SR_PW + pe_j[k]) * 4 + pe_c[k]) * 2) = tv;
+            if (!REDUCE) {
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int j = pe_j[k] - kw;
+                    if ((unsigned)j < (unsigned)SB_TW) patch[((kw * 3 + pe_c[k]) * (SB_TR + 2) + pe_r[k]) * SB_TW + j] = tv;
+                }
+            }
+        }
+        V16<T> gc[4];
+        bool vc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { gc[k] = gq[k]; vc[k] = gv[k]; }
+        __syncthreads();
+        if (tile + (int)gridDim.x < p.n_tiles) fetch(tile + gridDim.x);   // the next tile's loads fly under this tile's arithmetic
+        // ---- u of the tile: wave wv owns tile row wv, two 32-pixel column blocks ----
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            f32x16 ua;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) ua[e] = 0.0f;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const unsigned char* src = patch4 + (((wv + kh) * SR_PW + jb * 32 + fn + 2 * kg) * 8);
+                typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+                u64x2 rw;
+                rw[0] = *(const unsigned long long*)src;
+                rw[1] = *(const unsigned long long*)(src + 8);
+                const frag bf = __builtin_bit_cast(frag, rw);
+                if constexpr (std::is_same<T, f16_t>::value) ua = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kh], bf, ua, 0, 0, 0);
+                else ua = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kh], bf, ua, 0, 0, 0);
+            }
+            const int pix = wv * SB_TW + jb * 32 + fn;
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                u32x4 ov;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(pack2<T>(ua[8 * gp + 2 * h], ua[8 * gp + 2 * h + 1]), pack2<T>(ua[8 * gp + 4 + 2 * h], ua[8 * gp + 4 + 2 * h + 1]), false, false);
+                    ov[h] = (unsigned)sw[0];
+                    ov[2 + h] = (unsigned)sw[1];
+                }
+                const int chunk = gp * 2 + kg;
+                *(u32x4*)(utile + pix * 64 + ((chunk ^ (pix & 3)) << 4)) = ov;
+            }
+        }
+        __syncthreads();
+        // ---- the elementwise part: two horizontally adjacent pixels x 8 channels per thread and trip ----
+        f32x2 f0[4], f1[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f0[e] = f1[e] = f32x2{0.0f, 0.0f};
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int pi = (tid >> 2) + 64 * it;          // pixel pair of the tile
+            const int r = pi >> 5, pj = pi & 31;
+            const bool v0 = vc[2 * it], v1 = vc[2 * it + 1];
+            const int lp = r * SB_TW + 2 * pj;
+            const V16<T> x0 = *(const V16<T>*)(utile + lp * 64 + ((cg ^ (lp & 3)) << 4));
+            const V16<T> x1 = *(const V16<T>*)(utile + (lp + 1) * 64 + ((cg ^ ((lp + 1) & 3)) << 4));
+            const V16<T> g0 = gc[2 * it], g1 = gc[2 * it + 1];
+            float d0[8], d1[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f32x2 r0 = {0.0f, 0.0f}, r1 = {0.0f, 0.0f};
+                if (v0) {
+                    const f32x2 uf = ld2<T>(x0, 2 * e);
+                    f32x2 dz = ld2<T>(g0, 2 * e);
+                    if (SILU) { const f32x2 z = uf * sc[e] + sh[e]; dz *= silu_grad2(z, sigmoid2(z)); }
+                    const f32x2 xh = (uf - mu[e]) * is[e];
+                    if (REDUCE) { f0[e] += dz; f1[e] += dz * xh; }
+                    else r0 = sc[e] * (dz - m0[e] - xh * m1[e]);
+                }
+                if (v1) {
+                    const f32x2 uf = ld2<T>(x1, 2 * e);
+                    f32x2 dz = ld2<T>(g1, 2 * e);
+                    if (SILU) { const f32x2 z = uf * sc[e] + sh[e]; dz *= silu_grad2(z, sigmoid2(z)); }
+                    const f32x2 xh = (uf - mu[e]) * is[e];
+                    if (REDUCE) { f0[e] += dz; f1[e] += dz * xh; }
+                    else r1 = sc[e] * (dz - m0[e] - xh * m1[e]);
+                }
+                d0[2 * e] = r0[0]; d0[2 * e + 1] = r0[1]; d1[2 * e] = r1[0]; d1[2 * e + 1] = r1[1];
+            }
+            if (!REDUCE) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) *(unsigned*)(duT + (cg * 8 + e) * SB_ROWB + (r * SB_TW + 2 * pj) * 2) = pack2<T>(d0[e], d1[e]);
+            }
+        }
+        if (REDUCE) {   // fp32 over the tile's four pixels per thread, fp64 across tiles (channel_reduce_kernel's scheme)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { a0[e] += (double)f0[e / 2][e & 1]; a1[e] += (double)f1[e / 2][e & 1]; }
+            __syncthreads();   // utile / patch4 are rewritten by the next trip
+            continue;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const frag a = *(const frag*)(duT + a_off + 32 * s4);
+            frag bf = *(const frag*)(patch + b_off + 16 * s4);
+            if (!b_ok) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bf[e] = (T)0.0f;
+            }
+            if constexpr (std::is_same<T, f16_t>::value) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf, acc, 0, 0, 0);
+            else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bf, acc, 0, 0, 0);
+        }
+        __syncthreads();   // the tile's LDS is rewritten by the next trip
+    }
+    if constexpr (REDUCE) {
+        // lanes with the same cg (lane & 3) hold partial sums of the same 8 channels: butterfly over the other lane bits, then the four waves in wave order
+#pragma unroll
+        for (int off = 4; off < 64; off <<= 1)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { a0[e] += __shfl_xor(a0[e], off, 64); a1[e] += __shfl_xor(a1[e], off, 64); }
+        if (lane < 4) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { red[wv * 64 + (cg * 8 + e) * 2] = a0[e]; red[wv * 64 + (cg * 8 + e) * 2 + 1] = a1[e]; }
+        }
+        __syncthreads();
+        if (tid < 64) q.part_rows[(size_t)blockIdx.x * 64 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+    } else {
+        // ---- the four waves' tiles -> one partial tile per block: D[filter = 8 g + 4 kg + e][n = fn] ----
+        float* redf = (float*)duT;   // 4 x 1024 floats
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) redf[wv * 1024 + (8 * g + 4 * kg + e) * 32 + fn] = acc[4 * g + e];
+        __syncthreads();
+        float* out = p.part + (long long)blockIdx.x * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = tid + 256 * i;
+            out[o] = (redf[o] + redf[1024 + o]) + (redf[2048 + o] + redf[3072 + o]);
+        }
+    }
+}
+
 // dW[co][c][kh][kw] = sum over the blocks' partial tiles [co][n = (kh * 3 + kw) * Cin + c], block order (deterministic)
 __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ part, int nblocks, int cin, int cout, float* __restrict__ dw) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -1613,6 +1861,53 @@ extern "C" int y3_stem_bn_bwd_wgrad(const void* x_nchw, int32_t src_dtype, int32
     if (dtype == Y3_F16) { Y3_SB_SRC(f16_t) } else { Y3_SB_SRC(bf16_t) }
 #undef Y3_SB_SRC
 #undef Y3_SB
+    Y3_CHECK_LAUNCH();
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((32 * cin * 9 + 255) / 256), dim3(256), 0, st, (const float*)workspace, blocks, cin, 32, dw_oihw);
+    Y3_CHECK_LAUNCH();
+    return 0;
+}
+
+// Layer 0 backward when the forward did not store u (y3_stem_conv_stats_only + y3_stem_conv_fwd_bn): both passes recompute it from the image (stem_bwd_recompute_kernel)
+extern "C" int y3_stem_bn_bwd_wgrad_recompute(const void* x_nchw, int32_t src_dtype, int32_t n, int32_t cin, int32_t h, int32_t w, float divisor, const void* packed0,
+                                              const y3_tensor* dy, const float* scale, const float* shift, const float* mean, const float* invstd, int32_t dtype, int32_t act,
+                                              double* sums, float* dgamma, float* dbeta, float* dw_oihw, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x_nchw || !packed0 || !dy || !scale || !shift || !mean || !invstd || !sums || !dw_oihw || !workspace) Y3_FAIL("y3_stem_bn_bwd_wgrad_recompute: null argument");
+    if (cin < 1 || cin > 3) Y3_FAIL("y3_stem_bn_bwd_wgrad_recompute: %d input channels (1..3)", cin);
+    if (dy->c != 32 || dy->n != n || dy->h != h || dy->w != w) Y3_FAIL("y3_stem_bn_bwd_wgrad_recompute: the gradient must be (%d,%d,%d,32)", n, h, w);
+    if (dtype != Y3_F16 && dtype != Y3_BF16) Y3_FAIL("y3_stem_bn_bwd_wgrad_recompute: f16/bf16 only");
+    if (!vec_ok(dy, 2) || (((uintptr_t)packed0) & 15)) Y3_FAIL("y3_stem_bn_bwd_wgrad_recompute: alignment");
+    if (!(divisor > 0.0f)) Y3_FAIL("y3_stem_bn_bwd_wgrad_recompute: divisor must be positive");
+    if (workspace_bytes < y3_stem_bn_bwd_wgrad_workspace_bytes() || (((uintptr_t)workspace) & 15)) Y3_FAIL("y3_stem_bn_bwd_wgrad_recompute: workspace too small / unaligned");
+    const long long M = (long long)n * h * w;
+    if (M > 0x7fffffffLL / 4) Y3_FAIL("y3_stem_bn_bwd_wgrad_recompute: too many pixels");
+    hipStream_t st = (hipStream_t)stream;
+    StemRecArgs a;
+    memset(&a, 0, sizeof(a));
+    a.b.x = x_nchw; a.b.u = nullptr; a.b.dy = dy->data; a.b.upitch = 0; a.b.dpitch = dy->pitch;
+    a.b.scale = scale; a.b.shift = shift; a.b.mean = mean; a.b.invstd = invstd; a.b.sums = sums; a.b.count = (double)M;
+    a.b.part = (float*)workspace;
+    a.b.N = n; a.b.Cin = cin; a.b.H = h; a.b.W = w;
+    a.b.tiles_w = (w + SB_TW - 1) / SB_TW; a.b.tiles_h = (h + SB_TR - 1) / SB_TR;
+    const long long tiles = (long long)a.b.tiles_w * a.b.tiles_h * n;
+    a.b.n_tiles = (int)tiles;
+    a.b.divisor = divisor;
+    a.w0 = packed0;
+    a.part_rows = sums + 64;
+    const int cap_r = 2 * y3_cu_count() < Y3_BN_PARTIAL_ROWS ? 2 * y3_cu_count() : Y3_BN_PARTIAL_ROWS;   // the scratch holds Y3_BN_PARTIAL_ROWS partial rows
+    const int blocks_r = tiles < cap_r ? (int)tiles : cap_r;
+    const int cap = 2 * y3_cu_count() < 1024 ? 2 * y3_cu_count() : 1024;   // persistent: 2 blocks per CU (the one-tile-ahead registers put the kernel at ~230 VGPRs; the workspace holds 1024 partial tiles)
+    const int blocks = tiles < cap ? (int)tiles : cap;
+#define Y3_SR(TT, SS, RED, NB) do { if (act == Y3_ACT_SILU) hipLaunchKernelGGL((stem_bwd_recompute_kernel<TT, SS, true, RED>), dim3(NB), dim3(256), 0, st, a); \
+                                    else hipLaunchKernelGGL((stem_bwd_recompute_kernel<TT, SS, false, RED>), dim3(NB), dim3(256), 0, st, a); } while (0)
+#define Y3_SR_SRC(TT, RED, NB) switch (src_dtype) { case Y3_F16: Y3_SR(TT, f16_t, RED, NB); break; case Y3_BF16: Y3_SR(TT, bf16_t, RED, NB); break; case Y3_F32: Y3_SR(TT, float, RED, NB); break; \
+                                                   case Y3_U8: Y3_SR(TT, unsigned char, RED, NB); break; default: Y3_FAIL("y3_stem_bn_bwd_wgrad_recompute: bad source dtype %d", src_dtype); }
+    if (dtype == Y3_F16) { Y3_SR_SRC(f16_t, true, blocks_r) } else { Y3_SR_SRC(bf16_t, true, blocks_r) }
+    Y3_CHECK_LAUNCH();
+    hipLaunchKernelGGL(reduce_partials_kernel<2>, dim3((2 * 32 + 15) / 16), dim3(256), 0, st, sums, 2 * 32, blocks_r, BnFinalizeArgs{}, dbeta, dgamma, 0);
+    Y3_CHECK_LAUNCH();
+    if (dtype == Y3_F16) { Y3_SR_SRC(f16_t, false, blocks) } else { Y3_SR_SRC(bf16_t, false, blocks) }
+#undef Y3_SR_SRC
+#undef Y3_SR
     Y3_CHECK_LAUNCH();
     hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((32 * cin * 9 + 255) / 256), dim3(256), 0, st, (const float*)workspace, blocks, cin, 32, dw_oihw);
     Y3_CHECK_LAUNCH();

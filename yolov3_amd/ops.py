@@ -167,6 +167,43 @@ def stem_conv_stats(x_nchw: torch.Tensor, filt: torch.Tensor, bias: torch.Tensor
     return int(rows.value)
 
 
+def stem_conv_stats_only(x_nchw: torch.Tensor, filt: torch.Tensor, like: View, stat_rows: torch.Tensor, capacity_rows: int, divisor: float = 1.0) -> int:
+    """the statistics rows of stem_conv_stats WITHOUT writing the conv output (`like` gives its shape and dtype): layer 0 of the training step by recomputation"""
+    require_gpu(x_nchw, "stem_conv_stats_only")
+    x = x_nchw.contiguous()
+    n, c, h, w = x.shape
+    lt = like.y3()
+    rows = C.c_int64(0)
+    check(_lib.lib().y3_stem_conv_stats_only(x.data_ptr(), dtype_code(x.dtype), n, c, h, w, float(divisor), filt.data_ptr(), dtype_code(like.buf.dtype), C.byref(lt),
+                                             stat_rows.data_ptr(), int(capacity_rows), C.byref(rows), stream_ptr()), "y3_stem_conv_stats_only")
+    return int(rows.value)
+
+
+def stem_conv_bn(x_nchw: torch.Tensor, filt: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, act: int, y: View, divisor: float = 1.0):
+    """y = act(scale * round(conv0(x)) + shift) straight from the image: what bn_act_fwd would write from the stored conv output, which is never stored"""
+    require_gpu(x_nchw, "stem_conv_bn")
+    x = x_nchw.contiguous()
+    n, c, h, w = x.shape
+    yt = y.y3()
+    check(_lib.lib().y3_stem_conv_fwd_bn(x.data_ptr(), dtype_code(x.dtype), n, c, h, w, float(divisor), filt.data_ptr(), scale.data_ptr(), shift.data_ptr(), int(act),
+                                         dtype_code(y.buf.dtype), C.byref(yt), stream_ptr()), "y3_stem_conv_fwd_bn")
+
+
+def stem_bn_bwd_wgrad_recompute(x_nchw: torch.Tensor, filt: torch.Tensor, dy: View, scale, shift, mean, invstd, act: int, sums: torch.Tensor, dgamma, dbeta, dw: torch.Tensor,
+                                workspace: torch.Tensor, divisor: float = 1.0):
+    """stem_bn_bwd_wgrad without a stored u: both passes recompute it from the image (filt: the stem-packed filters of the forward)"""
+    require_gpu(x_nchw, "stem_bn_bwd_wgrad_recompute")
+    x = x_nchw.contiguous()
+    n, c, h, w = x.shape
+    if dw.dtype != torch.float32 or not dw.is_contiguous() or tuple(dw.shape) != (32, c, 3, 3):
+        raise TypeError("stem_bn_bwd_wgrad_recompute: dw must be a contiguous fp32 (32, cin, 3, 3) tensor")
+    gt = dy.y3()
+    check(_lib.lib().y3_stem_bn_bwd_wgrad_recompute(x.data_ptr(), dtype_code(x.dtype), n, c, h, w, float(divisor), filt.data_ptr(), C.byref(gt), scale.data_ptr(), shift.data_ptr(),
+                                                    mean.data_ptr(), invstd.data_ptr(), dtype_code(dy.buf.dtype), int(act), sums.data_ptr(),
+                                                    dgamma.data_ptr() if dgamma is not None else None, dbeta.data_ptr() if dbeta is not None else None, dw.data_ptr(),
+                                                    workspace.data_ptr(), workspace.numel(), stream_ptr()), "y3_stem_bn_bwd_wgrad_recompute")
+
+
 def stem_bwd_workspace(device) -> torch.Tensor:
     return torch.empty(int(_lib.lib().y3_stem_bn_bwd_wgrad_workspace_bytes()), dtype=torch.uint8, device=device)
 
