@@ -222,7 +222,16 @@ def run_train(args, rank, world, dev, parallel, yo, batch, steps, warmup):
     groups, timed_step_ms = None, None
     from yolov3_amd import _lib as y3lib
 
+    side_streams = []
     try:   # (every rank runs the extra step -- it contains the gradient collectives -- rank 0's record is the one reported)
+        # the instrumented step runs on ONE stream: with the filter gradients on their side stream (the default since round 6) two full-chip kernels are time-sliced and
+        # every call's event pair would measure the other stream's kernels too (the families then sum to more than the step)
+        from yolov3_amd.engine import plan_cache
+
+        for key, pl in plan_cache(model).plans.items():
+            if key[0] == "train" and getattr(pl, "wgrad_stream", None) is not None:
+                side_streams.append((pl, pl.wgrad_stream))
+                pl.wgrad_stream = None
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -236,6 +245,9 @@ def run_train(args, rank, world, dev, parallel, yo, batch, steps, warmup):
         groups["outside the library (torch glue, gaps)"] = {"ms_per_step": round(timed_step_ms - lib_ms, 3), "calls_per_step": 0}
     except Exception as e:  # noqa: BLE001
         groups = {"error": f"{type(e).__name__}: {e}"[:300]}
+    finally:
+        for pl, st_ in side_streams:
+            pl.wgrad_stream = st_
     parallel.barrier()
     rec = {
         "metric": "images/sec (640x640) train step", "value": round(world * bs * steps / dt, 2), "unit": "images/sec", "n_gpus": world,
@@ -248,7 +260,8 @@ def run_train(args, rank, world, dev, parallel, yo, batch, steps, warmup):
                      "whole_step_frac": round(tflops / MFMA_PEAK_TFLOPS, 4), "gflop_per_image": round(flops_img / 1e9, 2),
                      "note": "whole step (fwd + dgrad + wgrad conv FLOPs per GPU / step time)",
                      "kernel_groups": groups, "kernel_groups_step_ms": timed_step_ms,
-                     "kernel_groups_source": "measured in this run: HIP events around every C-ABI call of one more step (yolov3_amd._lib.CallTimer), after the timed steps"},
+                     "kernel_groups_source": "measured in this run: HIP events around every C-ABI call of one more step (yolov3_amd._lib.CallTimer), after the timed steps; that step runs on ONE "
+                                             "stream (the timed steps run the filter gradients on a second one: their families would overlap), so kernel_groups_step_ms is the one-stream step"},
     }
     del model, opt, ema, crit
     torch.cuda.empty_cache()
