@@ -26,6 +26,10 @@
 //   * split-K over contiguous position ranges, one fp32 slab per block in REGISTER order (every store instruction writes 1 KiB contiguous), summed in slice order
 //     by wgrad_patch_reduce_kernel: deterministic, no atomics.  The blocks of a slice are neighbours on one XCD (xcd_remap) and walk the same positions: the operand
 //     rows they share meet in that L2.
+//   * MEASURED AND NOT KEPT (round 6): reading the x positions of a tap row once (three groups of four positions) and cutting the three dw taps out of them in registers
+//     (four v_perm_b32 for dw = 0, three v_mov_b32 for dw = +1): 13 transposing reads per k-group instead of 22 -- and 3 % SLOWER per launch on the same box (247 / 244 / 252
+//     -> 254 / 252 / 261 us, profiles/r06_wgrad_patch_lab.txt): the VALU results feed MFMAs directly (two wait states each) and what this loop pays for is every
+//     instruction that sits between two MFMAs, not the LDS array's cycles.
 // LDS (129 KiB, one block per CU; the rings start at multiples of 32 KiB so that `& 0x7fc0` is the wrap): [plane 0: 32 KiB ring + 1 KiB mirror][du stage 0]
 // [plane 1 at 64 KiB: ring + mirror][du stages 1, 2].
 
