@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--dtype", default="fp16")
     ap.add_argument("--arms", default="", help='custom arms instead of the default three: "knob=value,knob=value;knob=value" (each with a workspace)')
     ap.add_argument("--noact", action="store_true", help="no activation (the training-mode launches)")
+    ap.add_argument("--train-forms", action="store_true", help="the three forms a 3x3 layer runs in the train step, interleaved: plain (no activation), forward with the "
+                    "BatchNorm statistics rows from the epilogue, data-gradient form (accumulating into the output through the residual port)")
     ap.add_argument("--sweep", action="store_true", help="also time the forced tile variants (knob conv = 4 / 5 / 6 / 15) and the forced v10 wave-tile widths")
     args = ap.parse_args()
     from yolov3_amd import ops
@@ -96,6 +98,32 @@ def main():
             arms += [(f"conv={v}", None, {"conv": v, "conv_v10": 0}) for v in (4, 6, 15)]
             if k == 3 and s == 1 and cout % 256 == 0:
                 arms += [(f"v10 mp{m}", ws, {"conv_v10": 2, "v10_mp": m}) for m in (6, 7, 8)]
+        if args.train_forms:   # what the statistics rows and the accumulating residual cost a launch of the same shape (same kernel source, same box, interleaved)
+            rows = ops.conv2d_stats_rows(xv, yv, k, s, workspace=ws)
+            sbuf = torch.empty(rows * 2 * cout, dtype=torch.float32, device=dev)
+            acc = ops.View.alloc(n, ho, wo, cout, dtype, dev)
+            acc.buf.zero_()
+            zb = torch.zeros(cout, device=dev)
+            forms = [("plain", lambda: ops.conv2d(xv, filt, zb, yv, k, s, False, None, workspace=ws)),
+                     ("fwd+stats", lambda: ops.conv2d_stats(xv, filt, zb, yv, k, s, sbuf, rows, workspace=ws)),
+                     ("dgrad-acc", lambda: ops.conv2d(xv, filt, zb, acc, k, s, False, acc, workspace=ws))]
+            tf = {f[0]: [] for f in forms}
+            for rnd in range(args.rounds + 1):
+                for fname, fn in forms:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    fn()
+                    e0.record()
+                    for _ in range(args.reps):
+                        fn()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    if rnd:
+                        tf[fname].append(e0.elapsed_time(e1) * 1e3 / args.reps)
+            for fname, _ in forms:
+                med, mn = statistics.median(tf[fname]), min(tf[fname])
+                print(f"{name:28s} {fname:10s} {'':18s} {med:9.1f} {mn:9.1f} {flops / med / 1e6:10.1f} {flops / mn / 1e6:10.1f}")
+            sys.stdout.flush()
+            continue
         times = {a[0]: [] for a in arms}
         outs = {}
         for rnd in range(args.rounds + 1):

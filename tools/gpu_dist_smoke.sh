@@ -2,7 +2,7 @@
 # (no torch.distributed.run wrapper: self_launch), rendezvous on 127.0.0.1, rank / device mapping, GradBuckets at world 2 (SUM + divide path on device
 # tensors), barrier + max-over-ranks timing, the rank-0 JSON line with the appended train leg, the watchdog -- before the driver's first 8-GPU run.
 # Outputs: gpurun_out/${TAG}_dist_smoke_{infer,train}.json (copy into profiles/).
-TAG=${1:-r05}
+TAG=${1:-r06}
 mkdir -p gpurun_out
 timeout 200 python3 bench.py --gpus 2 --train-timeout 90 --steps 3 --warmup 1 --batch 4 --train-batch 4 --train-steps 2 --dist-backend gloo --no-cpu-baseline --no-clocks \
   > gpurun_out/${TAG}_dist_smoke_infer.json 2> gpurun_out/dist_smoke_infer.err; echo "infer exit $?"

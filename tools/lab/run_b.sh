@@ -1,9 +1,9 @@
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "wgrad_patch or wgrad_benchmark_shapes" 2>&1 | tail -3
-for r in 1 2; do
-  for L in base new; do
-    if [ $L = base ]; then export Y3_LIB=$PWD/yolov3_amd/lib/libyolov3_hip_base.so; else unset Y3_LIB; fi
-    echo "== $L"; timeout 600 python tools/wgrad_lab.py --arms "wgrad_patch=1" --shapes L6cv2,L8cv2,L10cv2 --rounds 4 --reps 10 2>&1 | grep -v "amdgpu.ids\|^shape"
-  done
+run() { timeout 300 python bench.py --mode train --batch 64 --steps 10 --warmup 4 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['value'], d['ms_per_step'])"; }
+export Y3_NO_EXCHANGE_LEG=1
+for i in 1 2; do
+  run "defaults"
+  Y3_WGRAD_STREAM=0 run "one stream"
+  Y3_TUNE=wgrad_patch=0 run "wgrad_big"
+  Y3_WGRAD_STREAM=0 Y3_TUNE=wgrad_patch=0 run "one stream + wgrad_big"
+  (cd _prevtree && run "r05 tree")
 done
-unset Y3_LIB
-Y3_LIB=$PWD/yolov3_amd/lib/libyolov3_hip_wpabl.so timeout 900 python tools/wgrad_patch_ablate.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r06_wgrad_patch_ablate.txt
