@@ -395,6 +395,12 @@ int y3_conv2d_wgrad(const y3_conv_desc* desc, const y3_tensor* x, const y3_tenso
 int y3_upsample2x_bwd(const y3_tensor* dy, const y3_tensor* dx, int32_t dtype, int32_t accumulate, void* stream);
 int y3_maxpool2d_bwd(const y3_tensor* x, const y3_tensor* dy, const y3_tensor* dx, int32_t dtype, int32_t k, int32_t stride,
                      int32_t pad, int32_t zpad_r, int32_t zpad_b, int32_t accumulate, void* stream);
+/* The max-pool backward with a byte of workspace per OUTPUT element (y3_maxpool2d_bwd_workspace_bytes): pass 1 records each window's first maximum, pass 2 looks
+ * the k^2 windows of an input element up -- k^2 byte loads per element where y3_maxpool2d_bwd scans k^2 windows of k^2 elements (SPP's 13 x 13 pool: 210 ms -> well
+ * under a millisecond at batch 64).  Same sums in the same order.  Without a (large enough) workspace, or k > 15, it runs y3_maxpool2d_bwd. */
+size_t y3_maxpool2d_bwd_workspace_bytes(const y3_tensor* x, int32_t k, int32_t stride, int32_t pad, int32_t zpad_r, int32_t zpad_b);
+int y3_maxpool2d_bwd_ws(const y3_tensor* x, const y3_tensor* dy, const y3_tensor* dx, int32_t dtype, int32_t k, int32_t stride, int32_t pad, int32_t zpad_r,
+                        int32_t zpad_b, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
 int y3_detect_raw_bwd(const void* graw, int32_t dtype, int32_t bs, int32_t na, int32_t ny, int32_t nx, int32_t no,
                       const y3_tensor* ghead, void* stream);
 

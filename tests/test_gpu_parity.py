@@ -2299,6 +2299,50 @@ def test_train_step_with_and_without_layer0_recomputation(dev, monkeypatch):
             assert torch.equal(ga, gb), k
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("n,h,w,c,k,s,p,zr,zb", [(2, 20, 20, 64, 13, 1, 6, 0, 0), (2, 20, 20, 64, 9, 1, 4, 0, 0), (3, 11, 17, 40, 5, 1, 2, 0, 0), (2, 26, 26, 32, 2, 2, 0, 0, 0),
+                                                  (2, 13, 13, 48, 2, 1, 0, 1, 1), (1, 9, 7, 16, 3, 2, 1, 0, 0)],
+                         ids=["spp13", "spp9", "spp5_odd", "tiny_2x2s2", "tiny_zeropad_s1", "k3s2"])
+def test_maxpool_backward_indexed_form(dev, dtype, n, h, w, c, k, s, p, zr, zb):
+    """y3_maxpool2d_bwd_ws (round 6: first-maximum index per window + k^2 look-ups per element) against the gather form y3_maxpool2d_bwd it replaces in the training plans --
+    the same bits, write and accumulate, with ties in the input (half the values are repeated) -- and against torch's max_pool2d autograd on tie-free inputs."""
+    _lib, ops = _ops()
+    import ctypes as C
+
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(23)
+    ho, wo = (h + zb + 2 * p - k) // s + 1, (w + zr + 2 * p - k) // s + 1
+    for ties in (True, False):
+        xt = torch.randn(n, c, h, w, generator=g)
+        if ties:
+            xt = (xt * 2).round() / 2          # many equal values per window: the FIRST maximum in row-major order takes the gradient
+        xt = xt.to(dtype).float()
+        gy = torch.randn(n, c, ho, wo, generator=g).to(dtype).float()
+        xv = ops.View.alloc(n, h, w, c, dtype, dev)
+        ops.nchw_to_nhwc(xt.to(dev), xv)
+        gv = ops.View.alloc(n, ho, wo, c, dtype, dev)
+        ops.nchw_to_nhwc(gy.to(dev), gv)
+        outs = []
+        for form in ("gather", "indexed"):
+            dx = ops.View.alloc(n, h, w, c, dtype, dev)
+            dx.buf.fill_(float("nan"))
+            for acc in (False, True):
+                if form == "gather":
+                    a, b, d = xv.y3(), gv.y3(), dx.y3()
+                    _lib.check(L.y3_maxpool2d_bwd(C.byref(a), C.byref(b), C.byref(d), ops.dtype_code(dtype), k, s, p, zr, zb, int(acc), ops.stream_ptr()), "y3_maxpool2d_bwd")
+                else:
+                    ops.maxpool2d_bwd(xv, gv, dx, k, s, p, zr, zb, accumulate=acc)
+            torch.cuda.synchronize()
+            outs.append(dx.as_nhwc().float().cpu().clone())
+        assert torch.equal(outs[0], outs[1]), f"ties={ties}: indexed form differs from the gather form"
+        if not ties and zr == 0 and zb == 0:
+            xr = xt.clone().requires_grad_(True)
+            F.max_pool2d(xr, k, s, p).backward(gy)
+            ref2 = (2 * xr.grad).to(dtype).float() if dtype == torch.float32 else None   # (written once, accumulated once: 2 x the gradient; exact in fp32 only)
+            if ref2 is not None:
+                torch.testing.assert_close(outs[1].permute(0, 3, 1, 2), ref2, rtol=1e-6, atol=1e-6)
+
+
 def test_loss_rejects_out_of_range_targets(dev):
     """a target with image index >= bs (or < 0) or class >= nc used to index out of bounds in the match kernels; the
     reference raises an IndexError.  Here the row is dropped on the device and the loss comes back NaN (no host sync to raise

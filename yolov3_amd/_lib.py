@@ -179,6 +179,9 @@ _SIGNATURES = {
     "y3_conv2d_wgrad": (C.c_int, [_P(Y3ConvDesc), _P(Y3Tensor), _P(Y3Tensor), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "y3_upsample2x_bwd": (C.c_int, [_P(Y3Tensor), _P(Y3Tensor), C.c_int32, C.c_int32, C.c_void_p]),
     "y3_maxpool2d_bwd": (C.c_int, [_P(Y3Tensor), _P(Y3Tensor), _P(Y3Tensor), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "y3_maxpool2d_bwd_workspace_bytes": (C.c_size_t, [_P(Y3Tensor), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "y3_maxpool2d_bwd_ws": (C.c_int, [_P(Y3Tensor), _P(Y3Tensor), _P(Y3Tensor), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
+                                      C.c_void_p]),
     "y3_detect_raw_bwd": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P(Y3Tensor), C.c_void_p]),
     "y3_packed_filter_stem_elems": (C.c_size_t, [C.c_int32]),
     "y3_pack_filter_stem": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
@@ -246,7 +249,7 @@ _QUERIES = frozenset((
     "y3_abi_version", "y3_last_error", "y3_tune_set", "y3_tune_get", "y3_tune_reset", "y3_packed_filter_elems", "y3_conv_workspace_bytes", "y3_conv_last_variant",
     "y3_conv2d_fwd_variant", "y3_nms_workspace_bytes", "y3_loss_workspace_bytes", "y3_conv2d_fwd_stats_rows", "y3_conv2d_fwd_stats_rows_ws", "y3_conv2d_fwd_bnin_rows", "y3_pack_job_blocks",
     "y3_packed_filter_dgrad_s2_elems", "y3_conv2d_wgrad_workspace_bytes", "y3_conv2d_wgrad_plan", "y3_packed_filter_stem_elems", "y3_stem_bn_bwd_wgrad_workspace_bytes",
-    "y3_stem_conv_stats_rows", "y3_conv_v10_tiles", "y3_sgd_tensor_record_bytes"))
+    "y3_stem_conv_stats_rows", "y3_conv_v10_tiles", "y3_sgd_tensor_record_bytes", "y3_maxpool2d_bwd_workspace_bytes"))
 
 
 class CallTimer:

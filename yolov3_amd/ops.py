@@ -323,6 +323,15 @@ def maxpool2d(x: View, y: View, k: int, stride: int, pad: int, zpad_r: int = 0, 
     check(_lib.lib().y3_maxpool2d(C.byref(xt), C.byref(yt), dtype_code(x.buf.dtype), k, stride, pad, zpad_r, zpad_b, stream_ptr()), "y3_maxpool2d")
 
 
+def maxpool2d_bwd(x: View, dy: View, dx: View, k: int, stride: int, pad: int, zpad_r: int = 0, zpad_b: int = 0, accumulate: bool = False):
+    """dx (+)= backward of MaxPool2d(k, stride, pad) (+ right / bottom zero pad) through the indexed two-pass form (a byte of scratch per output element)"""
+    xt, gt, dt = x.y3(), dy.y3(), dx.y3()
+    need = int(_lib.lib().y3_maxpool2d_bwd_workspace_bytes(C.byref(xt), k, stride, pad, zpad_r, zpad_b))
+    ws = torch.empty(max(need, 1), dtype=torch.uint8, device=x.buf.device)
+    check(_lib.lib().y3_maxpool2d_bwd_ws(C.byref(xt), C.byref(gt), C.byref(dt), dtype_code(x.buf.dtype), k, stride, pad, zpad_r, zpad_b, int(bool(accumulate)), ws.data_ptr(), need,
+                                         stream_ptr()), "y3_maxpool2d_bwd_ws")
+
+
 def spp_pyramid(x: View, y3c: View):
     xt, yt = x.y3(), y3c.y3()
     check(_lib.lib().y3_spp_pyramid(C.byref(xt), C.byref(yt), dtype_code(x.buf.dtype), stream_ptr()), "y3_spp_pyramid")

@@ -434,18 +434,14 @@ class MaxPoolUnit(_Unit):
         ops.maxpool2d(self.x.view, self.y.view, self.k, self.s, self.p, self.zr, self.zb)
 
     def bwd(self, grads):
-        xt, gy, gx = self.x.view.y3(), self.y.grad().y3(), self.x.grad().y3()
-        check(
-            _lib.lib().y3_maxpool2d_bwd(C.byref(xt), C.byref(gy), C.byref(gx), ops.dtype_code(self.plan.dtype), self.k, self.s, self.p, self.zr, self.zb,
-                                        int(self.x.is_ready()), ops.stream_ptr()),
-            "y3_maxpool2d_bwd",
-        )
+        # the indexed two-pass form, 16 bytes of channels per thread (round 6; y3_maxpool2d_bwd's gather moved 2 bytes per thread: 8.5 ms of yolov3-tiny's 16.4 ms step)
+        ops.maxpool2d_bwd(self.x.view, self.y.grad(), self.x.grad(), self.k, self.s, self.p, self.zr, self.zb, accumulate=self.x.is_ready())
         self.x.mark_ready()
 
 
 class SPPPoolUnit(_Unit):
     """the 5/9/13 stride-1 max-pools of SPP (reference models/common.py:287-290), one forward launch; the backward is
-    three max-pool backward passes accumulating into the pooled tensor's gradient."""
+    three max-pool backward launches pairs (first-maximum index per window, then k^2 look-ups per element) accumulating into the pooled tensor's gradient."""
 
     def __init__(self, plan, x: Act, y3c: Act):
         self.plan, self.x, self.y = plan, x, y3c
@@ -455,11 +451,8 @@ class SPPPoolUnit(_Unit):
 
     def bwd(self, grads):
         c = self.x.view.c
-        xt, gx = self.x.view.y3(), self.x.grad().y3()
-        for j, k in enumerate((5, 9, 13)):
-            gy = self.y.grad().slice(j * c, c).y3()
-            check(_lib.lib().y3_maxpool2d_bwd(C.byref(xt), C.byref(gy), C.byref(gx), ops.dtype_code(self.plan.dtype), k, 1, k // 2, 0, 0, int(self.x.is_ready()), ops.stream_ptr()),
-                  "y3_maxpool2d_bwd")
+        for j, k in enumerate((5, 9, 13)):   # (round 6: the indexed two-pass backward -- the gather form cost 210 ms per batch-64 step on these three pools)
+            ops.maxpool2d_bwd(self.x.view, self.y.grad().slice(j * c, c), self.x.grad(), k, 1, k // 2, accumulate=self.x.is_ready())
             self.x.mark_ready()
 
 
