@@ -2146,7 +2146,8 @@ static void wgrad_geometry(const y3_conv_desc* d, long long M, int& n_ct, int& n
     n_ct = y3_ceil_div(d->cout, 128);
     n_nt = y3_ceil_div(d->ksize * d->ksize * d->cin, 128);
     const long long tiles = (long long)n_ct * n_nt;
-    slices = (1024 + tiles - 1) / tiles;                       // ~2 waves of resident blocks (2 per CU)
+    const long long want_blocks = y3_knob(Y3K_WGRAD_BLOCKS) > 0 ? y3_knob(Y3K_WGRAD_BLOCKS) : 512;
+    slices = (want_blocks + tiles - 1) / tiles;                // knob "wgrad_blocks": one round of resident blocks (2 per CU); 1024 = two rounds wrote twice the slabs for no gain (profiles/r06_wgrad_blocks_ab.txt)
     const long long max_slices = (M + 511) / 512;              // at least 8 K-steps (of 64 pixels) per block
     if (slices > max_slices) slices = max_slices;
     if (slices < 1) slices = 1;
