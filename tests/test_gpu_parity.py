@@ -718,6 +718,55 @@ def test_nms_properties(dev):
             assert again.shape[0] == n, f"idempotence: {n} -> {again.shape[0]}"
 
 
+@pytest.mark.parametrize("case", ["ties_fp16", "nc600_two_class_passes", "bf16", "max_nms_cut_fp32", "ragged_images", "agnostic_fp16"])
+def test_nms_block_sort_equals_device_sorts_and_oracle(dev, tune, case):
+    """nms_sort_kernel (one block per image: stable counting passes by score digits, then by class) against the two rocPRIM device sorts it replaces (knob
+    nms_sort = 0) and against the oracle: heavy score ties (stability = nonzero order), more than 512 classes (two class passes), bf16 / fp32 score digits,
+    the max_nms cut in score order, images with 0 / 1 / a few / many candidates in one batch, the single-segment (agnostic) form."""
+    from yolov3_amd import ops
+
+    g = torch.Generator().manual_seed(77)
+    kw = dict(conf_thres=0.05, iou_thres=0.5, classes=None, agnostic=False, multi_label=True, max_det=300)
+    extra = {}
+    oracle = True
+    if case == "ties_fp16":
+        pred = yo.synth_predictions(bs=3, n_rows=5000, nc=20, seed=5, dtype=torch.float16, hits=0.3)
+        pred[..., 4] = (pred[..., 4].float() * 8).round().div(8).half()         # 9 objectness levels
+        pred[..., 5:] = (pred[..., 5:].float() * 4).round().div(4).half()       # 5 class-score levels: thousands of exact ties per image
+    elif case == "nc600_two_class_passes":
+        pred = torch.rand(2, 1500, 5 + 600, generator=g)
+        pred[..., :2] *= 600
+        pred[..., 2:4] = pred[..., 2:4] * 60 + 4
+        pred[..., 5:] *= (torch.rand(2, 1500, 600, generator=g) < 0.02)          # ~12 labels per row, classes 0 .. 599
+    elif case == "bf16":
+        pred = yo.synth_predictions(bs=2, n_rows=6000, nc=80, seed=6, hits=0.1).to(torch.bfloat16)
+        oracle = False                                                            # (the CPU reference has no bf16 path for every op; the device sorts are the check)
+    elif case == "max_nms_cut_fp32":
+        pred = yo.synth_predictions(bs=2, n_rows=4000, nc=30, seed=7, hits=0.5)
+        extra = dict(max_nms=1000)
+        oracle = False                                                            # (max_nms is a constant inside the reference function)
+    elif case == "ragged_images":
+        pred = yo.synth_predictions(bs=5, n_rows=3000, nc=10, seed=8, dtype=torch.float16, hits=0.4)
+        pred[0, :, 4] = 0                                                         # no candidate
+        pred[2, 1:, 4] = 0                                                        # one row
+        pred[3, 70:, 4] = 0                                                       # fewer than one group per wave
+    else:
+        pred = yo.synth_predictions(bs=2, n_rows=5000, nc=80, seed=9, dtype=torch.float16, hits=0.2)
+        kw["agnostic"] = True
+
+    def run(form):
+        tune("nms_sort", form)
+        rows, counts = ops.nms_raw(pred.to(dev), kw["conf_thres"], kw["iou_thres"], None, kw["agnostic"], True, kw["max_det"], **extra)
+        return [rows[i, :c].cpu() for i, c in enumerate(counts)]
+
+    own, old = run(1), run(0)
+    assert sum(o.shape[0] for o in own) > 50, "the case keeps too few boxes to say anything"
+    _cmp_nms(own, old, case + " (own sort vs device sorts)")
+    if oracle:
+        okw = {k: v for k, v in kw.items() if k != "classes"}
+        _cmp_nms(own, yo.non_max_suppression(pred, **okw), case + " (oracle)")
+
+
 # ------------------------------------------------------------------------------------------------ full model
 def build_pair(name, nc, seed, dev, dtype):
     from yolov3_amd import DetectionModel

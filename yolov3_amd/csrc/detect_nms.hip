@@ -127,6 +127,7 @@ struct NmsWs {  // device pointers carved from the caller's workspace
     void* tmp;                     // rocprim temp storage
     size_t tmp_bytes;
     long long cap;
+    int own_sort;                  // 1: nms_sort_kernel orders the candidates (key_a / key_b / key_c / val_a are its scratch); 0: the rocPRIM sorts on key_a / val_a
 };
 
 template <typename T> Y3_DEV bool gt_thr(float v, float thr_T) { return v > thr_T; }
@@ -214,9 +215,11 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const T* __restrict
                             ws.cbox[g] = box;
                             ws.cscore[g] = conf;
                             ws.ccls[g] = c;
-                            ws.key_a[g] = ((unsigned long long)img << (32 + ORD_BITS)) | ((unsigned long long)(~__float_as_uint(conf)) << ORD_BITS) |
-                                          (unsigned long long)(ord & ((1u << ORD_BITS) - 1u));
-                            ws.val_a[g] = (unsigned)g;
+                            if (!ws.own_sort) {
+                                ws.key_a[g] = ((unsigned long long)img << (32 + ORD_BITS)) | ((unsigned long long)(~__float_as_uint(conf)) << ORD_BITS) |
+                                              (unsigned long long)(ord & ((1u << ORD_BITS) - 1u));
+                                ws.val_a[g] = (unsigned)g;
+                            }
                         } else {
                             status[0] = 1;
                         }
@@ -265,9 +268,11 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const T* __restrict
                         ws.cbox[g] = box;
                         ws.cscore[g] = conf;
                         ws.ccls[g] = c;
-                        ws.key_a[g] = ((unsigned long long)img << (32 + ORD_BITS)) | ((unsigned long long)(~__float_as_uint(conf)) << ORD_BITS) |
-                                      (unsigned long long)(ord & ((1u << ORD_BITS) - 1u));
-                        ws.val_a[g] = (unsigned)g;
+                        if (!ws.own_sort) {
+                            ws.key_a[g] = ((unsigned long long)img << (32 + ORD_BITS)) | ((unsigned long long)(~__float_as_uint(conf)) << ORD_BITS) |
+                                          (unsigned long long)(ord & ((1u << ORD_BITS) - 1u));
+                            ws.val_a[g] = (unsigned)g;
+                        }
                     } else {
                         status[0] = 1;
                     }
@@ -297,9 +302,11 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const T* __restrict
                     ws.cbox[g] = box;
                     ws.cscore[g] = best;
                     ws.ccls[g] = bi;
-                    ws.key_a[g] = ((unsigned long long)img << (32 + ORD_BITS)) | ((unsigned long long)(~__float_as_uint(best)) << ORD_BITS) |
-                                  (unsigned long long)(ord & ((1u << ORD_BITS) - 1u));
-                    ws.val_a[g] = (unsigned)g;
+                    if (!ws.own_sort) {
+                        ws.key_a[g] = ((unsigned long long)img << (32 + ORD_BITS)) | ((unsigned long long)(~__float_as_uint(best)) << ORD_BITS) |
+                                      (unsigned long long)(ord & ((1u << ORD_BITS) - 1u));
+                        ws.val_a[g] = (unsigned)g;
+                    }
                 } else {
                     status[0] = 1;
                 }
@@ -347,7 +354,189 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(NmsWs ws, int bs, int n_r
     val2[i] = (unsigned)i;
 }
 
+// ---- the two orderings of the pipeline by ONE launch (round 6; steps 4-6 of the list at the top) ----------------------------------------------------
+// Rounds 1-5 ran two device-wide rocprim::radix_sort_pairs over the whole candidate capacity (64-bit keys; at ~0.4 M elements rocPRIM takes its merge path: a block
+// sort + eight merge launches per sort, ~0.42 of the 0.72 ms NMS leg).  Neither ordering is device-wide: the candidates of an image are contiguous and already in
+// nonzero order (the emission slots come from a scan), the first ordering is "stable by descending score inside the image", the second "stable by class inside the
+// image's first max_nms".  One block of 16 waves per image does both as LSD counting passes over its own range:
+//   * a pass = (A) per-wave digit histograms in LDS, (B) exclusive prefix over (digit, wave) -- wave w's elements of digit d go behind those of waves < w --,
+//     (C) every wave walks ITS contiguous slice in order, 64 elements at a time: the lanes holding the same digit find each other with one ballot per digit bit
+//     (peers), a lane's slot is the wave's running count of the digit + the peers below it, the highest peer advances the count.  Stable by construction, no
+//     atomics with a result, no ordinal in the key;
+//   * score: the bits of conf that can differ in the tensor dtype (a value rounded to f16 / bf16 has 18 significant bits below the sign: two 9-bit passes;
+//     fp32: four 8-bit passes), complemented, so ascending digits = descending score;
+//   * class: one pass of ceil(log2(nseg)) <= 9 bits (two for more than 512 segments) over the image's first max_nms positions, together with what nms_rank_kernel
+//     did (class-offset boxes in score order, cleared keep flags).  An image that cannot be partitioned (agnostic, or a coordinate beyond max_wh / 2) is ONE segment.
+// The block reads what it wrote in the previous pass through agent-scope loads (L2): no reliance on how this CU's vector L1 treats its own stores.
+constexpr int SORT_WAVES = 16, SORT_NB = 512;
+struct SortLds {
+    unsigned hist[SORT_WAVES * SORT_NB];   // [wave][digit]: counts (A), then the wave's running offset inside the digit (B, C)
+    unsigned tot[SORT_NB];                 // per digit: count, then the digit's first slot
+};
+Y3_DEV unsigned ld_l2(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <typename Load, typename Digit, typename Put>
+Y3_DEV void counting_pass(SortLds& L, const int cnt, const int bits, Load load, Digit digit, Put put) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nb = 1 << bits;
+    for (int i = tid; i < SORT_WAVES * nb; i += SORT_WAVES * 64) L.hist[(i >> bits) * SORT_NB + (i & (nb - 1))] = 0u;
+    __syncthreads();
+    const int per = (((cnt + SORT_WAVES - 1) / SORT_WAVES) + 63) & ~63;   // a wave's slice: whole groups of 64, consecutive elements
+    const int lo = wv * per, hi = cnt < lo + per ? cnt : lo + per;
+    // (A)
+    for (int c0 = lo; c0 < hi; c0 += 256) {
+        uint2 e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {   // the loads of four groups in flight together (an index beyond the slice re-reads its first element: dropped below)
+            const int r = c0 + 64 * u + lane;
+            e[u] = load(r < hi ? r : lo);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = c0 + 64 * u + lane;
+            if (r < hi) atomicAdd(&L.hist[wv * SORT_NB + digit(e[u].x)], 1u);
+        }
+    }
+    __syncthreads();
+    // (B)
+    if (tid < nb) {
+        unsigned run = 0;
+#pragma unroll
+        for (int w = 0; w < SORT_WAVES; ++w) {
+            const unsigned t = L.hist[w * SORT_NB + tid];
+            L.hist[w * SORT_NB + tid] = run;
+            run += t;
+        }
+        L.tot[tid] = run;
+    }
+    __syncthreads();
+    if (wv == 0) {   // exclusive prefix of the digit totals: 8 consecutive digits per lane
+        unsigned v[SORT_NB / 64], sum = 0;
+#pragma unroll
+        for (int k = 0; k < SORT_NB / 64; ++k) {
+            const int d = lane * (SORT_NB / 64) + k;
+            v[k] = d < nb ? L.tot[d] : 0u;
+            sum += v[k];
+        }
+        unsigned inc = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned o = __shfl_up(inc, d);
+            if (lane >= d) inc += o;
+        }
+        unsigned run = inc - sum;
+#pragma unroll
+        for (int k = 0; k < SORT_NB / 64; ++k) {
+            const int d = lane * (SORT_NB / 64) + k;
+            if (d < nb) L.tot[d] = run;
+            run += v[k];
+        }
+    }
+    __syncthreads();
+    // (C)
+    volatile unsigned* H = L.hist + wv * SORT_NB;   // (volatile: group u + 1 reads what group u wrote, in program order)
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int c0 = lo; c0 < hi; c0 += 256) {
+        uint2 e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = c0 + 64 * u + lane;
+            e[u] = load(r < hi ? r : lo);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (c0 + 64 * u >= hi) break;   // (uniform)
+            const int r = c0 + 64 * u + lane;
+            const bool valid = r < hi;
+            const unsigned d = digit(e[u].x);
+            unsigned long long peers = __ballot(valid);
+            for (int b = 0; b < bits; ++b) {
+                const bool bit = (d >> b) & 1u;
+                const unsigned long long m = __ballot(valid && bit);
+                peers &= bit ? m : ~m;
+            }
+            if (valid) {
+                const unsigned base = H[d];
+                put(L.tot[d] + base + (unsigned)__builtin_popcountll(peers & below), e[u].x, e[u].y);
+                if ((peers >> lane) == 1ull) H[d] = base + (unsigned)__builtin_popcountll(peers);   // the highest lane of the digit
+            }
+        }
+    }
+    __syncthreads();   // the slots are written (workgroup scope); L is free
+}
+
+__global__ __launch_bounds__(SORT_WAVES * 64) void nms_sort_kernel(NmsWs ws, int bs, int n_rows, int max_nms, float max_wh, int agnostic, int nseg, int sbit0, int sbits,
+                                                                     int n_sp, int* __restrict__ status) {
+    __shared__ SortLds L;
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const long long total = ws.row_off[(long long)bs * n_rows];
+    if (img == 0 && tid == 0) status[1] = (int)(total > 0x7fffffffLL ? 0x7fffffff : total);
+    const long long start = ws.row_off[(long long)img * n_rows];
+    long long cnt_ll = (long long)ws.row_off[(long long)(img + 1) * n_rows] - start;
+    if (start + cnt_ll > ws.cap) cnt_ll = ws.cap - start > 0 ? ws.cap - start : 0;   // (overflow: status[0] is set by the emit pass, the caller grows the workspace)
+    const int cnt = (int)cnt_ll;
+    if (cnt <= 0) return;   // (uniform)
+    // scratch, 32-bit views: key_a = X0 | X1, key_b = X2 | X3, key_c = X4 (the segment id per slot of the final order) | X5
+    unsigned* const X0 = (unsigned*)ws.key_a + start, * const X1 = (unsigned*)ws.key_a + ws.cap + start;
+    unsigned* const X2 = (unsigned*)ws.key_b + start, * const X3 = (unsigned*)ws.key_b + ws.cap + start;
+    unsigned* const X4 = (unsigned*)ws.key_c + start, * const X5 = (unsigned*)ws.key_c + ws.cap + start;
+    unsigned* const VA = ws.val_a + start, * const VB = ws.val_b + start, * const VC = ws.val_c + start;
+    const float* __restrict__ score = ws.cscore + start;
+
+    // ---- per-image descending-score order (ties keep nonzero order): VB[rank] = candidate slot
+    const unsigned dmask = (1u << sbits) - 1u;
+    for (int p = 0; p < n_sp; ++p) {
+        const int shift = sbit0 + p * sbits;
+        const bool last = p == n_sp - 1;
+        const unsigned* kin = p == 1 ? X0 : p == 2 ? X2 : X5;
+        const unsigned* vin = p == 1 ? X1 : p == 2 ? X3 : VA;
+        unsigned* kout = p == 0 ? X0 : p == 1 ? X2 : X5;
+        unsigned* vout = last ? VB : p == 0 ? X1 : p == 1 ? X3 : VA;
+        counting_pass(
+            L, cnt, sbits,
+            [&](int r) { return p == 0 ? make_uint2(~__float_as_uint(score[r]), (unsigned)(start + r)) : make_uint2(ld_l2(kin + r), ld_l2(vin + r)); },
+            [&](unsigned k) { return (k >> shift) & dmask; },
+            [&](unsigned pos, unsigned k, unsigned v) {
+                if (!last) kout[pos] = k;
+                vout[pos] = v;
+            });
+    }
+
+    // ---- the first max_nms of the image: class-offset boxes in score order, keep flags (nms_rank_kernel), then per-(image, segment) runs in score order
+    const int cntm = cnt < max_nms ? cnt : max_nms;
+    const bool part = !agnostic && nseg > 1 && (__uint_as_float(ws.img_maxabs[img]) < max_wh * 0.5f);
+    for (int r = tid; r < cntm; r += SORT_WAVES * 64) {
+        const unsigned g = ld_l2(VB + r);
+        const float4 b = ws.cbox[g];
+        const float c = (float)ws.ccls[g] * (agnostic ? 0.0f : max_wh);   // x[:, 5:6] * (0 if agnostic else max_wh)  (:731)
+        ws.sbox[start + r] = make_float4(b.x + c, b.y + c, b.z + c, b.w + c);
+        ws.keep[start + r] = 0;
+        if (!part) { VC[r] = (unsigned)(start + r); X4[r] = 0u; }
+    }
+    if (!part) return;   // (uniform)
+    int cbits = 1;
+    while ((1 << cbits) < nseg) ++cbits;
+    auto seg_of = [&](int r) { return make_uint2((unsigned)ws.ccls[ld_l2(VB + r)], (unsigned)(start + r)); };
+    if (cbits <= 9) {
+        counting_pass(L, cntm, cbits, seg_of, [&](unsigned k) { return k; }, [&](unsigned pos, unsigned k, unsigned v) { X4[pos] = k; VC[pos] = v; });
+    } else {
+        counting_pass(L, cntm, 9, seg_of, [&](unsigned k) { return k & 511u; }, [&](unsigned pos, unsigned k, unsigned v) { X0[pos] = k; X1[pos] = v; });
+        counting_pass(
+            L, cntm, cbits - 9, [&](int r) { return make_uint2(ld_l2(X0 + r), ld_l2(X1 + r)); }, [&](unsigned k) { return k >> 9; },
+            [&](unsigned pos, unsigned k, unsigned v) { X4[pos] = k; VC[pos] = v; });
+    }
+}
+
 Y3_DEV long long lower_bound_u64(const unsigned long long* __restrict__ a, long long n, unsigned long long v) {
+    long long lo = 0, hi = n;
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+Y3_DEV long long lower_bound_u32(const unsigned* __restrict__ a, long long n, unsigned v) {
     long long lo = 0, hi = n;
     while (lo < hi) {
         const long long mid = (lo + hi) >> 1;
@@ -369,16 +558,26 @@ Y3_DEV long long lower_bound_u64(const unsigned long long* __restrict__ a, long 
 // The same IoU expression on the same operands decides every bit (inter / (area_i + area_j - inter) as a float, compared with the double threshold), so the
 // kept set is the loop's, bit for bit; four barriers per 64 boxes instead of three per kept box.
 __global__ __launch_bounds__(256) void nms_greedy_kernel(NmsWs ws, int nseg, double iou_thr, int max_det, int max_nms, const unsigned long long* __restrict__ key2,
-                                                          const unsigned* __restrict__ pos2) {
+                                                          const unsigned* __restrict__ pos2, const unsigned* __restrict__ seg_sorted, int n_rows) {
     __shared__ unsigned removed[(1 << RANK_BITS) / 32];  // 32768 bits = 4 KiB
     __shared__ float4 blk[64];                            // the current block's boxes
     __shared__ unsigned long long srow[64];               // their suppression rows inside the block
     __shared__ unsigned long long s_keepm;                // which of them were kept
     __shared__ int s_kept;                                // kept so far in the segment
     const int img = blockIdx.x / nseg, seg = blockIdx.x % nseg;
-    const unsigned long long kbase = ((unsigned long long)img << (CLS_BITS + RANK_BITS)) | ((unsigned long long)seg << RANK_BITS);
-    const long long lo = lower_bound_u64(key2, ws.cap, kbase);
-    const long long hi = lower_bound_u64(key2, ws.cap, kbase + (1ull << RANK_BITS));
+    long long lo, hi;
+    if (seg_sorted) {   // nms_sort_kernel's order: the image's first max_nms slots hold ascending segment ids
+        const long long start = ws.row_off[(long long)img * n_rows];
+        long long cnt = (long long)ws.row_off[(long long)(img + 1) * n_rows] - start;
+        if (start + cnt > ws.cap) cnt = ws.cap - start > 0 ? ws.cap - start : 0;
+        if (cnt > max_nms) cnt = max_nms;
+        lo = start + lower_bound_u32(seg_sorted + start, cnt, (unsigned)seg);
+        hi = start + lower_bound_u32(seg_sorted + start, cnt, (unsigned)seg + 1u);
+    } else {
+        const unsigned long long kbase = ((unsigned long long)img << (CLS_BITS + RANK_BITS)) | ((unsigned long long)seg << RANK_BITS);
+        lo = lower_bound_u64(key2, ws.cap, kbase);
+        hi = lower_bound_u64(key2, ws.cap, kbase + (1ull << RANK_BITS));
+    }
     const int n = (int)(hi - lo);
     if (n <= 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -566,7 +765,8 @@ int run_nms(const void* pred, int bs, int n_rows, int nc, const y3_nms_params* p
 
     Y3_HIP(hipMemsetAsync(out_status, 0, 2 * sizeof(int), st));
     Y3_HIP(hipMemsetAsync(ws.img_maxabs, 0, (size_t)bs * sizeof(unsigned), st));
-    Y3_HIP(hipMemsetAsync(ws.key_a, 0xff, (size_t)cap * 8, st));
+    ws.own_sort = y3_knob(Y3K_NMS_SORT) != 0 ? 1 : 0;
+    if (!ws.own_sort) Y3_HIP(hipMemsetAsync(ws.key_a, 0xff, (size_t)cap * 8, st));
     Y3_HIP(hipMemsetAsync(ws.row_count + scan_n, 0, sizeof(int), st));
 
     const long long waves = (long long)bs * ((n_rows + 63) / 64);
@@ -577,6 +777,19 @@ int run_nms(const void* pred, int bs, int n_rows, int nc, const y3_nms_params* p
     if (rocprim::exclusive_scan(ws.tmp, tb, ws.row_count, ws.row_off, 0, scan_n + 1, rocprim::plus<int>(), st) != hipSuccess) Y3_FAIL("y3_nms: scan failed");
     hipLaunchKernelGGL((nms_candidates_kernel<T, 1>), dim3(cblocks), dim3(256), 0, st, (const T*)pred, bs, n_rows, nc, thr, multi, classes, ncf, ws, out_status, ord_shift);
     Y3_CHECK_LAUNCH();
+    if (ws.own_sort) {
+        // conf is a value of T: below the sign an f16 / bf16 value has 18 bits that can differ (fp32 bits 13 .. 30), an fp32 value all of them
+        const bool narrow = sizeof(T) == 2;
+        hipLaunchKernelGGL(nms_sort_kernel, dim3((unsigned)bs), dim3(SORT_WAVES * 64), 0, st, ws, bs, n_rows, p->max_nms, p->max_wh, p->agnostic, nseg, narrow ? 13 : 0,
+                           narrow ? 9 : 8, narrow ? 2 : 4, out_status);
+        Y3_CHECK_LAUNCH();
+        hipLaunchKernelGGL(nms_greedy_kernel, dim3((unsigned)(bs * nseg)), dim3(256), 0, st, ws, nseg, p->iou_thres, p->max_det, p->max_nms,
+                           (const unsigned long long*)nullptr, ws.val_c, (const unsigned*)ws.key_c, n_rows);
+        Y3_CHECK_LAUNCH();
+        hipLaunchKernelGGL(nms_gather_kernel, dim3((unsigned)bs), dim3(256), 0, st, ws, n_rows, p->max_det, p->max_nms, ws.val_b, out_rows, out_counts);
+        Y3_CHECK_LAUNCH();
+        return 0;
+    }
     tb = ws.tmp_bytes;
     if (rocprim::radix_sort_pairs(ws.tmp, tb, ws.key_a, ws.key_b, ws.val_a, ws.val_b, (size_t)cap, 0u, 64u, st) != hipSuccess) Y3_FAIL("y3_nms: sort-1 failed");
     // (key_b, val_b) = per-image descending-score order.  key_a / val_a are free again: reuse for key2 / positions.
@@ -587,7 +800,8 @@ int run_nms(const void* pred, int bs, int n_rows, int nc, const y3_nms_params* p
     tb = ws.tmp_bytes;
     if (rocprim::radix_sort_pairs(ws.tmp, tb, ws.key_a, ws.key_c, ws.val_a, ws.val_c, (size_t)cap, 0u, (unsigned)(IMG_BITS + CLS_BITS + RANK_BITS), st) != hipSuccess)
         Y3_FAIL("y3_nms: sort-2 failed");
-    hipLaunchKernelGGL(nms_greedy_kernel, dim3((unsigned)(bs * nseg)), dim3(256), 0, st, ws, nseg, p->iou_thres, p->max_det, p->max_nms, ws.key_c, ws.val_c);
+    hipLaunchKernelGGL(nms_greedy_kernel, dim3((unsigned)(bs * nseg)), dim3(256), 0, st, ws, nseg, p->iou_thres, p->max_det, p->max_nms, ws.key_c, ws.val_c,
+                       (const unsigned*)nullptr, n_rows);
     Y3_CHECK_LAUNCH();
     hipLaunchKernelGGL(nms_gather_kernel, dim3((unsigned)bs), dim3(256), 0, st, ws, n_rows, p->max_det, p->max_nms, ws.val_b, out_rows, out_counts);
     Y3_CHECK_LAUNCH();

@@ -22,6 +22,7 @@ enum y3_knob_id {
     Y3K_CONV_1X1S,      // "conv_1x1s":   1 the persistent 1x1 kernel with register-resident filters (conv_1x1s.h) on the HBM-bound 1x1 layers (Cin <= 384, Cout <= 256, >= 32768 pixels); 0 never; 2 also small launches (tests)
     Y3K_WGRAD_PATCH,    // "wgrad_patch": 1 the padded-position filter-gradient kernel (wgrad_patch.h) on the 3x3 / stride-1 layers with Cin % 64 == 0, Cout % 128 == 0 at >= 16384 pixels; 0 never (wgrad_big / wgrad_dma); 2 every eligible shape (tests)
     Y3K_WGRAD_BLOCKS,   // "wgrad_blocks": blocks (tiles x pixel slices) the 128 x 128-tile filter-gradient kernel aims at: every slice writes a 64 KiB partial tile per column tile (512 = one round of resident blocks; 1024 until round 6: +0.6 ms per step of slab traffic)
+    Y3K_NMS_SORT,       // "nms_sort":    1 the two orderings of y3_nms (per-image score order, per-(image, class) segments) by ONE block-per-image launch of stable counting passes (detect_nms.hip::nms_sort_kernel); 0 two rocPRIM device radix sorts (rounds 1-5; A/B and cross-check in the tests)
     Y3K_COUNT
 };
 long long y3_knob(int id);
