@@ -4,17 +4,17 @@
 // Decode   : reference models/yolo.py:98-110.  HBM-bound streaming kernel.
 // NMS      : reference utils/general.py:630-750 + torchvision.ops.nms.  Pipeline (no host sync anywhere):
 //   1 count    wave per 64 anchor rows: obj filter by ballot, per-row label count (multi-label / best class)
-//   2 scan     rocprim exclusive scan of the per-row counts -> ordered (nonzero-order) emission slots
+//   2 scan     nms_scan_kernel (block per image; nms_sort = 0: rocprim exclusive scan) of the per-row counts -> ordered (nonzero-order) emission slots
 //   3 emit     candidates: xyxy box (input-dtype rounding), fp32 score, class; key1 = [img | ~score | ordinal]
-//   4 sort     rocprim radix sort by key1 -> per-image descending-score order (ties keep nonzero order)
-//   5 rank     cut at max_nms per image, class-offset boxes (+cls*max_wh, fp32), key2 = [img | class | rank]
-//   6 sort     by key2 -> per (image, class) segments in score order.  Boxes of different classes cannot overlap
-//              after the class offset when every |coord| < max_wh/2, so greedy NMS factorises per class; an
-//              image that violates the bound (or agnostic mode) falls back to ONE segment for the image.
-//   7 greedy   block per (image, class): visit in order; a kept box suppresses later ones with
+//   4 order    nms_sort_kernel, one block per image (round 6; knob nms_sort = 0: steps 4-6 of rounds 1-5 -- rocprim radix sort by key1, nms_rank_kernel, rocprim radix
+//              sort by key2 = [img | class | rank]): stable counting passes by the score bits -> per-image descending-score order (ties keep nonzero order), cut at
+//              max_nms, class-offset boxes (+cls*max_wh, fp32), one more stable pass by class -> per (image, class) segments in score order.  Boxes of different
+//              classes cannot overlap after the class offset when every |coord| < max_wh/2, so greedy NMS factorises per class; an image that violates the bound
+//              (or agnostic mode) is ONE segment.
+//   5 greedy   block per (image, class): visit in order; a kept box suppresses later ones with
 //              inter/(a_i+a_j-inter) > thr (strict, compared in double like torchvision's CPU kernel);
 //              IoU rows are evaluated lazily for kept boxes only; stop after max_det kept per segment.
-//   8 gather   block per image: kept flags back in score order, first max_det rows -> (bs, max_det, 6) fp32.
+//   6 gather   block per image: kept flags back in score order, first max_det rows -> (bs, max_det, 6) fp32.
 #include "y3_common.h"
 
 #include <rocprim/rocprim.hpp>
@@ -113,6 +113,7 @@ struct NmsWs {  // device pointers carved from the caller's workspace
     int* row_count;                // bs*n_rows (+1)
     int* row_off;                  // bs*n_rows + 1 (exclusive scan, last = total)
     unsigned* img_maxabs;          // bs  (float bits of max |coord| among the image's candidates)
+    unsigned* img_total;           // bs * 64: candidates of the image, spread over 64 slots by wave id (count pass; own scan) -- one slot per image serialised 1575 atomics on one address
     unsigned long long* key_a;     // cap
     unsigned long long* key_b;     // cap
     unsigned* val_a;               // cap
@@ -320,9 +321,73 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const T* __restrict
     }
     if (MODE == 0) {
         if (myrow < n_rows) ws.row_count[(long long)img * n_rows + myrow] = mycount;
+        if (ws.own_sort) {   // the image's total for nms_scan_kernel (integer adds: any order, same sum)
+            int t = mycount;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d);
+            if (lane == 0 && t > 0) atomicAdd(&ws.img_total[img * 64 + (int)(wave_id & 63)], (unsigned)t);
+        }
     } else {
         if (lane == 0 && maxabs > 0.0f) atomicMax(&ws.img_maxabs[img], __float_as_uint(maxabs));
     }
+}
+
+// exclusive scan of the per-row label counts -> emission slots (round 6; rounds 1-5: rocprim::exclusive_scan, two launches).  One block per image: the image's first
+// slot = the totals of the images before it (the count pass adds every wave's count to one of its image's 64 total slots), then per chunk of 1024 x 33 rows: counts
+// to LDS with coalesced loads, every thread scans ITS 33 consecutive rows there (odd stride: no bank conflicts), one block scan of the threads' sums, offsets back
+// through LDS with coalesced stores.  row_off[bs * n_rows] = the number of candidates of the batch.
+constexpr int SCAN_PER = 33, SCAN_CHUNK = 1024 * SCAN_PER;
+__global__ __launch_bounds__(1024) void nms_scan_kernel(NmsWs ws, int bs, int n_rows) {
+    __shared__ unsigned buf[SCAN_CHUNK];
+    __shared__ unsigned wsum[16];
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    auto block_sum_scan = [&](unsigned v, unsigned& excl, unsigned& total) {   // exclusive prefix of v over the block's threads, and the block's sum
+        unsigned inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned o = __shfl_up(inc, d);
+            if (lane >= d) inc += o;
+        }
+        __syncthreads();   // (wsum free; buf written)
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        unsigned before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const unsigned t = wsum[w];
+            if (w < wv) before += t;
+            all += t;
+        }
+        excl = before + inc - v;
+        total = all;
+    };
+    unsigned prev = 0;
+    for (int j = tid; j < img * 64; j += 1024) prev += ws.img_total[j];
+    unsigned e0, carry;
+    block_sum_scan(prev, e0, carry);
+    const int* __restrict__ cnt = ws.row_count + (long long)img * n_rows;
+    int* __restrict__ off = ws.row_off + (long long)img * n_rows;
+    for (int c0 = 0; c0 < n_rows; c0 += SCAN_CHUNK) {
+        const int n = n_rows - c0 < SCAN_CHUNK ? n_rows - c0 : SCAN_CHUNK;
+        __syncthreads();   // (buf free)
+        for (int i = tid; i < n; i += 1024) buf[i] = (unsigned)cnt[c0 + i];
+        __syncthreads();
+        const int r0 = tid * SCAN_PER, r1 = r0 + SCAN_PER < n ? r0 + SCAN_PER : n;
+        unsigned mine = 0;
+        for (int r = r0; r < r1; ++r) mine += buf[r];
+        unsigned excl, total;
+        block_sum_scan(mine, excl, total);
+        unsigned run = carry + excl;
+        for (int r = r0; r < r1; ++r) {
+            const unsigned c = buf[r];
+            buf[r] = run;
+            run += c;
+        }
+        __syncthreads();
+        for (int i = tid; i < n; i += 1024) off[c0 + i] = (int)buf[i];
+        carry += total;
+    }
+    if (img == bs - 1 && tid == 0) ws.row_off[(long long)bs * n_rows] = (int)carry;
 }
 
 // sorted-1 order -> per-image rank, max_nms cut, class-offset boxes, key2
@@ -723,7 +788,8 @@ size_t carve(NmsWs& ws, unsigned char* base, int bs, long long cap, size_t scan_
     ws.cap = cap;
     ws.row_count = (int*)take((scan_n + 1) * sizeof(int));
     ws.row_off = (int*)take((scan_n + 1) * sizeof(int));
-    ws.img_maxabs = (unsigned*)take((size_t)bs * sizeof(unsigned));
+    ws.img_maxabs = (unsigned*)take((size_t)65 * bs * sizeof(unsigned));
+    ws.img_total = ws.img_maxabs ? ws.img_maxabs + bs : nullptr;
     ws.key_a = (unsigned long long*)take((size_t)cap * 8);
     ws.key_b = (unsigned long long*)take((size_t)cap * 8);
     ws.key_c = (unsigned long long*)take((size_t)cap * 8);
@@ -764,7 +830,7 @@ int run_nms(const void* pred, int bs, int n_rows, int nc, const y3_nms_params* p
     const int nseg = one_seg ? 1 : nc;
 
     Y3_HIP(hipMemsetAsync(out_status, 0, 2 * sizeof(int), st));
-    Y3_HIP(hipMemsetAsync(ws.img_maxabs, 0, (size_t)bs * sizeof(unsigned), st));
+    Y3_HIP(hipMemsetAsync(ws.img_maxabs, 0, (size_t)65 * bs * sizeof(unsigned), st));   // (+ img_total)
     ws.own_sort = y3_knob(Y3K_NMS_SORT) != 0 ? 1 : 0;
     if (!ws.own_sort) Y3_HIP(hipMemsetAsync(ws.key_a, 0xff, (size_t)cap * 8, st));
     Y3_HIP(hipMemsetAsync(ws.row_count + scan_n, 0, sizeof(int), st));
@@ -774,7 +840,10 @@ int run_nms(const void* pred, int bs, int n_rows, int nc, const y3_nms_params* p
     hipLaunchKernelGGL((nms_candidates_kernel<T, 0>), dim3(cblocks), dim3(256), 0, st, (const T*)pred, bs, n_rows, nc, thr, multi, classes, ncf, ws, out_status, ord_shift);
     Y3_CHECK_LAUNCH();
     size_t tb = ws.tmp_bytes;
-    if (rocprim::exclusive_scan(ws.tmp, tb, ws.row_count, ws.row_off, 0, scan_n + 1, rocprim::plus<int>(), st) != hipSuccess) Y3_FAIL("y3_nms: scan failed");
+    if (ws.own_sort) {
+        hipLaunchKernelGGL(nms_scan_kernel, dim3((unsigned)bs), dim3(1024), 0, st, ws, bs, n_rows);
+        Y3_CHECK_LAUNCH();
+    } else if (rocprim::exclusive_scan(ws.tmp, tb, ws.row_count, ws.row_off, 0, scan_n + 1, rocprim::plus<int>(), st) != hipSuccess) Y3_FAIL("y3_nms: scan failed");
     hipLaunchKernelGGL((nms_candidates_kernel<T, 1>), dim3(cblocks), dim3(256), 0, st, (const T*)pred, bs, n_rows, nc, thr, multi, classes, ncf, ws, out_status, ord_shift);
     Y3_CHECK_LAUNCH();
     if (ws.own_sort) {

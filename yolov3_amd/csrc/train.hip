@@ -873,38 +873,62 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // The same sum, four consecutive filters per thread (one 16-byte non-temporal load per slice: the partials are read once) with up to 8
 // slices in flight.  The one-element kernel above was latency-bound -- 4-byte loads, two dependent batches of 4 per thread: 104 us for the
 // 151 MB of the 512 -> 1024 layer (1.45 TB/s).  Same summation order per element, so the result is bit-identical.
+// G slice groups per block (round 6): a launch with few units and many slices (64 -> 32 1x1: 4096 units x 512 slices) ran as 16 blocks of threads that each walked
+// every slice -- 0.1-0.4 ms for a few tens of MB.  The 256 threads of a block are 256 / G units x G groups: group g sums ITS run of consecutive slices in order, the
+// groups' sums meet in LDS and are added in group order by the threads of group 0.  The order depends on (slices, G) only, G on the launch's shape only: the same bits
+// from run to run (G = 1: the order of rounds 2-5).
 __global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float* __restrict__ part, int tiles, int n_nt, int slices, int Cin, int ks, int cin_real, int cout_real,
-                                                              float* __restrict__ dw, int tsh) {
-    const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+                                                              float* __restrict__ dw, int tsh, int G) {
+    __shared__ f32x4 red[256];
+    const int U = 256 / G, u = (int)threadIdx.x % U, g = (int)threadIdx.x / U;
+    const long long e = ((long long)blockIdx.x * U + u) * 4;
     const int ts = 1 << tsh;
-    if (e >= (long long)tiles << (2 * tsh)) return;
+    const bool in_range = e < (long long)tiles << (2 * tsh);
     const int col = (int)(e & (ts - 1)), nl = (int)((e >> tsh) & (ts - 1)), tile = (int)(e >> (2 * tsh));
     const int ct = tile / n_nt, nt = tile - ct * n_nt;
     const int co = ct * ts + col, n = nt * ts + nl;
     const int tap = n / Cin, ci = n - tap * Cin;
-    if (co >= cout_real || ci >= cin_real || tap >= ks * ks) return;
+    const bool live = in_range && !(co >= cout_real || ci >= cin_real || tap >= ks * ks);
     const size_t stride = (size_t)tiles << (2 * tsh);
     f32x4 a = {0.0f, 0.0f, 0.0f, 0.0f};
-    const float* src = part + e;
-    int s = 0;
-    for (; s + 8 <= slices; s += 8) {
-        f32x4 v[8];
+    if (live) {
+        const int per = (slices + G - 1) / G;
+        int s = g * per;
+        const int s_end = s + per < slices ? s + per : slices;
+        const float* src = part + e;
+        for (; s + 8 <= s_end; s += 8) {
+            f32x4 v[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = __builtin_nontemporal_load((const f32x4*)(src + (size_t)(s + q) * stride));
+            for (int q = 0; q < 8; ++q) v[q] = __builtin_nontemporal_load((const f32x4*)(src + (size_t)(s + q) * stride));
 #pragma unroll
-        for (int q = 0; q < 8; ++q) a += v[q];
+            for (int q = 0; q < 8; ++q) a += v[q];
+        }
+        if (s < s_end) {
+            f32x4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (s + q < s_end) v[q] = __builtin_nontemporal_load((const f32x4*)(src + (size_t)(s + q) * stride));
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (s + q < s_end) a += v[q];
+        }
     }
-    if (s < slices) {
-        f32x4 v[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) if (s + q < slices) v[q] = __builtin_nontemporal_load((const f32x4*)(src + (size_t)(s + q) * stride));
-#pragma unroll
-        for (int q = 0; q < 8; ++q) if (s + q < slices) a += v[q];
+    if (G > 1) {
+        red[threadIdx.x] = a;
+        __syncthreads();
+        if (g != 0) return;
+        for (int q = 1; q < G; ++q) a += red[q * U + u];
     }
+    if (!live) return;
     const int kk = ks * ks;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
         if (co + q < cout_real) dw[((long long)(co + q) * cin_real + ci) * kk + tap] = a[q];
+}
+
+// slice groups per block for a slab sum of `units` 16-byte units over `slices` slabs: enough threads to fill the chip, at least 8 slabs per group
+static int slab_sum_groups(long long units, long long slices) {
+    int G = 1;
+    while (G < 32 && units * G < 65536 && slices >= 16LL * G) G *= 2;
+    return G;
 }
 
 // per-channel sum of an NHWC tensor into fp32 (bias gradient of the Detect convs)
@@ -2233,7 +2257,11 @@ extern "C" int y3_conv2d_wgrad(const y3_conv_desc* d, const y3_tensor* x, const 
         a.dv_ho = y3_make_divisor(Ho); a.dv_strips = y3_make_divisor(sp.strips);
         if (d->dtype == Y3_F16) launch_strip_t<f16_t>(d, a, sp.blocks, st); else launch_strip_t<bf16_t>(d, a, sp.blocks, st);
         Y3_CHECK_LAUNCH();
-        hipLaunchKernelGGL(wgrad_strip_reduce_kernel, dim3(nblk((long long)9 * d->cin * d->cout / 4)), dim3(256), 0, st, (const float*)workspace, sp.blocks, d->cin, d->cout, dw_oihw);
+        {
+            const long long units = (long long)9 * d->cin * d->cout / 4;
+            const int G = slab_sum_groups(units, sp.blocks);
+            hipLaunchKernelGGL(wgrad_strip_reduce_kernel, dim3((unsigned)((units * G + 255) / 256)), dim3(256), 0, st, (const float*)workspace, sp.blocks, d->cin, d->cout, dw_oihw, G);
+        }
         Y3_CHECK_LAUNCH();
         return 0;
     }
@@ -2279,8 +2307,12 @@ extern "C" int y3_conv2d_wgrad(const y3_conv_desc* d, const y3_tensor* x, const 
         }
         Y3_CHECK_LAUNCH();
         if ((((uintptr_t)workspace) & 15) == 0)   // (the one-element kernel serves workspaces that are not 16-byte aligned)
-            hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(nblk((tiles << (2 * tsh)) / 4)), dim3(256), 0, st, (const float*)workspace, (int)tiles, a.n_nt, (int)slices, d->cin, d->ksize,
-                               cin_real, cout_real, dw_oihw, tsh);
+        {
+            const long long units = (tiles << (2 * tsh)) / 4;
+            const int G = slab_sum_groups(units, slices);
+            hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)((units * G + 255) / 256)), dim3(256), 0, st, (const float*)workspace, (int)tiles, a.n_nt, (int)slices, d->cin,
+                               d->ksize, cin_real, cout_real, dw_oihw, tsh, G);
+        }
         else
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk(tiles << (2 * tsh))), dim3(256), 0, st, (const float*)workspace, (int)tiles, a.n_nt, (int)slices, d->cin, d->ksize, cin_real,
                                cout_real, dw_oihw, tsh);
