@@ -33,8 +33,9 @@ template <bool NT, typename T> Y3_DEV void stv(T* p, const V16<T>& v) {
     const y3_u32x4 r = __builtin_bit_cast(y3_u32x4, v);
     if (NT) __builtin_nontemporal_store(r, (y3_u32x4*)p); else *(y3_u32x4*)p = r;
 }
-// tensors at least this large take the non-temporal forms of the elementwise passes (knob "bn_nt_bytes", default 128 MiB: below the
-// Infinity-Cache size the plain forms win, profiles/r02_bn_lab_sweep*.txt); the tests lower it to run the forms on small tensors
+// tensors at least this large take the non-temporal forms of the elementwise passes (knob "bn_nt_bytes", default 64 MiB: below the
+// Infinity-Cache size the plain forms win alone, profiles/r02_bn_lab_sweep*.txt; inside the two-stream train step 64 MiB measured 55.04 / 54.99 ms against 55.25 / 55.23 at
+// 128 MiB and 55.29 / 55.12 at 32, profiles/r06_train_knob_sweep.txt); the tests lower it to run the forms on small tensors
 #define Y3_NT_BYTES y3_knob(Y3K_BN_NT_BYTES)
 
 Y3_DEV float silu_grad(float z, float s) { return s + z * s * (1.0f - s); }  // d silu(z)/dz with s = sigmoid(z)
