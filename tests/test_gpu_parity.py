@@ -2868,7 +2868,7 @@ def test_bn_passes_on_a_tensor_beyond_the_nontemporal_threshold(dev):
 
     _lib, ops = _ops()
     L = _lib.lib()
-    assert ops.tune_get("bn_nt_bytes") == 128 << 20
+    assert ops.tune_get("bn_nt_bytes") == 64 << 20   # (round 6: 64 MiB; the tensor below is beyond either value)
     n, h, w, c = 64, 160, 160, 128
     dtype = torch.float16
     M = n * h * w
