@@ -77,6 +77,39 @@ __device__ __forceinline__ void role_lds(int iters, float* out) {
     asm volatile("s_waitcnt lgkmcnt(0)");
     if (acc == 12345.678f) out[threadIdx.x] = acc;
 }
+// roles 5 / 6: the SAME wave interleaves: per iteration four MFMAs and, between them, 16 independent v_fma_f32 (5) or 4 v_exp_f32 (6) -- 16 issue cycles of other work per
+// 32-cycle MFMA.  If the time stays at role 1's, a wave's own independent instructions do run in the shadow of its MFMAs.
+template <int KIND> __device__ __forceinline__ void role_mix(int iters, float* out) {
+    h8 a[4], b[4];
+    for (int k = 0; k < 4; ++k)
+        for (int i = 0; i < 8; ++i) { a[k][i] = (_Float16)(threadIdx.x * 0.001f + i + k); b[k][i] = (_Float16)(i * 0.5f - k); }
+    f16v c0 = {}, c1 = {}, c2 = {}, c3 = {};
+    float v[16];
+    for (int i = 0; i < 16; ++i) v[i] = threadIdx.x * 0.01f + i;
+    auto side = [&](int q) {
+        if (KIND == 5) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[4 * q + i] = __builtin_fmaf(v[4 * q + i], 0.999f, 0.001f);
+        } else {
+            v[4 * q] = __builtin_amdgcn_exp2f(v[4 * q] * 0.5f);
+        }
+    };
+    for (int it = 0; it < iters; ++it) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], c0, 0, 0, 0); side(0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[1], c1, 0, 0, 0); side(1);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2], b[2], c2, 0, 0, 0); side(2);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[3], b[3], c3, 0, 0, 0); side(3);
+    }
+    float s = 0;
+    for (int i = 0; i < 16; ++i) s += c0[i] + c1[i] + c2[i] + c3[i] + v[i];
+    if (s == 12345.678f) out[threadIdx.x] = s;
+}
+// role 7: role 1 behind s_setprio 3 (the other wave of the SIMD stays at priority 0): does the issue arbiter let the MFMA wave in when it is due?
+__device__ __forceinline__ void role_mfma_prio(int iters, float* out) {
+    __builtin_amdgcn_s_setprio(3);
+    role_mfma(iters, out);
+    __builtin_amdgcn_s_setprio(0);
+}
 __global__ __launch_bounds__(512, 1) void probe(int roleA, int roleB, int itA, int itB, float* out) {
     const int wv = threadIdx.x >> 6;
     const int role = wv < 4 ? roleA : roleB;
@@ -85,13 +118,16 @@ __global__ __launch_bounds__(512, 1) void probe(int roleA, int roleB, int itA, i
     else if (role == 2) role_valu(it, out);
     else if (role == 3) role_fma(it, out);
     else if (role == 4) role_lds(it, out);
+    else if (role == 5) role_mix<5>(itA, out);
+    else if (role == 7) role_mfma_prio(itA, out);
+    else if (role == 6) role_mix<6>(itA, out);
 }
 int main(int argc, char** argv) {
     const int itM = argc > 1 ? atoi(argv[1]) : 20000;   // x 4 MFMAs of 32 cycles = 128 cycles per iteration
     const int itV = argc > 2 ? atoi(argv[2]) : 1400;    // x 16 values x ~44 cycles = ~700 cycles per iteration
     float* out; hipMalloc(&out, 4096);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    const int modes[8][2] = {{1, 0}, {0, 2}, {1, 2}, {0, 3}, {1, 3}, {0, 4}, {1, 4}, {1, 1}};
+    const int modes[8][2] = {{1, 0}, {7, 0}, {0, 3}, {1, 3}, {7, 3}, {0, 2}, {7, 2}, {7, 4}};
     for (int rep = 0; rep < 2; ++rep)
         for (int m = 0; m < 8; ++m) {
             for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(probe, dim3(256), dim3(512), 0, 0, modes[m][0], modes[m][1], itM, itV, out);
@@ -100,7 +136,7 @@ int main(int argc, char** argv) {
             for (int w = 0; w < 10; ++w) hipLaunchKernelGGL(probe, dim3(256), dim3(512), 0, 0, modes[m][0], modes[m][1], itM, itV, out);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
-            const double waves = (modes[m][0] == 1 ? 4.0 : 0) + (modes[m][1] == 1 ? 4.0 : 0);
+            const double waves = ((modes[m][0] == 1 || modes[m][0] >= 5) ? 4.0 : 0) + ((modes[m][1] == 1 || modes[m][1] >= 5) ? 4.0 : 0);
             const double tf = waves * 256.0 * itM * 4.0 * (2.0 * 32 * 32 * 16) / (ms / 10 * 1e-3) / 1e12;
             printf("A=%d B=%d : %.3f ms per launch   MFMA %.0f TF\n", modes[m][0], modes[m][1], ms / 10, tf);
         }
