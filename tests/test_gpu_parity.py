@@ -567,6 +567,36 @@ def test_detect_decode_vs_reference_golden(dev, golden_dir, key, dtype, nc):
         assert (diff > 0).float().mean().item() < 2e-3, "too many fp16 rounding flips"
 
 
+@pytest.mark.parametrize("cin,cout,hw,res", [(128, 256, 40, True), (256, 512, 20, False), (512, 1024, 20, True)])
+def test_conv_v10_deferred_epilogue_form_is_bit_identical(dev, tune, cin, cout, hw, res):
+    """conv_v10d.h (knob v10_defer, off by default: measured 9-13 % slower, profiles/r06_v10_deferred_epilogue.txt): the previous tile's activation inside the next
+    tile's K loop, two accumulator sets, stores behind the K loop.  Same arithmetic per value as the shipped form: the outputs must be the same bits -- tiles of 3 and
+    4 column blocks, blocks that walk several tiles, the residual added in the pack step, first / last tile of a block."""
+    from yolov3_amd import ops
+
+    g = torch.Generator().manual_seed(cin + hw)
+    n, dt = 6, torch.float16
+    xv = ops.View.alloc(n, hw, hw, cin, dt, dev)
+    xv.buf.copy_(torch.randn(xv.buf.shape, generator=g).to(dt))
+    rv = ops.View.alloc(n, hw, hw, cout, dt, dev)
+    rv.buf.copy_(torch.randn(rv.buf.shape, generator=g).to(dt))
+    f = ops.pack_filter((torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin**0.5)).to(dev), cout, cin, dt)
+    b = torch.randn(cout, generator=g).to(dev)
+    outs = []
+    for defer, blocks in ((0, 0), (2, 0), (2, 3)):
+        tune("conv_v10", 2)
+        tune("v10_defer", defer)
+        tune("v10_blocks", blocks)
+        yv = ops.View.alloc(n, hw, hw, cout, dt, dev)
+        yv.buf.fill_(7.0)
+        ops.conv2d(xv, f, b, yv, 3, 1, True, residual=rv if res else None)
+        assert ops.last_conv_variant() == ("v10d" if defer else ("v10h" if cin <= 256 else "v10")), ops.last_conv_variant()
+        outs.append(yv.as_nhwc().clone())
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0], outs[1]), "deferred form differs from the shipped form"
+    assert torch.equal(outs[0], outs[2]), "deferred form, three blocks per filter tile (many tiles per block)"
+
+
 # ------------------------------------------------------------------------------------------------ NMS
 def _canon(t):
     """rows ordered by (-score, then x1,y1,x2,y2,cls): removes the arbitrary order the reference's unstable argsort

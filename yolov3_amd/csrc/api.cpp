@@ -31,7 +31,7 @@ const Knob kKnobs[] = {
     {"conv", 0}, {"conv_ahead", 3}, {"bn_nt_bytes", 64ll << 20},
     {"wgrad", 0}, {"wgrad_xcd", 2}, {"dgrad_quad", 1}, {"spp_direct", 0}, {"wgrad_strip", 1}, {"conv_strip", 1},
     {"conv_v10", 1}, {"v10_mp", 0}, {"v10_blocks", 0}, {"v10_half", 2}, {"v10_ksplit", 1}, {"v10_slices", 0},
-    {"v10_group", 1}, {"tile_xcd", 1}, {"conv_1x1s", 1}, {"wgrad_patch", 1}, {"wgrad_blocks", 512}, {"nms_sort", 1},
+    {"v10_group", 1}, {"tile_xcd", 1}, {"conv_1x1s", 1}, {"wgrad_patch", 1}, {"wgrad_blocks", 512}, {"nms_sort", 1}, {"v10_defer", 0},
 };
 constexpr int kCount = (int)(sizeof(kKnobs) / sizeof(kKnobs[0]));
 static_assert(kCount == Y3K_COUNT, "kKnobs and y3_knob_id (y3_common.h) list the same knobs in the same order");

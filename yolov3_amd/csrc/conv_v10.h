@@ -518,7 +518,7 @@ static int v10_patch_pieces(const ConvArgs& a, int mp) {   // worst case over ti
     const int npos = (vp - 1) + 2 * rc + PW * ic + 2 * PW + 3;
     return (npos * V10_PITCH + 1023) / 1024;
 }
-static bool v10_plan_form(const ConvArgs& a, V10Plan& pl, bool half) {
+static bool v10_plan_form(const ConvArgs& a, V10Plan& pl, bool half, int per_cu = 0) {   // per_cu: blocks per CU (0: two for the half form, one for the full one)
     const int n_ct = a.Cout / 256, cus = y3_cu_count();
     const int CB = (a.M + 31) / 32;
     if (n_ct < 1 || CB < 1) return false;
@@ -534,7 +534,7 @@ static bool v10_plan_form(const ConvArgs& a, V10Plan& pl, bool half) {
     }
     if (!pl.mp_max) return false;
     pl.xq = v10_patch_pieces(a, pl.mp_max) > 28 ? 2 : 1;
-    int B = (half ? 2 : 1) * cus / n_ct;
+    int B = (per_cu ? per_cu : (half ? 2 : 1)) * cus / n_ct;
     if (B < 1) B = 1;
     if (B > CB / mp_lo) B = CB / mp_lo > 0 ? CB / mp_lo : 1;   // at least one narrowest body of column blocks per block where the launch has them
     if (force_b > 0) B = force_b < CB ? force_b : CB;
@@ -628,8 +628,32 @@ static void v10_fill_args(ConvArgs& a, const V10Plan& pl) {
     a.nk = 9 * a.cin_blocks;
 }
 
+#include "conv_v10d.h"   // the deferred-epilogue form of the same tiles (uses the geometry and helpers above)
+static bool v10d_plan(const ConvArgs& a, V10Plan& pl) {
+    const long long mode = y3_knob(Y3K_V10_DEFER);
+    if (mode == 0 || a.stats != nullptr || a.act != Y3_ACT_SILU || a.Cin < 128) return false;
+    if (mode != 2 && !(y3_knob(Y3K_V10_HALF) == 2 && a.Cin <= 256)) return false;   // the shapes the half form serves
+    return v10_plan_form(a, pl, true, 1);
+}
+
 template <typename T> int launch_v10(ConvArgs& a, hipStream_t st) {
     V10Plan pl;
+    if (v10d_plan(a, pl)) {
+        v10_fill_args(a, pl);
+        a.stat_wp = 4;
+        g_last_variant = "v10d";
+        if (a.dry) { g_v10_dry = a; g_v10_dry_valid = true; return 0; }
+        const dim3 grid((unsigned)(a.n_ct * pl.B)), block(256);
+        if (a.res) {
+            if (pl.xq == 2) hipLaunchKernelGGL((conv_igemm_v10d_kernel<T, 2, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((conv_igemm_v10d_kernel<T, 1, true>), grid, block, 0, st, a);
+        } else {
+            if (pl.xq == 2) hipLaunchKernelGGL((conv_igemm_v10d_kernel<T, 2, false>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((conv_igemm_v10d_kernel<T, 1, false>), grid, block, 0, st, a);
+        }
+        Y3_CHECK_LAUNCH();
+        return 0;
+    }
     if (!v10_plan(a, pl)) Y3_FAIL("conv v10: no tile plan (internal)");
     v10_fill_args(a, pl);
     a.stat_wp = 4;   // statistics rows per tile: one per 64-pixel epilogue pass of the widest body (narrower bodies write zero rows)

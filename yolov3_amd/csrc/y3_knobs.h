@@ -23,6 +23,7 @@ enum y3_knob_id {
     Y3K_WGRAD_PATCH,    // "wgrad_patch": 1 the padded-position filter-gradient kernel (wgrad_patch.h) on the 3x3 / stride-1 layers with Cin % 64 == 0, Cout % 128 == 0 at >= 16384 pixels; 0 never (wgrad_big / wgrad_dma); 2 every eligible shape (tests)
     Y3K_WGRAD_BLOCKS,   // "wgrad_blocks": blocks (tiles x pixel slices) the 128 x 128-tile filter-gradient kernel aims at: every slice writes a 64 KiB partial tile per column tile (512 = one round of resident blocks; 1024 until round 6: +0.6 ms per step of slab traffic)
     Y3K_NMS_SORT,       // "nms_sort":    1 the two orderings of y3_nms (per-image score order, per-(image, class) segments) by ONE block-per-image launch of stable counting passes (detect_nms.hip::nms_sort_kernel); 0 two rocPRIM device radix sorts (rounds 1-5; A/B and cross-check in the tests)
+    Y3K_V10_DEFER,      // "v10_defer":   1 inference launches of conv_v10.h's half-form shapes (SiLU, no statistics) run conv_v10d.h: one block per CU, the previous tile's activation inside the next tile's K loop; 0 never; 2 every eligible shape incl. the full-form ones (tests / A/B)
     Y3K_COUNT
 };
 long long y3_knob(int id);
